@@ -1,0 +1,197 @@
+/*
+ * potus_hmc.h -- C ABI of libpotus_hmc.so, the MI355X-native HMC/NUTS sampler for the
+ * posterior defined by scripts/model/poll_model_2020.stan (and the
+ * poll_model_2020_no_mode_adjustment.stan variant) of TheEconomist/us-potus-model.
+ *
+ * What each entry point replaces in the reference
+ * -----------------------------------------------
+ * The reference has no FFI: the R scripts hand the `data` list to CmdStan through
+ * files and a process boundary:
+ *
+ *   scripts/model/final_2016.R:475-514   data <- list(...)            -> potus_data
+ *   scripts/model/final_2016.R:532       cmdstan_model(..., compile)  -> potus_create
+ *   scripts/model/final_2016.R:533-541   model$sample(data, seed, chains, iter_warmup,
+ *                                        iter_sampling, refresh)      -> potus_run (chunked)
+ *   scripts/model/final_2016.R:543       rstan::read_stan_csv(files)  -> potus_get_draws /
+ *                                                                        potus_write_array /
+ *                                                                        potus_write_stan_csv
+ *   scripts/model/final_2016.R:556,...   rstan::extract(out, pars=)   -> potus_write_array
+ *   (same call sites: final_2012.R:558-569, final_2008.R:562-573; the commented rstan
+ *    surface at final_2016.R:525-529 and scripts/deprecated/R/Refactored/poll_run_v9.R:387-390)
+ *
+ * Conventions
+ * -----------
+ *  - plain C, no C++/torch types; every function returns an int status (0 = ok) and
+ *    the message of the last failure is available from potus_last_error().
+ *  - the caller owns every buffer it passes; inputs are copied at potus_create and no
+ *    caller pointer is retained.  Device memory, streams and kernels live behind the
+ *    integer handle.
+ *  - indices inside potus_data are 1-based int32 exactly as in the Stan `data{}` block
+ *    (poll_model_2020.stan:1-41); matrices are column-major.
+ *  - all arithmetic is fp64.
+ *  - the `_R` entry points take only int* / double* / char** so that R's .C() can call
+ *    them (R passes every argument by pointer and ignores return values, so they also
+ *    write *status).
+ */
+#ifndef POTUS_HMC_H
+#define POTUS_HMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POTUS_VARIANT_FULL 0    /* scripts/model/poll_model_2020.stan */
+#define POTUS_VARIANT_NO_MODE 1 /* scripts/model/poll_model_2020_no_mode_adjustment.stan */
+
+/* status codes */
+#define POTUS_OK 0
+#define POTUS_ERR_ARG 1      /* bad argument / Stan data-block constraint violated */
+#define POTUS_ERR_DEVICE 2   /* HIP runtime failure or no gfx950 device */
+#define POTUS_ERR_INIT 3     /* no finite initial point after 100 attempts */
+#define POTUS_ERR_STATE 4    /* call order / handle state */
+#define POTUS_ERR_IO 5
+#define POTUS_ERR_UNSUPPORTED 6
+
+/* The Stan data block (poll_model_2020.stan:1-41) as a C struct.  For the no-mode
+ * variant the four poll_mode_* / poll_pop_* pointers, M, Pop, sigma_m, sigma_pop and
+ * sigma_e_bias and the unadjusted_* vectors are ignored (as Stan ignores extra list
+ * entries) and may be NULL / 0. */
+typedef struct potus_data {
+  int32_t N_national_polls, N_state_polls, T, S, P, M, Pop;
+  const int32_t *state;               /* [N_state_polls]    1..S   (stan:9)  */
+  const int32_t *day_state;           /* [N_state_polls]    1..T   (stan:10) */
+  const int32_t *day_national;        /* [N_national_polls] 1..T   (stan:11) */
+  const int32_t *poll_state;          /* [N_state_polls]    1..P   (stan:12) */
+  const int32_t *poll_national;       /* [N_national_polls] 1..P   (stan:13) */
+  const int32_t *poll_mode_state;     /* 1..M    (stan:14) */
+  const int32_t *poll_mode_national;  /* 1..M    (stan:15) */
+  const int32_t *poll_pop_state;      /* 1..Pop  (stan:16) */
+  const int32_t *poll_pop_national;   /* 1..Pop  (stan:17) */
+  const int32_t *n_democrat_national; /* (stan:18) */
+  const int32_t *n_two_share_national;
+  const int32_t *n_democrat_state;
+  const int32_t *n_two_share_state;
+  const double *unadjusted_national;  /* in [0,1] (stan:22) */
+  const double *unadjusted_state;     /* in [0,1] (stan:23) */
+  const double *mu_b_prior;           /* [S] (stan:28) */
+  const double *state_weights;        /* [S] (stan:29) */
+  double sigma_c, sigma_m, sigma_pop;
+  double sigma_measure_noise_national, sigma_measure_noise_state, sigma_e_bias;
+  const double *state_covariance_0;   /* [S*S] column-major, symmetric PD (stan:37) */
+  double random_walk_scale, mu_b_T_scale, polling_bias_scale;
+  int32_t variant;                    /* POTUS_VARIANT_* */
+} potus_data;
+
+/* Sampler options: the argument surface of cmdstanr's $sample() as used at
+ * final_2016.R:533-541 plus the CmdStan 2.24 defaults it implies. */
+typedef struct potus_opts {
+  int32_t chains;          /* chains run by THIS handle (one workgroup each)            */
+  int32_t chain_id_offset; /* global id of this handle's first chain minus 1; chain c of
+                              the handle uses RNG stream chain_id_offset + c + 1, so the
+                              draws do not depend on how chains are split over GPUs       */
+  int32_t num_warmup;      /* iter_warmup   (final_2016.R:538) */
+  int32_t num_samples;     /* iter_sampling (final_2016.R:539) */
+  int32_t max_depth;       /* 10 */
+  int32_t init_buffer, term_buffer, window; /* 75, 50, 25 */
+  double delta, gamma, kappa, t0;           /* 0.8, 0.05, 0.75, 10 */
+  double stepsize;         /* 1.0 */
+  double init_radius;      /* 2.0 : inits ~ U(-2,2) on the unconstrained scale */
+  uint64_t seed;           /* 1843 (final_2016.R:535) */
+  int32_t device;          /* HIP device ordinal */
+  int32_t save_warmup;     /* 0 */
+} potus_opts;
+
+/* per-draw sampler columns, in CmdStan order */
+#define POTUS_N_SAMPLER_COLS 7 /* lp__,accept_stat__,stepsize__,treedepth__,n_leapfrog__,divergent__,energy__ */
+
+const char *potus_version(void);
+int potus_last_error(char *buf, int len);
+void potus_default_opts(potus_opts *o);
+
+/* Number of unconstrained parameters D and of columns of one full output row
+ * (7 sampler + D constrained parameters + transformed parameters + generated
+ * quantities; 43 360 for the 2016 data). Pure host arithmetic, no device needed. */
+int potus_num_params(const potus_data *d, int *D);
+int potus_num_columns(const potus_data *d, int *n_cols);
+/* Column names in CmdStan CSV order ("raw_mu_b.3.17" style, column-major).  Writes at
+ * most n_names pointers into a caller array of char[name_len] rows. */
+int potus_column_name(const potus_data *d, int col, char *buf, int len);
+
+/* Validate data (Stan's declared bounds), build the three scaled Cholesky factors
+ * (transformed data, stan:42-55), upload everything, allocate chain state. */
+int potus_create(const potus_data *d, const potus_opts *o, int *handle);
+int potus_destroy(int handle);
+
+/* Parity hook: log-density (with Jacobians, constants dropped as `~` does) and its
+ * gradient for n points of the unconstrained space, evaluated by the same device
+ * code the leapfrog uses.  q: [n][D], lp: [n], grad: [n][D] (host pointers). */
+int potus_log_prob_grad(int handle, const double *q, int n, double *lp, double *grad);
+
+/* Initial values ~ U(-r,r) with retry (CmdStan semantics), then the initial
+ * step-size search.  Must be called once before potus_run. Optional user inits:
+ * q0 [chains][D] or NULL. */
+int potus_init(int handle, const double *q0);
+
+/* Advance every chain by n_iter NUTS transitions (warmup transitions adapt).
+ * Blocks until done.  R calls this in chunks of `refresh` iterations. */
+int potus_run(int handle, int n_iter);
+
+/* Progress / accounting. */
+int potus_iterations_done(int handle, int *n);
+int potus_total_leapfrogs(int handle, long long *n); /* sum over chains and iterations so far */
+int potus_chain_status(int handle, int *status /*[chains]*/, int *n_divergent /*[chains]*/);
+
+/* Adaptation result per chain: step size and diagonal inverse metric. */
+int potus_get_adaptation(int handle, double *stepsize /*[chains]*/, double *inv_metric /*[chains][D]*/);
+
+/* Saved draws on the unconstrained scale: out[chain][iter][7 + D] (host pointer).
+ * n_saved = num_samples (+ num_warmup when save_warmup). */
+int potus_get_draws(int handle, double *out, int *n_saved);
+
+/* Device pointer of the same array (for RCCL all-gather through torch); the buffer
+ * stays owned by the handle. */
+int potus_draws_device_ptr(int handle, void **dptr, long long *n_doubles);
+
+/* write_array: constrained parameters, transformed parameters (stan:70-113) and
+ * generated quantities (stan:134-140) for every saved draw, restricted to the columns
+ * [col_begin, col_end) of the full CmdStan row (0-based, including the 7 sampler
+ * columns).  out[iter][chain][col_end-col_begin] -- the as.array(stanfit) layout. */
+int potus_write_array(int handle, int col_begin, int col_end, double *out);
+
+/* One CmdStan-format CSV per chain (<dir>/<basename>-<chain>.csv) readable by
+ * rstan::read_stan_csv (final_2016.R:543). */
+int potus_write_stan_csv(int handle, const char *dir, const char *basename);
+
+/* Kernel timing of the most recent potus_run, measured with HIP events on the
+ * sampler's own stream: elapsed milliseconds and leapfrogs executed in it. */
+int potus_last_run_timing(int handle, double *ms, long long *leapfrogs);
+
+/* ---- .C()-callable wrappers (int* / double* / char** only) ---- */
+void potus_R_create(int *dims /*[8]: N_nat,N_state,T,S,P,M,Pop,variant*/,
+                    int *state, int *day_state, int *day_national, int *poll_state,
+                    int *poll_national, int *poll_mode_state, int *poll_mode_national,
+                    int *poll_pop_state, int *poll_pop_national, int *n_democrat_national,
+                    int *n_two_share_national, int *n_democrat_state, int *n_two_share_state,
+                    double *unadjusted_national, double *unadjusted_state, double *mu_b_prior,
+                    double *state_weights, double *scalars /*[9]: sigma_c,sigma_m,sigma_pop,
+                    sigma_noise_nat,sigma_noise_state,sigma_e_bias,random_walk_scale,
+                    mu_b_T_scale,polling_bias_scale*/,
+                    double *state_covariance_0,
+                    int *iopts /*[8]: chains,chain_id_offset,num_warmup,num_samples,max_depth,
+                    device,save_warmup,seed*/,
+                    double *dopts /*[6]: delta,gamma,kappa,t0,stepsize,init_radius*/,
+                    int *handle, int *status);
+void potus_R_init(int *handle, int *status);
+void potus_R_run(int *handle, int *n_iter, int *status);
+void potus_R_num_columns(int *handle, int *D, int *n_cols, int *status);
+void potus_R_write_array(int *handle, int *col_begin, int *col_end, double *out, int *status);
+void potus_R_write_stan_csv(int *handle, char **dir, char **basename, int *status);
+void potus_R_last_error(char **buf, int *len);
+void potus_R_destroy(int *handle, int *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POTUS_HMC_H */

@@ -1,0 +1,81 @@
+/*
+ * potus_oracle.h -- CPU fp64 restatement of the reference hot path.  TEST INFRASTRUCTURE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library.  The product (libpotus_hmc.so) never links, loads or calls it.
+ *
+ * PARITY UNPINNED: the reference (TheEconomist/us-potus-model) contains no tests,
+ * golden vectors or runnable implementation of this path -- the arithmetic lives in
+ * the third-party CmdStan 2.24.1 / Stan Math 3.3 / Eigen 3.3.7 toolchain, which is
+ * neither vendored nor installable here.  This oracle restates
+ *   - scripts/model/poll_model_2020.stan:42-140 (and the no_mode_adjustment variant)
+ *     line by line, and
+ *   - the published Stan 2.24 NUTS algorithm (stan/mcmc/hmc/nuts/base_nuts.hpp,
+ *     stan/mcmc/hmc/integrators/expl_leapfrog.hpp, stan/mcmc/hmc/hamiltonians/
+ *     diag_e_metric.hpp, stan/mcmc/stepsize_adaptation.hpp, stan/mcmc/
+ *     windowed_adaptation.hpp, stan/mcmc/var_adaptation.hpp, stan/mcmc/hmc/base_hmc.hpp,
+ *     stan/services/sample/hmc_nuts_diag_e_adapt.hpp) invoked at
+ *     scripts/model/final_2016.R:533-541,
+ * and is itself cross-checked by finite differences and by torch-fp64 autograd of an
+ * independent literal transcription of the Stan program (tests/test_oracle.py).
+ */
+#ifndef POTUS_ORACLE_H
+#define POTUS_ORACLE_H
+
+#include <stdint.h>
+#include "../include/potus_hmc.h" /* potus_data: the Stan data block as a C struct */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_model oracle_model;
+
+typedef struct oracle_opts {
+  int32_t num_warmup, num_samples, max_depth;
+  int32_t init_buffer, term_buffer, window;
+  double delta, gamma, kappa, t0, stepsize, init_radius;
+  uint64_t seed;
+  int32_t fast_grad;   /* 0: literal dense recursion (stan:86); 1: scan/sparse reformulation */
+  int32_t save_warmup;
+} oracle_opts;
+
+void oracle_default_opts(oracle_opts *o);
+
+/* returns NULL and fills err on a data-block violation */
+oracle_model *oracle_model_create(const potus_data *d, char *err, int errlen);
+void oracle_model_free(oracle_model *m);
+int oracle_num_params(const oracle_model *m);
+int oracle_num_columns(const oracle_model *m); /* 7 + D + TP + GQ */
+/* the three scaled Cholesky factors of transformed data (stan:42-55), col-major SxS */
+void oracle_cholesky_factors(const oracle_model *m, double *L_B, double *L_T, double *L_W);
+
+/* log_prob<propto=true, jacobian=true> and gradient; literal restatement */
+double oracle_log_prob_grad(const oracle_model *m, const double *q, double *grad);
+/* same value via suffix/prefix scans and the sparse poll structure */
+double oracle_log_prob_grad_fast(const oracle_model *m, const double *q, double *grad);
+
+/* write_array: out[0 .. n_cols-7): constrained params, transformed params, GQ */
+void oracle_write_array(const oracle_model *m, const double *q, double *out);
+
+/* Philox4x32-10 block and the derived draws shared with the device sampler */
+void oracle_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+double oracle_rng_uniform(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t purpose,
+                          uint32_t aux, uint32_t index);
+void oracle_rng_normal_pair(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t purpose,
+                            uint32_t aux, uint32_t index, double *n0, double *n1);
+
+/* One chain of adaptive NUTS.  draws: [n_saved][7 + D] row-major (unconstrained q);
+ * adapt_out: [1 + D] = final step size, inverse metric.  Returns 0 on success.
+ * q0: optional initial point (NULL -> U(-r,r) inits with retry). */
+int oracle_sample_chain(const oracle_model *m, const oracle_opts *o, int chain_id,
+                        const double *q0, double *draws, double *adapt_out,
+                        long long *total_leapfrogs);
+
+/* leapfrog micro-benchmark for bench.py's cpu_baseline: n steps from q0 with unit metric */
+double oracle_time_leapfrogs(const oracle_model *m, int n, double eps, int fast_grad, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
