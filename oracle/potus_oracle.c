@@ -693,36 +693,38 @@ static double nuts_transition(sampler *sp) {
   update_potential_gradient(sp, &sp->z); /* hamiltonian.init */
   pspoint z_fwd = ps_alloc(D), z_bck = ps_alloc(D), z_sample = ps_alloc(D), z_propose = ps_alloc(D);
   ps_copy(&z_fwd, &sp->z, D); ps_copy(&z_bck, &sp->z, D); ps_copy(&z_sample, &sp->z, D); ps_copy(&z_propose, &sp->z, D);
-  double *p_fwd_bck = vec(D), *psharp_fwd_bck = vec(D), *rho = vec(D);
-  double *p_fwd = vec(D), *psharp_fwd = vec(D), *p_bck = vec(D), *psharp_bck = vec(D);
-  double *rho_fwd = vec(D), *rho_bck = vec(D), *rho_ext = vec(D);
-  memcpy(p_fwd_bck, sp->z.p, sizeof(double) * (size_t)D);
-  dtau_dp(sp, sp->z.p, psharp_fwd_bck);
-  memcpy(rho, sp->z.p, sizeof(double) * (size_t)D);
-  memcpy(p_fwd, p_fwd_bck, sizeof(double) * (size_t)D); memcpy(p_bck, p_fwd_bck, sizeof(double) * (size_t)D);
-  memcpy(psharp_fwd, psharp_fwd_bck, sizeof(double) * (size_t)D); memcpy(psharp_bck, psharp_fwd_bck, sizeof(double) * (size_t)D);
+  /* the trajectory is [bck subtree][fwd subtree]; each has a forward and a backward end */
+  double *p_fwd_fwd = vec(D), *ps_fwd_fwd = vec(D), *p_fwd_bck = vec(D), *ps_fwd_bck = vec(D);
+  double *p_bck_fwd = vec(D), *ps_bck_fwd = vec(D), *p_bck_bck = vec(D), *ps_bck_bck = vec(D);
+  double *rho = vec(D), *rho_fwd = vec(D), *rho_bck = vec(D), *rho_ext = vec(D);
+  const size_t nb = sizeof(double) * (size_t)D;
+  memcpy(p_fwd_fwd, sp->z.p, nb); dtau_dp(sp, sp->z.p, ps_fwd_fwd);
+  memcpy(p_fwd_bck, p_fwd_fwd, nb); memcpy(ps_fwd_bck, ps_fwd_fwd, nb);
+  memcpy(p_bck_fwd, p_fwd_fwd, nb); memcpy(ps_bck_fwd, ps_fwd_fwd, nb);
+  memcpy(p_bck_bck, p_fwd_fwd, nb); memcpy(ps_bck_bck, ps_fwd_fwd, nb);
+  memcpy(rho, sp->z.p, nb);
   double log_sum_weight = 0.0, H0 = hamiltonian(sp, &sp->z);
   int n_leapfrog = 0; double sum_metro_prob = 0.0;
   sp->depth = 0; sp->divergent = 0;
   while (sp->depth < sp->o->max_depth) {
-    memset(rho_fwd, 0, sizeof(double) * (size_t)D); memset(rho_bck, 0, sizeof(double) * (size_t)D);
+    memset(rho_fwd, 0, nb); memset(rho_bck, 0, nb);
     int valid; double lsw_subtree = -INFINITY;
     sp->top_depth = sp->depth;
     double udir = oracle_rng_uniform(sp->o->seed, (uint32_t)sp->chain, sp->iter, RNG_DIRECTION, 0, (uint32_t)sp->depth);
-    if (udir > 0.5) {
+    if (udir > 0.5) { /* extend the current trajectory forward */
       ps_copy(&sp->z, &z_fwd, D);
-      memcpy(rho_bck, rho, sizeof(double) * (size_t)D);
-      memcpy(p_bck, p_fwd_bck, sizeof(double) * (size_t)D);
-      memcpy(psharp_bck, psharp_fwd_bck, sizeof(double) * (size_t)D);
-      valid = build_tree(sp, sp->depth, 0, &z_propose, psharp_fwd_bck, psharp_fwd, rho_fwd, p_fwd_bck, p_fwd, H0, 1.0,
+      memcpy(rho_bck, rho, nb);
+      memcpy(p_bck_fwd, p_fwd_fwd, nb);
+      memcpy(ps_bck_fwd, ps_fwd_fwd, nb);
+      valid = build_tree(sp, sp->depth, 0, &z_propose, ps_fwd_bck, ps_fwd_fwd, rho_fwd, p_fwd_bck, p_fwd_fwd, H0, 1.0,
                          &n_leapfrog, &lsw_subtree, &sum_metro_prob);
       ps_copy(&z_fwd, &sp->z, D);
-    } else {
+    } else { /* extend the current trajectory backwards */
       ps_copy(&sp->z, &z_bck, D);
-      memcpy(rho_fwd, rho, sizeof(double) * (size_t)D);
-      memcpy(p_fwd, p_fwd_bck, sizeof(double) * (size_t)D);
-      memcpy(psharp_fwd, psharp_fwd_bck, sizeof(double) * (size_t)D);
-      valid = build_tree(sp, sp->depth, 0, &z_propose, psharp_fwd_bck, psharp_bck, rho_bck, p_fwd_bck, p_bck, H0, -1.0,
+      memcpy(rho_fwd, rho, nb);
+      memcpy(p_fwd_bck, p_bck_bck, nb);
+      memcpy(ps_fwd_bck, ps_bck_bck, nb);
+      valid = build_tree(sp, sp->depth, 0, &z_propose, ps_bck_fwd, ps_bck_bck, rho_bck, p_bck_fwd, p_bck_bck, H0, -1.0,
                          &n_leapfrog, &lsw_subtree, &sum_metro_prob);
       ps_copy(&z_bck, &sp->z, D);
     }
@@ -736,11 +738,11 @@ static double nuts_transition(sampler *sp) {
     }
     log_sum_weight = log_sum_exp(log_sum_weight, lsw_subtree);
     for (int i = 0; i < D; i++) rho[i] = rho_bck[i] + rho_fwd[i];
-    int persist = criterion(sp, psharp_bck, psharp_fwd, rho);
-    for (int i = 0; i < D; i++) rho_ext[i] = rho_bck[i] + p_fwd_bck[i];
-    persist &= criterion(sp, psharp_bck, psharp_fwd_bck, rho_ext);
-    for (int i = 0; i < D; i++) rho_ext[i] = rho_fwd[i] + p_fwd_bck[i];
-    persist &= criterion(sp, psharp_fwd_bck, psharp_fwd, rho_ext);
+    int persist = criterion(sp, ps_bck_bck, ps_fwd_fwd, rho);            /* around the merged subtrees */
+    for (int i = 0; i < D; i++) rho_ext[i] = rho_bck[i] + p_fwd_bck[i];  /* between the subtrees */
+    persist &= criterion(sp, ps_bck_bck, ps_fwd_bck, rho_ext);
+    for (int i = 0; i < D; i++) rho_ext[i] = rho_fwd[i] + p_bck_fwd[i];
+    persist &= criterion(sp, ps_bck_fwd, ps_fwd_fwd, rho_ext);
     if (!persist) break;
   }
   sp->n_leapfrog = n_leapfrog;
@@ -749,8 +751,8 @@ static double nuts_transition(sampler *sp) {
   ps_copy(&sp->z, &z_sample, D);
   sp->energy = hamiltonian(sp, &sp->z);
   ps_free(&z_fwd); ps_free(&z_bck); ps_free(&z_sample); ps_free(&z_propose);
-  free(p_fwd_bck); free(psharp_fwd_bck); free(rho); free(p_fwd); free(psharp_fwd); free(p_bck); free(psharp_bck);
-  free(rho_fwd); free(rho_bck); free(rho_ext);
+  free(p_fwd_fwd); free(ps_fwd_fwd); free(p_fwd_bck); free(ps_fwd_bck); free(p_bck_fwd); free(ps_bck_fwd);
+  free(p_bck_bck); free(ps_bck_bck); free(rho); free(rho_fwd); free(rho_bck); free(rho_ext);
   return accept_stat;
 }
 

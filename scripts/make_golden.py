@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Mint the committed fixtures under tests/golden/ (run in the build container only).
+
+The reference has no golden vectors for this path, so these are minted
+from (a) the reference's own CSV data through us_potus_model_amd.dataprep and (b) the CPU
+oracle in oracle/ -- cross-checked here against torch-fp64 autograd of the independent
+transcription in tests/stan_transcription.py before anything is written.
+
+  python scripts/make_golden.py data        # tests/golden/data_2016.npz   (needs /root/reference)
+  python scripts/make_golden.py logprob     # tests/golden/logprob_*.npz
+  python scripts/make_golden.py posterior   # tests/golden/posterior_2016.npz (minutes, 8 processes)
+"""
+import multiprocessing as mp
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+GOLD = ROOT / "tests" / "golden"
+
+from us_potus_model_amd import _abi, dataprep, synthetic  # noqa: E402
+
+
+def cases():
+    return {
+        "2016": (dataprep.load_npz(GOLD / "data_2016.npz")["data"], "full"),
+        "small_full": (synthetic.small("full"), "full"),
+        "small_nomode": (synthetic.small("no_mode_adjustment"), "no_mode_adjustment"),
+    }
+
+
+def make_data():
+    built = dataprep.build_2016("/root/reference/data")
+    dataprep.save_npz(GOLD / "data_2016.npz", built)
+    d = built["data"]
+    print("data_2016:", {k: d[k] for k in ("N_state_polls", "N_national_polls", "T", "P", "M", "Pop")})
+
+
+def make_logprob():
+    from oracle_lib import OracleModel
+    import stan_transcription as st
+    for name, (data, variant) in cases().items():
+        m = OracleModel(data, variant)
+        rng = np.random.default_rng(12345)
+        qs = [np.zeros(m.D), rng.uniform(-2, 2, m.D), 0.3 * rng.standard_normal(m.D)]
+        lps, grads, was = [], [], []
+        for q in qs:
+            lp, g = m.log_prob_grad(q)
+            lpf, gf = m.log_prob_grad(q, fast=True)
+            lpt, gt, _ = st.log_prob_grad(data, q, variant)
+            scale = np.abs(gt).max()
+            assert abs(lp - lpt) <= 1e-11 * abs(lpt) and abs(lpf - lpt) <= 1e-11 * abs(lpt), (name, lp, lpf, lpt)
+            assert np.abs(g - gt).max() <= 1e-12 * scale and np.abs(gf - gt).max() <= 1e-12 * scale, name
+            lps.append(lp); grads.append(g); was.append(m.write_array(q))
+        layout, ncols = _abi.column_layout(data, variant)
+        assert ncols == m.n_cols
+        wa = np.stack(was)
+        keep = {}
+        for blk in ("mu_b", "predicted_score", "e_bias", "polling_bias", "national_mu_b_average",
+                    "logit_pi_democrat_state", "logit_pi_democrat_national", "sigma_rho"):
+            if blk in layout:
+                a, b, _ = layout[blk]
+                keep["wa__" + blk] = wa[:, a - 7:b - 7]
+        np.savez_compressed(GOLD / f"logprob_{name}.npz", q=np.stack(qs), lp=np.array(lps), grad=np.stack(grads),
+                            wa_checksum=wa.sum(axis=1), **keep)
+        print(name, "D", m.D, "lp", lps)
+
+
+def _chain(args):
+    from oracle_lib import OracleModel
+    data, variant, chain, nw, ns = args
+    m = OracleModel(data, variant)
+    o = m.default_opts(num_warmup=nw, num_samples=ns, fast_grad=1, seed=1843)
+    t = time.time()
+    draws, adapt, nl = m.sample_chain(chain, o)
+    return chain, draws, adapt, nl, time.time() - t
+
+
+def make_posterior(chains=8, nw=1000, ns=1000):
+    from oracle_lib import OracleModel
+    data, variant = cases()["2016"]
+    with mp.Pool(min(chains, mp.cpu_count())) as pool:
+        res = pool.map(_chain, [(data, variant, c + 1, nw, ns) for c in range(chains)])
+    res.sort(key=lambda r: r[0])
+    m = OracleModel(data, variant)
+    layout, _ = _abi.column_layout(data, variant)
+    S, T = int(data["S"]), int(data["T"])
+    a_mu, _, _ = layout["mu_b"]
+    a_ps, _, _ = layout["predicted_score"]
+    mu_bT, ps_T, samp = [], [], []
+    for _, draws, _, _, _ in res:
+        rows = np.stack([m.write_array(q) for q in draws[:, 7:]])
+        mu_b = rows[:, a_mu - 7:a_mu - 7 + S * T].reshape(-1, T, S)      # [draw, t, s] (col-major S x T)
+        ps = rows[:, a_ps - 7:a_ps - 7 + S * T].reshape(-1, S, T)        # [draw, s, t] (col-major T x S)
+        mu_bT.append(mu_b[:, T - 1, :]); ps_T.append(ps[:, :, T - 1]); samp.append(draws[:, :7])
+    mu_bT, ps_T, samp = np.stack(mu_bT), np.stack(ps_T), np.stack(samp)   # [chain, draw, S]
+    from us_potus_model_amd import diagnostics as dg
+    out = dict(stepsize=np.array([r[2][0] for r in res]), leapfrogs=np.array([r[3] for r in res]),
+               seconds=np.array([r[4] for r in res]), config=np.array([chains, nw, ns, 1843]),
+               sampler_mean=samp.mean(axis=1), treedepth_hist=np.bincount(samp[:, :, 3].astype(int).ravel(), minlength=12))
+    for name, x in (("mu_b_T", mu_bT), ("predicted_score_T", ps_T), ("lp", samp[:, :, :1])):
+        sm = dg.summarise(x)
+        pooled = x.reshape(-1, x.shape[-1])
+        out.update({f"{name}__mean": sm["mean"], f"{name}__sd": sm["sd"], f"{name}__mcse": sm["mcse"],
+                    f"{name}__rhat": sm["rhat"], f"{name}__ess_bulk": sm["ess_bulk"],
+                    f"{name}__q025": np.quantile(pooled, 0.025, axis=0), f"{name}__q975": np.quantile(pooled, 0.975, axis=0),
+                    f"{name}__chain_mean": x.mean(axis=1)})
+    out["predicted_score_T__p_win"] = (ps_T.reshape(-1, S) > 0.5).mean(axis=0)
+    w = np.asarray(data["state_weights"])
+    nat = ps_T @ w                                                         # [chain, draw]
+    out["national__mean"] = nat.mean(); out["national__q025"] = np.quantile(nat, 0.025)
+    out["national__q975"] = np.quantile(nat, 0.975); out["national__p_win"] = (nat > 0.5).mean()
+    np.savez_compressed(GOLD / "posterior_2016.npz", **out)
+    print("leapfrogs", [r[3] for r in res], "seconds", [round(r[4], 1) for r in res])
+    print("national", out["national__mean"], out["national__q025"], out["national__q975"], out["national__p_win"])
+    print("rhat max", out["mu_b_T__rhat"].max(), "min bulk ess", out["mu_b_T__ess_bulk"].min(), out["lp__ess_bulk"])
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    GOLD.mkdir(parents=True, exist_ok=True)
+    if what in ("data", "all"):
+        make_data()
+    if what in ("logprob", "all"):
+        make_logprob()
+    if what in ("posterior", "all"):
+        make_posterior()

@@ -1,0 +1,46 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+GOLD = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def data_2016():
+    from us_potus_model_amd import dataprep
+    return dataprep.load_npz(GOLD / "data_2016.npz")["data"]
+
+
+@pytest.fixture(scope="session")
+def cases(data_2016):
+    from us_potus_model_amd import synthetic
+    return {
+        "2016": (data_2016, "full"),
+        "small_full": (synthetic.small("full"), "full"),
+        "small_nomode": (synthetic.small("no_mode_adjustment"), "no_mode_adjustment"),
+    }

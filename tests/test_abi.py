@@ -1,0 +1,109 @@
+"""CPU tests of the C-ABI boundary: the library loads, exports every declared symbol, and the
+host-only entry points (layout arithmetic, column names, validation, error path) behave.
+No compute call is made here -- that needs an MI355X (tests/test_gpu_*.py)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from us_potus_model_amd import _abi, sampler
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = (ROOT / "include" / "potus_hmc.h").read_text()
+    declared = set(re.findall(r"\b(potus_[A-Za-z_0-9]+)\s*\(", hdr))
+    assert declared == set(sampler.EXPORTS), declared ^ set(sampler.EXPORTS)
+    L = sampler.load_library()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libpotus_hmc.so does not export {name}"
+    assert b"gfx950" in L.potus_version()
+
+
+def test_struct_layout_matches_header():
+    # potus_data: 7 int32 + pad, 13 + 4 pointers, 6 doubles, pointer, 3 doubles, int32 (+pad)
+    assert C.sizeof(_abi.PotusData) == 32 + 17 * 8 + 6 * 8 + 8 + 3 * 8 + 8
+    assert C.sizeof(_abi.PotusOpts) == 8 * 4 + 6 * 8 + 8 + 2 * 4
+
+
+@pytest.mark.parametrize("name,D,ncols", [("2016", 15098, 43360), ("small_full", 292, 753), ("small_nomode", 260, 690)])
+def test_num_params_and_columns(cases, name, D, ncols):
+    data, variant = cases[name]
+    L = sampler.load_library()
+    d, keep = _abi.make_data(data, variant)
+    a, b = C.c_int(), C.c_int()
+    assert L.potus_num_params(C.byref(d), C.byref(a)) == 0 and a.value == D == _abi.num_params(data, variant)
+    assert L.potus_num_columns(C.byref(d), C.byref(b)) == 0 and b.value == ncols
+    layout, n2 = _abi.column_layout(data, variant)
+    assert n2 == ncols
+
+
+def test_column_names_follow_cmdstan(cases):
+    data, variant = cases["2016"]
+    L = sampler.load_library()
+    d, keep = _abi.make_data(data, variant)
+    buf = C.create_string_buffer(96)
+
+    def name(k):
+        assert L.potus_column_name(C.byref(d), k, buf, 96) == 0
+        return buf.value.decode()
+
+    layout, ncols = _abi.column_layout(data, variant)
+    assert [name(k) for k in range(7)] == list(_abi.SAMPLER_COLS)
+    assert name(7) == "raw_mu_b_T.1"
+    a, b, _ = layout["raw_mu_b"]
+    assert name(a) == "raw_mu_b.1.1" and name(a + 1) == "raw_mu_b.2.1" and name(a + 51) == "raw_mu_b.1.2"
+    assert name(b - 1) == "raw_mu_b.51.254"
+    assert name(layout["mu_e_bias"][0]) == "mu_e_bias" and name(layout["rho_e_bias"][0]) == "rho_e_bias"
+    a, b, _ = layout["mu_b"]
+    assert name(a) == "mu_b.1.1" and name(b - 1) == "mu_b.51.254"
+    a, b, _ = layout["predicted_score"]
+    assert name(a) == "predicted_score.1.1" and name(a + 1) == "predicted_score.2.1" and name(b - 1) == "predicted_score.254.51"
+    assert b == ncols
+    assert L.potus_column_name(C.byref(d), ncols, buf, 96) != 0
+
+
+def test_create_rejects_bad_data_before_touching_the_device(cases):
+    data, variant = cases["small_full"]
+    L = sampler.load_library()
+    o = _abi.PotusOpts()
+    L.potus_default_opts(C.byref(o))
+    assert (o.num_warmup, o.num_samples, o.max_depth, o.seed) == (1000, 1000, 10, 1843)
+    assert (o.delta, o.gamma, o.kappa, o.t0) == (0.8, 0.05, 0.75, 10.0)
+    bad = dict(data)
+    bad["day_state"] = np.array(data["day_state"]).copy()
+    bad["day_state"][0] = int(data["T"]) + 1
+    d, keep = _abi.make_data(bad, variant)
+    h = C.c_int(-1)
+    rc = L.potus_create(C.byref(d), C.byref(o), C.byref(h))
+    assert rc == 1
+    buf = C.create_string_buffer(256)
+    L.potus_last_error(buf, 256)
+    assert b"day_state" in buf.value
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure path")
+def test_no_silent_cpu_fallback(cases):
+    """Without an MI355X the product path must fail loudly, never compute on the CPU."""
+    data, variant = cases["small_full"]
+    with pytest.raises(sampler.PotusError, match="HIP device|MI355X|gfx950|failed"):
+        sampler.Handle(data, variant, chains=1)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing in the package may import/link/dlopen it."""
+    for p in (ROOT / "us_potus_model_amd").rglob("*"):
+        if p.is_file() and p.suffix in {".py", ".hip", ".hpp", ".h"}:
+            txt = p.read_text()
+            assert "potus_oracle" not in txt and "oracle_lib" not in txt, p
+    import subprocess
+    out = subprocess.run(["ldd", str(sampler.lib_path())], capture_output=True, text=True).stdout
+    assert "oracle" not in out

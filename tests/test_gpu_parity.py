@@ -1,0 +1,212 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the golden
+fixtures.  Floating point, so tolerances are stated: log density 1e-11 relative; gradient
+1e-10 of its max-norm; early NUTS trajectories 1e-6; posterior summaries in units of MCSE."""
+import numpy as np
+import pytest
+
+from conftest import GOLD
+from oracle_lib import OracleModel
+from us_potus_model_amd import Handle, PotusModel, _abi, diagnostics as dg, sampler
+
+pytestmark = pytest.mark.gpu
+
+LP_RTOL, GRAD_RTOL = 1e-11, 1e-10
+
+
+def _blocks(data, variant):
+    layout, _ = _abi.column_layout(data, variant)
+    D = _abi.num_params(data, variant)
+    return {k: (a - 7, b - 7) for k, (a, b, _) in layout.items() if b - 7 <= D}
+
+
+@pytest.mark.parametrize("name", ["small_full", "small_nomode", "2016"])
+def test_log_prob_grad_matches_oracle_and_golden(cases, name):
+    data, variant = cases[name]
+    h = Handle(data, variant, chains=1)
+    m = OracleModel(data, variant)
+    g = np.load(GOLD / f"logprob_{name}.npz")
+    rng = np.random.default_rng(2024)
+    q = np.vstack([g["q"], rng.uniform(-2, 2, (5, h.D)), 0.2 * rng.standard_normal((4, h.D))])
+    lp, grad = h.log_prob_grad(q)
+    for i in range(q.shape[0]):
+        lpo, go = (g["lp"][i], g["grad"][i]) if i < 3 else m.log_prob_grad(q[i])
+        scale = np.abs(go).max()
+        err = np.abs(grad[i] - go)
+        if err.max() > GRAD_RTOL * scale or abs(lp[i] - lpo) > LP_RTOL * abs(lpo):
+            per_block = {k: float(err[a:b].max() / scale) for k, (a, b) in _blocks(data, variant).items()}
+            pytest.fail(f"{name} point {i}: lp {lp[i]!r} vs {lpo!r}; grad rel err by block {per_block}")
+    h.close()
+
+
+def test_log_prob_grad_is_deterministic_and_batched(cases):
+    data, variant = cases["2016"]
+    h = Handle(data, variant, chains=1)
+    q = np.random.default_rng(1).uniform(-2, 2, (40, h.D))
+    lp1, g1 = h.log_prob_grad(q)
+    lp2, g2 = h.log_prob_grad(q[::-1].copy())
+    assert np.array_equal(lp1, lp2[::-1]) and np.array_equal(g1, g2[::-1])   # same bytes, any batch slot
+    h.close()
+
+
+@pytest.mark.parametrize("name,iters", [("small_full", 8), ("small_nomode", 8), ("2016", 3)])
+def test_nuts_follows_the_oracle_chain(cases, name, iters):
+    """Same Philox streams + same algorithm => the first transitions agree to rounding."""
+    data, variant = cases[name]
+    h = Handle(data, variant, chains=2, num_warmup=30, num_samples=0, save_warmup=1, seed=1843)
+    h.init()
+    h.run(iters)
+    d = h.draws()[:, :iters]
+    m = OracleModel(data, variant)
+    o = m.default_opts(num_warmup=30, num_samples=0, save_warmup=1, seed=1843, fast_grad=1)
+    for c in (0, 1):
+        ref = m.sample_chain(c + 1, o)[0][:iters]
+        assert np.array_equal(d[c][:, 3:6], ref[:, 3:6]), (name, c, d[c][:, :7], ref[:, :7])   # depth, n_leapfrog, divergent
+        assert np.allclose(d[c][:, :3], ref[:, :3], rtol=1e-6, atol=1e-9), (d[c][:, :3], ref[:, :3])
+        assert np.allclose(d[c][:, 6], ref[:, 6], rtol=1e-8)
+        assert np.allclose(d[c][:, 7:], ref[:, 7:], rtol=1e-6, atol=1e-7)
+    h.close()
+
+
+def test_adaptation_matches_oracle_through_a_metric_update(cases):
+    """150 warmup iterations cover init buffer, first window end (metric update + init_stepsize)."""
+    data, variant = cases["small_full"]
+    nw = 150
+    h = Handle(data, variant, chains=1, num_warmup=nw, num_samples=0, save_warmup=1, seed=11)
+    h.init()
+    h.run(nw)
+    d = h.draws()[0]
+    eps, minv = h.adaptation()
+    m = OracleModel(data, variant)
+    ref, ad, nl = m.sample_chain(1, m.default_opts(num_warmup=nw, num_samples=0, save_warmup=1, seed=11, fast_grad=1))
+    # chaos amplifies rounding differences over thousands of leapfrogs, so compare what is robust:
+    k = 20
+    assert np.array_equal(d[:k, 3:6], ref[:k, 3:6]) and np.allclose(d[:k, 2], ref[:k, 2], rtol=1e-6)
+    assert abs(np.log(eps[0] / ad[0])) < 0.5
+    ratio = np.log(minv[0] / ad[1:])
+    assert abs(np.median(ratio)) < 0.15 and np.abs(ratio).max() < 2.5
+    assert abs(h.total_leapfrogs() - nl) / nl < 0.5
+    h.close()
+
+
+def test_same_seed_same_bytes_and_chain_ids(cases):
+    data, variant = cases["small_full"]
+    kw = dict(num_warmup=40, num_samples=20, seed=99)
+    a = Handle(data, variant, chains=3, **kw); a.init(); a.run(60); da = a.draws(); a.close()
+    b = Handle(data, variant, chains=3, **kw); b.init(); b.run(25); b.run(35); db = b.draws(); b.close()
+    assert np.array_equal(da, db)                      # deterministic, independent of chunking
+    c = Handle(data, variant, chains=1, chain_id_offset=2, **kw); c.init(); c.run(60); dc = c.draws(); c.close()
+    assert np.array_equal(da[2], dc[0])                # chain 3 is chain 3 wherever it runs
+    assert not np.array_equal(da[0], da[1])
+
+
+@pytest.mark.parametrize("name", ["small_full", "small_nomode", "2016"])
+def test_write_array_matches_oracle(cases, name):
+    data, variant = cases[name]
+    h = Handle(data, variant, chains=2, num_warmup=6, num_samples=0, save_warmup=1, seed=3)
+    h.init(); h.run(6)
+    d = h.draws()
+    m = OracleModel(data, variant)
+    full = h.write_array(0, h.n_cols, 6)               # [iter, chain, ncols]
+    assert np.array_equal(full[:, :, :7], np.transpose(d[:, :, :7], (1, 0, 2)))
+    for it in (0, 5):
+        for c in (0, 1):
+            want = m.write_array(d[c, it, 7:])
+            assert np.allclose(full[it, c, 7:], want, rtol=1e-11, atol=1e-12), name
+    a, b, dims = h.layout["predicted_score"]
+    part = h.write_array(a, b, 6)
+    assert np.array_equal(part, full[:, :, a:b])
+    h.close()
+
+
+def test_extract_shapes_and_transpose(cases):
+    data, variant = cases["small_full"]
+    model = PotusModel("scripts/model/poll_model_2020.stan")
+    fit = model.sample(data, seed=5, chains=2, iter_warmup=20, iter_sampling=10, refresh=10)
+    S, T = int(data["S"]), int(data["T"])
+    mu_b = fit.extract("mu_b")
+    ps = fit.extract("predicted_score")
+    assert mu_b.shape == (20, S, T) and ps.shape == (20, T, S)
+    assert np.allclose(ps, 1 / (1 + np.exp(-np.transpose(mu_b, (0, 2, 1)))), rtol=1e-12)   # stan:135-139
+    assert fit.extract("mu_e_bias").shape == (20,) and fit.model_name == "poll_model_2020_model"
+    sp = fit.sampler_params()
+    assert sp["n_leapfrog__"].shape == (2, 10) and (sp["stepsize__"] > 0).all()
+    model2 = PotusModel("scripts/model/poll_model_2020_no_mode_adjustment.stan")
+    with pytest.raises(KeyError):
+        model2.sample(cases["small_nomode"][0], chains=1, iter_warmup=5, iter_sampling=2, refresh=0).extract("mu_m")
+
+
+def test_stan_csv_round_trip(cases, tmp_path):
+    data, variant = cases["small_nomode"]
+    h = Handle(data, variant, chains=2, num_warmup=10, num_samples=4, seed=8)
+    h.init(); h.run(14)
+    files = h.write_stan_csv(tmp_path, "poll")
+    full = h.write_array(0, h.n_cols, 4)
+    for c, f in enumerate(files):
+        lines = open(f).read().splitlines()
+        header = [l for l in lines if l and not l.startswith("#")][0].split(",")
+        assert header[:7] == list(_abi.SAMPLER_COLS) and len(header) == h.n_cols
+        assert header[7] == "raw_mu_b_T.1" and header[-1].startswith("predicted_score.")
+        rows = np.array([[float(x) for x in l.split(",")] for l in lines if l and not l.startswith("#") and not l.startswith("lp__")])
+        assert rows.shape == (4, h.n_cols)
+        assert np.allclose(rows, full[:, c, :], rtol=2e-5, atol=1e-12)       # %.6g text, as CmdStan writes
+        assert any(l.startswith("# Step size") for l in lines) and any("Elapsed Time" in l for l in lines)
+    h.close()
+
+
+def test_error_paths(cases):
+    data, variant = cases["small_full"]
+    h = Handle(data, variant, chains=1, num_warmup=5, num_samples=5)
+    with pytest.raises(sampler.PotusError, match="potus_init"):
+        h.run(1)
+    with pytest.raises(sampler.PotusError):
+        h.write_array(5, 3, 1)
+    h.close()
+    with pytest.raises(sampler.PotusError, match="max_depth"):
+        Handle(data, variant, chains=1, max_depth=40)
+
+
+def test_posterior_parity_small(cases):
+    """Statistical parity: pooled means of every unconstrained coordinate within 5 combined MCSE."""
+    data, variant = cases["small_full"]
+    nw = ns = 400
+    h = Handle(data, variant, chains=4, num_warmup=nw, num_samples=ns, seed=1843)
+    h.init(); h.run(nw + ns)
+    x = h.draws()[:, :, 7:]
+    st, dv = h.chain_status()
+    assert st == [0, 0, 0, 0] and sum(dv) <= 8
+    m = OracleModel(data, variant)
+    o = m.default_opts(num_warmup=nw, num_samples=ns, seed=4242, fast_grad=1)      # different seed: independent run
+    y = np.stack([m.sample_chain(c, o)[0][:, 7:] for c in (1, 2, 3, 4)])
+    worst = 0.0
+    for j in range(h.D):
+        a, b = x[:, :, j], y[:, :, j]
+        se = np.hypot(a.std() / np.sqrt(dg.ess_mean(a)), b.std() / np.sqrt(dg.ess_mean(b)))
+        worst = max(worst, abs(a.mean() - b.mean()) / se)
+        assert dg.rhat(a) < 1.08
+    assert worst < 5.0, worst
+    h.close()
+
+
+def test_posterior_2016_against_golden_and_readme(data_2016):
+    """BASELINE configs[1]: 2016 backtest, 8 chains, 1000/1000, seed 1843 -- against the oracle's
+    committed posterior summary (tests/golden/posterior_2016.npz) and, softly (0.01), against the
+    reference's published table (README.md:279-332: national 0.512 / 0.485 / 0.540)."""
+    g = np.load(GOLD / "posterior_2016.npz")
+    model = PotusModel("full")
+    fit = model.sample(data_2016, seed=1843, chains=8, iter_warmup=1000, iter_sampling=1000, refresh=500)
+    S, T = 51, 254
+    mu_b_T = fit.extract("mu_b")[:, :, T - 1].reshape(8, 1000, S)
+    ps_T = fit.extract("predicted_score")[:, T - 1, :].reshape(8, 1000, S)
+    for name, x in (("mu_b_T", mu_b_T), ("predicted_score_T", ps_T)):
+        sm = dg.summarise(x)
+        se = np.hypot(sm["mcse"], g[f"{name}__mcse"])
+        z = np.abs(sm["mean"] - g[f"{name}__mean"]) / se
+        assert z.max() < 5.0, (name, z.max())
+        assert sm["rhat"].max() < 1.05
+        pooled = x.reshape(-1, S)
+        assert np.abs(np.quantile(pooled, 0.025, axis=0) - g[f"{name}__q025"]).max() < 6 * se.max() + 0.004
+        assert np.abs(np.quantile(pooled, 0.975, axis=0) - g[f"{name}__q975"]).max() < 6 * se.max() + 0.004
+    nat = ps_T @ np.asarray(data_2016["state_weights"])
+    assert abs(nat.mean() - 0.512) < 0.01 and abs(np.quantile(nat, 0.025) - 0.485) < 0.012 and abs(np.quantile(nat, 0.975) - 0.540) < 0.012
+    sp = fit.sampler_params()
+    assert sp["divergent__"].mean() < 0.01 and 0.6 < sp["accept_stat__"].mean() < 0.97

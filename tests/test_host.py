@@ -1,0 +1,120 @@
+"""CPU tests of host logic: data prep fixture, diagnostics, chain partitioning, gloo all-gather."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from us_potus_model_amd import _abi, diagnostics as dg, parallel, synthetic
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_data_2016_fixture(data_2016):
+    d = data_2016
+    # sizes re-derived from the reference CSVs (T = 254 at final_2016.R:556)
+    assert (d["N_state_polls"], d["N_national_polls"], d["T"], d["S"], d["P"], d["M"], d["Pop"]) == (1258, 361, 254, 51, 161, 3, 3)
+    assert d["state"].min() >= 1 and d["state"].max() <= 51
+    assert d["day_state"].max() <= 254 and d["day_national"].max() <= 254
+    assert abs(d["state_weights"].sum() - 1) < 1e-12
+    cov = d["state_covariance_0"]
+    assert np.allclose(cov, cov.T) and np.linalg.eigvalsh(cov).min() > 0
+    # cov_matrix(51, 0.07^2, 0.9) * corr; make.positive.definite lifts the diagonal slightly above 1
+    assert (np.diag(cov) >= 0.07 ** 2 - 1e-12).all() and (np.diag(cov) < 0.07 ** 2 * 1.1).all()
+    assert d["polling_bias_scale"] == pytest.approx(0.052) and d["mu_b_T_scale"] == pytest.approx(0.12)
+    assert d["random_walk_scale"] == pytest.approx(0.05 / np.sqrt(300) * 4)
+    assert (d["n_democrat_state"] <= d["n_two_share_state"]).all()
+    # national prior close to the value the script prints (final_2016.R:412-414): Clinton ~ 0.51
+    nat = (1 / (1 + np.exp(-d["mu_b_prior"]))) @ d["state_weights"]
+    assert 0.49 < nat < 0.53
+
+
+@pytest.mark.skipif(not Path("/root/reference/data").exists(), reason="reference CSVs only exist in the build container")
+def test_dataprep_reproduces_fixture(data_2016):
+    from us_potus_model_amd import dataprep
+    d = dataprep.build_2016("/root/reference/data")["data"]
+    for k, v in data_2016.items():
+        assert np.allclose(np.asarray(d[k], dtype=float), np.asarray(v, dtype=float), rtol=1e-12, atol=1e-14), k
+
+
+def test_make_positive_definite_and_cov_matrix():
+    from us_potus_model_amd import dataprep
+    m = dataprep.cov_matrix(4, 0.04, 0.9)
+    assert np.allclose(np.diag(m), 0.04) and m[0, 1] == pytest.approx(0.036)
+    a = np.array([[1.0, 0.99, 0.0], [0.99, 1.0, 0.99], [0.0, 0.99, 1.0]])   # indefinite
+    p = dataprep.make_positive_definite(a)
+    assert np.linalg.eigvalsh(p).min() > 0 and np.allclose(p, p.T)
+    spd = np.eye(3) * 2
+    assert np.allclose(dataprep.make_positive_definite(spd), spd)
+
+
+def test_synthetic_variants():
+    f, n = synthetic.small("full"), synthetic.small("no_mode_adjustment")
+    assert "poll_mode_state" in f and "poll_mode_state" not in n and "sigma_a" in n
+    assert _abi.num_params(f, "full") - _abi.num_params(n, "no_mode_adjustment") == 3 + 3 + 2 + 24
+    st = synthetic.stress()
+    assert _abi.num_params(st, "full") == 41610
+
+
+def test_diagnostics_iid_and_ar1():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((4, 2000))
+    assert 0.85 * 8000 < dg.ess_bulk(x) < 1.2 * 8000 and dg.rhat(x) < 1.01
+    phi = 0.9
+    y = np.zeros((4, 4000))
+    e = rng.standard_normal((4, 4000))
+    for t in range(1, 4000):
+        y[:, t] = phi * y[:, t - 1] + e[:, t]
+    expect = 16000 * (1 - phi) / (1 + phi)
+    assert 0.6 * expect < dg.ess_mean(y) < 1.6 * expect
+    z = x.copy()
+    z[0] += 3.0
+    assert dg.rhat(z) > 1.2
+
+
+def test_chain_block_partition():
+    for total in (1, 8, 64, 96, 7):
+        for world in (1, 2, 4, 8):
+            blocks = [parallel.chain_block(total, r, world) for r in range(world)]
+            assert sum(n for _, n in blocks) == total
+            off = 0
+            for o, n in blocks:
+                assert o == off
+                off += n
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch.distributed as dist
+from us_potus_model_amd import parallel
+rank, world, _ = parallel.init_process_group("gloo")
+total = 5
+off, n = parallel.chain_block(total, rank, world)
+local = np.zeros((n, 3, 2))
+for c in range(n):
+    local[c] = 100 * (off + c + 1) + np.arange(6).reshape(3, 2)
+pooled = parallel.all_gather_draws(local, total)
+assert pooled.shape == (total, 3, 2), pooled.shape
+for c in range(total):
+    assert np.array_equal(pooled[c], 100 * (c + 1) + np.arange(6).reshape(3, 2))
+assert parallel.max_over_ranks(float(rank)) == world - 1
+assert parallel.sum_over_ranks(1.0) == world
+parallel.barrier()
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_all_gather_world_size_2_gloo(tmp_path):
+    """The N>1 path (chain partition + pooled draws) on CPU with gloo, world_size 2."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), str(ROOT)],
+                         capture_output=True, text=True, env=env, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2

@@ -1,0 +1,155 @@
+"""CPU tests of the oracle (the checker itself): known answers, autograd, finite differences."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import stan_transcription as st
+from conftest import GOLD
+from oracle_lib import OracleModel, lib
+from us_potus_model_amd import _abi
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    L = lib()
+    kat = [
+        ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+        ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+        ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+    ]
+    for ctr, key, want in kat:
+        o = (C.c_uint32 * 4)()
+        L.oracle_philox((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), o)
+        assert list(o) == want
+
+
+def test_rng_moments():
+    L = lib()
+    u = np.array([L.oracle_rng_uniform(1843, 1, 0, 1, 0, i) for i in range(20000)])
+    assert 0 < u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.01
+    a, b = C.c_double(), C.c_double()
+    z = []
+    for i in range(10000):
+        L.oracle_rng_normal_pair(1843, 1, 0, 0, 0, i, C.byref(a), C.byref(b))
+        z += [a.value, b.value]
+    z = np.array(z)
+    assert abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03
+
+
+@pytest.mark.parametrize("name", ["2016", "small_full", "small_nomode"])
+def test_oracle_matches_golden_and_autograd(cases, name):
+    data, variant = cases[name]
+    m = OracleModel(data, variant)
+    g = np.load(GOLD / f"logprob_{name}.npz")
+    assert m.D == g["q"].shape[1] == _abi.num_params(data, variant)
+    for i, q in enumerate(g["q"]):
+        lp, grad = m.log_prob_grad(q)
+        lpf, gradf = m.log_prob_grad(q, fast=True)
+        assert lp == pytest.approx(g["lp"][i], rel=1e-13)
+        scale = np.abs(g["grad"][i]).max()
+        assert np.abs(grad - g["grad"][i]).max() <= 1e-13 * scale
+        assert abs(lpf - lp) <= 1e-12 * abs(lp) and np.abs(gradf - grad).max() <= 1e-12 * scale
+    # independent torch transcription (autograd) on a fresh point
+    q = np.random.default_rng(99).uniform(-1.5, 1.5, m.D)
+    lp, grad = m.log_prob_grad(q)
+    lpt, gt, aux = st.log_prob_grad(data, q, variant)
+    assert abs(lp - lpt) <= 1e-12 * abs(lpt)
+    assert np.abs(grad - gt).max() <= 1e-12 * np.abs(gt).max()
+    # write_array against the transcription's intermediates
+    layout, ncols = _abi.column_layout(data, variant)
+    assert ncols == m.n_cols
+    wa = m.write_array(q)
+    S, T = int(data["S"]), int(data["T"])
+    a, b, _ = layout["mu_b"]
+    assert np.allclose(wa[a - 7:b - 7].reshape(T, S).T, aux["mu_b"], rtol=1e-12, atol=1e-14)
+    a, b, _ = layout["predicted_score"]
+    ps = wa[a - 7:b - 7].reshape(S, T).T          # [T, S]
+    assert np.allclose(ps, 1 / (1 + np.exp(-aux["mu_b"].T)), rtol=1e-12)
+    a, b, _ = layout["logit_pi_democrat_state"]
+    assert np.allclose(wa[a - 7:b - 7], aux["eta_s"], rtol=1e-12, atol=1e-13)
+    a, b, _ = layout["logit_pi_democrat_national"]
+    assert np.allclose(wa[a - 7:b - 7], aux["eta_n"], rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("name", ["small_full", "small_nomode"])
+def test_finite_differences(cases, name):
+    data, variant = cases[name]
+    m = OracleModel(data, variant)
+    rng = np.random.default_rng(5)
+    q = rng.uniform(-1, 1, m.D)
+    _, g = m.log_prob_grad(q)
+    for i in rng.choice(m.D, 40, replace=False):
+        h = 1e-5
+        qp, qm = q.copy(), q.copy()
+        qp[i] += h
+        qm[i] -= h
+        fd = (m.log_prob_grad(qp)[0] - m.log_prob_grad(qm)[0]) / (2 * h)
+        assert fd == pytest.approx(g[i], rel=2e-5, abs=2e-4)
+
+
+def test_data_block_validation(cases):
+    data, variant = cases["small_full"]
+    bad = dict(data)
+    bad["state"] = np.array(data["state"]).copy()
+    bad["state"][0] = int(data["S"]) + 1          # declared legal (stan:9) but out of range at stan:97
+    with pytest.raises(ValueError):
+        OracleModel(bad, variant)
+    bad = dict(data)
+    bad["unadjusted_state"] = np.array(data["unadjusted_state"]).copy()
+    bad["unadjusted_state"][3] = 1.5
+    with pytest.raises(ValueError):
+        OracleModel(bad, variant)
+    bad = dict(data)
+    cov = np.array(data["state_covariance_0"]).copy()
+    cov[0, 0] = -1.0
+    bad["state_covariance_0"] = cov
+    with pytest.raises(ValueError):
+        OracleModel(bad, variant)
+
+
+def test_cholesky_factors(cases):
+    data, variant = cases["2016"]
+    m = OracleModel(data, variant)
+    LB, LT, LW = m.cholesky()
+    w, cov = np.asarray(data["state_weights"]), np.asarray(data["state_covariance_0"])
+    nsd = np.sqrt(w @ cov @ w)
+    for L, sc in ((LB, data["polling_bias_scale"]), (LT, data["mu_b_T_scale"]), (LW, data["random_walk_scale"])):
+        assert np.allclose(L @ L.T, cov * (sc / nsd) ** 2, rtol=1e-11, atol=1e-16)
+        assert np.allclose(L, np.tril(L))
+        # the scaling is what the R script prints as a check (final_2016.R:344-353)
+        assert np.sqrt(w @ (L @ L.T) @ w) == pytest.approx(sc, rel=1e-10)
+
+
+def test_sampler_small_posterior(cases):
+    """Adaptive NUTS on the small case: sane adaptation, R-hat ~ 1, literal == fast trajectories."""
+    from us_potus_model_amd import diagnostics as dg
+    data, variant = cases["small_full"]
+    m = OracleModel(data, variant)
+    o = m.default_opts(num_warmup=200, num_samples=200, fast_grad=1, seed=1843)
+    res = [m.sample_chain(c, o) for c in (1, 2, 3, 4)]
+    x = np.stack([r[0] for r in res])
+    assert np.isfinite(x).all()
+    assert (x[:, :, 5] == 0).mean() > 0.98                      # hardly any divergences
+    assert 0.6 < x[:, :, 1].mean() < 0.99                       # accept_stat near the 0.8 target
+    assert all(0.01 < r[1][0] < 1.0 for r in res)               # adapted step size
+    rh = [dg.rhat(x[:, :, 7 + j]) for j in range(0, m.D, 7)]
+    assert np.nanmax(rh) < 1.06
+    # n_leapfrog is 2^depth - 1 unless the last doubling was cut short
+    assert (x[:, :, 4] <= 2 ** x[:, :, 3] * 2 - 1).all() and (x[:, :, 4] >= 2 ** (x[:, :, 3] - 1)).all()
+    # energy = H at the sample: energy + lp = kinetic >= 0
+    assert (x[:, :, 6] + x[:, :, 0] >= 0).all()
+    o_lit = m.default_opts(num_warmup=10, num_samples=0, fast_grad=0, seed=7, save_warmup=1)
+    o_fast = m.default_opts(num_warmup=10, num_samples=0, fast_grad=1, seed=7, save_warmup=1)
+    a, b = m.sample_chain(1, o_lit)[0], m.sample_chain(1, o_fast)[0]
+    assert np.allclose(a[:5], b[:5], rtol=1e-7, atol=1e-7)
+
+
+def test_oracle_chains_are_independent_streams(cases):
+    data, variant = cases["small_full"]
+    m = OracleModel(data, variant)
+    o = m.default_opts(num_warmup=5, num_samples=0, seed=1843, save_warmup=1)
+    a, b = m.sample_chain(1, o)[0], m.sample_chain(2, o)[0]
+    a2 = m.sample_chain(1, o)[0]
+    assert np.array_equal(a, a2) and not np.allclose(a[:, 7:], b[:, 7:])

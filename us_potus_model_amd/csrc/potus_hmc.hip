@@ -1,0 +1,865 @@
+// potus_hmc.hip -- libpotus_hmc.so: C ABI (include/potus_hmc.h) over the gfx950 kernels.
+//
+// Host side: validates the Stan data block, builds transformed data (stan:42-55) and the
+// static poll schedule, owns device memory / stream / events behind an integer handle.
+// Device side: potus_model.hpp (log-density + gradient), potus_nuts.hpp (NUTS + adaptation).
+#include "../../include/potus_hmc.h"
+#include "potus_nuts.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// ======================================================================== kernels
+extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+
+__global__ __launch_bounds__(PT_THREADS) void k_logprob_grad(DevModel M, const double *q, double *lp, double *grad, int n) {
+  model_setup_lds(M, lds_dyn);
+  for (int b = blockIdx.x; b < n; b += gridDim.x) {
+    PlainPolicy pol{q + (size_t)b * M.D, grad + (size_t)b * M.D, {0}};
+    const double v = model_pass(M, lds_dyn, pol);
+    if (threadIdx.x == 0) lp[b] = v;
+  }
+}
+
+__device__ __forceinline__ Chain make_chain(const DevModel &M, const RunParams &R, int chain) {
+  TS *ts = reinterpret_cast<TS *>(lds_dyn + M.lds_doubles);
+  return Chain{M, R, lds_dyn, *ts, R.state + (size_t)chain * V_COUNT * R.Dpad, R.scal + chain,
+               RngKey{R.seed_lo, R.seed_hi, (uint32_t)(R.chain_id_offset + chain + 1)}, M.D, (int)threadIdx.x};
+}
+
+// Initial values (stan::services::util::initialize: U(-R,R), <= 100 attempts), unit metric,
+// adaptation windows (windowed_adaptation), mu = log(10*stepsize), initial init_stepsize.
+__global__ __launch_bounds__(PT_THREADS) void k_init(DevModel M, RunParams R, const double *q0) {
+  const int chain = blockIdx.x;
+  Chain c = make_chain(M, R, chain);
+  model_setup_lds(M, lds_dyn);
+  const int tid = c.tid;
+  double *Q0 = c.vec(V_Q0), *G0 = c.vec(V_G0), *minv = c.vec(V_MINV), *mean = c.vec(V_WMEAN), *m2 = c.vec(V_WM2);
+  for (int i = tid; i < c.D; i += PT_THREADS) { minv[i] = 1.0; mean[i] = 0.0; m2[i] = 0.0; }
+  if (tid == 0) {
+    ChainScalars *sc = c.sc;
+    sc->nom_eps = R.stepsize; sc->mu = log(10.0 * R.stepsize); sc->s_bar = 0; sc->x_bar = 0; sc->ad_counter = 0;
+    sc->wf_n = 0; sc->total_leapfrogs = 0; sc->iter = 0; sc->status = 0; sc->n_divergent = 0; sc->saved = 0;
+    sc->win_counter = 0; sc->win_size = R.window; sc->win_next = R.init_buffer + R.window - 1;
+  }
+  __syncthreads();
+  bool ok = false;
+  for (uint32_t attempt = 0; attempt < 100 && !ok; attempt++) {
+    for (int i = tid; i < c.D; i += PT_THREADS) {
+      if (q0) Q0[i] = q0[(size_t)chain * c.D + i];
+      else Q0[i] = R.init_radius * (2.0 * rng_uniform(c.key, PT_ITER_PRE, RNG_INITS, attempt, (uint32_t)i) - 1.0);
+    }
+    __syncthreads();
+    PlainPolicy pol{Q0, G0, {0}};
+    const double lp = model_pass(M, lds_dyn, pol);
+    double bad[1] = {0.0};
+    for (int i = tid; i < c.D; i += PT_THREADS) bad[0] += isfinite(G0[i]) ? 0.0 : 1.0;
+    block_sum(bad, lds_dyn + M.l_red, tid);
+    ok = isfinite(lp) && bad[0] == 0.0;
+    if (tid == 0 && ok) c.sc->lp_cur = lp;
+    __syncthreads();
+    if (q0) break;
+  }
+  if (!ok) { if (tid == 0) c.sc->status = POTUS_ERR_INIT; return; }
+  init_stepsize(c, PT_ITER_PRE);
+  if (tid == 0 && R.num_warmup == 0) c.sc->nom_eps = exp(c.sc->x_bar); // engage+disengage: complete_adaptation
+}
+
+// n_iter transitions per chain, adaptation during warmup, draws appended to the draws array.
+__global__ __launch_bounds__(PT_THREADS) void k_run(DevModel M, RunParams R, int n_iter) {
+  const int chain = blockIdx.x;
+  Chain c = make_chain(M, R, chain);
+  if (c.sc->status != 0) return;
+  model_setup_lds(M, lds_dyn);
+  const int tid = c.tid;
+  TS &ts = c.ts;
+  double *Q0 = c.vec(V_Q0);
+  for (int k = 0; k < n_iter; k++) {
+    const int it = c.sc->iter;
+    if (it >= R.num_warmup + R.num_samples) break;
+    nuts_transition(c, (uint32_t)it);
+    const double *qs = c.vec(V_POOLQ + ts.sample_qid);
+    const bool warm = it < R.num_warmup;
+    if (!warm || R.save_warmup) {
+      double *row = R.draws + ((size_t)chain * R.n_save_max + c.sc->saved) * R.row;
+      if (tid == 0) {
+        row[0] = ts.out_lp; row[1] = ts.accept_stat; row[2] = ts.eps; row[3] = ts.depth; row[4] = ts.n_leap;
+        row[5] = ts.divergent; row[6] = ts.out_h;
+      }
+      for (int i = tid; i < c.D; i += PT_THREADS) row[POTUS_N_SAMPLER_COLS + i] = qs[i];
+    }
+    for (int i = tid; i < c.D; i += PT_THREADS) Q0[i] = qs[i];
+    __syncthreads();
+    if (tid == 0) {
+      c.sc->lp_cur = ts.out_lp;
+      if (!warm || R.save_warmup) c.sc->saved += 1;
+    }
+    if (warm) adapt_after_transition(c, (uint32_t)it, Q0);
+    __syncthreads();
+    if (tid == 0) c.sc->iter = it + 1;
+    __syncthreads();
+  }
+}
+
+// write_array (stan:70-113 transformed parameters, stan:134-140 generated quantities) for saved
+// draws; one 256-thread workgroup per draw builds the full CmdStan row in scratch and copies
+// the requested column range.  out layout: [iter][chain][col_end - col_begin].
+struct WAParams {
+  const double *draws; // [chains][n_save_max][row]
+  int chains, n_save_max, n_saved, row, ncols, col_begin, col_end;
+  double *scratch;     // [gridDim.x][ncols]
+  double *out;
+  double sigma_ns, sigma_nn;
+};
+__global__ __launch_bounds__(256) void k_write_array(DevModel M, WAParams W) {
+  __shared__ double s_bT[64], s_pb[64], s_misc[4];
+  const int tid = threadIdx.x, S = M.S, T = M.T, D = M.D;
+  double *row = W.scratch + (size_t)blockIdx.x * W.ncols;
+  const int o_par = POTUS_N_SAMPLER_COLS;
+  const int o_mub = o_par + D, o_muc = o_mub + S * T;
+  const int o_mum = o_muc + M.P, o_mupop = o_mum + (M.full ? M.M : 0), o_eb = o_mupop + (M.full ? M.Pop : 0);
+  const int o_pb = o_eb + (M.full ? T : 0), o_nat = o_pb + S, o_natpb = o_nat + T, o_srho = o_natpb + 1;
+  const int o_etas = o_srho + (M.full ? 1 : 0), o_etan = o_etas + M.Ns, o_gq = o_etan + M.Nn;
+  for (int d = blockIdx.x; d < W.n_saved * W.chains; d += gridDim.x) {
+    const int iter = d / W.chains, chain = d % W.chains;
+    const double *src = W.draws + ((size_t)chain * W.n_save_max + iter) * W.row;
+    const double *q = src + POTUS_N_SAMPLER_COLS;
+    for (int i = tid; i < POTUS_N_SAMPLER_COLS + D; i += 256) row[i] = src[i];
+    __syncthreads();
+    double *Ct = row + o_gq; // suffix sums, staged where predicted_score will go
+    if (tid < S) {
+      double run = 0.0;
+      Ct[tid + S * (T - 1)] = 0.0;
+      for (int t = T - 2; t >= 0; t--) { run += q[M.o_Z + tid + S * t]; Ct[tid + S * t] = run; }
+      double bT = M.prior[tid], pb = 0.0;
+      for (int k = 0; k <= tid; k++) { bT += M.LT[tid * S + k] * q[M.o_zT + k]; pb += M.LB[tid * S + k] * q[M.o_zb + k]; }
+      s_bT[tid] = bT; s_pb[tid] = pb; row[o_pb + tid] = pb;
+    }
+    if (tid == 64 && M.full) {
+      const double mue = 0.02 * q[M.o_mue], rho = d_inv_logit(q[M.o_rho]), srho = sqrt(1.0 - rho * rho) * M.sigma_e;
+      row[o_par + M.o_mue] = mue; row[o_par + M.o_rho] = rho; row[o_srho] = srho;
+      double e = q[M.o_ze] * M.sigma_e;
+      row[o_eb] = e;
+      for (int t = 1; t < T; t++) { e = mue + rho * (e - mue) + q[M.o_ze + t] * srho; row[o_eb + t] = e; }
+    }
+    for (int i = tid; i < M.P; i += 256) row[o_muc + i] = q[M.o_c + i] * M.sigma_c;
+    if (M.full) {
+      for (int i = tid; i < M.M; i += 256) row[o_mum + i] = q[M.o_m + i] * M.sigma_m;
+      for (int i = tid; i < M.Pop; i += 256) row[o_mupop + i] = q[M.o_pop + i] * M.sigma_pop;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < S * T; idx += 256) {
+      const int s = idx % S, t = idx / S;
+      double a = s_bT[s];
+      const double *Lrow = M.Lw_ext + s * M.SP, *Cc = Ct + S * t;
+      for (int k = 0; k <= s; k++) a += Lrow[k] * Cc[k];
+      row[o_mub + idx] = a;
+    }
+    if (tid == 0) { double a = 0.0; for (int s = 0; s < S; s++) a += s_pb[s] * M.w[s]; s_misc[0] = a; row[o_natpb] = a; }
+    __syncthreads();
+    for (int t = tid; t < T; t += 256) {
+      double a = 0.0;
+      for (int s = 0; s < S; s++) a += row[o_mub + s + S * t] * M.w[s];
+      row[o_nat + t] = a;
+    }
+    __syncthreads();
+    for (int i = tid; i < M.Npoll; i += 256) {
+      const int s = M.ps[i], t = M.pt[i], qi = M.pqidx[i];
+      const bool nat = s == S;
+      double eta = (nat ? row[o_nat + t] : row[o_mub + s + S * t]) + row[o_muc + M.pp[i]];
+      if (M.full) eta += row[o_mum + M.pm[i]] + row[o_mupop + M.ppop[i]] + M.punadj[i] * row[o_eb + t];
+      eta += q[qi] * M.psig[i] + (nat ? s_misc[0] : s_pb[s]);
+      if (nat) row[o_etan + (qi - M.o_nn)] = eta; else row[o_etas + (qi - M.o_ns)] = eta;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < S * T; idx += 256) { // predicted_score[t,s] = inv_logit(mu_b[s,t]) (stan:135-139)
+      const int t = idx % T, s = idx / T;
+      row[o_gq + idx] = d_inv_logit(row[o_mub + s + S * t]);
+    }
+    __syncthreads();
+    const int nsel = W.col_end - W.col_begin;
+    double *dst = W.out + (size_t)d * nsel;
+    for (int i = tid; i < nsel; i += 256) dst[i] = row[W.col_begin + i];
+    __syncthreads();
+  }
+}
+
+// ======================================================================== host
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(POTUS_ERR_DEVICE, "%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
+
+struct Layout { // column blocks of one output row after the 7 sampler columns
+  int D, ncols;
+  int o_zT, o_Z, o_c, o_m, o_pop, o_mue, o_rho, o_ze, o_nn, o_ns, o_zb;
+};
+Layout make_layout(const potus_data *d) {
+  Layout L{};
+  const bool full = d->variant == POTUS_VARIANT_FULL;
+  int o = 0;
+  L.o_zT = o; o += d->S;
+  L.o_Z = o; o += d->S * d->T;
+  L.o_c = o; o += d->P;
+  if (full) { L.o_m = o; o += d->M; L.o_pop = o; o += d->Pop; L.o_mue = o; o += 1; L.o_rho = o; o += 1; L.o_ze = o; o += d->T; }
+  else L.o_m = L.o_pop = L.o_mue = L.o_rho = L.o_ze = -1;
+  L.o_nn = o; o += d->N_national_polls;
+  L.o_ns = o; o += d->N_state_polls;
+  L.o_zb = o; o += d->S;
+  L.D = o;
+  const int tp = d->S * d->T + d->P + (full ? d->M + d->Pop + d->T : 0) + d->S + d->T + 1 + (full ? 1 : 0)
+                 + d->N_state_polls + d->N_national_polls;
+  L.ncols = POTUS_N_SAMPLER_COLS + L.D + tp + d->T * d->S;
+  return L;
+}
+
+int validate(const potus_data *d) {
+  if (!d) return fail(POTUS_ERR_ARG, "null data");
+  if (d->variant != POTUS_VARIANT_FULL && d->variant != POTUS_VARIANT_NO_MODE) return fail(POTUS_ERR_ARG, "unknown variant %d", d->variant);
+  const bool full = d->variant == POTUS_VARIANT_FULL;
+  if (d->S < 1 || d->T < 2 || d->P < 1 || d->N_state_polls < 0 || d->N_national_polls < 0) return fail(POTUS_ERR_ARG, "bad sizes");
+  if (full && (d->M < 1 || d->Pop < 1)) return fail(POTUS_ERR_ARG, "bad sizes M/Pop");
+  auto range = [&](const int32_t *v, int n, int lo, int hi, const char *name) {
+    if (n > 0 && !v) return fail(POTUS_ERR_ARG, "%s is null", name);
+    for (int i = 0; i < n; i++) if (v[i] < lo || v[i] > hi) return fail(POTUS_ERR_ARG, "%s[%d] = %d outside [%d,%d]", name, i + 1, v[i], lo, hi);
+    return 0;
+  };
+  int rc;
+  // declared bounds stan:9-17; state = S+1 is declared legal but indexes out of range at stan:97
+  if ((rc = range(d->state, d->N_state_polls, 1, d->S, "state"))) return rc;
+  if ((rc = range(d->day_state, d->N_state_polls, 1, d->T, "day_state"))) return rc;
+  if ((rc = range(d->day_national, d->N_national_polls, 1, d->T, "day_national"))) return rc;
+  if ((rc = range(d->poll_state, d->N_state_polls, 1, d->P, "poll_state"))) return rc;
+  if ((rc = range(d->poll_national, d->N_national_polls, 1, d->P, "poll_national"))) return rc;
+  if (full) {
+    if ((rc = range(d->poll_mode_state, d->N_state_polls, 1, d->M, "poll_mode_state"))) return rc;
+    if ((rc = range(d->poll_mode_national, d->N_national_polls, 1, d->M, "poll_mode_national"))) return rc;
+    if ((rc = range(d->poll_pop_state, d->N_state_polls, 1, d->Pop, "poll_pop_state"))) return rc;
+    if ((rc = range(d->poll_pop_national, d->N_national_polls, 1, d->Pop, "poll_pop_national"))) return rc;
+    if ((d->N_state_polls && !d->unadjusted_state) || (d->N_national_polls && !d->unadjusted_national)) return fail(POTUS_ERR_ARG, "unadjusted_* is null");
+    for (int i = 0; i < d->N_state_polls; i++) if (!(d->unadjusted_state[i] >= 0 && d->unadjusted_state[i] <= 1)) return fail(POTUS_ERR_ARG, "unadjusted_state outside [0,1]");
+    for (int i = 0; i < d->N_national_polls; i++) if (!(d->unadjusted_national[i] >= 0 && d->unadjusted_national[i] <= 1)) return fail(POTUS_ERR_ARG, "unadjusted_national outside [0,1]");
+  }
+  if ((d->N_state_polls && (!d->n_democrat_state || !d->n_two_share_state)) || (d->N_national_polls && (!d->n_democrat_national || !d->n_two_share_national)))
+    return fail(POTUS_ERR_ARG, "poll counts are null");
+  for (int i = 0; i < d->N_state_polls; i++) if (d->n_democrat_state[i] < 0 || d->n_democrat_state[i] > d->n_two_share_state[i]) return fail(POTUS_ERR_ARG, "n_democrat_state outside [0,N]");
+  for (int i = 0; i < d->N_national_polls; i++) if (d->n_democrat_national[i] < 0 || d->n_democrat_national[i] > d->n_two_share_national[i]) return fail(POTUS_ERR_ARG, "n_democrat_national outside [0,N]");
+  if (!d->mu_b_prior || !d->state_weights || !d->state_covariance_0) return fail(POTUS_ERR_ARG, "null prior/weights/covariance");
+  const int S = d->S;
+  for (int i = 0; i < S; i++) for (int j = 0; j < i; j++) {
+    const double a = d->state_covariance_0[i + (size_t)j * S], b = d->state_covariance_0[j + (size_t)i * S];
+    if (std::fabs(a - b) > 1e-8 * std::max(1.0, std::max(std::fabs(a), std::fabs(b)))) return fail(POTUS_ERR_ARG, "state_covariance_0 is not symmetric");
+  }
+  return 0;
+}
+
+// lower Cholesky factor, column-major (cholesky_decompose, stan:52-54)
+bool chol(const std::vector<double> &A, std::vector<double> &L, int n) {
+  L.assign((size_t)n * n, 0.0);
+  for (int j = 0; j < n; j++) {
+    double s = A[j + (size_t)j * n];
+    for (int k = 0; k < j; k++) s -= L[j + (size_t)k * n] * L[j + (size_t)k * n];
+    if (!(s > 0)) return false;
+    const double ljj = std::sqrt(s);
+    L[j + (size_t)j * n] = ljj;
+    for (int i = j + 1; i < n; i++) {
+      double t = A[i + (size_t)j * n];
+      for (int k = 0; k < j; k++) t -= L[i + (size_t)k * n] * L[j + (size_t)k * n];
+      L[i + (size_t)j * n] = t / ljj;
+    }
+  }
+  return true;
+}
+
+struct Sampler {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  DevModel M{};
+  RunParams R{};
+  potus_opts opts{};
+  Layout L{};
+  double sigma_ns = 0, sigma_nn = 0;
+  std::vector<void *> allocs;
+  size_t lds_bytes = 0;
+  bool inited = false;
+  double last_ms = 0;
+  long long last_leapfrogs = 0;
+  double warm_ms = 0, samp_ms = 0;
+  std::vector<double> LB, LT, LW; // column-major host copies (transformed data)
+};
+
+std::mutex g_mu;
+std::vector<Sampler *> g_handles;
+
+Sampler *get(int h) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (h < 0 || h >= (int)g_handles.size()) return nullptr;
+  return g_handles[h];
+}
+
+template <class T>
+int upload(Sampler *s, const std::vector<T> &v, const T **dst) {
+  void *p = nullptr;
+  const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  HIP_TRY(hipMalloc(&p, bytes));
+  s->allocs.push_back(p);
+  if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dst = static_cast<const T *>(p);
+  return 0;
+}
+
+int build_model(Sampler *sp, const potus_data *d) {
+  const bool full = d->variant == POTUS_VARIANT_FULL;
+  const int S = d->S, T = d->T, Ns = d->N_state_polls, Nn = d->N_national_polls;
+  DevModel &M = sp->M;
+  const Layout &L = sp->L;
+  if (S + 1 > 64) return fail(POTUS_ERR_UNSUPPORTED, "S = %d: this kernel maps states to the 64 lanes of a wave (S <= 63)", S);
+  if (T > PT_NW * PT_CH) return fail(POTUS_ERR_UNSUPPORTED, "T = %d: the LDS-resident kernel handles T <= %d days", T, PT_NW * PT_CH);
+  M.S = S; M.T = T; M.P = d->P; M.M = full ? d->M : 0; M.Pop = full ? d->Pop : 0; M.Ns = Ns; M.Nn = Nn; M.Npoll = Ns + Nn;
+  M.D = L.D; M.full = full;
+  M.SE = S + 1; M.SP = S | 1; M.TP = T | 1;
+  M.o_zT = L.o_zT; M.o_Z = L.o_Z; M.o_c = L.o_c; M.o_m = L.o_m; M.o_pop = L.o_pop; M.o_mue = L.o_mue; M.o_rho = L.o_rho;
+  M.o_ze = L.o_ze; M.o_nn = L.o_nn; M.o_ns = L.o_ns; M.o_zb = L.o_zb; M.nmid = L.o_nn - L.o_c;
+  M.sigma_c = d->sigma_c; M.sigma_m = d->sigma_m; M.sigma_pop = d->sigma_pop; M.sigma_e = d->sigma_e_bias;
+  sp->sigma_ns = d->sigma_measure_noise_state; sp->sigma_nn = d->sigma_measure_noise_national;
+
+  // transformed data (stan:42-55)
+  std::vector<double> w(d->state_weights, d->state_weights + S), cov(d->state_covariance_0, d->state_covariance_0 + (size_t)S * S);
+  double nsd2 = 0;
+  for (int i = 0; i < S; i++) for (int j = 0; j < S; j++) nsd2 += w[i] * cov[i + (size_t)j * S] * w[j];
+  const double nsd = std::sqrt(nsd2);
+  auto scaled_chol = [&](double scale, std::vector<double> &Lout) {
+    std::vector<double> A(cov);
+    const double f = (scale / nsd) * (scale / nsd);
+    for (auto &x : A) x *= f;
+    return chol(A, Lout, S);
+  };
+  if (!scaled_chol(d->polling_bias_scale, sp->LB) || !scaled_chol(d->mu_b_T_scale, sp->LT) || !scaled_chol(d->random_walk_scale, sp->LW))
+    return fail(POTUS_ERR_ARG, "state_covariance_0 is not positive definite");
+  auto at = [&](const std::vector<double> &Lm, int i, int j) { return Lm[i + (size_t)j * S]; };
+
+  std::vector<double> Lw_ext((size_t)M.SE * M.SP, 0.0), LT_t((size_t)S * S), LB_t((size_t)S * S), LTr((size_t)S * S), LBr((size_t)S * S);
+  for (int s = 0; s < S; s++) for (int k = 0; k < S; k++) {
+    Lw_ext[(size_t)s * M.SP + k] = at(sp->LW, s, k);
+    LT_t[(size_t)k * S + s] = at(sp->LT, s, k); LTr[(size_t)s * S + k] = at(sp->LT, s, k);
+    LB_t[(size_t)k * S + s] = at(sp->LB, s, k); LBr[(size_t)s * S + k] = at(sp->LB, s, k);
+  }
+  for (int k = 0; k < S; k++) { double v = 0; for (int s = k; s < S; s++) v += at(sp->LW, s, k) * w[s]; Lw_ext[(size_t)S * M.SP + k] = v; }
+
+  // polls merged and sorted by day (then state); national polls carry the pseudo-state S
+  struct Poll { int s, t, p, m, pop, qidx; double y, n, unadj, sig; };
+  std::vector<Poll> polls;
+  for (int i = 0; i < Ns; i++)
+    polls.push_back({d->state[i] - 1, d->day_state[i] - 1, d->poll_state[i] - 1, full ? d->poll_mode_state[i] - 1 : 0,
+                     full ? d->poll_pop_state[i] - 1 : 0, L.o_ns + i, (double)d->n_democrat_state[i], (double)d->n_two_share_state[i],
+                     full ? d->unadjusted_state[i] : 0.0, d->sigma_measure_noise_state});
+  for (int j = 0; j < Nn; j++)
+    polls.push_back({S, d->day_national[j] - 1, d->poll_national[j] - 1, full ? d->poll_mode_national[j] - 1 : 0,
+                     full ? d->poll_pop_national[j] - 1 : 0, L.o_nn + j, (double)d->n_democrat_national[j],
+                     (double)d->n_two_share_national[j], full ? d->unadjusted_national[j] : 0.0, d->sigma_measure_noise_national});
+  std::stable_sort(polls.begin(), polls.end(), [](const Poll &a, const Poll &b) { return a.t != b.t ? a.t < b.t : a.s < b.s; });
+  const int Np = (int)polls.size();
+  std::vector<int> ps(Np), pt(Np), pp(Np), pm(Np), ppop(Np), pq(Np), day_ptr(T + 1, 0);
+  std::vector<double> py(Np), pn(Np), pu(Np), psig(Np);
+  for (int i = 0; i < Np; i++) {
+    ps[i] = polls[i].s; pt[i] = polls[i].t; pp[i] = polls[i].p; pm[i] = polls[i].m; ppop[i] = polls[i].pop; pq[i] = polls[i].qidx;
+    py[i] = polls[i].y; pn[i] = polls[i].n; pu[i] = polls[i].unadj; psig[i] = polls[i].sig;
+    day_ptr[polls[i].t + 1]++;
+  }
+  for (int t = 0; t < T; t++) day_ptr[t + 1] += day_ptr[t];
+
+  // per-day gather tasks balanced over the 16 waves (longest-processing-time first)
+  std::vector<int> order(T), load(PT_NW, 0);
+  for (int t = 0; t < T; t++) order[t] = t;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return day_ptr[a + 1] - day_ptr[a] > day_ptr[b + 1] - day_ptr[b]; });
+  std::vector<std::vector<int>> wt(PT_NW);
+  for (int t : order) {
+    const int wmin = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+    wt[wmin].push_back(t);
+    load[wmin] += day_ptr[t + 1] - day_ptr[t] + 2;
+  }
+  std::vector<int> wave_task_ptr(PT_NW + 1, 0), task_day;
+  for (int wv = 0; wv < PT_NW; wv++) { for (int t : wt[wv]) task_day.push_back(t); wave_task_ptr[wv + 1] = (int)task_day.size(); }
+
+  // two-level segment sums: level-1 tasks of <= PT_SUBLEN polls, level-2 one thread per segment
+  std::vector<int> sub_ptr{0}, sub_idx, seg_ptr{0}, seg_kind, seg_index;
+  std::vector<double> seg_scale;
+  auto add_group = [&](int nseg, int kind, int index0, double scale, auto key) {
+    std::vector<std::vector<int>> lists(nseg);
+    for (int i = 0; i < Np; i++) { const int k = key(i); if (k >= 0) lists[k].push_back(i); }
+    for (int sgi = 0; sgi < nseg; sgi++) {
+      const auto &l = lists[sgi];
+      for (size_t a = 0; a < l.size(); a += PT_SUBLEN) {
+        for (size_t j = a; j < std::min(l.size(), a + PT_SUBLEN); j++) sub_idx.push_back(l[j]);
+        sub_ptr.push_back((int)sub_idx.size());
+      }
+      seg_ptr.push_back((int)sub_ptr.size() - 1);
+      seg_kind.push_back(kind); seg_index.push_back(index0 + sgi); seg_scale.push_back(scale);
+    }
+  };
+  add_group(d->P, 0, L.o_c, d->sigma_c, [&](int i) { return pp[i]; });
+  if (full) {
+    add_group(d->M, 0, L.o_m, d->sigma_m, [&](int i) { return pm[i]; });
+    add_group(d->Pop, 0, L.o_pop, d->sigma_pop, [&](int i) { return ppop[i]; });
+  }
+  add_group(S + 1, 1, 0, 1.0, [&](int i) { return ps[i]; });
+  M.sub_weighted_begin = (int)sub_ptr.size() - 1;
+  if (full) add_group(T, 2, 0, 1.0, [&](int i) { return pt[i]; });
+  M.nsub = (int)sub_ptr.size() - 1;
+  M.nseg = (int)seg_kind.size();
+  if (!full) M.sub_weighted_begin = M.nsub;
+
+  // LDS layout (doubles)
+  int o = 0;
+  auto take = [&](int n) { const int a = o; o += (n + 1) & ~1; return a; };
+  M.l_C = take(std::max(S * M.TP, 2 * PT_NW * M.SE));
+  M.l_Lw = take(M.SE * M.SP);
+  M.l_X = take(std::max(2 * PT_NW * M.SE, Np));
+  M.l_Y = take(std::max(PT_NW * M.SE, M.nsub));
+  M.l_zT = take(S); M.l_zb = take(S); M.l_mid = take(M.nmid);
+  M.l_bT = take(M.SE); M.l_pb = take(M.SE); M.l_e = take(T); M.l_gs = take(M.SE); M.l_ge = take(T);
+  M.l_scal = take(SC_N); M.l_red = take(PT_NW * PT_NRED);
+  M.lds_doubles = o;
+  sp->lds_bytes = (size_t)o * 8 + sizeof(TS) + 16;
+  if (sp->lds_bytes > 160 * 1024)
+    return fail(POTUS_ERR_UNSUPPORTED, "model needs %zu bytes of LDS per workgroup (> 160 KiB): T=%d, polls=%d", sp->lds_bytes, T, Np);
+
+  int rc;
+  std::vector<double> prior(d->mu_b_prior, d->mu_b_prior + S);
+  if ((rc = upload(sp, Lw_ext, &M.Lw_ext)) || (rc = upload(sp, LT_t, &M.LT_t)) || (rc = upload(sp, LB_t, &M.LB_t)) ||
+      (rc = upload(sp, LTr, &M.LT)) || (rc = upload(sp, LBr, &M.LB)) || (rc = upload(sp, prior, &M.prior)) || (rc = upload(sp, w, &M.w)) ||
+      (rc = upload(sp, ps, &M.ps)) || (rc = upload(sp, pt, &M.pt)) || (rc = upload(sp, pp, &M.pp)) || (rc = upload(sp, pm, &M.pm)) ||
+      (rc = upload(sp, ppop, &M.ppop)) || (rc = upload(sp, pq, &M.pqidx)) || (rc = upload(sp, py, &M.py)) || (rc = upload(sp, pn, &M.pn)) ||
+      (rc = upload(sp, pu, &M.punadj)) || (rc = upload(sp, psig, &M.psig)) || (rc = upload(sp, day_ptr, &M.day_ptr)) ||
+      (rc = upload(sp, wave_task_ptr, &M.wave_task_ptr)) || (rc = upload(sp, task_day, &M.task_day)) ||
+      (rc = upload(sp, sub_ptr, &M.sub_ptr)) || (rc = upload(sp, sub_idx, &M.sub_idx)) || (rc = upload(sp, seg_ptr, &M.seg_ptr)) ||
+      (rc = upload(sp, seg_kind, &M.seg_kind)) || (rc = upload(sp, seg_index, &M.seg_index)) || (rc = upload(sp, seg_scale, &M.seg_scale)))
+    return rc;
+  return 0;
+}
+
+int set_lds_attr(Sampler *sp) {
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_logprob_grad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
+  return 0;
+}
+
+} // namespace
+
+// ======================================================================== C ABI
+extern "C" {
+
+const char *potus_version(void) { return "potus_hmc 0.1 (gfx950)"; }
+
+int potus_last_error(char *buf, int len) {
+  if (buf && len > 0) { std::snprintf(buf, (size_t)len, "%s", g_err.c_str()); }
+  return (int)g_err.size();
+}
+
+void potus_default_opts(potus_opts *o) {
+  std::memset(o, 0, sizeof *o);
+  o->chains = 4; o->chain_id_offset = 0; o->num_warmup = 1000; o->num_samples = 1000; o->max_depth = 10;
+  o->init_buffer = 75; o->term_buffer = 50; o->window = 25;
+  o->delta = 0.8; o->gamma = 0.05; o->kappa = 0.75; o->t0 = 10; o->stepsize = 1.0; o->init_radius = 2.0;
+  o->seed = 1843; o->device = 0; o->save_warmup = 0;
+}
+
+int potus_num_params(const potus_data *d, int *D) {
+  if (!d || !D) return fail(POTUS_ERR_ARG, "null argument");
+  *D = make_layout(d).D;
+  return 0;
+}
+int potus_num_columns(const potus_data *d, int *n_cols) {
+  if (!d || !n_cols) return fail(POTUS_ERR_ARG, "null argument");
+  *n_cols = make_layout(d).ncols;
+  return 0;
+}
+
+int potus_column_name(const potus_data *d, int col, char *buf, int len) {
+  if (!d || !buf || len <= 0) return fail(POTUS_ERR_ARG, "null argument");
+  static const char *samp[] = {"lp__", "accept_stat__", "stepsize__", "treedepth__", "n_leapfrog__", "divergent__", "energy__"};
+  if (col < 0) return fail(POTUS_ERR_ARG, "negative column");
+  if (col < POTUS_N_SAMPLER_COLS) { std::snprintf(buf, (size_t)len, "%s", samp[col]); return 0; }
+  const bool full = d->variant == POTUS_VARIANT_FULL;
+  struct Blk { const char *name; int r, c; }; // r x c column-major; c = 0: vector, r = 0: scalar
+  std::vector<Blk> b = {{"raw_mu_b_T", d->S, 0}, {"raw_mu_b", d->S, d->T}, {"raw_mu_c", d->P, 0}};
+  if (full) { b.push_back({"raw_mu_m", d->M, 0}); b.push_back({"raw_mu_pop", d->Pop, 0}); b.push_back({"mu_e_bias", 0, 0});
+              b.push_back({"rho_e_bias", 0, 0}); b.push_back({"raw_e_bias", d->T, 0}); }
+  b.push_back({"raw_measure_noise_national", d->N_national_polls, 0}); b.push_back({"raw_measure_noise_state", d->N_state_polls, 0});
+  b.push_back({"raw_polling_bias", d->S, 0});
+  b.push_back({"mu_b", d->S, d->T}); b.push_back({"mu_c", d->P, 0});
+  if (full) { b.push_back({"mu_m", d->M, 0}); b.push_back({"mu_pop", d->Pop, 0}); b.push_back({"e_bias", d->T, 0}); }
+  b.push_back({"polling_bias", d->S, 0}); b.push_back({"national_mu_b_average", d->T, 0}); b.push_back({"national_polling_bias_average", 0, 0});
+  if (full) b.push_back({"sigma_rho", 0, 0});
+  b.push_back({"logit_pi_democrat_state", d->N_state_polls, 0}); b.push_back({"logit_pi_democrat_national", d->N_national_polls, 0});
+  b.push_back({"predicted_score", d->T, d->S});
+  int c = col - POTUS_N_SAMPLER_COLS;
+  for (const Blk &k : b) {
+    const int n = k.r == 0 ? 1 : (k.c == 0 ? k.r : k.r * k.c);
+    if (c < n) {
+      if (k.r == 0) std::snprintf(buf, (size_t)len, "%s", k.name);
+      else if (k.c == 0) std::snprintf(buf, (size_t)len, "%s.%d", k.name, c + 1);
+      else std::snprintf(buf, (size_t)len, "%s.%d.%d", k.name, c % k.r + 1, c / k.r + 1);
+      return 0;
+    }
+    c -= n;
+  }
+  return fail(POTUS_ERR_ARG, "column %d out of range", col);
+}
+
+int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
+  if (!o || !handle) return fail(POTUS_ERR_ARG, "null argument");
+  int rc = validate(d);
+  if (rc) return rc;
+  if (o->chains < 1) return fail(POTUS_ERR_ARG, "chains must be >= 1");
+  if (o->max_depth < 1 || o->max_depth > PT_MAXD) return fail(POTUS_ERR_ARG, "max_depth must be in [1,%d]", PT_MAXD);
+  if (o->num_warmup < 0 || o->num_samples < 0) return fail(POTUS_ERR_ARG, "negative iteration counts");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(POTUS_ERR_DEVICE, "no HIP device: libpotus_hmc needs an MI355X (gfx950)");
+  if (o->device < 0 || o->device >= ndev) return fail(POTUS_ERR_DEVICE, "device %d out of range (have %d)", o->device, ndev);
+  HIP_TRY(hipSetDevice(o->device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, o->device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(POTUS_ERR_DEVICE, "device is %s; this library is built for gfx950 only", prop.gcnArchName);
+
+  Sampler *sp = new Sampler();
+  sp->device = o->device; sp->opts = *o; sp->L = make_layout(d);
+  auto bail = [&](int code) { for (void *p : sp->allocs) (void)hipFree(p); delete sp; return code; };
+  if ((rc = build_model(sp, d))) return bail(rc);
+  if ((rc = set_lds_attr(sp))) return bail(rc);
+  if (hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&sp->ev0) != hipSuccess ||
+      hipEventCreate(&sp->ev1) != hipSuccess)
+    return bail(fail(POTUS_ERR_DEVICE, "stream/event creation failed"));
+
+  RunParams &R = sp->R;
+  R.chains = o->chains; R.chain_id_offset = o->chain_id_offset; R.num_warmup = o->num_warmup; R.num_samples = o->num_samples;
+  R.max_depth = o->max_depth; R.save_warmup = o->save_warmup;
+  // windowed_adaptation::set_window_params
+  int ib = o->init_buffer, tb = o->term_buffer, bw = o->window;
+  if (o->num_warmup >= 20 && ib + bw + tb > o->num_warmup) { ib = (int)(0.15 * o->num_warmup); tb = (int)(0.1 * o->num_warmup); bw = o->num_warmup - (ib + tb); }
+  R.init_buffer = ib; R.term_buffer = tb; R.window = bw;
+  R.delta = o->delta; R.gamma = o->gamma; R.kappa = o->kappa; R.t0 = o->t0; R.stepsize = o->stepsize; R.init_radius = o->init_radius;
+  R.seed_lo = (unsigned)(o->seed & 0xFFFFFFFFu); R.seed_hi = (unsigned)(o->seed >> 32);
+  R.Dpad = (sp->L.D + 7) & ~7;
+  R.row = POTUS_N_SAMPLER_COLS + sp->L.D;
+  R.n_save_max = o->num_samples + (o->save_warmup ? o->num_warmup : 0);
+  void *p = nullptr;
+  const size_t state_bytes = (size_t)o->chains * V_COUNT * R.Dpad * sizeof(double);
+  if (hipMalloc(&p, state_bytes) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc(%zu) for chain state failed", state_bytes));
+  sp->allocs.push_back(p); R.state = (double *)p;
+  (void)hipMemset(p, 0, state_bytes);
+  if (hipMalloc(&p, sizeof(ChainScalars) * o->chains) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for chain scalars failed"));
+  sp->allocs.push_back(p); R.scal = (ChainScalars *)p;
+  (void)hipMemset(p, 0, sizeof(ChainScalars) * o->chains);
+  const size_t draw_bytes = std::max<size_t>((size_t)o->chains * R.n_save_max * R.row, 1) * sizeof(double);
+  if (hipMalloc(&p, draw_bytes) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc(%zu) for draws failed", draw_bytes));
+  sp->allocs.push_back(p); R.draws = (double *)p;
+  (void)hipMemset(p, 0, draw_bytes);
+
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_handles.push_back(sp);
+  *handle = (int)g_handles.size() - 1;
+  return 0;
+}
+
+int potus_destroy(int handle) {
+  Sampler *sp = get(handle);
+  if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
+  (void)hipSetDevice(sp->device);
+  (void)hipStreamSynchronize(sp->stream);
+  for (void *p : sp->allocs) (void)hipFree(p);
+  (void)hipEventDestroy(sp->ev0); (void)hipEventDestroy(sp->ev1); (void)hipStreamDestroy(sp->stream);
+  { std::lock_guard<std::mutex> lk(g_mu); g_handles[handle] = nullptr; }
+  delete sp;
+  return 0;
+}
+
+int potus_log_prob_grad(int handle, const double *q, int n, double *lp, double *grad) {
+  Sampler *sp = get(handle);
+  if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
+  if (n < 0 || (n > 0 && (!q || !lp || !grad))) return fail(POTUS_ERR_ARG, "null argument");
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(sp->device));
+  const size_t D = sp->L.D;
+  double *dq = nullptr, *dlp = nullptr, *dg = nullptr;
+  HIP_TRY(hipMalloc((void **)&dq, n * D * 8)); HIP_TRY(hipMalloc((void **)&dg, n * D * 8)); HIP_TRY(hipMalloc((void **)&dlp, (size_t)n * 8));
+  HIP_TRY(hipMemcpyAsync(dq, q, n * D * 8, hipMemcpyHostToDevice, sp->stream));
+  const int grid = std::min(n, 1024);
+  hipLaunchKernelGGL(k_logprob_grad, dim3(grid), dim3(PT_THREADS), sp->lds_bytes, sp->stream, sp->M, dq, dlp, dg, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(lp, dlp, (size_t)n * 8, hipMemcpyDeviceToHost, sp->stream));
+  HIP_TRY(hipMemcpyAsync(grad, dg, n * D * 8, hipMemcpyDeviceToHost, sp->stream));
+  HIP_TRY(hipStreamSynchronize(sp->stream));
+  (void)hipFree(dq); (void)hipFree(dg); (void)hipFree(dlp);
+  return 0;
+}
+
+int potus_init(int handle, const double *q0) {
+  Sampler *sp = get(handle);
+  if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
+  HIP_TRY(hipSetDevice(sp->device));
+  double *dq0 = nullptr;
+  const size_t bytes = (size_t)sp->R.chains * sp->L.D * 8;
+  if (q0) { HIP_TRY(hipMalloc((void **)&dq0, bytes)); HIP_TRY(hipMemcpyAsync(dq0, q0, bytes, hipMemcpyHostToDevice, sp->stream)); }
+  hipLaunchKernelGGL(k_init, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, sp->M, sp->R, (const double *)dq0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(sp->stream));
+  if (dq0) (void)hipFree(dq0);
+  std::vector<ChainScalars> sc(sp->R.chains);
+  HIP_TRY(hipMemcpy(sc.data(), sp->R.scal, sizeof(ChainScalars) * sc.size(), hipMemcpyDeviceToHost));
+  for (int c = 0; c < sp->R.chains; c++)
+    if (sc[c].status == POTUS_ERR_INIT) return fail(POTUS_ERR_INIT, "chain %d: no finite initial log density/gradient after 100 attempts", c + 1);
+  sp->inited = true;
+  return 0;
+}
+
+int potus_run(int handle, int n_iter) {
+  Sampler *sp = get(handle);
+  if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
+  if (!sp->inited) return fail(POTUS_ERR_STATE, "potus_init must be called before potus_run");
+  if (n_iter <= 0) return 0;
+  HIP_TRY(hipSetDevice(sp->device));
+  long long before = 0, after = 0;
+  potus_total_leapfrogs(handle, &before);
+  int it0 = 0; potus_iterations_done(handle, &it0);
+  HIP_TRY(hipEventRecord(sp->ev0, sp->stream));
+  hipLaunchKernelGGL(k_run, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, sp->M, sp->R, n_iter);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(sp->ev1, sp->stream));
+  HIP_TRY(hipStreamSynchronize(sp->stream));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, sp->ev0, sp->ev1));
+  potus_total_leapfrogs(handle, &after);
+  sp->last_ms = ms; sp->last_leapfrogs = after - before;
+  int it1 = 0; potus_iterations_done(handle, &it1);
+  // split elapsed time between warm-up and sampling in proportion to iterations (for the CSV footer)
+  const int nw = sp->R.num_warmup;
+  const int w_it = std::max(0, std::min(it1, nw) - std::min(it0, nw)), tot = std::max(1, it1 - it0);
+  sp->warm_ms += ms * w_it / tot; sp->samp_ms += ms * (tot - w_it) / tot;
+  return 0;
+}
+
+int potus_iterations_done(int handle, int *n) {
+  Sampler *sp = get(handle);
+  if (!sp || !n) return fail(POTUS_ERR_STATE, "bad handle");
+  HIP_TRY(hipSetDevice(sp->device));
+  std::vector<ChainScalars> sc(sp->R.chains);
+  HIP_TRY(hipMemcpy(sc.data(), sp->R.scal, sizeof(ChainScalars) * sc.size(), hipMemcpyDeviceToHost));
+  int m = sc[0].iter;
+  for (auto &s : sc) m = std::min(m, s.iter);
+  *n = m;
+  return 0;
+}
+
+int potus_total_leapfrogs(int handle, long long *n) {
+  Sampler *sp = get(handle);
+  if (!sp || !n) return fail(POTUS_ERR_STATE, "bad handle");
+  HIP_TRY(hipSetDevice(sp->device));
+  std::vector<ChainScalars> sc(sp->R.chains);
+  HIP_TRY(hipMemcpy(sc.data(), sp->R.scal, sizeof(ChainScalars) * sc.size(), hipMemcpyDeviceToHost));
+  long long t = 0;
+  for (auto &s : sc) t += s.total_leapfrogs;
+  *n = t;
+  return 0;
+}
+
+int potus_chain_status(int handle, int *status, int *n_divergent) {
+  Sampler *sp = get(handle);
+  if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
+  HIP_TRY(hipSetDevice(sp->device));
+  std::vector<ChainScalars> sc(sp->R.chains);
+  HIP_TRY(hipMemcpy(sc.data(), sp->R.scal, sizeof(ChainScalars) * sc.size(), hipMemcpyDeviceToHost));
+  for (int c = 0; c < sp->R.chains; c++) { if (status) status[c] = sc[c].status; if (n_divergent) n_divergent[c] = sc[c].n_divergent; }
+  return 0;
+}
+
+int potus_get_adaptation(int handle, double *stepsize, double *inv_metric) {
+  Sampler *sp = get(handle);
+  if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
+  HIP_TRY(hipSetDevice(sp->device));
+  std::vector<ChainScalars> sc(sp->R.chains);
+  HIP_TRY(hipMemcpy(sc.data(), sp->R.scal, sizeof(ChainScalars) * sc.size(), hipMemcpyDeviceToHost));
+  for (int c = 0; c < sp->R.chains; c++) {
+    if (stepsize) stepsize[c] = sc[c].nom_eps;
+    if (inv_metric)
+      HIP_TRY(hipMemcpy(inv_metric + (size_t)c * sp->L.D, sp->R.state + ((size_t)c * V_COUNT + V_MINV) * sp->R.Dpad, (size_t)sp->L.D * 8, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+static int saved_count(Sampler *sp, int *n_saved) {
+  std::vector<ChainScalars> sc(sp->R.chains);
+  HIP_TRY(hipMemcpy(sc.data(), sp->R.scal, sizeof(ChainScalars) * sc.size(), hipMemcpyDeviceToHost));
+  int m = sc[0].saved;
+  for (auto &s : sc) m = std::min(m, s.saved);
+  *n_saved = m;
+  return 0;
+}
+
+int potus_get_draws(int handle, double *out, int *n_saved) {
+  Sampler *sp = get(handle);
+  if (!sp || !n_saved) return fail(POTUS_ERR_STATE, "bad handle");
+  HIP_TRY(hipSetDevice(sp->device));
+  int rc = saved_count(sp, n_saved);
+  if (rc) return rc;
+  if (out) {
+    for (int c = 0; c < sp->R.chains; c++)
+      HIP_TRY(hipMemcpy(out + (size_t)c * *n_saved * sp->R.row, sp->R.draws + (size_t)c * sp->R.n_save_max * sp->R.row,
+                        (size_t)*n_saved * sp->R.row * 8, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+int potus_draws_device_ptr(int handle, void **dptr, long long *n_doubles) {
+  Sampler *sp = get(handle);
+  if (!sp || !dptr) return fail(POTUS_ERR_STATE, "bad handle");
+  *dptr = sp->R.draws;
+  if (n_doubles) *n_doubles = (long long)sp->R.chains * sp->R.n_save_max * sp->R.row;
+  return 0;
+}
+
+static int write_array_range(Sampler *sp, int n_saved, int col_begin, int col_end, double *out) {
+  const int nsel = col_end - col_begin;
+  const int ndraw = n_saved * sp->R.chains;
+  if (ndraw == 0) return 0;
+  const int grid = std::min(ndraw, 512);
+  double *scratch = nullptr, *dout = nullptr;
+  HIP_TRY(hipMalloc((void **)&scratch, (size_t)grid * sp->L.ncols * 8));
+  HIP_TRY(hipMalloc((void **)&dout, (size_t)ndraw * nsel * 8));
+  WAParams W{sp->R.draws, sp->R.chains, sp->R.n_save_max, n_saved, sp->R.row, sp->L.ncols, col_begin, col_end, scratch, dout, sp->sigma_ns, sp->sigma_nn};
+  hipLaunchKernelGGL(k_write_array, dim3(grid), dim3(256), 0, sp->stream, sp->M, W);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, dout, (size_t)ndraw * nsel * 8, hipMemcpyDeviceToHost, sp->stream));
+  HIP_TRY(hipStreamSynchronize(sp->stream));
+  (void)hipFree(scratch); (void)hipFree(dout);
+  return 0;
+}
+
+int potus_write_array(int handle, int col_begin, int col_end, double *out) {
+  Sampler *sp = get(handle);
+  if (!sp || !out) return fail(POTUS_ERR_STATE, "bad handle or null output");
+  if (col_begin < 0 || col_end > sp->L.ncols || col_begin >= col_end) return fail(POTUS_ERR_ARG, "bad column range [%d,%d) of %d", col_begin, col_end, sp->L.ncols);
+  HIP_TRY(hipSetDevice(sp->device));
+  int n_saved = 0, rc = saved_count(sp, &n_saved);
+  if (rc) return rc;
+  return write_array_range(sp, n_saved, col_begin, col_end, out);
+}
+
+int potus_last_run_timing(int handle, double *ms, long long *leapfrogs) {
+  Sampler *sp = get(handle);
+  if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
+  if (ms) *ms = sp->last_ms;
+  if (leapfrogs) *leapfrogs = sp->last_leapfrogs;
+  return 0;
+}
+
+// CmdStan-format CSV, one file per chain (what rstan::read_stan_csv consumes, final_2016.R:543)
+int potus_write_stan_csv(int handle, const char *dir, const char *basename) {
+  Sampler *sp = get(handle);
+  if (!sp || !dir || !basename) return fail(POTUS_ERR_STATE, "bad handle or null path");
+  HIP_TRY(hipSetDevice(sp->device));
+  int n_saved = 0, rc = saved_count(sp, &n_saved);
+  if (rc) return rc;
+  const int chains = sp->R.chains, ncols = sp->L.ncols, D = sp->L.D;
+  std::vector<double> eps(chains), minv((size_t)chains * D);
+  if ((rc = potus_get_adaptation(handle, eps.data(), minv.data()))) return rc;
+  // reconstruct a potus_data shell for the column names
+  potus_data dd{}; dd.S = sp->M.S; dd.T = sp->M.T; dd.P = sp->M.P; dd.M = sp->M.M; dd.Pop = sp->M.Pop;
+  dd.N_state_polls = sp->M.Ns; dd.N_national_polls = sp->M.Nn; dd.variant = sp->M.full ? POTUS_VARIANT_FULL : POTUS_VARIANT_NO_MODE;
+  std::vector<FILE *> fp(chains, nullptr);
+  auto close_all = [&]() { for (FILE *f : fp) if (f) fclose(f); };
+  for (int c = 0; c < chains; c++) {
+    const std::string path = std::string(dir) + "/" + basename + "-" + std::to_string(sp->R.chain_id_offset + c + 1) + ".csv";
+    fp[c] = fopen(path.c_str(), "w");
+    if (!fp[c]) { close_all(); return fail(POTUS_ERR_IO, "cannot open %s", path.c_str()); }
+    FILE *f = fp[c];
+    const potus_opts &o = sp->opts;
+    fprintf(f, "# stan_version_major = 2\n# stan_version_minor = 24\n# stan_version_patch = 1\n");
+    fprintf(f, "# model = %s\n", sp->M.full ? "poll_model_2020_model" : "poll_model_2020_no_mode_adjustment_model");
+    fprintf(f, "# method = sample (Default)\n#   sample\n#     num_samples = %d\n#     num_warmup = %d\n#     save_warmup = %d\n#     thin = 1 (Default)\n",
+            o.num_samples, o.num_warmup, o.save_warmup);
+    fprintf(f, "#     adapt\n#       engaged = 1 (Default)\n#       gamma = %g\n#       delta = %g\n#       kappa = %g\n#       t0 = %g\n#       init_buffer = %d\n#       term_buffer = %d\n#       window = %d\n",
+            o.gamma, o.delta, o.kappa, o.t0, sp->R.init_buffer, sp->R.term_buffer, sp->R.window);
+    fprintf(f, "#     algorithm = hmc (Default)\n#       hmc\n#         engine = nuts (Default)\n#           nuts\n#             max_depth = %d\n#         metric = diag_e (Default)\n#         metric_file =  (Default)\n#         stepsize = %g\n#         stepsize_jitter = 0 (Default)\n",
+            o.max_depth, o.stepsize);
+    fprintf(f, "# id = %d\n# data\n#   file = (in-memory)\n# init = %g\n# random\n#   seed = %llu\n# output\n#   file = %s\n#   diagnostic_file =  (Default)\n#   refresh = 100 (Default)\n",
+            sp->R.chain_id_offset + c + 1, o.init_radius, (unsigned long long)o.seed, path.c_str());
+    char name[96];
+    for (int k = 0; k < ncols; k++) { potus_column_name(&dd, k, name, sizeof name); fprintf(f, k ? ",%s" : "%s", name); }
+    fprintf(f, "\n# Adaptation terminated\n# Step size = %.6g\n# Diagonal elements of inverse mass matrix:\n# ", eps[c]);
+    for (int i = 0; i < D; i++) fprintf(f, i ? ", %.6g" : "%.6g", minv[(size_t)c * D + i]);
+    fprintf(f, "\n");
+  }
+  // stream the rows in blocks of draws: rows come back as [iter][chain][ncols]
+  const int blk = 32;
+  std::vector<double> rows((size_t)blk * chains * ncols);
+  Sampler view = *sp; // shallow copy to address a sub-range of iterations
+  for (int i0 = 0; i0 < n_saved; i0 += blk) {
+    const int nb = std::min(blk, n_saved - i0);
+    view.R.draws = sp->R.draws + (size_t)i0 * sp->R.row;
+    if ((rc = write_array_range(&view, nb, 0, ncols, rows.data()))) { close_all(); return rc; }
+    for (int i = 0; i < nb; i++)
+      for (int c = 0; c < chains; c++) {
+        const double *r = rows.data() + ((size_t)i * chains + c) * ncols;
+        FILE *f = fp[c];
+        for (int k = 0; k < ncols; k++) fprintf(f, k ? ",%.6g" : "%.6g", r[k]);
+        fputc('\n', f);
+      }
+  }
+  for (int c = 0; c < chains; c++)
+    fprintf(fp[c], "# \n#  Elapsed Time: %.3f seconds (Warm-up)\n#                %.3f seconds (Sampling)\n#                %.3f seconds (Total)\n# \n",
+            sp->warm_ms * 1e-3, sp->samp_ms * 1e-3, (sp->warm_ms + sp->samp_ms) * 1e-3);
+  close_all();
+  return 0;
+}
+
+// ---------------------------------------------------------------- .C() wrappers
+void potus_R_create(int *dims, int *state, int *day_state, int *day_national, int *poll_state, int *poll_national,
+                    int *poll_mode_state, int *poll_mode_national, int *poll_pop_state, int *poll_pop_national,
+                    int *n_democrat_national, int *n_two_share_national, int *n_democrat_state, int *n_two_share_state,
+                    double *unadjusted_national, double *unadjusted_state, double *mu_b_prior, double *state_weights,
+                    double *scalars, double *state_covariance_0, int *iopts, double *dopts, int *handle, int *status) {
+  potus_data d{};
+  d.N_national_polls = dims[0]; d.N_state_polls = dims[1]; d.T = dims[2]; d.S = dims[3]; d.P = dims[4]; d.M = dims[5]; d.Pop = dims[6];
+  d.variant = dims[7];
+  d.state = state; d.day_state = day_state; d.day_national = day_national; d.poll_state = poll_state; d.poll_national = poll_national;
+  d.poll_mode_state = poll_mode_state; d.poll_mode_national = poll_mode_national; d.poll_pop_state = poll_pop_state;
+  d.poll_pop_national = poll_pop_national; d.n_democrat_national = n_democrat_national; d.n_two_share_national = n_two_share_national;
+  d.n_democrat_state = n_democrat_state; d.n_two_share_state = n_two_share_state; d.unadjusted_national = unadjusted_national;
+  d.unadjusted_state = unadjusted_state; d.mu_b_prior = mu_b_prior; d.state_weights = state_weights;
+  d.sigma_c = scalars[0]; d.sigma_m = scalars[1]; d.sigma_pop = scalars[2]; d.sigma_measure_noise_national = scalars[3];
+  d.sigma_measure_noise_state = scalars[4]; d.sigma_e_bias = scalars[5]; d.random_walk_scale = scalars[6]; d.mu_b_T_scale = scalars[7];
+  d.polling_bias_scale = scalars[8]; d.state_covariance_0 = state_covariance_0;
+  potus_opts o; potus_default_opts(&o);
+  o.chains = iopts[0]; o.chain_id_offset = iopts[1]; o.num_warmup = iopts[2]; o.num_samples = iopts[3]; o.max_depth = iopts[4];
+  o.device = iopts[5]; o.save_warmup = iopts[6]; o.seed = (uint64_t)(unsigned)iopts[7];
+  o.delta = dopts[0]; o.gamma = dopts[1]; o.kappa = dopts[2]; o.t0 = dopts[3]; o.stepsize = dopts[4]; o.init_radius = dopts[5];
+  *status = potus_create(&d, &o, handle);
+}
+void potus_R_init(int *handle, int *status) { *status = potus_init(*handle, nullptr); }
+void potus_R_run(int *handle, int *n_iter, int *status) { *status = potus_run(*handle, *n_iter); }
+void potus_R_num_columns(int *handle, int *D, int *n_cols, int *status) {
+  Sampler *sp = get(*handle);
+  if (!sp) { *status = fail(POTUS_ERR_STATE, "bad handle"); return; }
+  *D = sp->L.D; *n_cols = sp->L.ncols; *status = 0;
+}
+void potus_R_write_array(int *handle, int *col_begin, int *col_end, double *out, int *status) { *status = potus_write_array(*handle, *col_begin, *col_end, out); }
+void potus_R_write_stan_csv(int *handle, char **dir, char **basename, int *status) { *status = potus_write_stan_csv(*handle, dir[0], basename[0]); }
+void potus_R_last_error(char **buf, int *len) { potus_last_error(buf[0], *len); }
+void potus_R_destroy(int *handle, int *status) { *status = potus_destroy(*handle); }
+
+} // extern "C"

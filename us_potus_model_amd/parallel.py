@@ -1,0 +1,94 @@
+"""Chains over GPUs: one process per GPU, no communication while sampling, one all-gather.
+
+The reference runs each chain as an independent CmdStan process (`parallel_chains`,
+scripts/model/final_2016.R:536); nothing is exchanged between chains.  Here rank r of a
+`torch.distributed` job owns a contiguous block of chains; the RNG stream of a chain is keyed by
+its GLOBAL id (chain_id_offset), so the draws do not depend on the number of GPUs.  The only
+collective is the all-gather that pools the draws-of-interest for R-hat / ESS (RCCL over xGMI
+when the backend is "nccl", gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def chain_block(total_chains: int, rank: int, world: int):
+    """Contiguous split; returns (chain_id_offset, n_local). Ranks beyond total_chains get 0."""
+    base, rem = divmod(total_chains, world)
+    n = base + (1 if rank < rem else 0)
+    off = rank * base + min(rank, rem)
+    return off, n
+
+
+def init_process_group(backend: str | None = None):
+    import torch
+    import torch.distributed as dist
+    rank, world, local = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def all_gather_draws(local: np.ndarray, total_chains: int, device=None) -> np.ndarray:
+    """Pool [n_local_chains, n_draws, k] arrays from every rank into [total_chains, n_draws, k].
+
+    Ranks may own different chain counts: shards are padded to the maximum before the
+    (equal-size) all_gather and trimmed afterwards.
+    """
+    import torch
+    import torch.distributed as dist
+    rank, world, _ = env_rank_world()
+    if world == 1 or not dist.is_initialized():
+        return local
+    n_max = -(-total_chains // world)
+    shape = (n_max,) + tuple(local.shape[1:])
+    buf = torch.zeros(shape, dtype=torch.float64, device=device)
+    if local.shape[0]:
+        buf[: local.shape[0]] = torch.as_tensor(local, dtype=torch.float64, device=device)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    parts = []
+    for r in range(world):
+        _, n = chain_block(total_chains, r, world)
+        parts.append(out[r][:n].cpu().numpy())
+    return np.concatenate(parts, axis=0)
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(x: float, device=None) -> float:
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(x: float, device=None) -> float:
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

@@ -1,0 +1,304 @@
+"""Host-side mirror of the reference's sampler call surface, over libpotus_hmc.so.
+
+The reference drives CmdStan from R (R is not available in this image, so the host side
+above the C ABI is Python; R/potus_sampling.R is the same thin shim for R users):
+
+    model <- cmdstanr::cmdstan_model("scripts/model/poll_model_2020.stan")   # final_2016.R:532
+    fit   <- model$sample(data=, seed=1843, parallel_chains=, chains=,
+                          iter_warmup=, iter_sampling=, refresh=)            # final_2016.R:533-541
+    out   <- rstan::read_stan_csv(fit$output_files())                        # final_2016.R:543
+    rstan::extract(out, pars = "mu_b")[[1]]                                  # final_2016.R:556,...
+
+becomes
+
+    model = PotusModel("full")                       # or "no_mode_adjustment" (final_2012.R:558)
+    fit   = model.sample(data=, seed=1843, chains=, iter_warmup=, iter_sampling=, refresh=)
+    fit.extract("mu_b")                              # [draws, S, T], chains merged
+
+`sampling()` is the rstan::sampling() spelling (iter includes warmup; final_2016.R:525-529).
+There is no CPU fallback: without the HIP library and an MI355X every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+from . import _abi
+
+_LIB = None
+_HERE = Path(__file__).resolve().parent
+
+
+class PotusError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _HERE / "libpotus_hmc.so"
+
+
+def load_library():
+    """dlopen libpotus_hmc.so (built in-tree by __graft_entry__.build()). Fails loudly."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not p.exists():
+        raise PotusError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(str(p))
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    L.potus_version.restype = C.c_char_p
+    L.potus_last_error.argtypes = [C.c_char_p, C.c_int]
+    L.potus_default_opts.argtypes = [C.POINTER(_abi.PotusOpts)]
+    L.potus_num_params.argtypes = [C.POINTER(_abi.PotusData), ip]
+    L.potus_num_columns.argtypes = [C.POINTER(_abi.PotusData), ip]
+    L.potus_column_name.argtypes = [C.POINTER(_abi.PotusData), C.c_int, C.c_char_p, C.c_int]
+    L.potus_create.argtypes = [C.POINTER(_abi.PotusData), C.POINTER(_abi.PotusOpts), ip]
+    L.potus_destroy.argtypes = [C.c_int]
+    L.potus_log_prob_grad.argtypes = [C.c_int, dp, C.c_int, dp, dp]
+    L.potus_init.argtypes = [C.c_int, dp]
+    L.potus_run.argtypes = [C.c_int, C.c_int]
+    L.potus_iterations_done.argtypes = [C.c_int, ip]
+    L.potus_total_leapfrogs.argtypes = [C.c_int, C.POINTER(C.c_longlong)]
+    L.potus_chain_status.argtypes = [C.c_int, ip, ip]
+    L.potus_get_adaptation.argtypes = [C.c_int, dp, dp]
+    L.potus_get_draws.argtypes = [C.c_int, dp, ip]
+    L.potus_draws_device_ptr.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]
+    L.potus_write_array.argtypes = [C.c_int, C.c_int, C.c_int, dp]
+    L.potus_write_stan_csv.argtypes = [C.c_int, C.c_char_p, C.c_char_p]
+    L.potus_last_run_timing.argtypes = [C.c_int, dp, C.POINTER(C.c_longlong)]
+    _LIB = L
+    return L
+
+
+EXPORTS = [
+    "potus_version", "potus_last_error", "potus_default_opts", "potus_num_params", "potus_num_columns",
+    "potus_column_name", "potus_create", "potus_destroy", "potus_log_prob_grad", "potus_init", "potus_run",
+    "potus_iterations_done", "potus_total_leapfrogs", "potus_chain_status", "potus_get_adaptation",
+    "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_stan_csv",
+    "potus_last_run_timing", "potus_R_create", "potus_R_init", "potus_R_run", "potus_R_num_columns",
+    "potus_R_write_array", "potus_R_write_stan_csv", "potus_R_last_error", "potus_R_destroy",
+]
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _check(L, rc):
+    if rc != 0:
+        buf = C.create_string_buffer(512)
+        L.potus_last_error(buf, 512)
+        raise PotusError(f"libpotus_hmc error {rc}: {buf.value.decode()}")
+
+
+class Handle:
+    """One sampler instance on one GPU (a set of chains)."""
+
+    def __init__(self, data: dict, variant="full", **opts):
+        self.L = load_library()
+        self.data = data
+        self.variant = variant
+        self._d, self._keep = _abi.make_data(data, variant)
+        o = _abi.PotusOpts()
+        self.L.potus_default_opts(C.byref(o))
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown sampler option {k!r}")
+            setattr(o, k, v)
+        self.opts = o
+        h = C.c_int(-1)
+        _check(self.L, self.L.potus_create(C.byref(self._d), C.byref(o), C.byref(h)))
+        self.h = h.value
+        D, nc = C.c_int(), C.c_int()
+        _check(self.L, self.L.potus_num_params(C.byref(self._d), C.byref(D)))
+        _check(self.L, self.L.potus_num_columns(C.byref(self._d), C.byref(nc)))
+        self.D, self.n_cols = D.value, nc.value
+        self.layout, ncols2 = _abi.column_layout(data, variant)
+        assert ncols2 == self.n_cols
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h >= 0:
+            self.L.potus_destroy(self.h)
+            self.h = -1
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def log_prob_grad(self, q):
+        q = np.ascontiguousarray(np.atleast_2d(q), dtype=np.float64)
+        n = q.shape[0]
+        assert q.shape[1] == self.D
+        lp, g = np.zeros(n), np.zeros((n, self.D))
+        _check(self.L, self.L.potus_log_prob_grad(self.h, _dp(q), n, _dp(lp), _dp(g)))
+        return lp, g
+
+    def init(self, q0=None):
+        p = None
+        if q0 is not None:
+            q0 = np.ascontiguousarray(q0, dtype=np.float64).reshape(self.opts.chains, self.D)
+            p = _dp(q0)
+        _check(self.L, self.L.potus_init(self.h, p))
+
+    def run(self, n_iter):
+        _check(self.L, self.L.potus_run(self.h, int(n_iter)))
+
+    def iterations_done(self):
+        n = C.c_int()
+        _check(self.L, self.L.potus_iterations_done(self.h, C.byref(n)))
+        return n.value
+
+    def total_leapfrogs(self):
+        n = C.c_longlong()
+        _check(self.L, self.L.potus_total_leapfrogs(self.h, C.byref(n)))
+        return n.value
+
+    def last_run_timing(self):
+        ms, n = C.c_double(), C.c_longlong()
+        _check(self.L, self.L.potus_last_run_timing(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def chain_status(self):
+        ch = self.opts.chains
+        st, dv = (C.c_int * ch)(), (C.c_int * ch)()
+        _check(self.L, self.L.potus_chain_status(self.h, st, dv))
+        return list(st), list(dv)
+
+    def adaptation(self):
+        ch = self.opts.chains
+        eps, minv = np.zeros(ch), np.zeros((ch, self.D))
+        _check(self.L, self.L.potus_get_adaptation(self.h, _dp(eps), _dp(minv)))
+        return eps, minv
+
+    def draws(self):
+        """[chains, n_saved, 7 + D] on the unconstrained scale."""
+        n = C.c_int()
+        _check(self.L, self.L.potus_get_draws(self.h, None, C.byref(n)))
+        out = np.zeros((self.opts.chains, n.value, _abi.N_SAMPLER_COLS + self.D))
+        if n.value:
+            _check(self.L, self.L.potus_get_draws(self.h, _dp(out), C.byref(n)))
+        return out
+
+    def draws_device_ptr(self):
+        p, n = C.c_void_p(), C.c_longlong()
+        _check(self.L, self.L.potus_draws_device_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def write_array(self, col_begin, col_end, n_saved):
+        out = np.zeros((n_saved, self.opts.chains, col_end - col_begin))
+        if n_saved:
+            _check(self.L, self.L.potus_write_array(self.h, col_begin, col_end, _dp(out)))
+        return out
+
+    def write_stan_csv(self, directory, basename="poll_model_2020"):
+        os.makedirs(directory, exist_ok=True)
+        _check(self.L, self.L.potus_write_stan_csv(self.h, str(directory).encode(), basename.encode()))
+        off = self.opts.chain_id_offset
+        return [str(Path(directory) / f"{basename}-{off + c + 1}.csv") for c in range(self.opts.chains)]
+
+
+class StanFit:
+    """What the scripts use of rstan's stanfit: extract(pars), model_name, sampler params."""
+
+    def __init__(self, handle: Handle, model_name: str):
+        self._h = handle
+        self.model_name = model_name  # out@model_name, final_2016.R:825
+        self._draws = handle.draws()
+        self.n_saved = self._draws.shape[1]
+        self.chains = self._draws.shape[0]
+
+    def sampler_params(self):
+        """dict of [chains, draws] arrays: lp__, accept_stat__, ... (rstan::get_sampler_params)."""
+        return {n: self._draws[:, :, i] for i, n in enumerate(_abi.SAMPLER_COLS)}
+
+    def unconstrained(self):
+        return self._draws[:, :, _abi.N_SAMPLER_COLS:]
+
+    def extract(self, pars, permuted=False):
+        """rstan::extract(out, pars=)[[1]]: array [draws, ...dims], chains merged.
+
+        rstan additionally permutes the merged draws at random; the summaries the scripts
+        take (means, quantiles, P(>0.5): final_2016.R:708-762) are permutation invariant, so
+        the default keeps chain-major order.
+        """
+        single = isinstance(pars, str)
+        names = [pars] if single else list(pars)
+        out = {}
+        for name in names:
+            if name in _abi.SAMPLER_COLS:
+                out[name] = self._draws[:, :, _abi.SAMPLER_COLS.index(name)].reshape(-1)
+                continue
+            if name not in self._h.layout:
+                raise KeyError(f"unknown parameter {name!r}")
+            a, b, dims = self._h.layout[name]
+            arr = self._h.write_array(a, b, self.n_saved)            # [iter, chain, n]
+            arr = np.transpose(arr, (1, 0, 2)).reshape(self.chains * self.n_saved, b - a)
+            if dims:
+                arr = arr.reshape((arr.shape[0],) + tuple(reversed(dims))).transpose(
+                    (0,) + tuple(range(len(dims), 0, -1)))            # column-major -> [draw, *dims]
+            else:
+                arr = arr[:, 0]
+            out[name] = arr
+        if permuted:
+            perm = np.random.default_rng(self._h.opts.seed).permutation(self.chains * self.n_saved)
+            out = {k: v[perm] for k, v in out.items()}
+        return out[pars] if single else out
+
+    def as_array(self, pars):
+        """as.array(stanfit)[, , pars]: [iterations, chains, columns]."""
+        a, b, _ = self._h.layout[pars]
+        return self._h.write_array(a, b, self.n_saved)
+
+    def output_files(self, directory, basename=None):
+        """fit$output_files(): writes CmdStan CSVs for rstan::read_stan_csv (final_2016.R:543)."""
+        return self._h.write_stan_csv(directory, basename or self.model_name.replace("_model", ""))
+
+
+class PotusModel:
+    """cmdstanr::cmdstan_model() for the two poll models (final_2016.R:532, final_2012.R:558)."""
+
+    def __init__(self, stan_file_or_variant="full"):
+        v = str(stan_file_or_variant)
+        if v.endswith(".stan"):
+            v = "no_mode_adjustment" if "no_mode_adjustment" in v else "full"
+        if v not in _abi.VARIANTS:
+            raise ValueError(f"unknown model {stan_file_or_variant!r}")
+        self.variant = v
+        self.model_name = "poll_model_2020_model" if v == "full" else "poll_model_2020_no_mode_adjustment_model"
+
+    def sample(self, data, seed=1843, chains=4, parallel_chains=None, iter_warmup=1000, iter_sampling=1000,
+               refresh=100, adapt_delta=0.8, max_treedepth=10, init=2.0, save_warmup=False, device=0,
+               chain_id_offset=0, show_messages=False, inits=None):
+        h = Handle(data, self.variant, chains=int(chains), chain_id_offset=int(chain_id_offset),
+                   num_warmup=int(iter_warmup), num_samples=int(iter_sampling), max_depth=int(max_treedepth),
+                   delta=float(adapt_delta), init_radius=float(init), seed=int(seed), device=int(device),
+                   save_warmup=int(bool(save_warmup)))
+        h.init(inits)
+        total = int(iter_warmup) + int(iter_sampling)
+        chunk = max(1, int(refresh)) if refresh else total
+        done = 0
+        while done < total:
+            n = min(chunk, total - done)
+            h.run(n)
+            done += n
+            if show_messages:
+                phase = "Warmup" if done <= iter_warmup else "Sampling"
+                print(f"Iteration: {done:5d} / {total} [{100 * done // total:3d}%]  ({phase})", flush=True)
+        self.last_handle = h
+        return StanFit(h, self.model_name)
+
+
+def sampling(model: PotusModel, data, chains=4, iter=2000, warmup=None, refresh=None, seed=1843, control=None,
+             **kw):
+    """rstan::sampling(model, data=, chains=, iter=, warmup=, refresh=) (final_2016.R:525-529)."""
+    warmup = iter // 2 if warmup is None else warmup
+    control = control or {}
+    return model.sample(data, seed=seed, chains=chains, iter_warmup=warmup, iter_sampling=iter - warmup,
+                        refresh=refresh if refresh is not None else max(iter // 10, 1),
+                        adapt_delta=control.get("adapt_delta", 0.8), max_treedepth=control.get("max_treedepth", 10), **kw)
