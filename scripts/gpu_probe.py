@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Development probe (GPU box): quick timings of the model pass and of NUTS at several chain counts."""
+"""Development probe (GPU box): NUTS timings at several chain counts; with POTUS_LIB pointing at
+the -DPOTUS_PROF build also the in-kernel cycle breakdown per phase."""
+import ctypes as C
+import os
 import sys
 import time
 from pathlib import Path
@@ -8,22 +11,14 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-from us_potus_model_amd import Handle, dataprep  # noqa: E402
+from us_potus_model_amd import Handle, dataprep, sampler  # noqa: E402
 
 data = dataprep.load_npz(ROOT / "tests" / "golden" / "data_2016.npz")["data"]
-h = Handle(data, "full", chains=1)
-rng = np.random.default_rng(0)
-for n in (1, 256, 1024):
-    q = rng.uniform(-2, 2, (n, h.D))
-    h.log_prob_grad(q)
-    t = time.perf_counter()
-    for _ in range(3):
-        h.log_prob_grad(q)
-    dt = (time.perf_counter() - t) / 3
-    print(f"log_prob_grad n={n}: {dt*1e3:.2f} ms incl. PCIe copies", flush=True)
-h.close()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-for chains in (1, 8, 64, 256, 512):
+chain_counts = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 8, 64, 256]
+NAMES = {0: "A load+suffix", 1: "B carry/C/AR1", 2: "C polls", 3: "D gathers", 4: "E prefix/seg2", 5: "F dZ/adjoint", 6: "G reduce",
+         8: "momentum", 9: "init copy", 10: "leaf scalar", 11: "merge", 12: "copy q", 13: "p_near", 14: "adapt", 15: "save"}
+for chains in chain_counts:
     h = Handle(data, "full", chains=chains, num_warmup=iters, num_samples=0, seed=1843)
     h.init()
     ms_tot, lf_tot = 0.0, 0
@@ -33,5 +28,16 @@ for chains in (1, 8, 64, 256, 512):
         ms_tot += ms
         lf_tot += lf
     print(f"NUTS chains={chains}: {lf_tot} leapfrogs in {ms_tot:.1f} ms -> {lf_tot/ms_tot*1e3:.0f} leapfrogs/s, "
-          f"{ms_tot*1e3*chains/lf_tot:.2f} us/leapfrog/chain (if all chains were concurrent)", flush=True)
+          f"{ms_tot*1e3*chains/lf_tot:.2f} us/leapfrog/chain", flush=True)
+    L = sampler.load_library()
+    if hasattr(L, "potus_debug_profile"):
+        out = np.zeros((chains, 32))
+        L.potus_debug_profile.argtypes = [C.c_int, C.POINTER(C.c_double)]
+        if L.potus_debug_profile(h.h, out.ctypes.data_as(C.POINTER(C.c_double))):
+            p = out[0]
+            leaves, merges = p[16], p[17]
+            tot = sum(p[k] for k in NAMES)
+            print(f"  chain 0: leaves {leaves:.0f} merges {merges:.0f}; cycles per leaf by phase (clock64 ticks):")
+            for k, nm in NAMES.items():
+                print(f"    {nm:16s} {p[k]/max(leaves,1):10.0f}  ({100*p[k]/tot:4.1f}%)")
     h.close()

@@ -171,9 +171,10 @@ def test_posterior_parity_small(cases):
     nw = ns = 400
     h = Handle(data, variant, chains=4, num_warmup=nw, num_samples=ns, seed=1843)
     h.init(); h.run(nw + ns)
-    x = h.draws()[:, :, 7:]
-    st, dv = h.chain_status()
-    assert st == [0, 0, 0, 0] and sum(dv) <= 8
+    d = h.draws()
+    x = d[:, :, 7:]
+    st, _ = h.chain_status()
+    assert st == [0, 0, 0, 0] and d[:, :, 5].mean() < 0.02        # divergent__ among the saved draws
     m = OracleModel(data, variant)
     o = m.default_opts(num_warmup=nw, num_samples=ns, seed=4242, fast_grad=1)      # different seed: independent run
     y = np.stack([m.sample_chain(c, o)[0][:, 7:] for c in (1, 2, 3, 4)])

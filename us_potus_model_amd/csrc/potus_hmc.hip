@@ -18,32 +18,46 @@
 // ======================================================================== kernels
 extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
 
-__global__ __launch_bounds__(PT_THREADS) void k_logprob_grad(DevModel M, const double *q, double *lp, double *grad, int n) {
-  model_setup_lds(M, lds_dyn);
+__global__ __launch_bounds__(PT_THREADS) void k_logprob_grad(const DevModel *Mg, const double *q, double *lp, double *grad, int n) {
+  CMp M = (CMp)Mg;
+  ldp lds = (ldp)lds_dyn;
+  model_setup_lds(M, lds);
+  const int D = M->D;
   for (int b = blockIdx.x; b < n; b += gridDim.x) {
-    PlainPolicy pol{q + (size_t)b * M.D, grad + (size_t)b * M.D, {0}};
-    const double v = model_pass(M, lds_dyn, pol);
+    PlainPolicy pol{as_g(q) + (size_t)b * D, as_g(grad) + (size_t)b * D, {0}};
+    const double v = model_pass(M, lds, pol);
     if (threadIdx.x == 0) lp[b] = v;
   }
 }
 
-__device__ __forceinline__ Chain make_chain(const DevModel &M, const RunParams &R, int chain) {
-  TS *ts = reinterpret_cast<TS *>(lds_dyn + M.lds_doubles);
-  return Chain{M, R, lds_dyn, *ts, R.state + (size_t)chain * V_COUNT * R.Dpad, R.scal + chain,
-               RngKey{R.seed_lo, R.seed_hi, (uint32_t)(R.chain_id_offset + chain + 1)}, M.D, (int)threadIdx.x};
+__device__ __forceinline__ Chain make_chain(CMp M, const RunParams &R, int chain) {
+  ldp lds = (ldp)lds_dyn;
+  Chain c;
+  c.M = M; c.lds = lds; c.ts = (ltp)(lds + M->lds_doubles);
+  c.base = as_g(R.state) + (size_t)chain * V_COUNT * R.Dpad;
+  c.sc = (gsc)(R.scal + chain);
+  c.key = RngKey{R.seed_lo, R.seed_hi, (uint32_t)(R.chain_id_offset + chain + 1)};
+  c.D = M->D; c.Dpad = R.Dpad; c.tid = (int)threadIdx.x; c.max_depth = R.max_depth; c.num_warmup = R.num_warmup;
+  c.init_buffer = R.init_buffer; c.term_buffer = R.term_buffer;
+  c.delta = R.delta; c.gamma = R.gamma; c.kappa = R.kappa; c.t0 = R.t0;
+#ifdef POTUS_PROF
+  c.prof = lds + M->l_prof;
+#endif
+  return c;
 }
 
 // Initial values (stan::services::util::initialize: U(-R,R), <= 100 attempts), unit metric,
 // adaptation windows (windowed_adaptation), mu = log(10*stepsize), initial init_stepsize.
-__global__ __launch_bounds__(PT_THREADS) void k_init(DevModel M, RunParams R, const double *q0) {
+__global__ __launch_bounds__(PT_THREADS) void k_init(const DevModel *Mg, RunParams R, const double *q0) {
+  CMp M = (CMp)Mg;
   const int chain = blockIdx.x;
   Chain c = make_chain(M, R, chain);
-  model_setup_lds(M, lds_dyn);
+  model_setup_lds(M, c.lds);
   const int tid = c.tid;
-  double *Q0 = c.vec(V_Q0), *G0 = c.vec(V_G0), *minv = c.vec(V_MINV), *mean = c.vec(V_WMEAN), *m2 = c.vec(V_WM2);
+  gdp Q0 = c.vec(V_Q0), G0 = c.vec(V_G0), minv = c.vec(V_MINV), mean = c.vec(V_WMEAN), m2 = c.vec(V_WM2);
   for (int i = tid; i < c.D; i += PT_THREADS) { minv[i] = 1.0; mean[i] = 0.0; m2[i] = 0.0; }
   if (tid == 0) {
-    ChainScalars *sc = c.sc;
+    gsc sc = c.sc;
     sc->nom_eps = R.stepsize; sc->mu = log(10.0 * R.stepsize); sc->s_bar = 0; sc->x_bar = 0; sc->ad_counter = 0;
     sc->wf_n = 0; sc->total_leapfrogs = 0; sc->iter = 0; sc->status = 0; sc->n_divergent = 0; sc->saved = 0;
     sc->win_counter = 0; sc->win_size = R.window; sc->win_next = R.init_buffer + R.window - 1;
@@ -52,15 +66,15 @@ __global__ __launch_bounds__(PT_THREADS) void k_init(DevModel M, RunParams R, co
   bool ok = false;
   for (uint32_t attempt = 0; attempt < 100 && !ok; attempt++) {
     for (int i = tid; i < c.D; i += PT_THREADS) {
-      if (q0) Q0[i] = q0[(size_t)chain * c.D + i];
+      if (q0) Q0[i] = as_g(q0)[(size_t)chain * c.D + i];
       else Q0[i] = R.init_radius * (2.0 * rng_uniform(c.key, PT_ITER_PRE, RNG_INITS, attempt, (uint32_t)i) - 1.0);
     }
     __syncthreads();
     PlainPolicy pol{Q0, G0, {0}};
-    const double lp = model_pass(M, lds_dyn, pol);
+    const double lp = model_pass(M, c.lds, pol);
     double bad[1] = {0.0};
     for (int i = tid; i < c.D; i += PT_THREADS) bad[0] += isfinite(G0[i]) ? 0.0 : 1.0;
-    block_sum(bad, lds_dyn + M.l_red, tid);
+    block_sum(bad, c.red(), tid);
     ok = isfinite(lp) && bad[0] == 0.0;
     if (tid == 0 && ok) c.sc->lp_cur = lp;
     __syncthreads();
@@ -72,39 +86,53 @@ __global__ __launch_bounds__(PT_THREADS) void k_init(DevModel M, RunParams R, co
 }
 
 // n_iter transitions per chain, adaptation during warmup, draws appended to the draws array.
-__global__ __launch_bounds__(PT_THREADS) void k_run(DevModel M, RunParams R, int n_iter) {
+__global__ __launch_bounds__(PT_THREADS) void k_run(const DevModel *Mg, RunParams R, int n_iter) {
+  CMp M = (CMp)Mg;
   const int chain = blockIdx.x;
   Chain c = make_chain(M, R, chain);
   if (c.sc->status != 0) return;
-  model_setup_lds(M, lds_dyn);
+  model_setup_lds(M, c.lds);
   const int tid = c.tid;
-  TS &ts = c.ts;
-  double *Q0 = c.vec(V_Q0);
+  ltp ts = c.ts;
+  gdp Q0 = c.vec(V_Q0);
   for (int k = 0; k < n_iter; k++) {
     const int it = c.sc->iter;
     if (it >= R.num_warmup + R.num_samples) break;
     nuts_transition(c, (uint32_t)it);
-    const double *qs = c.vec(V_POOLQ + ts.sample_qid);
+    CPROF_START(c);
+    gcdp qs = c.vec(V_POOLQ + ts->sample_qid);
     const bool warm = it < R.num_warmup;
-    if (!warm || R.save_warmup) {
-      double *row = R.draws + ((size_t)chain * R.n_save_max + c.sc->saved) * R.row;
-      if (tid == 0) {
-        row[0] = ts.out_lp; row[1] = ts.accept_stat; row[2] = ts.eps; row[3] = ts.depth; row[4] = ts.n_leap;
-        row[5] = ts.divergent; row[6] = ts.out_h;
-      }
-      for (int i = tid; i < c.D; i += PT_THREADS) row[POTUS_N_SAMPLER_COLS + i] = qs[i];
+    const bool save = !warm || R.save_warmup;
+    gdp row = as_g(R.draws) + ((size_t)chain * R.n_save_max + c.sc->saved) * R.row;
+    if (save && tid == 0) {
+      row[0] = ts->out_lp; row[1] = ts->accept_stat; row[2] = ts->eps; row[3] = ts->depth; row[4] = ts->n_leap;
+      row[5] = ts->divergent; row[6] = ts->out_h;
     }
-    for (int i = tid; i < c.D; i += PT_THREADS) Q0[i] = qs[i];
+    for (int base = tid; base < c.D; base += PT_UNR * PT_THREADS) {
+      double v[PT_UNR];
+#pragma unroll
+      for (int u = 0; u < PT_UNR; u++) { const int i = base + u * PT_THREADS; v[u] = i < c.D ? qs[i] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < PT_UNR; u++) {
+        const int i = base + u * PT_THREADS;
+        if (i < c.D) { Q0[i] = v[u]; if (save) row[POTUS_N_SAMPLER_COLS + i] = v[u]; }
+      }
+    }
     __syncthreads();
     if (tid == 0) {
-      c.sc->lp_cur = ts.out_lp;
-      if (!warm || R.save_warmup) c.sc->saved += 1;
+      c.sc->lp_cur = ts->out_lp;
+      if (save) c.sc->saved += 1;
     }
+    CPROF_MARK(c, PF_SAVE);
     if (warm) adapt_after_transition(c, (uint32_t)it, Q0);
+    CPROF_MARK(c, PF_ADAPT);
     __syncthreads();
     if (tid == 0) c.sc->iter = it + 1;
     __syncthreads();
   }
+#ifdef POTUS_PROF
+  if (R.prof) for (int i = tid; i < PT_NPROF; i += PT_THREADS) as_g(R.prof)[(size_t)chain * PT_NPROF + i] += c.prof[i];
+#endif
 }
 
 // write_array (stan:70-113 transformed parameters, stan:134-140 generated quantities) for saved
@@ -117,7 +145,8 @@ struct WAParams {
   double *out;
   double sigma_ns, sigma_nn;
 };
-__global__ __launch_bounds__(256) void k_write_array(DevModel M, WAParams W) {
+__global__ __launch_bounds__(256) void k_write_array(const DevModel *Mg, WAParams W) {
+  const DevModel M = *Mg;
   __shared__ double s_bT[64], s_pb[64], s_misc[4];
   const int tid = threadIdx.x, S = M.S, T = M.T, D = M.D;
   double *row = W.scratch + (size_t)blockIdx.x * W.ncols;
@@ -137,8 +166,8 @@ __global__ __launch_bounds__(256) void k_write_array(DevModel M, WAParams W) {
       double run = 0.0;
       Ct[tid + S * (T - 1)] = 0.0;
       for (int t = T - 2; t >= 0; t--) { run += q[M.o_Z + tid + S * t]; Ct[tid + S * t] = run; }
-      double bT = M.prior[tid], pb = 0.0;
-      for (int k = 0; k <= tid; k++) { bT += M.LT[tid * S + k] * q[M.o_zT + k]; pb += M.LB[tid * S + k] * q[M.o_zb + k]; }
+      double bT = M.mat[M.m_prior + tid], pb = 0.0;
+      for (int k = 0; k <= tid; k++) { bT += M.mat[M.m_LT + tid * S + k] * q[M.o_zT + k]; pb += M.mat[M.m_LB + tid * S + k] * q[M.o_zb + k]; }
       s_bT[tid] = bT; s_pb[tid] = pb; row[o_pb + tid] = pb;
     }
     if (tid == 64 && M.full) {
@@ -157,24 +186,24 @@ __global__ __launch_bounds__(256) void k_write_array(DevModel M, WAParams W) {
     for (int idx = tid; idx < S * T; idx += 256) {
       const int s = idx % S, t = idx / S;
       double a = s_bT[s];
-      const double *Lrow = M.Lw_ext + s * M.SP, *Cc = Ct + S * t;
+      const double *Lrow = M.mat + s * M.SP, *Cc = Ct + S * t;
       for (int k = 0; k <= s; k++) a += Lrow[k] * Cc[k];
       row[o_mub + idx] = a;
     }
-    if (tid == 0) { double a = 0.0; for (int s = 0; s < S; s++) a += s_pb[s] * M.w[s]; s_misc[0] = a; row[o_natpb] = a; }
+    if (tid == 0) { double a = 0.0; for (int s = 0; s < S; s++) a += s_pb[s] * M.mat[M.m_w + s]; s_misc[0] = a; row[o_natpb] = a; }
     __syncthreads();
     for (int t = tid; t < T; t += 256) {
       double a = 0.0;
-      for (int s = 0; s < S; s++) a += row[o_mub + s + S * t] * M.w[s];
+      for (int s = 0; s < S; s++) a += row[o_mub + s + S * t] * M.mat[M.m_w + s];
       row[o_nat + t] = a;
     }
     __syncthreads();
     for (int i = tid; i < M.Npoll; i += 256) {
-      const int s = M.ps[i], t = M.pt[i], qi = M.pqidx[i];
+      const int s = M.pi[i], t = M.pi[M.Npad + i], qi = M.pi[5 * M.Npad + i];
       const bool nat = s == S;
-      double eta = (nat ? row[o_nat + t] : row[o_mub + s + S * t]) + row[o_muc + M.pp[i]];
-      if (M.full) eta += row[o_mum + M.pm[i]] + row[o_mupop + M.ppop[i]] + M.punadj[i] * row[o_eb + t];
-      eta += q[qi] * M.psig[i] + (nat ? s_misc[0] : s_pb[s]);
+      double eta = (nat ? row[o_nat + t] : row[o_mub + s + S * t]) + row[o_muc + M.pi[2 * M.Npad + i]];
+      if (M.full) eta += row[o_mum + M.pi[3 * M.Npad + i]] + row[o_mupop + M.pi[4 * M.Npad + i]] + M.pd[2 * M.Npad + i] * row[o_eb + t];
+      eta += q[qi] * M.pd[3 * M.Npad + i] + (nat ? s_misc[0] : s_pb[s]);
       if (nat) row[o_etan + (qi - M.o_nn)] = eta; else row[o_etas + (qi - M.o_ns)] = eta;
     }
     __syncthreads();
@@ -288,6 +317,7 @@ struct Sampler {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevModel M{};
+  DevModel *dM = nullptr; // device copy read by the kernels through scalar loads
   RunParams R{};
   potus_opts opts{};
   Layout L{};
@@ -432,22 +462,42 @@ int build_model(Sampler *sp, const potus_data *d) {
   M.l_zT = take(S); M.l_zb = take(S); M.l_mid = take(M.nmid);
   M.l_bT = take(M.SE); M.l_pb = take(M.SE); M.l_e = take(T); M.l_gs = take(M.SE); M.l_ge = take(T);
   M.l_scal = take(SC_N); M.l_red = take(PT_NW * PT_NRED);
+#ifdef POTUS_PROF
+  M.l_prof = take(PT_NPROF);
+#else
+  M.l_prof = 0;
+#endif
   M.lds_doubles = o;
   sp->lds_bytes = (size_t)o * 8 + sizeof(TS) + 16;
   if (sp->lds_bytes > 160 * 1024)
     return fail(POTUS_ERR_UNSUPPORTED, "model needs %zu bytes of LDS per workgroup (> 160 KiB): T=%d, polls=%d", sp->lds_bytes, T, Np);
 
   int rc;
-  std::vector<double> prior(d->mu_b_prior, d->mu_b_prior + S);
-  if ((rc = upload(sp, Lw_ext, &M.Lw_ext)) || (rc = upload(sp, LT_t, &M.LT_t)) || (rc = upload(sp, LB_t, &M.LB_t)) ||
-      (rc = upload(sp, LTr, &M.LT)) || (rc = upload(sp, LBr, &M.LB)) || (rc = upload(sp, prior, &M.prior)) || (rc = upload(sp, w, &M.w)) ||
-      (rc = upload(sp, ps, &M.ps)) || (rc = upload(sp, pt, &M.pt)) || (rc = upload(sp, pp, &M.pp)) || (rc = upload(sp, pm, &M.pm)) ||
-      (rc = upload(sp, ppop, &M.ppop)) || (rc = upload(sp, pq, &M.pqidx)) || (rc = upload(sp, py, &M.py)) || (rc = upload(sp, pn, &M.pn)) ||
-      (rc = upload(sp, pu, &M.punadj)) || (rc = upload(sp, psig, &M.psig)) || (rc = upload(sp, day_ptr, &M.day_ptr)) ||
-      (rc = upload(sp, wave_task_ptr, &M.wave_task_ptr)) || (rc = upload(sp, task_day, &M.task_day)) ||
-      (rc = upload(sp, sub_ptr, &M.sub_ptr)) || (rc = upload(sp, sub_idx, &M.sub_idx)) || (rc = upload(sp, seg_ptr, &M.seg_ptr)) ||
-      (rc = upload(sp, seg_kind, &M.seg_kind)) || (rc = upload(sp, seg_index, &M.seg_index)) || (rc = upload(sp, seg_scale, &M.seg_scale)))
+  // pack: mat = Lw_ext | LT_t | LB_t | LT | LB | prior | w
+  std::vector<double> mat(Lw_ext);
+  auto app = [&](const std::vector<double> &v) { const int off = (int)mat.size(); mat.insert(mat.end(), v.begin(), v.end()); return off; };
+  M.m_LTt = app(LT_t); M.m_LBt = app(LB_t); M.m_LT = app(LTr); M.m_LB = app(LBr);
+  M.m_prior = app(std::vector<double>(d->mu_b_prior, d->mu_b_prior + S)); M.m_w = app(w);
+  M.Npad = (Np + 15) & ~15;
+  std::vector<int> pi((size_t)6 * M.Npad, 0);
+  std::vector<double> pdv((size_t)4 * M.Npad, 0.0);
+  for (int i = 0; i < Np; i++) {
+    pi[i] = ps[i]; pi[M.Npad + i] = pt[i]; pi[2 * M.Npad + i] = pp[i]; pi[3 * M.Npad + i] = pm[i]; pi[4 * M.Npad + i] = ppop[i];
+    pi[5 * M.Npad + i] = pq[i];
+    pdv[i] = py[i]; pdv[M.Npad + i] = pn[i]; pdv[2 * M.Npad + i] = pu[i]; pdv[3 * M.Npad + i] = psig[i];
+  }
+  std::vector<int> sched(day_ptr);
+  auto appi = [&](const std::vector<int> &v) { const int off = (int)sched.size(); sched.insert(sched.end(), v.begin(), v.end()); return off; };
+  M.c_wtp = appi(wave_task_ptr); M.c_td = appi(task_day); M.c_subptr = appi(sub_ptr); M.c_subidx = appi(sub_idx);
+  M.c_segptr = appi(seg_ptr); M.c_segkind = appi(seg_kind); M.c_segidx = appi(seg_index);
+  if ((rc = upload(sp, mat, &M.mat)) || (rc = upload(sp, pi, &M.pi)) || (rc = upload(sp, pdv, &M.pd)) ||
+      (rc = upload(sp, sched, &M.sched)) || (rc = upload(sp, seg_scale, &M.seg_scale)))
     return rc;
+  void *pdm = nullptr;
+  HIP_TRY(hipMalloc(&pdm, sizeof(DevModel)));
+  sp->allocs.push_back(pdm);
+  HIP_TRY(hipMemcpy(pdm, &M, sizeof(DevModel), hipMemcpyHostToDevice));
+  sp->dM = (DevModel *)pdm;
   return 0;
 }
 
@@ -570,6 +620,13 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   sp->allocs.push_back(p); R.draws = (double *)p;
   (void)hipMemset(p, 0, draw_bytes);
 
+#ifdef POTUS_PROF
+  if (hipMalloc(&p, sizeof(double) * PT_NPROF * o->chains) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for profile failed"));
+  sp->allocs.push_back(p); R.prof = (double *)p;
+  (void)hipMemset(p, 0, sizeof(double) * PT_NPROF * o->chains);
+#else
+  R.prof = nullptr;
+#endif
   std::lock_guard<std::mutex> lk(g_mu);
   g_handles.push_back(sp);
   *handle = (int)g_handles.size() - 1;
@@ -599,7 +656,7 @@ int potus_log_prob_grad(int handle, const double *q, int n, double *lp, double *
   HIP_TRY(hipMalloc((void **)&dq, n * D * 8)); HIP_TRY(hipMalloc((void **)&dg, n * D * 8)); HIP_TRY(hipMalloc((void **)&dlp, (size_t)n * 8));
   HIP_TRY(hipMemcpyAsync(dq, q, n * D * 8, hipMemcpyHostToDevice, sp->stream));
   const int grid = std::min(n, 1024);
-  hipLaunchKernelGGL(k_logprob_grad, dim3(grid), dim3(PT_THREADS), sp->lds_bytes, sp->stream, sp->M, dq, dlp, dg, n);
+  hipLaunchKernelGGL(k_logprob_grad, dim3(grid), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const double *)dq, dlp, dg, n);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(lp, dlp, (size_t)n * 8, hipMemcpyDeviceToHost, sp->stream));
   HIP_TRY(hipMemcpyAsync(grad, dg, n * D * 8, hipMemcpyDeviceToHost, sp->stream));
@@ -615,7 +672,7 @@ int potus_init(int handle, const double *q0) {
   double *dq0 = nullptr;
   const size_t bytes = (size_t)sp->R.chains * sp->L.D * 8;
   if (q0) { HIP_TRY(hipMalloc((void **)&dq0, bytes)); HIP_TRY(hipMemcpyAsync(dq0, q0, bytes, hipMemcpyHostToDevice, sp->stream)); }
-  hipLaunchKernelGGL(k_init, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, sp->M, sp->R, (const double *)dq0);
+  hipLaunchKernelGGL(k_init, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, sp->R, (const double *)dq0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(sp->stream));
   if (dq0) (void)hipFree(dq0);
@@ -637,7 +694,7 @@ int potus_run(int handle, int n_iter) {
   potus_total_leapfrogs(handle, &before);
   int it0 = 0; potus_iterations_done(handle, &it0);
   HIP_TRY(hipEventRecord(sp->ev0, sp->stream));
-  hipLaunchKernelGGL(k_run, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, sp->M, sp->R, n_iter);
+  hipLaunchKernelGGL(k_run, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, sp->R, n_iter);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(sp->ev1, sp->stream));
   HIP_TRY(hipStreamSynchronize(sp->stream));
@@ -741,7 +798,7 @@ static int write_array_range(Sampler *sp, int n_saved, int col_begin, int col_en
   HIP_TRY(hipMalloc((void **)&scratch, (size_t)grid * sp->L.ncols * 8));
   HIP_TRY(hipMalloc((void **)&dout, (size_t)ndraw * nsel * 8));
   WAParams W{sp->R.draws, sp->R.chains, sp->R.n_save_max, n_saved, sp->R.row, sp->L.ncols, col_begin, col_end, scratch, dout, sp->sigma_ns, sp->sigma_nn};
-  hipLaunchKernelGGL(k_write_array, dim3(grid), dim3(256), 0, sp->stream, sp->M, W);
+  hipLaunchKernelGGL(k_write_array, dim3(grid), dim3(256), 0, sp->stream, (const DevModel *)sp->dM, W);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, dout, (size_t)ndraw * nsel * 8, hipMemcpyDeviceToHost, sp->stream));
   HIP_TRY(hipStreamSynchronize(sp->stream));
@@ -825,6 +882,16 @@ int potus_write_stan_csv(int handle, const char *dir, const char *basename) {
             sp->warm_ms * 1e-3, sp->samp_ms * 1e-3, (sp->warm_ms + sp->samp_ms) * 1e-3);
   close_all();
   return 0;
+}
+
+// Development aid (POTUS_PROF builds only; not part of include/potus_hmc.h): per-chain cycle
+// counters of the kernel phases.  Returns the number of slots written per chain, 0 otherwise.
+int potus_debug_profile(int handle, double *out) {
+  Sampler *sp = get(handle);
+  if (!sp || !sp->R.prof || !out) return 0;
+  (void)hipSetDevice(sp->device);
+  if (hipMemcpy(out, sp->R.prof, sizeof(double) * PT_NPROF * sp->R.chains, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  return PT_NPROF;
 }
 
 // ---------------------------------------------------------------- .C() wrappers

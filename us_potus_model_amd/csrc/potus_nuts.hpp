@@ -43,11 +43,15 @@ enum {
   V_COUNT = V_POOLQ + PT_NPQ
 };
 
+// profile slots (POTUS_PROF builds): 0-6 model pass phases, then
+enum { PF_MOMENTUM = 8, PF_INITCOPY, PF_LEAF_SCALAR, PF_MERGE, PF_COPYQ, PF_PNEAR, PF_ADAPT, PF_SAVE, PF_LEAVES, PF_MERGES };
+
 struct ChainScalars { // persistent per chain, global memory
   double nom_eps, mu, s_bar, x_bar, ad_counter, wf_n, lp_cur;
   long long total_leapfrogs;
   int iter, win_counter, win_next, win_size, status, n_divergent, saved, pad;
 };
+typedef ChainScalars AS_G *gsc;
 
 struct RunParams {
   int chains, chain_id_offset, num_warmup, num_samples, max_depth, init_buffer, term_buffer, window;
@@ -57,6 +61,7 @@ struct RunParams {
   double *state;           // [chains][V_COUNT][Dpad]
   ChainScalars *scal;      // [chains]
   double *draws;           // [chains][n_save_max][7 + D]
+  double *prof;            // [chains][PT_NPROF] (POTUS_PROF builds) or null
 };
 
 struct TS { // transition state, LDS
@@ -71,6 +76,7 @@ struct TS { // transition state, LDS
   int depth, dir, divergent, abort, m, leaf_id, copy_q_id, sample_qid, n_leap, stop;
   int flag_a, flag_b, direction, done;
 };
+typedef TS AS_L *ltp;
 
 // ---------------------------------------------------------------- RNG
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
@@ -111,40 +117,59 @@ __device__ __forceinline__ void rng_normal_pair(const RngKey &K, uint32_t iter, 
 // G holds grad lp.  The full-step momentum is also written to the leaf's pool slot and the
 // kinetic energy sum_i minv_i p_i^2 is accumulated for the Hamiltonian.
 struct LeapPolicy {
-  double *Q, *P, *G;
-  const double *minv;
-  double *leafp;
+  gdp Q, P, G;
+  gcdp minv;
+  gdp leafp;
   double he, e;
   static constexpr int NEXTRA = 1;
   double extra[1];
-  __device__ __forceinline__ double q(int i) {
-    const double ph = P[i] + he * G[i];
+  struct QT { double p, g, q, m; };
+  struct GT { double p, m, q; };
+  __device__ __forceinline__ void q_load(int i, QT &t) { t.p = P[i]; t.g = G[i]; t.q = Q[i]; t.m = minv[i]; }
+  __device__ __forceinline__ double q_fin(int i, const QT &t) {
+    const double ph = t.p + he * t.g;
     P[i] = ph;
-    const double qn = Q[i] + e * minv[i] * ph;
+    const double qn = t.q + e * t.m * ph;
     Q[i] = qn;
     return qn;
   }
-  __device__ __forceinline__ double q_again(int i) { return Q[i]; }
-  __device__ __forceinline__ void g(int i, double v) {
+  __device__ __forceinline__ void g_load(int i, GT &t) { t.p = P[i]; t.m = minv[i]; }
+  __device__ __forceinline__ void g_load_q(int i, GT &t) { t.p = P[i]; t.m = minv[i]; t.q = Q[i]; }
+  __device__ __forceinline__ void g_fin(int i, double v, const GT &t) {
     G[i] = v;
-    const double pf = P[i] + he * v;
+    const double pf = t.p + he * v;
     P[i] = pf;
     leafp[i] = pf;
-    extra[0] += minv[i] * pf * pf;
+    extra[0] += t.m * pf * pf;
   }
+  __device__ __forceinline__ double q(int i) { QT t; q_load(i, t); return q_fin(i, t); }
+  __device__ __forceinline__ void g(int i, double v) { GT t; g_load(i, t); g_fin(i, v, t); }
 };
 
 struct Chain {
-  const DevModel &M;
-  const RunParams &R;
-  double *lds;
-  TS &ts;
-  double *base;
-  ChainScalars *sc;
+  CMp M;
+  ldp lds;
+  ltp ts;
+  gdp base;
+  gsc sc;
   RngKey key;
-  int D, tid;
-  __device__ __forceinline__ double *vec(int slot) const { return base + (size_t)slot * R.Dpad; }
+  int D, Dpad, tid, max_depth, num_warmup, init_buffer, term_buffer;
+  double delta, gamma, kappa, t0;
+#ifdef POTUS_PROF
+  ldp prof;
+#endif
+  __device__ __forceinline__ gdp vec(int slot) const { return base + (size_t)slot * Dpad; }
+  __device__ __forceinline__ ldp red() const { return lds + M->l_red; }
 };
+#ifdef POTUS_PROF
+#define CPROF_MARK(c, k) do { if ((c).tid == 0) { const long long t_ = clock64(); (c).prof[k] += (double)(t_ - (long long)(c).prof[PT_NPROF - 1]); (c).prof[PT_NPROF - 1] = (double)t_; } } while (0)
+#define CPROF_START(c) do { if ((c).tid == 0) (c).prof[PT_NPROF - 1] = (double)clock64(); } while (0)
+#define CPROF_COUNT(c, k) do { if ((c).tid == 0) (c).prof[k] += 1.0; } while (0)
+#else
+#define CPROF_MARK(c, k) do { } while (0)
+#define CPROF_START(c) do { } while (0)
+#define CPROF_COUNT(c, k) do { } while (0)
+#endif
 
 __device__ __forceinline__ double d_lse(double a, double b) {
   if (a == -INFINITY) return b;
@@ -158,176 +183,234 @@ __device__ __forceinline__ int pool_alloc(unsigned &mask, int n) {
 __device__ __forceinline__ void pool_free(unsigned &mask, int i) { if (i >= 0) mask &= ~(1u << i); }
 
 // ---------------------------------------------------------------- block-wide vector sweeps (all end with a barrier)
-__device__ void vop_copy(const Chain &c, double *dst, const double *src) {
-  for (int i = c.tid; i < c.D; i += PT_THREADS) dst[i] = src[i];
+// Each thread handles elements tid, tid+1024, ...; four elements are in flight per trip so the
+// loads of a trip are issued together (the sweeps are latency-, not bandwidth-limited).
+#define PT_UNR 4
+__device__ __forceinline__ int fresh_tid(const Chain &c) { // keeps per-thread index math inside the loop it belongs to
+  int t = c.tid;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+__device__ void vop_copy(const Chain &c, gdp dst, gcdp src) {
+  const int tid0 = fresh_tid(c);
+  for (int base = tid0; base < c.D; base += PT_UNR * PT_THREADS) {
+    double v[PT_UNR];
+#pragma unroll
+    for (int k = 0; k < PT_UNR; k++) { const int i = base + k * PT_THREADS; v[k] = i < c.D ? src[i] : 0.0; }
+#pragma unroll
+    for (int k = 0; k < PT_UNR; k++) { const int i = base + k * PT_THREADS; if (i < c.D) dst[i] = v[k]; }
+  }
   __syncthreads();
 }
 // diag_e_metric::sample_p: p_i = N(0,1) / sqrt(minv_i); returns sum_i minv_i p_i^2
-__device__ double vop_momentum(const Chain &c, double *P, uint32_t iter, uint32_t purpose, uint32_t aux) {
-  const double *minv = c.vec(V_MINV);
+__device__ double vop_momentum(const Chain &c, gdp P, uint32_t iter, uint32_t purpose, uint32_t aux) {
+  gcdp minv = c.vec(V_MINV);
   double v[1] = {0.0};
-  for (int j = c.tid; 2 * j < c.D; j += PT_THREADS) {
+  const int tid0 = fresh_tid(c);
+  for (int j = tid0; 2 * j < c.D; j += PT_THREADS) {
+    const bool two = 2 * j + 1 < c.D;
+    const double m0 = minv[2 * j], m1 = two ? minv[2 * j + 1] : 1.0;
     double a, b;
     rng_normal_pair(c.key, iter, purpose, aux, (uint32_t)j, a, b);
-    const double pa = a / sqrt(minv[2 * j]);
-    P[2 * j] = pa;
+    P[2 * j] = a / sqrt(m0);
     v[0] += a * a;
-    if (2 * j + 1 < c.D) { P[2 * j + 1] = b / sqrt(minv[2 * j + 1]); v[0] += b * b; }
+    if (two) { P[2 * j + 1] = b / sqrt(m1); v[0] += b * b; }
   }
-  block_sum(v, c.lds + c.M.l_red, c.tid);
+  block_sum(v, c.red(), tid0);
   return v[0];
 }
 // One merge of an (init, final) pair of subtrees: the three checks of base_nuts::build_tree /
 // transition need six metric-weighted dot products; also emits rho_init + rho_final.
-__device__ bool vop_merge(const Chain &c, const double *a_beg, const double *a_end, const double *a_rho, const double *b_beg,
-                          const double *b_end, const double *b_rho, double *out) {
-  const double *minv = c.vec(V_MINV);
+__device__ bool vop_merge(const Chain &c, gcdp a_beg, gcdp a_end, gcdp a_rho, gcdp b_beg, gcdp b_end, gcdp b_rho, gdp out) {
+  gcdp minv = c.vec(V_MINV);
   double v[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = c.tid; i < c.D; i += PT_THREADS) {
-    const double mi = minv[i];
-    const double ab = a_beg[i], ae = a_end[i], ar = a_rho[i], bb = b_beg[i], be = b_end[i], br = b_rho[i];
-    const double rs = ar + br;
-    out[i] = rs;
-    const double sab = mi * ab, sbe = mi * be;
-    v[0] += sab * rs;            // p#_beg . rho_subtree
-    v[1] += sbe * rs;            // p#_end . rho_subtree
-    const double e1 = ar + bb;   // rho_init + p_final_beg
-    v[2] += sab * e1;
-    v[3] += mi * bb * e1;
-    const double e2 = br + ae;   // rho_final + p_init_end
-    v[4] += mi * ae * e2;
-    v[5] += sbe * e2;
+  const int tid0 = fresh_tid(c);
+  for (int base = tid0; base < c.D; base += PT_UNR * PT_THREADS) {
+    double mi[PT_UNR], ab[PT_UNR], ae[PT_UNR], ar[PT_UNR], bb[PT_UNR], be[PT_UNR], br[PT_UNR];
+#pragma unroll
+    for (int k = 0; k < PT_UNR; k++) {
+      const int i = min(base + k * PT_THREADS, c.D - 1);
+      mi[k] = minv[i]; ab[k] = a_beg[i]; ae[k] = a_end[i]; ar[k] = a_rho[i]; bb[k] = b_beg[i]; be[k] = b_end[i]; br[k] = b_rho[i];
+    }
+#pragma unroll
+    for (int k = 0; k < PT_UNR; k++) {
+      const int i = base + k * PT_THREADS;
+      if (i < c.D) {
+        const double rs = ar[k] + br[k];
+        out[i] = rs;
+        const double sab = mi[k] * ab[k], sbe = mi[k] * be[k];
+        v[0] += sab * rs;                 // p#_beg . rho_subtree
+        v[1] += sbe * rs;                 // p#_end . rho_subtree
+        const double e1 = ar[k] + bb[k];  // rho_init + p_final_beg
+        v[2] += sab * e1;
+        v[3] += mi[k] * bb[k] * e1;
+        const double e2 = br[k] + ae[k];  // rho_final + p_init_end
+        v[4] += mi[k] * ae[k] * e2;
+        v[5] += sbe * e2;
+      }
+    }
   }
-  block_sum(v, c.lds + c.M.l_red, c.tid);
+  block_sum(v, c.red(), tid0);
   return v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0 && v[4] > 0 && v[5] > 0;
 }
 
 // ---------------------------------------------------------------- one NUTS transition (base_nuts::transition)
-// On return ts.sample_qid names the pool slot holding the new sample, ts.out_lp / out_h its
-// log density and Hamiltonian, ts.accept_stat the adaptation statistic.
+// On return ts->sample_qid names the pool slot holding the new sample, ts->out_lp / out_h its
+// log density and Hamiltonian, ts->accept_stat the adaptation statistic.
 __device__ void nuts_transition(const Chain &c, uint32_t iter) {
-  TS &ts = c.ts;
+  ltp ts = c.ts;
   const int tid = c.tid;
-  double *Q[2] = {c.vec(V_Q0), c.vec(V_Q1)}, *P[2] = {c.vec(V_P0), c.vec(V_P1)}, *G[2] = {c.vec(V_G0), c.vec(V_G1)};
   const double eps = c.sc->nom_eps; // sample_stepsize(): no jitter
+  CPROF_START(c);
 
-  const double kin0 = vop_momentum(c, P[0], iter, RNG_MOMENTUM, 0);
-  PlainPolicy pp{Q[0], G[0], {0}};
+  const double kin0 = vop_momentum(c, c.vec(V_P0), iter, RNG_MOMENTUM, 0);
+  CPROF_MARK(c, PF_MOMENTUM);
+  PlainPolicy pp{c.vec(V_Q0), c.vec(V_G0), {0}};
   const double lp0 = model_pass(c.M, c.lds, pp); // hamiltonian.init
+  CPROF_START(c);
   if (tid == 0) {
-    ts.H0 = 0.5 * kin0 - lp0;
-    ts.lsw = 0.0; ts.sum_metro = 0.0; ts.n_leap = 0; ts.depth = 0; ts.divergent = 0; ts.stop = 0; ts.eps = eps;
-    ts.qmask = 0;
-    const int id = pool_alloc(ts.qmask, PT_NPQ);
-    ts.sample_qid = id; ts.q_lp[id] = lp0; ts.q_h[id] = ts.H0;
+    ts->H0 = 0.5 * kin0 - lp0;
+    ts->lsw = 0.0; ts->sum_metro = 0.0; ts->n_leap = 0; ts->depth = 0; ts->divergent = 0; ts->stop = 0; ts->eps = eps;
+    unsigned qm = 0;
+    const int id = pool_alloc(qm, PT_NPQ);
+    ts->qmask = qm;
+    ts->sample_qid = id; ts->q_lp[id] = lp0; ts->q_h[id] = 0.5 * kin0 - lp0;
   }
   __syncthreads();
   {
-    double *rt = c.vec(V_RHOTOP), *qs = c.vec(V_POOLQ + ts.sample_qid);
-    for (int i = tid; i < c.D; i += PT_THREADS) {
-      const double q = Q[0][i], p = P[0][i];
-      Q[1][i] = q; P[1][i] = p; G[1][i] = G[0][i]; rt[i] = p; qs[i] = q;
+    gdp rt = c.vec(V_RHOTOP), qs = c.vec(V_POOLQ + ts->sample_qid);
+    gdp Q0 = c.vec(V_Q0), Q1 = c.vec(V_Q1), P0 = c.vec(V_P0), P1 = c.vec(V_P1), G0 = c.vec(V_G0), G1 = c.vec(V_G1);
+    const int tid0 = fresh_tid(c);
+    for (int base = tid0; base < c.D; base += PT_UNR * PT_THREADS) {
+      double q[PT_UNR], p[PT_UNR], g[PT_UNR];
+#pragma unroll
+      for (int k = 0; k < PT_UNR; k++) { const int i = min(base + k * PT_THREADS, c.D - 1); q[k] = Q0[i]; p[k] = P0[i]; g[k] = G0[i]; }
+#pragma unroll
+      for (int k = 0; k < PT_UNR; k++) {
+        const int i = base + k * PT_THREADS;
+        if (i < c.D) { Q1[i] = q[k]; P1[i] = p[k]; G1[i] = g[k]; rt[i] = p[k]; qs[i] = q[k]; }
+      }
     }
   }
+  CPROF_MARK(c, PF_INITCOPY);
   while (true) {
     __syncthreads();
-    if (ts.depth >= c.R.max_depth || ts.stop) break;
-    const int depth = ts.depth;
+    if (ts->depth >= c.max_depth || ts->stop) break;
+    const int depth = ts->depth;
     if (tid == 0) {
-      ts.dir = rng_uniform(c.key, iter, RNG_DIRECTION, 0, (uint32_t)depth) > 0.5 ? 1 : 0;
-      ts.pmask = 0;
-      ts.qmask = 1u << ts.sample_qid;
+      ts->dir = rng_uniform(c.key, iter, RNG_DIRECTION, 0, (uint32_t)depth) > 0.5 ? 1 : 0;
+      ts->pmask = 0;
+      ts->qmask = 1u << ts->sample_qid;
     }
     __syncthreads();
-    const int dir = ts.dir;
-    vop_copy(c, c.vec(V_PNEAR), P[dir]);
+    const int dir = ts->dir;
+    CPROF_START(c);
+    vop_copy(c, c.vec(V_PNEAR), c.vec(V_P0 + dir));
+    CPROF_MARK(c, PF_PNEAR);
     bool valid = true;
     const int nleaf = 1 << depth;
     for (int n = 0; n < nleaf; n++) {
-      if (tid == 0) ts.leaf_id = pool_alloc(ts.pmask, PT_NPP);
+      if (tid == 0) { unsigned pm = ts->pmask; ts->leaf_id = pool_alloc(pm, PT_NPP); ts->pmask = pm; }
       __syncthreads();
       const double e = dir ? eps : -eps;
-      LeapPolicy lp{Q[dir], P[dir], G[dir], c.vec(V_MINV), c.vec(V_POOLP + ts.leaf_id), 0.5 * e, e, {0.0}};
+      LeapPolicy lp{c.vec(V_Q0 + dir), c.vec(V_P0 + dir), c.vec(V_G0 + dir), c.vec(V_MINV), c.vec(V_POOLP + ts->leaf_id), 0.5 * e, e, {0.0}};
       const double lpv = model_pass(c.M, c.lds, lp);
+      CPROF_START(c);
+      CPROF_COUNT(c, PF_LEAVES);
       if (tid == 0) {
+        const double H0 = ts->H0;
         double h = 0.5 * lp.extra[0] - lpv;
         if (isnan(h)) h = INFINITY;
-        if (h - ts.H0 > 1000.0) ts.divergent = 1;
-        const double wgt = ts.H0 - h;
-        ts.sum_metro += wgt > 0 ? 1.0 : exp(wgt);
-        ts.n_leap++;
-        ts.cur_beg = ts.cur_end = ts.leaf_id;
-        ts.cur_lsw = wgt; ts.cur_prop = -1; ts.cur_lp = lpv; ts.cur_h = h;
-        ts.abort = ts.divergent;
-        ts.m = __builtin_ctz(~(unsigned)n);
+        const int div = (h - H0 > 1000.0) ? 1 : ts->divergent;
+        ts->divergent = div;
+        const double wgt = H0 - h;
+        ts->sum_metro += wgt > 0 ? 1.0 : exp(wgt);
+        ts->n_leap += 1;
+        ts->cur_beg = ts->cur_end = ts->leaf_id;
+        ts->cur_lsw = wgt; ts->cur_prop = -1; ts->cur_lp = lpv; ts->cur_h = h;
+        ts->abort = div;
+        ts->m = __builtin_ctz(~(unsigned)n);
       }
       __syncthreads();
-      if (ts.abort) { valid = false; break; }
-      const int m = ts.m;
+      CPROF_MARK(c, PF_LEAF_SCALAR);
+      if (ts->abort) { valid = false; break; }
+      const int m = ts->m;
       for (int j = 1; j <= m; j++) {
-        const int ib = ts.pend_beg[j - 1], ie = ts.pend_end[j - 1], cb = ts.cur_beg, ce = ts.cur_end;
-        const double *a_rho = j == 1 ? c.vec(V_POOLP + ib) : c.vec(V_RHOLEV + j - 1);
-        const double *b_rho = j == 1 ? c.vec(V_POOLP + cb) : c.vec(V_SCR0 + ((j - 1) & 1));
-        double *out = j == m ? c.vec(V_RHOLEV + j) : c.vec(V_SCR0 + (j & 1));
+        const int ib = ts->pend_beg[j - 1], ie = ts->pend_end[j - 1], cb = ts->cur_beg, ce = ts->cur_end;
+        gcdp a_rho = j == 1 ? c.vec(V_POOLP + ib) : c.vec(V_RHOLEV + j - 1);
+        gcdp b_rho = j == 1 ? c.vec(V_POOLP + cb) : c.vec(V_SCR0 + ((j - 1) & 1));
+        gdp out = j == m ? c.vec(V_RHOLEV + j) : c.vec(V_SCR0 + (j & 1));
         const bool persist = vop_merge(c, c.vec(V_POOLP + ib), c.vec(V_POOLP + ie), a_rho, c.vec(V_POOLP + cb),
                                        c.vec(V_POOLP + ce), b_rho, out);
+        CPROF_COUNT(c, PF_MERGES);
         if (tid == 0) {
-          const double lsw_sub = d_lse(ts.pend_lsw[j - 1], ts.cur_lsw);
+          const double cur_lsw = ts->cur_lsw;
+          const double lsw_sub = d_lse(ts->pend_lsw[j - 1], cur_lsw);
           bool take_final;
-          if (ts.cur_lsw > lsw_sub) take_final = true;
+          if (cur_lsw > lsw_sub) take_final = true;
           else {
             const uint32_t slot = ((uint32_t)depth << 24) | ((uint32_t)j << 16) | (uint32_t)(n >> j);
-            take_final = rng_uniform(c.key, iter, RNG_SUB_ACCEPT, 0, slot) < exp(ts.cur_lsw - lsw_sub);
+            take_final = rng_uniform(c.key, iter, RNG_SUB_ACCEPT, 0, slot) < exp(cur_lsw - lsw_sub);
           }
-          if (take_final) pool_free(ts.qmask, ts.pend_prop[j - 1]);
-          else { pool_free(ts.qmask, ts.cur_prop); ts.cur_prop = ts.pend_prop[j - 1]; }
-          if (ie != ib) pool_free(ts.pmask, ie);
-          if (cb != ce) pool_free(ts.pmask, cb);
-          ts.cur_beg = ib;
-          ts.cur_lsw = lsw_sub;
-          ts.abort = !persist;
+          unsigned qm = ts->qmask, pm = ts->pmask;
+          if (take_final) pool_free(qm, ts->pend_prop[j - 1]);
+          else { pool_free(qm, ts->cur_prop); ts->cur_prop = ts->pend_prop[j - 1]; }
+          if (ie != ib) pool_free(pm, ie);
+          if (cb != ce) pool_free(pm, cb);
+          ts->qmask = qm; ts->pmask = pm;
+          ts->cur_beg = ib;
+          ts->cur_lsw = lsw_sub;
+          ts->abort = !persist;
         }
         __syncthreads();
-        if (ts.abort) { valid = false; break; }
+        CPROF_MARK(c, PF_MERGE);
+        if (ts->abort) { valid = false; break; }
       }
       if (!valid) break;
       if (tid == 0) {
-        ts.copy_q_id = -1;
-        if (ts.cur_prop < 0) { // the leaf itself is this subtree's proposal: keep its position
-          const int id = pool_alloc(ts.qmask, PT_NPQ);
-          ts.q_lp[id] = ts.cur_lp; ts.q_h[id] = ts.cur_h;
-          ts.cur_prop = id; ts.copy_q_id = id;
+        int cq = -1, prop = ts->cur_prop;
+        if (prop < 0) { // the leaf itself is this subtree's proposal: keep its position
+          unsigned qm = ts->qmask;
+          const int id = pool_alloc(qm, PT_NPQ);
+          ts->qmask = qm;
+          ts->q_lp[id] = ts->cur_lp; ts->q_h[id] = ts->cur_h;
+          prop = id; cq = id;
         }
-        ts.pend_beg[m] = ts.cur_beg; ts.pend_end[m] = ts.cur_end; ts.pend_lsw[m] = ts.cur_lsw; ts.pend_prop[m] = ts.cur_prop;
+        ts->copy_q_id = cq;
+        ts->pend_beg[m] = ts->cur_beg; ts->pend_end[m] = ts->cur_end; ts->pend_lsw[m] = ts->cur_lsw; ts->pend_prop[m] = prop;
       }
       __syncthreads();
-      if (ts.copy_q_id >= 0) vop_copy(c, c.vec(V_POOLQ + ts.copy_q_id), Q[dir]);
+      if (ts->copy_q_id >= 0) vop_copy(c, c.vec(V_POOLQ + ts->copy_q_id), c.vec(V_Q0 + dir));
+      CPROF_MARK(c, PF_COPYQ);
     }
     if (!valid) break;
     // merge the finished subtree with the old trajectory (the checks at the end of transition())
-    const int nb = ts.pend_beg[depth], ne = ts.pend_end[depth];
-    const double *n_rho = depth == 0 ? c.vec(V_POOLP + nb) : c.vec(V_RHOLEV + depth);
-    const bool persist = vop_merge(c, P[1 - dir], c.vec(V_PNEAR), c.vec(V_RHOTOP), c.vec(V_POOLP + nb), c.vec(V_POOLP + ne),
+    const int nb = ts->pend_beg[depth], ne = ts->pend_end[depth];
+    gcdp n_rho = depth == 0 ? c.vec(V_POOLP + nb) : c.vec(V_RHOLEV + depth);
+    const bool persist = vop_merge(c, c.vec(V_P1 - dir), c.vec(V_PNEAR), c.vec(V_RHOTOP), c.vec(V_POOLP + nb), c.vec(V_POOLP + ne),
                                    n_rho, c.vec(V_RHOTOP));
     if (tid == 0) {
-      ts.depth = depth + 1;
-      const double lsw_sub = ts.pend_lsw[depth];
+      ts->depth = depth + 1;
+      const double lsw_sub = ts->pend_lsw[depth], lsw = ts->lsw;
       bool accept;
-      if (lsw_sub > ts.lsw) accept = true;
-      else accept = rng_uniform(c.key, iter, RNG_TOP_ACCEPT, 0, (uint32_t)depth) < exp(lsw_sub - ts.lsw);
-      if (accept) { pool_free(ts.qmask, ts.sample_qid); ts.sample_qid = ts.pend_prop[depth]; }
-      else pool_free(ts.qmask, ts.pend_prop[depth]);
-      ts.lsw = d_lse(ts.lsw, lsw_sub);
-      if (!persist) ts.stop = 1;
+      if (lsw_sub > lsw) accept = true;
+      else accept = rng_uniform(c.key, iter, RNG_TOP_ACCEPT, 0, (uint32_t)depth) < exp(lsw_sub - lsw);
+      unsigned qm = ts->qmask;
+      if (accept) { pool_free(qm, ts->sample_qid); ts->sample_qid = ts->pend_prop[depth]; }
+      else pool_free(qm, ts->pend_prop[depth]);
+      ts->qmask = qm;
+      ts->lsw = d_lse(lsw, lsw_sub);
+      if (!persist) ts->stop = 1;
     }
+    CPROF_MARK(c, PF_MERGE);
   }
   __syncthreads();
   if (tid == 0) {
-    ts.accept_stat = ts.sum_metro / (double)ts.n_leap;
-    ts.out_lp = ts.q_lp[ts.sample_qid];
-    ts.out_h = ts.q_h[ts.sample_qid];
-    c.sc->total_leapfrogs += ts.n_leap;
-    c.sc->n_divergent += ts.divergent;
+    ts->accept_stat = ts->sum_metro / (double)ts->n_leap;
+    ts->out_lp = ts->q_lp[ts->sample_qid];
+    ts->out_h = ts->q_h[ts->sample_qid];
+    c.sc->total_leapfrogs += ts->n_leap;
+    c.sc->n_divergent += ts->divergent;
   }
   __syncthreads();
 }
@@ -335,12 +418,12 @@ __device__ void nuts_transition(const Chain &c, uint32_t iter) {
 // ---------------------------------------------------------------- base_hmc::init_stepsize
 // Works on end 1 as scratch; the chain's point is Q0 with gradient G0 (already evaluated).
 __device__ void init_stepsize(const Chain &c, uint32_t iter) {
-  TS &ts = c.ts;
+  ltp ts = c.ts;
   const int tid = c.tid;
-  double *Q1 = c.vec(V_Q1), *P1 = c.vec(V_P1), *G1 = c.vec(V_G1);
-  const double *Q0 = c.vec(V_Q0), *G0 = c.vec(V_G0);
+  gdp Q1 = c.vec(V_Q1), P1 = c.vec(V_P1), G1 = c.vec(V_G1);
+  gcdp Q0 = c.vec(V_Q0), G0 = c.vec(V_G0);
   const double lp0 = c.sc->lp_cur;
-  if (tid == 0) { ts.done = 0; ts.direction = 0; }
+  if (tid == 0) { ts->done = 0; ts->direction = 0; }
   __syncthreads();
   {
     const double e0 = c.sc->nom_eps;
@@ -357,56 +440,59 @@ __device__ void init_stepsize(const Chain &c, uint32_t iter) {
       double h = 0.5 * lp.extra[0] - lpv;
       if (isnan(h)) h = INFINITY;
       const double delta_H = H0 - h, thr = log(0.8);
-      if (attempt == 0) ts.direction = delta_H > thr ? 1 : -1;
+      if (attempt == 0) ts->direction = delta_H > thr ? 1 : -1;
       else {
-        if (ts.direction == 1 && !(delta_H > thr)) ts.done = 1;
-        else if (ts.direction == -1 && !(delta_H < thr)) ts.done = 1;
+        const int dirn = ts->direction;
+        if (dirn == 1 && !(delta_H > thr)) ts->done = 1;
+        else if (dirn == -1 && !(delta_H < thr)) ts->done = 1;
         else {
-          const double ne = ts.direction == 1 ? 2.0 * eps : 0.5 * eps;
+          const double ne = dirn == 1 ? 2.0 * eps : 0.5 * eps;
           c.sc->nom_eps = ne;
-          if (ne > 1e7 || ne == 0) { ts.done = 1; c.sc->status = 2; } // upstream throws here
+          if (ne > 1e7 || ne == 0) { ts->done = 1; c.sc->status = 2; } // upstream throws here
         }
       }
     }
     __syncthreads();
-    if (ts.done) break;
+    if (ts->done) break;
   }
   __syncthreads();
 }
 
 // ---------------------------------------------------------------- adaptation (adapt_diag_e_nuts::transition)
 // qs: the new sample, already stored as the chain's point Q0 (its gradient G0 may be stale).
-__device__ void adapt_after_transition(const Chain &c, uint32_t iter, const double *qs) {
-  TS &ts = c.ts;
-  ChainScalars *sc = c.sc;
-  const RunParams &R = c.R;
+__device__ void adapt_after_transition(const Chain &c, uint32_t iter, gcdp qs) {
+  ltp ts = c.ts;
+  gsc sc = c.sc;
   const int tid = c.tid;
   if (tid == 0) {
     // stepsize_adaptation::learn_stepsize
-    sc->ad_counter += 1;
-    const double as = ts.accept_stat > 1 ? 1.0 : ts.accept_stat;
-    const double eta = 1.0 / (sc->ad_counter + R.t0);
-    sc->s_bar = (1.0 - eta) * sc->s_bar + eta * (R.delta - as);
-    const double x = sc->mu - sc->s_bar * sqrt(sc->ad_counter) / R.gamma;
-    const double x_eta = pow(sc->ad_counter, -R.kappa);
+    const double cnt = sc->ad_counter + 1;
+    sc->ad_counter = cnt;
+    const double as = ts->accept_stat > 1 ? 1.0 : ts->accept_stat;
+    const double eta = 1.0 / (cnt + c.t0);
+    const double s_bar = (1.0 - eta) * sc->s_bar + eta * (c.delta - as);
+    sc->s_bar = s_bar;
+    const double x = sc->mu - s_bar * sqrt(cnt) / c.gamma;
+    const double x_eta = pow(cnt, -c.kappa);
     sc->x_bar = (1.0 - x_eta) * sc->x_bar + x_eta * x;
     sc->nom_eps = exp(x);
     // var_adaptation::learn_variance window logic
-    int nw = R.num_warmup, ib = R.init_buffer, tb = R.term_buffer;
-    ts.flag_a = ts.flag_b = 0;
+    const int nw = c.num_warmup, ib = c.init_buffer, tb = c.term_buffer, wc = sc->win_counter;
+    int fa = 0, fb = 0;
     if (nw >= 20) {
-      ts.flag_a = sc->win_counter >= ib && sc->win_counter < nw - tb && sc->win_counter != nw;
-      ts.flag_b = sc->win_counter == sc->win_next && sc->win_counter != nw;
-      if (ts.flag_a) sc->wf_n += 1;
+      fa = wc >= ib && wc < nw - tb && wc != nw;
+      fb = wc == sc->win_next && wc != nw;
+      if (fa) sc->wf_n += 1;
     }
+    ts->flag_a = fa; ts->flag_b = fb;
   }
   __syncthreads();
-  const int in_window = ts.flag_a, end_window = ts.flag_b;
-  double *mean = c.vec(V_WMEAN), *m2 = c.vec(V_WM2), *minv = c.vec(V_MINV);
+  const int in_window = ts->flag_a, end_window = ts->flag_b;
+  gdp mean = c.vec(V_WMEAN), m2 = c.vec(V_WM2), minv = c.vec(V_MINV);
   if (in_window) { // welford_var_estimator::add_sample
     const double n = sc->wf_n;
     for (int i = tid; i < c.D; i += PT_THREADS) {
-      const double q = qs[i], delta = q - mean[i], mn = mean[i] + delta / n;
+      const double q = qs[i], mo = mean[i], delta = q - mo, mn = mo + delta / n;
       mean[i] = mn;
       m2[i] += (q - mn) * delta;
     }
@@ -420,17 +506,19 @@ __device__ void adapt_after_transition(const Chain &c, uint32_t iter, const doub
     }
   }
   __syncthreads();
-  if (tid == 0 && R.num_warmup >= 20) {
+  if (tid == 0 && c.num_warmup >= 20) {
     if (end_window) { // windowed_adaptation::compute_next_window
-      const int last = R.num_warmup - R.term_buffer - 1;
-      if (sc->win_next != last) {
-        sc->win_size *= 2;
-        sc->win_next = sc->win_counter + sc->win_size;
-        if (sc->win_next != last) {
-          const int boundary = sc->win_next + 2 * sc->win_size;
-          if (boundary >= R.num_warmup - R.term_buffer) sc->win_next = last;
+      const int last = c.num_warmup - c.term_buffer - 1;
+      int wn = sc->win_next, wsz = sc->win_size;
+      if (wn != last) {
+        wsz *= 2;
+        wn = sc->win_counter + wsz;
+        if (wn != last) {
+          const int boundary = wn + 2 * wsz;
+          if (boundary >= c.num_warmup - c.term_buffer) wn = last;
         }
       }
+      sc->win_next = wn; sc->win_size = wsz;
       sc->wf_n = 0;
     }
     sc->win_counter += 1;
@@ -446,6 +534,6 @@ __device__ void adapt_after_transition(const Chain &c, uint32_t iter, const doub
     if (tid == 0) { sc->mu = log(10.0 * sc->nom_eps); sc->s_bar = 0; sc->x_bar = 0; sc->ad_counter = 0; }
     __syncthreads();
   }
-  if (tid == 0 && (int)iter == R.num_warmup - 1) sc->nom_eps = exp(sc->x_bar); // complete_adaptation
+  if (tid == 0 && (int)iter == c.num_warmup - 1) sc->nom_eps = exp(sc->x_bar); // complete_adaptation
   __syncthreads();
 }

@@ -37,7 +37,8 @@ class PotusError(RuntimeError):
 
 
 def lib_path() -> Path:
-    return _HERE / "libpotus_hmc.so"
+    # POTUS_LIB selects a development build (e.g. the -DPOTUS_PROF one); default is the product library
+    return Path(os.environ["POTUS_LIB"]) if os.environ.get("POTUS_LIB") else _HERE / "libpotus_hmc.so"
 
 
 def load_library():
@@ -191,7 +192,7 @@ class Handle:
         return p.value, n.value
 
     def write_array(self, col_begin, col_end, n_saved):
-        out = np.zeros((n_saved, self.opts.chains, col_end - col_begin))
+        out = np.zeros((n_saved, self.opts.chains, max(col_end - col_begin, 1)))
         if n_saved:
             _check(self.L, self.L.potus_write_array(self.h, col_begin, col_end, _dp(out)))
         return out
