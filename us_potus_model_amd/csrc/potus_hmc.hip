@@ -16,7 +16,6 @@
 #include <vector>
 
 // ======================================================================== kernels
-extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
 
 __global__ __launch_bounds__(PT_THREADS) void k_logprob_grad(const DevModel *Mg, const double *q, double *lp, double *grad, int n) {
   CMp M = (CMp)Mg;
@@ -24,22 +23,25 @@ __global__ __launch_bounds__(PT_THREADS) void k_logprob_grad(const DevModel *Mg,
   model_setup_lds(M, lds);
   const int D = M->D;
   for (int b = blockIdx.x; b < n; b += gridDim.x) {
-    PlainPolicy pol{as_g(q) + (size_t)b * D, as_g(grad) + (size_t)b * D, {0}};
+    PlainPolicy pol{make_rsrc(q + (size_t)b * D, 8u * D), make_rsrc(grad + (size_t)b * D, 8u * D), 0u, 0u, {0}};
     const double v = model_pass(M, lds, pol);
     if (threadIdx.x == 0) lp[b] = v;
   }
 }
 
-__device__ __forceinline__ Chain make_chain(CMp M, const RunParams &R, int chain) {
+__device__ __forceinline__ Chain make_chain(CMp M, CRp R, int chain) {
   ldp lds = (ldp)lds_dyn;
   Chain c;
+  const int Dpad = R->Dpad;
+  double *state = R->state + (size_t)chain * V_COUNT * Dpad;
   c.M = M; c.lds = lds; c.ts = (ltp)(lds + M->lds_doubles);
-  c.base = as_g(R.state) + (size_t)chain * V_COUNT * R.Dpad;
-  c.sc = (gsc)(R.scal + chain);
-  c.key = RngKey{R.seed_lo, R.seed_hi, (uint32_t)(R.chain_id_offset + chain + 1)};
-  c.D = M->D; c.Dpad = R.Dpad; c.tid = (int)threadIdx.x; c.max_depth = R.max_depth; c.num_warmup = R.num_warmup;
-  c.init_buffer = R.init_buffer; c.term_buffer = R.term_buffer;
-  c.delta = R.delta; c.gamma = R.gamma; c.kappa = R.kappa; c.t0 = R.t0;
+  c.base = as_g(state);
+  c.st = make_rsrc(state, (unsigned)V_COUNT * (unsigned)Dpad * 8u);
+  c.sc = (gsc)(R->scal + chain);
+  c.key = RngKey{R->seed_lo, R->seed_hi, (uint32_t)(R->chain_id_offset + chain + 1)};
+  c.D = M->D; c.Dpad = Dpad; c.tid = (int)threadIdx.x; c.max_depth = R->max_depth; c.num_warmup = R->num_warmup;
+  c.init_buffer = R->init_buffer; c.term_buffer = R->term_buffer;
+  c.delta = R->delta; c.gamma = R->gamma; c.kappa = R->kappa; c.t0 = R->t0;
 #ifdef POTUS_PROF
   c.prof = lds + M->l_prof;
 #endif
@@ -48,8 +50,9 @@ __device__ __forceinline__ Chain make_chain(CMp M, const RunParams &R, int chain
 
 // Initial values (stan::services::util::initialize: U(-R,R), <= 100 attempts), unit metric,
 // adaptation windows (windowed_adaptation), mu = log(10*stepsize), initial init_stepsize.
-__global__ __launch_bounds__(PT_THREADS) void k_init(const DevModel *Mg, RunParams R, const double *q0) {
+__global__ __launch_bounds__(PT_THREADS) void k_init(const DevModel *Mg, const RunParams *Rg, const double *q0) {
   CMp M = (CMp)Mg;
+  CRp R = (CRp)Rg;
   const int chain = blockIdx.x;
   Chain c = make_chain(M, R, chain);
   model_setup_lds(M, c.lds);
@@ -58,19 +61,20 @@ __global__ __launch_bounds__(PT_THREADS) void k_init(const DevModel *Mg, RunPara
   for (int i = tid; i < c.D; i += PT_THREADS) { minv[i] = 1.0; mean[i] = 0.0; m2[i] = 0.0; }
   if (tid == 0) {
     gsc sc = c.sc;
-    sc->nom_eps = R.stepsize; sc->mu = log(10.0 * R.stepsize); sc->s_bar = 0; sc->x_bar = 0; sc->ad_counter = 0;
+    sc->nom_eps = R->stepsize; sc->mu = log(10.0 * R->stepsize); sc->s_bar = 0; sc->x_bar = 0; sc->ad_counter = 0;
     sc->wf_n = 0; sc->total_leapfrogs = 0; sc->iter = 0; sc->status = 0; sc->n_divergent = 0; sc->saved = 0;
-    sc->win_counter = 0; sc->win_size = R.window; sc->win_next = R.init_buffer + R.window - 1;
+    sc->win_counter = 0; sc->win_size = R->window; sc->win_next = R->init_buffer + R->window - 1;
   }
   __syncthreads();
   bool ok = false;
+  const double radius = R->init_radius;
   for (uint32_t attempt = 0; attempt < 100 && !ok; attempt++) {
     for (int i = tid; i < c.D; i += PT_THREADS) {
       if (q0) Q0[i] = as_g(q0)[(size_t)chain * c.D + i];
-      else Q0[i] = R.init_radius * (2.0 * rng_uniform(c.key, PT_ITER_PRE, RNG_INITS, attempt, (uint32_t)i) - 1.0);
+      else Q0[i] = radius * (2.0 * rng_uniform(c.key, PT_ITER_PRE, RNG_INITS, attempt, (uint32_t)i) - 1.0);
     }
     __syncthreads();
-    PlainPolicy pol{Q0, G0, {0}};
+    PlainPolicy pol{c.st, c.st, c.soff(V_Q0), c.soff(V_G0), {0}};
     const double lp = model_pass(M, c.lds, pol);
     double bad[1] = {0.0};
     for (int i = tid; i < c.D; i += PT_THREADS) bad[0] += isfinite(G0[i]) ? 0.0 : 1.0;
@@ -82,56 +86,82 @@ __global__ __launch_bounds__(PT_THREADS) void k_init(const DevModel *Mg, RunPara
   }
   if (!ok) { if (tid == 0) c.sc->status = POTUS_ERR_INIT; return; }
   init_stepsize(c, PT_ITER_PRE);
-  if (tid == 0 && R.num_warmup == 0) c.sc->nom_eps = exp(c.sc->x_bar); // engage+disengage: complete_adaptation
+  if (tid == 0 && R->num_warmup == 0) c.sc->nom_eps = exp(c.sc->x_bar); // engage+disengage: complete_adaptation
+}
+
+// The once-per-transition work is kept out of line so that the register allocator only sees the
+// tree loop (leaves + merges) in the kernel body.  Arguments are re-made wave-uniform on entry.
+__device__ __noinline__ void cold_transition_begin(const DevModel *Mg, const RunParams *Rg, int chain, uint32_t iter) {
+  CMp M = (CMp)uni_ptr(Mg);
+  CRp R = (CRp)uni_ptr(Rg);
+  const Chain c = make_chain(M, R, (int)uni32((unsigned)chain));
+  transition_begin(c, uni32(iter));
+}
+
+// New sample -> chain position and draws array; warmup adaptation.
+__device__ __noinline__ void cold_transition_end(const DevModel *Mg, const RunParams *Rg, int chain_, uint32_t iter) {
+  CMp M = (CMp)uni_ptr(Mg);
+  CRp R = (CRp)uni_ptr(Rg);
+  const int chain = (int)uni32((unsigned)chain_);
+  const int it = (int)uni32(iter);
+  const Chain c = make_chain(M, R, chain);
+  ltp ts = c.ts;
+  const int tid = c.tid;
+  if (tid == 0) {
+    ts->accept_stat = ts->sum_metro / (double)ts->n_leap;
+    ts->out_lp = ts->q_lp[ts->sample_qid];
+    ts->out_h = ts->q_h[ts->sample_qid];
+    c.sc->total_leapfrogs += ts->n_leap;
+    c.sc->n_divergent += ts->divergent;
+  }
+  __syncthreads();
+  CPROF_START(c);
+  gcdp qs = c.vec(V_POOLQ + ts->sample_qid);
+  gdp Q0 = c.vec(V_Q0);
+  const bool warm = it < R->num_warmup;
+  const bool save = !warm || R->save_warmup;
+  const int row_len = R->row;
+  gdp row = as_g(R->draws) + ((size_t)chain * R->n_save_max + c.sc->saved) * row_len;
+  if (save && tid == 0) {
+    row[0] = ts->out_lp; row[1] = ts->accept_stat; row[2] = ts->eps; row[3] = ts->depth; row[4] = ts->n_leap;
+    row[5] = ts->divergent; row[6] = ts->out_h;
+  }
+  for (int i = tid; i < c.D; i += PT_THREADS) {
+    const double v = qs[i];
+    Q0[i] = v;
+    if (save) row[POTUS_N_SAMPLER_COLS + i] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    c.sc->lp_cur = ts->out_lp;
+    if (save) c.sc->saved += 1;
+  }
+  CPROF_MARK(c, PF_SAVE);
+  if (warm) adapt_after_transition(c, (uint32_t)it, Q0);
+  CPROF_MARK(c, PF_ADAPT);
+  __syncthreads();
+  if (tid == 0) c.sc->iter = it + 1;
+  __syncthreads();
 }
 
 // n_iter transitions per chain, adaptation during warmup, draws appended to the draws array.
-__global__ __launch_bounds__(PT_THREADS) void k_run(const DevModel *Mg, RunParams R, int n_iter) {
+__global__ __launch_bounds__(PT_THREADS) void k_run(const DevModel *Mg, const RunParams *Rg, int n_iter) {
   CMp M = (CMp)Mg;
+  CRp R = (CRp)Rg;
   const int chain = blockIdx.x;
-  Chain c = make_chain(M, R, chain);
+  const Chain c = make_chain(M, R, chain);
   if (c.sc->status != 0) return;
   model_setup_lds(M, c.lds);
-  const int tid = c.tid;
-  ltp ts = c.ts;
-  gdp Q0 = c.vec(V_Q0);
+  const int total = R->num_warmup + R->num_samples;
   for (int k = 0; k < n_iter; k++) {
     const int it = c.sc->iter;
-    if (it >= R.num_warmup + R.num_samples) break;
-    nuts_transition(c, (uint32_t)it);
-    CPROF_START(c);
-    gcdp qs = c.vec(V_POOLQ + ts->sample_qid);
-    const bool warm = it < R.num_warmup;
-    const bool save = !warm || R.save_warmup;
-    gdp row = as_g(R.draws) + ((size_t)chain * R.n_save_max + c.sc->saved) * R.row;
-    if (save && tid == 0) {
-      row[0] = ts->out_lp; row[1] = ts->accept_stat; row[2] = ts->eps; row[3] = ts->depth; row[4] = ts->n_leap;
-      row[5] = ts->divergent; row[6] = ts->out_h;
-    }
-    for (int base = tid; base < c.D; base += PT_UNR * PT_THREADS) {
-      double v[PT_UNR];
-#pragma unroll
-      for (int u = 0; u < PT_UNR; u++) { const int i = base + u * PT_THREADS; v[u] = i < c.D ? qs[i] : 0.0; }
-#pragma unroll
-      for (int u = 0; u < PT_UNR; u++) {
-        const int i = base + u * PT_THREADS;
-        if (i < c.D) { Q0[i] = v[u]; if (save) row[POTUS_N_SAMPLER_COLS + i] = v[u]; }
-      }
-    }
-    __syncthreads();
-    if (tid == 0) {
-      c.sc->lp_cur = ts->out_lp;
-      if (save) c.sc->saved += 1;
-    }
-    CPROF_MARK(c, PF_SAVE);
-    if (warm) adapt_after_transition(c, (uint32_t)it, Q0);
-    CPROF_MARK(c, PF_ADAPT);
-    __syncthreads();
-    if (tid == 0) c.sc->iter = it + 1;
-    __syncthreads();
+    if (it >= total) break;
+    cold_transition_begin(Mg, Rg, chain, (uint32_t)it);
+    transition_tree(c, (uint32_t)it);
+    cold_transition_end(Mg, Rg, chain, (uint32_t)it);
   }
 #ifdef POTUS_PROF
-  if (R.prof) for (int i = tid; i < PT_NPROF; i += PT_THREADS) as_g(R.prof)[(size_t)chain * PT_NPROF + i] += c.prof[i];
+  if (R->prof) for (int i = c.tid; i < PT_NPROF; i += PT_THREADS) as_g(R->prof)[(size_t)chain * PT_NPROF + i] += c.prof[i];
 #endif
 }
 
@@ -318,6 +348,7 @@ struct Sampler {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevModel M{};
   DevModel *dM = nullptr; // device copy read by the kernels through scalar loads
+  RunParams *dR = nullptr;
   RunParams R{};
   potus_opts opts{};
   Layout L{};
@@ -411,55 +442,66 @@ int build_model(Sampler *sp, const potus_data *d) {
   }
   for (int t = 0; t < T; t++) day_ptr[t + 1] += day_ptr[t];
 
-  // per-day gather tasks balanced over the 16 waves (longest-processing-time first)
-  std::vector<int> order(T), load(PT_NW, 0);
-  for (int t = 0; t < T; t++) order[t] = t;
+  // per-day gathers: days balanced over the 16 waves (longest-processing-time first); each wave gets
+  // the polls of its days as one contiguous entry list (index, day, state)
+  std::vector<int> order, load(PT_NW, 0);
+  for (int t = 0; t < T; t++) if (day_ptr[t + 1] > day_ptr[t]) order.push_back(t);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return day_ptr[a + 1] - day_ptr[a] > day_ptr[b + 1] - day_ptr[b]; });
   std::vector<std::vector<int>> wt(PT_NW);
   for (int t : order) {
     const int wmin = (int)(std::min_element(load.begin(), load.end()) - load.begin());
     wt[wmin].push_back(t);
-    load[wmin] += day_ptr[t + 1] - day_ptr[t] + 2;
+    load[wmin] += day_ptr[t + 1] - day_ptr[t] + 1;
   }
-  std::vector<int> wave_task_ptr(PT_NW + 1, 0), task_day;
-  for (int wv = 0; wv < PT_NW; wv++) { for (int t : wt[wv]) task_day.push_back(t); wave_task_ptr[wv + 1] = (int)task_day.size(); }
+  std::vector<int> we_ptr(PT_NW + 1, 0), we_idx, we_day, we_state, daymask(PT_NW, 0);
+  for (int wv = 0; wv < PT_NW; wv++) {
+    for (int t : wt[wv])
+      for (int i = day_ptr[t]; i < day_ptr[t + 1]; i++) { we_idx.push_back(i); we_day.push_back(t); we_state.push_back(ps[i]); }
+    we_ptr[wv + 1] = (int)we_idx.size();
+  }
+  for (int t = 0; t < T; t++) if (day_ptr[t + 1] > day_ptr[t]) daymask[t / PT_CH] |= (int)(1u << (t % PT_CH));
 
-  // two-level segment sums: level-1 tasks of <= PT_SUBLEN polls, level-2 one thread per segment
-  std::vector<int> sub_ptr{0}, sub_idx, seg_ptr{0}, seg_kind, seg_index;
-  std::vector<double> seg_scale;
-  auto add_group = [&](int nseg, int kind, int index0, double scale, auto key) {
+  // two-level segment sums: level-1 tasks of <= PT_SUBLEN polls (padded with the zero slot Npoll),
+  // level-2 one thread per segment
+  std::vector<int> sub16, seg_ptr{0}, seg_kind, seg_index;
+  std::vector<double> seg_scale, sub_wt16;
+  int nsub = 0;
+  auto add_group = [&](int nseg, int kind, int index0, double scale, bool weighted, auto key) {
     std::vector<std::vector<int>> lists(nseg);
     for (int i = 0; i < Np; i++) { const int k = key(i); if (k >= 0) lists[k].push_back(i); }
     for (int sgi = 0; sgi < nseg; sgi++) {
       const auto &l = lists[sgi];
       for (size_t a = 0; a < l.size(); a += PT_SUBLEN) {
-        for (size_t j = a; j < std::min(l.size(), a + PT_SUBLEN); j++) sub_idx.push_back(l[j]);
-        sub_ptr.push_back((int)sub_idx.size());
+        for (size_t j = a; j < a + PT_SUBLEN; j++) {
+          sub16.push_back(j < l.size() ? l[j] : Np);
+          if (weighted) sub_wt16.push_back(j < l.size() ? pu[l[j]] : 0.0);
+        }
+        nsub++;
       }
-      seg_ptr.push_back((int)sub_ptr.size() - 1);
+      seg_ptr.push_back(nsub);
       seg_kind.push_back(kind); seg_index.push_back(index0 + sgi); seg_scale.push_back(scale);
     }
   };
-  add_group(d->P, 0, L.o_c, d->sigma_c, [&](int i) { return pp[i]; });
+  add_group(d->P, 0, L.o_c, d->sigma_c, false, [&](int i) { return pp[i]; });
   if (full) {
-    add_group(d->M, 0, L.o_m, d->sigma_m, [&](int i) { return pm[i]; });
-    add_group(d->Pop, 0, L.o_pop, d->sigma_pop, [&](int i) { return ppop[i]; });
+    add_group(d->M, 0, L.o_m, d->sigma_m, false, [&](int i) { return pm[i]; });
+    add_group(d->Pop, 0, L.o_pop, d->sigma_pop, false, [&](int i) { return ppop[i]; });
   }
-  add_group(S + 1, 1, 0, 1.0, [&](int i) { return ps[i]; });
-  M.sub_weighted_begin = (int)sub_ptr.size() - 1;
-  if (full) add_group(T, 2, 0, 1.0, [&](int i) { return pt[i]; });
-  M.nsub = (int)sub_ptr.size() - 1;
+  add_group(S + 1, 1, 0, 1.0, false, [&](int i) { return ps[i]; });
+  M.sub_weighted_begin = nsub;
+  if (full) add_group(T, 2, 0, 1.0, true, [&](int i) { return pt[i]; });
+  M.nsub = nsub;
   M.nseg = (int)seg_kind.size();
-  if (!full) M.sub_weighted_begin = M.nsub;
+  seg_ptr.push_back(nsub); // so that seg_ptr[seg + 1] is loadable for every seg
 
   // LDS layout (doubles)
   int o = 0;
   auto take = [&](int n) { const int a = o; o += (n + 1) & ~1; return a; };
   M.l_C = take(std::max(S * M.TP, 2 * PT_NW * M.SE));
   M.l_Lw = take(M.SE * M.SP);
-  M.l_X = take(std::max(2 * PT_NW * M.SE, Np));
+  M.l_X = take(std::max(2 * PT_NW * M.SE, Np + 2));
   M.l_Y = take(std::max(PT_NW * M.SE, M.nsub));
-  M.l_zT = take(S); M.l_zb = take(S); M.l_mid = take(M.nmid);
+  M.l_zT = take(S + 1); M.l_zb = take(S + 1); M.l_mid = take(M.nmid + 1);
   M.l_bT = take(M.SE); M.l_pb = take(M.SE); M.l_e = take(T); M.l_gs = take(M.SE); M.l_ge = take(T);
   M.l_scal = take(SC_N); M.l_red = take(PT_NW * PT_NRED);
 #ifdef POTUS_PROF
@@ -486,12 +528,19 @@ int build_model(Sampler *sp, const potus_data *d) {
     pi[5 * M.Npad + i] = pq[i];
     pdv[i] = py[i]; pdv[M.Npad + i] = pn[i]; pdv[2 * M.Npad + i] = pu[i]; pdv[3 * M.Npad + i] = psig[i];
   }
-  std::vector<int> sched(day_ptr);
-  auto appi = [&](const std::vector<int> &v) { const int off = (int)sched.size(); sched.insert(sched.end(), v.begin(), v.end()); return off; };
-  M.c_wtp = appi(wave_task_ptr); M.c_td = appi(task_day); M.c_subptr = appi(sub_ptr); M.c_subidx = appi(sub_idx);
-  M.c_segptr = appi(seg_ptr); M.c_segkind = appi(seg_kind); M.c_segidx = appi(seg_index);
+  std::vector<int> sched(we_ptr);
+  auto appi = [&](const std::vector<int> &v) {
+    while (sched.size() % 4) sched.push_back(0);   // 16-byte aligned blocks (sub16 is read with 128-bit loads)
+    const int off = (int)sched.size();
+    sched.insert(sched.end(), v.begin(), v.end());
+    return off;
+  };
+  M.c_weidx = appi(we_idx); M.c_weday = appi(we_day); M.c_west = appi(we_state); M.c_mask = appi(daymask);
+  M.c_sub16 = appi(sub16); M.c_segptr = appi(seg_ptr); M.c_segkind = appi(seg_kind); M.c_segidx = appi(seg_index);
+  for (int k = 0; k < 8; k++) sched.push_back(0);
+  if (sub_wt16.empty()) sub_wt16.assign(2, 0.0);
   if ((rc = upload(sp, mat, &M.mat)) || (rc = upload(sp, pi, &M.pi)) || (rc = upload(sp, pdv, &M.pd)) ||
-      (rc = upload(sp, sched, &M.sched)) || (rc = upload(sp, seg_scale, &M.seg_scale)))
+      (rc = upload(sp, sched, &M.sched)) || (rc = upload(sp, seg_scale, &M.seg_scale)) || (rc = upload(sp, sub_wt16, &M.sub_wt16)))
     return rc;
   void *pdm = nullptr;
   HIP_TRY(hipMalloc(&pdm, sizeof(DevModel)));
@@ -627,6 +676,9 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
 #else
   R.prof = nullptr;
 #endif
+  if (hipMalloc(&p, sizeof(RunParams)) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for run parameters failed"));
+  sp->allocs.push_back(p); sp->dR = (RunParams *)p;
+  if (hipMemcpy(p, &R, sizeof(RunParams), hipMemcpyHostToDevice) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "upload of run parameters failed"));
   std::lock_guard<std::mutex> lk(g_mu);
   g_handles.push_back(sp);
   *handle = (int)g_handles.size() - 1;
@@ -672,7 +724,7 @@ int potus_init(int handle, const double *q0) {
   double *dq0 = nullptr;
   const size_t bytes = (size_t)sp->R.chains * sp->L.D * 8;
   if (q0) { HIP_TRY(hipMalloc((void **)&dq0, bytes)); HIP_TRY(hipMemcpyAsync(dq0, q0, bytes, hipMemcpyHostToDevice, sp->stream)); }
-  hipLaunchKernelGGL(k_init, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, sp->R, (const double *)dq0);
+  hipLaunchKernelGGL(k_init, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, (const double *)dq0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(sp->stream));
   if (dq0) (void)hipFree(dq0);
@@ -694,7 +746,7 @@ int potus_run(int handle, int n_iter) {
   potus_total_leapfrogs(handle, &before);
   int it0 = 0; potus_iterations_done(handle, &it0);
   HIP_TRY(hipEventRecord(sp->ev0, sp->stream));
-  hipLaunchKernelGGL(k_run, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, sp->R, n_iter);
+  hipLaunchKernelGGL(k_run, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, n_iter);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(sp->ev1, sp->stream));
   HIP_TRY(hipStreamSynchronize(sp->stream));

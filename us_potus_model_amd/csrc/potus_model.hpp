@@ -29,11 +29,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define PT_THREADS 1024
-#define PT_NW 16          // waves per workgroup
-#define PT_CH 16          // days per wave in the S x T block layout  (T <= PT_NW*PT_CH)
+#ifndef PT_NW
+#define PT_NW 8           // waves per workgroup: 8 -> two waves per SIMD, 256 VGPRs each (no spills)
+#endif
+#define PT_THREADS (64 * PT_NW)
+#define PT_CH (256 / PT_NW) // days per wave in the S x T block layout  (T <= 256)
+#define PT_KJ (64 / PT_NW)  // rows of a 51 x 51 factor handled per wave in the split mat-vecs
 #define PT_SUBLEN 16      // entries per level-1 segment-sum task
-#define PT_QB 8           // S x T elements per thread whose loads are issued together
 
 #define AS_G __attribute__((address_space(1)))
 #define AS_L __attribute__((address_space(3)))
@@ -43,6 +45,30 @@ typedef const double AS_G *gcdp;
 typedef const int AS_G *gcip;
 typedef double AS_L *ldp;
 template <class T> __device__ __forceinline__ T AS_G *as_g(T *p) { return (T AS_G *)p; }
+template <class T> __device__ __forceinline__ const T AS_C *as_c(const T *p) { return (const T AS_C *)p; }
+
+// Buffer addressing (SGPR resource + 32-bit VGPR byte offset + SGPR offset): one VGPR addresses the
+// same element of every vector of a chain, instead of a 64-bit VGPR pair per access.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ double bld(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ int bld_i(rsrc_t r, unsigned voff, unsigned soff) {
+  return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
+__device__ __forceinline__ u32x4 bld_i4(rsrc_t r, unsigned voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); }
+__device__ __forceinline__ void bld_d2(rsrc_t r, unsigned voff, unsigned soff, double &a, double &b) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  a = __hiloint2double((int)v[1], (int)v[0]); b = __hiloint2double((int)v[3], (int)v[2]);
+}
+__device__ __forceinline__ void bst(rsrc_t r, unsigned voff, unsigned soff, double v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+}
 
 struct DevModel {
   int S, T, P, M, Pop, Ns, Nn, Npoll, D, full;
@@ -57,9 +83,17 @@ struct DevModel {
   const int *pi;            // polls sorted by day, struct of arrays with stride Npad:
   const double *pd;         //   pi: ps | pt | pp | pm | ppop | pqidx      pd: py | pn | punadj | psig
   int Npad;
-  const int *sched;         // day_ptr [T+1] | wave_task_ptr [NW+1] | task_day [T] | sub_ptr | sub_idx | seg_ptr | seg_kind | seg_index
-  int c_wtp, c_td, c_subptr, c_subidx, c_segptr, c_segkind, c_segidx;  // offsets into sched (day_ptr at 0)
-  const double *seg_scale;
+  // Static schedule, built on the host (all offsets in ints into sched):
+  //   we_ptr [NW+1]          entries of wave w: [we_ptr[w], we_ptr[w+1])
+  //   we_idx | we_day | we_state   per entry: sorted poll index, its day, its (pseudo-)state; a wave's
+  //                          entries are grouped by day, days balanced over waves (LPT)
+  //   daymask [NW]           bit j of word w: day 16w+j has at least one poll
+  //   sub16 [nsub][16]       level-1 segment-sum tasks: poll indices, padded with Npoll (a zero slot)
+  //   seg_ptr [nseg+1] | seg_kind | seg_index   level-2: range of tasks, what the sum feeds
+  const int *sched;
+  int c_weidx, c_weday, c_west, c_mask, c_sub16, c_segptr, c_segkind, c_segidx;
+  const double *seg_scale;  // [nseg]
+  const double *sub_wt16;   // [(nsub - sub_weighted_begin)][16] weights of the weighted tasks (0 for padding)
   int nsub, nseg, sub_weighted_begin;
   // LDS layout, offsets in doubles
   int l_C, l_Lw, l_X, l_Y, l_zT, l_zb, l_mid, l_bT, l_pb, l_e, l_gs, l_ge, l_scal, l_red, l_prof;
@@ -113,20 +147,26 @@ __device__ __forceinline__ void block_sum(double (&v)[N], ldp red, int tid) {
 // Policy API: q_load/q_fin fetch one position element (split so that callers can issue a batch
 // of loads before the first dependent store); g_load/g_fin consume one gradient element;
 // g_load_q additionally returns the position again (t.q).
+// All element accesses take the element's BYTE offset (8*index) or PT_OOB: buffer loads beyond the
+// resource return 0 and stores are dropped, so masked-off elements need no branch -- which matters,
+// because the compiler drains the whole memory queue (s_waitcnt vmcnt(0)) at every branch join.
+#define PT_OOB 0xFFFFFF00u
 struct PlainPolicy {
-  gcdp q_;
-  gdp g_;
+  rsrc_t rq, rg;        // buffers holding q and receiving grad (may be the same buffer)
+  unsigned sq, sg;      // byte offsets of the two vectors inside them
   static constexpr int NEXTRA = 0;
+  static constexpr int QB = 16;
   double extra[1];  // unused
   struct QT { double q; };
   struct GT { double q; };
-  __device__ __forceinline__ void q_load(int i, QT &t) { t.q = q_[i]; }
-  __device__ __forceinline__ double q_fin(int, const QT &t) { return t.q; }
-  __device__ __forceinline__ void g_load(int, GT &) {}
-  __device__ __forceinline__ void g_load_q(int i, GT &t) { t.q = q_[i]; }
-  __device__ __forceinline__ void g_fin(int i, double v, const GT &) { g_[i] = v; }
-  __device__ __forceinline__ double q(int i) { return q_[i]; }
-  __device__ __forceinline__ void g(int i, double v) { g_[i] = v; }
+  __device__ __forceinline__ void q_load(unsigned vo, QT &t) { t.q = bld(rq, vo, sq); }
+  __device__ __forceinline__ double q_fin(unsigned, QT &t) { return t.q; }
+  __device__ __forceinline__ void g_load(unsigned, GT &) {}
+  __device__ __forceinline__ void g_load_q(unsigned vo, GT &t) { t.q = bld(rq, vo, sq); }
+  __device__ __forceinline__ void g_from_q(const QT &, GT &) {}   // same thread did q_load earlier in the pass
+  __device__ __forceinline__ void g_fin(unsigned vo, double v, const GT &) { bst(rg, vo, sg, v); }
+  __device__ __forceinline__ double q(int i) { return bld(rq, 8u * i, sq); }
+  __device__ __forceinline__ void g(int i, double v) { bst(rg, 8u * i, sg, v); }
 };
 
 // Stage the (S+1) x S walk factor in LDS once per kernel; it stays resident across passes.
@@ -170,36 +210,52 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
 
   // ---------------- phase A: small parameters, then the S x T block with local suffix sums
   {
-    // raw_mu_b_T / raw_polling_bias: wave w owns k = w, w+16, ... and starts both mat-vecs
-    double vT = 0.0, vB = 0.0;
+    // raw_mu_b_T / raw_polling_bias (wave w owns k = w, w+16, ... and starts both mat-vecs) and the
+    // parameters between the S x T block and the noise blocks: every load issued up front, no branches
     const int kk = w + PT_NW * lane;
-    if (lane < 4 && kk < S) {
-      vT = pol.q(M->o_zT + kk);
-      vB = pol.q(M->o_zb + kk);
-      s_zT[kk] = vT;
-      s_zb[kk] = vB;
-      lp -= 0.5 * (vT * vT + vB * vB);          // stan:117,128
+    const bool okz = lane < PT_KJ && kk < S;
+    const unsigned vzT = okz ? 8u * (unsigned)(M->o_zT + kk) : PT_OOB, vzb = okz ? 8u * (unsigned)(M->o_zb + kk) : PT_OOB;
+    typename Pol::QT qa, qb, qm;
+    pol.q_load(vzT, qa);
+    pol.q_load(vzb, qb);
+    const int nmid = M->nmid, o_mue = M->o_mue, o_rho = M->o_rho;
+    const unsigned vmid = tid < nmid ? 8u * (unsigned)(o_c + tid) : PT_OOB;
+    pol.q_load(vmid, qm);
+    const rsrc_t rm = make_rsrc(M->mat, 8u * (unsigned)(M->m_w + S));
+    const unsigned sLT = 8u * (unsigned)M->m_LTt, sLB = 8u * (unsigned)M->m_LBt;
+    double lt[PT_KJ], lb[PT_KJ];
+#pragma unroll
+    for (int j = 0; j < PT_KJ; j++) {
+      const int k = w + PT_NW * j;
+      const unsigned vo = (k < S && lane < S) ? 8u * (unsigned)(k * S + lane) : PT_OOB;
+      lt[j] = bld(rm, vo, sLT);                 // L_T[lane][k], stan:85
+      lb[j] = bld(rm, vo, sLB);                 // L_B[lane][k], stan:77
     }
-    gcdp LT_t = as_g(M->mat) + M->m_LTt, LB_t = as_g(M->mat) + M->m_LBt;
+    const double vT = pol.q_fin(vzT, qa), vB = pol.q_fin(vzb, qb); // 0 on masked lanes
+    const int kz = okz ? kk : S;                // masked lanes write the spare slot
+    s_zT[kz] = vT;
+    s_zb[kz] = vB;
+    lp -= 0.5 * (vT * vT + vB * vB);            // stan:117,128
+    {
+      const double v = pol.q_fin(vmid, qm);
+      const int idx = o_c + tid;
+      s_mid[tid < nmid ? tid : nmid] = v;
+      if (!(full && (idx == o_mue || idx == o_rho))) lp -= 0.5 * v * v; // stan:120-122,125
+    }
     double pT = 0.0, pB = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int k = w + PT_NW * j;
-      const double a = __shfl(vT, j, 64), b = __shfl(vB, j, 64);
-      if (k < S && lane < S) {
-        pT += LT_t[k * S + lane] * a;           // stan:85
-        pB += LB_t[k * S + lane] * b;           // stan:77
-      }
+    for (int j = 0; j < PT_KJ; j++) {
+      pT += lt[j] * __shfl(vT, j, 64);
+      pB += lb[j] * __shfl(vB, j, 64);
     }
-    if (lane < S) { X[w * SE + lane] = pT; X[(PT_NW + w) * SE + lane] = pB; }
-  }
-  {
-    const int nmid = M->nmid, o_mue = M->o_mue, o_rho = M->o_rho;
-    for (int i = tid; i < nmid; i += PT_THREADS) {
+    const int sx = lane < S ? lane : S;         // X rows are SE = S+1 wide
+    X[w * SE + sx] = pT;
+    X[(PT_NW + w) * SE + sx] = pB;
+    for (int i = tid + PT_THREADS; i < nmid; i += PT_THREADS) { // only when there are more than 1024 such parameters
       const int idx = o_c + i;
       const double v = pol.q(idx);
       s_mid[i] = v;
-      if (!(full && (idx == o_mue || idx == o_rho))) lp -= 0.5 * v * v; // stan:120-122,125
+      if (!(full && (idx == o_mue || idx == o_rho))) lp -= 0.5 * v * v;
     }
   }
   double cs[PT_CH];
@@ -207,14 +263,19 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
     const int t0 = w * PT_CH;
     double run = 0.0;
 #pragma unroll
-    for (int h = PT_CH - PT_QB; h >= 0; h -= PT_QB) { // batches from the last day backwards: loads of a batch issue before its stores
-      typename Pol::QT qt[PT_QB];
+    for (int h = PT_CH - Pol::QB; h >= 0; h -= Pol::QB) { // batches from the last day backwards; no branches inside
+      typename Pol::QT qt[Pol::QB];
+      unsigned vo[Pol::QB];
 #pragma unroll
-      for (int j = 0; j < PT_QB; j++) if (lane < S && t0 + h + j < T) pol.q_load(o_Z + lane + S * (t0 + h + j), qt[j]);
-#pragma unroll
-      for (int j = PT_QB - 1; j >= 0; j--) {
+      for (int j = 0; j < Pol::QB; j++) {
         const int t = t0 + h + j;
-        const double z = (lane < S && t < T) ? pol.q_fin(o_Z + lane + S * t, qt[j]) : 0.0;
+        vo[j] = (lane < S && t < T) ? 8u * (unsigned)(o_Z + lane + S * t) : PT_OOB;
+        pol.q_load(vo[j], qt[j]);
+      }
+#pragma unroll
+      for (int j = Pol::QB - 1; j >= 0; j--) {
+        const int t = t0 + h + j;
+        const double z = pol.q_fin(vo[j], qt[j]);  // 0 for masked-off elements
         lp -= 0.5 * z * z;                      // to_vector(raw_mu_b) ~ std_normal(), stan:119
         run += (t < T - 1) ? z : 0.0;           // column T is not part of the walk (stan:86)
         cs[h + j] = run;
@@ -284,64 +345,134 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
 
   // ---------------- phase C: one thread per poll (stan:95-112, 130-131)
   ldp r_lds = X;
+  if (tid == 0) r_lds[M->Npoll] = 0.0;
   {
-    const int Npad = M->Npad;
-    gcip ps = as_g(M->pi), pt = ps + Npad, pp = ps + 2 * Npad, pm = ps + 3 * Npad, ppop = ps + 4 * Npad, pqidx = ps + 5 * Npad;
-    gcdp py = as_g(M->pd), pn = py + Npad, punadj = py + 2 * Npad, psig = py + 3 * Npad;
+    const unsigned Npad = M->Npad;
+    const rsrc_t rpi = make_rsrc(M->pi, 6u * Npad * 4u), rpd = make_rsrc(M->pd, 4u * Npad * 8u);
     const int Npoll = M->Npoll, om = M->o_m - o_c, opop = M->o_pop - o_c;
     const double sigma_c = M->sigma_c, sigma_m = M->sigma_m, sigma_pop = M->sigma_pop;
-    for (int i = tid; i < Npoll; i += PT_THREADS) {
-      const int s = ps[i], t = pt[i], qi = pqidx[i], ip = pp[i];
-      const double y = py[i], N = pn[i], sg = psig[i];
-      const double zn = pol.q(qi);
-      double eta = s_bT[s] + s_pb[s] + sg * zn + sigma_c * s_mid[ip];
-      if (full) eta += sigma_m * s_mid[om + pm[i]] + sigma_pop * s_mid[opop + ppop[i]] + punadj[i] * s_e[t];
-      ldp Lrow = Lw + s * SP, Ccol = C + t;
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      int k = 0;
-      for (; k + 3 < S; k += 4) {
-        a0 += Lrow[k] * Ccol[k * TP];
-        a1 += Lrow[k + 1] * Ccol[(k + 1) * TP];
-        a2 += Lrow[k + 2] * Ccol[(k + 2) * TP];
-        a3 += Lrow[k + 3] * Ccol[(k + 3) * TP];
+    for (int i0 = 0; i0 < Npoll; i0 += 2 * PT_THREADS) {   // two polls per thread per trip, no branches inside
+      int s[2], t[2], ip[2], qi[2], im[2], ipop[2];
+      double un[2], y[2], N[2], sg[2];
+      unsigned vq[2];
+      typename Pol::QT qt[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int i = i0 + u * PT_THREADS + tid;
+        const bool ok = i < Npoll;
+        const unsigned vi = ok ? 4u * i : PT_OOB, vd = ok ? 8u * i : PT_OOB;   // masked polls read zeros: N = y = 0
+        s[u] = bld_i(rpi, vi, 0); t[u] = bld_i(rpi, vi, 4u * Npad); ip[u] = bld_i(rpi, vi, 8u * Npad); qi[u] = bld_i(rpi, vi, 20u * Npad);
+        im[u] = 0; ipop[u] = 0; un[u] = 0.0;
+        if (full) { im[u] = bld_i(rpi, vi, 12u * Npad); ipop[u] = bld_i(rpi, vi, 16u * Npad); un[u] = bld(rpd, vd, 16u * Npad); }
+        y[u] = bld(rpd, vd, 0); N[u] = bld(rpd, vd, 8u * Npad); sg[u] = bld(rpd, vd, 24u * Npad);
       }
-      for (; k < S; k++) a0 += Lrow[k] * Ccol[k * TP];
-      eta += (a0 + a1) + (a2 + a3);
-      const double r = y - N * d_inv_logit(eta);
-      lp += y * d_log_inv_logit(eta) + (N - y) * d_log_inv_logit(-eta) - 0.5 * zn * zn; // stan:126-127,130-131
-      r_lds[i] = r;
-      pol.g(qi, sg * r - zn);
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int i = i0 + u * PT_THREADS + tid;
+        vq[u] = (i < Npoll) ? 8u * (unsigned)qi[u] : PT_OOB;
+        pol.q_load(vq[u], qt[u]);
+      }
+      ldp L0 = Lw + s[0] * SP, C0 = C + t[0], L1 = Lw + s[1] * SP, C1 = C + t[1];
+      double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+      int k = 0;
+      for (; k + 1 < S; k += 2) {
+        a0 += L0[k] * C0[k * TP];
+        b0 += L1[k] * C1[k * TP];
+        a1 += L0[k + 1] * C0[(k + 1) * TP];
+        b1 += L1[k + 1] * C1[(k + 1) * TP];
+      }
+      for (; k < S; k++) { a0 += L0[k] * C0[k * TP]; b0 += L1[k] * C1[k * TP]; }
+      const double dot[2] = {a0 + a1, b0 + b1};
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int i = i0 + u * PT_THREADS + tid;
+        const double zn = pol.q_fin(vq[u], qt[u]);
+        double eta = s_bT[s[u]] + s_pb[s[u]] + sg[u] * zn + sigma_c * s_mid[ip[u]] + dot[u];
+        if (full) eta += sigma_m * s_mid[om + im[u]] + sigma_pop * s_mid[opop + ipop[u]] + un[u] * s_e[t[u]];
+        // binomial_logit with one exp, one log1p, one division:  e = exp(-|eta|), l = log1p(e)
+        //   log inv_logit(eta) = min(eta,0) - l,  log inv_logit(-eta) = min(-eta,0) - l,
+        //   inv_logit(eta) = (eta >= 0 ? 1 : e) / (1 + e)
+        const double ex = exp(-fabs(eta)), l1 = log1p(ex), pr = (eta >= 0.0 ? 1.0 : ex) / (1.0 + ex);
+        const double r = y[u] - N[u] * pr;
+        lp += y[u] * (fmin(eta, 0.0) - l1) + (N[u] - y[u]) * (fmin(-eta, 0.0) - l1) - 0.5 * zn * zn; // stan:126-127,130-131
+        r_lds[i < Npoll ? i : Npoll + 1] = r;    // slot Npoll stays 0 (padding of the task lists), Npoll+1 is a dump
+        typename Pol::GT gt;
+        pol.g_from_q(qt[u], gt);
+        pol.g_fin(vq[u], sg[u] * r - zn, gt);
+      }
     }
   }
   __syncthreads();
   PROF_MARK(2);
 
   // ---------------- phase D: per-day gathers gC[:,t] = sum_i r_i Lw_ext[s_i,:]; level-1 segment sums
+  // level-2 metadata for phase E is requested first so that its latency hides behind the gathers
+  const rsrc_t rsc = make_rsrc(M->sched, 0x7ffffff0u);
+  int sg_a = 0, sg_b = 0, sg_kind = 1, sg_index = 0;
+  double sg_scale = 0.0;
+  typename Pol::GT sg_gt;
+  unsigned sg_vg = PT_OOB;
   {
-    gcip day_ptr = as_g(M->sched), wave_task_ptr = day_ptr + M->c_wtp, task_day = day_ptr + M->c_td, ps = as_g(M->pi);
-    const int ta = wave_task_ptr[w], tb = wave_task_ptr[w + 1];
-    const int lk = lane < S ? lane : 0;
-    for (int ti = ta; ti < tb; ti++) {
-      const int t = __builtin_amdgcn_readfirstlane(task_day[ti]);
-      const int a = __builtin_amdgcn_readfirstlane(day_ptr[t]), b = __builtin_amdgcn_readfirstlane(day_ptr[t + 1]);
-      double acc = 0.0;
-      for (int i = a; i < b; i++) {
-        const int s = __builtin_amdgcn_readfirstlane(ps[i]);
-        acc += r_lds[i] * Lw[s * SP + lk];
-      }
-      if (lane < S) C[lane * TP + t] = acc;
-    }
+    const int nseg = M->nseg;
+    const unsigned vs = tid < nseg ? 4u * (unsigned)tid : PT_OOB;
+    sg_a = bld_i(rsc, vs, 4u * (unsigned)M->c_segptr);
+    sg_b = bld_i(rsc, vs, 4u * (unsigned)M->c_segptr + 4u);
+    sg_kind = tid < nseg ? bld_i(rsc, vs, 4u * (unsigned)M->c_segkind) : 1;
+    sg_index = bld_i(rsc, vs, 4u * (unsigned)M->c_segidx);
+    const rsrc_t rss = make_rsrc(M->seg_scale, 8u * (unsigned)nseg);
+    sg_scale = bld(rss, tid < nseg ? 8u * (unsigned)tid : PT_OOB, 0);
+    sg_vg = (tid < nseg && sg_kind == 0) ? 8u * (unsigned)sg_index : PT_OOB;
+    pol.g_load(sg_vg, sg_gt);
   }
   {
-    gcip sub_ptr = as_g(M->sched) + M->c_subptr, sub_idx = as_g(M->sched) + M->c_subidx;
-    gcdp punadj = as_g(M->pd) + 2 * M->Npad;
+    const int AS_C *we_ptr = as_c(M->sched);
+    const unsigned o_idx = 4u * (unsigned)M->c_weidx, o_day = 4u * (unsigned)M->c_weday, o_st = 4u * (unsigned)M->c_west;
+    const int e0 = we_ptr[w], e1 = we_ptr[w + 1], Npoll = M->Npoll;
+    const int lk = lane < S ? lane : 0;
+    double acc = 0.0;
+    int cur_t = -1;
+    for (int c0 = e0; c0 < e1; c0 += 64) {     // this wave's polls, 64 at a time: one per lane, then broadcast
+      const int nb = min(64, e1 - c0);
+      const unsigned ve = lane < nb ? 4u * (unsigned)(c0 + lane) : PT_OOB;
+      const int ei = bld_i(rsc, ve, o_idx), et = bld_i(rsc, ve, o_day), es = bld_i(rsc, ve, o_st);
+      const double rv = r_lds[lane < nb ? ei : Npoll];
+      const int rlo = __double2loint(rv), rhi = __double2hiint(rv);
+      for (int j = 0; j < nb; j++) {
+        const int t = __builtin_amdgcn_readlane(et, j), s = __builtin_amdgcn_readlane(es, j);
+        const double r = __hiloint2double(__builtin_amdgcn_readlane(rhi, j), __builtin_amdgcn_readlane(rlo, j));
+        if (t != cur_t) {
+          if (cur_t >= 0 && lane < S) C[lane * TP + cur_t] = acc;
+          acc = 0.0;
+          cur_t = t;
+        }
+        acc += r * Lw[s * SP + lk];
+      }
+    }
+    if (cur_t >= 0 && lane < S) C[lane * TP + cur_t] = acc;
+  }
+  {
     const int nsub = M->nsub, wb = M->sub_weighted_begin;
-    for (int sub = tid; sub < nsub; sub += PT_THREADS) {
-      const int a = sub_ptr[sub], b = sub_ptr[sub + 1];
+    const unsigned o_sub = 4u * (unsigned)M->c_sub16;
+    const rsrc_t rwt = make_rsrc(M->sub_wt16, 8u * 16u * (unsigned)(nsub - wb) + 16u);
+    for (int sub0 = 0; sub0 < nsub; sub0 += PT_THREADS) {
+      const int sub = sub0 + tid;
+      const bool ok = sub < nsub, wtd = ok && sub >= wb;
+      const unsigned vs = ok ? 64u * (unsigned)sub : PT_OOB, vw = wtd ? 128u * (unsigned)(sub - wb) : PT_OOB;
+      u32x4 ix[4];
+      double wt[PT_SUBLEN];
+#pragma unroll
+      for (int j = 0; j < 4; j++) ix[j] = bld_i4(rsc, vs + 16u * j, o_sub);
+#pragma unroll
+      for (int j = 0; j < PT_SUBLEN / 2; j++) bld_d2(rwt, vw + 16u * j, 0, wt[2 * j], wt[2 * j + 1]);
       double sum = 0.0;
-      if (sub >= wb) for (int j = a; j < b; j++) { const int i = sub_idx[j]; sum += r_lds[i] * punadj[i]; }
-      else for (int j = a; j < b; j++) sum += r_lds[sub_idx[j]];
-      Y[sub] = sum;
+      if (wtd) {
+#pragma unroll
+        for (int j = 0; j < PT_SUBLEN; j++) sum += r_lds[ix[j >> 2][j & 3]] * wt[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < PT_SUBLEN; j++) sum += r_lds[ok ? ix[j >> 2][j & 3] : 0];
+      }
+      if (ok) Y[sub] = sum;
     }
   }
   __syncthreads();
@@ -351,27 +482,30 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
   double pre[PT_CH];
   {
     const int t0 = w * PT_CH;
+    const unsigned mask = (unsigned)(as_c(M->sched) + M->c_mask)[w];   // days of this wave that have polls
     double run = 0.0;
 #pragma unroll
     for (int j = 0; j < PT_CH; j++) {
       const int t = t0 + j;
-      if (lane < S && t < T - 1) run += C[lane * TP + t];
+      if (((mask >> j) & 1u) && lane < S && t < T - 1) run += C[lane * TP + t];
       pre[j] = run;
     }
     if (lane < S) X[w * SE + lane] = run;  // r_lds is dead from here on
   }
   {
-    gcip seg_ptr = as_g(M->sched) + M->c_segptr, seg_kind = as_g(M->sched) + M->c_segkind, seg_index = as_g(M->sched) + M->c_segidx;
-    gcdp seg_scale = as_g(M->seg_scale);
+    double sum = 0.0;
+    for (int j = sg_a; j < sg_b; j++) sum += Y[j];
+    if (sg_kind == 0) pol.g_fin(sg_vg, sg_scale * sum - s_mid[sg_index - o_c], sg_gt);
+    else if (tid < M->nseg) { if (sg_kind == 1) s_gs[sg_index] = sum; else s_ge[sg_index] = sum; }
     const int nseg = M->nseg;
-    for (int seg = tid; seg < nseg; seg += PT_THREADS) {
-      const int a = seg_ptr[seg], b = seg_ptr[seg + 1];
-      double sum = 0.0;
-      for (int j = a; j < b; j++) sum += Y[j];
-      const int kind = seg_kind[seg], index = seg_index[seg];
-      if (kind == 0) pol.g(index, seg_scale[seg] * sum - s_mid[index - o_c]);
-      else if (kind == 1) s_gs[index] = sum;
-      else s_ge[index] = sum;
+    for (int seg = tid + PT_THREADS; seg < nseg; seg += PT_THREADS) {   // only with more than 1024 segments
+      const int AS_C *sc = as_c(M->sched);
+      const int a = sc[M->c_segptr + seg], b = sc[M->c_segptr + seg + 1], kind = sc[M->c_segkind + seg], index = sc[M->c_segidx + seg];
+      double s2 = 0.0;
+      for (int j = a; j < b; j++) s2 += Y[j];
+      if (kind == 0) pol.g(index, as_g(M->seg_scale)[seg] * s2 - s_mid[index - o_c]);
+      else if (kind == 1) s_gs[index] = s2;
+      else s_ge[index] = s2;
     }
   }
   __syncthreads();
@@ -383,14 +517,19 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
     for (int w2 = 0; w2 < w; w2++) carry += X[w2 * SE + lane];
     const int t0 = w * PT_CH;
 #pragma unroll
-    for (int h = 0; h < PT_CH; h += PT_QB) {
-      typename Pol::GT gt[PT_QB];
+    for (int h = 0; h < PT_CH; h += Pol::QB) {
+      typename Pol::GT gt[Pol::QB];
+      unsigned vo[Pol::QB];
 #pragma unroll
-      for (int j = 0; j < PT_QB; j++) if (t0 + h + j < T) pol.g_load_q(o_Z + lane + S * (t0 + h + j), gt[j]);
-#pragma unroll
-      for (int j = 0; j < PT_QB; j++) {
+      for (int j = 0; j < Pol::QB; j++) {
         const int t = t0 + h + j;
-        if (t < T) pol.g_fin(o_Z + lane + S * t, (t < T - 1 ? pre[h + j] + carry : 0.0) - gt[j].q, gt[j]);
+        vo[j] = (t < T) ? 8u * (unsigned)(o_Z + lane + S * t) : PT_OOB;
+        pol.g_load_q(vo[j], gt[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < Pol::QB; j++) {
+        const int t = t0 + h + j;
+        pol.g_fin(vo[j], (t < T - 1 ? pre[h + j] + carry : 0.0) - gt[j].q, gt[j]);
       }
     }
   }
@@ -400,7 +539,7 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
     double pT = 0.0, pB = 0.0;
     const double gnat = s_gs[S];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < PT_KJ; j++) {
       const int s = w + PT_NW * j;
       if (s < S && lane < S) {
         const double G = s_gs[s] + wv[s] * gnat;

@@ -27,6 +27,8 @@
 #pragma once
 #include "potus_model.hpp"
 
+extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+
 #define PT_MAXD 12
 #define PT_NPP (2 * PT_MAXD + 4)
 #define PT_NPQ (PT_MAXD + 4)
@@ -63,6 +65,16 @@ struct RunParams {
   double *draws;           // [chains][n_save_max][7 + D]
   double *prof;            // [chains][PT_NPROF] (POTUS_PROF builds) or null
 };
+
+typedef const RunParams AS_C *CRp;
+
+// make a value provably wave-uniform (arguments of non-inlined functions arrive in VGPRs)
+__device__ __forceinline__ unsigned uni32(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class P> __device__ __forceinline__ P uni_ptr(P p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = uni32((unsigned)v), hi = uni32((unsigned)(v >> 32));
+  return (P)(((unsigned long long)hi << 32) | lo);
+}
 
 struct TS { // transition state, LDS
   double H0, lsw, sum_metro, eps;
@@ -117,33 +129,37 @@ __device__ __forceinline__ void rng_normal_pair(const RngKey &K, uint32_t iter, 
 // G holds grad lp.  The full-step momentum is also written to the leaf's pool slot and the
 // kinetic energy sum_i minv_i p_i^2 is accumulated for the Hamiltonian.
 struct LeapPolicy {
-  gdp Q, P, G;
-  gcdp minv;
-  gdp leafp;
+  rsrc_t r;                       // the chain's state block
+  unsigned sQ, sP, sG, sM, sL;    // byte offsets of position, momentum, gradient, inverse metric, leaf slot
   double he, e;
   static constexpr int NEXTRA = 1;
+  static constexpr int QB = 8;
   double extra[1];
   struct QT { double p, g, q, m; };
   struct GT { double p, m, q; };
-  __device__ __forceinline__ void q_load(int i, QT &t) { t.p = P[i]; t.g = G[i]; t.q = Q[i]; t.m = minv[i]; }
-  __device__ __forceinline__ double q_fin(int i, const QT &t) {
+  __device__ __forceinline__ void q_load(unsigned vo, QT &t) {
+    t.p = bld(r, vo, sP); t.g = bld(r, vo, sG); t.q = bld(r, vo, sQ); t.m = bld(r, vo, sM);
+  }
+  __device__ __forceinline__ double q_fin(unsigned vo, QT &t) {
     const double ph = t.p + he * t.g;
-    P[i] = ph;
+    t.p = ph;
+    bst(r, vo, sP, ph);
     const double qn = t.q + e * t.m * ph;
-    Q[i] = qn;
+    bst(r, vo, sQ, qn);
     return qn;
   }
-  __device__ __forceinline__ void g_load(int i, GT &t) { t.p = P[i]; t.m = minv[i]; }
-  __device__ __forceinline__ void g_load_q(int i, GT &t) { t.p = P[i]; t.m = minv[i]; t.q = Q[i]; }
-  __device__ __forceinline__ void g_fin(int i, double v, const GT &t) {
-    G[i] = v;
+  __device__ __forceinline__ void g_load(unsigned vo, GT &t) { t.p = bld(r, vo, sP); t.m = bld(r, vo, sM); }
+  __device__ __forceinline__ void g_load_q(unsigned vo, GT &t) { t.p = bld(r, vo, sP); t.m = bld(r, vo, sM); t.q = bld(r, vo, sQ); }
+  __device__ __forceinline__ void g_from_q(const QT &q, GT &t) { t.p = q.p; t.m = q.m; } // q.p is the half-step momentum after q_fin
+  __device__ __forceinline__ void g_fin(unsigned vo, double v, const GT &t) {
+    bst(r, vo, sG, v);
     const double pf = t.p + he * v;
-    P[i] = pf;
-    leafp[i] = pf;
-    extra[0] += t.m * pf * pf;
+    bst(r, vo, sP, pf);
+    bst(r, vo, sL, pf);
+    extra[0] += t.m * pf * pf;   // masked-off elements loaded m = 0
   }
-  __device__ __forceinline__ double q(int i) { QT t; q_load(i, t); return q_fin(i, t); }
-  __device__ __forceinline__ void g(int i, double v) { GT t; g_load(i, t); g_fin(i, v, t); }
+  __device__ __forceinline__ double q(int i) { QT t; q_load(8u * i, t); return q_fin(8u * i, t); }
+  __device__ __forceinline__ void g(int i, double v) { GT t; g_load(8u * i, t); g_fin(8u * i, v, t); }
 };
 
 struct Chain {
@@ -158,7 +174,9 @@ struct Chain {
 #ifdef POTUS_PROF
   ldp prof;
 #endif
+  rsrc_t st;   // buffer resource over this chain's whole state block
   __device__ __forceinline__ gdp vec(int slot) const { return base + (size_t)slot * Dpad; }
+  __device__ __forceinline__ unsigned soff(int slot) const { return (unsigned)slot * (unsigned)Dpad * 8u; }
   __device__ __forceinline__ ldp red() const { return lds + M->l_red; }
 };
 #ifdef POTUS_PROF
@@ -185,59 +203,62 @@ __device__ __forceinline__ void pool_free(unsigned &mask, int i) { if (i >= 0) m
 // ---------------------------------------------------------------- block-wide vector sweeps (all end with a barrier)
 // Each thread handles elements tid, tid+1024, ...; four elements are in flight per trip so the
 // loads of a trip are issued together (the sweeps are latency-, not bandwidth-limited).
-#define PT_UNR 4
+#define PT_UNR 8
 __device__ __forceinline__ int fresh_tid(const Chain &c) { // keeps per-thread index math inside the loop it belongs to
   int t = c.tid;
   asm volatile("" : "+v"(t));
   return t;
 }
-__device__ void vop_copy(const Chain &c, gdp dst, gcdp src) {
+__device__ __forceinline__ void vop_copy(const Chain &c, unsigned s_dst, unsigned s_src) {
   const int tid0 = fresh_tid(c);
   for (int base = tid0; base < c.D; base += PT_UNR * PT_THREADS) {
     double v[PT_UNR];
 #pragma unroll
-    for (int k = 0; k < PT_UNR; k++) { const int i = base + k * PT_THREADS; v[k] = i < c.D ? src[i] : 0.0; }
+    for (int k = 0; k < PT_UNR; k++) { const int i = base + k * PT_THREADS; v[k] = bld(c.st, i < c.D ? 8u * i : PT_OOB, s_src); }
 #pragma unroll
-    for (int k = 0; k < PT_UNR; k++) { const int i = base + k * PT_THREADS; if (i < c.D) dst[i] = v[k]; }
+    for (int k = 0; k < PT_UNR; k++) { const int i = base + k * PT_THREADS; bst(c.st, i < c.D ? 8u * i : PT_OOB, s_dst, v[k]); }
   }
   __syncthreads();
 }
 // diag_e_metric::sample_p: p_i = N(0,1) / sqrt(minv_i); returns sum_i minv_i p_i^2
-__device__ double vop_momentum(const Chain &c, gdp P, uint32_t iter, uint32_t purpose, uint32_t aux) {
-  gcdp minv = c.vec(V_MINV);
+__device__ __forceinline__ double vop_momentum(const Chain &c, unsigned sP, uint32_t iter, uint32_t purpose, uint32_t aux) {
+  const unsigned sM = c.soff(V_MINV);
   double v[1] = {0.0};
   const int tid0 = fresh_tid(c);
   for (int j = tid0; 2 * j < c.D; j += PT_THREADS) {
     const bool two = 2 * j + 1 < c.D;
-    const double m0 = minv[2 * j], m1 = two ? minv[2 * j + 1] : 1.0;
+    const double m0 = bld(c.st, 16u * j, sM), m1 = two ? bld(c.st, 16u * j + 8u, sM) : 1.0;
     double a, b;
     rng_normal_pair(c.key, iter, purpose, aux, (uint32_t)j, a, b);
-    P[2 * j] = a / sqrt(m0);
+    bst(c.st, 16u * j, sP, a / sqrt(m0));
     v[0] += a * a;
-    if (two) { P[2 * j + 1] = b / sqrt(m1); v[0] += b * b; }
+    if (two) { bst(c.st, 16u * j + 8u, sP, b / sqrt(m1)); v[0] += b * b; }
   }
   block_sum(v, c.red(), tid0);
   return v[0];
 }
 // One merge of an (init, final) pair of subtrees: the three checks of base_nuts::build_tree /
 // transition need six metric-weighted dot products; also emits rho_init + rho_final.
-__device__ bool vop_merge(const Chain &c, gcdp a_beg, gcdp a_end, gcdp a_rho, gcdp b_beg, gcdp b_end, gcdp b_rho, gdp out) {
-  gcdp minv = c.vec(V_MINV);
+__device__ __forceinline__ bool vop_merge(const Chain &c, unsigned a_beg, unsigned a_end, unsigned a_rho, unsigned b_beg, unsigned b_end,
+                                          unsigned b_rho, unsigned out) {
+  const unsigned sM = c.soff(V_MINV);
   double v[6] = {0, 0, 0, 0, 0, 0};
   const int tid0 = fresh_tid(c);
   for (int base = tid0; base < c.D; base += PT_UNR * PT_THREADS) {
     double mi[PT_UNR], ab[PT_UNR], ae[PT_UNR], ar[PT_UNR], bb[PT_UNR], be[PT_UNR], br[PT_UNR];
 #pragma unroll
     for (int k = 0; k < PT_UNR; k++) {
-      const int i = min(base + k * PT_THREADS, c.D - 1);
-      mi[k] = minv[i]; ab[k] = a_beg[i]; ae[k] = a_end[i]; ar[k] = a_rho[i]; bb[k] = b_beg[i]; be[k] = b_end[i]; br[k] = b_rho[i];
+      const int i = base + k * PT_THREADS;
+      const unsigned o = i < c.D ? 8u * i : PT_OOB;   // masked elements read zeros and add nothing
+      mi[k] = bld(c.st, o, sM); ab[k] = bld(c.st, o, a_beg); ae[k] = bld(c.st, o, a_end); ar[k] = bld(c.st, o, a_rho);
+      bb[k] = bld(c.st, o, b_beg); be[k] = bld(c.st, o, b_end); br[k] = bld(c.st, o, b_rho);
     }
 #pragma unroll
     for (int k = 0; k < PT_UNR; k++) {
       const int i = base + k * PT_THREADS;
-      if (i < c.D) {
+      {
         const double rs = ar[k] + br[k];
-        out[i] = rs;
+        bst(c.st, i < c.D ? 8u * i : PT_OOB, out, rs);
         const double sab = mi[k] * ab[k], sbe = mi[k] * be[k];
         v[0] += sab * rs;                 // p#_beg . rho_subtree
         v[1] += sbe * rs;                 // p#_end . rho_subtree
@@ -257,15 +278,17 @@ __device__ bool vop_merge(const Chain &c, gcdp a_beg, gcdp a_end, gcdp a_rho, gc
 // ---------------------------------------------------------------- one NUTS transition (base_nuts::transition)
 // On return ts->sample_qid names the pool slot holding the new sample, ts->out_lp / out_h its
 // log density and Hamiltonian, ts->accept_stat the adaptation statistic.
-__device__ void nuts_transition(const Chain &c, uint32_t iter) {
+// Part 1 (once per transition, kept out of line): momentum refresh, Hamiltonian at the start
+// point, both trajectory ends := start point.
+__device__ __forceinline__ void transition_begin(const Chain &c, uint32_t iter) {
   ltp ts = c.ts;
   const int tid = c.tid;
   const double eps = c.sc->nom_eps; // sample_stepsize(): no jitter
   CPROF_START(c);
 
-  const double kin0 = vop_momentum(c, c.vec(V_P0), iter, RNG_MOMENTUM, 0);
+  const double kin0 = vop_momentum(c, c.soff(V_P0), iter, RNG_MOMENTUM, 0);
   CPROF_MARK(c, PF_MOMENTUM);
-  PlainPolicy pp{c.vec(V_Q0), c.vec(V_G0), {0}};
+  PlainPolicy pp{c.st, c.st, c.soff(V_Q0), c.soff(V_G0), {0}};
   const double lp0 = model_pass(c.M, c.lds, pp); // hamiltonian.init
   CPROF_START(c);
   if (tid == 0) {
@@ -278,21 +301,36 @@ __device__ void nuts_transition(const Chain &c, uint32_t iter) {
   }
   __syncthreads();
   {
-    gdp rt = c.vec(V_RHOTOP), qs = c.vec(V_POOLQ + ts->sample_qid);
-    gdp Q0 = c.vec(V_Q0), Q1 = c.vec(V_Q1), P0 = c.vec(V_P0), P1 = c.vec(V_P1), G0 = c.vec(V_G0), G1 = c.vec(V_G1);
+    const unsigned s_rt = c.soff(V_RHOTOP), s_qs = c.soff(V_POOLQ + ts->sample_qid);
     const int tid0 = fresh_tid(c);
     for (int base = tid0; base < c.D; base += PT_UNR * PT_THREADS) {
       double q[PT_UNR], p[PT_UNR], g[PT_UNR];
 #pragma unroll
-      for (int k = 0; k < PT_UNR; k++) { const int i = min(base + k * PT_THREADS, c.D - 1); q[k] = Q0[i]; p[k] = P0[i]; g[k] = G0[i]; }
+      for (int k = 0; k < PT_UNR; k++) {
+        const int i = base + k * PT_THREADS;
+        const unsigned o = i < c.D ? 8u * i : PT_OOB;
+        q[k] = bld(c.st, o, c.soff(V_Q0)); p[k] = bld(c.st, o, c.soff(V_P0)); g[k] = bld(c.st, o, c.soff(V_G0));
+      }
 #pragma unroll
       for (int k = 0; k < PT_UNR; k++) {
         const int i = base + k * PT_THREADS;
-        if (i < c.D) { Q1[i] = q[k]; P1[i] = p[k]; G1[i] = g[k]; rt[i] = p[k]; qs[i] = q[k]; }
+        {
+          const unsigned o = i < c.D ? 8u * i : PT_OOB;
+          bst(c.st, o, c.soff(V_Q1), q[k]); bst(c.st, o, c.soff(V_P1), p[k]); bst(c.st, o, c.soff(V_G1), g[k]);
+          bst(c.st, o, s_rt, p[k]); bst(c.st, o, s_qs, q[k]);
+        }
       }
     }
   }
   CPROF_MARK(c, PF_INITCOPY);
+  __syncthreads();
+}
+
+// Part 2 (the hot loop, inlined into the kernel): doublings, leaves, merges.
+__device__ __forceinline__ void transition_tree(const Chain &c, uint32_t iter) {
+  ltp ts = c.ts;
+  const int tid = c.tid;
+  const double eps = ts->eps;
   while (true) {
     __syncthreads();
     if (ts->depth >= c.max_depth || ts->stop) break;
@@ -305,7 +343,7 @@ __device__ void nuts_transition(const Chain &c, uint32_t iter) {
     __syncthreads();
     const int dir = ts->dir;
     CPROF_START(c);
-    vop_copy(c, c.vec(V_PNEAR), c.vec(V_P0 + dir));
+    vop_copy(c, c.soff(V_PNEAR), c.soff(V_P0 + dir));
     CPROF_MARK(c, PF_PNEAR);
     bool valid = true;
     const int nleaf = 1 << depth;
@@ -313,7 +351,7 @@ __device__ void nuts_transition(const Chain &c, uint32_t iter) {
       if (tid == 0) { unsigned pm = ts->pmask; ts->leaf_id = pool_alloc(pm, PT_NPP); ts->pmask = pm; }
       __syncthreads();
       const double e = dir ? eps : -eps;
-      LeapPolicy lp{c.vec(V_Q0 + dir), c.vec(V_P0 + dir), c.vec(V_G0 + dir), c.vec(V_MINV), c.vec(V_POOLP + ts->leaf_id), 0.5 * e, e, {0.0}};
+      LeapPolicy lp{c.st, c.soff(V_Q0 + dir), c.soff(V_P0 + dir), c.soff(V_G0 + dir), c.soff(V_MINV), c.soff(V_POOLP + ts->leaf_id), 0.5 * e, e, {0.0}};
       const double lpv = model_pass(c.M, c.lds, lp);
       CPROF_START(c);
       CPROF_COUNT(c, PF_LEAVES);
@@ -337,11 +375,11 @@ __device__ void nuts_transition(const Chain &c, uint32_t iter) {
       const int m = ts->m;
       for (int j = 1; j <= m; j++) {
         const int ib = ts->pend_beg[j - 1], ie = ts->pend_end[j - 1], cb = ts->cur_beg, ce = ts->cur_end;
-        gcdp a_rho = j == 1 ? c.vec(V_POOLP + ib) : c.vec(V_RHOLEV + j - 1);
-        gcdp b_rho = j == 1 ? c.vec(V_POOLP + cb) : c.vec(V_SCR0 + ((j - 1) & 1));
-        gdp out = j == m ? c.vec(V_RHOLEV + j) : c.vec(V_SCR0 + (j & 1));
-        const bool persist = vop_merge(c, c.vec(V_POOLP + ib), c.vec(V_POOLP + ie), a_rho, c.vec(V_POOLP + cb),
-                                       c.vec(V_POOLP + ce), b_rho, out);
+        const unsigned a_rho = j == 1 ? c.soff(V_POOLP + ib) : c.soff(V_RHOLEV + j - 1);
+        const unsigned b_rho = j == 1 ? c.soff(V_POOLP + cb) : c.soff(V_SCR0 + ((j - 1) & 1));
+        const unsigned out = j == m ? c.soff(V_RHOLEV + j) : c.soff(V_SCR0 + (j & 1));
+        const bool persist = vop_merge(c, c.soff(V_POOLP + ib), c.soff(V_POOLP + ie), a_rho, c.soff(V_POOLP + cb),
+                                       c.soff(V_POOLP + ce), b_rho, out);
         CPROF_COUNT(c, PF_MERGES);
         if (tid == 0) {
           const double cur_lsw = ts->cur_lsw;
@@ -380,15 +418,15 @@ __device__ void nuts_transition(const Chain &c, uint32_t iter) {
         ts->pend_beg[m] = ts->cur_beg; ts->pend_end[m] = ts->cur_end; ts->pend_lsw[m] = ts->cur_lsw; ts->pend_prop[m] = prop;
       }
       __syncthreads();
-      if (ts->copy_q_id >= 0) vop_copy(c, c.vec(V_POOLQ + ts->copy_q_id), c.vec(V_Q0 + dir));
+      if (ts->copy_q_id >= 0) vop_copy(c, c.soff(V_POOLQ + ts->copy_q_id), c.soff(V_Q0 + dir));
       CPROF_MARK(c, PF_COPYQ);
     }
     if (!valid) break;
     // merge the finished subtree with the old trajectory (the checks at the end of transition())
     const int nb = ts->pend_beg[depth], ne = ts->pend_end[depth];
-    gcdp n_rho = depth == 0 ? c.vec(V_POOLP + nb) : c.vec(V_RHOLEV + depth);
-    const bool persist = vop_merge(c, c.vec(V_P1 - dir), c.vec(V_PNEAR), c.vec(V_RHOTOP), c.vec(V_POOLP + nb), c.vec(V_POOLP + ne),
-                                   n_rho, c.vec(V_RHOTOP));
+    const unsigned n_rho = depth == 0 ? c.soff(V_POOLP + nb) : c.soff(V_RHOLEV + depth);
+    const bool persist = vop_merge(c, c.soff(V_P1 - dir), c.soff(V_PNEAR), c.soff(V_RHOTOP), c.soff(V_POOLP + nb), c.soff(V_POOLP + ne),
+                                   n_rho, c.soff(V_RHOTOP));
     if (tid == 0) {
       ts->depth = depth + 1;
       const double lsw_sub = ts->pend_lsw[depth], lsw = ts->lsw;
@@ -405,22 +443,14 @@ __device__ void nuts_transition(const Chain &c, uint32_t iter) {
     CPROF_MARK(c, PF_MERGE);
   }
   __syncthreads();
-  if (tid == 0) {
-    ts->accept_stat = ts->sum_metro / (double)ts->n_leap;
-    ts->out_lp = ts->q_lp[ts->sample_qid];
-    ts->out_h = ts->q_h[ts->sample_qid];
-    c.sc->total_leapfrogs += ts->n_leap;
-    c.sc->n_divergent += ts->divergent;
-  }
-  __syncthreads();
 }
 
 // ---------------------------------------------------------------- base_hmc::init_stepsize
 // Works on end 1 as scratch; the chain's point is Q0 with gradient G0 (already evaluated).
-__device__ void init_stepsize(const Chain &c, uint32_t iter) {
+__device__ __forceinline__ void init_stepsize(const Chain &c, uint32_t iter) {
   ltp ts = c.ts;
   const int tid = c.tid;
-  gdp Q1 = c.vec(V_Q1), P1 = c.vec(V_P1), G1 = c.vec(V_G1);
+  gdp Q1 = c.vec(V_Q1), G1 = c.vec(V_G1);
   gcdp Q0 = c.vec(V_Q0), G0 = c.vec(V_G0);
   const double lp0 = c.sc->lp_cur;
   if (tid == 0) { ts->done = 0; ts->direction = 0; }
@@ -432,9 +462,9 @@ __device__ void init_stepsize(const Chain &c, uint32_t iter) {
   for (uint32_t attempt = 0;; attempt++) {
     const double eps = c.sc->nom_eps;
     for (int i = tid; i < c.D; i += PT_THREADS) { Q1[i] = Q0[i]; G1[i] = G0[i]; }
-    const double kin0 = vop_momentum(c, P1, iter, RNG_INIT_EPS, attempt);
+    const double kin0 = vop_momentum(c, c.soff(V_P1), iter, RNG_INIT_EPS, attempt);
     const double H0 = 0.5 * kin0 - lp0;
-    LeapPolicy lp{Q1, P1, G1, c.vec(V_MINV), c.vec(V_SCR0), 0.5 * eps, eps, {0.0}};
+    LeapPolicy lp{c.st, c.soff(V_Q1), c.soff(V_P1), c.soff(V_G1), c.soff(V_MINV), c.soff(V_SCR0), 0.5 * eps, eps, {0.0}};
     const double lpv = model_pass(c.M, c.lds, lp);
     if (tid == 0) {
       double h = 0.5 * lp.extra[0] - lpv;
@@ -460,7 +490,7 @@ __device__ void init_stepsize(const Chain &c, uint32_t iter) {
 
 // ---------------------------------------------------------------- adaptation (adapt_diag_e_nuts::transition)
 // qs: the new sample, already stored as the chain's point Q0 (its gradient G0 may be stale).
-__device__ void adapt_after_transition(const Chain &c, uint32_t iter, gcdp qs) {
+__device__ __forceinline__ void adapt_after_transition(const Chain &c, uint32_t iter, gcdp qs) {
   ltp ts = c.ts;
   gsc sc = c.sc;
   const int tid = c.tid;
@@ -526,7 +556,7 @@ __device__ void adapt_after_transition(const Chain &c, uint32_t iter, gcdp qs) {
   __syncthreads();
   if (end_window) {
     // init_stepsize starts from the current point: refresh its log density and gradient
-    PlainPolicy pol{c.vec(V_Q0), c.vec(V_G0), {0}};
+    PlainPolicy pol{c.st, c.st, c.soff(V_Q0), c.soff(V_G0), {0}};
     const double lpq = model_pass(c.M, c.lds, pol);
     if (tid == 0) sc->lp_cur = lpq;
     __syncthreads();
