@@ -40,4 +40,9 @@ for chains in chain_counts:
             print(f"  chain 0: leaves {leaves:.0f} merges {merges:.0f}; cycles per leaf by phase (clock64 ticks):")
             for k, nm in NAMES.items():
                 print(f"    {nm:16s} {p[k]/max(leaves,1):10.0f}  ({100*p[k]/tot:4.1f}%)")
+            sub = {18: "C: wave0 after dots (per trip sum)", 25: "C: wave0 at barrier", 19: "D: wave0 after prefetch issue", 20: "D: wave0 after gathers",
+                   21: "D: wave0 at barrier", 24: "E: wave0 at barrier", 22: "F: wave0 after dZ", 23: "F: wave0 at barrier", 26: "B: wave0 at barrier"}
+            passes = leaves + 1e-9
+            for k, nm in sub.items():
+                print(f"    [{nm:36s}] {p[k]/passes:10.0f}")
     h.close()

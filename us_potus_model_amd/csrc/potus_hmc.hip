@@ -20,11 +20,11 @@
 __global__ __launch_bounds__(PT_THREADS) void k_logprob_grad(const DevModel *Mg, const double *q, double *lp, double *grad, int n) {
   CMp M = (CMp)Mg;
   ldp lds = (ldp)lds_dyn;
-  model_setup_lds(M, lds);
+  const PassStatic pst = model_setup_lds(M, lds);
   const int D = M->D;
   for (int b = blockIdx.x; b < n; b += gridDim.x) {
     PlainPolicy pol{make_rsrc(q + (size_t)b * D, 8u * D), make_rsrc(grad + (size_t)b * D, 8u * D), 0u, 0u, {0}};
-    const double v = model_pass(M, lds, pol);
+    const double v = model_pass(M, lds, pst, pol);
     if (threadIdx.x == 0) lp[b] = v;
   }
 }
@@ -55,9 +55,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_init(const DevModel *Mg, const R
   CRp R = (CRp)Rg;
   const int chain = blockIdx.x;
   Chain c = make_chain(M, R, chain);
-  model_setup_lds(M, c.lds);
+  c.pst = model_setup_lds(M, c.lds);
   const int tid = c.tid;
-  gdp Q0 = c.vec(V_Q0), G0 = c.vec(V_G0), minv = c.vec(V_MINV), mean = c.vec(V_WMEAN), m2 = c.vec(V_WM2);
+  gdp Q0 = c.vec(V_QC), G0 = c.vec(V_GC), minv = c.vec(V_MINV), mean = c.vec(V_WMEAN), m2 = c.vec(V_WM2);
   for (int i = tid; i < c.D; i += PT_THREADS) { minv[i] = 1.0; mean[i] = 0.0; m2[i] = 0.0; }
   if (tid == 0) {
     gsc sc = c.sc;
@@ -74,8 +74,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_init(const DevModel *Mg, const R
       else Q0[i] = radius * (2.0 * rng_uniform(c.key, PT_ITER_PRE, RNG_INITS, attempt, (uint32_t)i) - 1.0);
     }
     __syncthreads();
-    PlainPolicy pol{c.st, c.st, c.soff(V_Q0), c.soff(V_G0), {0}};
-    const double lp = model_pass(M, c.lds, pol);
+    PlainPolicy pol{c.st, c.st, c.soff(V_QC), c.soff(V_GC), {0}};
+    const double lp = model_pass(M, c.lds, c.pst, pol);
     double bad[1] = {0.0};
     for (int i = tid; i < c.D; i += PT_THREADS) bad[0] += isfinite(G0[i]) ? 0.0 : 1.0;
     block_sum(bad, c.red(), tid);
@@ -94,7 +94,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_init(const DevModel *Mg, const R
 __device__ __noinline__ void cold_transition_begin(const DevModel *Mg, const RunParams *Rg, int chain, uint32_t iter) {
   CMp M = (CMp)uni_ptr(Mg);
   CRp R = (CRp)uni_ptr(Rg);
-  const Chain c = make_chain(M, R, (int)uni32((unsigned)chain));
+  Chain c = make_chain(M, R, (int)uni32((unsigned)chain));
+  c.pst = model_load_static(M);
   transition_begin(c, uni32(iter));
 }
 
@@ -104,7 +105,8 @@ __device__ __noinline__ void cold_transition_end(const DevModel *Mg, const RunPa
   CRp R = (CRp)uni_ptr(Rg);
   const int chain = (int)uni32((unsigned)chain_);
   const int it = (int)uni32(iter);
-  const Chain c = make_chain(M, R, chain);
+  Chain c = make_chain(M, R, chain);
+  c.pst = model_load_static(M);
   ltp ts = c.ts;
   const int tid = c.tid;
   if (tid == 0) {
@@ -117,7 +119,7 @@ __device__ __noinline__ void cold_transition_end(const DevModel *Mg, const RunPa
   __syncthreads();
   CPROF_START(c);
   gcdp qs = c.vec(V_POOLQ + ts->sample_qid);
-  gdp Q0 = c.vec(V_Q0);
+  gdp Q0 = c.vec(V_QC);
   const bool warm = it < R->num_warmup;
   const bool save = !warm || R->save_warmup;
   const int row_len = R->row;
@@ -149,9 +151,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_run(const DevModel *Mg, const Ru
   CMp M = (CMp)Mg;
   CRp R = (CRp)Rg;
   const int chain = blockIdx.x;
-  const Chain c = make_chain(M, R, chain);
+  Chain c = make_chain(M, R, chain);
   if (c.sc->status != 0) return;
-  model_setup_lds(M, c.lds);
+  c.pst = model_setup_lds(M, c.lds);
   const int total = R->num_warmup + R->num_samples;
   for (int k = 0; k < n_iter; k++) {
     const int it = c.sc->iter;
@@ -396,6 +398,7 @@ int build_model(Sampler *sp, const potus_data *d) {
   M.o_ze = L.o_ze; M.o_nn = L.o_nn; M.o_ns = L.o_ns; M.o_zb = L.o_zb; M.nmid = L.o_nn - L.o_c;
   M.sigma_c = d->sigma_c; M.sigma_m = d->sigma_m; M.sigma_pop = d->sigma_pop; M.sigma_e = d->sigma_e_bias;
   sp->sigma_ns = d->sigma_measure_noise_state; sp->sigma_nn = d->sigma_measure_noise_national;
+  M.sigma_ns = d->sigma_measure_noise_state; M.sigma_nn = d->sigma_measure_noise_national;
 
   // transformed data (stan:42-55)
   std::vector<double> w(d->state_weights, d->state_weights + S), cov(d->state_covariance_0, d->state_covariance_0 + (size_t)S * S);
@@ -444,20 +447,28 @@ int build_model(Sampler *sp, const potus_data *d) {
 
   // per-day gathers: days balanced over the 16 waves (longest-processing-time first); each wave gets
   // the polls of its days as one contiguous entry list (index, day, state)
-  std::vector<int> order, load(PT_NW, 0);
+  std::vector<int> order, load(PT_NW, 0), npolls_w(PT_NW, 0);
   for (int t = 0; t < T; t++) if (day_ptr[t + 1] > day_ptr[t]) order.push_back(t);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return day_ptr[a + 1] - day_ptr[a] > day_ptr[b + 1] - day_ptr[b]; });
   std::vector<std::vector<int>> wt(PT_NW);
   for (int t : order) {
-    const int wmin = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+    int wmin = -1;   // least-loaded wave with a free day slot (64) and room for the polls (256 packed states)
+    const int nt = day_ptr[t + 1] - day_ptr[t];
+    for (int wv = 0; wv < PT_NW; wv++)
+      if (wt[wv].size() < 64 && npolls_w[wv] + nt <= 256 && (wmin < 0 || load[wv] < load[wmin])) wmin = wv;
+    if (wmin < 0) return fail(POTUS_ERR_UNSUPPORTED, "poll schedule does not fit: more than %d polls", 256 * PT_NW);
+    npolls_w[wmin] += nt;
     wt[wmin].push_back(t);
-    load[wmin] += day_ptr[t + 1] - day_ptr[t] + 1;
+    load[wmin] += day_ptr[t + 1] - day_ptr[t] + 2;
   }
-  std::vector<int> we_ptr(PT_NW + 1, 0), we_idx, we_day, we_state, daymask(PT_NW, 0);
+  std::vector<int> wd_t(PT_NW * 64, 0), wd_a(PT_NW * 64, 0), wd_b(PT_NW * 64, 0), wpk(PT_NW * 64, 0), daymask(PT_NW, 0);
   for (int wv = 0; wv < PT_NW; wv++) {
-    for (int t : wt[wv])
-      for (int i = day_ptr[t]; i < day_ptr[t + 1]; i++) { we_idx.push_back(i); we_day.push_back(t); we_state.push_back(ps[i]); }
-    we_ptr[wv + 1] = (int)we_idx.size();
+    int e = 0;
+    for (size_t j = 0; j < wt[wv].size(); j++) {
+      const int t = wt[wv][j];
+      wd_t[wv * 64 + j] = t; wd_a[wv * 64 + j] = day_ptr[t]; wd_b[wv * 64 + j] = day_ptr[t + 1];
+      for (int i = day_ptr[t]; i < day_ptr[t + 1]; i++, e++) wpk[wv * 64 + e / 4] |= ps[i] << (8 * (e % 4));
+    }
   }
   for (int t = 0; t < T; t++) if (day_ptr[t + 1] > day_ptr[t]) daymask[t / PT_CH] |= (int)(1u << (t % PT_CH));
 
@@ -503,7 +514,7 @@ int build_model(Sampler *sp, const potus_data *d) {
   M.l_Y = take(std::max(PT_NW * M.SE, M.nsub));
   M.l_zT = take(S + 1); M.l_zb = take(S + 1); M.l_mid = take(M.nmid + 1);
   M.l_bT = take(M.SE); M.l_pb = take(M.SE); M.l_e = take(T); M.l_gs = take(M.SE); M.l_ge = take(T);
-  M.l_scal = take(SC_N); M.l_red = take(PT_NW * PT_NRED);
+  M.l_scal = take(SC_N); M.l_red = take(PT_NW * PT_NRED); M.l_st = take((Np + 8 + 7) / 8);
 #ifdef POTUS_PROF
   M.l_prof = take(PT_NPROF);
 #else
@@ -528,14 +539,14 @@ int build_model(Sampler *sp, const potus_data *d) {
     pi[5 * M.Npad + i] = pq[i];
     pdv[i] = py[i]; pdv[M.Npad + i] = pn[i]; pdv[2 * M.Npad + i] = pu[i]; pdv[3 * M.Npad + i] = psig[i];
   }
-  std::vector<int> sched(we_ptr);
+  std::vector<int> sched(wd_t);
   auto appi = [&](const std::vector<int> &v) {
     while (sched.size() % 4) sched.push_back(0);   // 16-byte aligned blocks (sub16 is read with 128-bit loads)
     const int off = (int)sched.size();
     sched.insert(sched.end(), v.begin(), v.end());
     return off;
   };
-  M.c_weidx = appi(we_idx); M.c_weday = appi(we_day); M.c_west = appi(we_state); M.c_mask = appi(daymask);
+  M.c_wda = appi(wd_a); M.c_wdb = appi(wd_b); M.c_wpk = appi(wpk); M.c_mask = appi(daymask);
   M.c_sub16 = appi(sub16); M.c_segptr = appi(seg_ptr); M.c_segkind = appi(seg_kind); M.c_segidx = appi(seg_index);
   for (int k = 0; k < 8; k++) sched.push_back(0);
   if (sub_wt16.empty()) sub_wt16.assign(2, 0.0);

@@ -75,7 +75,7 @@ struct DevModel {
   int SE, SP, TP;           // SE = S+1 (rows of Lw_ext); SP, TP odd LDS row strides
   int o_zT, o_Z, o_c, o_m, o_pop, o_mue, o_rho, o_ze, o_nn, o_ns, o_zb;
   int nmid;                 // o_nn - o_c : parameters between the S x T block and the noise blocks
-  double sigma_c, sigma_m, sigma_pop, sigma_e;
+  double sigma_c, sigma_m, sigma_pop, sigma_e, sigma_ns, sigma_nn;
   // Static data is packed into three buffers so that the descriptor costs few scalar registers.
   const double *mat;        // Lw_ext [SE][SP] | LT_t [k][s] | LB_t [k][s] | LT [s][k] | LB [s][k] | prior [S] | w [S]
   int m_LTt, m_LBt, m_LT, m_LB, m_prior, m_w;   // offsets into mat (Lw_ext at 0)
@@ -84,19 +84,19 @@ struct DevModel {
   const double *pd;         //   pi: ps | pt | pp | pm | ppop | pqidx      pd: py | pn | punadj | psig
   int Npad;
   // Static schedule, built on the host (all offsets in ints into sched):
-  //   we_ptr [NW+1]          entries of wave w: [we_ptr[w], we_ptr[w+1])
-  //   we_idx | we_day | we_state   per entry: sorted poll index, its day, its (pseudo-)state; a wave's
-  //                          entries are grouped by day, days balanced over waves (LPT)
-  //   daymask [NW]           bit j of word w: day 16w+j has at least one poll
+  //   wd_t | wd_a | wd_b [NW][64]  days gathered by wave w (balanced over waves, LPT): day and its
+  //                          poll range [a,b) in the day-sorted poll order; unused slots have a = b
+  //   wpk [NW][64]           states of wave w's gathered polls in gather order, four bytes per word
+  //   daymask [NW]           bit j of word w: day PT_CH*w+j has at least one poll
   //   sub16 [nsub][16]       level-1 segment-sum tasks: poll indices, padded with Npoll (a zero slot)
   //   seg_ptr [nseg+1] | seg_kind | seg_index   level-2: range of tasks, what the sum feeds
   const int *sched;
-  int c_weidx, c_weday, c_west, c_mask, c_sub16, c_segptr, c_segkind, c_segidx;
+  int c_wda, c_wdb, c_wpk, c_mask, c_sub16, c_segptr, c_segkind, c_segidx;   // wd_t at 0
   const double *seg_scale;  // [nseg]
   const double *sub_wt16;   // [(nsub - sub_weighted_begin)][16] weights of the weighted tasks (0 for padding)
   int nsub, nseg, sub_weighted_begin;
   // LDS layout, offsets in doubles
-  int l_C, l_Lw, l_X, l_Y, l_zT, l_zb, l_mid, l_bT, l_pb, l_e, l_gs, l_ge, l_scal, l_red, l_prof;
+  int l_C, l_Lw, l_X, l_Y, l_zT, l_zb, l_mid, l_bT, l_pb, l_e, l_gs, l_ge, l_scal, l_red, l_prof, l_st;
   int lds_doubles;
 };
 typedef const DevModel AS_C *CMp; // the model descriptor lives in device memory, read through scalar loads
@@ -109,9 +109,11 @@ enum { SC_MUE = 0, SC_RHO, SC_SRHO, SC_XMUE, SC_XRHO, SC_N };
 #ifdef POTUS_PROF
 #define PROF_MARK(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); prof[k] += (double)(t_ - (long long)prof[PT_NPROF - 1]); prof[PT_NPROF - 1] = (double)t_; } } while (0)
 #define PROF_START() do { if (threadIdx.x == 0) prof[PT_NPROF - 1] = (double)clock64(); } while (0)
+#define PROF_SUB(k) do { if (threadIdx.x == 0) { prof[k] += (double)(clock64() - (long long)prof[PT_NPROF - 1]); } } while (0)
 #else
 #define PROF_MARK(k) do { } while (0)
 #define PROF_START() do { } while (0)
+#define PROF_SUB(k) do { } while (0)
 #endif
 
 __device__ __forceinline__ double d_log_inv_logit(double x) { return x > 0 ? -log1p(exp(-x)) : x - log1p(exp(x)); }
@@ -120,6 +122,10 @@ __device__ __forceinline__ double d_inv_logit(double x) {
   double e = exp(x);
   return e / (1.0 + e);
 }
+
+// The compiler tends to sink every LDS read next to its use (read, wait ~100 cycles, one FMA, next
+// read ...).  ISSUE_FENCE() pins the order "all loads of the batch, then all uses".
+#define ISSUE_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // Sum N values over the workgroup; every thread returns with the totals.  Fixed order.
 template <int N>
@@ -145,8 +151,8 @@ __device__ __forceinline__ void block_sum(double (&v)[N], ldp red, int tid) {
 
 // Plain policy: read q, write grad (parity hook, Hamiltonian init).
 // Policy API: q_load/q_fin fetch one position element (split so that callers can issue a batch
-// of loads before the first dependent store); g_load/g_fin consume one gradient element;
-// g_load_q additionally returns the position again (t.q).
+// of loads before the first dependent use); g_load/g_fin consume one gradient element, g_fin is
+// also handed the element's position (the integrator needs it for the next position update).
 // All element accesses take the element's BYTE offset (8*index) or PT_OOB: buffer loads beyond the
 // resource return 0 and stores are dropped, so masked-off elements need no branch -- which matters,
 // because the compiler drains the whole memory queue (s_waitcnt vmcnt(0)) at every branch join.
@@ -155,35 +161,57 @@ struct PlainPolicy {
   rsrc_t rq, rg;        // buffers holding q and receiving grad (may be the same buffer)
   unsigned sq, sg;      // byte offsets of the two vectors inside them
   static constexpr int NEXTRA = 0;
-  static constexpr int QB = 16;
+  static constexpr int GB = 8;    // gradient elements finished per batch in the S x T block
   double extra[1];  // unused
   struct QT { double q; };
-  struct GT { double q; };
+  struct GT { };
   __device__ __forceinline__ void q_load(unsigned vo, QT &t) { t.q = bld(rq, vo, sq); }
   __device__ __forceinline__ double q_fin(unsigned, QT &t) { return t.q; }
   __device__ __forceinline__ void g_load(unsigned, GT &) {}
-  __device__ __forceinline__ void g_load_q(unsigned vo, GT &t) { t.q = bld(rq, vo, sq); }
-  __device__ __forceinline__ void g_from_q(const QT &, GT &) {}   // same thread did q_load earlier in the pass
-  __device__ __forceinline__ void g_fin(unsigned vo, double v, const GT &) { bst(rg, vo, sg, v); }
+  __device__ __forceinline__ void g_fin(unsigned vo, double v, double /*q*/, const GT &) { bst(rg, vo, sg, v); }
   __device__ __forceinline__ double q(int i) { return bld(rq, 8u * i, sq); }
-  __device__ __forceinline__ void g(int i, double v) { bst(rg, 8u * i, sg, v); }
+  __device__ __forceinline__ void g(int i, double v, double) { bst(rg, 8u * i, sg, v); }
 };
 
 // Stage the (S+1) x S walk factor in LDS once per kernel; it stays resident across passes.
-__device__ __forceinline__ void model_setup_lds(CMp M, ldp lds) {
+// Per-thread registers that never change during a kernel: the day gathered by (wave, lane).
+struct PassStatic {
+  int d_t, d_a, d_b;        // lane j of wave w: j-th day gathered by the wave and its poll range
+};
+
+// Load the per-thread static registers (also used by the out-of-line functions, which cannot
+// inherit them from the kernel).
+__device__ __forceinline__ PassStatic model_load_static(CMp M) {
+  PassStatic pst;
+  gcip sc = as_g(M->sched);
+  const int slot = threadIdx.x;   // [wave][lane]
+  pst.d_t = sc[slot]; pst.d_a = sc[M->c_wda + slot]; pst.d_b = sc[M->c_wdb + slot];
+  return pst;
+}
+
+__device__ __forceinline__ PassStatic model_setup_lds(CMp M, ldp lds) {
   ldp Lw = lds + M->l_Lw;
   gcdp src = as_g(M->mat);
   for (int i = threadIdx.x; i < M->SE * M->SP; i += PT_THREADS) Lw[i] = src[i];
+  {
+    // (pseudo-)state of every poll as one byte each: the gathers of phase D read them as LDS broadcasts
+    unsigned char AS_L *st = (unsigned char AS_L *)(lds + M->l_st);
+    gcip ps = as_g(M->pi);
+    const int Npoll = M->Npoll;
+    for (int i = threadIdx.x; i < Npoll + 8; i += PT_THREADS) st[i] = i < Npoll ? (unsigned char)ps[i] : (unsigned char)0;
+  }
+  const PassStatic pst = model_load_static(M);
 #ifdef POTUS_PROF
   for (int i = threadIdx.x; i < PT_NPROF; i += PT_THREADS) (lds + M->l_prof)[i] = 0.0;
 #endif
   __syncthreads();
+  return pst;
 }
 
 // One full pass.  Returns lp (log_prob<propto,jacobian>) in every thread; pol.extra[] are
 // block-summed alongside.  Ends with a barrier, so LDS may be reused immediately.
 template <class Pol>
-__device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
+__device__ __forceinline__ double model_pass(CMp M_in, ldp lds, const PassStatic &pst, Pol &pol_io) {
   Pol pol = pol_io; // private copy: its address never escapes, so it lives in registers
   // The pass is inlined into loops (leaves of a tree, transitions).  Launder the thread id and the
   // descriptor pointer so that nothing derived from them is hoisted out of those loops and then
@@ -258,28 +286,24 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
       if (!(full && (idx == o_mue || idx == o_rho))) lp -= 0.5 * v * v;
     }
   }
-  double cs[PT_CH];
+  double cs[PT_CH], zq[PT_CH];   // suffix sums; positions (kept in registers until phase F)
   {
     const int t0 = w * PT_CH;
+    typename Pol::QT qt[PT_CH];
+#pragma unroll
+    for (int j = 0; j < PT_CH; j++) {            // every load of the block issued together, no branches
+      const int t = t0 + j;
+      pol.q_load((lane < S && t < T) ? 8u * (unsigned)(o_Z + lane + S * t) : PT_OOB, qt[j]);
+    }
     double run = 0.0;
 #pragma unroll
-    for (int h = PT_CH - Pol::QB; h >= 0; h -= Pol::QB) { // batches from the last day backwards; no branches inside
-      typename Pol::QT qt[Pol::QB];
-      unsigned vo[Pol::QB];
-#pragma unroll
-      for (int j = 0; j < Pol::QB; j++) {
-        const int t = t0 + h + j;
-        vo[j] = (lane < S && t < T) ? 8u * (unsigned)(o_Z + lane + S * t) : PT_OOB;
-        pol.q_load(vo[j], qt[j]);
-      }
-#pragma unroll
-      for (int j = Pol::QB - 1; j >= 0; j--) {
-        const int t = t0 + h + j;
-        const double z = pol.q_fin(vo[j], qt[j]);  // 0 for masked-off elements
-        lp -= 0.5 * z * z;                      // to_vector(raw_mu_b) ~ std_normal(), stan:119
-        run += (t < T - 1) ? z : 0.0;           // column T is not part of the walk (stan:86)
-        cs[h + j] = run;
-      }
+    for (int j = PT_CH - 1; j >= 0; j--) {
+      const int t = t0 + j;
+      const double z = pol.q_fin(0u, qt[j]);    // 0 for masked-off elements
+      zq[j] = z;
+      lp -= 0.5 * z * z;                        // to_vector(raw_mu_b) ~ std_normal(), stan:119
+      run += (t < T - 1) ? z : 0.0;             // column T is not part of the walk (stan:86)
+      cs[j] = run;
     }
     if (lane < S) Y[w * SE + lane] = run;
   }
@@ -288,8 +312,12 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
 
   // ---------------- phase B: carries -> C in LDS; bT, polling bias; AR(1) forward
   if (lane < S) {
-    double carry = 0.0;
-    for (int w2 = w + 1; w2 < PT_NW; w2++) carry += Y[w2 * SE + lane];
+    double carry = 0.0, cy[PT_NW];
+#pragma unroll
+    for (int w2 = 0; w2 < PT_NW; w2++) cy[w2] = Y[w2 * SE + lane];
+    ISSUE_FENCE();
+#pragma unroll
+    for (int w2 = 0; w2 < PT_NW; w2++) carry += w2 > w ? cy[w2] : 0.0;
     const int t0 = w * PT_CH;
 #pragma unroll
     for (int j = 0; j < PT_CH; j++)
@@ -340,6 +368,7 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
       lp += log(0.02) - 0.5 * xm * xm + log(rho) + log1p(-rho) - 0.5 * ((rho - 0.7) / 0.1) * ((rho - 0.7) / 0.1);
     }
   }
+  PROF_SUB(26);
   __syncthreads();
   PROF_MARK(1);
 
@@ -356,6 +385,7 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
       double un[2], y[2], N[2], sg[2];
       unsigned vq[2];
       typename Pol::QT qt[2];
+      typename Pol::GT gt[2];
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int i = i0 + u * PT_THREADS + tid;
@@ -371,18 +401,27 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
         const int i = i0 + u * PT_THREADS + tid;
         vq[u] = (i < Npoll) ? 8u * (unsigned)qi[u] : PT_OOB;
         pol.q_load(vq[u], qt[u]);
+        pol.g_load(vq[u], gt[u]);
       }
       ldp L0 = Lw + s[0] * SP, C0 = C + t[0], L1 = Lw + s[1] * SP, C1 = C + t[1];
       double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-      int k = 0;
-      for (; k + 1 < S; k += 2) {
-        a0 += L0[k] * C0[k * TP];
-        b0 += L1[k] * C1[k * TP];
-        a1 += L0[k + 1] * C0[(k + 1) * TP];
-        b1 += L1[k + 1] * C1[(k + 1) * TP];
+      for (int k0 = 0; k0 < S; k0 += 8) {        // 51-term dots, eight terms of both polls in flight at once
+        double l0[8], c0[8], l1[8], c1[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int kk = min(k0 + j, S - 1);
+          l0[j] = L0[kk]; c0[j] = C0[kk * TP]; l1[j] = L1[kk]; c1[j] = C1[kk * TP];
+        }
+        ISSUE_FENCE();
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const double m0 = k0 + j < S ? 1.0 : 0.0, m1 = k0 + j + 1 < S ? 1.0 : 0.0;
+          a0 += m0 * l0[j] * c0[j];         b0 += m0 * l1[j] * c1[j];
+          a1 += m1 * l0[j + 1] * c0[j + 1]; b1 += m1 * l1[j + 1] * c1[j + 1];
+        }
       }
-      for (; k < S; k++) { a0 += L0[k] * C0[k * TP]; b0 += L1[k] * C1[k * TP]; }
       const double dot[2] = {a0 + a1, b0 + b1};
+      PROF_SUB(18);
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int i = i0 + u * PT_THREADS + tid;
@@ -396,12 +435,11 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
         const double r = y[u] - N[u] * pr;
         lp += y[u] * (fmin(eta, 0.0) - l1) + (N[u] - y[u]) * (fmin(-eta, 0.0) - l1) - 0.5 * zn * zn; // stan:126-127,130-131
         r_lds[i < Npoll ? i : Npoll + 1] = r;    // slot Npoll stays 0 (padding of the task lists), Npoll+1 is a dump
-        typename Pol::GT gt;
-        pol.g_from_q(qt[u], gt);
-        pol.g_fin(vq[u], sg[u] * r - zn, gt);
+        pol.g_fin(vq[u], sg[u] * r - zn, zn, gt[u]);
       }
     }
   }
+  PROF_SUB(25);
   __syncthreads();
   PROF_MARK(2);
 
@@ -424,32 +462,33 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
     sg_vg = (tid < nseg && sg_kind == 0) ? 8u * (unsigned)sg_index : PT_OOB;
     pol.g_load(sg_vg, sg_gt);
   }
+  PROF_SUB(19);
   {
-    const int AS_C *we_ptr = as_c(M->sched);
-    const unsigned o_idx = 4u * (unsigned)M->c_weidx, o_day = 4u * (unsigned)M->c_weday, o_st = 4u * (unsigned)M->c_west;
-    const int e0 = we_ptr[w], e1 = we_ptr[w + 1], Npoll = M->Npoll;
-    const int lk = lane < S ? lane : 0;
-    double acc = 0.0;
-    int cur_t = -1;
-    for (int c0 = e0; c0 < e1; c0 += 64) {     // this wave's polls, 64 at a time: one per lane, then broadcast
-      const int nb = min(64, e1 - c0);
-      const unsigned ve = lane < nb ? 4u * (unsigned)(c0 + lane) : PT_OOB;
-      const int ei = bld_i(rsc, ve, o_idx), et = bld_i(rsc, ve, o_day), es = bld_i(rsc, ve, o_st);
-      const double rv = r_lds[lane < nb ? ei : Npoll];
-      const int rlo = __double2loint(rv), rhi = __double2hiint(rv);
-      for (int j = 0; j < nb; j++) {
-        const int t = __builtin_amdgcn_readlane(et, j), s = __builtin_amdgcn_readlane(es, j);
-        const double r = __hiloint2double(__builtin_amdgcn_readlane(rhi, j), __builtin_amdgcn_readlane(rlo, j));
-        if (t != cur_t) {
-          if (cur_t >= 0 && lane < S) C[lane * TP + cur_t] = acc;
-          acc = 0.0;
-          cur_t = t;
-        }
-        acc += r * Lw[s * SP + lk];
+    // lanes = k; the wave walks the days it owns (day and poll range sit in registers, one day per
+    // lane, broadcast with readlane); poll state and residual are LDS broadcasts: no memory latency
+    const unsigned char AS_L *st = (const unsigned char AS_L *)(lds + M->l_st);
+    const int lk = lane < S ? lane : 0, Npoll = M->Npoll;
+    for (int dj = 0; dj < 64; dj++) {
+      const int a = __builtin_amdgcn_readlane(pst.d_a, dj), b = __builtin_amdgcn_readlane(pst.d_b, dj);
+      if (a >= b) break;                          // a wave's days are packed at the front
+      const int t = __builtin_amdgcn_readlane(pst.d_t, dj);
+      double acc0 = 0.0, acc1 = 0.0;
+      for (int i = a; i < b; i += 8) {            // eight polls per trip, reads beyond b hit the zero slot
+        int s8[8];
+        double r8[8], l8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int ii = i + u < b ? i + u : Npoll; s8[u] = st[ii]; r8[u] = r_lds[ii]; }
+        ISSUE_FENCE();
+#pragma unroll
+        for (int u = 0; u < 8; u++) l8[u] = Lw[s8[u] * SP + lk];
+        ISSUE_FENCE();
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { acc0 += r8[u] * l8[u]; acc1 += r8[u + 1] * l8[u + 1]; }
       }
+      if (lane < S) C[lane * TP + t] = acc0 + acc1;
     }
-    if (cur_t >= 0 && lane < S) C[lane * TP + cur_t] = acc;
   }
+  PROF_SUB(20);
   {
     const int nsub = M->nsub, wb = M->sub_weighted_begin;
     const unsigned o_sub = 4u * (unsigned)M->c_sub16;
@@ -464,17 +503,17 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
       for (int j = 0; j < 4; j++) ix[j] = bld_i4(rsc, vs + 16u * j, o_sub);
 #pragma unroll
       for (int j = 0; j < PT_SUBLEN / 2; j++) bld_d2(rwt, vw + 16u * j, 0, wt[2 * j], wt[2 * j + 1]);
+      double rr[PT_SUBLEN];
+#pragma unroll
+      for (int j = 0; j < PT_SUBLEN; j++) rr[j] = r_lds[ok ? ix[j >> 2][j & 3] : 0];
+      ISSUE_FENCE();
       double sum = 0.0;
-      if (wtd) {
 #pragma unroll
-        for (int j = 0; j < PT_SUBLEN; j++) sum += r_lds[ix[j >> 2][j & 3]] * wt[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < PT_SUBLEN; j++) sum += r_lds[ok ? ix[j >> 2][j & 3] : 0];
-      }
+      for (int j = 0; j < PT_SUBLEN; j++) sum += wtd ? rr[j] * wt[j] : rr[j];
       if (ok) Y[sub] = sum;
     }
   }
+  PROF_SUB(21);
   __syncthreads();
   PROF_MARK(3);
 
@@ -494,8 +533,15 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
   }
   {
     double sum = 0.0;
-    for (int j = sg_a; j < sg_b; j++) sum += Y[j];
-    if (sg_kind == 0) pol.g_fin(sg_vg, sg_scale * sum - s_mid[sg_index - o_c], sg_gt);
+    for (int j0 = sg_a; j0 < sg_b; j0 += 8) {
+      double yy[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) yy[u] = Y[min(j0 + u, sg_b - 1)];
+      ISSUE_FENCE();
+#pragma unroll
+      for (int u = 0; u < 8; u++) sum += j0 + u < sg_b ? yy[u] : 0.0;
+    }
+    if (sg_kind == 0) { const double qv = s_mid[sg_index - o_c]; pol.g_fin(sg_vg, sg_scale * sum - qv, qv, sg_gt); }
     else if (tid < M->nseg) { if (sg_kind == 1) s_gs[sg_index] = sum; else s_ge[sg_index] = sum; }
     const int nseg = M->nseg;
     for (int seg = tid + PT_THREADS; seg < nseg; seg += PT_THREADS) {   // only with more than 1024 segments
@@ -503,36 +549,42 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
       const int a = sc[M->c_segptr + seg], b = sc[M->c_segptr + seg + 1], kind = sc[M->c_segkind + seg], index = sc[M->c_segidx + seg];
       double s2 = 0.0;
       for (int j = a; j < b; j++) s2 += Y[j];
-      if (kind == 0) pol.g(index, as_g(M->seg_scale)[seg] * s2 - s_mid[index - o_c]);
+      if (kind == 0) { const double qv = s_mid[index - o_c]; pol.g(index, as_g(M->seg_scale)[seg] * s2 - qv, qv); }
       else if (kind == 1) s_gs[index] = s2;
       else s_ge[index] = s2;
     }
   }
+  PROF_SUB(24);
   __syncthreads();
   PROF_MARK(4);
 
   // ---------------- phase F: dZ; transposed mat-vecs; AR(1) adjoint
   if (lane < S) {
-    double carry = 0.0;
-    for (int w2 = 0; w2 < w; w2++) carry += X[w2 * SE + lane];
+    double carry = 0.0, cy[PT_NW];
+#pragma unroll
+    for (int w2 = 0; w2 < PT_NW; w2++) cy[w2] = X[w2 * SE + lane];
+    ISSUE_FENCE();
+#pragma unroll
+    for (int w2 = 0; w2 < PT_NW; w2++) carry += w2 < w ? cy[w2] : 0.0;
     const int t0 = w * PT_CH;
 #pragma unroll
-    for (int h = 0; h < PT_CH; h += Pol::QB) {
-      typename Pol::GT gt[Pol::QB];
-      unsigned vo[Pol::QB];
+    for (int h = 0; h < PT_CH; h += Pol::GB) {
+      typename Pol::GT gt[Pol::GB];
+      unsigned vo[Pol::GB];
 #pragma unroll
-      for (int j = 0; j < Pol::QB; j++) {
+      for (int j = 0; j < Pol::GB; j++) {
         const int t = t0 + h + j;
         vo[j] = (t < T) ? 8u * (unsigned)(o_Z + lane + S * t) : PT_OOB;
-        pol.g_load_q(vo[j], gt[j]);
+        pol.g_load(vo[j], gt[j]);
       }
 #pragma unroll
-      for (int j = 0; j < Pol::QB; j++) {
+      for (int j = 0; j < Pol::GB; j++) {
         const int t = t0 + h + j;
-        pol.g_fin(vo[j], (t < T - 1 ? pre[h + j] + carry : 0.0) - gt[j].q, gt[j]);
+        pol.g_fin(vo[j], (t < T - 1 ? pre[h + j] + carry : 0.0) - zq[h + j], zq[h + j], gt[j]);
       }
     }
   }
+  PROF_SUB(22);
   {
     // dbT[s] = dpolling_bias[s] = residuals of state s + w_s * national residuals; C region is free now
     gcdp LT = as_g(M->mat) + M->m_LT, LB = as_g(M->mat) + M->m_LB, wv = as_g(M->mat) + M->m_w;
@@ -566,26 +618,35 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
     double a = __shfl_down(B, 1, 64);
     if (lane == 63) a = 0.0;
     double S1 = 0.0, S2 = 0.0, S3 = 0.0;
-    for (int t = tb - 1; t >= ta; t--) {
-      a = s_ge[t] + rho * a;
-      if (t >= 1) {
-        S1 += a; S2 += a * (s_e[t - 1] - mue); S3 += a * ze[t];
-        pol.g(o_ze + t, a * srho - ze[t]);
-      } else {
-        pol.g(o_ze, a * sigma_e - ze[0]);
-      }
+    constexpr int PER = 4;                       // T <= 256 -> at most four days per lane
+    typename Pol::GT gz[PER];
+    unsigned vz[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) { vz[u] = ta + u < tb ? 8u * (unsigned)(o_ze + ta + u) : PT_OOB; pol.g_load(vz[u], gz[u]); }
+#pragma unroll
+    for (int u = PER - 1; u >= 0; u--) {         // no branches: masked days add nothing and their stores are dropped
+      const int t = ta + u;
+      const bool ok = t < tb;
+      const int tc = ok ? t : 0;
+      const double a_new = s_ge[tc] + rho * a;
+      a = ok ? a_new : a;
+      const double z = ze[tc], dprev = s_e[tc >= 1 ? tc - 1 : 0] - mue;
+      const bool inner = ok && t >= 1;
+      S1 += inner ? a : 0.0; S2 += inner ? a * dprev : 0.0; S3 += inner ? a * z : 0.0;
+      pol.g_fin(vz[u], a * (t >= 1 ? srho : sigma_e) - z, z, gz[u]);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       S1 += __shfl_down(S1, off, 64); S2 += __shfl_down(S2, off, 64); S3 += __shfl_down(S3, off, 64);
     }
     if (lane == 0) {
-      const double xm = s_scal[SC_XMUE];
+      const double xm = s_scal[SC_XMUE], xr = s_scal[SC_XRHO];
       const double adj_rho = S2 + S3 * sigma_e * (-rho / sqrt(1.0 - rho * rho));
-      pol.g(M->o_mue, 0.02 * (1.0 - rho) * S1 - xm);
-      pol.g(M->o_rho, (adj_rho - (rho - 0.7) / 0.01) * rho * (1.0 - rho) + (1.0 - 2.0 * rho));
+      pol.g(M->o_mue, 0.02 * (1.0 - rho) * S1 - xm, xm);
+      pol.g(M->o_rho, (adj_rho - (rho - 0.7) / 0.01) * rho * (1.0 - rho) + (1.0 - 2.0 * rho), xr);
     }
   }
+  PROF_SUB(23);
   __syncthreads();
   PROF_MARK(5);
 
@@ -596,8 +657,8 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, Pol &pol_io) {
       double sum = 0.0;
 #pragma unroll
       for (int w2 = 0; w2 < PT_NW; w2++) sum += C[(which * PT_NW + w2) * SE + lane];
-      if (which == 0) pol.g(M->o_zT + lane, sum - s_zT[lane]);
-      else pol.g(M->o_zb + lane, sum - s_zb[lane]);
+      if (which == 0) pol.g(M->o_zT + lane, sum - s_zT[lane], s_zT[lane]);
+      else pol.g(M->o_zb + lane, sum - s_zb[lane], s_zb[lane]);
     }
   }
   double v[1 + Pol::NEXTRA];

@@ -36,9 +36,17 @@ extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
 enum { RNG_MOMENTUM = 0, RNG_DIRECTION = 1, RNG_TOP_ACCEPT = 2, RNG_SUB_ACCEPT = 3, RNG_INIT_EPS = 4, RNG_INITS = 5 };
 #define PT_ITER_PRE 0xFFFFFFFFu
 
-// vector slots of one chain's state block (each Dpad doubles)
+// vector slots of one chain's state block (each Dpad doubles).
+// The chain's point lives in QC/GC.  Each end e of the trajectory (0 = backward, 1 = forward) keeps
+//   QA[e], QB[e]  ping-pong positions: one holds the position the NEXT leapfrog of this end will
+//                 evaluate, the other still holds the previous leaf's position (proposal copies)
+//   PH[e]         momentum already kicked half a step towards that next position
+//   PF[e]         full-step momentum at the end point (for the U-turn checks across subtrees)
+// so a leapfrog reads one vector (the position) in the model pass and finishes with
+// {PH, minv} -> {leaf slot, PH, next position}: the gradient itself never goes to memory.
 enum {
-  V_Q0 = 0, V_Q1, V_P0, V_P1, V_G0, V_G1, V_MINV, V_RHOTOP, V_PNEAR, V_WMEAN, V_WM2, V_SCR0, V_SCR1,
+  V_QC = 0, V_GC, V_PC, V_QA0, V_QA1, V_QB0, V_QB1, V_PH0, V_PH1, V_PF0, V_PF1,
+  V_MINV, V_RHOTOP, V_PNEAR, V_WMEAN, V_WM2, V_SCR0, V_SCR1,
   V_RHOLEV, /* PT_MAXD+1 */
   V_POOLP = V_RHOLEV + PT_MAXD + 1,
   V_POOLQ = V_POOLP + PT_NPP,
@@ -87,6 +95,7 @@ struct TS { // transition state, LDS
   unsigned pmask, qmask;
   int depth, dir, divergent, abort, m, leaf_id, copy_q_id, sample_qid, n_leap, stop;
   int flag_a, flag_b, direction, done;
+  int qsel[2];   // which of QA/QB holds the position the next leapfrog of end e evaluates (0 = QA)
 };
 typedef TS AS_L *ltp;
 
@@ -126,40 +135,35 @@ __device__ __forceinline__ void rng_normal_pair(const RngKey &K, uint32_t iter, 
 
 // ---------------------------------------------------------------- leapfrog fused into the model pass
 // expl_leapfrog: p -= eps/2 dV/dq ; q += eps M^-1 p ; (V, dV/dq)(q) ; p -= eps/2 dV/dq, with dV/dq = -grad lp.
-// G holds grad lp.  The full-step momentum is also written to the leaf's pool slot and the
-// kinetic energy sum_i minv_i p_i^2 is accumulated for the Hamiltonian.
+// Consecutive leapfrogs of one trajectory end always use the same signed step, so the second
+// half-kick of one step and the first half-kick and drift of the next are applied together as
+// soon as the gradient g is known (phase F of the pass):
+//     pf  = ph + he*g          full-step momentum of THIS leaf  -> leaf slot
+//     ph' = pf + he*g          half-kicked momentum for the next leaf -> PH
+//     q'  = q + e*minv*ph'     position the next leaf evaluates -> the other ping-pong buffer
+// The arithmetic per leaf is exactly Stan's; only the order of stores differs.
 struct LeapPolicy {
-  rsrc_t r;                       // the chain's state block
-  unsigned sQ, sP, sG, sM, sL;    // byte offsets of position, momentum, gradient, inverse metric, leaf slot
+  rsrc_t r;                          // the chain's state block
+  unsigned sQc, sQn, sPH, sM, sL;    // byte offsets: position (this leaf / next), PH, inverse metric, leaf slot
   double he, e;
   static constexpr int NEXTRA = 1;
-  static constexpr int QB = 8;
+  static constexpr int GB = 8;
   double extra[1];
-  struct QT { double p, g, q, m; };
-  struct GT { double p, m, q; };
-  __device__ __forceinline__ void q_load(unsigned vo, QT &t) {
-    t.p = bld(r, vo, sP); t.g = bld(r, vo, sG); t.q = bld(r, vo, sQ); t.m = bld(r, vo, sM);
-  }
-  __device__ __forceinline__ double q_fin(unsigned vo, QT &t) {
-    const double ph = t.p + he * t.g;
-    t.p = ph;
-    bst(r, vo, sP, ph);
-    const double qn = t.q + e * t.m * ph;
-    bst(r, vo, sQ, qn);
-    return qn;
-  }
-  __device__ __forceinline__ void g_load(unsigned vo, GT &t) { t.p = bld(r, vo, sP); t.m = bld(r, vo, sM); }
-  __device__ __forceinline__ void g_load_q(unsigned vo, GT &t) { t.p = bld(r, vo, sP); t.m = bld(r, vo, sM); t.q = bld(r, vo, sQ); }
-  __device__ __forceinline__ void g_from_q(const QT &q, GT &t) { t.p = q.p; t.m = q.m; } // q.p is the half-step momentum after q_fin
-  __device__ __forceinline__ void g_fin(unsigned vo, double v, const GT &t) {
-    bst(r, vo, sG, v);
+  struct QT { double q; };
+  struct GT { double p, m; };
+  __device__ __forceinline__ void q_load(unsigned vo, QT &t) { t.q = bld(r, vo, sQc); }
+  __device__ __forceinline__ double q_fin(unsigned, QT &t) { return t.q; }
+  __device__ __forceinline__ void g_load(unsigned vo, GT &t) { t.p = bld(r, vo, sPH); t.m = bld(r, vo, sM); }
+  __device__ __forceinline__ void g_fin(unsigned vo, double v, double q, const GT &t) {
     const double pf = t.p + he * v;
-    bst(r, vo, sP, pf);
     bst(r, vo, sL, pf);
+    const double ph = pf + he * v;
+    bst(r, vo, sPH, ph);
+    bst(r, vo, sQn, q + e * t.m * ph);
     extra[0] += t.m * pf * pf;   // masked-off elements loaded m = 0
   }
-  __device__ __forceinline__ double q(int i) { QT t; q_load(8u * i, t); return q_fin(8u * i, t); }
-  __device__ __forceinline__ void g(int i, double v) { GT t; g_load(8u * i, t); g_fin(8u * i, v, t); }
+  __device__ __forceinline__ double q(int i) { return bld(r, 8u * i, sQc); }
+  __device__ __forceinline__ void g(int i, double v, double q) { GT t; g_load(8u * i, t); g_fin(8u * i, v, q, t); }
 };
 
 struct Chain {
@@ -169,6 +173,7 @@ struct Chain {
   gdp base;
   gsc sc;
   RngKey key;
+  PassStatic pst;
   int D, Dpad, tid, max_depth, num_warmup, init_buffer, term_buffer;
   double delta, gamma, kappa, t0;
 #ifdef POTUS_PROF
@@ -278,47 +283,73 @@ __device__ __forceinline__ bool vop_merge(const Chain &c, unsigned a_beg, unsign
 // ---------------------------------------------------------------- one NUTS transition (base_nuts::transition)
 // On return ts->sample_qid names the pool slot holding the new sample, ts->out_lp / out_h its
 // log density and Hamiltonian, ts->accept_stat the adaptation statistic.
+// Kick-and-drift from a point (q, p, grad lp g) towards the first leaf of end e:
+//   PH[e] = p + he*g ; position buffer `dst` = q + e*minv*PH[e] ; optionally PF[e] = p.
+__device__ __forceinline__ void vop_prekick(const Chain &c, unsigned sq, unsigned sp, unsigned sg, unsigned s_ph, unsigned s_dst,
+                                            unsigned s_pf, double he, double e) {
+  const unsigned sM = c.soff(V_MINV);
+  const int tid0 = fresh_tid(c);
+  for (int base = tid0; base < c.D; base += PT_UNR * PT_THREADS) {
+    double q[PT_UNR], p[PT_UNR], g[PT_UNR], m[PT_UNR];
+#pragma unroll
+    for (int k = 0; k < PT_UNR; k++) {
+      const int i = base + k * PT_THREADS;
+      const unsigned o = i < c.D ? 8u * i : PT_OOB;
+      q[k] = bld(c.st, o, sq); p[k] = bld(c.st, o, sp); g[k] = bld(c.st, o, sg); m[k] = bld(c.st, o, sM);
+    }
+#pragma unroll
+    for (int k = 0; k < PT_UNR; k++) {
+      const int i = base + k * PT_THREADS;
+      const unsigned o = i < c.D ? 8u * i : PT_OOB;
+      const double ph = p[k] + he * g[k];
+      bst(c.st, o, s_ph, ph);
+      bst(c.st, o, s_dst, q[k] + e * m[k] * ph);
+      bst(c.st, o, s_pf, p[k]);
+    }
+  }
+  __syncthreads();
+}
+
 // Part 1 (once per transition, kept out of line): momentum refresh, Hamiltonian at the start
-// point, both trajectory ends := start point.
+// point, both trajectory ends := start point, kicked towards their first leaves.
 __device__ __forceinline__ void transition_begin(const Chain &c, uint32_t iter) {
   ltp ts = c.ts;
   const int tid = c.tid;
   const double eps = c.sc->nom_eps; // sample_stepsize(): no jitter
   CPROF_START(c);
-
-  const double kin0 = vop_momentum(c, c.soff(V_P0), iter, RNG_MOMENTUM, 0);
+  const double kin0 = vop_momentum(c, c.soff(V_PC), iter, RNG_MOMENTUM, 0);
   CPROF_MARK(c, PF_MOMENTUM);
-  PlainPolicy pp{c.st, c.st, c.soff(V_Q0), c.soff(V_G0), {0}};
-  const double lp0 = model_pass(c.M, c.lds, pp); // hamiltonian.init
+  PlainPolicy pp{c.st, c.st, c.soff(V_QC), c.soff(V_GC), {0}};
+  const double lp0 = model_pass(c.M, c.lds, c.pst, pp); // hamiltonian.init
   CPROF_START(c);
   if (tid == 0) {
     ts->H0 = 0.5 * kin0 - lp0;
     ts->lsw = 0.0; ts->sum_metro = 0.0; ts->n_leap = 0; ts->depth = 0; ts->divergent = 0; ts->stop = 0; ts->eps = eps;
+    ts->qsel[0] = 0; ts->qsel[1] = 0;
     unsigned qm = 0;
     const int id = pool_alloc(qm, PT_NPQ);
     ts->qmask = qm;
     ts->sample_qid = id; ts->q_lp[id] = lp0; ts->q_h[id] = 0.5 * kin0 - lp0;
   }
   __syncthreads();
+  vop_prekick(c, c.soff(V_QC), c.soff(V_PC), c.soff(V_GC), c.soff(V_PH1), c.soff(V_QA1), c.soff(V_PF1), 0.5 * eps, eps);
+  vop_prekick(c, c.soff(V_QC), c.soff(V_PC), c.soff(V_GC), c.soff(V_PH0), c.soff(V_QA0), c.soff(V_PF0), -0.5 * eps, -eps);
   {
     const unsigned s_rt = c.soff(V_RHOTOP), s_qs = c.soff(V_POOLQ + ts->sample_qid);
     const int tid0 = fresh_tid(c);
     for (int base = tid0; base < c.D; base += PT_UNR * PT_THREADS) {
-      double q[PT_UNR], p[PT_UNR], g[PT_UNR];
+      double q[PT_UNR], p[PT_UNR];
 #pragma unroll
       for (int k = 0; k < PT_UNR; k++) {
         const int i = base + k * PT_THREADS;
         const unsigned o = i < c.D ? 8u * i : PT_OOB;
-        q[k] = bld(c.st, o, c.soff(V_Q0)); p[k] = bld(c.st, o, c.soff(V_P0)); g[k] = bld(c.st, o, c.soff(V_G0));
+        q[k] = bld(c.st, o, c.soff(V_QC)); p[k] = bld(c.st, o, c.soff(V_PC));
       }
 #pragma unroll
       for (int k = 0; k < PT_UNR; k++) {
         const int i = base + k * PT_THREADS;
-        {
-          const unsigned o = i < c.D ? 8u * i : PT_OOB;
-          bst(c.st, o, c.soff(V_Q1), q[k]); bst(c.st, o, c.soff(V_P1), p[k]); bst(c.st, o, c.soff(V_G1), g[k]);
-          bst(c.st, o, s_rt, p[k]); bst(c.st, o, s_qs, q[k]);
-        }
+        const unsigned o = i < c.D ? 8u * i : PT_OOB;
+        bst(c.st, o, s_rt, p[k]); bst(c.st, o, s_qs, q[k]);
       }
     }
   }
@@ -343,7 +374,7 @@ __device__ __forceinline__ void transition_tree(const Chain &c, uint32_t iter) {
     __syncthreads();
     const int dir = ts->dir;
     CPROF_START(c);
-    vop_copy(c, c.soff(V_PNEAR), c.soff(V_P0 + dir));
+    vop_copy(c, c.soff(V_PNEAR), c.soff(V_PF0 + dir));
     CPROF_MARK(c, PF_PNEAR);
     bool valid = true;
     const int nleaf = 1 << depth;
@@ -351,8 +382,11 @@ __device__ __forceinline__ void transition_tree(const Chain &c, uint32_t iter) {
       if (tid == 0) { unsigned pm = ts->pmask; ts->leaf_id = pool_alloc(pm, PT_NPP); ts->pmask = pm; }
       __syncthreads();
       const double e = dir ? eps : -eps;
-      LeapPolicy lp{c.st, c.soff(V_Q0 + dir), c.soff(V_P0 + dir), c.soff(V_G0 + dir), c.soff(V_MINV), c.soff(V_POOLP + ts->leaf_id), 0.5 * e, e, {0.0}};
-      const double lpv = model_pass(c.M, c.lds, lp);
+      const int sel = ts->qsel[dir];              // buffer holding this leaf's position
+      const unsigned s_leaf = c.soff(V_POOLP + ts->leaf_id);
+      LeapPolicy lp{c.st, c.soff((sel ? V_QB0 : V_QA0) + dir), c.soff((sel ? V_QA0 : V_QB0) + dir), c.soff(V_PH0 + dir), c.soff(V_MINV),
+                    s_leaf, 0.5 * e, e, {0.0}};
+      const double lpv = model_pass(c.M, c.lds, c.pst, lp);
       CPROF_START(c);
       CPROF_COUNT(c, PF_LEAVES);
       if (tid == 0) {
@@ -368,6 +402,7 @@ __device__ __forceinline__ void transition_tree(const Chain &c, uint32_t iter) {
         ts->cur_lsw = wgt; ts->cur_prop = -1; ts->cur_lp = lpv; ts->cur_h = h;
         ts->abort = div;
         ts->m = __builtin_ctz(~(unsigned)n);
+        ts->qsel[dir] = sel ^ 1;                  // the next leaf of this end reads the buffer just written
       }
       __syncthreads();
       CPROF_MARK(c, PF_LEAF_SCALAR);
@@ -418,14 +453,15 @@ __device__ __forceinline__ void transition_tree(const Chain &c, uint32_t iter) {
         ts->pend_beg[m] = ts->cur_beg; ts->pend_end[m] = ts->cur_end; ts->pend_lsw[m] = ts->cur_lsw; ts->pend_prop[m] = prop;
       }
       __syncthreads();
-      if (ts->copy_q_id >= 0) vop_copy(c, c.soff(V_POOLQ + ts->copy_q_id), c.soff(V_Q0 + dir));
+      if (ts->copy_q_id >= 0) vop_copy(c, c.soff(V_POOLQ + ts->copy_q_id), c.soff((sel ? V_QB0 : V_QA0) + dir));
       CPROF_MARK(c, PF_COPYQ);
     }
     if (!valid) break;
     // merge the finished subtree with the old trajectory (the checks at the end of transition())
     const int nb = ts->pend_beg[depth], ne = ts->pend_end[depth];
+    vop_copy(c, c.soff(V_PF0 + dir), c.soff(V_POOLP + ne));   // the last leaf is the new end point
     const unsigned n_rho = depth == 0 ? c.soff(V_POOLP + nb) : c.soff(V_RHOLEV + depth);
-    const bool persist = vop_merge(c, c.soff(V_P1 - dir), c.soff(V_PNEAR), c.soff(V_RHOTOP), c.soff(V_POOLP + nb), c.soff(V_POOLP + ne),
+    const bool persist = vop_merge(c, c.soff(V_PF1 - dir), c.soff(V_PNEAR), c.soff(V_RHOTOP), c.soff(V_POOLP + nb), c.soff(V_POOLP + ne),
                                    n_rho, c.soff(V_RHOTOP));
     if (tid == 0) {
       ts->depth = depth + 1;
@@ -446,12 +482,10 @@ __device__ __forceinline__ void transition_tree(const Chain &c, uint32_t iter) {
 }
 
 // ---------------------------------------------------------------- base_hmc::init_stepsize
-// Works on end 1 as scratch; the chain's point is Q0 with gradient G0 (already evaluated).
+// Works on end 1's buffers as scratch; the chain's point is QC with gradient GC (already evaluated).
 __device__ __forceinline__ void init_stepsize(const Chain &c, uint32_t iter) {
   ltp ts = c.ts;
   const int tid = c.tid;
-  gdp Q1 = c.vec(V_Q1), G1 = c.vec(V_G1);
-  gcdp Q0 = c.vec(V_Q0), G0 = c.vec(V_G0);
   const double lp0 = c.sc->lp_cur;
   if (tid == 0) { ts->done = 0; ts->direction = 0; }
   __syncthreads();
@@ -461,11 +495,11 @@ __device__ __forceinline__ void init_stepsize(const Chain &c, uint32_t iter) {
   }
   for (uint32_t attempt = 0;; attempt++) {
     const double eps = c.sc->nom_eps;
-    for (int i = tid; i < c.D; i += PT_THREADS) { Q1[i] = Q0[i]; G1[i] = G0[i]; }
-    const double kin0 = vop_momentum(c, c.soff(V_P1), iter, RNG_INIT_EPS, attempt);
+    const double kin0 = vop_momentum(c, c.soff(V_PC), iter, RNG_INIT_EPS, attempt);
     const double H0 = 0.5 * kin0 - lp0;
-    LeapPolicy lp{c.st, c.soff(V_Q1), c.soff(V_P1), c.soff(V_G1), c.soff(V_MINV), c.soff(V_SCR0), 0.5 * eps, eps, {0.0}};
-    const double lpv = model_pass(c.M, c.lds, lp);
+    vop_prekick(c, c.soff(V_QC), c.soff(V_PC), c.soff(V_GC), c.soff(V_PH1), c.soff(V_QA1), c.soff(V_PF1), 0.5 * eps, eps);
+    LeapPolicy lp{c.st, c.soff(V_QA1), c.soff(V_QB1), c.soff(V_PH1), c.soff(V_MINV), c.soff(V_SCR0), 0.5 * eps, eps, {0.0}};
+    const double lpv = model_pass(c.M, c.lds, c.pst, lp);
     if (tid == 0) {
       double h = 0.5 * lp.extra[0] - lpv;
       if (isnan(h)) h = INFINITY;
@@ -556,8 +590,8 @@ __device__ __forceinline__ void adapt_after_transition(const Chain &c, uint32_t 
   __syncthreads();
   if (end_window) {
     // init_stepsize starts from the current point: refresh its log density and gradient
-    PlainPolicy pol{c.st, c.st, c.soff(V_Q0), c.soff(V_G0), {0}};
-    const double lpq = model_pass(c.M, c.lds, pol);
+    PlainPolicy pol{c.st, c.st, c.soff(V_QC), c.soff(V_GC), {0}};
+    const double lpq = model_pass(c.M, c.lds, c.pst, pol);
     if (tid == 0) sc->lp_cur = lpq;
     __syncthreads();
     init_stepsize(c, iter);
