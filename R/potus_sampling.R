@@ -1,0 +1,115 @@
+# potus_sampling.R -- R host shim over libpotus_hmc.so (plain .C(), no Rcpp, no Rinternals.h).
+#
+# Drop-in for the sampler call of the reference scripts:
+#
+#   scripts/model/final_2016.R:532-543
+#     model <- cmdstanr::cmdstan_model("scripts/model/poll_model_2020.stan", compile=TRUE, force=TRUE)
+#     fit   <- model$sample(data = data, seed = 1843, parallel_chains = n_cores, chains = n_chains,
+#                           iter_warmup = n_warmup, iter_sampling = n_sampling, refresh = n_refresh)
+#     out   <- rstan::read_stan_csv(fit$output_files())
+#
+# becomes
+#
+#   source("R/potus_sampling.R"); potus_load("us_potus_model_amd/libpotus_hmc.so")
+#   fit <- potus_sample(data, variant = "full", seed = 1843, chains = n_chains,
+#                       iter_warmup = n_warmup, iter_sampling = n_sampling, refresh = n_refresh)
+#   mu_b <- potus_extract(fit, "mu_b")             # = rstan::extract(out, pars = "mu_b")[[1]]
+#   out  <- rstan::read_stan_csv(potus_output_files(fit, tempdir()))   # the literal plumbing, if a stanfit is needed
+#
+# NOTE: R is not installed in the build image, so this file is exercised only through its C
+# entry points (tests/test_gpu_parity.py drives the same symbols with ctypes).
+
+potus_load <- function(path) dyn.load(path)
+
+.potus_check <- function(status) {
+  if (status != 0L) {
+    msg <- .C("potus_R_last_error", buf = paste(rep(" ", 512), collapse = ""), len = 512L)$buf
+    stop(sprintf("libpotus_hmc error %d: %s", status, trimws(msg)), call. = FALSE)
+  }
+}
+
+potus_sample <- function(data, variant = c("full", "no_mode_adjustment"), seed = 1843, chains = 4,
+                         parallel_chains = chains, iter_warmup = 1000, iter_sampling = 1000, refresh = 100,
+                         adapt_delta = 0.8, max_treedepth = 10, init = 2, device = 0, chain_id_offset = 0,
+                         save_warmup = FALSE) {
+  variant <- match.arg(variant)
+  full <- variant == "full"
+  iv <- function(x, n) if (is.null(x)) integer(max(n, 1)) else as.integer(x)
+  dv <- function(x, n) if (is.null(x)) double(max(n, 1)) else as.double(x)
+  Ns <- as.integer(data$N_state_polls); Nn <- as.integer(data$N_national_polls)
+  dims <- as.integer(c(Nn, Ns, data$T, data$S, data$P, if (full) data$M else 0L, if (full) data$Pop else 0L,
+                       if (full) 0L else 1L))
+  scalars <- as.double(c(data$sigma_c, if (full) data$sigma_m else 0, if (full) data$sigma_pop else 0,
+                         data$sigma_measure_noise_national, data$sigma_measure_noise_state,
+                         if (full) data$sigma_e_bias else 0, data$random_walk_scale, data$mu_b_T_scale,
+                         data$polling_bias_scale))
+  res <- .C("potus_R_create", dims,
+            iv(data$state, Ns), iv(data$day_state, Ns), iv(data$day_national, Nn), iv(data$poll_state, Ns),
+            iv(data$poll_national, Nn), iv(data$poll_mode_state, Ns), iv(data$poll_mode_national, Nn),
+            iv(data$poll_pop_state, Ns), iv(data$poll_pop_national, Nn),
+            iv(data$n_democrat_national, Nn), iv(data$n_two_share_national, Nn),
+            iv(data$n_democrat_state, Ns), iv(data$n_two_share_state, Ns),
+            dv(data$unadjusted_national, Nn), dv(data$unadjusted_state, Ns),
+            as.double(data$mu_b_prior), as.double(data$state_weights), scalars,
+            as.double(data$state_covariance_0),           # column-major, as R stores it
+            as.integer(c(chains, chain_id_offset, iter_warmup, iter_sampling, max_treedepth, device,
+                         as.integer(save_warmup), seed)),
+            as.double(c(adapt_delta, 0.05, 0.75, 10, 1, init)),
+            handle = integer(1), status = integer(1))
+  .potus_check(res$status)
+  h <- res$handle
+  .potus_check(.C("potus_R_init", h, status = integer(1))$status)
+  total <- iter_warmup + iter_sampling
+  done <- 0L
+  chunk <- if (is.null(refresh) || refresh <= 0) total else as.integer(refresh)
+  while (done < total) {                     # chunked so that R can print progress / be interrupted
+    n <- min(chunk, total - done)
+    .potus_check(.C("potus_R_run", h, as.integer(n), status = integer(1))$status)
+    done <- done + n
+    message(sprintf("Iteration: %5d / %d [%3d%%]  (%s)", done, total, as.integer(100 * done / total),
+                    if (done <= iter_warmup) "Warmup" else "Sampling"))
+  }
+  info <- .C("potus_R_num_columns", h, D = integer(1), n_cols = integer(1), status = integer(1))
+  .potus_check(info$status)
+  structure(list(handle = h, D = info$D, n_cols = info$n_cols, chains = chains,
+                 n_saved = iter_sampling + if (save_warmup) iter_warmup else 0L, data = data, variant = variant,
+                 model_name = if (full) "poll_model_2020_model" else "poll_model_2020_no_mode_adjustment_model"),
+            class = "potus_fit")
+}
+
+# column ranges of the CmdStan row, 0-based [begin, end): same arithmetic as _abi.column_layout
+.potus_layout <- function(fit) {
+  d <- fit$data; full <- fit$variant == "full"
+  S <- d$S; T <- d$T; P <- d$P; Ns <- d$N_state_polls; Nn <- d$N_national_polls
+  blocks <- list(raw_mu_b_T = S, raw_mu_b = c(S, T), raw_mu_c = P)
+  if (full) blocks <- c(blocks, list(raw_mu_m = d$M, raw_mu_pop = d$Pop, mu_e_bias = integer(0), rho_e_bias = integer(0), raw_e_bias = T))
+  blocks <- c(blocks, list(raw_measure_noise_national = Nn, raw_measure_noise_state = Ns, raw_polling_bias = S,
+                           mu_b = c(S, T), mu_c = P))
+  if (full) blocks <- c(blocks, list(mu_m = d$M, mu_pop = d$Pop, e_bias = T))
+  blocks <- c(blocks, list(polling_bias = S, national_mu_b_average = T, national_polling_bias_average = integer(0)))
+  if (full) blocks <- c(blocks, list(sigma_rho = integer(0)))
+  blocks <- c(blocks, list(logit_pi_democrat_state = Ns, logit_pi_democrat_national = Nn, predicted_score = c(T, S)))
+  col <- 7L; out <- list()
+  for (nm in names(blocks)) { n <- as.integer(prod(blocks[[nm]])); out[[nm]] <- list(begin = col, end = col + n, dims = blocks[[nm]]); col <- col + n }
+  out
+}
+
+# rstan::extract(out, pars = name)[[1]] : array [draws, dims...], chains merged (chain-major)
+potus_extract <- function(fit, name) {
+  b <- .potus_layout(fit)[[name]]
+  if (is.null(b)) stop("unknown parameter ", name)
+  n <- b$end - b$begin
+  res <- .C("potus_R_write_array", fit$handle, as.integer(b$begin), as.integer(b$end),
+            out = double(fit$n_saved * fit$chains * n), status = integer(1))
+  .potus_check(res$status)
+  a <- aperm(array(res$out, c(n, fit$chains, fit$n_saved)), c(3, 2, 1))   # [iter, chain, col]
+  a <- matrix(aperm(a, c(1, 2, 3)), fit$n_saved * fit$chains, n)          # chain-major merge
+  if (length(b$dims)) array(a, c(nrow(a), b$dims)) else as.vector(a)
+}
+
+potus_output_files <- function(fit, dir, basename = "poll_model_2020") {
+  .potus_check(.C("potus_R_write_stan_csv", fit$handle, as.character(dir), as.character(basename), status = integer(1))$status)
+  file.path(dir, sprintf("%s-%d.csv", basename, seq_len(fit$chains)))
+}
+
+potus_free <- function(fit) invisible(.C("potus_R_destroy", fit$handle, status = integer(1)))
