@@ -101,6 +101,12 @@ typedef struct potus_opts {
   uint64_t seed;           /* 1843 (final_2016.R:535) */
   int32_t device;          /* HIP device ordinal */
   int32_t save_warmup;     /* 0 */
+  int32_t cus_per_chain;   /* compute units (workgroups) cooperating on one chain: 1 = one workgroup per
+                              chain (best throughput with >= 64 chains), 2..32 = a cluster per chain
+                              (lowest latency with few chains; chains * cus_per_chain <= CUs of the device),
+                              0 = choose from {16, 8, 1} by what fits.  Draws are reproducible bit for bit
+                              for a given value; different values differ in floating-point summation order. */
+  int32_t reserved;
 } potus_opts;
 
 /* per-draw sampler columns, in CmdStan order */

@@ -16,10 +16,16 @@ from us_potus_model_amd import Handle, dataprep, sampler  # noqa: E402
 data = dataprep.load_npz(ROOT / "tests" / "golden" / "data_2016.npz")["data"]
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 chain_counts = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 8, 64, 256]
-NAMES = {0: "A load+suffix", 1: "B carry/C/AR1", 2: "C polls", 3: "D gathers", 4: "E prefix/seg2", 5: "F dZ/adjoint", 6: "G reduce",
+KCL = int(os.environ.get("POTUS_K", "1"))
+NAMESK = {0: "A load+suffix", 1: "B matvec/AR + X1", 2: "carry -> C", 3: "C polls", 4: "D gathers/seg1", 5: "E prefix/seg2", 6: "E2 payload parts",
+          7: "X2 publish+wait", 18: "F finish grads", 19: "X3 allreduce", 10: "leaf scalar", 11: "merge", 12: "copy q", 13: "p_near",
+          9: "begin (all transitions)", 15: "end (all transitions)", 20: "ar:shuffle", 21: "ar:drain", 22: "ar:barrier1", 23: "ar:payload st",
+          24: "ar:signal+poll", 25: "ar:barrier2", 26: "ar:gather"}
+NAMES1 = {0: "A load+suffix", 1: "B carry/C/AR1", 2: "C polls", 3: "D gathers", 4: "E prefix/seg2", 5: "F dZ/adjoint", 6: "G reduce",
          8: "momentum", 9: "init copy", 10: "leaf scalar", 11: "merge", 12: "copy q", 13: "p_near", 14: "adapt", 15: "save"}
+NAMES = NAMES1 if KCL == 1 else NAMESK
 for chains in chain_counts:
-    h = Handle(data, "full", chains=chains, num_warmup=iters, num_samples=0, seed=1843)
+    h = Handle(data, "full", chains=chains, num_warmup=iters, num_samples=0, seed=1843, cus_per_chain=KCL)
     h.init()
     ms_tot, lf_tot = 0.0, 0
     for _ in range(3):
@@ -31,7 +37,7 @@ for chains in chain_counts:
           f"{ms_tot*1e3*chains/lf_tot:.2f} us/leapfrog/chain", flush=True)
     L = sampler.load_library()
     if hasattr(L, "potus_debug_profile"):
-        out = np.zeros((chains, 32))
+        out = np.zeros((chains * KCL, 32))
         L.potus_debug_profile.argtypes = [C.c_int, C.POINTER(C.c_double)]
         if L.potus_debug_profile(h.h, out.ctypes.data_as(C.POINTER(C.c_double))):
             p = out[0]
@@ -42,6 +48,10 @@ for chains in chain_counts:
                 print(f"    {nm:16s} {p[k]/max(leaves,1):10.0f}  ({100*p[k]/tot:4.1f}%)")
             sub = {18: "C: wave0 after dots (per trip sum)", 25: "C: wave0 at barrier", 19: "D: wave0 after prefetch issue", 20: "D: wave0 after gathers",
                    21: "D: wave0 at barrier", 24: "E: wave0 at barrier", 22: "F: wave0 after dZ", 23: "F: wave0 at barrier", 26: "B: wave0 at barrier"}
+            if KCL > 1:
+                print("  per member (cycles per leaf):  " + " ".join(f"{nm[:9]:>9s}" for nm in NAMES.values()))
+                for mm in range(KCL):
+                    print(f"    m={mm:2d}                        " + " ".join(f"{out[mm][k]/max(leaves,1):9.0f}" for k in NAMES))
             passes = leaves + 1e-9
             for k, nm in sub.items():
                 print(f"    [{nm:36s}] {p[k]/passes:10.0f}")

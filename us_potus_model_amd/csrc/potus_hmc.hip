@@ -5,6 +5,7 @@
 // Device side: potus_model.hpp (log-density + gradient), potus_nuts.hpp (NUTS + adaptation).
 #include "../../include/potus_hmc.h"
 #include "potus_nuts.hpp"
+#include "potus_cluster.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -164,6 +165,157 @@ __global__ __launch_bounds__(PT_THREADS) void k_run(const DevModel *Mg, const Ru
   }
 #ifdef POTUS_PROF
   if (R->prof) for (int i = c.tid; i < PT_NPROF; i += PT_THREADS) as_g(R->prof)[(size_t)chain * PT_NPROF + i] += c.prof[i];
+#endif
+}
+
+// ------------------------------------------------------------------------ cluster kernels (potus_cluster.hpp)
+// grid = chains * K; block b works for chain b % chains as member b / chains.
+__device__ __forceinline__ ClChain make_clchain(CMp M, CCp CL, CRp R, int chain, int m) {
+  ldp lds = (ldp)lds_dyn;
+  ClChain c;
+  const int Dpad = R->Dpad, K = CL->K;
+  double *state = R->state + (size_t)chain * V_COUNT * Dpad;
+  c.M = M; c.CL = CL; c.part = (cip)(CL->part + m * CP_N); c.lds = lds; c.ts = (ltp)(lds + CL->lds_doubles);
+  c.st = make_rsrc(state, (unsigned)V_COUNT * (unsigned)Dpad * 8u);
+  c.sc = (gsc)(R->scal + (size_t)chain * K + m);
+  c.key = RngKey{R->seed_lo, R->seed_hi, (uint32_t)(R->chain_id_offset + chain + 1)};
+  c.perm = as_g(CL->perm);
+  c.x.xb = make_rsrc(R->xbuf + (size_t)chain * 2 * K * CL->XW, 2u * (unsigned)K * (unsigned)CL->XW * 8u);
+  c.x.cnt = R->xcnt + (size_t)chain * 64;
+  c.x.epoch = 0; c.x.K = K; c.x.m = m; c.x.XW = CL->XW;
+  c.D = M->D; c.Dpad = Dpad; c.tid = (int)threadIdx.x;
+  c.e0 = c.part[CP_E0]; c.e1 = c.e0 + c.part[CP_NE];
+  c.max_depth = R->max_depth; c.num_warmup = R->num_warmup; c.init_buffer = R->init_buffer; c.term_buffer = R->term_buffer;
+  c.delta = R->delta; c.gamma = R->gamma; c.kappa = R->kappa; c.t0 = R->t0;
+#ifdef POTUS_PROF
+  c.prof = lds + CL->l_prof;
+#endif
+  return c;
+}
+
+// Parity hook on one cluster (grid = K): q, grad in Stan order; scratch = [2][Dpad] in internal order.
+__global__ __launch_bounds__(PT_THREADS) void k_cl_logprob_grad(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, const double *q,
+                                                                double *lp, double *grad, int n, double *scratch) {
+  CMp M = (CMp)Mg;
+  CCp CL = (CCp)CLg;
+  CRp R = (CRp)Rg;
+  ClChain c = make_clchain(M, CL, R, 0, blockIdx.x);
+  c.cst = cl_setup_lds(M, CL, c.part, c.lds);
+  const int D = M->D, Dpad = R->Dpad;
+  const rsrc_t rs = make_rsrc(scratch, 2u * (unsigned)Dpad * 8u);
+  for (int b = 0; b < n; b++) {
+    for (int i = c.e0 + c.tid; i < c.e1; i += PT_THREADS) bst_s(rs, 8u * i, 0, as_g(q)[(size_t)b * D + c.perm[i]]);
+    cl_sync(c.x);
+    ClPlainPolicy pol{rs, rs, 0u, (unsigned)Dpad * 8u, {0}};
+    const double v = cl_pass(M, CL, c.part, c.lds, c.cst, c.x, pol);
+    drain_vmem();
+    __syncthreads();
+    for (int i = c.e0 + c.tid; i < c.e1; i += PT_THREADS) as_g(grad)[(size_t)b * D + c.perm[i]] = bld(rs, 8u * i, (unsigned)Dpad * 8u);
+    if (blockIdx.x == 0 && c.tid == 0) lp[b] = v;
+    cl_sync(c.x);
+  }
+}
+
+__global__ __launch_bounds__(PT_THREADS) void k_cl_init(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, const double *q0) {
+  CMp M = (CMp)Mg;
+  CCp CL = (CCp)CLg;
+  CRp R = (CRp)Rg;
+  const int chain = blockIdx.x % R->chains, m = blockIdx.x / R->chains;
+  ClChain c = make_clchain(M, CL, R, chain, m);
+  c.cst = cl_setup_lds(M, CL, c.part, c.lds);
+  const int tid = c.tid;
+  const unsigned sQ = c.soff(V_QC), sG = c.soff(V_GC);
+  for (int i = c.e0 + tid; i < c.e1; i += PT_THREADS) { bst(c.st, 8u * i, c.soff(V_MINV), 1.0); bst(c.st, 8u * i, c.soff(V_WMEAN), 0.0); bst(c.st, 8u * i, c.soff(V_WM2), 0.0); }
+  if (tid == 0) {
+    gsc sc = c.sc;
+    sc->nom_eps = R->stepsize; sc->mu = log(10.0 * R->stepsize); sc->s_bar = 0; sc->x_bar = 0; sc->ad_counter = 0;
+    sc->wf_n = 0; sc->total_leapfrogs = 0; sc->iter = 0; sc->status = 0; sc->n_divergent = 0; sc->saved = 0;
+    sc->win_counter = 0; sc->win_size = R->window; sc->win_next = R->init_buffer + R->window - 1;
+  }
+  __syncthreads();
+  bool ok = false;
+  const double radius = R->init_radius;
+  for (uint32_t attempt = 0; attempt < 100 && !ok; attempt++) {
+    for (int i = c.e0 + tid; i < c.e1; i += PT_THREADS) {
+      const int si = c.perm[i];
+      bst_s(c.st, 8u * i, sQ, q0 ? as_g(q0)[(size_t)chain * c.D + si] : radius * (2.0 * rng_uniform(c.key, PT_ITER_PRE, RNG_INITS, attempt, (uint32_t)si) - 1.0));
+    }
+    cl_sync(c.x);
+    ClPlainPolicy pol{c.st, c.st, sQ, sG, {0}};
+    const double lp = cl_pass(M, CL, c.part, c.lds, c.cst, c.x, pol);
+    drain_vmem();
+    __syncthreads();
+    double bad[1] = {0.0};
+    for (int i = c.e0 + tid; i < c.e1; i += PT_THREADS) bad[0] += isfinite(bld(c.st, 8u * i, sG)) ? 0.0 : 1.0;
+    cl_allreduce(bad, c.red(), c.x, tid);
+    ok = isfinite(lp) && bad[0] == 0.0;
+    if (tid == 0 && ok) c.sc->lp_cur = lp;
+    __syncthreads();
+    if (q0) break;
+  }
+  if (!ok) { if (tid == 0) c.sc->status = POTUS_ERR_INIT; return; }   // every member takes this branch together
+  cl_init_stepsize(c, PT_ITER_PRE);
+  if (tid == 0 && R->num_warmup == 0) c.sc->nom_eps = exp(c.sc->x_bar);
+}
+
+// New sample -> chain position and draws array (Stan order); warmup adaptation.
+__device__ __forceinline__ void cl_transition_end(ClChain &c, CRp R, int chain, int it) {
+  ltp ts = c.ts;
+  const int tid = c.tid;
+  if (tid == 0) {
+    ts->accept_stat = ts->sum_metro / (double)ts->n_leap;
+    ts->out_lp = ts->q_lp[ts->sample_qid];
+    ts->out_h = ts->q_h[ts->sample_qid];
+    c.sc->total_leapfrogs += ts->n_leap;
+    c.sc->n_divergent += ts->divergent;
+  }
+  __syncthreads();
+  const bool warm = it < R->num_warmup;
+  const bool save = !warm || R->save_warmup;
+  gdp row = as_g(R->draws) + ((size_t)chain * R->n_save_max + c.sc->saved) * R->row;
+  if (save && tid == 0 && c.x.m == 0) {
+    row[0] = ts->out_lp; row[1] = ts->accept_stat; row[2] = ts->eps; row[3] = ts->depth; row[4] = ts->n_leap;
+    row[5] = ts->divergent; row[6] = ts->out_h;
+  }
+  const unsigned s_src = c.soff(V_POOLQ + ts->sample_qid), sQ = c.soff(V_QC);
+  for (int i = c.e0 + tid; i < c.e1; i += PT_THREADS) {
+    const double v = bld(c.st, 8u * i, s_src);
+    bst_s(c.st, 8u * i, sQ, v);
+    if (save) row[POTUS_N_SAMPLER_COLS + c.perm[i]] = v;
+  }
+  cl_sync(c.x);
+  if (tid == 0) {
+    c.sc->lp_cur = ts->out_lp;
+    if (save) c.sc->saved += 1;
+  }
+  if (warm) cl_adapt_after_transition(c, (uint32_t)it);
+  __syncthreads();
+  if (tid == 0) c.sc->iter = it + 1;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(PT_THREADS) void k_cl_run(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, int n_iter) {
+  CMp M = (CMp)Mg;
+  CCp CL = (CCp)CLg;
+  CRp R = (CRp)Rg;
+  const int chain = blockIdx.x % R->chains, m = blockIdx.x / R->chains;
+  ClChain c = make_clchain(M, CL, R, chain, m);
+  if (c.sc->status != 0) return;
+  c.cst = cl_setup_lds(M, CL, c.part, c.lds);
+  const int total = R->num_warmup + R->num_samples;
+  for (int k = 0; k < n_iter; k++) {
+    const int it = c.sc->iter;
+    if (it >= total) break;
+    CPROF_START(c);
+    cl_transition_begin(c, (uint32_t)it);
+    CPROF_MARK(c, PF_INITCOPY);
+    cl_transition_tree(c, (uint32_t)it);
+    CPROF_START(c);
+    cl_transition_end(c, R, chain, it);
+    CPROF_MARK(c, PF_SAVE);
+  }
+#ifdef POTUS_PROF
+  if (R->prof) for (int i = c.tid; i < PT_NPROF; i += PT_THREADS) as_g(R->prof)[((size_t)chain * CL->K + m) * PT_NPROF + i] += c.prof[i];
 #endif
 }
 
@@ -362,6 +514,13 @@ struct Sampler {
   long long last_leapfrogs = 0;
   double warm_ms = 0, samp_ms = 0;
   std::vector<double> LB, LT, LW; // column-major host copies (transformed data)
+  // cluster mode (K > 1)
+  int K = 1;
+  ClModel CL{};
+  ClModel *dCL = nullptr;
+  size_t cl_lds_bytes = 0;
+  std::vector<int> h_ps, h_pt, h_pp, h_pm, h_ppop, h_pq, h_dayptr, h_perm;   // day-sorted polls (host copies)
+  std::vector<double> h_pu;
 };
 
 std::mutex g_mu;
@@ -553,6 +712,7 @@ int build_model(Sampler *sp, const potus_data *d) {
   if ((rc = upload(sp, mat, &M.mat)) || (rc = upload(sp, pi, &M.pi)) || (rc = upload(sp, pdv, &M.pd)) ||
       (rc = upload(sp, sched, &M.sched)) || (rc = upload(sp, seg_scale, &M.seg_scale)) || (rc = upload(sp, sub_wt16, &M.sub_wt16)))
     return rc;
+  sp->h_ps = ps; sp->h_pt = pt; sp->h_pp = pp; sp->h_pm = pm; sp->h_ppop = ppop; sp->h_pq = pq; sp->h_dayptr = day_ptr; sp->h_pu = pu;
   void *pdm = nullptr;
   HIP_TRY(hipMalloc(&pdm, sizeof(DevModel)));
   sp->allocs.push_back(pdm);
@@ -565,6 +725,187 @@ int set_lds_attr(Sampler *sp) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_logprob_grad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
+  return 0;
+}
+
+// Cluster mode: split the days over K members (contiguous ranges balanced by days + polls), give every
+// parameter one owner, lay the owners' elements out contiguously and build each member's schedule.
+int build_cluster(Sampler *sp, const potus_data *d, int K) {
+  const DevModel &M = sp->M;
+  const Layout &L = sp->L;
+  const bool full = M.full;
+  const int S = M.S, T = M.T, Np = M.Npoll, P = M.P;
+  if (K < 2 || K > CL_MAXK) return fail(POTUS_ERR_ARG, "cus_per_chain must be 1 or in [2,%d]", CL_MAXK);
+  ClModel &C = sp->CL;
+  C.K = K;
+  C.NR = 2 * S + P + (full ? M.M + M.Pop + 2 : 0);
+  C.NREP = 2 * S + M.nmid;
+  C.NDP = CL_MAXDAYS + 1;
+  C.XW = (XP_P + C.NR + 7) & ~7;
+  if (C.NREP > 2 * PT_THREADS) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: %d small parameters (> %d)", C.NREP, 2 * PT_THREADS);
+  if ((C.NR + K - 1) / K > PT_THREADS - 128) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: too many pollsters for K = %d", K);
+  const std::vector<int> &dp = sp->h_dayptr;
+
+  // contiguous day ranges: minimise the largest (days + polls) with at most CL_MAXDAYS days each
+  auto groups_for = [&](int B, std::vector<int> *cut) {
+    int g = 0, t = 0;
+    if (cut) cut->assign(1, 0);
+    while (t < T) {
+      int nd = 0, cost = 0;
+      while (t < T && nd < CL_MAXDAYS) {
+        const int c1 = 1 + dp[t + 1] - dp[t];
+        if (nd > 0 && cost + c1 > B) break;
+        cost += c1; nd++; t++;
+      }
+      g++;
+      if (cut) cut->push_back(t);
+    }
+    return g;
+  };
+  int lo = 1, hi = T + Np;
+  while (lo < hi) { const int mid = (lo + hi) / 2; if (groups_for(mid, nullptr) <= K) hi = mid; else lo = mid + 1; }
+  std::vector<int> cut;
+  if (groups_for(lo, &cut) > K) return fail(POTUS_ERR_UNSUPPORTED, "T = %d days do not fit %d members of at most %d days", T, K, CL_MAXDAYS);
+  while ((int)cut.size() < K + 1) cut.push_back(T);   // members without days still own a share of the small vectors
+
+  std::vector<int> part((size_t)K * CP_N, 0), sched, perm(L.D, -1);
+  std::vector<double> wts;
+  int e = 0, npmax = 0, nsubmax = 0;
+  for (int m = 0; m < K; m++) {
+    int *pt_ = &part[(size_t)m * CP_N];
+    const int d0 = cut[m], nd = cut[m + 1] - cut[m], p0 = dp[d0], np = dp[d0 + nd] - p0;
+    const int r0 = (int)((long long)C.NR * m / K), nr = (int)((long long)C.NR * (m + 1) / K) - r0;
+    pt_[CP_D0] = d0; pt_[CP_ND] = nd; pt_[CP_P0] = p0; pt_[CP_NP] = np; pt_[CP_E0] = e; pt_[CP_R0] = r0; pt_[CP_NR] = nr;
+    npmax = std::max(npmax, np);
+    // internal order: days of raw_mu_b | noise of own polls | own days of raw_e_bias | share of the small vectors
+    for (int tl = 0; tl < nd; tl++) for (int k = 0; k < S; k++) perm[e + k + S * tl] = L.o_Z + k + S * (d0 + tl);
+    e += S * nd;
+    for (int il = 0; il < np; il++) perm[e + il] = sp->h_pq[p0 + il];
+    e += np;
+    if (full) { for (int tl = 0; tl < nd; tl++) perm[e + tl] = L.o_ze + d0 + tl; e += nd; }
+    for (int j = 0; j < nr; j++) { const int r = r0 + j; perm[e + j] = r < S ? L.o_zT + r : r < 2 * S ? L.o_zb + (r - S) : L.o_c + (r - 2 * S); }
+    e += nr;
+    pt_[CP_NE] = e - pt_[CP_E0];
+
+    // per-day gathers: local days with polls balanced over the waves (longest first)
+    std::vector<int> order, load(PT_NW, 0);
+    for (int tl = 0; tl < nd; tl++) if (dp[d0 + tl + 1] > dp[d0 + tl]) order.push_back(tl);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return dp[d0 + a + 1] - dp[d0 + a] > dp[d0 + b + 1] - dp[d0 + b]; });
+    std::vector<std::vector<int>> wt(PT_NW);
+    for (int tl : order) {
+      int wmin = 0;
+      for (int wv = 1; wv < PT_NW; wv++) if (load[wv] < load[wmin]) wmin = wv;
+      wt[wmin].push_back(tl);
+      load[wmin] += dp[d0 + tl + 1] - dp[d0 + tl] + 2;
+    }
+    std::vector<int> wd_t(PT_THREADS, 0), wd_a(PT_THREADS, 0), wd_b(PT_THREADS, 0), daymask(PT_NW, 0);
+    for (int wv = 0; wv < PT_NW; wv++)
+      for (size_t j = 0; j < wt[wv].size(); j++) {
+        const int tl = wt[wv][j];
+        wd_t[wv * 64 + j] = tl; wd_a[wv * 64 + j] = dp[d0 + tl] - p0; wd_b[wv * 64 + j] = dp[d0 + tl + 1] - p0;
+      }
+    for (int tl = 0; tl < nd; tl++) if (dp[d0 + tl + 1] > dp[d0 + tl]) daymask[tl / CL_DW] |= (int)(1u << (tl % CL_DW));
+
+    // two-level segment sums over the member's polls (local poll indices, padded with the zero slot np)
+    std::vector<int> sub16, seg_ptr{0}, seg_kind, seg_index;
+    std::vector<double> sub_wt;
+    int nsub = 0;
+    auto add_group = [&](int nseg, int kind, int index0, bool weighted, auto key) {
+      std::vector<std::vector<int>> lists(nseg);
+      for (int il = 0; il < np; il++) lists[key(p0 + il)].push_back(il);
+      for (int sgi = 0; sgi < nseg; sgi++) {
+        const auto &l = lists[sgi];
+        if (l.empty()) continue;
+        for (size_t a = 0; a < l.size(); a += PT_SUBLEN) {
+          for (size_t j = a; j < a + PT_SUBLEN; j++) {
+            sub16.push_back(j < l.size() ? l[j] : np);
+            if (weighted) sub_wt.push_back(j < l.size() ? sp->h_pu[p0 + l[j]] : 0.0);
+          }
+          nsub++;
+        }
+        seg_ptr.push_back(nsub);
+        seg_kind.push_back(kind); seg_index.push_back(index0 + sgi);
+      }
+    };
+    add_group(P, 0, 2 * S, false, [&](int i) { return sp->h_pp[i]; });
+    if (full) {
+      add_group(M.M, 0, 2 * S + P, false, [&](int i) { return sp->h_pm[i]; });
+      add_group(M.Pop, 0, 2 * S + P + M.M, false, [&](int i) { return sp->h_ppop[i]; });
+    }
+    add_group(S + 1, 1, 0, false, [&](int i) { return sp->h_ps[i]; });
+    const int wb = nsub;
+    if (full) add_group(nd, 2, 0, true, [&](int i) { return sp->h_pt[i] - d0; });
+    seg_ptr.push_back(nsub);
+    if ((int)seg_kind.size() > PT_THREADS) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: member %d has %zu segments (> %d)", m, seg_kind.size(), PT_THREADS);
+    pt_[CP_NSUB] = nsub; pt_[CP_NSEG] = (int)seg_kind.size(); pt_[CP_WB] = wb;
+    nsubmax = std::max(nsubmax, nsub);
+    auto appi = [&](const std::vector<int> &v) {
+      while (sched.size() % 4) sched.push_back(0);
+      const int off = (int)sched.size();
+      sched.insert(sched.end(), v.begin(), v.end());
+      return off;
+    };
+    pt_[CP_O_WD] = appi(wd_t); appi(wd_a); appi(wd_b);
+    pt_[CP_O_MASK] = appi(daymask); pt_[CP_O_SUB] = appi(sub16); pt_[CP_O_SEGPTR] = appi(seg_ptr);
+    pt_[CP_O_SEGKIND] = appi(seg_kind); pt_[CP_O_SEGIDX] = appi(seg_index);
+    while (wts.size() % 2) wts.push_back(0.0);
+    pt_[CP_O_WT] = (int)wts.size();
+    wts.insert(wts.end(), sub_wt.begin(), sub_wt.end());
+  }
+  if (e != L.D) return fail(POTUS_ERR_STATE, "internal: cluster layout covers %d of %d parameters", e, L.D);
+  for (int k = 0; k < 16; k++) { sched.push_back(0); wts.push_back(0.0); }
+  C.npmax = npmax; C.nsubmax = nsubmax;
+
+  std::vector<int> iperm(L.D);
+  for (int i = 0; i < L.D; i++) { if (perm[i] < 0 || perm[i] >= L.D) return fail(POTUS_ERR_STATE, "internal: bad permutation"); iperm[perm[i]] = i; }
+  std::vector<int> rep_pos(C.NREP);
+  for (int j = 0; j < C.NREP; j++) rep_pos[j] = iperm[j < S ? L.o_zT + j : j < 2 * S ? L.o_zb + (j - S) : L.o_c + (j - 2 * S)];
+  std::vector<double> rep_scale(C.NR, 1.0);
+  for (int i = 0; i < P; i++) rep_scale[2 * S + i] = d->sigma_c;
+  if (full) {
+    for (int i = 0; i < M.M; i++) rep_scale[2 * S + P + i] = d->sigma_m;
+    for (int i = 0; i < M.Pop; i++) rep_scale[2 * S + P + M.M + i] = d->sigma_pop;
+  }
+  sp->h_perm = perm;
+
+  int o = 0;
+  auto take = [&](int n) { const int a = o; o += (n + 1) & ~1; return a; };
+  C.l_C = take(std::max(S * C.NDP, 12 * M.SE));
+  C.l_Lw = take(M.SE * M.SP);
+  C.l_X = take(12 * M.SE);
+  C.l_Y = take(std::max(PT_NW * M.SE, nsubmax));
+  C.l_r = take(npmax + 2);
+  C.l_rep = take(C.NREP + 2);
+  C.l_bT = take(M.SE); C.l_pb = take(M.SE); C.l_e = take(T); C.l_c1 = take(T); C.l_c2 = take(T); C.l_c3 = take(T);
+  C.l_gs = take(M.SE); C.l_ge = take(CL_MAXDAYS); C.l_P = take(C.NR + 8); C.l_scal = take(SC_N); C.l_red = take(PT_NW * PT_NRED);
+  C.l_st = take((npmax + 8 + 7) / 8);
+  C.l_prof = take(PT_NPROF);
+  C.lds_doubles = o;
+  sp->cl_lds_bytes = (size_t)o * 8 + sizeof(TS) + 16;
+  if (sp->cl_lds_bytes > 160 * 1024) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode needs %zu bytes of LDS per workgroup", sp->cl_lds_bytes);
+
+  int rc;
+  if ((rc = upload(sp, part, &C.part)) || (rc = upload(sp, sched, &C.sched)) || (rc = upload(sp, wts, &C.wt)) ||
+      (rc = upload(sp, rep_pos, &C.rep_pos)) || (rc = upload(sp, rep_scale, &C.rep_scale)) || (rc = upload(sp, perm, &C.perm)))
+    return rc;
+  void *pc = nullptr;
+  HIP_TRY(hipMalloc(&pc, sizeof(ClModel)));
+  sp->allocs.push_back(pc);
+  HIP_TRY(hipMemcpy(pc, &C, sizeof(ClModel), hipMemcpyHostToDevice));
+  sp->dCL = (ClModel *)pc;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cl_logprob_grad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cl_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cl_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
+  sp->K = K;
+  return 0;
+}
+
+// replica 0 of every chain's scalars
+int read_scalars(Sampler *sp, std::vector<ChainScalars> &sc) {
+  std::vector<ChainScalars> all((size_t)sp->R.chains * sp->K);
+  HIP_TRY(hipMemcpy(all.data(), sp->R.scal, sizeof(ChainScalars) * all.size(), hipMemcpyDeviceToHost));
+  sc.resize(sp->R.chains);
+  for (int c = 0; c < sp->R.chains; c++) sc[c] = all[(size_t)c * sp->K];
   return 0;
 }
 
@@ -585,7 +926,7 @@ void potus_default_opts(potus_opts *o) {
   o->chains = 4; o->chain_id_offset = 0; o->num_warmup = 1000; o->num_samples = 1000; o->max_depth = 10;
   o->init_buffer = 75; o->term_buffer = 50; o->window = 25;
   o->delta = 0.8; o->gamma = 0.05; o->kappa = 0.75; o->t0 = 10; o->stepsize = 1.0; o->init_radius = 2.0;
-  o->seed = 1843; o->device = 0; o->save_warmup = 0;
+  o->seed = 1843; o->device = 0; o->save_warmup = 0; o->cus_per_chain = 0;
 }
 
 int potus_num_params(const potus_data *d, int *D) {
@@ -651,6 +992,15 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   auto bail = [&](int code) { for (void *p : sp->allocs) (void)hipFree(p); delete sp; return code; };
   if ((rc = build_model(sp, d))) return bail(rc);
   if ((rc = set_lds_attr(sp))) return bail(rc);
+  {
+    // workgroups (CUs) per chain: 0 = as many as fit the device, in {16, 8, 1}; chains * K blocks must be co-resident
+    const int ncu = prop.multiProcessorCount;
+    int K = o->cus_per_chain;
+    if (K < 0 || K > CL_MAXK) return bail(fail(POTUS_ERR_ARG, "cus_per_chain must be in [0,%d]", CL_MAXK));
+    if (K == 0) K = o->chains * 16 <= ncu ? 16 : o->chains * 8 <= ncu ? 8 : 1;
+    if (K > 1 && o->chains * K > ncu) return bail(fail(POTUS_ERR_ARG, "chains * cus_per_chain = %d exceeds the %d compute units of the device", o->chains * K, ncu));
+    if (K > 1 && (rc = build_cluster(sp, d, K))) return bail(rc);
+  }
   if (hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&sp->ev0) != hipSuccess ||
       hipEventCreate(&sp->ev1) != hipSuccess)
     return bail(fail(POTUS_ERR_DEVICE, "stream/event creation failed"));
@@ -672,18 +1022,28 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   if (hipMalloc(&p, state_bytes) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc(%zu) for chain state failed", state_bytes));
   sp->allocs.push_back(p); R.state = (double *)p;
   (void)hipMemset(p, 0, state_bytes);
-  if (hipMalloc(&p, sizeof(ChainScalars) * o->chains) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for chain scalars failed"));
+  if (hipMalloc(&p, sizeof(ChainScalars) * o->chains * sp->K) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for chain scalars failed"));
   sp->allocs.push_back(p); R.scal = (ChainScalars *)p;
-  (void)hipMemset(p, 0, sizeof(ChainScalars) * o->chains);
+  (void)hipMemset(p, 0, sizeof(ChainScalars) * o->chains * sp->K);
+  R.K = sp->K; R.xbuf = nullptr; R.xcnt = nullptr;
+  if (sp->K > 1) {
+    const size_t xb = (size_t)o->chains * 2 * sp->K * sp->CL.XW * sizeof(double);
+    if (hipMalloc(&p, xb) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for exchange buffers failed"));
+    sp->allocs.push_back(p); R.xbuf = (double *)p;
+    (void)hipMemset(p, 0, xb);
+    if (hipMalloc(&p, (size_t)o->chains * 64 * sizeof(unsigned)) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for exchange counters failed"));
+    sp->allocs.push_back(p); R.xcnt = (unsigned *)p;
+    (void)hipMemset(p, 0, (size_t)o->chains * 64 * sizeof(unsigned));
+  }
   const size_t draw_bytes = std::max<size_t>((size_t)o->chains * R.n_save_max * R.row, 1) * sizeof(double);
   if (hipMalloc(&p, draw_bytes) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc(%zu) for draws failed", draw_bytes));
   sp->allocs.push_back(p); R.draws = (double *)p;
   (void)hipMemset(p, 0, draw_bytes);
 
 #ifdef POTUS_PROF
-  if (hipMalloc(&p, sizeof(double) * PT_NPROF * o->chains) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for profile failed"));
+  if (hipMalloc(&p, sizeof(double) * PT_NPROF * o->chains * sp->K) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for profile failed"));
   sp->allocs.push_back(p); R.prof = (double *)p;
-  (void)hipMemset(p, 0, sizeof(double) * PT_NPROF * o->chains);
+  (void)hipMemset(p, 0, sizeof(double) * PT_NPROF * o->chains * sp->K);
 #else
   R.prof = nullptr;
 #endif
@@ -718,13 +1078,22 @@ int potus_log_prob_grad(int handle, const double *q, int n, double *lp, double *
   double *dq = nullptr, *dlp = nullptr, *dg = nullptr;
   HIP_TRY(hipMalloc((void **)&dq, n * D * 8)); HIP_TRY(hipMalloc((void **)&dg, n * D * 8)); HIP_TRY(hipMalloc((void **)&dlp, (size_t)n * 8));
   HIP_TRY(hipMemcpyAsync(dq, q, n * D * 8, hipMemcpyHostToDevice, sp->stream));
-  const int grid = std::min(n, 1024);
-  hipLaunchKernelGGL(k_logprob_grad, dim3(grid), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const double *)dq, dlp, dg, n);
+  double *dscr = nullptr;
+  if (sp->K > 1) {   // the cluster's own pass, on one cluster
+    HIP_TRY(hipMalloc((void **)&dscr, 2 * (size_t)sp->R.Dpad * 8));
+    HIP_TRY(hipMemsetAsync(sp->R.xcnt, 0, (size_t)sp->R.chains * 64 * sizeof(unsigned), sp->stream));
+    hipLaunchKernelGGL(k_cl_logprob_grad, dim3(sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
+                       (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq, dlp, dg, n, dscr);
+  } else {
+    const int grid = std::min(n, 1024);
+    hipLaunchKernelGGL(k_logprob_grad, dim3(grid), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const double *)dq, dlp, dg, n);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(lp, dlp, (size_t)n * 8, hipMemcpyDeviceToHost, sp->stream));
   HIP_TRY(hipMemcpyAsync(grad, dg, n * D * 8, hipMemcpyDeviceToHost, sp->stream));
   HIP_TRY(hipStreamSynchronize(sp->stream));
   (void)hipFree(dq); (void)hipFree(dg); (void)hipFree(dlp);
+  if (dscr) (void)hipFree(dscr);
   return 0;
 }
 
@@ -735,12 +1104,17 @@ int potus_init(int handle, const double *q0) {
   double *dq0 = nullptr;
   const size_t bytes = (size_t)sp->R.chains * sp->L.D * 8;
   if (q0) { HIP_TRY(hipMalloc((void **)&dq0, bytes)); HIP_TRY(hipMemcpyAsync(dq0, q0, bytes, hipMemcpyHostToDevice, sp->stream)); }
-  hipLaunchKernelGGL(k_init, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, (const double *)dq0);
+  if (sp->K > 1) {
+    HIP_TRY(hipMemsetAsync(sp->R.xcnt, 0, (size_t)sp->R.chains * 64 * sizeof(unsigned), sp->stream));
+    hipLaunchKernelGGL(k_cl_init, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
+                       (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq0);
+  } else
+    hipLaunchKernelGGL(k_init, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, (const double *)dq0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(sp->stream));
   if (dq0) (void)hipFree(dq0);
-  std::vector<ChainScalars> sc(sp->R.chains);
-  HIP_TRY(hipMemcpy(sc.data(), sp->R.scal, sizeof(ChainScalars) * sc.size(), hipMemcpyDeviceToHost));
+  std::vector<ChainScalars> sc;
+  { const int rc_ = read_scalars(sp, sc); if (rc_) return rc_; }
   for (int c = 0; c < sp->R.chains; c++)
     if (sc[c].status == POTUS_ERR_INIT) return fail(POTUS_ERR_INIT, "chain %d: no finite initial log density/gradient after 100 attempts", c + 1);
   sp->inited = true;
@@ -756,8 +1130,13 @@ int potus_run(int handle, int n_iter) {
   long long before = 0, after = 0;
   potus_total_leapfrogs(handle, &before);
   int it0 = 0; potus_iterations_done(handle, &it0);
+  if (sp->K > 1) HIP_TRY(hipMemsetAsync(sp->R.xcnt, 0, (size_t)sp->R.chains * 64 * sizeof(unsigned), sp->stream));
   HIP_TRY(hipEventRecord(sp->ev0, sp->stream));
-  hipLaunchKernelGGL(k_run, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, n_iter);
+  if (sp->K > 1)
+    hipLaunchKernelGGL(k_cl_run, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
+                       (const ClModel *)sp->dCL, (const RunParams *)sp->dR, n_iter);
+  else
+    hipLaunchKernelGGL(k_run, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, n_iter);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(sp->ev1, sp->stream));
   HIP_TRY(hipStreamSynchronize(sp->stream));
@@ -777,8 +1156,8 @@ int potus_iterations_done(int handle, int *n) {
   Sampler *sp = get(handle);
   if (!sp || !n) return fail(POTUS_ERR_STATE, "bad handle");
   HIP_TRY(hipSetDevice(sp->device));
-  std::vector<ChainScalars> sc(sp->R.chains);
-  HIP_TRY(hipMemcpy(sc.data(), sp->R.scal, sizeof(ChainScalars) * sc.size(), hipMemcpyDeviceToHost));
+  std::vector<ChainScalars> sc;
+  { const int rc_ = read_scalars(sp, sc); if (rc_) return rc_; }
   int m = sc[0].iter;
   for (auto &s : sc) m = std::min(m, s.iter);
   *n = m;
@@ -789,8 +1168,8 @@ int potus_total_leapfrogs(int handle, long long *n) {
   Sampler *sp = get(handle);
   if (!sp || !n) return fail(POTUS_ERR_STATE, "bad handle");
   HIP_TRY(hipSetDevice(sp->device));
-  std::vector<ChainScalars> sc(sp->R.chains);
-  HIP_TRY(hipMemcpy(sc.data(), sp->R.scal, sizeof(ChainScalars) * sc.size(), hipMemcpyDeviceToHost));
+  std::vector<ChainScalars> sc;
+  { const int rc_ = read_scalars(sp, sc); if (rc_) return rc_; }
   long long t = 0;
   for (auto &s : sc) t += s.total_leapfrogs;
   *n = t;
@@ -801,8 +1180,8 @@ int potus_chain_status(int handle, int *status, int *n_divergent) {
   Sampler *sp = get(handle);
   if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
   HIP_TRY(hipSetDevice(sp->device));
-  std::vector<ChainScalars> sc(sp->R.chains);
-  HIP_TRY(hipMemcpy(sc.data(), sp->R.scal, sizeof(ChainScalars) * sc.size(), hipMemcpyDeviceToHost));
+  std::vector<ChainScalars> sc;
+  { const int rc_ = read_scalars(sp, sc); if (rc_) return rc_; }
   for (int c = 0; c < sp->R.chains; c++) { if (status) status[c] = sc[c].status; if (n_divergent) n_divergent[c] = sc[c].n_divergent; }
   return 0;
 }
@@ -811,19 +1190,25 @@ int potus_get_adaptation(int handle, double *stepsize, double *inv_metric) {
   Sampler *sp = get(handle);
   if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
   HIP_TRY(hipSetDevice(sp->device));
-  std::vector<ChainScalars> sc(sp->R.chains);
-  HIP_TRY(hipMemcpy(sc.data(), sp->R.scal, sizeof(ChainScalars) * sc.size(), hipMemcpyDeviceToHost));
+  std::vector<ChainScalars> sc;
+  { const int rc_ = read_scalars(sp, sc); if (rc_) return rc_; }
   for (int c = 0; c < sp->R.chains; c++) {
     if (stepsize) stepsize[c] = sc[c].nom_eps;
-    if (inv_metric)
-      HIP_TRY(hipMemcpy(inv_metric + (size_t)c * sp->L.D, sp->R.state + ((size_t)c * V_COUNT + V_MINV) * sp->R.Dpad, (size_t)sp->L.D * 8, hipMemcpyDeviceToHost));
+    if (inv_metric) {
+      double *dst = inv_metric + (size_t)c * sp->L.D;
+      HIP_TRY(hipMemcpy(dst, sp->R.state + ((size_t)c * V_COUNT + V_MINV) * sp->R.Dpad, (size_t)sp->L.D * 8, hipMemcpyDeviceToHost));
+      if (sp->K > 1) {   // the cluster keeps its vectors in internal order
+        std::vector<double> tmp(dst, dst + sp->L.D);
+        for (int i = 0; i < sp->L.D; i++) dst[sp->h_perm[i]] = tmp[i];
+      }
+    }
   }
   return 0;
 }
 
 static int saved_count(Sampler *sp, int *n_saved) {
-  std::vector<ChainScalars> sc(sp->R.chains);
-  HIP_TRY(hipMemcpy(sc.data(), sp->R.scal, sizeof(ChainScalars) * sc.size(), hipMemcpyDeviceToHost));
+  std::vector<ChainScalars> sc;
+  { const int rc_ = read_scalars(sp, sc); if (rc_) return rc_; }
   int m = sc[0].saved;
   for (auto &s : sc) m = std::min(m, s.saved);
   *n_saved = m;
@@ -953,7 +1338,7 @@ int potus_debug_profile(int handle, double *out) {
   Sampler *sp = get(handle);
   if (!sp || !sp->R.prof || !out) return 0;
   (void)hipSetDevice(sp->device);
-  if (hipMemcpy(out, sp->R.prof, sizeof(double) * PT_NPROF * sp->R.chains, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  if (hipMemcpy(out, sp->R.prof, sizeof(double) * PT_NPROF * sp->R.chains * sp->K, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return PT_NPROF;
 }
 
