@@ -37,7 +37,7 @@ for chains in chain_counts:
           f"{ms_tot*1e3*chains/lf_tot:.2f} us/leapfrog/chain", flush=True)
     L = sampler.load_library()
     if hasattr(L, "potus_debug_profile"):
-        out = np.zeros((chains * KCL, 32))
+        out = np.zeros((chains * KCL, 64))
         L.potus_debug_profile.argtypes = [C.c_int, C.POINTER(C.c_double)]
         if L.potus_debug_profile(h.h, out.ctypes.data_as(C.POINTER(C.c_double))):
             p = out[0]
@@ -52,6 +52,10 @@ for chains in chain_counts:
                 print("  per member (cycles per leaf):  " + " ".join(f"{nm[:9]:>9s}" for nm in NAMES.values()))
                 for mm in range(KCL):
                     print(f"    m={mm:2d}                        " + " ".join(f"{out[mm][k]/max(leaves,1):9.0f}" for k in NAMES))
+            if KCL > 1:
+                for ph, nm in ((0, "B per wave"), (1, "D gathers per wave"), (2, "D gathers+seg1 per wave")):
+                    for mm in (0, KCL - 4, KCL - 1):
+                        print(f"  {nm} (cycles per leaf, member {mm}): ", [int(out[mm][32 + 8 * ph + w] / max(leaves, 1)) for w in range(8)])
             passes = leaves + 1e-9
             for k, nm in sub.items():
                 print(f"    [{nm:36s}] {p[k]/passes:10.0f}")

@@ -27,6 +27,7 @@
 // its L2.  All blocks must be co-resident (grid <= number of CUs; checked on the host).
 #pragma once
 #include "potus_nuts.hpp"
+#include "potus_dpp.hpp"
 
 #define CL_DW 8                          // days per wave
 #define CL_MAXDAYS (PT_NW * CL_DW)       // days per member
@@ -45,12 +46,12 @@ enum { XP_PRE = 0, XP_AR = 64, XP_S = 66, XP_P = 72 };
 struct ClModel {
   int K, XW, NR, NREP, NDP, npmax, nsubmax, pad0;
   const int *part;          // [K][CP_N]
-  const int *sched;         // per member: wd_t|wd_a|wd_b [PT_THREADS] each, daymask [PT_NW], sub16, seg_ptr, seg_kind, seg_index
+  const int *sched;         // per member: wd_a|wd_b [PT_THREADS], wd0|wnd [PT_NW], sub16, seg_ptr, seg_kind, seg_index
   const double *wt;         // weights of the weighted level-1 tasks
   const int *rep_pos;       // [NREP] internal index of the small parameters every member reads: zT | zb | c,m,pop,mue,rho,ze
   const double *rep_scale;  // [NR] scale of owned slot r (sigma_c ... ; 1 for zT, zb)
   const int *perm;          // [D] internal index -> Stan index
-  int l_C, l_Lw, l_X, l_Y, l_r, l_rep, l_bT, l_pb, l_e, l_c1, l_c2, l_c3, l_gs, l_ge, l_P, l_scal, l_red, l_st, l_prof;
+  int l_C, l_Lw, l_LT, l_LB, l_w, l_prior, l_pm, l_py, l_pN, l_pun, l_sub, l_tab, l_gev, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_pb, l_e, l_c1, l_c2, l_c3, l_gs, l_ge, l_P, l_scal, l_red, l_st, l_prof;
   int lds_doubles;
 };
 typedef const ClModel AS_C *CCp;
@@ -82,38 +83,62 @@ template <class P> __device__ __forceinline__ P launder_s(P p) { // keep address
 #define CPROFPTR(c) nullptr
 #endif
 // ---------------------------------------------------------------- exchanges
+// Every payload word travels as 16 bytes {value, tag}: tag = (launch id, exchange number).  A reader
+// simply re-loads until the tag is the one it expects, so publishing is a fire-and-forget store and
+// there is no counter, no separate flag and no barrier on the consumer side.  Payload buffers rotate
+// over four slots (exchange number mod 4).  Safe because a member publishes exchange e+3 only after
+// consuming e+1 and e+2, at least one of which is read by every member from every member (only X1 is
+// not, and two X1 are never adjacent): everybody has then published that one, hence finished reading e.
 struct Xch {
-  rsrc_t xb;               // the chain's exchange buffer [2][K][XW] doubles
-  unsigned *cnt;           // the chain's arrival counter (zeroed by the host before every launch)
-  unsigned epoch;          // exchanges completed so far in this launch (identical in every member)
+  rsrc_t xb;               // the chain's exchange buffer [4][K][XW] words of 16 bytes
+  unsigned epoch;          // exchanges published so far in this launch (identical in every member)
+  unsigned launch;         // launch id (host counter): stale words of earlier launches never match
   int K, m, XW;
 };
-// byte offset of member mm's payload: w = the exchange being assembled, r = the one just completed
-__device__ __forceinline__ unsigned xch_wslot(const Xch &x, int mm) { return ((((x.epoch + 1u) & 1u) * (unsigned)x.K + (unsigned)mm) * (unsigned)x.XW) * 8u; }
-__device__ __forceinline__ unsigned xch_rslot(const Xch &x, int mm) { return (((x.epoch & 1u) * (unsigned)x.K + (unsigned)mm) * (unsigned)x.XW) * 8u; }
-// Wave 0 only, after a barrier that follows every payload store of the workgroup: publish and wait.
-__device__ __forceinline__ void xch_signal_wait(const Xch &x) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if ((threadIdx.x & 63) == 0) {
-    __hip_atomic_fetch_add(x.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned want = (x.epoch + 1u) * (unsigned)x.K;
-    unsigned spins = 0;
-    while (__hip_atomic_load(x.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > CL_SPIN_LIMIT) __builtin_trap();   // a member is missing: fail loudly instead of hanging the GPU
+// byte offset of member mm's payload: w = the exchange being assembled (number epoch+1), r = the one
+// just published (call after epoch++)
+__device__ __forceinline__ unsigned xch_wslot(const Xch &x, int mm) { return ((((x.epoch + 1u) & 3u) * (unsigned)x.K + (unsigned)mm) * (unsigned)x.XW) * 16u; }
+__device__ __forceinline__ unsigned xch_rslot(const Xch &x, int mm) { return (((x.epoch & 3u) * (unsigned)x.K + (unsigned)mm) * (unsigned)x.XW) * 16u; }
+// publish one word of the exchange being assembled (voff = 16 * word, or PT_OOB for idle lanes)
+__device__ __forceinline__ void xst(const Xch &x, unsigned voff, double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const u32x4 w = {(unsigned)u, (unsigned)(u >> 32), x.epoch + 1u, x.launch};
+  __builtin_amdgcn_raw_buffer_store_b128(w, x.xb, voff, xch_wslot(x, x.m), CL_AUX_SC1);
+}
+// fetch NB words of the exchange just published (per-lane byte offsets vo, PT_OOB = idle lane -> 0;
+// uniform slot offsets so); spins until every tag of the wave matches
+template <int NB>
+__device__ __forceinline__ void xld(const Xch &x, const unsigned (&vo)[NB], const unsigned (&so)[NB], double (&out)[NB]) {
+  u32x4 w[NB];
+  bool done[NB];                                   // wave-uniform
+#pragma unroll
+  for (int u = 0; u < NB; u++) w[u] = __builtin_amdgcn_raw_buffer_load_b128(x.xb, vo[u], so[u], CL_AUX_SC1);
+  bool all = true;
+#pragma unroll
+  for (int u = 0; u < NB; u++) { done[u] = __all(vo[u] == PT_OOB || (w[u][2] == x.epoch && w[u][3] == x.launch)); all = all && done[u]; }
+  // words that were not there yet are fetched again together; words already in hand are not re-read (an
+  // out-of-range offset costs no memory traffic), so a spinning wave does not flood the memory pipeline
+  for (unsigned spins = 0; !all; spins++) {
+    if (spins > CL_SPIN_LIMIT) __builtin_trap();   // a member is missing: fail loudly instead of hanging the GPU
+    __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < NB; u++)
+      if (!done[u]) w[u] = __builtin_amdgcn_raw_buffer_load_b128(x.xb, vo[u], so[u], CL_AUX_SC1 | (int)0x80000000);
+    all = true;
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+      if (!done[u]) done[u] = __all(vo[u] == PT_OOB || (w[u][2] == x.epoch && w[u][3] == x.launch));
+      all = all && done[u];
     }
   }
+#pragma unroll
+  for (int u = 0; u < NB; u++) out[u] = __hiloint2double((int)w[u][1], (int)w[u][0]);   // idle lanes loaded zeros
 }
-// Cluster-wide barrier that also orders sc1 stores before it against sc1 loads after it.
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void cl_sync(Xch &x) {
-  drain_vmem();
-  __syncthreads();
-  if (threadIdx.x < 64) xch_signal_wait(x);
-  __syncthreads();
-  x.epoch++;
-}
 // Sum N <= 8 values over every thread of every member; all threads of all members return the same bits.
+// Also a cluster-wide barrier: plain or write-through stores issued by any wave of any member before
+// the call are visible to sc1 loads issued after it.
 template <int N>
 __device__ __forceinline__ void cl_allreduce(double (&v)[N], ldp red, Xch &x, int tid, ldp prof = nullptr) {
   (void)prof;
@@ -121,13 +146,11 @@ __device__ __forceinline__ void cl_allreduce(double (&v)[N], ldp red, Xch &x, in
   const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    double t = v[k];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) t += __shfl_down(t, off, 64);
-    if (lane == 0) red[w * N + k] = t;
+    const double t = dpp_scan_sum(v[k]);
+    if (lane == 63) red[w * N + k] = t;
   }
   PROF_MARK(20);
-  drain_vmem();   // this wave's write-through stores are complete before the workgroup signals
+  drain_vmem();   // this wave's stores are complete before the workgroup publishes
   PROF_MARK(21);
   __syncthreads();
   PROF_MARK(22);
@@ -136,28 +159,76 @@ __device__ __forceinline__ void cl_allreduce(double (&v)[N], ldp red, Xch &x, in
     const int k = lane < N ? lane : N - 1;
 #pragma unroll
     for (int i = 0; i < PT_NW; i++) s += red[i * N + k];
-    bst_s(x.xb, lane < N ? 8u * (unsigned)lane : PT_OOB, xch_wslot(x, x.m), s);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PROF_MARK(23);
-    xch_signal_wait(x);
+    xst(x, lane < N ? 16u * (unsigned)lane : PT_OOB, s);
+  }
+  x.epoch++;
+  PROF_MARK(23);
+  // wave 0: lane l fetches word (l & 7) of members (l >> 3) + 8u; fixed-shape tree over the members
+  if (w == 0) {
+    double s[CL_MAXK / 8];
+    unsigned vo[CL_MAXK / 8], so[CL_MAXK / 8];
+#pragma unroll
+    for (int u = 0; u < CL_MAXK / 8; u++) {
+      const int mm = (lane >> 3) + 8 * u;
+      vo[u] = (mm < x.K && (lane & 7) < N) ? (unsigned)mm * (unsigned)x.XW * 16u + 16u * (unsigned)(lane & 7) : PT_OOB;
+      so[u] = xch_rslot(x, 0);
+    }
+    xld(x, vo, so, s);
+    PROF_MARK(24);
+    double t = ((s[0] + s[1]) + s[2]) + s[3];
+    t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+    if (lane < N) red[PT_NW * N + lane] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; k++) v[k] = red[PT_NW * N + k];
+  PROF_MARK(26);
+}
+// All-reduce of nv <= CL_WIDE values whose per-wave partial sums sit in LDS (part[v * PT_NW + wave]); the
+// totals land in out[0 .. nv) (LDS) for every thread of every member, bit-identical everywhere.
+#define CL_WIDE 96
+__device__ __forceinline__ void cl_allreduce_wide(ldp part, int nv, ldp out, Xch &x, ldp prof = nullptr) {
+  (void)prof;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  PROF_MARK(20);
+  drain_vmem();
+  PROF_MARK(21);
+  __syncthreads();
+  PROF_MARK(22);
+  if (w == 0) {
+    for (int l0 = 0; l0 < nv; l0 += 64) {
+      const int l = l0 + lane;
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < PT_NW; i++) s += part[(l < nv ? l : 0) * PT_NW + i];
+      xst(x, l < nv ? 16u * (unsigned)l : PT_OOB, s);
+    }
+  }
+  x.epoch++;
+  PROF_MARK(23);
+  if (w == 0) {
+    for (int l0 = 0; l0 < nv; l0 += 64) {
+      const int l = l0 + lane;
+      double tot = 0.0;
+      for (int mm0 = 0; mm0 < x.K; mm0 += 16) {
+        double t16[16];
+        unsigned vo[16], so[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int mm = mm0 + u; vo[u] = (mm < x.K && l < nv) ? 16u * (unsigned)l : PT_OOB; so[u] = xch_rslot(x, mm < x.K ? mm : 0); }
+        xld(x, vo, so, t16);
+#pragma unroll
+        for (int u = 0; u < 16; u++) tot += t16[u];
+      }
+      if (l < nv) out[l] = tot;
+    }
     PROF_MARK(24);
   }
   __syncthreads();
-  PROF_MARK(25);
-  x.epoch++;
-  // lane l fetches word (l & 7) of members (l >> 3) + 8u; fixed-shape tree over the members
-  double s[CL_MAXK / 8];
-  const unsigned base = xch_rslot(x, 0);
-#pragma unroll
-  for (int u = 0; u < CL_MAXK / 8; u++) {
-    const int mm = (lane >> 3) + 8 * u;
-    s[u] = bld_s(x.xb, (mm < x.K && (lane & 7) < N) ? (unsigned)mm * (unsigned)x.XW * 8u + 8u * (unsigned)(lane & 7) : PT_OOB, base);
-  }
-  double t = ((s[0] + s[1]) + s[2]) + s[3];
-  t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
-#pragma unroll
-  for (int k = 0; k < N; k++) v[k] = readlane_d(t, k);
   PROF_MARK(26);
+}
+__device__ __forceinline__ void cl_sync(Xch &x, ldp red) {
+  double v[1] = {0.0};
+  cl_allreduce(v, red, x, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------- policies (internal element order)
@@ -208,19 +279,37 @@ struct ClLeapPolicy {
 };
 
 struct ClStatic {           // per-thread registers that never change during a kernel
-  int d_t, d_a, d_b;        // lane j of wave w: j-th day gathered by the wave (local day, local poll range)
+  int s2info;               // lane j < CL_DW of wave w, for the wave's j-th day: (last polled local day <= it) + 1 (0 = none)
+                            //   | chunk holding that day's last poll << 8
+  int wd0, wnd;             // the wave's days: local days [wd0, wd0 + wnd), wnd <= CL_DW
+  int ca, cb;               // the wave's chunk of the member's polls (day order) in the adjoint gather
   unsigned rep_vo[2];       // byte offsets of the small parameters this thread fetches for the workgroup
+  int sg_a, sg_b, sg_kind, sg_index;   // level-2 segment summed by this thread: task range, what the sum feeds
+  double scale_r;           // scale of the small-vector slot this thread owns (threads 128 ..)
 };
 
 __device__ __forceinline__ ClStatic cl_load_static(CCp CL, cip part) {
   ClStatic c;
   gcip sc = as_g(CL->sched) + part[CP_O_WD];
   const int tid = threadIdx.x;
-  c.d_t = sc[tid]; c.d_a = sc[PT_THREADS + tid]; c.d_b = sc[2 * PT_THREADS + tid];
+  c.s2info = sc[tid];
+  c.wd0 = sc[PT_THREADS + (tid >> 6)]; c.wnd = sc[PT_THREADS + PT_NW + (tid >> 6)];
+  c.ca = sc[PT_THREADS + 2 * PT_NW + (tid >> 6)]; c.cb = sc[PT_THREADS + 3 * PT_NW + (tid >> 6)];
   gcip rp = as_g(CL->rep_pos);
   const int NREP = CL->NREP;
 #pragma unroll
   for (int u = 0; u < 2; u++) { const int j = tid + u * PT_THREADS; c.rep_vo[u] = j < NREP ? 8u * (unsigned)rp[j] : PT_OOB; }
+  {
+    gcip sch = as_g(CL->sched);
+    const int nseg = part[CP_NSEG];
+    const bool ok = tid < nseg;
+    c.sg_a = ok ? sch[part[CP_O_SEGPTR] + tid] : 0;
+    c.sg_b = ok ? sch[part[CP_O_SEGPTR] + tid + 1] : 0;
+    c.sg_kind = ok ? sch[part[CP_O_SEGKIND] + tid] : 3;
+    c.sg_index = ok ? sch[part[CP_O_SEGIDX] + tid] : 0;
+    const int jr = tid - 128;
+    c.scale_r = (jr >= 0 && jr < part[CP_NR]) ? as_g(CL->rep_scale)[part[CP_R0] + jr] : 0.0;
+  }
   return c;
 }
 // Stage the walk factor and the (pseudo-)states of the member's polls in LDS, once per kernel.
@@ -228,10 +317,50 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
   ldp Lw = lds + CL->l_Lw;
   gcdp src = as_g(M->mat);
   for (int i = threadIdx.x; i < M->SE * M->SP; i += PT_THREADS) Lw[i] = src[i];
+  {
+    // the two 51 x 51 factors of stan:77,85, row-major with the odd row stride SP
+    ldp LT = lds + CL->l_LT, LB = lds + CL->l_LB;
+    const int S = M->S, SP = M->SP;
+    for (int i = threadIdx.x; i < S * S; i += PT_THREADS) {
+      const int r = i / S, k = i - r * S;
+      LT[r * SP + k] = src[M->m_LT + i];
+      LB[r * SP + k] = src[M->m_LB + i];
+    }
+    for (int i = threadIdx.x; i < S; i += PT_THREADS) { (lds + CL->l_w)[i] = src[M->m_w + i]; (lds + CL->l_prior)[i] = src[M->m_prior + i]; }
+  }
   unsigned char AS_L *st = (unsigned char AS_L *)(lds + CL->l_st);
   gcip ps = as_g(M->pi) + part[CP_P0];
   const int np = part[CP_NP];
   for (int i = threadIdx.x; i < np + 8; i += PT_THREADS) st[i] = i < np ? (unsigned char)ps[i] : (unsigned char)0;
+  {
+    // per-poll constants: {state, local day, pollster, mode, population} packed in 64 bits; y, N, unadjusted flag
+    unsigned long long AS_L *pm = (unsigned long long AS_L *)(lds + CL->l_pm);
+    ldp py = lds + CL->l_py, pN = lds + CL->l_pN, pun = lds + CL->l_pun;
+    const int Npad = M->Npad, p0 = part[CP_P0], d0 = part[CP_D0], full = M->full;
+    gcip pi = as_g(M->pi);
+    gcdp pd = as_g(M->pd);
+    for (int i = threadIdx.x; i < np + 8; i += PT_THREADS) {
+      unsigned long long v = 0;
+      double y = 0.0, N = 0.0, un = 0.0;
+      if (i < np) {
+        const int g = p0 + i;
+        v = (unsigned long long)(unsigned)pi[g] | ((unsigned long long)(unsigned)(pi[Npad + g] - d0) << 8) |
+            ((unsigned long long)(unsigned)pi[2 * Npad + g] << 16);
+        if (full) v |= ((unsigned long long)(unsigned)pi[3 * Npad + g] << 32) | ((unsigned long long)(unsigned)pi[4 * Npad + g] << 40);
+        y = pd[g]; N = pd[Npad + g]; un = full ? pd[2 * Npad + g] : 0.0;
+      }
+      pm[i] = v; py[i] = y; pN[i] = N; pun[i] = un;
+    }
+    // gather program: per poll (day order) state | local day << 8 | flags << 16
+    unsigned AS_L *tab = (unsigned AS_L *)(lds + CL->l_tab);
+    gcip src_tab = as_g(CL->sched) + part[CP_O_MASK];
+    for (int i = threadIdx.x; i < np + 64; i += PT_THREADS) tab[i] = i < np ? (unsigned)src_tab[i] : 0u;
+    // level-1 task lists (16 local poll indices each) as 16-bit entries
+    unsigned short AS_L *sb = (unsigned short AS_L *)(lds + CL->l_sub);
+    gcip src_sub = as_g(CL->sched) + part[CP_O_SUB];
+    const int n16 = part[CP_NSUB] * PT_SUBLEN;
+    for (int i = threadIdx.x; i < n16; i += PT_THREADS) sb[i] = (unsigned short)src_sub[i];
+  }
   const ClStatic c = cl_load_static(CL, part);
 #ifdef POTUS_PROF
   for (int i = threadIdx.x; i < PT_NPROF; i += PT_THREADS) (lds + CL->l_prof)[i] = 0.0;
@@ -242,8 +371,11 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
 
 // ---------------------------------------------------------------- one pass of the member's share
 // Returns the chain's lp in every thread of every member; pol.extra[] are summed alongside.
+// cl_pass_partial returns THIS THREAD's share of lp (and leaves the thread's share of pol.extra[] in
+// pol_io); the caller reduces them over the cluster (cl_pass below, or together with the U-turn dot
+// products of the leaf in cl_transition_tree).
 template <class Pol>
-__device__ __forceinline__ double cl_pass(CMp M_in, CCp CL_in, cip part_in, ldp lds, const ClStatic &cst, Xch &x, Pol &pol_io) {
+__device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_in, ldp lds, const ClStatic &cst, Xch &x, Pol &pol_io) {
   Pol pol = pol_io;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
@@ -256,6 +388,7 @@ __device__ __forceinline__ double cl_pass(CMp M_in, CCp CL_in, cip part_in, ldp 
   const int NDP = CL->NDP, NR = CL->NR, NREP = CL->NREP;
   const int d0 = part[CP_D0], nd = part[CP_ND], p0 = part[CP_P0], np = part[CP_NP], e0 = part[CP_E0], r0 = part[CP_R0], nr = part[CP_NR];
   const int K = x.K, m = x.m;
+  const int wd0 = __builtin_amdgcn_readfirstlane(cst.wd0), wnd = __builtin_amdgcn_readfirstlane(cst.wnd);
   ldp C = lds + CL->l_C, Lw = lds + CL->l_Lw, X = lds + CL->l_X, Y = lds + CL->l_Y, r_lds = lds + CL->l_r;
   ldp s_rep = lds + CL->l_rep;
   ldp s_zT = s_rep, s_zb = s_rep + S, s_mid = s_rep + 2 * S;
@@ -276,18 +409,19 @@ __device__ __forceinline__ double cl_pass(CMp M_in, CCp CL_in, cip part_in, ldp 
     pol.qs_load(cst.rep_vo[1], qr[1]);
 #pragma unroll
     for (int j = 0; j < CL_DW; j++) {
-      const int tl = w * CL_DW + j;
-      pol.q_load((lane < S && tl < nd) ? 8u * (unsigned)(e0 + lane + S * tl) : PT_OOB, qt[j]);
+      const int tl = wd0 + j;
+      pol.q_load((lane < S && j < wnd) ? 8u * (unsigned)(e0 + lane + S * tl) : PT_OOB, qt[j]);
     }
     for (int i = tid; i < NR + 8; i += PT_THREADS) s_P[i] = 0.0;   // accumulators that this member's polls may not cover
     if (tid < SE) s_gs[tid] = 0.0;
     if (tid >= 64 && tid < 64 + CL_MAXDAYS) s_ge[tid - 64] = 0.0;
+    (lds + CL->l_gev)[tid] = 0.0;                  // [PT_NW][64] per-chunk day sums of unadjusted * residual
 #pragma unroll
     for (int u = 0; u < 2; u++) { const int j = tid + u * PT_THREADS; s_rep[j < NREP ? j : NREP] = pol.q_fin(qr[u]); }
     double run = 0.0;
 #pragma unroll
     for (int j = CL_DW - 1; j >= 0; j--) {
-      const int t = d0 + w * CL_DW + j;
+      const int t = d0 + wd0 + j;
       const double z = pol.q_fin(qt[j]);          // 0 for masked-off elements
       zq[j] = z;
       lp -= 0.5 * z * z;                          // stan:119
@@ -298,6 +432,7 @@ __device__ __forceinline__ double cl_pass(CMp M_in, CCp CL_in, cip part_in, ldp 
   }
   __syncthreads();
   PROF_MARK(0);
+  WPROF_T0();
 
   // ---------------- phase B: X1 (suffix totals); meanwhile mu_b_T / polling-bias mat-vecs and the AR(1) bias
   if (w == 0) {
@@ -306,71 +441,73 @@ __device__ __forceinline__ double cl_pass(CMp M_in, CCp CL_in, cip part_in, ldp 
 #pragma unroll
       for (int w2 = 0; w2 < PT_NW; w2++) tot += Y[w2 * SE + lane];
     }
-    bst_s(x.xb, lane < S ? 8u * (unsigned)lane : PT_OOB, xch_wslot(x, m), tot);
-    xch_signal_wait(x);
-  } else if (w == 1) {
+    xst(x, lane < S ? 16u * (unsigned)lane : PT_OOB, tot);
+  }
+  x.epoch++;                                      // X1 is on its way; the consumers below spin on its tags
+  if (w == 1) {
     if (full) {
       // e_bias (stan:91-93): d[t] = e[t]-mu_e = rho d[t-1] + sigma_rho z[t], plus the three tangent
       // recurrences that turn the adjoint sums of mu_e_bias / rho_e_bias into per-day dot products:
       //   c1[t] = rho c1[t-1] + 1, c2[t] = rho c2[t-1] + d[t-1], c3[t] = rho c3[t-1] + z[t]   (c.[0] = 0)
+      // Each lane owns four consecutive days (T <= 256); affine scans across lanes on the DPP path.
       const double sigma_e = M->sigma_e;
       ldp ze = s_mid + (M->o_ze - o_c);
       const double xm = s_mid[M->o_mue - o_c], xr = s_mid[M->o_rho - o_c];
       const double mue = 0.02 * xm, rho = d_inv_logit(xr);
       const double srho = sqrt(1.0 - rho * rho) * sigma_e;
-      const int per = (T + 63) / 64, ta = lane * per, tb = min(T, ta + per);
-      double A = 1.0, B = 0.0;
-      for (int t = ta; t < tb; t++) {
-        if (t == 0) { A = 0.0; B = ze[0] * sigma_e - mue; }
-        else { A = rho * A; B = rho * B + srho * ze[t]; }
-      }
+      constexpr int PER = 4;
+      const int ta = lane * PER;
+      double z[PER];
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const double A2 = __shfl_up(A, off, 64), B2 = __shfl_up(B, off, 64);
-        if (lane >= off) { B = A * B2 + B; A = A * A2; }
-      }
-      double d_in = __shfl_up(B, 1, 64);
-      if (lane == 0) d_in = 0.0;
-      double A2 = 1.0, B1 = 0.0, B2 = 0.0, B3 = 0.0, d = d_in;
-      for (int t = ta; t < tb; t++) {
-        const double dprev = d;
-        d = (t == 0) ? ze[0] * sigma_e - mue : rho * d + srho * ze[t];
-        s_e[t] = d + mue;
-        if (t == 0) { A2 = 0.0; B1 = 0.0; B2 = 0.0; B3 = 0.0; }
-        else { A2 = rho * A2; B1 = rho * B1 + 1.0; B2 = rho * B2 + dprev; B3 = rho * B3 + ze[t]; }
-      }
+      for (int u = 0; u < PER; u++) z[u] = ze[min(ta + u, T - 1)];
+      ISSUE_FENCE();
+      double A = 1.0, Bd[1] = {0.0};
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const double a2 = __shfl_up(A2, off, 64), b1 = __shfl_up(B1, off, 64), b2 = __shfl_up(B2, off, 64), b3 = __shfl_up(B3, off, 64);
-        if (lane >= off) { B1 = A2 * b1 + B1; B2 = A2 * b2 + B2; B3 = A2 * b3 + B3; A2 = A2 * a2; }
+      for (int u = 0; u < PER; u++) {
+        const int t = ta + u;
+        const bool in = t < T, first = t == 0;
+        const double An = first ? 0.0 : rho * A, Bn = first ? z[u] * sigma_e - mue : rho * Bd[0] + srho * z[u];
+        A = in ? An : A; Bd[0] = in ? Bn : Bd[0];
       }
-      double c1 = __shfl_up(B1, 1, 64), c2 = __shfl_up(B2, 1, 64), c3 = __shfl_up(B3, 1, 64);
-      if (lane == 0) { c1 = 0.0; c2 = 0.0; c3 = 0.0; }
-      d = d_in;
-      for (int t = ta; t < tb; t++) {
-        const double dprev = d;
-        d = (t == 0) ? ze[0] * sigma_e - mue : rho * d + srho * ze[t];
-        if (t == 0) { c1 = 0.0; c2 = 0.0; c3 = 0.0; }
-        else { c1 = rho * c1 + 1.0; c2 = rho * c2 + dprev; c3 = rho * c3 + ze[t]; }
-        s_c1[t] = c1; s_c2[t] = c2; s_c3[t] = c3;
+      dpp_scan_affine(A, Bd);
+      const double d_in = dpp_prev_lane(Bd[0], 0.0);
+      double A2 = 1.0, Bc[3] = {0.0, 0.0, 0.0}, d = d_in, dp[PER];
+#pragma unroll
+      for (int u = 0; u < PER; u++) {
+        const int t = ta + u;
+        const bool in = t < T, first = t == 0;
+        dp[u] = d;
+        d = first ? z[u] * sigma_e - mue : rho * d + srho * z[u];
+        if (in) s_e[t] = d + mue;
+        const double An = first ? 0.0 : rho * A2;
+        const double B1 = first ? 0.0 : rho * Bc[0] + 1.0, B2 = first ? 0.0 : rho * Bc[1] + dp[u], B3 = first ? 0.0 : rho * Bc[2] + z[u];
+        A2 = in ? An : A2; Bc[0] = in ? B1 : Bc[0]; Bc[1] = in ? B2 : Bc[1]; Bc[2] = in ? B3 : Bc[2];
+      }
+      dpp_scan_affine(A2, Bc);
+      double c1 = dpp_prev_lane(Bc[0], 0.0), c2 = dpp_prev_lane(Bc[1], 0.0), c3 = dpp_prev_lane(Bc[2], 0.0);
+#pragma unroll
+      for (int u = 0; u < PER; u++) {
+        const int t = ta + u;
+        const bool first = t == 0;
+        c1 = first ? 0.0 : rho * c1 + 1.0; c2 = first ? 0.0 : rho * c2 + dp[u]; c3 = first ? 0.0 : rho * c3 + z[u];
+        if (t < T) { s_c1[t] = c1; s_c2[t] = c2; s_c3[t] = c3; }
       }
       if (lane == 0) { s_scal[SC_MUE] = mue; s_scal[SC_RHO] = rho; s_scal[SC_SRHO] = srho; s_scal[SC_XMUE] = xm; s_scal[SC_XRHO] = xr; }
     }
-  } else {
+  } else if (w >= 2) {
     // partial products of the two 51 x 51 factors: wave w-2 takes columns k = w-2, w+4, ...
     const int wj = w - 2;
-    const rsrc_t rm = make_rsrc(M->mat, 8u * (unsigned)(M->m_w + S));
-    const unsigned sLT = 8u * (unsigned)M->m_LTt, sLB = 8u * (unsigned)M->m_LBt;
+    ldp LT = lds + CL->l_LT, LB = lds + CL->l_LB;
     constexpr int NJ = 11;                        // 6 waves x 11 columns >= 63
     double lt[NJ], lb[NJ], zt[NJ], zb[NJ];
+    const int ls = lane < S ? lane : 0;
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-      const int k = wj + 6 * j;
-      const unsigned vo = (k < S && lane < S) ? 8u * (unsigned)(k * S + lane) : PT_OOB;
-      lt[j] = bld(rm, vo, sLT);                   // L_T[lane][k], stan:85
-      lb[j] = bld(rm, vo, sLB);                   // L_B[lane][k], stan:77
-      zt[j] = s_zT[k < S ? k : 0];
-      zb[j] = s_zb[k < S ? k : 0];
+      const int k = wj + 6 * j, kc = k < S ? k : 0;
+      lt[j] = LT[ls * SP + kc];                   // L_T[lane][k], stan:85
+      lb[j] = LB[ls * SP + kc];                   // L_B[lane][k], stan:77
+      zt[j] = k < S ? s_zT[kc] : 0.0;
+      zb[j] = k < S ? s_zb[kc] : 0.0;
     }
     ISSUE_FENCE();
     double pT = 0.0, pB = 0.0;
@@ -380,33 +517,41 @@ __device__ __forceinline__ double cl_pass(CMp M_in, CCp CL_in, cip part_in, ldp 
     X[wj * SE + sx] = pT;
     X[(6 + wj) * SE + sx] = pB;
   }
+  // suffix totals of the members that own later days: fetched once per workgroup (wave 0, which has
+  // nothing else to do here) and handed to the other waves through LDS
+  if (w == 0) {
+    double carry_m = 0.0;
+    for (int mm0 = m + 1; mm0 < K; mm0 += 16) {
+      double t16[16];
+      unsigned vo[16], so[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int mm = mm0 + u;
+        vo[u] = (mm < K && lane < S) ? 16u * (unsigned)lane : PT_OOB;
+        so[u] = xch_rslot(x, mm < K ? mm : 0);
+      }
+      xld(x, vo, so, t16);
+#pragma unroll
+      for (int u = 0; u < 16; u++) carry_m += t16[u];
+    }
+    if (lane < S) Y[PT_NW * SE + lane] = carry_m;
+  }
+  WPROF_ACC(0);
   __syncthreads();
   PROF_MARK(1);
-  x.epoch++;
   {
     // C[k][t] for the member's days: local suffix + later waves + later members
-    double carry = 0.0;
-    for (int mm0 = m + 1; mm0 < K; mm0 += 8) {
-      double t8[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int mm = mm0 + u;
-        t8[u] = bld_s(x.xb, (mm < K && lane < S) ? 8u * (unsigned)lane : PT_OOB, xch_rslot(x, mm < K ? mm : 0));
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) carry += t8[u];
-    }
     if (lane < S) {
-      double cy[PT_NW];
+      double cy[PT_NW + 1];
 #pragma unroll
-      for (int w2 = 0; w2 < PT_NW; w2++) cy[w2] = Y[w2 * SE + lane];
+      for (int w2 = 0; w2 <= PT_NW; w2++) cy[w2] = Y[w2 * SE + lane];
       ISSUE_FENCE();
+      double carry = cy[PT_NW];
 #pragma unroll
       for (int w2 = 0; w2 < PT_NW; w2++) carry += w2 > w ? cy[w2] : 0.0;
 #pragma unroll
       for (int j = 0; j < CL_DW; j++) {
-        const int tl = w * CL_DW + j;
-        if (tl < nd) C[lane * NDP + tl] = cs[j] + carry;
+        if (j < wnd) C[lane * NDP + wd0 + j] = cs[j] + carry;
       }
     }
   }
@@ -415,151 +560,184 @@ __device__ __forceinline__ double cl_pass(CMp M_in, CCp CL_in, cip part_in, ldp 
     if (lane < S) {
 #pragma unroll
       for (int w2 = 0; w2 < 6; w2++) { bT += X[w2 * SE + lane]; pb += X[(6 + w2) * SE + lane]; }
-      bT += (as_g(M->mat) + M->m_prior)[lane];
+      bT += (lds + CL->l_prior)[lane];
       s_bT[lane] = bT;
       s_pb[lane] = pb;
     }
-    const double ww = lane < S ? (as_g(M->mat) + M->m_w)[lane] : 0.0;
-    double nb = ww * bT, npb = ww * pb;          // stan:79 and the national average of mu_b[:,T]
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { nb += __shfl_down(nb, off, 64); npb += __shfl_down(npb, off, 64); }
-    if (lane == 0) { s_bT[S] = nb; s_pb[S] = npb; }
+    const double ww = lane < S ? (lds + CL->l_w)[lane] : 0.0;
+    const double nb = dpp_scan_sum(ww * bT), npb = dpp_scan_sum(ww * pb);   // stan:79 and the national average of mu_b[:,T]
+    if (lane == 63) { s_bT[S] = nb; s_pb[S] = npb; }
   }
   if (tid == 0) r_lds[np] = 0.0;
   __syncthreads();
   PROF_MARK(2);
 
-  // ---------------- phase C: the member's polls, CL_LPP lanes per poll (stan:95-112, 130-131)
+  // ---------------- phase C: the member's polls, one thread per poll (stan:95-112, 130-131).  The exp / log1p /
+  // division of the binomial term are ~250 double-precision instructions per wave: polls are dealt to the
+  // waves in blocks of 64 so that a member with n polls pays for ceil(n/64) wave passes, spread over the SIMDs
   {
-    const unsigned Npad = M->Npad;
-    const rsrc_t rpi = make_rsrc(M->pi, 6u * Npad * 4u), rpd = make_rsrc(M->pd, 4u * Npad * 8u);
     const int om = M->o_m - o_c, opop = M->o_pop - o_c;
-    const double sigma_c = M->sigma_c, sigma_m = M->sigma_m, sigma_pop = M->sigma_pop;
-    const int sub = tid & (CL_LPP - 1);
-    for (int i0 = 0; i0 < np; i0 += CL_PPR) {
-      const int il = i0 + (tid >> 2);
-      const bool ok = il < np, lead = ok && sub == 0;
-      const unsigned gi = (unsigned)(p0 + il);
-      const unsigned vi = ok ? 4u * gi : PT_OOB, vd = lead ? 8u * gi : PT_OOB;   // masked polls read zeros: N = y = 0
-      const int s = bld_i(rpi, vi, 0), t = bld_i(rpi, vi, 4u * Npad), ip = bld_i(rpi, vi, 8u * Npad);
-      int im = 0, ipop = 0;
-      double un = 0.0;
-      if (full) { im = bld_i(rpi, vi, 12u * Npad); ipop = bld_i(rpi, vi, 16u * Npad); un = bld(rpd, vd, 16u * Npad); }
-      const double y = bld(rpd, vd, 0), N = bld(rpd, vd, 8u * Npad), sg = bld(rpd, vd, 24u * Npad);
-      const unsigned vq = lead ? 8u * (unsigned)(e_noise + il) : PT_OOB;
+    const double sigma_c = M->sigma_c, sigma_m = M->sigma_m, sigma_pop = M->sigma_pop, sigma_ns = M->sigma_ns, sigma_nn = M->sigma_nn;
+    const unsigned long long AS_L *pm = (const unsigned long long AS_L *)(lds + CL->l_pm);
+    ldp py = lds + CL->l_py, pN = lds + CL->l_pN, pun = lds + CL->l_pun;
+    for (int i0 = 0; i0 < np; i0 += PT_THREADS) {
+      if (i0 + 64 * w >= np) break;                      // this wave has no polls (wave-uniform)
+      const int il = i0 + tid;
+      const bool ok = il < np;
+      const int ic = ok ? il : np;                       // slot np holds zeros: N = y = 0
+      const unsigned vq = ok ? 8u * (unsigned)(e_noise + il) : PT_OOB;
       typename Pol::QT qt;
       typename Pol::GT gt;
       pol.q_load(vq, qt);
       pol.g_load(vq, gt);
-      const int tl = ok ? t - d0 : 0;
+      const unsigned long long meta = pm[ic];
+      const int s = (int)(meta & 0xffu), tl = (int)((meta >> 8) & 0xffu), ip = (int)((meta >> 16) & 0xffffu);
+      const int im = (int)((meta >> 32) & 0xffu), ipop = (int)((meta >> 40) & 0xffu);
+      const double y = py[ic], N = pN[ic], un = pun[ic];
+      const int t = d0 + tl;
       ldp L0 = Lw + s * SP, C0 = C + tl;
-      constexpr int NT = (64 + CL_LPP - 1) / CL_LPP;   // terms per lane, S <= 63
-      double l[NT], c[NT];
-#pragma unroll
-      for (int j = 0; j < NT; j++) {
-        const int kk = min(sub + CL_LPP * j, S - 1);
-        l[j] = L0[kk]; c[j] = C0[kk * NDP];
-      }
-      ISSUE_FENCE();
       double a0 = 0.0, a1 = 0.0;
+      for (int k0 = 0; k0 < S; k0 += 16) {               // 51-term dot, sixteen terms in flight
+        double l[16], c[16];
 #pragma unroll
-      for (int j = 0; j < NT; j += 2) {
-        a0 += (sub + CL_LPP * j < S ? 1.0 : 0.0) * l[j] * c[j];
-        if (j + 1 < NT) a1 += (sub + CL_LPP * (j + 1) < S ? 1.0 : 0.0) * l[j + 1] * c[j + 1];
+        for (int j = 0; j < 16; j++) { const int kk = min(k0 + j, S - 1); l[j] = L0[kk]; c[j] = C0[kk * NDP]; }
+        ISSUE_FENCE();
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+          a0 += (k0 + j < S ? 1.0 : 0.0) * l[j] * c[j];
+          a1 += (k0 + j + 1 < S ? 1.0 : 0.0) * l[j + 1] * c[j + 1];
+        }
       }
-      double dot = a0 + a1;
-      dot += __shfl_xor(dot, 1, 64);
-      dot += __shfl_xor(dot, 2, 64);
+      const double dot = a0 + a1;
+      const double sg = s == S ? sigma_nn : sigma_ns;
       const double zn = pol.q_fin(qt);
       double eta = s_bT[s] + s_pb[s] + sg * zn + sigma_c * s_mid[ip] + dot;
-      if (full) eta += sigma_m * s_mid[om + im] + sigma_pop * s_mid[opop + ipop] + un * s_e[ok ? t : 0];
+      if (full) eta += sigma_m * s_mid[om + im] + sigma_pop * s_mid[opop + ipop] + un * s_e[t];
+      // binomial_logit with one exp, one log1p, one division:  e = exp(-|eta|), l = log1p(e)
       const double ex = exp(-fabs(eta)), l1 = log1p(ex), pr = (eta >= 0.0 ? 1.0 : ex) / (1.0 + ex);
-      const double r = y - N * pr;                       // y = N = 0 on the helper lanes
-      lp += y * (fmin(eta, 0.0) - l1) + (N - y) * (fmin(-eta, 0.0) - l1) - (lead ? 0.5 * zn * zn : 0.0); // stan:126-127,130-131
-      r_lds[lead ? il : np + 1] = r;                     // slot np stays 0 (padding of the task lists), np+1 is a dump
+      const double r = y - N * pr;
+      lp += y * (fmin(eta, 0.0) - l1) + (N - y) * (fmin(-eta, 0.0) - l1) - 0.5 * zn * zn; // stan:126-127,130-131 (zn = 0 on idle lanes)
+      r_lds[ok ? il : np + 1] = r;                       // slot np stays 0 (padding of the task lists), np+1 is a dump
       pol.g_fin(vq, sg * r - zn, zn, gt);
     }
   }
   __syncthreads();
   PROF_MARK(3);
 
-  // ---------------- phase D: per-day gathers gC[:,t] = sum_i r_i Lw_ext[s_i,:]; level-1 segment sums
-  const rsrc_t rsc = make_rsrc(CL->sched, 0x7ffffff0u);
-  int sg_a = 0, sg_b = 0, sg_kind = 3, sg_index = 0;
+  // ---------------- phase D: adjoint of the walk, gC[:,t] = sum_i r_i Lw_ext[s_i,:] summed over days <= t.
+  // The member's polls (day order) are cut into PT_NW equal chunks, one per wave, whatever the days: a wave
+  // fetches (program word, residual, unadjusted flag) of 64 polls with one LDS round, then walks them through
+  // readlane; lanes < S keep the running sum over the chunk, lane 63 the day's sum of unadjusted * residual
+  // (the adjoint input of e_bias[t]).  At the last poll of a day the running values go to LDS; the owners
+  // of the days pick them up in phase E.  Level-1 segment sums follow.
+  WPROF_T0B();
   {
-    const int nseg = part[CP_NSEG];
-    const unsigned vs = tid < nseg ? 4u * (unsigned)tid : PT_OOB;
-    sg_a = bld_i(rsc, vs, 4u * (unsigned)part[CP_O_SEGPTR]);
-    sg_b = bld_i(rsc, vs, 4u * (unsigned)part[CP_O_SEGPTR] + 4u);
-    sg_kind = tid < nseg ? bld_i(rsc, vs, 4u * (unsigned)part[CP_O_SEGKIND]) : 3;
-    sg_index = bld_i(rsc, vs, 4u * (unsigned)part[CP_O_SEGIDX]);
-  }
-  {
-    const unsigned char AS_L *st = (const unsigned char AS_L *)(lds + CL->l_st);
+    const unsigned AS_L *tab = (const unsigned AS_L *)(lds + CL->l_tab);
+    ldp pun = lds + CL->l_pun, gev = lds + CL->l_gev;
     const int lk = lane < S ? lane : 0;
-    for (int dj = 0; dj < 64; dj++) {
-      const int a = __builtin_amdgcn_readlane(cst.d_a, dj), b = __builtin_amdgcn_readlane(cst.d_b, dj);
-      if (a >= b) break;                          // a wave's days are packed at the front
-      const int tl = __builtin_amdgcn_readlane(cst.d_t, dj);
-      double acc0 = 0.0, acc1 = 0.0;
-      for (int i = a; i < b; i += 8) {            // eight polls per trip, reads beyond b hit the zero slot
-        int s8[8];
-        double r8[8], l8[8];
+    const bool l63 = lane == 63;
+    const int ca = __builtin_amdgcn_readfirstlane(cst.ca), cb = __builtin_amdgcn_readfirstlane(cst.cb);
+    double acc = 0.0;
+    for (int base = ca; base < cb; base += 64) {
+      const int mine = base + lane < cb ? base + lane : np;   // slot np: program word 0, residual 0
+      const unsigned ev = tab[mine];
+      const double rv = r_lds[mine], uv = pun[mine];
+      const int cnt = min(64, cb - base);
+      for (int p0 = 0; p0 < cnt; p0 += 8) {
+        unsigned e8[8];
+        double r8[8], u8[8], l8[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int ii = i + u < b ? i + u : np; s8[u] = st[ii]; r8[u] = r_lds[ii]; }
+        for (int u = 0; u < 8; u++) {
+          const int pu = p0 + u;                    // < 64; lanes beyond the chunk hold the zero slot
+          e8[u] = (unsigned)__builtin_amdgcn_readlane((int)ev, pu);
+          r8[u] = readlane_d(rv, pu);
+          u8[u] = readlane_d(uv, pu);
+          l8[u] = Lw[(int)(e8[u] & 0xffu) * SP + lk];
+        }
         ISSUE_FENCE();
 #pragma unroll
-        for (int u = 0; u < 8; u++) l8[u] = Lw[s8[u] * SP + lk];
-        ISSUE_FENCE();
-#pragma unroll
-        for (int u = 0; u < 8; u += 2) { acc0 += r8[u] * l8[u]; acc1 += r8[u + 1] * l8[u + 1]; }
+        for (int u = 0; u < 8; u++) {
+          const double mult = l63 ? u8[u] : ((e8[u] & 0x20000u) ? 0.0 : l8[u]);   // flag 2: polls of day T feed mu_b_T only (stan:86)
+          acc += r8[u] * mult;
+          if (e8[u] & 0x10000u) {                   // flag 1: last poll of its day (wave-uniform)
+            const int tl = (int)((e8[u] >> 8) & 0xffu);
+            if (lane < S) C[lane * NDP + tl] = acc;
+            else if (l63) { gev[w * 64 + tl] = acc; acc = 0.0; }
+          }
+        }
       }
-      if (lane < S) C[lane * NDP + tl] = acc0 + acc1;
+    }
+    if (lane < S) X[w * SE + lane] = acc;          // chunk total
+    if (cb > ca) {
+      const unsigned le = tab[cb - 1];              // a day cut by the chunk boundary: lane 63 leaves its part
+      if (l63 && !(le & 0x10000u)) gev[w * 64 + (int)((le >> 8) & 0xffu)] = acc;
     }
   }
+  WPROF_ACCB(1);
   {
-    const int nsub = part[CP_NSUB], wb = part[CP_WB];
-    const unsigned o_sub = 4u * (unsigned)part[CP_O_SUB];
-    const rsrc_t rwt = make_rsrc(CL->wt, 0x7ffffff0u);
-    const unsigned o_wt = 8u * (unsigned)part[CP_O_WT];
+    const int nsub = part[CP_NSUB];
+    const u32x4 AS_L *sb = (const u32x4 AS_L *)(lds + CL->l_sub);
     for (int sub0 = 0; sub0 < nsub; sub0 += PT_THREADS) {
       const int sub = sub0 + tid;
-      const bool ok = sub < nsub, wtd = ok && sub >= wb;
-      const unsigned vs = ok ? 64u * (unsigned)sub : PT_OOB, vw = wtd ? 128u * (unsigned)(sub - wb) : PT_OOB;
-      u32x4 ix[4];
-      double wt[PT_SUBLEN];
-#pragma unroll
-      for (int j = 0; j < 4; j++) ix[j] = bld_i4(rsc, vs + 16u * j, o_sub);
-#pragma unroll
-      for (int j = 0; j < PT_SUBLEN / 2; j++) bld_d2(rwt, vw + 16u * j, o_wt, wt[2 * j], wt[2 * j + 1]);
+      const bool ok = sub < nsub;
+      const u32x4 ia = sb[ok ? 2 * sub : 0], ib = sb[ok ? 2 * sub + 1 : 0];
       double rr[PT_SUBLEN];
 #pragma unroll
-      for (int j = 0; j < PT_SUBLEN; j++) rr[j] = r_lds[ok ? ix[j >> 2][j & 3] : np];
+      for (int j = 0; j < 4; j++) {
+        rr[2 * j] = r_lds[ok ? (int)(ia[j] & 0xffffu) : np]; rr[2 * j + 1] = r_lds[ok ? (int)(ia[j] >> 16) : np];
+        rr[8 + 2 * j] = r_lds[ok ? (int)(ib[j] & 0xffffu) : np]; rr[9 + 2 * j] = r_lds[ok ? (int)(ib[j] >> 16) : np];
+      }
       ISSUE_FENCE();
       double sum = 0.0;
 #pragma unroll
-      for (int j = 0; j < PT_SUBLEN; j++) sum += wtd ? rr[j] * wt[j] : rr[j];
+      for (int j = 0; j < PT_SUBLEN; j++) sum += rr[j];
       if (ok) Y[sub] = sum;
     }
   }
+  WPROF_ACCB(2);
   __syncthreads();
   PROF_MARK(4);
 
-  // ---------------- phase E: local prefix sums of gC; level-2 segment sums
+  // ---------------- phase E: the owners of the days pick up the running sums; level-2 segment sums
   double pre[CL_DW];
   {
-    const unsigned mask = (unsigned)(as_g(CL->sched) + part[CP_O_MASK])[w];   // days of this wave that have polls
-    double run = 0.0;
+    double ct[PT_NW], cpre[PT_NW];
+#pragma unroll
+    for (int c = 0; c < PT_NW; c++) ct[c] = X[c * SE + (lane < S ? lane : S)];
+    int tlast[CL_DW], ch[CL_DW];
+    double cv[CL_DW];
 #pragma unroll
     for (int j = 0; j < CL_DW; j++) {
-      const int tl = w * CL_DW + j;
-      if (((mask >> j) & 1u) && lane < S && d0 + tl < T - 1) run += C[lane * NDP + tl];
-      pre[j] = run;
+      const int info = __builtin_amdgcn_readlane(cst.s2info, j);
+      tlast[j] = (info & 0xff) - 1; ch[j] = info >> 8;
+      cv[j] = C[(lane < S ? lane : 0) * NDP + max(tlast[j], 0)];
     }
-    if (lane < S) X[w * SE + lane] = run;
+    ISSUE_FENCE();
+    double run = 0.0;
+#pragma unroll
+    for (int c = 0; c < PT_NW; c++) { cpre[c] = run; run += ct[c]; }
+#pragma unroll
+    for (int j = 0; j < CL_DW; j++) {
+      double cc = cpre[0];
+#pragma unroll
+      for (int c = 1; c < PT_NW; c++) cc = ch[j] == c ? cpre[c] : cc;
+      pre[j] = tlast[j] >= 0 ? cv[j] + cc : 0.0;
+    }
+    if (tid >= 64 && tid < 64 + CL_MAXDAYS) {       // day sums of unadjusted * residual: add the chunks' parts
+      ldp gev = lds + CL->l_gev;
+      double g[PT_NW];
+#pragma unroll
+      for (int c = 0; c < PT_NW; c++) g[c] = gev[c * 64 + tid - 64];
+      ISSUE_FENCE();
+      double sum = 0.0;
+#pragma unroll
+      for (int c = 0; c < PT_NW; c++) sum += g[c];
+      s_ge[tid - 64] = sum;
+    }
   }
   {
     double sum = 0.0;
+    const int sg_a = cst.sg_a, sg_b = cst.sg_b, sg_kind = cst.sg_kind, sg_index = cst.sg_index;
     for (int j0 = sg_a; j0 < sg_b; j0 += 8) {
       double yy[8];
 #pragma unroll
@@ -570,7 +748,6 @@ __device__ __forceinline__ double cl_pass(CMp M_in, CCp CL_in, cip part_in, ldp 
     }
     if (sg_kind == 0) s_P[sg_index] = sum;          // pollster / mode / population partial (slot index)
     else if (sg_kind == 1) s_gs[sg_index] = sum;    // residual sum of (pseudo-)state
-    else if (sg_kind == 2) s_ge[sg_index] = sum;    // sum of unadjusted * residual over a local day
   }
   __syncthreads();
   PROF_MARK(5);
@@ -583,48 +760,46 @@ __device__ __forceinline__ double cl_pass(CMp M_in, CCp CL_in, cip part_in, ldp 
 #pragma unroll
       for (int w2 = 0; w2 < PT_NW; w2++) tot += X[w2 * SE + lane];
     }
-    bst_s(x.xb, lane < S ? 8u * (unsigned)(XP_PRE + lane) : PT_OOB, xch_wslot(x, m), tot);
+    xst(x, lane < S ? 16u * (unsigned)(XP_PRE + lane) : PT_OOB, tot);
   } else if (w == 1) {
     if (full) {
       // adjoint of the AR(1) recursion over the member's days (one lane per day): a[t] = ge[t] + rho a[t+1]
+      // (one lane per day, lane l = local day nd-1-l, so that the recursion runs in lane order)
       const double rho = s_scal[SC_RHO];
       const bool in = lane < nd;
-      const double ge = in ? s_ge[lane] : 0.0;
-      arA = in ? rho : 1.0; arB = ge;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const double A2 = __shfl_down(arA, off, 64), B2 = __shfl_down(arB, off, 64);
-        if (lane + off < 64) { arB = arB + arA * B2; arA = arA * A2; }
-      }
-      const int t = in ? d0 + lane : 0;
-      double S1 = ge * s_c1[t], S2 = ge * s_c2[t], S3 = ge * s_c3[t];
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) { S1 += __shfl_down(S1, off, 64); S2 += __shfl_down(S2, off, 64); S3 += __shfl_down(S3, off, 64); }
-      const double v = lane == 0 ? arA : lane == 1 ? arB : lane == 2 ? S1 : lane == 3 ? S2 : S3;
-      const double S1b = __shfl(S1, 0, 64), S2b = __shfl(S2, 0, 64), S3b = __shfl(S3, 0, 64);
-      const double A0 = __shfl(arA, 0, 64), B0 = __shfl(arB, 0, 64);
-      const double pv = lane == 0 ? A0 : lane == 1 ? B0 : lane == 2 ? S1b : lane == 3 ? S2b : S3b;
-      (void)v;
-      bst_s(x.xb, lane < 5 ? 8u * (unsigned)(XP_AR + lane) : PT_OOB, xch_wslot(x, m), pv);   // XP_S = XP_AR + 2
-      drain_vmem();
+      const int tl = in ? nd - 1 - lane : 0;
+      const double ge = in ? s_ge[tl] : 0.0;
+      double Bv[1] = {ge};
+      arA = in ? rho : 1.0;
+      dpp_scan_affine(arA, Bv);
+      arB = Bv[0];                                  // a[t] = arB + arA * a[first day of the next member]
+      const int t = d0 + tl;
+      const double S1 = dpp_scan_sum(ge * s_c1[t]), S2 = dpp_scan_sum(ge * s_c2[t]), S3 = dpp_scan_sum(ge * s_c3[t]);
+      // lane 63 holds the member's composite and the three sums
+      const double pv0 = dpp_readlane_d(arA, 63), pv1 = dpp_readlane_d(arB, 63);
+      const double pv2 = dpp_readlane_d(S1, 63), pv3 = dpp_readlane_d(S2, 63), pv4 = dpp_readlane_d(S3, 63);
+      const double pv = lane == 0 ? pv0 : lane == 1 ? pv1 : lane == 2 ? pv2 : lane == 3 ? pv3 : pv4;
+      xst(x, lane < 5 ? 16u * (unsigned)(XP_AR + lane) : PT_OOB, pv);   // XP_S = XP_AR + 2
     }
   } else {
     // dbT[s] = dpolling_bias[s] = residuals of state s + w_s * national residuals (this member's polls
     // only: the products are linear, the owners add the K partials); C region is free now
     const int wj = w - 2;
-    gcdp LT = as_g(M->mat) + M->m_LT, LB = as_g(M->mat) + M->m_LB, wv = as_g(M->mat) + M->m_w;
+    ldp LT = lds + CL->l_LT, LB = lds + CL->l_LB, s_w = lds + CL->l_w;
     double pT = 0.0, pB = 0.0;
     const double gnat = s_gs[S];
     constexpr int NJ = 11;
+    double lt[NJ], lb[NJ], gg[NJ];
+    const int lk = lane < S ? lane : 0;
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-      const int s = wj + 6 * j;
-      if (s < S && lane < S) {
-        const double G = s_gs[s] + wv[s] * gnat;
-        pT += LT[s * S + lane] * G;
-        pB += LB[s * S + lane] * G;
-      }
+      const int s = wj + 6 * j, sc = s < S ? s : 0;
+      lt[j] = LT[sc * SP + lk]; lb[j] = LB[sc * SP + lk];
+      gg[j] = s < S ? s_gs[sc] + s_w[sc] * gnat : 0.0;
     }
+    ISSUE_FENCE();
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { pT += lt[j] * gg[j]; pB += lb[j] * gg[j]; }
     if (lane < S) { C[wj * SE + lane] = pT; C[(6 + wj) * SE + lane] = pB; }
   }
   __syncthreads();
@@ -638,89 +813,92 @@ __device__ __forceinline__ double cl_pass(CMp M_in, CCp CL_in, cip part_in, ldp 
 #pragma unroll
         for (int w2 = 0; w2 < 6; w2++) v += C[(which * 6 + w2) * SE + k];
       } else v = s_P[rr];
-      bst_s(x.xb, 8u * (unsigned)(XP_P + rr), xch_wslot(x, m), v);
+      xst(x, 16u * (unsigned)(XP_P + rr), v);
     }
-    xch_signal_wait(x);
   }
   // loads that do not depend on the exchange are issued while wave 0 waits
   typename Pol::GT gz[CL_DW];
   unsigned voz[CL_DW];
 #pragma unroll
   for (int j = 0; j < CL_DW; j++) {
-    const int tl = w * CL_DW + j;
-    voz[j] = (lane < S && tl < nd) ? 8u * (unsigned)(e0 + lane + S * tl) : PT_OOB;
+    voz[j] = (lane < S && j < wnd) ? 8u * (unsigned)(e0 + lane + S * (wd0 + j)) : PT_OOB;
     pol.g_load(voz[j], gz[j]);
   }
   const bool arl = full && w == 1 && lane < nd;                 // owner of raw_e_bias[d0 + lane]
   const int jr = tid - 128;
   const bool repl = jr >= 0 && jr < nr;                         // owner of small-vector slot r0 + jr
   const int rslot = repl ? r0 + jr : 0;
-  const unsigned vo_x = arl ? 8u * (unsigned)(e_ze + lane) : repl ? 8u * (unsigned)(e_rep + jr) : PT_OOB;
+  const unsigned vo_x = arl ? 8u * (unsigned)(e_ze + nd - 1 - lane) : repl ? 8u * (unsigned)(e_rep + jr) : PT_OOB;
   typename Pol::GT gx;
   pol.g_load(vo_x, gx);
-  const rsrc_t rscale = make_rsrc(CL->rep_scale, 8u * (unsigned)NR);
-  const double scale_r = bld(rscale, repl ? 8u * (unsigned)rslot : PT_OOB, 0);
-  __syncthreads();
-  PROF_MARK(7);
+  const double scale_r = cst.scale_r;
   x.epoch++;
 
   // ---------------- phase F: finish the gradients of everything this member owns
-  {
-    double carry = 0.0;
-    for (int mm0 = 0; mm0 < m; mm0 += 8) {
-      double t8[8];
+  // wave 0 fetches the prefix totals of the members that own earlier days (for the whole workgroup),
+  // wave 1 finishes raw_e_bias, the owners of small-vector slots finish theirs; then the S x T block
+  if (w == 0) {
+    double carry_m = 0.0;
+    for (int mm0 = 0; mm0 < m; mm0 += 16) {
+      double t16[16];
+      unsigned vo[16], so[16];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < 16; u++) {
         const int mm = mm0 + u;
-        t8[u] = bld_s(x.xb, (mm < m && lane < S) ? 8u * (unsigned)(XP_PRE + lane) : PT_OOB, xch_rslot(x, mm < m ? mm : 0));
+        vo[u] = (mm < m && lane < S) ? 16u * (unsigned)(XP_PRE + lane) : PT_OOB;
+        so[u] = xch_rslot(x, mm < m ? mm : 0);
       }
+      xld(x, vo, so, t16);
 #pragma unroll
-      for (int u = 0; u < 8; u++) carry += t8[u];
+      for (int u = 0; u < 16; u++) carry_m += t16[u];
     }
-    if (lane < S) {
-      double cy[PT_NW];
-#pragma unroll
-      for (int w2 = 0; w2 < PT_NW; w2++) cy[w2] = X[w2 * SE + lane];
-      ISSUE_FENCE();
-#pragma unroll
-      for (int w2 = 0; w2 < PT_NW; w2++) carry += w2 < w ? cy[w2] : 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < CL_DW; j++) {
-      const int t = d0 + w * CL_DW + j;
-      pol.g_fin(voz[j], (t < T - 1 ? pre[j] + carry : 0.0) - zq[j], zq[j], gz[j]);
-    }
+    if (lane < S) X[PT_NW * SE + lane] = carry_m;
+    PROF_MARK(7);
   }
   if (w == 1) {
     if (full) {
       // carry of the adjoint from the members that own later days, then raw_e_bias of the member's days
-      const unsigned vA = lane < K ? (unsigned)lane * (unsigned)x.XW * 8u + 8u * (unsigned)XP_AR : PT_OOB;
-      const double mA = bld_s(x.xb, vA, xch_rslot(x, 0)), mB = bld_s(x.xb, vA + 8u, xch_rslot(x, 0));
+      const unsigned vA = lane < K ? (unsigned)lane * (unsigned)x.XW * 16u + 16u * (unsigned)XP_AR : PT_OOB;
+      double mAB[2];
+      {
+        const unsigned vo[2] = {vA, lane < K ? vA + 16u : PT_OOB}, so[2] = {xch_rslot(x, 0), xch_rslot(x, 0)};
+        xld(x, vo, so, mAB);
+      }
+      const double mA = mAB[0], mB = mAB[1];
       double a_in = 0.0;
       for (int mm = K - 1; mm > m; mm--) a_in = readlane_d(mB, mm) + readlane_d(mA, mm) * a_in;
       const double a = arB + arA * a_in;
-      const int t = d0 + lane;
+      const int t = d0 + (arl ? nd - 1 - lane : 0);
       const double z = s_mid[M->o_ze - o_c + (arl ? t : 0)];
       const double gv = a * (t >= 1 ? s_scal[SC_SRHO] : M->sigma_e) - z;
       lp -= arl ? 0.5 * z * z : 0.0;               // stan:125
       pol.gs_fin(vo_x, gv, z, gx);
     }
-  } else if (w >= 2) {
+  } else if (w >= 2 && __any(repl)) {
     // owned slots of the small vectors: sum the K partials in member order
     double sum = 0.0, sum2 = 0.0, sum3 = 0.0;
     const bool is_mue = full && repl && rslot == NR - 2, is_rho = full && repl && rslot == NR - 1;
-    const unsigned v1 = !repl ? PT_OOB : is_mue ? 8u * (unsigned)XP_S : is_rho ? 8u * (unsigned)(XP_S + 1) : 8u * (unsigned)(XP_P + rslot);
-    const unsigned v2 = is_rho ? 8u * (unsigned)(XP_S + 2) : PT_OOB;
-    for (int mm0 = 0; mm0 < K; mm0 += 8) {
-      double t8[8], u8[8];
+    const unsigned v1 = !repl ? PT_OOB : is_mue ? 16u * (unsigned)XP_S : is_rho ? 16u * (unsigned)(XP_S + 1) : 16u * (unsigned)(XP_P + rslot);
+    const unsigned v2 = is_rho ? 16u * (unsigned)(XP_S + 2) : PT_OOB;
+    for (int mm0 = 0; mm0 < K; mm0 += 16) {
+      double t16[16];
+      unsigned vo[16], so[16];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int mm = mm0 + u;
-        t8[u] = bld_s(x.xb, mm < K ? v1 : PT_OOB, xch_rslot(x, mm < K ? mm : 0));
-        u8[u] = bld_s(x.xb, mm < K ? v2 : PT_OOB, xch_rslot(x, mm < K ? mm : 0));
+      for (int u = 0; u < 16; u++) { const int mm = mm0 + u; vo[u] = mm < K ? v1 : PT_OOB; so[u] = xch_rslot(x, mm < K ? mm : 0); }
+      xld(x, vo, so, t16);
+#pragma unroll
+      for (int u = 0; u < 16; u++) sum += t16[u];
+    }
+    if (__any(is_rho)) {                           // the one wave that owns rho_e_bias needs a second sum
+      for (int mm0 = 0; mm0 < K; mm0 += 16) {
+        double t16[16];
+        unsigned vo[16], so[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int mm = mm0 + u; vo[u] = mm < K ? v2 : PT_OOB; so[u] = xch_rslot(x, mm < K ? mm : 0); }
+        xld(x, vo, so, t16);
+#pragma unroll
+        for (int u = 0; u < 16; u++) sum2 += t16[u];
       }
-#pragma unroll
-      for (int u = 0; u < 8; u++) { sum += t8[u]; sum2 += u8[u]; }
     }
     (void)sum3;
     const double qv = s_rep[rslot];
@@ -740,13 +918,28 @@ __device__ __forceinline__ double cl_pass(CMp M_in, CCp CL_in, cip part_in, ldp 
     lp += repl ? dl : 0.0;
     pol.gs_fin(vo_x, gv, qv, gx);
   }
-  PROF_MARK(18);
-  double v[1 + Pol::NEXTRA];
-  v[0] = lp;
+  __syncthreads();
+  {
+    const double carry = lane < S ? X[PT_NW * SE + lane] : 0.0;   // pre[] is already the prefix within the member
 #pragma unroll
-  for (int k = 0; k < Pol::NEXTRA; k++) v[1 + k] = pol.extra[k];
-  cl_allreduce(v, red, x, tid, PROFPTR);
-  PROF_MARK(19);
+    for (int j = 0; j < CL_DW; j++) {
+      const int t = d0 + wd0 + j;
+      pol.g_fin(voz[j], (t < T - 1 ? pre[j] + carry : 0.0) - zq[j], zq[j], gz[j]);
+    }
+  }
+  PROF_MARK(18);
+#pragma unroll
+  for (int k = 0; k < Pol::NEXTRA; k++) pol_io.extra[k] = pol.extra[k];
+  (void)red;
+  return lp;
+}
+template <class Pol>
+__device__ __forceinline__ double cl_pass(CMp M, CCp CL, cip part, ldp lds, const ClStatic &cst, Xch &x, Pol &pol_io) {
+  double v[1 + Pol::NEXTRA];
+  v[0] = cl_pass_partial(M, CL, part, lds, cst, x, pol_io);
+#pragma unroll
+  for (int k = 0; k < Pol::NEXTRA; k++) v[1 + k] = pol_io.extra[k];
+  cl_allreduce(v, lds + CL->l_red, x, (int)threadIdx.x);
 #pragma unroll
   for (int k = 0; k < Pol::NEXTRA; k++) pol_io.extra[k] = v[1 + k];
   return v[0];
@@ -843,6 +1036,46 @@ __device__ __forceinline__ bool cl_vop_merge(ClChain &c, unsigned a_beg, unsigne
   cl_allreduce(v, c.red(), c.x, c.tid, CPROFPTR(c));
   return v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0 && v[4] > 0 && v[5] > 0;
 }
+// Same sweep, but the six dot products stay per-wave partial sums in LDS (part[(6 slot + k) * PT_NW + wave]);
+// the leaf's single all-reduce adds them over the cluster.
+__device__ __forceinline__ void cl_vop_merge_partial(ClChain &c, unsigned a_beg, unsigned a_end, unsigned a_rho, unsigned b_beg, unsigned b_end,
+                                                     unsigned b_rho, unsigned out, ldp part) {
+  const unsigned sM = c.soff(V_MINV);
+  double v[6] = {0, 0, 0, 0, 0, 0};
+  for (int base = cl_first(c); base < c.e1; base += CL_UNR * PT_THREADS) {
+    double mi[CL_UNR], ab[CL_UNR], ae[CL_UNR], ar[CL_UNR], bb[CL_UNR], be[CL_UNR], br[CL_UNR];
+#pragma unroll
+    for (int k = 0; k < CL_UNR; k++) {
+      const int i = base + k * PT_THREADS;
+      const unsigned o = i < c.e1 ? 8u * i : PT_OOB;
+      mi[k] = bld(c.st, o, sM); ab[k] = bld(c.st, o, a_beg); ae[k] = bld(c.st, o, a_end); ar[k] = bld(c.st, o, a_rho);
+      bb[k] = bld(c.st, o, b_beg); be[k] = bld(c.st, o, b_end); br[k] = bld(c.st, o, b_rho);
+    }
+#pragma unroll
+    for (int k = 0; k < CL_UNR; k++) {
+      const int i = base + k * PT_THREADS;
+      const double rs = ar[k] + br[k];
+      bst(c.st, i < c.e1 ? 8u * i : PT_OOB, out, rs);
+      const double sab = mi[k] * ab[k], sbe = mi[k] * be[k];
+      v[0] += sab * rs;
+      v[1] += sbe * rs;
+      const double e1 = ar[k] + bb[k];
+      v[2] += sab * e1;
+      v[3] += mi[k] * bb[k] * e1;
+      const double e2 = br[k] + ae[k];
+      v[4] += mi[k] * ae[k] * e2;
+      v[5] += sbe * e2;
+    }
+  }
+  const int lane = c.tid & 63, w = c.tid >> 6;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const double t = dpp_scan_sum(v[k]);
+    if (lane == 63) part[k * PT_NW + w] = t;
+  }
+  // the sweep of the next level reads the vector `out` with a different thread-to-element map only through
+  // the same element index i -> same thread: no barrier needed between consecutive sweeps
+}
 // PH[e] = p + he*g ; position buffer dst = q + e*minv*PH[e] ; PF[e] = p.  Ends with a cluster barrier:
 // the next pass of every member reads the new position of the small vectors.
 __device__ __forceinline__ void cl_vop_prekick(ClChain &c, unsigned sq, unsigned sp, unsigned sg, unsigned s_ph, unsigned s_dst, unsigned s_pf,
@@ -866,7 +1099,7 @@ __device__ __forceinline__ void cl_vop_prekick(ClChain &c, unsigned sq, unsigned
       bst(c.st, o, s_pf, p[k]);
     }
   }
-  cl_sync(c.x);
+  cl_sync(c.x, c.red());
 }
 
 __device__ __forceinline__ void cl_transition_begin(ClChain &c, uint32_t iter) {
@@ -928,46 +1161,68 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
     CPROF_MARK(c, PF_PNEAR);
     bool valid = true;
     const int nleaf = 1 << depth;
+    ldp wpart = c.lds + c.CL->l_wide, wout = c.lds + c.CL->l_wout;
     for (int n = 0; n < nleaf; n++) {
       if (tid == 0) { unsigned pm = ts->pmask; ts->leaf_id = pool_alloc(pm, PT_NPP); ts->pmask = pm; }
       __syncthreads();
       const double e = dir ? eps : -eps;
       const int sel = ts->qsel[dir];              // buffer holding this leaf's position
-      const unsigned s_leaf = c.soff(V_POOLP + ts->leaf_id);
+      const int leaf = ts->leaf_id;
+      const unsigned s_leaf = c.soff(V_POOLP + leaf);
       ClLeapPolicy lp{c.st, c.soff((sel ? V_QB0 : V_QA0) + dir), c.soff((sel ? V_QA0 : V_QB0) + dir), c.soff(V_PH0 + dir), c.soff(V_MINV),
                       s_leaf, 0.5 * e, e, {0.0}};
-      const double lpv = cl_pass(c.M, c.CL, c.part, c.lds, c.cst, c.x, lp);
+      const double lpp = cl_pass_partial(c.M, c.CL, c.part, c.lds, c.cst, c.x, lp);
       CPROF_START(c);
       CPROF_COUNT(c, PF_LEAVES);
+      // One all-reduce per leaf: log density, kinetic energy and the six dot products of every U-turn check
+      // this leaf completes (the subtrees of 2, 4, ... leaves that end here, and the whole new subtree against
+      // the old trajectory when it is the last leaf of the doubling).  The sweeps only need vectors that are
+      // already final; their verdicts are taken after the reduction, exactly in build_tree's order.
+      const int m = __builtin_ctz(~(unsigned)n);  // levels merged at this leaf
+      const bool top = n == nleaf - 1;            // then m == depth
+      {
+        const int lane = tid & 63, w = tid >> 6;
+        const double t0 = dpp_scan_sum(lpp), t1 = dpp_scan_sum(lp.extra[0]);
+        if (lane == 63) { wpart[0 * PT_NW + w] = t0; wpart[1 * PT_NW + w] = t1; }
+      }
+      if (m > 0 || top) { drain_vmem(); __syncthreads(); }   // the leaf's momentum is read back with another thread map
+      for (int j = 1; j <= m; j++) {
+        const int ib = ts->pend_beg[j - 1], ie = ts->pend_end[j - 1], cb = j == 1 ? leaf : ts->pend_beg[j - 2];
+        const unsigned a_rho = j == 1 ? c.soff(V_POOLP + ib) : c.soff(V_RHOLEV + j - 1);
+        const unsigned b_rho = j == 1 ? c.soff(V_POOLP + leaf) : c.soff(V_SCR0 + ((j - 1) & 1));
+        const unsigned out = j == m ? c.soff(V_RHOLEV + j) : c.soff(V_SCR0 + (j & 1));
+        cl_vop_merge_partial(c, c.soff(V_POOLP + ib), c.soff(V_POOLP + ie), a_rho, c.soff(V_POOLP + cb), c.soff(V_POOLP + leaf), b_rho, out,
+                             wpart + (2 + 6 * (j - 1)) * PT_NW);
+      }
+      if (top) {
+        // the checks at the end of transition(): old trajectory (init side) against the new subtree
+        const int nb = depth >= 1 ? ts->pend_beg[depth - 1] : leaf;
+        const unsigned n_rho = depth == 0 ? c.soff(V_POOLP + leaf) : c.soff(V_RHOLEV + depth);
+        cl_vop_merge_partial(c, c.soff(V_PF1 - dir), c.soff(V_PNEAR), c.soff(V_RHOTOP), c.soff(V_POOLP + nb), c.soff(V_POOLP + leaf), n_rho,
+                             c.soff(V_RHOTOP), wpart + (2 + 6 * m) * PT_NW);
+      }
+      CPROF_MARK(c, PF_MERGE);
+      cl_allreduce_wide(wpart, 2 + 6 * (m + (top ? 1 : 0)), wout, c.x, CPROFPTR(c));
+      CPROF_START(c);
       if (tid == 0) {
-        const double H0 = ts->H0;
-        double h = 0.5 * lp.extra[0] - lpv;
+        const double H0 = ts->H0, lpv = wout[0];
+        double h = 0.5 * wout[1] - lpv;
         if (isnan(h)) h = INFINITY;
         const int div = (h - H0 > 1000.0) ? 1 : ts->divergent;
         ts->divergent = div;
         const double wgt = H0 - h;
         ts->sum_metro += wgt > 0 ? 1.0 : exp(wgt);
         ts->n_leap += 1;
-        ts->cur_beg = ts->cur_end = ts->leaf_id;
-        ts->cur_lsw = wgt; ts->cur_prop = -1; ts->cur_lp = lpv; ts->cur_h = h;
-        ts->abort = div;
-        ts->m = __builtin_ctz(~(unsigned)n);
         ts->qsel[dir] = sel ^ 1;                  // the next leaf of this end reads the buffer just written
-      }
-      __syncthreads();
-      CPROF_MARK(c, PF_LEAF_SCALAR);
-      if (ts->abort) { valid = false; break; }
-      const int m = ts->m;
-      for (int j = 1; j <= m; j++) {
-        const int ib = ts->pend_beg[j - 1], ie = ts->pend_end[j - 1], cb = ts->cur_beg, ce = ts->cur_end;
-        const unsigned a_rho = j == 1 ? c.soff(V_POOLP + ib) : c.soff(V_RHOLEV + j - 1);
-        const unsigned b_rho = j == 1 ? c.soff(V_POOLP + cb) : c.soff(V_SCR0 + ((j - 1) & 1));
-        const unsigned out = j == m ? c.soff(V_RHOLEV + j) : c.soff(V_SCR0 + (j & 1));
-        const bool persist = cl_vop_merge(c, c.soff(V_POOLP + ib), c.soff(V_POOLP + ie), a_rho, c.soff(V_POOLP + cb),
-                                          c.soff(V_POOLP + ce), b_rho, out);
-        __syncthreads();
-        if (tid == 0) {
-          const double cur_lsw = ts->cur_lsw;
+        int cur_beg = leaf, cur_prop = -1, abort = div;
+        const int cur_end = leaf;
+        double cur_lsw = wgt;
+        const double cur_lp = lpv, cur_h = h;
+        unsigned qm = ts->qmask, pm = ts->pmask;
+        for (int j = 1; j <= m && !abort; j++) {
+          const int ib = ts->pend_beg[j - 1], ie = ts->pend_end[j - 1], cb = cur_beg;
+          ldp d = wout + 2 + 6 * (j - 1);
+          const bool persist = d[0] > 0 && d[1] > 0 && d[2] > 0 && d[3] > 0 && d[4] > 0 && d[5] > 0;
           const double lsw_sub = d_lse(ts->pend_lsw[j - 1], cur_lsw);
           bool take_final;
           if (cur_lsw > lsw_sub) take_final = true;
@@ -975,60 +1230,50 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
             const uint32_t slot = ((uint32_t)depth << 24) | ((uint32_t)j << 16) | (uint32_t)(n >> j);
             take_final = rng_uniform(c.key, iter, RNG_SUB_ACCEPT, 0, slot) < exp(cur_lsw - lsw_sub);
           }
-          unsigned qm = ts->qmask, pm = ts->pmask;
           if (take_final) pool_free(qm, ts->pend_prop[j - 1]);
-          else { pool_free(qm, ts->cur_prop); ts->cur_prop = ts->pend_prop[j - 1]; }
+          else { pool_free(qm, cur_prop); cur_prop = ts->pend_prop[j - 1]; }
           if (ie != ib) pool_free(pm, ie);
-          if (cb != ce) pool_free(pm, cb);
-          ts->qmask = qm; ts->pmask = pm;
-          ts->cur_beg = ib;
-          ts->cur_lsw = lsw_sub;
-          ts->abort = !persist;
+          if (cb != cur_end) pool_free(pm, cb);
+          cur_beg = ib;
+          cur_lsw = lsw_sub;
+          abort = !persist;
         }
-        __syncthreads();
-        CPROF_COUNT(c, PF_MERGES);
-        CPROF_MARK(c, PF_MERGE);
-        if (ts->abort) { valid = false; break; }
-      }
-      if (!valid) break;
-      if (tid == 0) {
-        int cq = -1, prop = ts->cur_prop;
-        if (prop < 0) { // the leaf itself is this subtree's proposal: keep its position
-          unsigned qm = ts->qmask;
-          const int id = pool_alloc(qm, PT_NPQ);
-          ts->qmask = qm;
-          ts->q_lp[id] = ts->cur_lp; ts->q_h[id] = ts->cur_h;
-          prop = id; cq = id;
+        int cq = -1;
+        if (!abort) {
+          int prop = cur_prop;
+          if (prop < 0) { // the leaf itself is this subtree's proposal: keep its position
+            const int id = pool_alloc(qm, PT_NPQ);
+            ts->q_lp[id] = cur_lp; ts->q_h[id] = cur_h;
+            prop = id; cq = id;
+          }
+          ts->pend_beg[m] = cur_beg; ts->pend_end[m] = cur_end; ts->pend_lsw[m] = cur_lsw; ts->pend_prop[m] = prop;
+          if (top) {
+            ldp d = wout + 2 + 6 * m;
+            const bool persist = d[0] > 0 && d[1] > 0 && d[2] > 0 && d[3] > 0 && d[4] > 0 && d[5] > 0;
+            ts->depth = depth + 1;
+            const double lsw_sub = cur_lsw, lsw = ts->lsw;
+            bool accept;
+            if (lsw_sub > lsw) accept = true;
+            else accept = rng_uniform(c.key, iter, RNG_TOP_ACCEPT, 0, (uint32_t)depth) < exp(lsw_sub - lsw);
+            if (accept) { pool_free(qm, ts->sample_qid); ts->sample_qid = prop; }
+            else if (prop != cq) pool_free(qm, prop);
+            else { pool_free(qm, prop); cq = -1; }   // a rejected single-leaf proposal needs no copy
+            ts->lsw = d_lse(lsw, lsw_sub);
+            if (!persist) ts->stop = 1;
+          }
         }
+        ts->qmask = qm; ts->pmask = pm;
         ts->copy_q_id = cq;
-        ts->pend_beg[m] = ts->cur_beg; ts->pend_end[m] = ts->cur_end; ts->pend_lsw[m] = ts->cur_lsw; ts->pend_prop[m] = prop;
+        ts->abort = abort;
       }
       __syncthreads();
+      CPROF_MARK(c, PF_LEAF_SCALAR);
+      if (ts->abort) { valid = false; break; }
       if (ts->copy_q_id >= 0) cl_vop_copy<false>(c, c.soff(V_POOLQ + ts->copy_q_id), c.soff((sel ? V_QB0 : V_QA0) + dir));
+      if (top) cl_vop_copy<false>(c, c.soff(V_PF0 + dir), c.soff(V_POOLP + leaf));   // the last leaf is the new end point
       CPROF_MARK(c, PF_COPYQ);
     }
     if (!valid) break;
-    // merge the finished subtree with the old trajectory (the checks at the end of transition())
-    const int nb = ts->pend_beg[depth], ne = ts->pend_end[depth];
-    cl_vop_copy<false>(c, c.soff(V_PF0 + dir), c.soff(V_POOLP + ne));   // the last leaf is the new end point
-    const unsigned n_rho = depth == 0 ? c.soff(V_POOLP + nb) : c.soff(V_RHOLEV + depth);
-    const bool persist = cl_vop_merge(c, c.soff(V_PF1 - dir), c.soff(V_PNEAR), c.soff(V_RHOTOP), c.soff(V_POOLP + nb), c.soff(V_POOLP + ne),
-                                      n_rho, c.soff(V_RHOTOP));
-    __syncthreads();
-    if (tid == 0) {
-      ts->depth = depth + 1;
-      const double lsw_sub = ts->pend_lsw[depth], lsw = ts->lsw;
-      bool accept;
-      if (lsw_sub > lsw) accept = true;
-      else accept = rng_uniform(c.key, iter, RNG_TOP_ACCEPT, 0, (uint32_t)depth) < exp(lsw_sub - lsw);
-      unsigned qm = ts->qmask;
-      if (accept) { pool_free(qm, ts->sample_qid); ts->sample_qid = ts->pend_prop[depth]; }
-      else pool_free(qm, ts->pend_prop[depth]);
-      ts->qmask = qm;
-      ts->lsw = d_lse(lsw, lsw_sub);
-      if (!persist) ts->stop = 1;
-    }
-    CPROF_MARK(c, PF_MERGE);
   }
   __syncthreads();
 }

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_run(const DevModel *Mg, const Ru
 
 // ------------------------------------------------------------------------ cluster kernels (potus_cluster.hpp)
 // grid = chains * K; block b works for chain b % chains as member b / chains.
-__device__ __forceinline__ ClChain make_clchain(CMp M, CCp CL, CRp R, int chain, int m) {
+__device__ __forceinline__ ClChain make_clchain(CMp M, CCp CL, CRp R, int chain, int m, unsigned launch) {
   ldp lds = (ldp)lds_dyn;
   ClChain c;
   const int Dpad = R->Dpad, K = CL->K;
@@ -180,9 +181,8 @@ __device__ __forceinline__ ClChain make_clchain(CMp M, CCp CL, CRp R, int chain,
   c.sc = (gsc)(R->scal + (size_t)chain * K + m);
   c.key = RngKey{R->seed_lo, R->seed_hi, (uint32_t)(R->chain_id_offset + chain + 1)};
   c.perm = as_g(CL->perm);
-  c.x.xb = make_rsrc(R->xbuf + (size_t)chain * 2 * K * CL->XW, 2u * (unsigned)K * (unsigned)CL->XW * 8u);
-  c.x.cnt = R->xcnt + (size_t)chain * 64;
-  c.x.epoch = 0; c.x.K = K; c.x.m = m; c.x.XW = CL->XW;
+  c.x.xb = make_rsrc(R->xbuf + (size_t)chain * 8 * K * CL->XW, 4u * (unsigned)K * (unsigned)CL->XW * 16u);
+  c.x.epoch = 0; c.x.launch = launch; c.x.K = K; c.x.m = m; c.x.XW = CL->XW;
   c.D = M->D; c.Dpad = Dpad; c.tid = (int)threadIdx.x;
   c.e0 = c.part[CP_E0]; c.e1 = c.e0 + c.part[CP_NE];
   c.max_depth = R->max_depth; c.num_warmup = R->num_warmup; c.init_buffer = R->init_buffer; c.term_buffer = R->term_buffer;
@@ -195,33 +195,33 @@ __device__ __forceinline__ ClChain make_clchain(CMp M, CCp CL, CRp R, int chain,
 
 // Parity hook on one cluster (grid = K): q, grad in Stan order; scratch = [2][Dpad] in internal order.
 __global__ __launch_bounds__(PT_THREADS) void k_cl_logprob_grad(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, const double *q,
-                                                                double *lp, double *grad, int n, double *scratch) {
+                                                                double *lp, double *grad, int n, double *scratch, unsigned launch) {
   CMp M = (CMp)Mg;
   CCp CL = (CCp)CLg;
   CRp R = (CRp)Rg;
-  ClChain c = make_clchain(M, CL, R, 0, blockIdx.x);
+  ClChain c = make_clchain(M, CL, R, 0, blockIdx.x, launch);
   c.cst = cl_setup_lds(M, CL, c.part, c.lds);
   const int D = M->D, Dpad = R->Dpad;
   const rsrc_t rs = make_rsrc(scratch, 2u * (unsigned)Dpad * 8u);
   for (int b = 0; b < n; b++) {
     for (int i = c.e0 + c.tid; i < c.e1; i += PT_THREADS) bst_s(rs, 8u * i, 0, as_g(q)[(size_t)b * D + c.perm[i]]);
-    cl_sync(c.x);
+    cl_sync(c.x, c.red());
     ClPlainPolicy pol{rs, rs, 0u, (unsigned)Dpad * 8u, {0}};
     const double v = cl_pass(M, CL, c.part, c.lds, c.cst, c.x, pol);
     drain_vmem();
     __syncthreads();
     for (int i = c.e0 + c.tid; i < c.e1; i += PT_THREADS) as_g(grad)[(size_t)b * D + c.perm[i]] = bld(rs, 8u * i, (unsigned)Dpad * 8u);
     if (blockIdx.x == 0 && c.tid == 0) lp[b] = v;
-    cl_sync(c.x);
+    cl_sync(c.x, c.red());
   }
 }
 
-__global__ __launch_bounds__(PT_THREADS) void k_cl_init(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, const double *q0) {
+__global__ __launch_bounds__(PT_THREADS) void k_cl_init(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, const double *q0, unsigned launch) {
   CMp M = (CMp)Mg;
   CCp CL = (CCp)CLg;
   CRp R = (CRp)Rg;
   const int chain = blockIdx.x % R->chains, m = blockIdx.x / R->chains;
-  ClChain c = make_clchain(M, CL, R, chain, m);
+  ClChain c = make_clchain(M, CL, R, chain, m, launch);
   c.cst = cl_setup_lds(M, CL, c.part, c.lds);
   const int tid = c.tid;
   const unsigned sQ = c.soff(V_QC), sG = c.soff(V_GC);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_init(const DevModel *Mg, cons
       const int si = c.perm[i];
       bst_s(c.st, 8u * i, sQ, q0 ? as_g(q0)[(size_t)chain * c.D + si] : radius * (2.0 * rng_uniform(c.key, PT_ITER_PRE, RNG_INITS, attempt, (uint32_t)si) - 1.0));
     }
-    cl_sync(c.x);
+    cl_sync(c.x, c.red());
     ClPlainPolicy pol{c.st, c.st, sQ, sG, {0}};
     const double lp = cl_pass(M, CL, c.part, c.lds, c.cst, c.x, pol);
     drain_vmem();
@@ -283,7 +283,7 @@ __device__ __forceinline__ void cl_transition_end(ClChain &c, CRp R, int chain, 
     bst_s(c.st, 8u * i, sQ, v);
     if (save) row[POTUS_N_SAMPLER_COLS + c.perm[i]] = v;
   }
-  cl_sync(c.x);
+  cl_sync(c.x, c.red());
   if (tid == 0) {
     c.sc->lp_cur = ts->out_lp;
     if (save) c.sc->saved += 1;
@@ -294,12 +294,12 @@ __device__ __forceinline__ void cl_transition_end(ClChain &c, CRp R, int chain, 
   __syncthreads();
 }
 
-__global__ __launch_bounds__(PT_THREADS) void k_cl_run(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, int n_iter) {
+__global__ __launch_bounds__(PT_THREADS) void k_cl_run(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, int n_iter, unsigned launch) {
   CMp M = (CMp)Mg;
   CCp CL = (CCp)CLg;
   CRp R = (CRp)Rg;
   const int chain = blockIdx.x % R->chains, m = blockIdx.x / R->chains;
-  ClChain c = make_clchain(M, CL, R, chain, m);
+  ClChain c = make_clchain(M, CL, R, chain, m, launch);
   if (c.sc->status != 0) return;
   c.cst = cl_setup_lds(M, CL, c.part, c.lds);
   const int total = R->num_warmup + R->num_samples;
@@ -516,6 +516,7 @@ struct Sampler {
   std::vector<double> LB, LT, LW; // column-major host copies (transformed data)
   // cluster mode (K > 1)
   int K = 1;
+  unsigned launch_id = 0;   // tags the exchange words of each launch
   ClModel CL{};
   ClModel *dCL = nullptr;
   size_t cl_lds_bytes = 0;
@@ -742,18 +743,21 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   C.NREP = 2 * S + M.nmid;
   C.NDP = CL_MAXDAYS + 1;
   C.XW = (XP_P + C.NR + 7) & ~7;
+  if (P > 65535 || M.M > 255 || M.Pop > 255) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode packs pollster/mode/population indices in 16/8/8 bits");
   if (C.NREP > 2 * PT_THREADS) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: %d small parameters (> %d)", C.NREP, 2 * PT_THREADS);
   if ((C.NR + K - 1) / K > PT_THREADS - 128) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: too many pollsters for K = %d", K);
   const std::vector<int> &dp = sp->h_dayptr;
 
-  // contiguous day ranges: minimise the largest (days + polls) with at most CL_MAXDAYS days each
+  // contiguous day ranges: minimise the largest cost (a day = S elements of vector work, a poll = a
+  // 51-term dot + a gather) with at most CL_MAXDAYS days each
+  const int cw_day = getenv("POTUS_CW_DAY") ? atoi(getenv("POTUS_CW_DAY")) : S, cw_poll = getenv("POTUS_CW_POLL") ? atoi(getenv("POTUS_CW_POLL")) : 4;
   auto groups_for = [&](int B, std::vector<int> *cut) {
     int g = 0, t = 0;
     if (cut) cut->assign(1, 0);
     while (t < T) {
       int nd = 0, cost = 0;
       while (t < T && nd < CL_MAXDAYS) {
-        const int c1 = 1 + dp[t + 1] - dp[t];
+        const int c1 = cw_day + cw_poll * (dp[t + 1] - dp[t]);
         if (nd > 0 && cost + c1 > B) break;
         cost += c1; nd++; t++;
       }
@@ -762,7 +766,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
     }
     return g;
   };
-  int lo = 1, hi = T + Np;
+  int lo = 1, hi = cw_day * T + cw_poll * Np;
   while (lo < hi) { const int mid = (lo + hi) / 2; if (groups_for(mid, nullptr) <= K) hi = mid; else lo = mid + 1; }
   std::vector<int> cut;
   if (groups_for(lo, &cut) > K) return fail(POTUS_ERR_UNSUPPORTED, "T = %d days do not fit %d members of at most %d days", T, K, CL_MAXDAYS);
@@ -787,24 +791,63 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
     e += nr;
     pt_[CP_NE] = e - pt_[CP_E0];
 
-    // per-day gathers: local days with polls balanced over the waves (longest first)
-    std::vector<int> order, load(PT_NW, 0);
-    for (int tl = 0; tl < nd; tl++) if (dp[d0 + tl + 1] > dp[d0 + tl]) order.push_back(tl);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return dp[d0 + a + 1] - dp[d0 + a] > dp[d0 + b + 1] - dp[d0 + b]; });
-    std::vector<std::vector<int>> wt(PT_NW);
-    for (int tl : order) {
-      int wmin = 0;
-      for (int wv = 1; wv < PT_NW; wv++) if (load[wv] < load[wmin]) wmin = wv;
-      wt[wmin].push_back(tl);
-      load[wmin] += dp[d0 + tl + 1] - dp[d0 + tl] + 2;
+    // the member's days are dealt to the waves as contiguous ranges of at most CL_DW days, balanced by
+    // polls (a wave gathers the adjoint of the days it owns): smallest feasible bound on polls per wave
+    std::vector<int> wd0(PT_NW, nd), wnd(PT_NW, 0);
+    {
+      auto assign = [&](int B, bool commit) {
+        int tl = 0;
+        for (int wv = 0; wv < PT_NW; wv++) {
+          int n = 0, polls = 0;
+          const int start = tl;
+          while (tl < nd && n < CL_DW) {
+            const int c1 = dp[d0 + tl + 1] - dp[d0 + tl];
+            // leave enough room in the remaining waves for the remaining days
+            if (n > 0 && polls + c1 > B && (nd - tl) <= (PT_NW - 1 - wv) * CL_DW) break;
+            polls += c1; n++; tl++;
+          }
+          if (commit) { wd0[wv] = start; wnd[wv] = n; }
+        }
+        return tl == nd;
+      };
+      int lo2 = 0, hi2 = np + 1;
+      auto maxpolls = [&](int B) {   // feasibility: all days placed and no wave above the bound unless forced by one day
+        int tl = 0, worst = 0;
+        for (int wv = 0; wv < PT_NW; wv++) {
+          int n = 0, polls = 0;
+          while (tl < nd && n < CL_DW) {
+            const int c1 = dp[d0 + tl + 1] - dp[d0 + tl];
+            if (n > 0 && polls + c1 > B && (nd - tl) <= (PT_NW - 1 - wv) * CL_DW) break;
+            polls += c1; n++; tl++;
+          }
+          worst = std::max(worst, polls);
+        }
+        return tl == nd ? worst : 1 << 30;
+      };
+      int best = hi2, bestB = hi2;
+      for (int B = lo2; B <= hi2; B++) { const int w_ = maxpolls(B); if (w_ < best) { best = w_; bestB = B; } }
+      if (!assign(bestB, true)) return fail(POTUS_ERR_STATE, "internal: member %d: %d days do not fit %d waves", m, nd, PT_NW);
     }
-    std::vector<int> wd_t(PT_THREADS, 0), wd_a(PT_THREADS, 0), wd_b(PT_THREADS, 0), daymask(PT_NW, 0);
+    // adjoint gather: equal chunks of the member's polls per wave; program word per poll; what the owner of
+    // each day reads back (last polled day <= it, chunk of that day's last poll)
+    std::vector<int> ca(PT_NW), cb(PT_NW), tab(np), s2info(PT_THREADS, 0);
+    for (int wv = 0; wv < PT_NW; wv++) { ca[wv] = (int)((long long)np * wv / PT_NW); cb[wv] = (int)((long long)np * (wv + 1) / PT_NW); }
+    auto chunk_of = [&](int il) { int c = 0; while (c < PT_NW - 1 && il >= cb[c]) c++; return c; };
+    for (int il = 0; il < np; il++) {
+      const int g = p0 + il, tl = sp->h_pt[g] - d0;
+      const bool dayend = il == np - 1 || sp->h_pt[g + 1] != sp->h_pt[g];
+      tab[il] = sp->h_ps[g] | (tl << 8) | ((dayend ? 1 : 0) << 16) | ((sp->h_pt[g] == T - 1 ? 2 : 0) << 16);
+    }
     for (int wv = 0; wv < PT_NW; wv++)
-      for (size_t j = 0; j < wt[wv].size(); j++) {
-        const int tl = wt[wv][j];
-        wd_t[wv * 64 + j] = tl; wd_a[wv * 64 + j] = dp[d0 + tl] - p0; wd_b[wv * 64 + j] = dp[d0 + tl + 1] - p0;
+      for (int j = 0; j < wnd[wv]; j++) {
+        int tl = wd0[wv] + j;
+        while (tl >= 0 && dp[d0 + tl + 1] == dp[d0 + tl]) tl--;   // last day with polls at or before this one
+        s2info[wv * 64 + j] = tl < 0 ? 0 : ((tl + 1) | (chunk_of(dp[d0 + tl + 1] - 1 - p0) << 8));
       }
-    for (int tl = 0; tl < nd; tl++) if (dp[d0 + tl + 1] > dp[d0 + tl]) daymask[tl / CL_DW] |= (int)(1u << (tl % CL_DW));
+    std::vector<int> wdays(wd0);
+    wdays.insert(wdays.end(), wnd.begin(), wnd.end());
+    wdays.insert(wdays.end(), ca.begin(), ca.end());
+    wdays.insert(wdays.end(), cb.begin(), cb.end());
 
     // two-level segment sums over the member's polls (local poll indices, padded with the zero slot np)
     std::vector<int> sub16, seg_ptr{0}, seg_kind, seg_index;
@@ -833,8 +876,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
       add_group(M.Pop, 0, 2 * S + P + M.M, false, [&](int i) { return sp->h_ppop[i]; });
     }
     add_group(S + 1, 1, 0, false, [&](int i) { return sp->h_ps[i]; });
-    const int wb = nsub;
-    if (full) add_group(nd, 2, 0, true, [&](int i) { return sp->h_pt[i] - d0; });
+    const int wb = nsub;   // (day sums of unadjusted * residual come out of the per-day gathers)
     seg_ptr.push_back(nsub);
     if ((int)seg_kind.size() > PT_THREADS) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: member %d has %zu segments (> %d)", m, seg_kind.size(), PT_THREADS);
     pt_[CP_NSUB] = nsub; pt_[CP_NSEG] = (int)seg_kind.size(); pt_[CP_WB] = wb;
@@ -845,8 +887,8 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
       sched.insert(sched.end(), v.begin(), v.end());
       return off;
     };
-    pt_[CP_O_WD] = appi(wd_t); appi(wd_a); appi(wd_b);
-    pt_[CP_O_MASK] = appi(daymask); pt_[CP_O_SUB] = appi(sub16); pt_[CP_O_SEGPTR] = appi(seg_ptr);
+    pt_[CP_O_WD] = appi(s2info); appi(wdays);
+    pt_[CP_O_MASK] = appi(tab); pt_[CP_O_SUB] = appi(sub16); pt_[CP_O_SEGPTR] = appi(seg_ptr);
     pt_[CP_O_SEGKIND] = appi(seg_kind); pt_[CP_O_SEGIDX] = appi(seg_index);
     while (wts.size() % 2) wts.push_back(0.0);
     pt_[CP_O_WT] = (int)wts.size();
@@ -872,12 +914,17 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   auto take = [&](int n) { const int a = o; o += (n + 1) & ~1; return a; };
   C.l_C = take(std::max(S * C.NDP, 12 * M.SE));
   C.l_Lw = take(M.SE * M.SP);
+  C.l_LT = take(S * M.SP); C.l_LB = take(S * M.SP); C.l_w = take(M.SE); C.l_prior = take(M.SE);
+  C.l_pm = take(npmax + 8); C.l_py = take(npmax + 8); C.l_pN = take(npmax + 8); C.l_pun = take(npmax + 8);
+  C.l_sub = take(nsubmax * 4 + 4);
+  C.l_tab = take((npmax + 64) / 2 + 2); C.l_gev = take(PT_NW * 64);
+  C.l_wide = take(CL_WIDE * PT_NW); C.l_wout = take(CL_WIDE);
   C.l_X = take(12 * M.SE);
   C.l_Y = take(std::max(PT_NW * M.SE, nsubmax));
   C.l_r = take(npmax + 2);
   C.l_rep = take(C.NREP + 2);
   C.l_bT = take(M.SE); C.l_pb = take(M.SE); C.l_e = take(T); C.l_c1 = take(T); C.l_c2 = take(T); C.l_c3 = take(T);
-  C.l_gs = take(M.SE); C.l_ge = take(CL_MAXDAYS); C.l_P = take(C.NR + 8); C.l_scal = take(SC_N); C.l_red = take(PT_NW * PT_NRED);
+  C.l_gs = take(M.SE); C.l_ge = take(CL_MAXDAYS); C.l_P = take(C.NR + 8); C.l_scal = take(SC_N); C.l_red = take((PT_NW + 1) * PT_NRED);
   C.l_st = take((npmax + 8 + 7) / 8);
   C.l_prof = take(PT_NPROF);
   C.lds_doubles = o;
@@ -1027,7 +1074,7 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   (void)hipMemset(p, 0, sizeof(ChainScalars) * o->chains * sp->K);
   R.K = sp->K; R.xbuf = nullptr; R.xcnt = nullptr;
   if (sp->K > 1) {
-    const size_t xb = (size_t)o->chains * 2 * sp->K * sp->CL.XW * sizeof(double);
+    const size_t xb = (size_t)o->chains * 4 * sp->K * sp->CL.XW * 16;
     if (hipMalloc(&p, xb) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for exchange buffers failed"));
     sp->allocs.push_back(p); R.xbuf = (double *)p;
     (void)hipMemset(p, 0, xb);
@@ -1081,9 +1128,8 @@ int potus_log_prob_grad(int handle, const double *q, int n, double *lp, double *
   double *dscr = nullptr;
   if (sp->K > 1) {   // the cluster's own pass, on one cluster
     HIP_TRY(hipMalloc((void **)&dscr, 2 * (size_t)sp->R.Dpad * 8));
-    HIP_TRY(hipMemsetAsync(sp->R.xcnt, 0, (size_t)sp->R.chains * 64 * sizeof(unsigned), sp->stream));
     hipLaunchKernelGGL(k_cl_logprob_grad, dim3(sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
-                       (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq, dlp, dg, n, dscr);
+                       (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq, dlp, dg, n, dscr, ++sp->launch_id);
   } else {
     const int grid = std::min(n, 1024);
     hipLaunchKernelGGL(k_logprob_grad, dim3(grid), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const double *)dq, dlp, dg, n);
@@ -1105,9 +1151,8 @@ int potus_init(int handle, const double *q0) {
   const size_t bytes = (size_t)sp->R.chains * sp->L.D * 8;
   if (q0) { HIP_TRY(hipMalloc((void **)&dq0, bytes)); HIP_TRY(hipMemcpyAsync(dq0, q0, bytes, hipMemcpyHostToDevice, sp->stream)); }
   if (sp->K > 1) {
-    HIP_TRY(hipMemsetAsync(sp->R.xcnt, 0, (size_t)sp->R.chains * 64 * sizeof(unsigned), sp->stream));
     hipLaunchKernelGGL(k_cl_init, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
-                       (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq0);
+                       (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq0, ++sp->launch_id);
   } else
     hipLaunchKernelGGL(k_init, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, (const double *)dq0);
   HIP_TRY(hipGetLastError());
@@ -1130,11 +1175,10 @@ int potus_run(int handle, int n_iter) {
   long long before = 0, after = 0;
   potus_total_leapfrogs(handle, &before);
   int it0 = 0; potus_iterations_done(handle, &it0);
-  if (sp->K > 1) HIP_TRY(hipMemsetAsync(sp->R.xcnt, 0, (size_t)sp->R.chains * 64 * sizeof(unsigned), sp->stream));
   HIP_TRY(hipEventRecord(sp->ev0, sp->stream));
   if (sp->K > 1)
     hipLaunchKernelGGL(k_cl_run, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
-                       (const ClModel *)sp->dCL, (const RunParams *)sp->dR, n_iter);
+                       (const ClModel *)sp->dCL, (const RunParams *)sp->dR, n_iter, ++sp->launch_id);
   else
     hipLaunchKernelGGL(k_run, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, n_iter);
   HIP_TRY(hipGetLastError());

@@ -104,13 +104,26 @@ typedef const DevModel AS_C *CMp; // the model descriptor lives in device memory
 // scalar slots in LDS (l_scal)
 enum { SC_MUE = 0, SC_RHO, SC_SRHO, SC_XMUE, SC_XRHO, SC_N };
 #define PT_NRED 8  // reduction slots
-#define PT_NPROF 32
+#define PT_NPROF 64
 
 #ifdef POTUS_PROF
 #define PROF_MARK(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); prof[k] += (double)(t_ - (long long)prof[PT_NPROF - 1]); prof[PT_NPROF - 1] = (double)t_; } } while (0)
 #define PROF_START() do { if (threadIdx.x == 0) prof[PT_NPROF - 1] = (double)clock64(); } while (0)
 #define PROF_SUB(k) do { if (threadIdx.x == 0) { prof[k] += (double)(clock64() - (long long)prof[PT_NPROF - 1]); } } while (0)
+// per-wave timers: slot 32 + 8*ph + wave accumulates the time a wave spends between WPROF_T0 and WPROF_ACC(ph)
+#define WPROF_T0() const long long wt0_ = clock64()
+#define WPROF_ACC(ph) do { if ((threadIdx.x & 63) == 0) prof[32 + 8 * (ph) + (threadIdx.x >> 6)] += (double)(clock64() - wt0_); } while (0)
+#define WPROF_T0B() const long long wt0b_ = clock64()
+#define WPROF_ACCB(ph) do { if ((threadIdx.x & 63) == 0) prof[32 + 8 * (ph) + (threadIdx.x >> 6)] += (double)(clock64() - wt0b_); } while (0)
+#define WPROF_T0C() const long long wt0c_ = clock64()
+#define WPROF_ACCC(ph) do { if ((threadIdx.x & 63) == 0) prof[32 + 8 * (ph) + (threadIdx.x >> 6)] += (double)(clock64() - wt0c_); } while (0)
 #else
+#define WPROF_T0B() do { } while (0)
+#define WPROF_ACCB(ph) do { } while (0)
+#define WPROF_T0C() do { } while (0)
+#define WPROF_ACCC(ph) do { } while (0)
+#define WPROF_T0() do { } while (0)
+#define WPROF_ACC(ph) do { } while (0)
 #define PROF_MARK(k) do { } while (0)
 #define PROF_START() do { } while (0)
 #define PROF_SUB(k) do { } while (0)

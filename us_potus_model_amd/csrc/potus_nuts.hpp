@@ -72,7 +72,7 @@ struct RunParams {
   ChainScalars *scal;      // [chains]
   double *draws;           // [chains][n_save_max][7 + D]
   double *prof;            // [chains][PT_NPROF] (POTUS_PROF builds) or null
-  double *xbuf;            // cluster mode: [chains][2][K][XW] exchange payloads
+  double *xbuf;            // cluster mode: [chains][2][K][XW] exchange words of 16 bytes {value, tag}
   unsigned *xcnt;          // cluster mode: [chains][64] arrival counters (one cache line apart)
   int K, pad;              // workgroups per chain (1: potus_nuts.hpp; > 1: potus_cluster.hpp, scal is [chains][K])
 };
