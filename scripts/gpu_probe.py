@@ -53,7 +53,14 @@ for chains in chain_counts:
                 for mm in range(KCL):
                     print(f"    m={mm:2d}                        " + " ".join(f"{out[mm][k]/max(leaves,1):9.0f}" for k in NAMES))
             if KCL > 1:
-                for ph, nm in ((0, "B per wave"), (1, "D gathers per wave"), (2, "D gathers+seg1 per wave")):
+                names = ["start", "A done (bar1)", "B done/X1 in (bar2)", "C written (bar3)", "polls done", "D done", "E done", "E2 done (X2 out)",
+                         "X2 prefix in (w0)", "F done", "sweeps done (bar)", "X3 in"]
+                st = np.array([out[mm][40:52] for mm in range(KCL)])
+                t0 = st[:, 0].min()
+                print("  timeline of leaf 3000 (us since the first member entered the pass), members as columns:")
+                for k, nm in enumerate(names):
+                    print(f"    {nm:22s}" + " ".join(f"{(st[mm, k] - t0) / 100.0:6.2f}" for mm in range(KCL)))
+                for ph, nm in ((0, "B per wave"),):
                     for mm in (0, KCL - 4, KCL - 1):
                         print(f"  {nm} (cycles per leaf, member {mm}): ", [int(out[mm][32 + 8 * ph + w] / max(leaves, 1)) for w in range(8)])
             passes = leaves + 1e-9

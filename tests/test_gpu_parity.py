@@ -1,6 +1,9 @@
 """Parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the golden
 fixtures.  Floating point, so tolerances are stated: log density 1e-11 relative; gradient
-1e-10 of its max-norm; early NUTS trajectories 1e-6; posterior summaries in units of MCSE."""
+1e-10 of its max-norm; early NUTS trajectories 1e-6; posterior summaries in units of MCSE.
+
+Both device paths are covered: cus_per_chain = 1 (one workgroup per chain, potus_model.hpp /
+potus_nuts.hpp) and clusters of 8 and 16 workgroups per chain (potus_cluster.hpp)."""
 import numpy as np
 import pytest
 
@@ -19,10 +22,14 @@ def _blocks(data, variant):
     return {k: (a - 7, b - 7) for k, (a, b, _) in layout.items() if b - 7 <= D}
 
 
+CUS = [1, 8, 16]
+
+
+@pytest.mark.parametrize("cus", CUS)
 @pytest.mark.parametrize("name", ["small_full", "small_nomode", "2016"])
-def test_log_prob_grad_matches_oracle_and_golden(cases, name):
+def test_log_prob_grad_matches_oracle_and_golden(cases, name, cus):
     data, variant = cases[name]
-    h = Handle(data, variant, chains=1)
+    h = Handle(data, variant, chains=1, cus_per_chain=cus)
     m = OracleModel(data, variant)
     g = np.load(GOLD / f"logprob_{name}.npz")
     rng = np.random.default_rng(2024)
@@ -38,9 +45,10 @@ def test_log_prob_grad_matches_oracle_and_golden(cases, name):
     h.close()
 
 
-def test_log_prob_grad_is_deterministic_and_batched(cases):
+@pytest.mark.parametrize("cus", [1, 16])
+def test_log_prob_grad_is_deterministic_and_batched(cases, cus):
     data, variant = cases["2016"]
-    h = Handle(data, variant, chains=1)
+    h = Handle(data, variant, chains=1, cus_per_chain=cus)
     q = np.random.default_rng(1).uniform(-2, 2, (40, h.D))
     lp1, g1 = h.log_prob_grad(q)
     lp2, g2 = h.log_prob_grad(q[::-1].copy())
@@ -48,11 +56,12 @@ def test_log_prob_grad_is_deterministic_and_batched(cases):
     h.close()
 
 
+@pytest.mark.parametrize("cus", CUS)
 @pytest.mark.parametrize("name,iters", [("small_full", 8), ("small_nomode", 8), ("2016", 3)])
-def test_nuts_follows_the_oracle_chain(cases, name, iters):
+def test_nuts_follows_the_oracle_chain(cases, name, iters, cus):
     """Same Philox streams + same algorithm => the first transitions agree to rounding."""
     data, variant = cases[name]
-    h = Handle(data, variant, chains=2, num_warmup=30, num_samples=0, save_warmup=1, seed=1843)
+    h = Handle(data, variant, chains=2, num_warmup=30, num_samples=0, save_warmup=1, seed=1843, cus_per_chain=cus)
     h.init()
     h.run(iters)
     d = h.draws()[:, :iters]
@@ -67,11 +76,12 @@ def test_nuts_follows_the_oracle_chain(cases, name, iters):
     h.close()
 
 
-def test_adaptation_matches_oracle_through_a_metric_update(cases):
+@pytest.mark.parametrize("cus", [1, 16])
+def test_adaptation_matches_oracle_through_a_metric_update(cases, cus):
     """150 warmup iterations cover init buffer, first window end (metric update + init_stepsize)."""
     data, variant = cases["small_full"]
     nw = 150
-    h = Handle(data, variant, chains=1, num_warmup=nw, num_samples=0, save_warmup=1, seed=11)
+    h = Handle(data, variant, chains=1, num_warmup=nw, num_samples=0, save_warmup=1, seed=11, cus_per_chain=cus)
     h.init()
     h.run(nw)
     d = h.draws()[0]
@@ -88,9 +98,10 @@ def test_adaptation_matches_oracle_through_a_metric_update(cases):
     h.close()
 
 
-def test_same_seed_same_bytes_and_chain_ids(cases):
+@pytest.mark.parametrize("cus", [1, 16])
+def test_same_seed_same_bytes_and_chain_ids(cases, cus):
     data, variant = cases["small_full"]
-    kw = dict(num_warmup=40, num_samples=20, seed=99)
+    kw = dict(num_warmup=40, num_samples=20, seed=99, cus_per_chain=cus)
     a = Handle(data, variant, chains=3, **kw); a.init(); a.run(60); da = a.draws(); a.close()
     b = Handle(data, variant, chains=3, **kw); b.init(); b.run(25); b.run(35); db = b.draws(); b.close()
     assert np.array_equal(da, db)                      # deterministic, independent of chunking
@@ -165,19 +176,25 @@ def test_error_paths(cases):
         Handle(data, variant, chains=1, max_depth=40)
 
 
-def test_posterior_parity_small(cases):
+_ORACLE_POSTERIOR = {}
+
+
+@pytest.mark.parametrize("cus", [1, 16])
+def test_posterior_parity_small(cases, cus):
     """Statistical parity: pooled means of every unconstrained coordinate within 5 combined MCSE."""
     data, variant = cases["small_full"]
     nw = ns = 400
-    h = Handle(data, variant, chains=4, num_warmup=nw, num_samples=ns, seed=1843)
+    h = Handle(data, variant, chains=4, num_warmup=nw, num_samples=ns, seed=1843, cus_per_chain=cus)
     h.init(); h.run(nw + ns)
     d = h.draws()
     x = d[:, :, 7:]
     st, _ = h.chain_status()
     assert st == [0, 0, 0, 0] and d[:, :, 5].mean() < 0.02        # divergent__ among the saved draws
-    m = OracleModel(data, variant)
-    o = m.default_opts(num_warmup=nw, num_samples=ns, seed=4242, fast_grad=1)      # different seed: independent run
-    y = np.stack([m.sample_chain(c, o)[0][:, 7:] for c in (1, 2, 3, 4)])
+    if "y" not in _ORACLE_POSTERIOR:
+        m = OracleModel(data, variant)
+        o = m.default_opts(num_warmup=nw, num_samples=ns, seed=4242, fast_grad=1)      # different seed: independent run
+        _ORACLE_POSTERIOR["y"] = np.stack([m.sample_chain(c, o)[0][:, 7:] for c in (1, 2, 3, 4)])
+    y = _ORACLE_POSTERIOR["y"]
     worst = 0.0
     for j in range(h.D):
         a, b = x[:, :, j], y[:, :, j]

@@ -154,12 +154,14 @@ __device__ __forceinline__ void cl_allreduce(double (&v)[N], ldp red, Xch &x, in
   PROF_MARK(21);
   __syncthreads();
   PROF_MARK(22);
-  if (w == 0) {
+  {
+    // (global memory operations are kept out of branches: the compiler drains the whole memory queue, i.e.
+    // waits for the write-through store to complete, wherever control flow joins after one)
     double s = 0.0;
     const int k = lane < N ? lane : N - 1;
 #pragma unroll
     for (int i = 0; i < PT_NW; i++) s += red[i * N + k];
-    xst(x, lane < N ? 16u * (unsigned)lane : PT_OOB, s);
+    xst(x, (w == 0 && lane < N) ? 16u * (unsigned)lane : PT_OOB, s);
   }
   x.epoch++;
   PROF_MARK(23);
@@ -195,14 +197,15 @@ __device__ __forceinline__ void cl_allreduce_wide(ldp part, int nv, ldp out, Xch
   PROF_MARK(21);
   __syncthreads();
   PROF_MARK(22);
-  if (w == 0) {
-    for (int l0 = 0; l0 < nv; l0 += 64) {
-      const int l = l0 + lane;
-      double s = 0.0;
+  TSTAMP(10);
 #pragma unroll
-      for (int i = 0; i < PT_NW; i++) s += part[(l < nv ? l : 0) * PT_NW + i];
-      xst(x, l < nv ? 16u * (unsigned)l : PT_OOB, s);
-    }
+  for (int l0 = 0; l0 < CL_WIDE; l0 += 64) {
+    const int l = l0 + lane;
+    const bool ok = w == 0 && l < nv;
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < PT_NW; i++) s += part[(ok ? l : 0) * PT_NW + i];
+    xst(x, ok ? 16u * (unsigned)l : PT_OOB, s);
   }
   x.epoch++;
   PROF_MARK(23);
@@ -222,6 +225,7 @@ __device__ __forceinline__ void cl_allreduce_wide(ldp part, int nv, ldp out, Xch
       if (l < nv) out[l] = tot;
     }
     PROF_MARK(24);
+    TSTAMP(11);
   }
   __syncthreads();
   PROF_MARK(26);
@@ -400,6 +404,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   ldp prof = lds + CL->l_prof;
 #endif
   PROF_START();
+  TSTAMP(0);
 
   // ---------------- phase A: the small vectors (all members read all of them), own days of the S x T block
   double cs[CL_DW], zq[CL_DW];
@@ -432,16 +437,15 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   }
   __syncthreads();
   PROF_MARK(0);
+  TSTAMP(1);
   WPROF_T0();
 
   // ---------------- phase B: X1 (suffix totals); meanwhile mu_b_T / polling-bias mat-vecs and the AR(1) bias
-  if (w == 0) {
+  {
     double tot = 0.0;
-    if (lane < S) {
 #pragma unroll
-      for (int w2 = 0; w2 < PT_NW; w2++) tot += Y[w2 * SE + lane];
-    }
-    xst(x, lane < S ? 16u * (unsigned)lane : PT_OOB, tot);
+    for (int w2 = 0; w2 < PT_NW; w2++) tot += Y[w2 * SE + (lane < S ? lane : S)];
+    xst(x, (w == 0 && lane < S) ? 16u * (unsigned)lane : PT_OOB, tot);   // no branch around the store
   }
   x.epoch++;                                      // X1 is on its way; the consumers below spin on its tags
   if (w == 1) {
@@ -539,6 +543,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   WPROF_ACC(0);
   __syncthreads();
   PROF_MARK(1);
+  TSTAMP(2);
   {
     // C[k][t] for the member's days: local suffix + later waves + later members
     if (lane < S) {
@@ -571,6 +576,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   if (tid == 0) r_lds[np] = 0.0;
   __syncthreads();
   PROF_MARK(2);
+  TSTAMP(3);
 
   // ---------------- phase C: the member's polls, one thread per poll (stan:95-112, 130-131).  The exp / log1p /
   // division of the binomial term are ~250 double-precision instructions per wave: polls are dealt to the
@@ -580,8 +586,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     const double sigma_c = M->sigma_c, sigma_m = M->sigma_m, sigma_pop = M->sigma_pop, sigma_ns = M->sigma_ns, sigma_nn = M->sigma_nn;
     const unsigned long long AS_L *pm = (const unsigned long long AS_L *)(lds + CL->l_pm);
     ldp py = lds + CL->l_py, pN = lds + CL->l_pN, pun = lds + CL->l_pun;
-    for (int i0 = 0; i0 < np; i0 += PT_THREADS) {
-      if (i0 + 64 * w >= np) break;                      // this wave has no polls (wave-uniform)
+    for (int i0 = 0; i0 < np; i0 += PT_THREADS) {        // one trip unless a member has more than 512 polls
       const int il = i0 + tid;
       const bool ok = il < np;
       const int ic = ok ? il : np;                       // slot np holds zeros: N = y = 0
@@ -590,39 +595,44 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       typename Pol::GT gt;
       pol.q_load(vq, qt);
       pol.g_load(vq, gt);
-      const unsigned long long meta = pm[ic];
-      const int s = (int)(meta & 0xffu), tl = (int)((meta >> 8) & 0xffu), ip = (int)((meta >> 16) & 0xffffu);
-      const int im = (int)((meta >> 32) & 0xffu), ipop = (int)((meta >> 40) & 0xffu);
-      const double y = py[ic], N = pN[ic], un = pun[ic];
-      const int t = d0 + tl;
-      ldp L0 = Lw + s * SP, C0 = C + tl;
-      double a0 = 0.0, a1 = 0.0;
-      for (int k0 = 0; k0 < S; k0 += 16) {               // 51-term dot, sixteen terms in flight
-        double l[16], c[16];
+      double gval = 0.0, zn = 0.0;
+      if (i0 + 64 * w < np) {                            // waves without polls skip the arithmetic (wave-uniform); no global
+        const unsigned long long meta = pm[ic];          // memory operation inside the branch
+        const int s = (int)(meta & 0xffu), tl = (int)((meta >> 8) & 0xffu), ip = (int)((meta >> 16) & 0xffffu);
+        const int im = (int)((meta >> 32) & 0xffu), ipop = (int)((meta >> 40) & 0xffu);
+        const double y = py[ic], N = pN[ic], un = pun[ic];
+        const int t = d0 + tl;
+        ldp L0 = Lw + s * SP, C0 = C + tl;
+        double a0 = 0.0, a1 = 0.0;
+        for (int k0 = 0; k0 < S; k0 += 16) {             // 51-term dot, sixteen terms in flight
+          double l[16], c[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) { const int kk = min(k0 + j, S - 1); l[j] = L0[kk]; c[j] = C0[kk * NDP]; }
-        ISSUE_FENCE();
+          for (int j = 0; j < 16; j++) { const int kk = min(k0 + j, S - 1); l[j] = L0[kk]; c[j] = C0[kk * NDP]; }
+          ISSUE_FENCE();
 #pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-          a0 += (k0 + j < S ? 1.0 : 0.0) * l[j] * c[j];
-          a1 += (k0 + j + 1 < S ? 1.0 : 0.0) * l[j + 1] * c[j + 1];
+          for (int j = 0; j < 16; j += 2) {
+            a0 += (k0 + j < S ? 1.0 : 0.0) * l[j] * c[j];
+            a1 += (k0 + j + 1 < S ? 1.0 : 0.0) * l[j + 1] * c[j + 1];
+          }
         }
+        const double dot = a0 + a1;
+        const double sg = s == S ? sigma_nn : sigma_ns;
+        zn = pol.q_fin(qt);
+        double eta = s_bT[s] + s_pb[s] + sg * zn + sigma_c * s_mid[ip] + dot;
+        if (full) eta += sigma_m * s_mid[om + im] + sigma_pop * s_mid[opop + ipop] + un * s_e[t];
+        // binomial_logit with one exp, one log1p, one division:  e = exp(-|eta|), l = log1p(e)
+        const double ex = exp(-fabs(eta)), l1 = log1p(ex), pr = (eta >= 0.0 ? 1.0 : ex) / (1.0 + ex);
+        const double r = y - N * pr;
+        lp += y * (fmin(eta, 0.0) - l1) + (N - y) * (fmin(-eta, 0.0) - l1) - 0.5 * zn * zn; // stan:126-127,130-131 (zn = 0 on idle lanes)
+        r_lds[ok ? il : np + 1] = r;                     // slot np stays 0 (padding of the task lists), np+1 is a dump
+        gval = sg * r - zn;
       }
-      const double dot = a0 + a1;
-      const double sg = s == S ? sigma_nn : sigma_ns;
-      const double zn = pol.q_fin(qt);
-      double eta = s_bT[s] + s_pb[s] + sg * zn + sigma_c * s_mid[ip] + dot;
-      if (full) eta += sigma_m * s_mid[om + im] + sigma_pop * s_mid[opop + ipop] + un * s_e[t];
-      // binomial_logit with one exp, one log1p, one division:  e = exp(-|eta|), l = log1p(e)
-      const double ex = exp(-fabs(eta)), l1 = log1p(ex), pr = (eta >= 0.0 ? 1.0 : ex) / (1.0 + ex);
-      const double r = y - N * pr;
-      lp += y * (fmin(eta, 0.0) - l1) + (N - y) * (fmin(-eta, 0.0) - l1) - 0.5 * zn * zn; // stan:126-127,130-131 (zn = 0 on idle lanes)
-      r_lds[ok ? il : np + 1] = r;                       // slot np stays 0 (padding of the task lists), np+1 is a dump
-      pol.g_fin(vq, sg * r - zn, zn, gt);
+      pol.g_fin(vq, gval, zn, gt);
     }
   }
   __syncthreads();
   PROF_MARK(3);
+  TSTAMP(4);
 
   // ---------------- phase D: adjoint of the walk, gC[:,t] = sum_i r_i Lw_ext[s_i,:] summed over days <= t.
   // The member's polls (day order) are cut into PT_NW equal chunks, one per wave, whatever the days: a wave
@@ -630,7 +640,6 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // readlane; lanes < S keep the running sum over the chunk, lane 63 the day's sum of unadjusted * residual
   // (the adjoint input of e_bias[t]).  At the last poll of a day the running values go to LDS; the owners
   // of the days pick them up in phase E.  Level-1 segment sums follow.
-  WPROF_T0B();
   {
     const unsigned AS_L *tab = (const unsigned AS_L *)(lds + CL->l_tab);
     ldp pun = lds + CL->l_pun, gev = lds + CL->l_gev;
@@ -673,7 +682,6 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       if (l63 && !(le & 0x10000u)) gev[w * 64 + (int)((le >> 8) & 0xffu)] = acc;
     }
   }
-  WPROF_ACCB(1);
   {
     const int nsub = part[CP_NSUB];
     const u32x4 AS_L *sb = (const u32x4 AS_L *)(lds + CL->l_sub);
@@ -694,9 +702,9 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       if (ok) Y[sub] = sum;
     }
   }
-  WPROF_ACCB(2);
   __syncthreads();
   PROF_MARK(4);
+  TSTAMP(5);
 
   // ---------------- phase E: the owners of the days pick up the running sums; level-2 segment sums
   double pre[CL_DW];
@@ -751,16 +759,14 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   }
   __syncthreads();
   PROF_MARK(5);
+  TSTAMP(6);
 
   // ---------------- phase E2: payload of X2
   double arA = 1.0, arB = 0.0;                      // wave 1 keeps its per-day adjoint composites for phase F
+  double pay = 0.0;                                 // the word this lane publishes (wave 0: prefix total, wave 1: AR words)
   if (w == 0) {
-    double tot = 0.0;
-    if (lane < S) {
 #pragma unroll
-      for (int w2 = 0; w2 < PT_NW; w2++) tot += X[w2 * SE + lane];
-    }
-    xst(x, lane < S ? 16u * (unsigned)(XP_PRE + lane) : PT_OOB, tot);
+    for (int w2 = 0; w2 < PT_NW; w2++) pay += X[w2 * SE + (lane < S ? lane : S)];
   } else if (w == 1) {
     if (full) {
       // adjoint of the AR(1) recursion over the member's days (one lane per day): a[t] = ge[t] + rho a[t+1]
@@ -778,8 +784,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       // lane 63 holds the member's composite and the three sums
       const double pv0 = dpp_readlane_d(arA, 63), pv1 = dpp_readlane_d(arB, 63);
       const double pv2 = dpp_readlane_d(S1, 63), pv3 = dpp_readlane_d(S2, 63), pv4 = dpp_readlane_d(S3, 63);
-      const double pv = lane == 0 ? pv0 : lane == 1 ? pv1 : lane == 2 ? pv2 : lane == 3 ? pv3 : pv4;
-      xst(x, lane < 5 ? 16u * (unsigned)(XP_AR + lane) : PT_OOB, pv);   // XP_S = XP_AR + 2
+      pay = lane == 0 ? pv0 : lane == 1 ? pv1 : lane == 2 ? pv2 : lane == 3 ? pv3 : pv4;   // XP_S = XP_AR + 2
     }
   } else {
     // dbT[s] = dpolling_bias[s] = residuals of state s + w_s * national residuals (this member's polls
@@ -802,18 +807,25 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     for (int j = 0; j < NJ; j++) { pT += lt[j] * gg[j]; pB += lb[j] * gg[j]; }
     if (lane < S) { C[wj * SE + lane] = pT; C[(6 + wj) * SE + lane] = pB; }
   }
+  xst(x, (w == 0 && lane < S) ? 16u * (unsigned)(XP_PRE + lane) : (w == 1 && full && lane < 5) ? 16u * (unsigned)(XP_AR + lane) : PT_OOB, pay);
   __syncthreads();
   PROF_MARK(6);
-  if (w == 0) {
-    for (int rr = lane; rr < NR; rr += 64) {
-      double v;
-      if (rr < 2 * S) {
-        const int which = rr >= S, k = rr - which * S;
-        v = 0.0;
+  TSTAMP(7);
+  {
+    // slot partials: every thread publishes one slot (two with more than 512 slots); no branch around the stores
 #pragma unroll
-        for (int w2 = 0; w2 < 6; w2++) v += C[(which * 6 + w2) * SE + k];
-      } else v = s_P[rr];
-      xst(x, 16u * (unsigned)(XP_P + rr), v);
+    for (int h = 0; h < 2; h++) {
+      const int rr = tid + h * PT_THREADS;
+      const bool ok = rr < NR;
+      const int rc = ok ? rr : 0;
+      const int which = rc >= S, k = rc < 2 * S ? rc - which * S : 0;
+      double v6[6];
+#pragma unroll
+      for (int w2 = 0; w2 < 6; w2++) v6[w2] = C[(which * 6 + w2) * SE + k];
+      const double vp = s_P[rc];
+      ISSUE_FENCE();
+      const double v = rc < 2 * S ? ((((v6[0] + v6[1]) + v6[2]) + v6[3]) + v6[4]) + v6[5] : vp;
+      xst(x, ok ? 16u * (unsigned)(XP_P + rr) : PT_OOB, v);
     }
   }
   // loads that do not depend on the exchange are issued while wave 0 waits
@@ -854,7 +866,9 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     }
     if (lane < S) X[PT_NW * SE + lane] = carry_m;
     PROF_MARK(7);
+    TSTAMP(8);
   }
+  double own_g = 0.0, own_q = 0.0;                 // gradient / position of the element this thread owns besides the S x T block
   if (w == 1) {
     if (full) {
       // carry of the adjoint from the members that own later days, then raw_e_bias of the member's days
@@ -872,7 +886,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       const double z = s_mid[M->o_ze - o_c + (arl ? t : 0)];
       const double gv = a * (t >= 1 ? s_scal[SC_SRHO] : M->sigma_e) - z;
       lp -= arl ? 0.5 * z * z : 0.0;               // stan:125
-      pol.gs_fin(vo_x, gv, z, gx);
+      own_g = gv; own_q = z;
     }
   } else if (w >= 2 && __any(repl)) {
     // owned slots of the small vectors: sum the K partials in member order
@@ -916,8 +930,9 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       }
     }
     lp += repl ? dl : 0.0;
-    pol.gs_fin(vo_x, gv, qv, gx);
+    own_g = gv; own_q = qv;
   }
+  pol.gs_fin(vo_x, own_g, own_q, gx);              // outside the branches (vo_x is out of range for non-owners)
   __syncthreads();
   {
     const double carry = lane < S ? X[PT_NW * SE + lane] : 0.0;   // pre[] is already the prefix within the member
@@ -928,6 +943,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     }
   }
   PROF_MARK(18);
+  TSTAMP(9);
 #pragma unroll
   for (int k = 0; k < Pol::NEXTRA; k++) pol_io.extra[k] = pol.extra[k];
   (void)red;
