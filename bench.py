@@ -11,6 +11,8 @@ transitions of a throw-away sampler first (clocks, code objects, allocator).
   python bench.py [--gpus N] [--steps K] [--warmup W] [--chains-per-gpu C]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Each chain runs on a cluster of K workgroups (K compute units of one XCD; K = 16 for 8 chains, see
+potus_cluster.hpp; --cus-per-chain 1 selects the one-workgroup-per-chain kernel instead).
 N > 1: one process per GPU; rank r owns chains [r*C, (r+1)*C) (RNG streams keyed by global chain
 id), no communication while sampling, one RCCL all-gather of the draws-of-interest for pooled
 R-hat / ESS (inside the timed region).  Weak scaling: C chains per GPU whatever N is.
@@ -42,6 +44,21 @@ def algorithmic_bytes_per_leapfrog(d, variant="full"):
     S = int(d["S"])
     per_state, per_nat = (36, 32) if variant == "full" else (28, 24)
     return 48 * D + per_state * int(d["N_state_polls"]) + per_nat * int(d["N_national_polls"]) + 24 * S * S + 16 * S
+
+
+def measured_traffic(kernel):
+    """HBM bytes per leapfrog from the committed rocprofv3 PMC passes of this command (profiles/*pmc_traffic.json,
+    written by the recipe in scripts/profile_round.sh): FETCH_SIZE and WRITE_SIZE cannot be collected from inside
+    the benchmark, so the bench line quotes the per-leapfrog figure of the latest committed pass for the same kernel."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("*pmc_traffic.json")):
+        try:
+            d = json.loads(f.read_text())
+        except (OSError, ValueError):
+            continue
+        if d.get("kernel") == kernel:
+            best = (f.name, d)
+    return best
 
 
 def _cpu_worker(args):
@@ -77,6 +94,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--chains-per-gpu", type=int, default=8)
+    ap.add_argument("--cus-per-chain", type=int, default=0, help="workgroups per chain (0 = auto: 16, 8 or 1 by what fits)")
     ap.add_argument("--chunk", type=int, default=100, help="transitions per kernel launch")
     ap.add_argument("--seed", type=int, default=1843)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -102,13 +120,14 @@ def main():
 
     if args.warmup > 0:  # untimed: throw-away sampler
         hw = Handle(data, variant, chains=C, chain_id_offset=rank * C, num_warmup=args.warmup, num_samples=0,
-                    seed=args.seed + 1, device=local)
+                    seed=args.seed + 1, device=local, cus_per_chain=args.cus_per_chain)
         hw.init()
         hw.run(args.warmup)
         hw.close()
 
     h = Handle(data, variant, chains=C, chain_id_offset=rank * C, num_warmup=nw, num_samples=ns, seed=args.seed,
-               device=local)
+               device=local, cus_per_chain=args.cus_per_chain)
+    K = h.cus_per_chain
     S, T = int(data["S"]), int(data["T"])
     a_mu = h.layout["mu_b"][0]
 
@@ -154,6 +173,9 @@ def main():
             rh = float(max(dg.rhat(cols[:, :, j]) for j in range(cols.shape[2])))
         bpl = algorithmic_bytes_per_leapfrog(data, variant)
         achieved = leapfrogs_local * bpl / (kernel_ms * 1e-3) / 1e9  # this rank's kernel, its own stream's events
+        kernel = "k_cl_run" if K > 1 else "k_run"
+        tr = measured_traffic(kernel)
+        traffic = tr[1]["hbm_bytes_per_leapfrog"] * leapfrogs_local / (kernel_ms * 1e-3) / 1e9 if tr else None
         line = {
             "metric": "leapfrog_steps_per_sec", "value": leapfrogs / elapsed, "unit": "leapfrogs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -163,17 +185,24 @@ def main():
                                    f"{nw} warmup + {ns} sampling, seed {args.seed}",
                        "chains_per_gpu": C, "total_chains": total_chains, "D": h.D, "S": S, "T": T,
                        "polls": int(data["N_state_polls"]) + int(data["N_national_polls"]),
-                       "parallelism": f"chains sharded {C}/GPU x {world}, no data-path collective; "
-                                      "one all-gather of draws-of-interest" if world > 1 else f"{C} chains, one workgroup each"},
+                       "cus_per_chain": K,
+                       "parallelism": (f"chains sharded {C}/GPU x {world}, no data-path collective; one all-gather of draws-of-interest; "
+                                       if world > 1 else f"{C} chains; ") +
+                                      (f"each chain on a cluster of {K} workgroups ({C * K} of 256 CUs busy)" if K > 1
+                                       else "one workgroup per chain")},
             "leapfrogs": int(leapfrogs), "seconds": elapsed,
             "us_per_leapfrog_per_chain": 1e6 * kernel_ms_max * 1e-3 * C / max(leapfrogs_local, 1),
             "ess_bulk_min": ess, "ess_per_sec": (ess / samp_time) if ess else None, "rhat_max": rh if ess else None,
             "divergent_transitions": int(sum(dv)), "chain_status": st,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_run", "algorithmic_bytes_per_leapfrog": bpl,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_note": (f"GB/s over the same launches: {tr[1]['hbm_bytes_per_leapfrog']:.0f} HBM bytes per leapfrog "
+                                          f"(2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/{tr[0]}) x leapfrogs / launch time"
+                                          if tr else "no PMC pass committed for this kernel"),
+                         "kernel": kernel, "algorithmic_bytes_per_leapfrog": bpl,
                          "leapfrogs_in_launches": int(leapfrogs_local), "launch_ms_total": kernel_ms,
-                         "note": "latency-bound by design at 8 chains (8 of 256 CUs busy); see DESIGN.md"},
+                         "note": f"latency-bound at {C} chains ({C * K} of 256 CUs busy): the state of a chain stays in L2, "
+                                 "the leapfrog is a chain of dependent exchanges between the CUs of a cluster; see DESIGN.md"},
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(data, variant, C, args.cpu_budget)

@@ -129,6 +129,8 @@ int potus_column_name(const potus_data *d, int col, char *buf, int len);
  * (transformed data, stan:42-55), upload everything, allocate chain state. */
 int potus_create(const potus_data *d, const potus_opts *o, int *handle);
 int potus_destroy(int handle);
+/* Compute units (workgroups) per chain the handle actually runs with (cus_per_chain = 0 resolved). */
+int potus_cus_per_chain(int handle, int *k);
 
 /* Parity hook: log-density (with Jacobians, constants dropped as `~` does) and its
  * gradient for n points of the unconstrained space, evaluated by the same device

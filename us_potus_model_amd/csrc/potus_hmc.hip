@@ -1115,6 +1115,13 @@ int potus_destroy(int handle) {
   return 0;
 }
 
+int potus_cus_per_chain(int handle, int *k) {
+  Sampler *sp = get(handle);
+  if (!sp || !k) return fail(POTUS_ERR_STATE, "bad handle");
+  *k = sp->K;
+  return 0;
+}
+
 int potus_log_prob_grad(int handle, const double *q, int n, double *lp, double *grad) {
   Sampler *sp = get(handle);
   if (!sp) return fail(POTUS_ERR_STATE, "bad handle");

@@ -77,7 +77,7 @@ def load_library():
 
 EXPORTS = [
     "potus_version", "potus_last_error", "potus_default_opts", "potus_num_params", "potus_num_columns",
-    "potus_column_name", "potus_create", "potus_destroy", "potus_log_prob_grad", "potus_init", "potus_run",
+    "potus_column_name", "potus_create", "potus_destroy", "potus_cus_per_chain", "potus_log_prob_grad", "potus_init", "potus_run",
     "potus_iterations_done", "potus_total_leapfrogs", "potus_chain_status", "potus_get_adaptation",
     "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_stan_csv",
     "potus_last_run_timing", "potus_R_create", "potus_R_init", "potus_R_run", "potus_R_num_columns",
@@ -120,6 +120,9 @@ class Handle:
         self.D, self.n_cols = D.value, nc.value
         self.layout, ncols2 = _abi.column_layout(data, variant)
         assert ncols2 == self.n_cols
+        k = C.c_int()
+        _check(self.L, self.L.potus_cus_per_chain(self.h, C.byref(k)))
+        self.cus_per_chain = k.value
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h >= 0:
