@@ -496,7 +496,13 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         c1 = first ? 0.0 : rho * c1 + 1.0; c2 = first ? 0.0 : rho * c2 + dp[u]; c3 = first ? 0.0 : rho * c3 + z[u];
         if (t < T) { s_c1[t] = c1; s_c2[t] = c2; s_c3[t] = c3; }
       }
-      if (lane == 0) { s_scal[SC_MUE] = mue; s_scal[SC_RHO] = rho; s_scal[SC_SRHO] = srho; s_scal[SC_XMUE] = xm; s_scal[SC_XRHO] = xr; }
+      if (lane == 0) {
+        s_scal[SC_MUE] = mue; s_scal[SC_RHO] = rho; s_scal[SC_SRHO] = srho; s_scal[SC_XMUE] = xm; s_scal[SC_XRHO] = xr;
+        // what the owner of rho_e_bias needs in phase F, computed here where the wave has slack:
+        // Jacobian + prior of rho (stan:63,124) and d sigma_rho / d rho
+        s_scal[SC_LPRHO] = log(rho) + log1p(-rho) - 0.5 * ((rho - 0.7) / 0.1) * ((rho - 0.7) / 0.1);
+        s_scal[SC_DSRHO] = sigma_e * (-rho / sqrt(1.0 - rho * rho));
+      }
     }
   } else if (w >= 2) {
     // partial products of the two 51 x 51 factors: wave w-2 takes columns k = w-2, w+4, ...
@@ -837,10 +843,17 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     pol.g_load(voz[j], gz[j]);
   }
   const bool arl = full && w == 1 && lane < nd;                 // owner of raw_e_bias[d0 + lane]
+  // small-vector slots: threads 128.. take the ordinary slots of the member; mu_e_bias and rho_e_bias (the last
+  // two slots, whose gradients come from the three tangent sums) go to the last lanes of the last wave of their
+  // owner so that they run beside, not after, the ordinary ones (thread 511 fetches the third sum for 510)
+  const int NRo = full ? NR - 2 : NR;                           // ordinary slots
+  const int nro = max(0, min(r0 + nr, NRo) - r0);               // ordinary slots of this member (<= 381, checked on the host)
   const int jr = tid - 128;
-  const bool repl = jr >= 0 && jr < nr;                         // owner of small-vector slot r0 + jr
-  const int rslot = repl ? r0 + jr : 0;
-  const unsigned vo_x = arl ? 8u * (unsigned)(e_ze + nd - 1 - lane) : repl ? 8u * (unsigned)(e_rep + jr) : PT_OOB;
+  const bool own_mue = full && r0 <= NR - 2 && NR - 2 < r0 + nr, own_rho = full && r0 <= NR - 1 && NR - 1 < r0 + nr;
+  const bool is_mue = own_mue && tid == PT_THREADS - 3, is_rho = own_rho && tid == PT_THREADS - 2, is_s3 = own_rho && tid == PT_THREADS - 1;
+  const bool repl = (jr >= 0 && jr < nro) || is_mue || is_rho;
+  const int rslot = is_mue ? NR - 2 : is_rho ? NR - 1 : (repl ? r0 + jr : 0);
+  const unsigned vo_x = arl ? 8u * (unsigned)(e_ze + nd - 1 - lane) : repl ? 8u * (unsigned)(e_rep + rslot - r0) : PT_OOB;
   typename Pol::GT gx;
   pol.g_load(vo_x, gx);
   const double scale_r = cst.scale_r;
@@ -888,12 +901,11 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       lp -= arl ? 0.5 * z * z : 0.0;               // stan:125
       own_g = gv; own_q = z;
     }
-  } else if (w >= 2 && __any(repl)) {
+  } else if (w >= 2 && __any(repl || is_s3)) {
     // owned slots of the small vectors: sum the K partials in member order
-    double sum = 0.0, sum2 = 0.0, sum3 = 0.0;
-    const bool is_mue = full && repl && rslot == NR - 2, is_rho = full && repl && rslot == NR - 1;
-    const unsigned v1 = !repl ? PT_OOB : is_mue ? 16u * (unsigned)XP_S : is_rho ? 16u * (unsigned)(XP_S + 1) : 16u * (unsigned)(XP_P + rslot);
-    const unsigned v2 = is_rho ? 16u * (unsigned)(XP_S + 2) : PT_OOB;
+    double sum = 0.0;
+    const unsigned v1 = is_mue ? 16u * (unsigned)XP_S : is_rho ? 16u * (unsigned)(XP_S + 1) : is_s3 ? 16u * (unsigned)(XP_S + 2)
+                        : repl ? 16u * (unsigned)(XP_P + rslot) : PT_OOB;
     for (int mm0 = 0; mm0 < K; mm0 += 16) {
       double t16[16];
       unsigned vo[16], so[16];
@@ -903,31 +915,16 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
 #pragma unroll
       for (int u = 0; u < 16; u++) sum += t16[u];
     }
-    if (__any(is_rho)) {                           // the one wave that owns rho_e_bias needs a second sum
-      for (int mm0 = 0; mm0 < K; mm0 += 16) {
-        double t16[16];
-        unsigned vo[16], so[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) { const int mm = mm0 + u; vo[u] = mm < K ? v2 : PT_OOB; so[u] = xch_rslot(x, mm < K ? mm : 0); }
-        xld(x, vo, so, t16);
-#pragma unroll
-        for (int u = 0; u < 16; u++) sum2 += t16[u];
-      }
-    }
-    (void)sum3;
+    const double s3 = readlane_d(sum, 63);           // third tangent sum (meaningful in the wave that owns rho_e_bias)
     const double qv = s_rep[rslot];
     double gv = scale_r * sum - qv;
     double dl = -0.5 * qv * qv;                    // stan:117,120-122,128
-    if (full && (is_mue || is_rho)) {
+    if (is_mue || is_rho) {
       const double rho = s_scal[SC_RHO];
-      if (is_mue) {
-        gv = 0.02 * (1.0 - rho) * sum - qv;       // sum = S1
-        dl = log(0.02) - 0.5 * qv * qv;           // Jacobian of mu_e_bias (stan:62) + its prior (stan:123)
-      } else {
-        const double adj_rho = sum + sum2 * M->sigma_e * (-rho / sqrt(1.0 - rho * rho));   // S2, S3
-        gv = (adj_rho - (rho - 0.7) / 0.01) * rho * (1.0 - rho) + (1.0 - 2.0 * rho);
-        dl = log(rho) + log1p(-rho) - 0.5 * ((rho - 0.7) / 0.1) * ((rho - 0.7) / 0.1);      // stan:63,124
-      }
+      const double g_mue = 0.02 * (1.0 - rho) * sum - qv;                       // sum = S1
+      const double g_rho = ((sum + s3 * s_scal[SC_DSRHO]) - (rho - 0.7) / 0.01) * rho * (1.0 - rho) + (1.0 - 2.0 * rho);   // S2, S3
+      gv = is_mue ? g_mue : g_rho;
+      dl = is_mue ? -3.912023005428146 - 0.5 * qv * qv : s_scal[SC_LPRHO];     // log(0.02) + prior (stan:62,123) : stan:63,124
     }
     lp += repl ? dl : 0.0;
     own_g = gv; own_q = qv;
@@ -1187,6 +1184,15 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
       const unsigned s_leaf = c.soff(V_POOLP + leaf);
       ClLeapPolicy lp{c.st, c.soff((sel ? V_QB0 : V_QA0) + dir), c.soff((sel ? V_QA0 : V_QB0) + dir), c.soff(V_PH0 + dir), c.soff(V_MINV),
                       s_leaf, 0.5 * e, e, {0.0}};
+      const int m = __builtin_ctz(~(unsigned)n);  // levels merged at this leaf
+      const bool top = n == nleaf - 1;            // then m == depth
+      if (tid >= PT_THREADS - 64) {
+        // the uniforms of this leaf's accept steps depend on nothing computed here: the last wave draws them
+        // now (one lane per level) instead of thread 0 drawing them one after the other after the reduction
+        const int j = tid - (PT_THREADS - 64) + 1;
+        if (j <= m) ts->u_sub[j] = rng_uniform(c.key, iter, RNG_SUB_ACCEPT, 0, ((uint32_t)depth << 24) | ((uint32_t)j << 16) | (uint32_t)(n >> j));
+        if (j == 64 && top) ts->u_top = rng_uniform(c.key, iter, RNG_TOP_ACCEPT, 0, (uint32_t)depth);
+      }
       const double lpp = cl_pass_partial(c.M, c.CL, c.part, c.lds, c.cst, c.x, lp);
       CPROF_START(c);
       CPROF_COUNT(c, PF_LEAVES);
@@ -1194,8 +1200,6 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
       // this leaf completes (the subtrees of 2, 4, ... leaves that end here, and the whole new subtree against
       // the old trajectory when it is the last leaf of the doubling).  The sweeps only need vectors that are
       // already final; their verdicts are taken after the reduction, exactly in build_tree's order.
-      const int m = __builtin_ctz(~(unsigned)n);  // levels merged at this leaf
-      const bool top = n == nleaf - 1;            // then m == depth
       {
         const int lane = tid & 63, w = tid >> 6;
         const double t0 = dpp_scan_sum(lpp), t1 = dpp_scan_sum(lp.extra[0]);
@@ -1242,10 +1246,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
           const double lsw_sub = d_lse(ts->pend_lsw[j - 1], cur_lsw);
           bool take_final;
           if (cur_lsw > lsw_sub) take_final = true;
-          else {
-            const uint32_t slot = ((uint32_t)depth << 24) | ((uint32_t)j << 16) | (uint32_t)(n >> j);
-            take_final = rng_uniform(c.key, iter, RNG_SUB_ACCEPT, 0, slot) < exp(cur_lsw - lsw_sub);
-          }
+          else take_final = ts->u_sub[j] < exp(cur_lsw - lsw_sub);
           if (take_final) pool_free(qm, ts->pend_prop[j - 1]);
           else { pool_free(qm, cur_prop); cur_prop = ts->pend_prop[j - 1]; }
           if (ie != ib) pool_free(pm, ie);
@@ -1270,7 +1271,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
             const double lsw_sub = cur_lsw, lsw = ts->lsw;
             bool accept;
             if (lsw_sub > lsw) accept = true;
-            else accept = rng_uniform(c.key, iter, RNG_TOP_ACCEPT, 0, (uint32_t)depth) < exp(lsw_sub - lsw);
+            else accept = ts->u_top < exp(lsw_sub - lsw);
             if (accept) { pool_free(qm, ts->sample_qid); ts->sample_qid = prop; }
             else if (prop != cq) pool_free(qm, prop);
             else { pool_free(qm, prop); cq = -1; }   // a rejected single-leaf proposal needs no copy

@@ -745,7 +745,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   C.XW = (XP_P + C.NR + 7) & ~7;
   if (P > 65535 || M.M > 255 || M.Pop > 255) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode packs pollster/mode/population indices in 16/8/8 bits");
   if (C.NREP > 2 * PT_THREADS) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: %d small parameters (> %d)", C.NREP, 2 * PT_THREADS);
-  if ((C.NR + K - 1) / K > PT_THREADS - 128) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: too many pollsters for K = %d", K);
+  if ((C.NR + K - 1) / K > PT_THREADS - 128 - 3) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: too many pollsters for K = %d", K);
   const std::vector<int> &dp = sp->h_dayptr;
 
   // contiguous day ranges: minimise the largest cost (a day = S elements of vector work, a poll = a

@@ -102,7 +102,7 @@ struct DevModel {
 typedef const DevModel AS_C *CMp; // the model descriptor lives in device memory, read through scalar loads
 
 // scalar slots in LDS (l_scal)
-enum { SC_MUE = 0, SC_RHO, SC_SRHO, SC_XMUE, SC_XRHO, SC_N };
+enum { SC_MUE = 0, SC_RHO, SC_SRHO, SC_XMUE, SC_XRHO, SC_LPRHO, SC_DSRHO, SC_N };
 #define PT_NRED 8  // reduction slots
 #define PT_NPROF 64
 

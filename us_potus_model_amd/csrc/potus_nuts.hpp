@@ -93,6 +93,7 @@ struct TS { // transition state, LDS
   double pend_lsw[PT_MAXD + 1];
   double q_lp[PT_NPQ], q_h[PT_NPQ];
   double accept_stat, out_lp, out_h, delta_H;
+  double u_sub[PT_MAXD + 1], u_top;   // cluster mode: uniforms of the leaf's accept steps, drawn ahead by idle lanes
   int pend_beg[PT_MAXD + 1], pend_end[PT_MAXD + 1], pend_prop[PT_MAXD + 1];
   int cur_beg, cur_end, cur_prop;
   unsigned pmask, qmask;
