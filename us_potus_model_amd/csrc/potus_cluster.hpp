@@ -29,8 +29,9 @@
 #include "potus_nuts.hpp"
 #include "potus_dpp.hpp"
 
-#define CL_DW 8                          // days per wave
-#define CL_MAXDAYS (PT_NW * CL_DW)       // days per member
+// Days per wave (DW) is a compile-time parameter of the pass: 4 (members of at most 32 days, e.g. 2016 with
+// K = 16) keeps the per-day register arrays small enough not to spill; 8 covers up to 64 days per member.
+#define CL_MAXDAYS 64                    // LDS sizing: days per member at DW = 8
 #define CL_LPP 4                         // lanes cooperating on one poll's 51-term dot
 #define CL_PPR (PT_THREADS / CL_LPP)     // polls per round of the poll phase
 #define CL_MAXK 32
@@ -256,30 +257,39 @@ struct ClLeapPolicy {
   rsrc_t r;
   unsigned sQc, sQn, sPH, sM, sL;
   double he, e;
-  static constexpr int NEXTRA = 1;
-  double extra[1];
+  // Level-1 U-turn check fused into the epilogue: when this leaf closes a two-leaf subtree (odd leaf number)
+  // the previous leaf's momentum is its whole left half (begin = end = rho), so the six dot products of
+  // build_tree collapse to two, p_prev . (p_prev + p) and p . (p_prev + p), and cost one extra load; the
+  // sum p_prev + p (rho of the pair) is stored for the checks one level up.
+  unsigned sPrev, sOut1;
+  bool fuse1;
+  static constexpr int NEXTRA = 3;
+  double extra[3];
   struct QT { double q; };
-  struct GT { double p, m; };
+  struct GT { double p, m, pp; };
   __device__ __forceinline__ void q_load(unsigned vo, QT &t) { t.q = bld(r, vo, sQc); }
   __device__ __forceinline__ void qs_load(unsigned vo, QT &t) { t.q = bld_s(r, vo, sQc); }
   __device__ __forceinline__ double q_fin(QT &t) { return t.q; }
-  __device__ __forceinline__ void g_load(unsigned vo, GT &t) { t.p = bld(r, vo, sPH); t.m = bld(r, vo, sM); }
-  __device__ __forceinline__ void g_fin(unsigned vo, double v, double q, const GT &t) {
+  __device__ __forceinline__ void g_load(unsigned vo, GT &t) {
+    t.p = bld(r, vo, sPH); t.m = bld(r, vo, sM);
+    t.pp = bld(r, fuse1 ? vo : PT_OOB, sPrev);
+  }
+  template <bool SHARED>
+  __device__ __forceinline__ void fin(unsigned vo, double v, double q, const GT &t) {
     const double pf = t.p + he * v;
     bst(r, vo, sL, pf);
     const double ph = pf + he * v;
     bst(r, vo, sPH, ph);
-    bst(r, vo, sQn, q + e * t.m * ph);
-    extra[0] += t.m * pf * pf;
+    if (SHARED) bst_s(r, vo, sQn, q + e * t.m * ph);
+    else bst(r, vo, sQn, q + e * t.m * ph);
+    const double rs = t.pp + pf;
+    bst(r, fuse1 ? vo : PT_OOB, sOut1, rs);
+    extra[0] += t.m * pf * pf;                    // masked-off elements loaded m = 0
+    extra[1] += t.m * t.pp * rs;
+    extra[2] += t.m * pf * rs;
   }
-  __device__ __forceinline__ void gs_fin(unsigned vo, double v, double q, const GT &t) {
-    const double pf = t.p + he * v;
-    bst(r, vo, sL, pf);
-    const double ph = pf + he * v;
-    bst(r, vo, sPH, ph);
-    bst_s(r, vo, sQn, q + e * t.m * ph);
-    extra[0] += t.m * pf * pf;
-  }
+  __device__ __forceinline__ void g_fin(unsigned vo, double v, double q, const GT &t) { fin<false>(vo, v, q, t); }
+  __device__ __forceinline__ void gs_fin(unsigned vo, double v, double q, const GT &t) { fin<true>(vo, v, q, t); }
 };
 
 struct ClStatic {           // per-thread registers that never change during a kernel
@@ -378,7 +388,7 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
 // cl_pass_partial returns THIS THREAD's share of lp (and leaves the thread's share of pol.extra[] in
 // pol_io); the caller reduces them over the cluster (cl_pass below, or together with the U-turn dot
 // products of the leaf in cl_transition_tree).
-template <class Pol>
+template <int CL_DW, class Pol>
 __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_in, ldp lds, const ClStatic &cst, Xch &x, Pol &pol_io) {
   Pol pol = pol_io;
   int tid = threadIdx.x;
@@ -946,10 +956,10 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   (void)red;
   return lp;
 }
-template <class Pol>
+template <int CL_DW, class Pol>
 __device__ __forceinline__ double cl_pass(CMp M, CCp CL, cip part, ldp lds, const ClStatic &cst, Xch &x, Pol &pol_io) {
   double v[1 + Pol::NEXTRA];
-  v[0] = cl_pass_partial(M, CL, part, lds, cst, x, pol_io);
+  v[0] = cl_pass_partial<CL_DW>(M, CL, part, lds, cst, x, pol_io);
 #pragma unroll
   for (int k = 0; k < Pol::NEXTRA; k++) v[1 + k] = pol_io.extra[k];
   cl_allreduce(v, lds + CL->l_red, x, (int)threadIdx.x);
@@ -1115,13 +1125,14 @@ __device__ __forceinline__ void cl_vop_prekick(ClChain &c, unsigned sq, unsigned
   cl_sync(c.x, c.red());
 }
 
+template <int CL_DW>
 __device__ __forceinline__ void cl_transition_begin(ClChain &c, uint32_t iter) {
   ltp ts = c.ts;
   const int tid = c.tid;
   const double eps = c.sc->nom_eps; // sample_stepsize(): no jitter
   const double kin0 = cl_vop_momentum(c, c.soff(V_PC), iter, RNG_MOMENTUM, 0);
   ClPlainPolicy pp{c.st, c.st, c.soff(V_QC), c.soff(V_GC), {0}};
-  const double lp0 = cl_pass(c.M, c.CL, c.part, c.lds, c.cst, c.x, pp); // hamiltonian.init
+  const double lp0 = cl_pass<CL_DW>(c.M, c.CL, c.part, c.lds, c.cst, c.x, pp); // hamiltonian.init
   if (tid == 0) {
     ts->H0 = 0.5 * kin0 - lp0;
     ts->lsw = 0.0; ts->sum_metro = 0.0; ts->n_leap = 0; ts->depth = 0; ts->divergent = 0; ts->stop = 0; ts->eps = eps;
@@ -1154,6 +1165,7 @@ __device__ __forceinline__ void cl_transition_begin(ClChain &c, uint32_t iter) {
   cl_vop_prekick(c, c.soff(V_QC), c.soff(V_PC), c.soff(V_GC), c.soff(V_PH0), c.soff(V_QA0), c.soff(V_PF0), -0.5 * eps, -eps);
 }
 
+template <int CL_DW>
 __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
   ltp ts = c.ts;
   const int tid = c.tid;
@@ -1182,10 +1194,11 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
       const int sel = ts->qsel[dir];              // buffer holding this leaf's position
       const int leaf = ts->leaf_id;
       const unsigned s_leaf = c.soff(V_POOLP + leaf);
-      ClLeapPolicy lp{c.st, c.soff((sel ? V_QB0 : V_QA0) + dir), c.soff((sel ? V_QA0 : V_QB0) + dir), c.soff(V_PH0 + dir), c.soff(V_MINV),
-                      s_leaf, 0.5 * e, e, {0.0}};
       const int m = __builtin_ctz(~(unsigned)n);  // levels merged at this leaf
       const bool top = n == nleaf - 1;            // then m == depth
+      ClLeapPolicy lp{c.st, c.soff((sel ? V_QB0 : V_QA0) + dir), c.soff((sel ? V_QA0 : V_QB0) + dir), c.soff(V_PH0 + dir), c.soff(V_MINV),
+                      s_leaf, 0.5 * e, e, c.soff(V_POOLP + (m >= 1 ? ts->pend_beg[0] : 0)), m == 1 ? c.soff(V_RHOLEV + 1) : c.soff(V_SCR0 + 1),
+                      m >= 1, {0.0, 0.0, 0.0}};
       if (tid >= PT_THREADS - 64) {
         // the uniforms of this leaf's accept steps depend on nothing computed here: the last wave draws them
         // now (one lane per level) instead of thread 0 drawing them one after the other after the reduction
@@ -1193,7 +1206,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
         if (j <= m) ts->u_sub[j] = rng_uniform(c.key, iter, RNG_SUB_ACCEPT, 0, ((uint32_t)depth << 24) | ((uint32_t)j << 16) | (uint32_t)(n >> j));
         if (j == 64 && top) ts->u_top = rng_uniform(c.key, iter, RNG_TOP_ACCEPT, 0, (uint32_t)depth);
       }
-      const double lpp = cl_pass_partial(c.M, c.CL, c.part, c.lds, c.cst, c.x, lp);
+      const double lpp = cl_pass_partial<CL_DW>(c.M, c.CL, c.part, c.lds, c.cst, c.x, lp);
       CPROF_START(c);
       CPROF_COUNT(c, PF_LEAVES);
       // One all-reduce per leaf: log density, kinetic energy and the six dot products of every U-turn check
@@ -1204,9 +1217,16 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
         const int lane = tid & 63, w = tid >> 6;
         const double t0 = dpp_scan_sum(lpp), t1 = dpp_scan_sum(lp.extra[0]);
         if (lane == 63) { wpart[0 * PT_NW + w] = t0; wpart[1 * PT_NW + w] = t1; }
+        if (m >= 1) {                               // level 1 came out of the epilogue: v0 = v2 = v4, v1 = v3 = v5
+          const double a = dpp_scan_sum(lp.extra[1]), b = dpp_scan_sum(lp.extra[2]);
+          if (lane == 63) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) wpart[(2 + k) * PT_NW + w] = (k & 1) ? b : a;
+          }
+        }
       }
-      if (m > 0 || top) { drain_vmem(); __syncthreads(); }   // the leaf's momentum is read back with another thread map
-      for (int j = 1; j <= m; j++) {
+      if (m > 1 || top) { drain_vmem(); __syncthreads(); }   // the leaf's momentum is read back with another thread map
+      for (int j = 2; j <= m; j++) {
         const int ib = ts->pend_beg[j - 1], ie = ts->pend_end[j - 1], cb = j == 1 ? leaf : ts->pend_beg[j - 2];
         const unsigned a_rho = j == 1 ? c.soff(V_POOLP + ib) : c.soff(V_RHOLEV + j - 1);
         const unsigned b_rho = j == 1 ? c.soff(V_POOLP + leaf) : c.soff(V_SCR0 + ((j - 1) & 1));
@@ -1296,6 +1316,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
 }
 
 // base_hmc::init_stepsize; the chain's point is QC with gradient GC (already evaluated).
+template <int CL_DW>
 __device__ __forceinline__ void cl_init_stepsize(ClChain &c, uint32_t iter) {
   ltp ts = c.ts;
   const int tid = c.tid;
@@ -1311,8 +1332,8 @@ __device__ __forceinline__ void cl_init_stepsize(ClChain &c, uint32_t iter) {
     const double kin0 = cl_vop_momentum(c, c.soff(V_PC), iter, RNG_INIT_EPS, attempt);
     const double H0 = 0.5 * kin0 - lp0;
     cl_vop_prekick(c, c.soff(V_QC), c.soff(V_PC), c.soff(V_GC), c.soff(V_PH1), c.soff(V_QA1), c.soff(V_PF1), 0.5 * eps, eps);
-    ClLeapPolicy lp{c.st, c.soff(V_QA1), c.soff(V_QB1), c.soff(V_PH1), c.soff(V_MINV), c.soff(V_SCR0), 0.5 * eps, eps, {0.0}};
-    const double lpv = cl_pass(c.M, c.CL, c.part, c.lds, c.cst, c.x, lp);
+    ClLeapPolicy lp{c.st, c.soff(V_QA1), c.soff(V_QB1), c.soff(V_PH1), c.soff(V_MINV), c.soff(V_SCR0), 0.5 * eps, eps, 0u, 0u, false, {0.0, 0.0, 0.0}};
+    const double lpv = cl_pass<CL_DW>(c.M, c.CL, c.part, c.lds, c.cst, c.x, lp);
     __syncthreads();
     if (tid == 0) {
       double h = 0.5 * lp.extra[0] - lpv;
@@ -1337,6 +1358,7 @@ __device__ __forceinline__ void cl_init_stepsize(ClChain &c, uint32_t iter) {
 }
 
 // adapt_diag_e_nuts::transition; the new sample is already the chain's point QC.
+template <int CL_DW>
 __device__ __forceinline__ void cl_adapt_after_transition(ClChain &c, uint32_t iter) {
   ltp ts = c.ts;
   gsc sc = c.sc;
@@ -1401,10 +1423,10 @@ __device__ __forceinline__ void cl_adapt_after_transition(ClChain &c, uint32_t i
   __syncthreads();
   if (end_window) {
     ClPlainPolicy pol{c.st, c.st, c.soff(V_QC), c.soff(V_GC), {0}};
-    const double lpq = cl_pass(c.M, c.CL, c.part, c.lds, c.cst, c.x, pol);
+    const double lpq = cl_pass<CL_DW>(c.M, c.CL, c.part, c.lds, c.cst, c.x, pol);
     if (tid == 0) sc->lp_cur = lpq;
     __syncthreads();
-    cl_init_stepsize(c, iter);
+    cl_init_stepsize<CL_DW>(c, iter);
     if (tid == 0) { sc->mu = log(10.0 * sc->nom_eps); sc->s_bar = 0; sc->x_bar = 0; sc->ad_counter = 0; }
     __syncthreads();
   }

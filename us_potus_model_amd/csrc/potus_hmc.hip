@@ -194,6 +194,7 @@ __device__ __forceinline__ ClChain make_clchain(CMp M, CCp CL, CRp R, int chain,
 }
 
 // Parity hook on one cluster (grid = K): q, grad in Stan order; scratch = [2][Dpad] in internal order.
+template <int CL_DW>
 __global__ __launch_bounds__(PT_THREADS) void k_cl_logprob_grad(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, const double *q,
                                                                 double *lp, double *grad, int n, double *scratch, unsigned launch) {
   CMp M = (CMp)Mg;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_logprob_grad(const DevModel *
     for (int i = c.e0 + c.tid; i < c.e1; i += PT_THREADS) bst_s(rs, 8u * i, 0, as_g(q)[(size_t)b * D + c.perm[i]]);
     cl_sync(c.x, c.red());
     ClPlainPolicy pol{rs, rs, 0u, (unsigned)Dpad * 8u, {0}};
-    const double v = cl_pass(M, CL, c.part, c.lds, c.cst, c.x, pol);
+    const double v = cl_pass<CL_DW>(M, CL, c.part, c.lds, c.cst, c.x, pol);
     drain_vmem();
     __syncthreads();
     for (int i = c.e0 + c.tid; i < c.e1; i += PT_THREADS) as_g(grad)[(size_t)b * D + c.perm[i]] = bld(rs, 8u * i, (unsigned)Dpad * 8u);
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_logprob_grad(const DevModel *
   }
 }
 
+template <int CL_DW>
 __global__ __launch_bounds__(PT_THREADS) void k_cl_init(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, const double *q0, unsigned launch) {
   CMp M = (CMp)Mg;
   CCp CL = (CCp)CLg;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_init(const DevModel *Mg, cons
     }
     cl_sync(c.x, c.red());
     ClPlainPolicy pol{c.st, c.st, sQ, sG, {0}};
-    const double lp = cl_pass(M, CL, c.part, c.lds, c.cst, c.x, pol);
+    const double lp = cl_pass<CL_DW>(M, CL, c.part, c.lds, c.cst, c.x, pol);
     drain_vmem();
     __syncthreads();
     double bad[1] = {0.0};
@@ -254,11 +256,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_init(const DevModel *Mg, cons
     if (q0) break;
   }
   if (!ok) { if (tid == 0) c.sc->status = POTUS_ERR_INIT; return; }   // every member takes this branch together
-  cl_init_stepsize(c, PT_ITER_PRE);
+  cl_init_stepsize<CL_DW>(c, PT_ITER_PRE);
   if (tid == 0 && R->num_warmup == 0) c.sc->nom_eps = exp(c.sc->x_bar);
 }
 
 // New sample -> chain position and draws array (Stan order); warmup adaptation.
+template <int CL_DW>
 __device__ __forceinline__ void cl_transition_end(ClChain &c, CRp R, int chain, int it) {
   ltp ts = c.ts;
   const int tid = c.tid;
@@ -288,12 +291,13 @@ __device__ __forceinline__ void cl_transition_end(ClChain &c, CRp R, int chain, 
     c.sc->lp_cur = ts->out_lp;
     if (save) c.sc->saved += 1;
   }
-  if (warm) cl_adapt_after_transition(c, (uint32_t)it);
+  if (warm) cl_adapt_after_transition<CL_DW>(c, (uint32_t)it);
   __syncthreads();
   if (tid == 0) c.sc->iter = it + 1;
   __syncthreads();
 }
 
+template <int CL_DW>
 __global__ __launch_bounds__(PT_THREADS) void k_cl_run(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, int n_iter, unsigned launch) {
   CMp M = (CMp)Mg;
   CCp CL = (CCp)CLg;
@@ -307,11 +311,11 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_run(const DevModel *Mg, const
     const int it = c.sc->iter;
     if (it >= total) break;
     CPROF_START(c);
-    cl_transition_begin(c, (uint32_t)it);
+    cl_transition_begin<CL_DW>(c, (uint32_t)it);
     CPROF_MARK(c, PF_INITCOPY);
-    cl_transition_tree(c, (uint32_t)it);
+    cl_transition_tree<CL_DW>(c, (uint32_t)it);
     CPROF_START(c);
-    cl_transition_end(c, R, chain, it);
+    cl_transition_end<CL_DW>(c, R, chain, it);
     CPROF_MARK(c, PF_SAVE);
   }
 #ifdef POTUS_PROF
@@ -515,7 +519,7 @@ struct Sampler {
   double warm_ms = 0, samp_ms = 0;
   std::vector<double> LB, LT, LW; // column-major host copies (transformed data)
   // cluster mode (K > 1)
-  int K = 1;
+  int K = 1, cl_dw = 8;
   unsigned launch_id = 0;   // tags the exchange words of each launch
   ClModel CL{};
   ClModel *dCL = nullptr;
@@ -742,6 +746,10 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   C.NR = 2 * S + P + (full ? M.M + M.Pop + 2 : 0);
   C.NREP = 2 * S + M.nmid;
   C.NDP = CL_MAXDAYS + 1;
+  // days per wave: 4 (at most 32 days per member) when that leaves room to balance the members by polls, else 8
+  const int DW = (T + K - 1) / K <= 3 * PT_NW ? 4 : 8;
+  const int maxdays = PT_NW * DW;
+  sp->cl_dw = DW;
   C.XW = (XP_P + C.NR + 7) & ~7;
   if (P > 65535 || M.M > 255 || M.Pop > 255) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode packs pollster/mode/population indices in 16/8/8 bits");
   if (C.NREP > 2 * PT_THREADS) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: %d small parameters (> %d)", C.NREP, 2 * PT_THREADS);
@@ -756,7 +764,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
     if (cut) cut->assign(1, 0);
     while (t < T) {
       int nd = 0, cost = 0;
-      while (t < T && nd < CL_MAXDAYS) {
+      while (t < T && nd < maxdays) {
         const int c1 = cw_day + cw_poll * (dp[t + 1] - dp[t]);
         if (nd > 0 && cost + c1 > B) break;
         cost += c1; nd++; t++;
@@ -769,7 +777,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   int lo = 1, hi = cw_day * T + cw_poll * Np;
   while (lo < hi) { const int mid = (lo + hi) / 2; if (groups_for(mid, nullptr) <= K) hi = mid; else lo = mid + 1; }
   std::vector<int> cut;
-  if (groups_for(lo, &cut) > K) return fail(POTUS_ERR_UNSUPPORTED, "T = %d days do not fit %d members of at most %d days", T, K, CL_MAXDAYS);
+  if (groups_for(lo, &cut) > K) return fail(POTUS_ERR_UNSUPPORTED, "T = %d days do not fit %d members of at most %d days", T, K, maxdays);
   while ((int)cut.size() < K + 1) cut.push_back(T);   // members without days still own a share of the small vectors
 
   std::vector<int> part((size_t)K * CP_N, 0), sched, perm(L.D, -1);
@@ -800,10 +808,10 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
         for (int wv = 0; wv < PT_NW; wv++) {
           int n = 0, polls = 0;
           const int start = tl;
-          while (tl < nd && n < CL_DW) {
+          while (tl < nd && n < DW) {
             const int c1 = dp[d0 + tl + 1] - dp[d0 + tl];
             // leave enough room in the remaining waves for the remaining days
-            if (n > 0 && polls + c1 > B && (nd - tl) <= (PT_NW - 1 - wv) * CL_DW) break;
+            if (n > 0 && polls + c1 > B && (nd - tl) <= (PT_NW - 1 - wv) * DW) break;
             polls += c1; n++; tl++;
           }
           if (commit) { wd0[wv] = start; wnd[wv] = n; }
@@ -815,9 +823,9 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
         int tl = 0, worst = 0;
         for (int wv = 0; wv < PT_NW; wv++) {
           int n = 0, polls = 0;
-          while (tl < nd && n < CL_DW) {
+          while (tl < nd && n < DW) {
             const int c1 = dp[d0 + tl + 1] - dp[d0 + tl];
-            if (n > 0 && polls + c1 > B && (nd - tl) <= (PT_NW - 1 - wv) * CL_DW) break;
+            if (n > 0 && polls + c1 > B && (nd - tl) <= (PT_NW - 1 - wv) * DW) break;
             polls += c1; n++; tl++;
           }
           worst = std::max(worst, polls);
@@ -940,9 +948,10 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   sp->allocs.push_back(pc);
   HIP_TRY(hipMemcpy(pc, &C, sizeof(ClModel), hipMemcpyHostToDevice));
   sp->dCL = (ClModel *)pc;
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cl_logprob_grad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cl_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cl_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
+  for (const void *f : {reinterpret_cast<const void *>(k_cl_logprob_grad<4>), reinterpret_cast<const void *>(k_cl_logprob_grad<8>),
+                        reinterpret_cast<const void *>(k_cl_init<4>), reinterpret_cast<const void *>(k_cl_init<8>),
+                        reinterpret_cast<const void *>(k_cl_run<4>), reinterpret_cast<const void *>(k_cl_run<8>)})
+    HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
   sp->K = K;
   return 0;
 }
@@ -1135,8 +1144,13 @@ int potus_log_prob_grad(int handle, const double *q, int n, double *lp, double *
   double *dscr = nullptr;
   if (sp->K > 1) {   // the cluster's own pass, on one cluster
     HIP_TRY(hipMalloc((void **)&dscr, 2 * (size_t)sp->R.Dpad * 8));
-    hipLaunchKernelGGL(k_cl_logprob_grad, dim3(sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
-                       (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq, dlp, dg, n, dscr, ++sp->launch_id);
+    const unsigned lid = ++sp->launch_id;
+    if (sp->cl_dw == 4)
+      hipLaunchKernelGGL(k_cl_logprob_grad<4>, dim3(sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
+                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq, dlp, dg, n, dscr, lid);
+    else
+      hipLaunchKernelGGL(k_cl_logprob_grad<8>, dim3(sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
+                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq, dlp, dg, n, dscr, lid);
   } else {
     const int grid = std::min(n, 1024);
     hipLaunchKernelGGL(k_logprob_grad, dim3(grid), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const double *)dq, dlp, dg, n);
@@ -1158,8 +1172,13 @@ int potus_init(int handle, const double *q0) {
   const size_t bytes = (size_t)sp->R.chains * sp->L.D * 8;
   if (q0) { HIP_TRY(hipMalloc((void **)&dq0, bytes)); HIP_TRY(hipMemcpyAsync(dq0, q0, bytes, hipMemcpyHostToDevice, sp->stream)); }
   if (sp->K > 1) {
-    hipLaunchKernelGGL(k_cl_init, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
-                       (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq0, ++sp->launch_id);
+    const unsigned lid = ++sp->launch_id;
+    if (sp->cl_dw == 4)
+      hipLaunchKernelGGL(k_cl_init<4>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
+                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq0, lid);
+    else
+      hipLaunchKernelGGL(k_cl_init<8>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
+                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq0, lid);
   } else
     hipLaunchKernelGGL(k_init, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, (const double *)dq0);
   HIP_TRY(hipGetLastError());
@@ -1184,8 +1203,15 @@ int potus_run(int handle, int n_iter) {
   int it0 = 0; potus_iterations_done(handle, &it0);
   HIP_TRY(hipEventRecord(sp->ev0, sp->stream));
   if (sp->K > 1)
-    hipLaunchKernelGGL(k_cl_run, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
-                       (const ClModel *)sp->dCL, (const RunParams *)sp->dR, n_iter, ++sp->launch_id);
+  {
+    const unsigned lid = ++sp->launch_id;
+    if (sp->cl_dw == 4)
+      hipLaunchKernelGGL(k_cl_run<4>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
+                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, n_iter, lid);
+    else
+      hipLaunchKernelGGL(k_cl_run<8>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
+                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, n_iter, lid);
+  }
   else
     hipLaunchKernelGGL(k_run, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, n_iter);
   HIP_TRY(hipGetLastError());
