@@ -52,7 +52,7 @@ struct ClModel {
   const int *rep_pos;       // [NREP] internal index of the small parameters every member reads: zT | zb | c,m,pop,mue,rho,ze
   const double *rep_scale;  // [NR] scale of owned slot r (sigma_c ... ; 1 for zT, zb)
   const int *perm;          // [D] internal index -> Stan index
-  int l_C, l_Lw, l_LT, l_LB, l_w, l_prior, l_pm, l_py, l_pN, l_pun, l_sub, l_tab, l_gev, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_pb, l_e, l_c1, l_c2, l_c3, l_gs, l_ge, l_P, l_scal, l_red, l_st, l_prof;
+  int l_C, l_Lw, l_LT, l_LB, l_w, l_prior, l_pm, l_py, l_pN, l_pun, l_sub, l_tab, l_ru, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_pb, l_e, l_c1, l_c2, l_c3, l_gs, l_ge, l_P, l_scal, l_red, l_st, l_prof;
   int lds_doubles;
 };
 typedef const ClModel AS_C *CCp;
@@ -199,9 +199,19 @@ __device__ __forceinline__ void cl_allreduce_wide(ldp part, int nv, ldp out, Xch
   __syncthreads();
   PROF_MARK(22);
   TSTAMP(10);
+  {
+    const bool ok = w == 0 && lane < nv;
+    double p8[PT_NW];
 #pragma unroll
-  for (int l0 = 0; l0 < CL_WIDE; l0 += 64) {
-    const int l = l0 + lane;
+    for (int i = 0; i < PT_NW; i++) p8[i] = part[(ok ? lane : 0) * PT_NW + i];
+    ISSUE_FENCE();
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < PT_NW; i++) s += p8[i];
+    xst(x, ok ? 16u * (unsigned)lane : PT_OOB, s);
+  }
+  if (nv > 64) {                                   // trees deeper than 10 doublings only
+    const int l = 64 + lane;
     const bool ok = w == 0 && l < nv;
     double s = 0.0;
 #pragma unroll
@@ -330,7 +340,7 @@ __device__ __forceinline__ ClStatic cl_load_static(CCp CL, cip part) {
 __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp lds) {
   ldp Lw = lds + CL->l_Lw;
   gcdp src = as_g(M->mat);
-  for (int i = threadIdx.x; i < M->SE * M->SP; i += PT_THREADS) Lw[i] = src[i];
+  for (int i = threadIdx.x; i < (M->SE + 1) * M->SP; i += PT_THREADS) Lw[i] = i < M->SE * M->SP ? src[i] : 0.0;   // + a zero row
   {
     // the two 51 x 51 factors of stan:77,85, row-major with the odd row stride SP
     ldp LT = lds + CL->l_LT, LB = lds + CL->l_LB;
@@ -403,7 +413,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   const int d0 = part[CP_D0], nd = part[CP_ND], p0 = part[CP_P0], np = part[CP_NP], e0 = part[CP_E0], r0 = part[CP_R0], nr = part[CP_NR];
   const int K = x.K, m = x.m;
   const int wd0 = __builtin_amdgcn_readfirstlane(cst.wd0), wnd = __builtin_amdgcn_readfirstlane(cst.wnd);
-  ldp C = lds + CL->l_C, Lw = lds + CL->l_Lw, X = lds + CL->l_X, Y = lds + CL->l_Y, r_lds = lds + CL->l_r;
+  ldp C = lds + CL->l_C, Lw = lds + CL->l_Lw, X = lds + CL->l_X, Y = lds + CL->l_Y, r_lds = lds + CL->l_r, ru_lds = lds + CL->l_ru;
   ldp s_rep = lds + CL->l_rep;
   ldp s_zT = s_rep, s_zb = s_rep + S, s_mid = s_rep + 2 * S;
   ldp s_bT = lds + CL->l_bT, s_pb = lds + CL->l_pb, s_e = lds + CL->l_e, s_c1 = lds + CL->l_c1, s_c2 = lds + CL->l_c2, s_c3 = lds + CL->l_c3;
@@ -430,7 +440,6 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     for (int i = tid; i < NR + 8; i += PT_THREADS) s_P[i] = 0.0;   // accumulators that this member's polls may not cover
     if (tid < SE) s_gs[tid] = 0.0;
     if (tid >= 64 && tid < 64 + CL_MAXDAYS) s_ge[tid - 64] = 0.0;
-    (lds + CL->l_gev)[tid] = 0.0;                  // [PT_NW][64] per-chunk day sums of unadjusted * residual
 #pragma unroll
     for (int u = 0; u < 2; u++) { const int j = tid + u * PT_THREADS; s_rep[j < NREP ? j : NREP] = pol.q_fin(qr[u]); }
     double run = 0.0;
@@ -589,7 +598,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     const double nb = dpp_scan_sum(ww * bT), npb = dpp_scan_sum(ww * pb);   // stan:79 and the national average of mu_b[:,T]
     if (lane == 63) { s_bT[S] = nb; s_pb[S] = npb; }
   }
-  if (tid == 0) r_lds[np] = 0.0;
+  if (tid == 0) { r_lds[np] = 0.0; ru_lds[np] = 0.0; }
   __syncthreads();
   PROF_MARK(2);
   TSTAMP(3);
@@ -620,15 +629,24 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         const int t = d0 + tl;
         ldp L0 = Lw + s * SP, C0 = C + tl;
         double a0 = 0.0, a1 = 0.0;
-        for (int k0 = 0; k0 < S; k0 += 16) {             // 51-term dot, sixteen terms in flight
+        int k0 = 0;
+        for (; k0 + 16 <= S; k0 += 16) {                 // 51-term dot, sixteen terms in flight
+          double l[16], c[16];
+#pragma unroll
+          for (int j = 0; j < 16; j++) { l[j] = L0[k0 + j]; c[j] = C0[(k0 + j) * NDP]; }
+          ISSUE_FENCE();
+#pragma unroll
+          for (int j = 0; j < 16; j += 2) { a0 += l[j] * c[j]; a1 += l[j + 1] * c[j + 1]; }
+        }
+        if (k0 < S) {                                    // remainder: clamped reads, masked products
           double l[16], c[16];
 #pragma unroll
           for (int j = 0; j < 16; j++) { const int kk = min(k0 + j, S - 1); l[j] = L0[kk]; c[j] = C0[kk * NDP]; }
           ISSUE_FENCE();
 #pragma unroll
           for (int j = 0; j < 16; j += 2) {
-            a0 += (k0 + j < S ? 1.0 : 0.0) * l[j] * c[j];
-            a1 += (k0 + j + 1 < S ? 1.0 : 0.0) * l[j + 1] * c[j + 1];
+            a0 += (k0 + j < S ? l[j] : 0.0) * c[j];
+            a1 += (k0 + j + 1 < S ? l[j + 1] : 0.0) * c[j + 1];
           }
         }
         const double dot = a0 + a1;
@@ -641,6 +659,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         const double r = y - N * pr;
         lp += y * (fmin(eta, 0.0) - l1) + (N - y) * (fmin(-eta, 0.0) - l1) - 0.5 * zn * zn; // stan:126-127,130-131 (zn = 0 on idle lanes)
         r_lds[ok ? il : np + 1] = r;                     // slot np stays 0 (padding of the task lists), np+1 is a dump
+        ru_lds[ok ? il : np + 1] = r * un;               // feeds the day sums of the AR(1) adjoint
         gval = sg * r - zn;
       }
       pol.g_fin(vq, gval, zn, gt);
@@ -658,58 +677,49 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // of the days pick them up in phase E.  Level-1 segment sums follow.
   {
     const unsigned AS_L *tab = (const unsigned AS_L *)(lds + CL->l_tab);
-    ldp pun = lds + CL->l_pun, gev = lds + CL->l_gev;
     const int lk = lane < S ? lane : 0;
-    const bool l63 = lane == 63;
     const int ca = __builtin_amdgcn_readfirstlane(cst.ca), cb = __builtin_amdgcn_readfirstlane(cst.cb);
     double acc = 0.0;
     for (int base = ca; base < cb; base += 64) {
       const int mine = base + lane < cb ? base + lane : np;   // slot np: program word 0, residual 0
       const unsigned ev = tab[mine];
-      const double rv = r_lds[mine], uv = pun[mine];
+      const double rv = r_lds[mine];
       const int cnt = min(64, cb - base);
       for (int p0 = 0; p0 < cnt; p0 += 8) {
         unsigned e8[8];
-        double r8[8], u8[8], l8[8];
+        double r8[8], l8[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
           const int pu = p0 + u;                    // < 64; lanes beyond the chunk hold the zero slot
           e8[u] = (unsigned)__builtin_amdgcn_readlane((int)ev, pu);
           r8[u] = readlane_d(rv, pu);
-          u8[u] = readlane_d(uv, pu);
-          l8[u] = Lw[(int)(e8[u] & 0xffu) * SP + lk];
+          l8[u] = Lw[(int)(e8[u] & 0xffu) * SP + lk];   // polls of day T point at the zero row (stan:86: they feed mu_b_T only)
         }
         ISSUE_FENCE();
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-          const double mult = l63 ? u8[u] : ((e8[u] & 0x20000u) ? 0.0 : l8[u]);   // flag 2: polls of day T feed mu_b_T only (stan:86)
-          acc += r8[u] * mult;
-          if (e8[u] & 0x10000u) {                   // flag 1: last poll of its day (wave-uniform)
-            const int tl = (int)((e8[u] >> 8) & 0xffu);
-            if (lane < S) C[lane * NDP + tl] = acc;
-            else if (l63) { gev[w * 64 + tl] = acc; acc = 0.0; }
+          acc += r8[u] * l8[u];
+          if (e8[u] & 0x10000u) {                   // last poll of its day (wave-uniform): running sum to LDS
+            if (lane < S) C[lane * NDP + (int)((e8[u] >> 8) & 0xffu)] = acc;
           }
         }
       }
     }
     if (lane < S) X[w * SE + lane] = acc;          // chunk total
-    if (cb > ca) {
-      const unsigned le = tab[cb - 1];              // a day cut by the chunk boundary: lane 63 leaves its part
-      if (l63 && !(le & 0x10000u)) gev[w * 64 + (int)((le >> 8) & 0xffu)] = acc;
-    }
   }
   {
-    const int nsub = part[CP_NSUB];
+    const int nsub = part[CP_NSUB], wb = part[CP_WB];   // tasks from wb on sum unadjusted * residual (day sums)
     const u32x4 AS_L *sb = (const u32x4 AS_L *)(lds + CL->l_sub);
     for (int sub0 = 0; sub0 < nsub; sub0 += PT_THREADS) {
       const int sub = sub0 + tid;
       const bool ok = sub < nsub;
       const u32x4 ia = sb[ok ? 2 * sub : 0], ib = sb[ok ? 2 * sub + 1 : 0];
       double rr[PT_SUBLEN];
+      ldp rsrc_ = sub >= wb ? ru_lds : r_lds;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        rr[2 * j] = r_lds[ok ? (int)(ia[j] & 0xffffu) : np]; rr[2 * j + 1] = r_lds[ok ? (int)(ia[j] >> 16) : np];
-        rr[8 + 2 * j] = r_lds[ok ? (int)(ib[j] & 0xffffu) : np]; rr[9 + 2 * j] = r_lds[ok ? (int)(ib[j] >> 16) : np];
+        rr[2 * j] = rsrc_[ok ? (int)(ia[j] & 0xffffu) : np]; rr[2 * j + 1] = rsrc_[ok ? (int)(ia[j] >> 16) : np];
+        rr[8 + 2 * j] = rsrc_[ok ? (int)(ib[j] & 0xffffu) : np]; rr[9 + 2 * j] = rsrc_[ok ? (int)(ib[j] >> 16) : np];
       }
       ISSUE_FENCE();
       double sum = 0.0;
@@ -747,17 +757,6 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       for (int c = 1; c < PT_NW; c++) cc = ch[j] == c ? cpre[c] : cc;
       pre[j] = tlast[j] >= 0 ? cv[j] + cc : 0.0;
     }
-    if (tid >= 64 && tid < 64 + CL_MAXDAYS) {       // day sums of unadjusted * residual: add the chunks' parts
-      ldp gev = lds + CL->l_gev;
-      double g[PT_NW];
-#pragma unroll
-      for (int c = 0; c < PT_NW; c++) g[c] = gev[c * 64 + tid - 64];
-      ISSUE_FENCE();
-      double sum = 0.0;
-#pragma unroll
-      for (int c = 0; c < PT_NW; c++) sum += g[c];
-      s_ge[tid - 64] = sum;
-    }
   }
   {
     double sum = 0.0;
@@ -772,6 +771,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     }
     if (sg_kind == 0) s_P[sg_index] = sum;          // pollster / mode / population partial (slot index)
     else if (sg_kind == 1) s_gs[sg_index] = sum;    // residual sum of (pseudo-)state
+    else if (sg_kind == 2) s_ge[sg_index] = sum;    // sum of unadjusted * residual over a local day
   }
   __syncthreads();
   PROF_MARK(5);

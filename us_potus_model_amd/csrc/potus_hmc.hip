@@ -844,7 +844,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
     for (int il = 0; il < np; il++) {
       const int g = p0 + il, tl = sp->h_pt[g] - d0;
       const bool dayend = il == np - 1 || sp->h_pt[g + 1] != sp->h_pt[g];
-      tab[il] = sp->h_ps[g] | (tl << 8) | ((dayend ? 1 : 0) << 16) | ((sp->h_pt[g] == T - 1 ? 2 : 0) << 16);
+      tab[il] = (sp->h_pt[g] == T - 1 ? M.SE : sp->h_ps[g]) | (tl << 8) | ((dayend ? 1 : 0) << 16);   // day T: the zero row
     }
     for (int wv = 0; wv < PT_NW; wv++)
       for (int j = 0; j < wnd[wv]; j++) {
@@ -884,7 +884,8 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
       add_group(M.Pop, 0, 2 * S + P + M.M, false, [&](int i) { return sp->h_ppop[i]; });
     }
     add_group(S + 1, 1, 0, false, [&](int i) { return sp->h_ps[i]; });
-    const int wb = nsub;   // (day sums of unadjusted * residual come out of the per-day gathers)
+    const int wb = nsub;   // tasks from here on sum unadjusted * residual
+    if (full) add_group(nd, 2, 0, false, [&](int i) { return sp->h_pt[i] - d0; });
     seg_ptr.push_back(nsub);
     if ((int)seg_kind.size() > PT_THREADS) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: member %d has %zu segments (> %d)", m, seg_kind.size(), PT_THREADS);
     pt_[CP_NSUB] = nsub; pt_[CP_NSEG] = (int)seg_kind.size(); pt_[CP_WB] = wb;
@@ -921,11 +922,11 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   int o = 0;
   auto take = [&](int n) { const int a = o; o += (n + 1) & ~1; return a; };
   C.l_C = take(std::max(S * C.NDP, 12 * M.SE));
-  C.l_Lw = take(M.SE * M.SP);
+  C.l_Lw = take((M.SE + 1) * M.SP);
   C.l_LT = take(S * M.SP); C.l_LB = take(S * M.SP); C.l_w = take(M.SE); C.l_prior = take(M.SE);
   C.l_pm = take(npmax + 8); C.l_py = take(npmax + 8); C.l_pN = take(npmax + 8); C.l_pun = take(npmax + 8);
   C.l_sub = take(nsubmax * 4 + 4);
-  C.l_tab = take((npmax + 64) / 2 + 2); C.l_gev = take(PT_NW * 64);
+  C.l_tab = take((npmax + 64) / 2 + 2); C.l_ru = take(npmax + 2);
   C.l_wide = take(CL_WIDE * PT_NW); C.l_wout = take(CL_WIDE);
   C.l_X = take(12 * M.SE);
   C.l_Y = take(std::max(PT_NW * M.SE, nsubmax));
