@@ -94,12 +94,14 @@ struct Xch {
   rsrc_t xb;               // the chain's exchange buffer [4][K][XW] words of 16 bytes
   unsigned epoch;          // exchanges published so far in this launch (identical in every member)
   unsigned launch;         // launch id (host counter): stale words of earlier launches never match
+  unsigned x1e;            // number of an X1 published ahead for the next pass (0 = none), see cl_pass_partial
   int K, m, XW;
 };
 // byte offset of member mm's payload: w = the exchange being assembled (number epoch+1), r = the one
 // just published (call after epoch++)
 __device__ __forceinline__ unsigned xch_wslot(const Xch &x, int mm) { return ((((x.epoch + 1u) & 3u) * (unsigned)x.K + (unsigned)mm) * (unsigned)x.XW) * 16u; }
 __device__ __forceinline__ unsigned xch_rslot(const Xch &x, int mm) { return (((x.epoch & 3u) * (unsigned)x.K + (unsigned)mm) * (unsigned)x.XW) * 16u; }
+__device__ __forceinline__ unsigned xch_eslot(const Xch &x, unsigned e, int mm) { return (((e & 3u) * (unsigned)x.K + (unsigned)mm) * (unsigned)x.XW) * 16u; }
 // publish one word of the exchange being assembled (voff = 16 * word, or PT_OOB for idle lanes)
 __device__ __forceinline__ void xst(const Xch &x, unsigned voff, double v) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -109,7 +111,9 @@ __device__ __forceinline__ void xst(const Xch &x, unsigned voff, double v) {
 // fetch NB words of the exchange just published (per-lane byte offsets vo, PT_OOB = idle lane -> 0;
 // uniform slot offsets so); spins until every tag of the wave matches
 template <int NB>
-__device__ __forceinline__ void xld(const Xch &x, const unsigned (&vo)[NB], const unsigned (&so)[NB], double (&out)[NB]) {
+__device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], const unsigned (&so)[NB], double (&out)[NB], unsigned tag = 0) {
+  Xch x = x_in;
+  if (tag) x.epoch = tag;                          // an exchange other than the latest one
   u32x4 w[NB];
   bool done[NB];                                   // wave-uniform
 #pragma unroll
@@ -258,8 +262,8 @@ struct ClPlainPolicy {
   __device__ __forceinline__ void qs_load(unsigned vo, QT &t) { t.q = bld_s(rq, vo, sq); }   // written by another member
   __device__ __forceinline__ double q_fin(QT &t) { return t.q; }
   __device__ __forceinline__ void g_load(unsigned, GT &) {}
-  __device__ __forceinline__ void g_fin(unsigned vo, double v, double, const GT &) { bst(rg, vo, sg, v); }
-  __device__ __forceinline__ void gs_fin(unsigned vo, double v, double, const GT &) { bst(rg, vo, sg, v); }
+  __device__ __forceinline__ double g_fin(unsigned vo, double v, double q, const GT &) { bst(rg, vo, sg, v); return q; }
+  __device__ __forceinline__ double gs_fin(unsigned vo, double v, double q, const GT &) { bst(rg, vo, sg, v); return q; }
 };
 // Pre-kicked leapfrog (LeapPolicy of potus_nuts.hpp); positions that other members read next pass
 // (the small vectors, raw_e_bias) are stored write-through.
@@ -285,21 +289,23 @@ struct ClLeapPolicy {
     t.pp = bld(r, fuse1 ? vo : PT_OOB, sPrev);
   }
   template <bool SHARED>
-  __device__ __forceinline__ void fin(unsigned vo, double v, double q, const GT &t) {
+  __device__ __forceinline__ double fin(unsigned vo, double v, double q, const GT &t) {   // returns the next position
     const double pf = t.p + he * v;
     bst(r, vo, sL, pf);
     const double ph = pf + he * v;
     bst(r, vo, sPH, ph);
-    if (SHARED) bst_s(r, vo, sQn, q + e * t.m * ph);
-    else bst(r, vo, sQn, q + e * t.m * ph);
+    const double qn = q + e * t.m * ph;
+    if (SHARED) bst_s(r, vo, sQn, qn);
+    else bst(r, vo, sQn, qn);
     const double rs = t.pp + pf;
     bst(r, fuse1 ? vo : PT_OOB, sOut1, rs);
     extra[0] += t.m * pf * pf;                    // masked-off elements loaded m = 0
     extra[1] += t.m * t.pp * rs;
     extra[2] += t.m * pf * rs;
+    return qn;
   }
-  __device__ __forceinline__ void g_fin(unsigned vo, double v, double q, const GT &t) { fin<false>(vo, v, q, t); }
-  __device__ __forceinline__ void gs_fin(unsigned vo, double v, double q, const GT &t) { fin<true>(vo, v, q, t); }
+  __device__ __forceinline__ double g_fin(unsigned vo, double v, double q, const GT &t) { return fin<false>(vo, v, q, t); }
+  __device__ __forceinline__ double gs_fin(unsigned vo, double v, double q, const GT &t) { return fin<true>(vo, v, q, t); }
 };
 
 struct ClStatic {           // per-thread registers that never change during a kernel
@@ -398,8 +404,12 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
 // cl_pass_partial returns THIS THREAD's share of lp (and leaves the thread's share of pol.extra[] in
 // pol_io); the caller reduces them over the cluster (cl_pass below, or together with the U-turn dot
 // products of the leaf in cl_transition_tree).
+// pubnext: the position this pass writes is the one the next pass evaluates (consecutive leaves of a subtree),
+// so the suffix totals of that position (exchange X1 of the NEXT pass) are published here, as soon as the
+// epilogue has produced it; the next pass then finds x.x1e set and does not wait for its X1 at all.
 template <int CL_DW, class Pol>
-__device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_in, ldp lds, const ClStatic &cst, Xch &x, Pol &pol_io) {
+__device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_in, ldp lds, const ClStatic &cst, Xch &x, Pol &pol_io,
+                                                  bool pubnext = false) {
   Pol pol = pol_io;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
@@ -464,15 +474,18 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     double tot = 0.0;
 #pragma unroll
     for (int w2 = 0; w2 < PT_NW; w2++) tot += Y[w2 * SE + (lane < S ? lane : S)];
-    xst(x, (w == 0 && lane < S) ? 16u * (unsigned)lane : PT_OOB, tot);   // no branch around the store
+    xst(x, (w == 0 && lane < S && x.x1e == 0) ? 16u * (unsigned)lane : PT_OOB, tot);   // no branch around the store
   }
-  x.epoch++;                                      // X1 is on its way; the consumers below spin on its tags
+  x.epoch += x.x1e == 0 ? 1u : 0u;                // X1 is on its way (or was sent by the previous pass)
+  const unsigned x1tag = x.x1e ? x.x1e : x.epoch;
+  x.x1e = 0;
   if (w == 1) {
     if (full) {
-      // e_bias (stan:91-93): d[t] = e[t]-mu_e = rho d[t-1] + sigma_rho z[t], plus the three tangent
-      // recurrences that turn the adjoint sums of mu_e_bias / rho_e_bias into per-day dot products:
-      //   c1[t] = rho c1[t-1] + 1, c2[t] = rho c2[t-1] + d[t-1], c3[t] = rho c3[t-1] + z[t]   (c.[0] = 0)
-      // Each lane owns four consecutive days (T <= 256); affine scans across lanes on the DPP path.
+      // e_bias (stan:91-93): d[t] = e[t]-mu_e = rho d[t-1] + sigma_rho z[t].  Each lane owns four consecutive
+      // days (T <= 256); affine scan across lanes on the DPP path.  The three tangent recurrences that turn the
+      // adjoint sums of mu_e_bias / rho_e_bias into per-day dot products,
+      //   c1[t] = rho c1[t-1] + 1, c2[t] = rho c2[t-1] + d[t-1], c3[t] = rho c3[t-1] + z[t]   (c.[0] = 0),
+      // are only needed in phase E2 and run in phase C on an idle wave.
       const double sigma_e = M->sigma_e;
       ldp ze = s_mid + (M->o_ze - o_c);
       const double xm = s_mid[M->o_mue - o_c], xr = s_mid[M->o_rho - o_c];
@@ -493,35 +506,14 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         A = in ? An : A; Bd[0] = in ? Bn : Bd[0];
       }
       dpp_scan_affine(A, Bd);
-      const double d_in = dpp_prev_lane(Bd[0], 0.0);
-      double A2 = 1.0, Bc[3] = {0.0, 0.0, 0.0}, d = d_in, dp[PER];
+      double d = dpp_prev_lane(Bd[0], 0.0);
 #pragma unroll
       for (int u = 0; u < PER; u++) {
         const int t = ta + u;
-        const bool in = t < T, first = t == 0;
-        dp[u] = d;
-        d = first ? z[u] * sigma_e - mue : rho * d + srho * z[u];
-        if (in) s_e[t] = d + mue;
-        const double An = first ? 0.0 : rho * A2;
-        const double B1 = first ? 0.0 : rho * Bc[0] + 1.0, B2 = first ? 0.0 : rho * Bc[1] + dp[u], B3 = first ? 0.0 : rho * Bc[2] + z[u];
-        A2 = in ? An : A2; Bc[0] = in ? B1 : Bc[0]; Bc[1] = in ? B2 : Bc[1]; Bc[2] = in ? B3 : Bc[2];
+        d = t == 0 ? z[u] * sigma_e - mue : rho * d + srho * z[u];
+        if (t < T) s_e[t] = d + mue;
       }
-      dpp_scan_affine(A2, Bc);
-      double c1 = dpp_prev_lane(Bc[0], 0.0), c2 = dpp_prev_lane(Bc[1], 0.0), c3 = dpp_prev_lane(Bc[2], 0.0);
-#pragma unroll
-      for (int u = 0; u < PER; u++) {
-        const int t = ta + u;
-        const bool first = t == 0;
-        c1 = first ? 0.0 : rho * c1 + 1.0; c2 = first ? 0.0 : rho * c2 + dp[u]; c3 = first ? 0.0 : rho * c3 + z[u];
-        if (t < T) { s_c1[t] = c1; s_c2[t] = c2; s_c3[t] = c3; }
-      }
-      if (lane == 0) {
-        s_scal[SC_MUE] = mue; s_scal[SC_RHO] = rho; s_scal[SC_SRHO] = srho; s_scal[SC_XMUE] = xm; s_scal[SC_XRHO] = xr;
-        // what the owner of rho_e_bias needs in phase F, computed here where the wave has slack:
-        // Jacobian + prior of rho (stan:63,124) and d sigma_rho / d rho
-        s_scal[SC_LPRHO] = log(rho) + log1p(-rho) - 0.5 * ((rho - 0.7) / 0.1) * ((rho - 0.7) / 0.1);
-        s_scal[SC_DSRHO] = sigma_e * (-rho / sqrt(1.0 - rho * rho));
-      }
+      if (lane == 0) { s_scal[SC_MUE] = mue; s_scal[SC_RHO] = rho; s_scal[SC_SRHO] = srho; s_scal[SC_XMUE] = xm; s_scal[SC_XRHO] = xr; }
     }
   } else if (w >= 2) {
     // partial products of the two 51 x 51 factors: wave w-2 takes columns k = w-2, w+4, ...
@@ -557,9 +549,9 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       for (int u = 0; u < 16; u++) {
         const int mm = mm0 + u;
         vo[u] = (mm < K && lane < S) ? 16u * (unsigned)lane : PT_OOB;
-        so[u] = xch_rslot(x, mm < K ? mm : 0);
+        so[u] = xch_eslot(x, x1tag, mm < K ? mm : 0);
       }
-      xld(x, vo, so, t16);
+      xld(x, vo, so, t16, x1tag);
 #pragma unroll
       for (int u = 0; u < 16; u++) carry_m += t16[u];
     }
@@ -611,6 +603,41 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     const double sigma_c = M->sigma_c, sigma_m = M->sigma_m, sigma_pop = M->sigma_pop, sigma_ns = M->sigma_ns, sigma_nn = M->sigma_nn;
     const unsigned long long AS_L *pm = (const unsigned long long AS_L *)(lds + CL->l_pm);
     ldp py = lds + CL->l_py, pN = lds + CL->l_pN, pun = lds + CL->l_pun;
+    if (full && w == PT_NW - 1) {
+      // the three tangent recurrences of the AR(1) bias (needed in phase E2 only) run here, on the wave that
+      // has no polls unless the member has more than 448 of them, instead of lengthening phase B
+      const double rho = s_scal[SC_RHO], mue = s_scal[SC_MUE], sigma_e = M->sigma_e;
+      ldp ze = s_mid + (M->o_ze - o_c);
+      constexpr int PER = 4;
+      const int ta = lane * PER;
+      double z[PER], dp[PER];
+#pragma unroll
+      for (int u = 0; u < PER; u++) { const int t = ta + u; z[u] = ze[min(t, T - 1)]; dp[u] = s_e[min(max(t - 1, 0), T - 1)] - mue; }
+      ISSUE_FENCE();
+      double A2 = 1.0, Bc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < PER; u++) {
+        const int t = ta + u;
+        const bool in = t < T, first = t == 0;
+        const double An = first ? 0.0 : rho * A2;
+        const double B1 = first ? 0.0 : rho * Bc[0] + 1.0, B2 = first ? 0.0 : rho * Bc[1] + dp[u], B3 = first ? 0.0 : rho * Bc[2] + z[u];
+        A2 = in ? An : A2; Bc[0] = in ? B1 : Bc[0]; Bc[1] = in ? B2 : Bc[1]; Bc[2] = in ? B3 : Bc[2];
+      }
+      dpp_scan_affine(A2, Bc);
+      double c1 = dpp_prev_lane(Bc[0], 0.0), c2 = dpp_prev_lane(Bc[1], 0.0), c3 = dpp_prev_lane(Bc[2], 0.0);
+#pragma unroll
+      for (int u = 0; u < PER; u++) {
+        const int t = ta + u;
+        const bool first = t == 0;
+        c1 = first ? 0.0 : rho * c1 + 1.0; c2 = first ? 0.0 : rho * c2 + dp[u]; c3 = first ? 0.0 : rho * c3 + z[u];
+        if (t < T) { s_c1[t] = c1; s_c2[t] = c2; s_c3[t] = c3; }
+      }
+      if (lane == 0) {
+        // what the owner of rho_e_bias needs in phase F: Jacobian + prior of rho (stan:63,124), d sigma_rho / d rho
+        s_scal[SC_LPRHO] = log(rho) + log1p(-rho) - 0.5 * ((rho - 0.7) / 0.1) * ((rho - 0.7) / 0.1);
+        s_scal[SC_DSRHO] = sigma_e * (-rho / sqrt(1.0 - rho * rho));
+      }
+    }
     for (int i0 = 0; i0 < np; i0 += PT_THREADS) {        // one trip unless a member has more than 512 polls
       const int il = i0 + tid;
       const bool ok = il < np;
@@ -943,11 +970,25 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   __syncthreads();
   {
     const double carry = lane < S ? X[PT_NW * SE + lane] : 0.0;   // pre[] is already the prefix within the member
+    double nrun = 0.0;                              // suffix total of the next position over the wave's days
 #pragma unroll
     for (int j = 0; j < CL_DW; j++) {
       const int t = d0 + wd0 + j;
-      pol.g_fin(voz[j], (t < T - 1 ? pre[j] + carry : 0.0) - zq[j], zq[j], gz[j]);
+      const double qn = pol.g_fin(voz[j], (t < T - 1 ? pre[j] + carry : 0.0) - zq[j], zq[j], gz[j]);
+      nrun += (j < wnd && t < T - 1) ? qn : 0.0;
     }
+    if (pubnext) {                                  // wave-uniform; LDS and a barrier only, the store stays outside
+      if (lane < S) Y[w * SE + lane] = nrun;
+      __syncthreads();
+    }
+  }
+  {
+    double tot = 0.0;
+#pragma unroll
+    for (int w2 = 0; w2 < PT_NW; w2++) tot += Y[w2 * SE + (lane < S ? lane : S)];
+    xst(x, (pubnext && w == 0 && lane < S) ? 16u * (unsigned)lane : PT_OOB, tot);
+    x.epoch += pubnext ? 1u : 0u;
+    x.x1e = pubnext ? x.epoch : 0u;
   }
   PROF_MARK(18);
   TSTAMP(9);
@@ -1206,7 +1247,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
         if (j <= m) ts->u_sub[j] = rng_uniform(c.key, iter, RNG_SUB_ACCEPT, 0, ((uint32_t)depth << 24) | ((uint32_t)j << 16) | (uint32_t)(n >> j));
         if (j == 64 && top) ts->u_top = rng_uniform(c.key, iter, RNG_TOP_ACCEPT, 0, (uint32_t)depth);
       }
-      const double lpp = cl_pass_partial<CL_DW>(c.M, c.CL, c.part, c.lds, c.cst, c.x, lp);
+      const double lpp = cl_pass_partial<CL_DW>(c.M, c.CL, c.part, c.lds, c.cst, c.x, lp, n < nleaf - 1);
       CPROF_START(c);
       CPROF_COUNT(c, PF_LEAVES);
       // One all-reduce per leaf: log density, kinetic energy and the six dot products of every U-turn check
@@ -1305,7 +1346,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
       }
       __syncthreads();
       CPROF_MARK(c, PF_LEAF_SCALAR);
-      if (ts->abort) { valid = false; break; }
+      if (ts->abort) { valid = false; c.x.x1e = 0; break; }   // an X1 sent ahead is simply never read
       if (ts->copy_q_id >= 0) cl_vop_copy<false>(c, c.soff(V_POOLQ + ts->copy_q_id), c.soff((sel ? V_QB0 : V_QA0) + dir));
       if (top) cl_vop_copy<false>(c, c.soff(V_PF0 + dir), c.soff(V_POOLP + leaf));   // the last leaf is the new end point
       CPROF_MARK(c, PF_COPYQ);

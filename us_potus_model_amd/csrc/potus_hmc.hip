@@ -182,7 +182,7 @@ __device__ __forceinline__ ClChain make_clchain(CMp M, CCp CL, CRp R, int chain,
   c.key = RngKey{R->seed_lo, R->seed_hi, (uint32_t)(R->chain_id_offset + chain + 1)};
   c.perm = as_g(CL->perm);
   c.x.xb = make_rsrc(R->xbuf + (size_t)chain * 8 * K * CL->XW, 4u * (unsigned)K * (unsigned)CL->XW * 16u);
-  c.x.epoch = 0; c.x.launch = launch; c.x.K = K; c.x.m = m; c.x.XW = CL->XW;
+  c.x.epoch = 0; c.x.launch = launch; c.x.x1e = 0; c.x.K = K; c.x.m = m; c.x.XW = CL->XW;
   c.D = M->D; c.Dpad = Dpad; c.tid = (int)threadIdx.x;
   c.e0 = c.part[CP_E0]; c.e1 = c.e0 + c.part[CP_NE];
   c.max_depth = R->max_depth; c.num_warmup = R->num_warmup; c.init_buffer = R->init_buffer; c.term_buffer = R->term_buffer;
