@@ -6,7 +6,7 @@ from (a) the reference's own CSV data through us_potus_model_amd.dataprep and (b
 oracle in oracle/ -- cross-checked here against torch-fp64 autograd of the independent
 transcription in tests/stan_transcription.py before anything is written.
 
-  python scripts/make_golden.py data        # tests/golden/data_2016.npz   (needs /root/reference)
+  python scripts/make_golden.py data        # tests/golden/data_{2016,2012,2008}.npz   (needs /root/reference)
   python scripts/make_golden.py logprob     # tests/golden/logprob_*.npz
   python scripts/make_golden.py posterior   # tests/golden/posterior_2016.npz (minutes, 8 processes)
 """
@@ -28,6 +28,8 @@ from us_potus_model_amd import _abi, dataprep, synthetic  # noqa: E402
 def cases():
     return {
         "2016": (dataprep.load_npz(GOLD / "data_2016.npz")["data"], "full"),
+        "2012": (dataprep.load_npz(GOLD / "data_2012.npz")["data"], "no_mode_adjustment"),
+        "2008": (dataprep.load_npz(GOLD / "data_2008.npz")["data"], "no_mode_adjustment"),
         "small_full": (synthetic.small("full"), "full"),
         "small_nomode": (synthetic.small("no_mode_adjustment"), "no_mode_adjustment"),
     }
@@ -38,6 +40,11 @@ def make_data():
     dataprep.save_npz(GOLD / "data_2016.npz", built)
     d = built["data"]
     print("data_2016:", {k: d[k] for k in ("N_state_polls", "N_national_polls", "T", "P", "M", "Pop")})
+    for year in (2012, 2008):   # the backtests that run the no-mode model (final_2012.R:558, final_2008.R:562)
+        built = dataprep.build_backtest("/root/reference/data", year)
+        dataprep.save_npz(GOLD / f"data_{year}.npz", built)
+        d = built["data"]
+        print(f"data_{year}:", {k: d[k] for k in ("N_state_polls", "N_national_polls", "T", "P", "M", "Pop")})
 
 
 def make_logprob():

@@ -38,9 +38,11 @@ def data_2016():
 
 @pytest.fixture(scope="session")
 def cases(data_2016):
-    from us_potus_model_amd import synthetic
+    from us_potus_model_amd import dataprep, synthetic
     return {
         "2016": (data_2016, "full"),
+        "2012": (dataprep.load_npz(GOLD / "data_2012.npz")["data"], "no_mode_adjustment"),
+        "2008": (dataprep.load_npz(GOLD / "data_2008.npz")["data"], "no_mode_adjustment"),
         "small_full": (synthetic.small("full"), "full"),
         "small_nomode": (synthetic.small("no_mode_adjustment"), "no_mode_adjustment"),
     }

@@ -26,7 +26,7 @@ CUS = [1, 8, 16]
 
 
 @pytest.mark.parametrize("cus", CUS)
-@pytest.mark.parametrize("name", ["small_full", "small_nomode", "2016"])
+@pytest.mark.parametrize("name", ["small_full", "small_nomode", "2016", "2012", "2008"])
 def test_log_prob_grad_matches_oracle_and_golden(cases, name, cus):
     data, variant = cases[name]
     h = Handle(data, variant, chains=1, cus_per_chain=cus)
@@ -57,7 +57,7 @@ def test_log_prob_grad_is_deterministic_and_batched(cases, cus):
 
 
 @pytest.mark.parametrize("cus", CUS)
-@pytest.mark.parametrize("name,iters", [("small_full", 8), ("small_nomode", 8), ("2016", 3)])
+@pytest.mark.parametrize("name,iters", [("small_full", 8), ("small_nomode", 8), ("2016", 3), ("2012", 3), ("2008", 3)])
 def test_nuts_follows_the_oracle_chain(cases, name, iters, cus):
     """Same Philox streams + same algorithm => the first transitions agree to rounding."""
     data, variant = cases[name]

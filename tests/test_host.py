@@ -31,6 +31,33 @@ def test_data_2016_fixture(data_2016):
     assert 0.49 < nat < 0.53
 
 
+@pytest.mark.parametrize("year,sizes", [(2012, (966, 191, 251, 160)), (2008, (960, 251, 247, 90))])
+def test_backtest_fixtures(cases, year, sizes):
+    """2012 / 2008 backtests (final_2012.R:63-556, final_2008.R:63-560): sizes as re-derived in SURVEY.md section 8
+    (T: the scripts index 250 / 247 at final_2012.R:582, final_2008.R:586); they run the no-mode model."""
+    d, variant = cases[str(year)]
+    assert variant == "no_mode_adjustment"
+    assert (d["N_state_polls"], d["N_national_polls"], d["T"], d["P"]) == sizes and d["S"] == 51
+    assert 1 <= d["state"].min() and d["state"].max() <= 51
+    assert d["day_state"].max() <= d["T"] and d["day_national"].max() <= d["T"] and min(d["day_state"].min(), d["day_national"].min()) == 1
+    assert d["poll_state"].max() <= d["P"] and d["poll_national"].max() <= d["P"]
+    assert abs(d["state_weights"].sum() - 1) < 1e-12 and "sigma_a" in d          # the unused entry Stan ignores
+    assert (d["n_democrat_state"] <= d["n_two_share_state"]).all() and (d["n_democrat_national"] <= d["n_two_share_national"]).all()
+    assert set(np.unique(d["unadjusted_state"])) <= {0.0, 1.0}
+    assert d["mu_b_T_scale"] == pytest.approx(0.12)                                # RUN_DATE = election day
+    nat = (1 / (1 + np.exp(-d["mu_b_prior"]))) @ d["state_weights"]
+    assert 0.48 < nat < 0.56                                                       # Obama two-party prior
+
+
+@pytest.mark.skipif(not Path("/root/reference/data").exists(), reason="reference CSVs only exist in the build container")
+@pytest.mark.parametrize("year", [2012, 2008])
+def test_dataprep_reproduces_backtest_fixtures(cases, year):
+    from us_potus_model_amd import dataprep
+    d = dataprep.build_backtest("/root/reference/data", year)["data"]
+    for k, v in cases[str(year)][0].items():
+        assert np.allclose(np.asarray(d[k], dtype=float), np.asarray(v, dtype=float), rtol=1e-12, atol=1e-14), k
+
+
 @pytest.mark.skipif(not Path("/root/reference/data").exists(), reason="reference CSVs only exist in the build container")
 def test_dataprep_reproduces_fixture(data_2016):
     from us_potus_model_amd import dataprep

@@ -38,7 +38,7 @@ def test_rng_moments():
     assert abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03
 
 
-@pytest.mark.parametrize("name", ["2016", "small_full", "small_nomode"])
+@pytest.mark.parametrize("name", ["2016", "2012", "2008", "small_full", "small_nomode"])
 def test_oracle_matches_golden_and_autograd(cases, name):
     data, variant = cases[name]
     m = OracleModel(data, variant)

@@ -10,6 +10,9 @@ real-data fixtures can be produced without R:
   * state priors                 scripts/model/final_2016.R:400-410
   * the `data` list itself       scripts/model/final_2016.R:435-514
 
+  * 2012 / 2008 backtests        scripts/model/final_2012.R:63-556, final_2008.R:63-560
+                                 (feed poll_model_2020_no_mode_adjustment.stan)
+
 The output dict mirrors the `data{}` block of
 scripts/model/poll_model_2020.stan:1-41 (same names, 1-based indices).
 
@@ -215,6 +218,132 @@ def build_2016(data_dir: str | Path, run_date: str = "2016-11-08") -> dict:
     meta = dict(states=states, pollsters=pollsters, ev_state=st.ev.to_numpy(),
                 first_day=str(first_day.date()), election_day=str(election_day.date()))
     return dict(data=data, meta=meta)
+
+
+def _state_context_2008(data_dir: Path):
+    """final_2012.R:171-193 and final_2008.R:175-197 (both read data/2008.csv, a CR-terminated file)."""
+    st = pd.read_csv(data_dir / "2008.csv", lineterminator="\r") if b"\n" not in (data_dir / "2008.csv").read_bytes() \
+        else pd.read_csv(data_dir / "2008.csv")
+    st = st[st.state.notna()].copy()
+    st["state"] = st.state.astype(str).str.strip()
+    st["score"] = st.obama_count / (st.obama_count + st.mccain_count)
+    st["national_score"] = st.obama_count.sum() / (st.obama_count + st.mccain_count).sum()
+    st["delta"] = st.score - st.national_score
+    st["share_national_vote"] = st.total_count / st.total_count.sum()
+    st = st.sort_values("state", kind="stable").reset_index(drop=True)
+    w = (st.share_national_vote / st.share_national_vote.sum()).to_numpy()
+    return st, w
+
+
+_BACKTESTS = {
+    # year: (polls file, Republican column, RUN_DATE = election_day as scripted, start_date)
+    2012: ("all_polls_2012.csv", "romney", "2012-11-06", "2012-03-01"),   # final_2012.R:63-69,75
+    2008: ("all_polls_2008.csv", "mccain", "2008-11-03", "2008-03-01"),   # final_2008.R:63-69,75
+}
+
+
+def build_backtest(data_dir: str | Path, year: int, run_date: str | None = None) -> dict:
+    """The `data` list of the 2012 or 2008 backtest (final_2012.R:63-556 / final_2008.R:63-560), which the
+    scripts feed to poll_model_2020_no_mode_adjustment.stan (final_2012.R:558).  Differences from 2016: HuffPost
+    CSV with m/d/y dates (2008: UTF-8 BOM), no population filter, population recoded to 0/1/2 for the
+    de-duplication order only, three pollster renames, state context from the 2008 results without population
+    growth, no mode/population indices; the list carries an unused `sigma_a` that Stan ignores."""
+    if year not in _BACKTESTS:
+        raise ValueError("year must be 2012 or 2008 (2016: build_2016)")
+    data_dir = Path(data_dir)
+    fname, rep, eday, sday = _BACKTESTS[year]
+    election_day = pd.Timestamp(eday)
+    RUN_DATE = pd.Timestamp(run_date) if run_date else election_day
+    start_date = pd.Timestamp(sday)
+
+    ap = pd.read_csv(data_dir / fname, encoding="utf-8-sig")
+    ap = ap[["state", "pollster", "number.of.observations", "mode", "population", "start.date", "end.date",
+             "obama", rep, "undecided", "other"]].copy()
+    ap["end"] = pd.to_datetime(ap["end.date"], format="%m/%d/%y")
+    ap["begin"] = pd.to_datetime(ap["start.date"], format="%m/%d/%y")
+    ap = ap[ap.end <= RUN_DATE]
+
+    df = ap.rename(columns={"number.of.observations": "n"})
+    span = (df.end - df.begin).dt.days
+    df["t"] = df.end - pd.to_timedelta((1 + span) // 2, unit="D")
+    df = df[(df.t >= start_date) & df.t.notna() & (df.n > 1)].copy()
+
+    df["pollster"] = df.pollster.map(_extract_pollster).replace({"Fox News": "FOX", "WashPost": "Washington Post", "ABC News": "ABC"})
+    df["undecided"] = df.undecided.fillna(0)
+    df["other"] = df.other.fillna(0)
+    df["two_party_sum"] = df.obama + df[rep]
+    df["polltype"] = df.population.map({"Likely Voters": 0.0, "Registered Voters": 1.0, "Adults": 2.0})   # others NA (sorted last, as arrange does)
+    df["n_dem"] = _r_round(df.n * df.obama / 100.0)
+    df["n_rep"] = _r_round(df.n * df[rep] / 100.0)
+
+    state_abb_list = list(pd.read_csv(data_dir / "potus_results_76_16.csv").state.unique())
+    levels = ["--"] + state_abb_list
+    idx = df.state.map({s: i + 1 for i, s in enumerate(levels)})
+    df["index_s"] = np.where(idx == 1, 52, idx - 1)
+    tmin = df.t.min()
+    df["poll_day"] = (df.t - tmin).dt.days + 1
+    lev = sorted(df.pollster.astype(str).unique())
+    df["index_p"] = df.pollster.astype(str).map({v: i + 1 for i, v in enumerate(lev)})
+
+    df = df.sort_values(["state", "t", "polltype", "two_party_sum"], kind="stable", na_position="last")
+    df = df.drop_duplicates(subset=["state", "t", "pollster"], keep="first").reset_index(drop=True)
+
+    first_day = df.begin.min()
+    T = int(round((election_day - first_day).days))
+    pollsters = sorted(df.pollster.unique())
+
+    st, state_weights = _state_context_2008(data_dir)
+    states = list(st.state)
+    assert states == sorted(states) and len(states) == 51
+
+    corr = state_correlation(data_dir, 2016)               # final_2012.R:212: the 2016 results column, as scripted
+    state_covariance_0 = cov_matrix(51, 0.07 ** 2, 0.9) * corr
+
+    days_til_election = (election_day - RUN_DATE).days
+    expected_national_mu_b_T_error = 0.03 + (10 ** -6.6) * days_til_election ** 2
+    polling_bias_scale = 0.013 * 4
+    mu_b_T_scale = expected_national_mu_b_T_error * 4
+    random_walk_scale = 0.05 / np.sqrt(300.0) * 4
+
+    pri = pd.read_csv(data_dir / "state_priors_08_12_16.csv")
+    pri["date"] = pd.to_datetime(pri["date"])
+    pri = pri[pri.date <= RUN_DATE]
+    pri = pri[pri.date == pri.groupby("state").date.transform("max")]
+    pri = pri.sort_values("state", kind="stable")
+    assert list(pri.state) == states, "prior/state order mismatch (final_2012.R:460)"
+    mu_b_prior = logit(pri.pred.to_numpy())
+
+    unadj = (~df.pollster.isin(ADJUSTERS)).astype(np.float64)
+    nat = (df.index_s == 52).to_numpy()
+    sta = ~nat
+    i32 = lambda s: np.asarray(s, dtype=np.int32)
+    data = dict(
+        N_national_polls=int(nat.sum()), N_state_polls=int(sta.sum()),
+        T=T, S=51, P=len(pollsters), M=int(df["mode"].nunique(dropna=False)), Pop=int(df.polltype.nunique(dropna=False)),
+        state=i32(df.index_s[sta]), state_weights=state_weights,
+        day_state=i32(df.poll_day[sta]), day_national=i32(df.poll_day[nat]),
+        poll_state=i32(df.index_p[sta]), poll_national=i32(df.index_p[nat]),
+        unadjusted_national=unadj[nat].to_numpy(), unadjusted_state=unadj[sta].to_numpy(),
+        n_democrat_national=i32(df.n_dem[nat]), n_democrat_state=i32(df.n_dem[sta]),
+        n_two_share_national=i32((df.n_rep + df.n_dem)[nat]), n_two_share_state=i32((df.n_rep + df.n_dem)[sta]),
+        sigma_a=0.012,                                        # carried by the script, not declared by the Stan model
+        sigma_measure_noise_national=0.04, sigma_measure_noise_state=0.04,
+        mu_b_prior=mu_b_prior, sigma_c=0.06, sigma_m=0.04, sigma_pop=0.04, sigma_e_bias=0.02,
+        state_covariance_0=state_covariance_0,
+        polling_bias_scale=float(polling_bias_scale), mu_b_T_scale=float(mu_b_T_scale),
+        random_walk_scale=float(random_walk_scale),
+    )
+    meta = dict(states=states, pollsters=pollsters, ev_state=st.ev.to_numpy(),
+                first_day=str(first_day.date()), election_day=str(election_day.date()))
+    return dict(data=data, meta=meta)
+
+
+def build_2012(data_dir, run_date=None):
+    return build_backtest(data_dir, 2012, run_date)
+
+
+def build_2008(data_dir, run_date=None):
+    return build_backtest(data_dir, 2008, run_date)
 
 
 def save_npz(path: str | Path, built: dict) -> None:
