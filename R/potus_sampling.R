@@ -112,4 +112,17 @@ potus_output_files <- function(fit, dir, basename = "poll_model_2020") {
   file.path(dir, sprintf("%s-%d.csv", basename, seq_len(fit$chains)))
 }
 
+# Posterior summaries of predicted_score computed on the device (replaces final_2016.R:708-762 and :799-823:
+# no 8000 x 12954 array ever reaches R).  ev: electoral votes per state in state order (states2012$ev).
+# Returns list(state = array [T, S, 4] (low, high, mean, prob), national = [T, 4],
+#              electoral_votes = [T, 5] (mean, median, high, low, prob >= 270)).
+potus_summary <- function(fit, ev) {
+  S <- fit$data$S; T <- fit$data$T
+  r <- .C("potus_R_posterior_summary", fit$handle, as.double(ev), state = double(T * S * 4), natl = double(T * 4),
+          ev_out = double(T * 5), status = integer(1))
+  .potus_check(r$status)
+  list(state = aperm(array(r$state, c(4, T, S)), c(2, 3, 1)),       # C order [s][t][4] -> [t, s, 4]
+       national = t(matrix(r$natl, nrow = 4)), electoral_votes = t(matrix(r$ev_out, nrow = 5)))
+}
+
 potus_free <- function(fit) invisible(.C("potus_R_destroy", fit$handle, status = integer(1)))

@@ -172,6 +172,15 @@ int potus_write_array(int handle, int col_begin, int col_end, double *out);
  * rstan::read_stan_csv (final_2016.R:543). */
 int potus_write_stan_csv(int handle, const char *dir, const char *basename);
 
+/* Posterior summaries the run scripts build from extract(out, "predicted_score") (final_2016.R:708-762 state and
+ * national intervals, :799-823 electoral-college simulation), computed on the device from the saved draws of
+ * all chains of the handle (pooled, at most 16 384).  Cell order of state_out: t + T*s (CmdStan's column-major
+ * predicted_score[T,S]); quantiles are R's default (type 7).
+ *   state_out [T*S][4] = low (2.5 %), high (97.5 %), mean, P(score > 0.5)
+ *   natl_out  [T][4]   = the same for the state_weights-weighted national vote of each draw
+ *   ev_out    [T][5]   = mean, median, high, low, P(>= 270) of sum_s ev[s] 1[score > 0.5]      (ev: [S]) */
+int potus_posterior_summary(int handle, const double *ev, double *state_out, double *natl_out, double *ev_out);
+
 /* Kernel timing of the most recent potus_run, measured with HIP events on the
  * sampler's own stream: elapsed milliseconds and leapfrogs executed in it. */
 int potus_last_run_timing(int handle, double *ms, long long *leapfrogs);
@@ -196,6 +205,7 @@ void potus_R_run(int *handle, int *n_iter, int *status);
 void potus_R_num_columns(int *handle, int *D, int *n_cols, int *status);
 void potus_R_write_array(int *handle, int *col_begin, int *col_end, double *out, int *status);
 void potus_R_write_stan_csv(int *handle, char **dir, char **basename, int *status);
+void potus_R_posterior_summary(int *handle, double *ev, double *state_out, double *natl_out, double *ev_out, int *status);
 void potus_R_last_error(char **buf, int *len);
 void potus_R_destroy(int *handle, int *status);
 

@@ -228,3 +228,27 @@ def test_posterior_2016_against_golden_and_readme(data_2016):
     assert abs(nat.mean() - 0.512) < 0.01 and abs(np.quantile(nat, 0.025) - 0.485) < 0.012 and abs(np.quantile(nat, 0.975) - 0.540) < 0.012
     sp = fit.sampler_params()
     assert sp["divergent__"].mean() < 0.01 and 0.6 < sp["accept_stat__"].mean() < 0.97
+
+
+@pytest.mark.parametrize("name", ["small_full", "2016"])
+def test_posterior_summary_matches_numpy_restatement(cases, name):
+    """potus_posterior_summary (device: sort per cell in LDS) against oracle/posterior_summary_ref.py on the same
+    draws; quantiles/means to 1e-12, exceedance probabilities exactly."""
+    import sys
+    sys.path.insert(0, str(GOLD.parent.parent / "oracle"))
+    from posterior_summary_ref import posterior_summary
+    data, variant = cases[name]
+    S, T = int(data["S"]), int(data["T"])
+    ns = 150 if name == "small_full" else 40
+    h = Handle(data, variant, chains=4, num_warmup=60, num_samples=ns, seed=5)
+    h.init(); h.run(60 + ns)
+    ev = np.arange(3, 3 + S, dtype=np.float64) * (538.0 / np.arange(3, 3 + S).sum())   # any weights; sums to 538
+    got = h.posterior_summary(ev)
+    a, b, _ = h.layout["predicted_score"]
+    ps = h.write_array(a, b, ns).reshape(ns * 4, S, T).transpose(0, 2, 1)             # [draw, T, S]
+    ref = posterior_summary(ps, data["state_weights"], ev)
+    for k in ("state", "national", "electoral_votes"):
+        assert got[k].shape == ref[k].shape
+        assert np.allclose(got[k], ref[k], rtol=1e-12, atol=1e-12), (k, np.abs(got[k] - ref[k]).max())
+    assert np.array_equal(got["state"][..., 3], ref["state"][..., 3])
+    h.close()

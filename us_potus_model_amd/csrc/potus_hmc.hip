@@ -407,6 +407,79 @@ __global__ __launch_bounds__(256) void k_write_array(const DevModel *Mg, WAParam
   }
 }
 
+// ------------------------------------------------------------------------ posterior summaries
+// What the reference scripts compute from rstan::extract(out, "predicted_score") (final_2016.R:708-762 state and
+// national vote intervals, :799-823 electoral-college simulation), on the device, so that 8 000 x 12 954 doubles
+// never travel to R: one workgroup per cell pulls the pooled draws of its cell into LDS, sorts them (bitonic),
+// and emits mean / R type-7 quantiles / exceedance probability.
+//   cell <  T*S            predicted_score[t, s]                 -> low 2.5%, high 97.5%, mean, P(> 0.5)
+//   cell <  T*S + T        national vote: weighted mean over states (state_weights) per draw
+//   cell <  T*S + 2T       Democratic electoral votes sum_s ev[s] 1[p > 0.5] per draw
+//                          -> mean, median, high, low, P(>= 270)
+#define PS_MAXDRAWS 16384
+__device__ __forceinline__ double ps_quantile(const double *x, int n, double p) {   // R quantile(type = 7) on sorted x
+  const double h = (n - 1) * p;
+  const int lo = (int)floor(h);
+  const int hi = min(lo + 1, n - 1);
+  return x[lo] + (h - lo) * (x[hi] - x[lo]);
+}
+__global__ __launch_bounds__(512) void k_posterior_summary(const double *ps /*[nd][T*S], cell = t + T*s*/, int nd, int T, int S,
+                                                            const double *w, const double *ev, double *out_state, double *out_natl,
+                                                            double *out_ev) {
+  extern __shared__ __attribute__((aligned(16))) double xs[];
+  const int tid = threadIdx.x, TS = T * S;
+  int npad = 1;
+  while (npad < nd) npad <<= 1;
+  for (int cell = blockIdx.x; cell < TS + 2 * T; cell += gridDim.x) {
+    const int kind = cell < TS ? 0 : cell < TS + T ? 1 : 2;
+    const int t = kind == 0 ? 0 : (cell - TS) % T;
+    for (int d = tid; d < npad; d += 512) {
+      double v = INFINITY;                                   // padding sorts to the end
+      if (d < nd) {
+        const double *row = ps + (size_t)d * TS;
+        if (kind == 0) v = row[cell];
+        else {
+          v = 0.0;
+          for (int s = 0; s < S; s++) { const double x = row[t + T * s]; v += kind == 1 ? w[s] * x : (x > 0.5 ? ev[s] : 0.0); }
+        }
+      }
+      xs[d] = v;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < npad; i += 512) {
+          const int l = i ^ j;
+          if (l > i) {
+            const double a = xs[i], b = xs[l];
+            const bool up = (i & k) == 0;
+            if ((a > b) == up) { xs[i] = b; xs[l] = a; }
+          }
+        }
+        __syncthreads();
+      }
+    // mean and exceedance in a fixed order (tree over the sorted values)
+    __shared__ double red[2][512];
+    double sm = 0.0, ex = 0.0;
+    const double thr = kind == 2 ? 270.0 : 0.5;
+    for (int d = tid; d < nd; d += 512) { const double x = xs[d]; sm += x; ex += kind == 2 ? (x >= thr ? 1.0 : 0.0) : (x > thr ? 1.0 : 0.0); }
+    red[0][tid] = sm; red[1][tid] = ex;
+    __syncthreads();
+    for (int off = 256; off > 0; off >>= 1) {
+      if (tid < off) { red[0][tid] += red[0][tid + off]; red[1][tid] += red[1][tid + off]; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const double mean = red[0][0] / nd, prob = red[1][0] / nd;
+      const double lo = ps_quantile(xs, nd, 0.025), hi = ps_quantile(xs, nd, 0.975);
+      if (kind == 0) { double *o = out_state + (size_t)cell * 4; o[0] = lo; o[1] = hi; o[2] = mean; o[3] = prob; }
+      else if (kind == 1) { double *o = out_natl + (size_t)t * 4; o[0] = lo; o[1] = hi; o[2] = mean; o[3] = prob; }
+      else { double *o = out_ev + (size_t)t * 5; o[0] = mean; o[1] = ps_quantile(xs, nd, 0.5); o[2] = hi; o[3] = lo; o[4] = prob; }
+    }
+    __syncthreads();
+  }
+}
+
 // ======================================================================== host
 namespace {
 
@@ -525,6 +598,7 @@ struct Sampler {
   ClModel *dCL = nullptr;
   size_t cl_lds_bytes = 0;
   std::vector<int> h_ps, h_pt, h_pp, h_pm, h_ppop, h_pq, h_dayptr, h_perm;   // day-sorted polls (host copies)
+  std::vector<double> h_w;    // state_weights
   std::vector<double> h_pu;
 };
 
@@ -717,6 +791,8 @@ int build_model(Sampler *sp, const potus_data *d) {
   if ((rc = upload(sp, mat, &M.mat)) || (rc = upload(sp, pi, &M.pi)) || (rc = upload(sp, pdv, &M.pd)) ||
       (rc = upload(sp, sched, &M.sched)) || (rc = upload(sp, seg_scale, &M.seg_scale)) || (rc = upload(sp, sub_wt16, &M.sub_wt16)))
     return rc;
+  sp->h_w = w;   // weighted.mean() normalises: keep them summing to one
+  { double sw = 0; for (double x : sp->h_w) sw += x; for (double &x : sp->h_w) x /= sw; }
   sp->h_ps = ps; sp->h_pt = pt; sp->h_pp = pp; sp->h_pm = pm; sp->h_ppop = ppop; sp->h_pq = pq; sp->h_dayptr = day_ptr; sp->h_pu = pu;
   void *pdm = nullptr;
   HIP_TRY(hipMalloc(&pdm, sizeof(DevModel)));
@@ -1342,6 +1418,44 @@ int potus_write_array(int handle, int col_begin, int col_end, double *out) {
   return write_array_range(sp, n_saved, col_begin, col_end, out);
 }
 
+int potus_posterior_summary(int handle, const double *ev, double *state_out, double *natl_out, double *ev_out) {
+  Sampler *sp = get(handle);
+  if (!sp || !ev || !state_out || !natl_out || !ev_out) return fail(POTUS_ERR_STATE, "bad handle or null argument");
+  HIP_TRY(hipSetDevice(sp->device));
+  int n_saved = 0, rc = saved_count(sp, &n_saved);
+  if (rc) return rc;
+  const int nd = n_saved * sp->R.chains, S = sp->M.S, T = sp->M.T, TS = S * T;
+  if (nd < 2) return fail(POTUS_ERR_STATE, "posterior summaries need at least two saved draws");
+  if (nd > PS_MAXDRAWS) return fail(POTUS_ERR_UNSUPPORTED, "%d pooled draws: the LDS sort handles up to %d", nd, PS_MAXDRAWS);
+  // predicted_score of every saved draw, on the device: [iter][chain][T*S] (the generated-quantities block)
+  const int col_end = sp->L.ncols, col_begin = col_end - TS;
+  const int grid_w = std::min(nd, 512);
+  double *scratch = nullptr, *dps = nullptr, *dw = nullptr, *dev_ = nullptr, *dout = nullptr;
+  HIP_TRY(hipMalloc((void **)&scratch, (size_t)grid_w * sp->L.ncols * 8));
+  HIP_TRY(hipMalloc((void **)&dps, (size_t)nd * TS * 8));
+  HIP_TRY(hipMalloc((void **)&dw, (size_t)S * 8)); HIP_TRY(hipMalloc((void **)&dev_, (size_t)S * 8));
+  HIP_TRY(hipMalloc((void **)&dout, ((size_t)TS * 4 + (size_t)T * 9) * 8));
+  WAParams W{sp->R.draws, sp->R.chains, sp->R.n_save_max, n_saved, sp->R.row, sp->L.ncols, col_begin, col_end, scratch, dps, sp->sigma_ns, sp->sigma_nn};
+  hipLaunchKernelGGL(k_write_array, dim3(grid_w), dim3(256), 0, sp->stream, (const DevModel *)sp->dM, W);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(dw, sp->h_w.data(), (size_t)S * 8, hipMemcpyHostToDevice, sp->stream));
+  HIP_TRY(hipMemcpyAsync(dev_, ev, (size_t)S * 8, hipMemcpyHostToDevice, sp->stream));
+  int npad = 1;
+  while (npad < nd) npad <<= 1;
+  const size_t lds = (size_t)npad * 8;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_posterior_summary), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  double *o_state = dout, *o_natl = dout + (size_t)TS * 4, *o_ev = o_natl + (size_t)T * 4;
+  hipLaunchKernelGGL(k_posterior_summary, dim3(std::min(TS + 2 * T, 4096)), dim3(512), lds, sp->stream, (const double *)dps, nd, T, S,
+                     (const double *)dw, (const double *)dev_, o_state, o_natl, o_ev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(state_out, o_state, (size_t)TS * 4 * 8, hipMemcpyDeviceToHost, sp->stream));
+  HIP_TRY(hipMemcpyAsync(natl_out, o_natl, (size_t)T * 4 * 8, hipMemcpyDeviceToHost, sp->stream));
+  HIP_TRY(hipMemcpyAsync(ev_out, o_ev, (size_t)T * 5 * 8, hipMemcpyDeviceToHost, sp->stream));
+  HIP_TRY(hipStreamSynchronize(sp->stream));
+  (void)hipFree(scratch); (void)hipFree(dps); (void)hipFree(dw); (void)hipFree(dev_); (void)hipFree(dout);
+  return 0;
+}
+
 int potus_last_run_timing(int handle, double *ms, long long *leapfrogs) {
   Sampler *sp = get(handle);
   if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
@@ -1452,6 +1566,9 @@ void potus_R_num_columns(int *handle, int *D, int *n_cols, int *status) {
 }
 void potus_R_write_array(int *handle, int *col_begin, int *col_end, double *out, int *status) { *status = potus_write_array(*handle, *col_begin, *col_end, out); }
 void potus_R_write_stan_csv(int *handle, char **dir, char **basename, int *status) { *status = potus_write_stan_csv(*handle, dir[0], basename[0]); }
+void potus_R_posterior_summary(int *handle, double *ev, double *state_out, double *natl_out, double *ev_out, int *status) {
+  *status = potus_posterior_summary(*handle, ev, state_out, natl_out, ev_out);
+}
 void potus_R_last_error(char **buf, int *len) { potus_last_error(buf[0], *len); }
 void potus_R_destroy(int *handle, int *status) { *status = potus_destroy(*handle); }
 

@@ -71,6 +71,8 @@ def load_library():
     L.potus_write_array.argtypes = [C.c_int, C.c_int, C.c_int, dp]
     L.potus_write_stan_csv.argtypes = [C.c_int, C.c_char_p, C.c_char_p]
     L.potus_last_run_timing.argtypes = [C.c_int, dp, C.POINTER(C.c_longlong)]
+    L.potus_posterior_summary.argtypes = [C.c_int, dp, dp, dp, dp]
+    L.potus_cus_per_chain.argtypes = [C.c_int, ip]
     _LIB = L
     return L
 
@@ -80,8 +82,8 @@ EXPORTS = [
     "potus_column_name", "potus_create", "potus_destroy", "potus_cus_per_chain", "potus_log_prob_grad", "potus_init", "potus_run",
     "potus_iterations_done", "potus_total_leapfrogs", "potus_chain_status", "potus_get_adaptation",
     "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_stan_csv",
-    "potus_last_run_timing", "potus_R_create", "potus_R_init", "potus_R_run", "potus_R_num_columns",
-    "potus_R_write_array", "potus_R_write_stan_csv", "potus_R_last_error", "potus_R_destroy",
+    "potus_last_run_timing", "potus_posterior_summary", "potus_R_create", "potus_R_init", "potus_R_run", "potus_R_num_columns",
+    "potus_R_write_array", "potus_R_write_stan_csv", "potus_R_posterior_summary", "potus_R_last_error", "potus_R_destroy",
 ]
 
 
@@ -188,6 +190,17 @@ class Handle:
         if n.value:
             _check(self.L, self.L.potus_get_draws(self.h, _dp(out), C.byref(n)))
         return out
+
+    def posterior_summary(self, ev):
+        """Device-side summaries of predicted_score over all saved draws (final_2016.R:708-762, 799-823).
+
+        Returns dict(state=[T,S,4] (low, high, mean, prob), national=[T,4], electoral_votes=[T,5]
+        (mean, median, high, low, P(>=270))); `ev` = electoral votes per state, in state order."""
+        S, T = int(self.data["S"]), int(self.data["T"])
+        ev = np.ascontiguousarray(ev, dtype=np.float64).reshape(S)
+        st, na, eo = np.zeros((S, T, 4)), np.zeros((T, 4)), np.zeros((T, 5))
+        _check(self.L, self.L.potus_posterior_summary(self.h, _dp(ev), _dp(st), _dp(na), _dp(eo)))
+        return dict(state=np.ascontiguousarray(st.transpose(1, 0, 2)), national=na, electoral_votes=eo)
 
     def draws_device_ptr(self):
         p, n = C.c_void_p(), C.c_longlong()
