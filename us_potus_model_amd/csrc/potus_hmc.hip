@@ -604,6 +604,9 @@ struct Sampler {
 
 std::mutex g_mu;
 std::vector<Sampler *> g_handles;
+// Cluster kernels need all their workgroups co-resident (they wait for each other): launches of cluster-mode
+// handles are serialised per process, from launch to completion.
+std::mutex g_cluster_mu;
 
 Sampler *get(int h) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -1213,6 +1216,8 @@ int potus_log_prob_grad(int handle, const double *q, int n, double *lp, double *
   if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
   if (n < 0 || (n > 0 && (!q || !lp || !grad))) return fail(POTUS_ERR_ARG, "null argument");
   if (n == 0) return 0;
+  std::unique_lock<std::mutex> cluster_lock(g_cluster_mu, std::defer_lock);
+  if (sp->K > 1) cluster_lock.lock();
   HIP_TRY(hipSetDevice(sp->device));
   const size_t D = sp->L.D;
   double *dq = nullptr, *dlp = nullptr, *dg = nullptr;
@@ -1244,6 +1249,8 @@ int potus_log_prob_grad(int handle, const double *q, int n, double *lp, double *
 int potus_init(int handle, const double *q0) {
   Sampler *sp = get(handle);
   if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
+  std::unique_lock<std::mutex> cluster_lock(g_cluster_mu, std::defer_lock);
+  if (sp->K > 1) cluster_lock.lock();
   HIP_TRY(hipSetDevice(sp->device));
   double *dq0 = nullptr;
   const size_t bytes = (size_t)sp->R.chains * sp->L.D * 8;
@@ -1274,6 +1281,8 @@ int potus_run(int handle, int n_iter) {
   if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
   if (!sp->inited) return fail(POTUS_ERR_STATE, "potus_init must be called before potus_run");
   if (n_iter <= 0) return 0;
+  std::unique_lock<std::mutex> cluster_lock(g_cluster_mu, std::defer_lock);
+  if (sp->K > 1) cluster_lock.lock();
   HIP_TRY(hipSetDevice(sp->device));
   long long before = 0, after = 0;
   potus_total_leapfrogs(handle, &before);

@@ -28,6 +28,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "potus_dpp.hpp"
 
 #ifndef PT_NW
 #define PT_NW 8           // waves per workgroup: 8 -> two waves per SIMD, 256 VGPRs each (no spills)
@@ -149,10 +150,8 @@ __device__ __forceinline__ void block_sum(double (&v)[N], ldp red, int tid) {
   const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    double x = v[k];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off, 64);
-    if (lane == 0) red[w * N + k] = x;
+    const double x = dpp_scan_sum(v[k]);          // lane 63 ends up with the wave's total (DPP, no LDS crossbar)
+    if (lane == 63) red[w * N + k] = x;
   }
   __syncthreads();
 #pragma unroll
@@ -349,10 +348,8 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, const PassStatic
       s_pb[lane] = pb;
     }
     const double ww = lane < S ? (as_g(M->mat) + M->m_w)[lane] : 0.0;
-    double nb = ww * bT, np = ww * pb;          // stan:79 and the national average of mu_b[:,T]
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { nb += __shfl_down(nb, off, 64); np += __shfl_down(np, off, 64); }
-    if (lane == 0) { s_bT[S] = nb; s_pb[S] = np; }
+    const double nb = dpp_scan_sum(ww * bT), np = dpp_scan_sum(ww * pb);   // stan:79 and the national average of mu_b[:,T]
+    if (lane == 63) { s_bT[S] = nb; s_pb[S] = np; }
   }
   if (full && w == PT_NW - 2) {
     // e_bias (stan:91-93) as an affine scan over days: d[t] = e[t]-mu_e, d[t] = rho d[t-1] + sigma_rho z[t]
@@ -367,13 +364,12 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, const PassStatic
       if (t == 0) { A = 0.0; B = ze[0] * sigma_e - mue; }
       else { A = rho * A; B = rho * B + srho * ze[t]; }
     }
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double A2 = __shfl_up(A, off, 64), B2 = __shfl_up(B, off, 64);
-      if (lane >= off) { B = A * B2 + B; A = A * A2; }
+    {
+      double Bv[1] = {B};
+      dpp_scan_affine(A, Bv);                     // affine composites across lanes on the DPP path
+      B = Bv[0];
     }
-    double d = __shfl_up(B, 1, 64);
-    if (lane == 0) d = 0.0;
+    double d = dpp_prev_lane(B, 0.0);
     for (int t = ta; t < tb; t++) {
       d = (t == 0) ? ze[0] * sigma_e - mue : rho * d + srho * ze[t];
       s_e[t] = d + mue;
@@ -651,11 +647,8 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, const PassStatic
       S1 += inner ? a : 0.0; S2 += inner ? a * dprev : 0.0; S3 += inner ? a * z : 0.0;
       pol.g_fin(vz[u], a * (t >= 1 ? srho : sigma_e) - z, z, gz[u]);
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      S1 += __shfl_down(S1, off, 64); S2 += __shfl_down(S2, off, 64); S3 += __shfl_down(S3, off, 64);
-    }
-    if (lane == 0) {
+    S1 = dpp_scan_sum(S1); S2 = dpp_scan_sum(S2); S3 = dpp_scan_sum(S3);
+    if (lane == 63) {
       const double xm = s_scal[SC_XMUE], xr = s_scal[SC_XRHO];
       const double adj_rho = S2 + S3 * sigma_e * (-rho / sqrt(1.0 - rho * rho));
       pol.g(M->o_mue, 0.02 * (1.0 - rho) * S1 - xm, xm);
