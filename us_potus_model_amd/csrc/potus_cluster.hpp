@@ -1177,9 +1177,11 @@ __device__ __forceinline__ void cl_transition_begin(ClChain &c, uint32_t iter) {
   if (tid == 0) {
     ts->H0 = 0.5 * kin0 - lp0;
     ts->lsw = 0.0; ts->sum_metro = 0.0; ts->n_leap = 0; ts->depth = 0; ts->divergent = 0; ts->stop = 0; ts->eps = eps;
-    ts->qsel[0] = 0; ts->qsel[1] = 0;
+    // every position of the trajectory lives in a slot of the proposal pool: a leaf that becomes a proposal is kept
+    // by index, nothing is copied
     unsigned qm = 0;
     const int id = pool_alloc(qm, PT_NPQ);
+    ts->nextq[1] = pool_alloc(qm, PT_NPQ); ts->nextq[0] = pool_alloc(qm, PT_NPQ);
     ts->qmask = qm;
     ts->sample_qid = id; ts->q_lp[id] = lp0; ts->q_h[id] = 0.5 * kin0 - lp0;
   }
@@ -1202,8 +1204,8 @@ __device__ __forceinline__ void cl_transition_begin(ClChain &c, uint32_t iter) {
       }
     }
   }
-  cl_vop_prekick(c, c.soff(V_QC), c.soff(V_PC), c.soff(V_GC), c.soff(V_PH1), c.soff(V_QA1), c.soff(V_PF1), 0.5 * eps, eps);
-  cl_vop_prekick(c, c.soff(V_QC), c.soff(V_PC), c.soff(V_GC), c.soff(V_PH0), c.soff(V_QA0), c.soff(V_PF0), -0.5 * eps, -eps);
+  cl_vop_prekick(c, c.soff(V_QC), c.soff(V_PC), c.soff(V_GC), c.soff(V_PH1), c.soff(V_POOLQ + ts->nextq[1]), c.soff(V_PF1), 0.5 * eps, eps);
+  cl_vop_prekick(c, c.soff(V_QC), c.soff(V_PC), c.soff(V_GC), c.soff(V_PH0), c.soff(V_POOLQ + ts->nextq[0]), c.soff(V_PF0), -0.5 * eps, -eps);
 }
 
 template <int CL_DW>
@@ -1218,7 +1220,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
     if (tid == 0) {
       ts->dir = rng_uniform(c.key, iter, RNG_DIRECTION, 0, (uint32_t)depth) > 0.5 ? 1 : 0;
       ts->pmask = 0;
-      ts->qmask = 1u << ts->sample_qid;
+      ts->qmask = (1u << ts->sample_qid) | (1u << ts->nextq[0]) | (1u << ts->nextq[1]);
     }
     __syncthreads();
     const int dir = ts->dir;
@@ -1229,15 +1231,19 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
     const int nleaf = 1 << depth;
     ldp wpart = c.lds + c.CL->l_wide, wout = c.lds + c.CL->l_wout;
     for (int n = 0; n < nleaf; n++) {
-      if (tid == 0) { unsigned pm = ts->pmask; ts->leaf_id = pool_alloc(pm, PT_NPP); ts->pmask = pm; }
+      if (tid == 0) {
+        unsigned pm = ts->pmask, qm = ts->qmask;
+        ts->leaf_id = pool_alloc(pm, PT_NPP); ts->pmask = pm;
+        ts->out_q = pool_alloc(qm, PT_NPQ); ts->qmask = qm;   // slot receiving the position of the next leaf
+      }
       __syncthreads();
       const double e = dir ? eps : -eps;
-      const int sel = ts->qsel[dir];              // buffer holding this leaf's position
+      const int inq = ts->nextq[dir], outq = ts->out_q;   // slots of this leaf's position and of the one it produces
       const int leaf = ts->leaf_id;
       const unsigned s_leaf = c.soff(V_POOLP + leaf);
       const int m = __builtin_ctz(~(unsigned)n);  // levels merged at this leaf
       const bool top = n == nleaf - 1;            // then m == depth
-      ClLeapPolicy lp{c.st, c.soff((sel ? V_QB0 : V_QA0) + dir), c.soff((sel ? V_QA0 : V_QB0) + dir), c.soff(V_PH0 + dir), c.soff(V_MINV),
+      ClLeapPolicy lp{c.st, c.soff(V_POOLQ + inq), c.soff(V_POOLQ + outq), c.soff(V_PH0 + dir), c.soff(V_MINV),
                       s_leaf, 0.5 * e, e, c.soff(V_POOLP + (m >= 1 ? ts->pend_beg[0] : 0)), m == 1 ? c.soff(V_RHOLEV + 1) : c.soff(V_SCR0 + 1),
                       m >= 1, {0.0, 0.0, 0.0}};
       if (tid >= PT_THREADS - 64) {
@@ -1294,12 +1300,13 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
         const double wgt = H0 - h;
         ts->sum_metro += wgt > 0 ? 1.0 : exp(wgt);
         ts->n_leap += 1;
-        ts->qsel[dir] = sel ^ 1;                  // the next leaf of this end reads the buffer just written
-        int cur_beg = leaf, cur_prop = -1, abort = div;
+        ts->nextq[dir] = outq;                    // the next leaf of this end evaluates the position just written
+        int cur_beg = leaf, cur_prop = inq, abort = div;   // the leaf's own position is its subtree's first proposal
         const int cur_end = leaf;
         double cur_lsw = wgt;
         const double cur_lp = lpv, cur_h = h;
         unsigned qm = ts->qmask, pm = ts->pmask;
+        ts->q_lp[inq] = cur_lp; ts->q_h[inq] = cur_h;
         for (int j = 1; j <= m && !abort; j++) {
           const int ib = ts->pend_beg[j - 1], ie = ts->pend_end[j - 1], cb = cur_beg;
           ldp d = wout + 2 + 6 * (j - 1);
@@ -1316,14 +1323,8 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
           cur_lsw = lsw_sub;
           abort = !persist;
         }
-        int cq = -1;
         if (!abort) {
-          int prop = cur_prop;
-          if (prop < 0) { // the leaf itself is this subtree's proposal: keep its position
-            const int id = pool_alloc(qm, PT_NPQ);
-            ts->q_lp[id] = cur_lp; ts->q_h[id] = cur_h;
-            prop = id; cq = id;
-          }
+          const int prop = cur_prop;
           ts->pend_beg[m] = cur_beg; ts->pend_end[m] = cur_end; ts->pend_lsw[m] = cur_lsw; ts->pend_prop[m] = prop;
           if (top) {
             ldp d = wout + 2 + 6 * m;
@@ -1334,20 +1335,17 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
             if (lsw_sub > lsw) accept = true;
             else accept = ts->u_top < exp(lsw_sub - lsw);
             if (accept) { pool_free(qm, ts->sample_qid); ts->sample_qid = prop; }
-            else if (prop != cq) pool_free(qm, prop);
-            else { pool_free(qm, prop); cq = -1; }   // a rejected single-leaf proposal needs no copy
+            else pool_free(qm, prop);
             ts->lsw = d_lse(lsw, lsw_sub);
             if (!persist) ts->stop = 1;
           }
         }
         ts->qmask = qm; ts->pmask = pm;
-        ts->copy_q_id = cq;
         ts->abort = abort;
       }
       __syncthreads();
       CPROF_MARK(c, PF_LEAF_SCALAR);
       if (ts->abort) { valid = false; c.x.x1e = 0; break; }   // an X1 sent ahead is simply never read
-      if (ts->copy_q_id >= 0) cl_vop_copy<false>(c, c.soff(V_POOLQ + ts->copy_q_id), c.soff((sel ? V_QB0 : V_QA0) + dir));
       if (top) cl_vop_copy<false>(c, c.soff(V_PF0 + dir), c.soff(V_POOLP + leaf));   // the last leaf is the new end point
       CPROF_MARK(c, PF_COPYQ);
     }

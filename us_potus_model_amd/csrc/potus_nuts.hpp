@@ -31,7 +31,7 @@ extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
 
 #define PT_MAXD 12
 #define PT_NPP (2 * PT_MAXD + 4)
-#define PT_NPQ (PT_MAXD + 4)
+#define PT_NPQ (PT_MAXD + 6)
 
 enum { RNG_MOMENTUM = 0, RNG_DIRECTION = 1, RNG_TOP_ACCEPT = 2, RNG_SUB_ACCEPT = 3, RNG_INIT_EPS = 4, RNG_INITS = 5 };
 #define PT_ITER_PRE 0xFFFFFFFFu
@@ -100,6 +100,7 @@ struct TS { // transition state, LDS
   int depth, dir, divergent, abort, m, leaf_id, copy_q_id, sample_qid, n_leap, stop;
   int flag_a, flag_b, direction, done;
   int qsel[2];   // which of QA/QB holds the position the next leapfrog of end e evaluates (0 = QA)
+  int nextq[2], out_q;   // cluster mode: proposal-pool slots holding the next position of each end / receiving this leaf's output
 };
 typedef TS AS_L *ltp;
 
