@@ -98,6 +98,22 @@ def test_adaptation_matches_oracle_through_a_metric_update(cases, cus):
     h.close()
 
 
+@pytest.mark.parametrize("cus", [1, 8, 16])
+def test_launch_boundaries_do_not_change_the_draws_across_a_window_end(cases, cus):
+    """The metric update + init_stepsize of iteration 99 and the transition after it, inside one launch or split
+    over launches in every way, give the same bytes (a once-seen miscompilation of the oversized kernel broke this)."""
+    data, variant = cases["small_full"]
+    kw = dict(chains=1, num_warmup=150, num_samples=0, save_warmup=1, seed=11, cus_per_chain=cus)
+    out = []
+    for chunks in ([104], [99, 5], [100, 4], [99, 1, 4], [50, 49, 2, 3]):
+        h = Handle(data, variant, **kw); h.init()
+        for n in chunks:
+            h.run(n)
+        out.append(h.draws()[0][:104].copy()); h.close()
+    for d in out[1:]:
+        assert np.array_equal(out[0], d)
+
+
 @pytest.mark.parametrize("cus", [1, 16])
 def test_same_seed_same_bytes_and_chain_ids(cases, cus):
     data, variant = cases["small_full"]

@@ -40,16 +40,20 @@
 
 // fields of one member's part descriptor (ints)
 enum { CP_D0 = 0, CP_ND, CP_P0, CP_NP, CP_E0, CP_NE, CP_R0, CP_NR, CP_NSUB, CP_NSEG, CP_WB,
-       CP_O_WD, CP_O_MASK, CP_O_SUB, CP_O_SEGPTR, CP_O_SEGKIND, CP_O_SEGIDX, CP_O_WT, CP_N = 20 };
+       CP_O_WD, CP_O_MASK, CP_O_SUB, CP_O_SEGPTR, CP_O_SEGKIND, CP_O_SEGIDX, CP_O_WT, CP_E_SH, CP_N = 20 };
 // payload layout of exchange X2 (doubles); X1 and the scalar all-reduces use the first words
 enum { XP_PRE = 0, XP_AR = 64, XP_S = 66, XP_P = 72 };
+// the exchange sent ahead from the epilogue: words [0, S) suffix totals of the next position (X1), [XQ0, XQ0 + NREP) the
+// next position of the small vectors themselves
+enum { XQ0 = 64 };
 
 struct ClModel {
-  int K, XW, NR, NREP, NDP, npmax, nsubmax, pad0;
+  int K, XW, NR, NREP, NDP, npmax, nsubmax, Dint;   // Dint: internal length of a vector (parameters + line padding)
   const int *part;          // [K][CP_N]
   const int *sched;         // per member: wd_a|wd_b [PT_THREADS], wd0|wnd [PT_NW], sub16, seg_ptr, seg_kind, seg_index
   const double *wt;         // weights of the weighted level-1 tasks
   const int *rep_pos;       // [NREP] internal index of the small parameters every member reads: zT | zb | c,m,pop,mue,rho,ze
+  const int *rep_owner;     // [NREP] member that owns each of them
   const double *rep_scale;  // [NR] scale of owned slot r (sigma_c ... ; 1 for zT, zb)
   const int *perm;          // [D] internal index -> Stan index
   int l_C, l_Lw, l_LT, l_LB, l_w, l_prior, l_pm, l_py, l_pN, l_pun, l_sub, l_tab, l_ru, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_pb, l_e, l_c1, l_c2, l_c3, l_gs, l_ge, l_P, l_scal, l_red, l_st, l_prof;
@@ -141,6 +145,9 @@ __device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], c
   for (int u = 0; u < NB; u++) out[u] = __hiloint2double((int)w[u][1], (int)w[u][0]);   // idle lanes loaded zeros
 }
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// NOTE on position vectors (QC and the proposal-pool slots): their small-vector part is written with sc1
+// (write-through) stores, which do not refresh a line this compute unit's own L1 may still hold; every read of a
+// position outside the pass therefore uses sc1 loads as well (bld_s), never plain ones.
 // Sum N <= 8 values over every thread of every member; all threads of all members return the same bits.
 // Also a cluster-wide barrier: plain or write-through stores issued by any wave of any member before
 // the call are visible to sc1 loads issued after it.
@@ -191,18 +198,18 @@ __device__ __forceinline__ void cl_allreduce(double (&v)[N], ldp red, Xch &x, in
   for (int k = 0; k < N; k++) v[k] = red[PT_NW * N + k];
   PROF_MARK(26);
 }
-// All-reduce of nv <= CL_WIDE values whose per-wave partial sums sit in LDS (part[v * PT_NW + wave]); the
-// totals land in out[0 .. nv) (LDS) for every thread of every member, bit-identical everywhere.
+// All-reduce of nv <= CL_WIDE values whose per-wave partial sums sit in LDS (part[v * PT_NW + wave]), in two halves
+// so that the wait can be taken later: cl_wide_publish sends this member's sums and returns the exchange number;
+// cl_wide_consume (wave 0 only, no barrier) collects the totals into out[0 .. nv) (LDS), bit-identical everywhere.
 #define CL_WIDE 96
-__device__ __forceinline__ void cl_allreduce_wide(ldp part, int nv, ldp out, Xch &x, ldp prof = nullptr) {
+__device__ __forceinline__ unsigned cl_wide_publish(ldp part, int nv, Xch &x, ldp prof = nullptr) {
   (void)prof;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   PROF_MARK(20);
-  drain_vmem();
+  drain_vmem();                                    // every store of the leaf is complete before the member reports it
   PROF_MARK(21);
   __syncthreads();
   PROF_MARK(22);
-  TSTAMP(10);
   {
     const bool ok = w == 0 && lane < nv;
     double p8[PT_NW];
@@ -224,26 +231,83 @@ __device__ __forceinline__ void cl_allreduce_wide(ldp part, int nv, ldp out, Xch
   }
   x.epoch++;
   PROF_MARK(23);
-  if (w == 0) {
-    for (int l0 = 0; l0 < nv; l0 += 64) {
-      const int l = l0 + lane;
-      double tot = 0.0;
-      for (int mm0 = 0; mm0 < x.K; mm0 += 16) {
-        double t16[16];
-        unsigned vo[16], so[16];
+  return x.epoch;
+}
+__device__ __forceinline__ void cl_wide_consume(const Xch &x, unsigned tag, int nv, ldp out) {   // wave 0
+  const int lane = threadIdx.x & 63;
+  for (int l0 = 0; l0 < nv; l0 += 64) {
+    const int l = l0 + lane;
+    double tot = 0.0;
+    for (int mm0 = 0; mm0 < x.K; mm0 += 16) {
+      double t16[16];
+      unsigned vo[16], so[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) { const int mm = mm0 + u; vo[u] = (mm < x.K && l < nv) ? 16u * (unsigned)l : PT_OOB; so[u] = xch_rslot(x, mm < x.K ? mm : 0); }
-        xld(x, vo, so, t16);
+      for (int u = 0; u < 16; u++) { const int mm = mm0 + u; vo[u] = (mm < x.K && l < nv) ? 16u * (unsigned)l : PT_OOB; so[u] = xch_eslot(x, tag, mm < x.K ? mm : 0); }
+      xld(x, vo, so, t16, tag);
 #pragma unroll
-        for (int u = 0; u < 16; u++) tot += t16[u];
-      }
-      if (l < nv) out[l] = tot;
+      for (int u = 0; u < 16; u++) tot += t16[u];
     }
-    PROF_MARK(24);
-    TSTAMP(11);
+    if (l < nv) out[l] = tot;
   }
-  __syncthreads();
-  PROF_MARK(26);
+}
+
+// What thread 0 needs to take the verdicts of a leaf once its totals are in (base_nuts::build_tree's bookkeeping):
+// leaf number n of the doubling, m levels of subtrees it closes, whether it is the last leaf (top), its momentum
+// slot, the slots of its position and of the position it produced.  n < 0: nothing pending.
+struct LeafCtx { int n, m, top, depth, dir, leaf, inq, outq, nv; unsigned tag; };
+
+// totals: wout[0] = lp, [1] = kinetic, [2 + 6 (j-1) ..] the six dot products of level j, then the top check.
+__device__ __forceinline__ void cl_leaf_logic(ltp ts, const LeafCtx &L, ldp wout) {   // thread 0
+  const int m = L.m, leaf = L.leaf, inq = L.inq;
+  const double H0 = ts->H0, lpv = wout[0];
+  double h = 0.5 * wout[1] - lpv;
+  if (isnan(h)) h = INFINITY;
+  const int div = (h - H0 > 1000.0) ? 1 : ts->divergent;
+  ts->divergent = div;
+  const double wgt = H0 - h;
+  ts->sum_metro += wgt > 0 ? 1.0 : exp(wgt);
+  ts->n_leap += 1;
+  ts->nextq[L.dir] = L.outq;                      // the next leaf of this end evaluates the position just written
+  int cur_beg = leaf, cur_prop = inq, abort = div;   // the leaf's own position is its subtree's first proposal
+  const int cur_end = leaf;
+  double cur_lsw = wgt;
+  unsigned qm = ts->qmask, pm = ts->pmask;
+  ts->q_lp[inq] = lpv; ts->q_h[inq] = h;
+  for (int j = 1; j <= m && !abort; j++) {
+    const int ib = ts->pend_beg[j - 1], ie = ts->pend_end[j - 1], cb = cur_beg;
+    ldp d = wout + 2 + 6 * (j - 1);
+    const bool persist = d[0] > 0 && d[1] > 0 && d[2] > 0 && d[3] > 0 && d[4] > 0 && d[5] > 0;
+    const double lsw_sub = d_lse(ts->pend_lsw[j - 1], cur_lsw);
+    bool take_final;
+    if (cur_lsw > lsw_sub) take_final = true;
+    else take_final = ts->u_sub[L.n & 1][j] < exp(cur_lsw - lsw_sub);
+    if (take_final) pool_free(qm, ts->pend_prop[j - 1]);
+    else { pool_free(qm, cur_prop); cur_prop = ts->pend_prop[j - 1]; }
+    if (ie != ib) pool_free(pm, ie);
+    if (cb != cur_end) pool_free(pm, cb);
+    cur_beg = ib;
+    cur_lsw = lsw_sub;
+    abort = !persist;
+  }
+  if (!abort) {
+    const int prop = cur_prop;
+    ts->pend_beg[m] = cur_beg; ts->pend_end[m] = cur_end; ts->pend_lsw[m] = cur_lsw; ts->pend_prop[m] = prop;
+    if (L.top) {
+      ldp d = wout + 2 + 6 * m;
+      const bool persist = d[0] > 0 && d[1] > 0 && d[2] > 0 && d[3] > 0 && d[4] > 0 && d[5] > 0;
+      ts->depth = L.depth + 1;
+      const double lsw_sub = cur_lsw, lsw = ts->lsw;
+      bool accept;
+      if (lsw_sub > lsw) accept = true;
+      else accept = ts->u_top < exp(lsw_sub - lsw);
+      if (accept) { pool_free(qm, ts->sample_qid); ts->sample_qid = prop; }
+      else pool_free(qm, prop);
+      ts->lsw = d_lse(lsw, lsw_sub);
+      if (!persist) ts->stop = 1;
+    }
+  }
+  ts->qmask = qm; ts->pmask = pm;
+  ts->abort = abort;
 }
 __device__ __forceinline__ void cl_sync(Xch &x, ldp red) {
   double v[1] = {0.0};
@@ -314,6 +378,7 @@ struct ClStatic {           // per-thread registers that never change during a k
   int wd0, wnd;             // the wave's days: local days [wd0, wd0 + wnd), wnd <= CL_DW
   int ca, cb;               // the wave's chunk of the member's polls (day order) in the adjoint gather
   unsigned rep_vo[2];       // byte offsets of the small parameters this thread fetches for the workgroup
+  unsigned rep_xo[2];       // the same parameters as exchange words of their owners (member * XW + XQ0 + index) * 16
   int sg_a, sg_b, sg_kind, sg_index;   // level-2 segment summed by this thread: task range, what the sum feeds
   double scale_r;           // scale of the small-vector slot this thread owns (threads 128 ..)
 };
@@ -327,8 +392,13 @@ __device__ __forceinline__ ClStatic cl_load_static(CCp CL, cip part) {
   c.ca = sc[PT_THREADS + 2 * PT_NW + (tid >> 6)]; c.cb = sc[PT_THREADS + 3 * PT_NW + (tid >> 6)];
   gcip rp = as_g(CL->rep_pos);
   const int NREP = CL->NREP;
+  gcip ro = as_g(CL->rep_owner);
 #pragma unroll
-  for (int u = 0; u < 2; u++) { const int j = tid + u * PT_THREADS; c.rep_vo[u] = j < NREP ? 8u * (unsigned)rp[j] : PT_OOB; }
+  for (int u = 0; u < 2; u++) {
+    const int j = tid + u * PT_THREADS;
+    c.rep_vo[u] = j < NREP ? 8u * (unsigned)rp[j] : PT_OOB;
+    c.rep_xo[u] = j < NREP ? ((unsigned)ro[j] * (unsigned)CL->XW + (unsigned)(XQ0 + j)) * 16u : PT_OOB;
+  }
   {
     gcip sch = as_g(CL->sched);
     const int nseg = part[CP_NSEG];
@@ -407,9 +477,13 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
 // pubnext: the position this pass writes is the one the next pass evaluates (consecutive leaves of a subtree),
 // so the suffix totals of that position (exchange X1 of the NEXT pass) are published here, as soon as the
 // epilogue has produced it; the next pass then finds x.x1e set and does not wait for its X1 at all.
+// pend: a leaf whose totals (exchange pend.tag) have been sent but not looked at: wave 0 collects them while the
+// other waves work on phase B, thread 0 takes its verdicts (cl_leaf_logic), and if they end the trajectory the pass
+// stops right after the phase-B barrier, before it has stored anything (aborted = true).  This takes the wait for
+// the leaf's all-reduce and the serial bookkeeping off the critical path of consecutive leaves.
 template <int CL_DW, class Pol>
 __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_in, ldp lds, const ClStatic &cst, Xch &x, Pol &pol_io,
-                                                  bool pubnext = false) {
+                                                  bool pubnext, const LeafCtx &pend, ltp ts, ldp wout, bool &aborted) {
   Pol pol = pol_io;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
@@ -428,7 +502,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   ldp s_zT = s_rep, s_zb = s_rep + S, s_mid = s_rep + 2 * S;
   ldp s_bT = lds + CL->l_bT, s_pb = lds + CL->l_pb, s_e = lds + CL->l_e, s_c1 = lds + CL->l_c1, s_c2 = lds + CL->l_c2, s_c3 = lds + CL->l_c3;
   ldp s_gs = lds + CL->l_gs, s_ge = lds + CL->l_ge, s_P = lds + CL->l_P, s_scal = lds + CL->l_scal, red = lds + CL->l_red;
-  const int e_noise = e0 + S * nd, e_ze = e_noise + np, e_rep = e_ze + (full ? nd : 0);
+  const int e_noise = e0 + S * nd, e_ze = part[CP_E_SH], e_rep = e_ze + (full ? nd : 0);   // the shared block starts on its own line
   double lp = 0.0;
 #ifdef POTUS_PROF
   ldp prof = lds + CL->l_prof;
@@ -439,9 +513,18 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // ---------------- phase A: the small vectors (all members read all of them), own days of the S x T block
   double cs[CL_DW], zq[CL_DW];
   {
+    // the small vectors: from the exchange words their owners sent ahead with the previous leaf (x.x1e set: this
+    // pass evaluates the position that leaf produced), else from the state vector (visible: older than one leaf)
     typename Pol::QT qr[2], qt[CL_DW];
-    pol.qs_load(cst.rep_vo[0], qr[0]);
-    pol.qs_load(cst.rep_vo[1], qr[1]);
+    const bool ahead = x.x1e != 0;
+    pol.qs_load(ahead ? PT_OOB : cst.rep_vo[0], qr[0]);
+    pol.qs_load(ahead ? PT_OOB : cst.rep_vo[1], qr[1]);
+    double qx[2];
+    {
+      const unsigned vo[2] = {ahead ? cst.rep_xo[0] : PT_OOB, ahead ? cst.rep_xo[1] : PT_OOB};
+      const unsigned so[2] = {xch_eslot(x, x.x1e, 0), xch_eslot(x, x.x1e, 0)};
+      xld(x, vo, so, qx, ahead ? x.x1e : 1u);
+    }
 #pragma unroll
     for (int j = 0; j < CL_DW; j++) {
       const int tl = wd0 + j;
@@ -451,7 +534,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     if (tid < SE) s_gs[tid] = 0.0;
     if (tid >= 64 && tid < 64 + CL_MAXDAYS) s_ge[tid - 64] = 0.0;
 #pragma unroll
-    for (int u = 0; u < 2; u++) { const int j = tid + u * PT_THREADS; s_rep[j < NREP ? j : NREP] = pol.q_fin(qr[u]); }
+    for (int u = 0; u < 2; u++) { const int j = tid + u * PT_THREADS; s_rep[j < NREP ? j : NREP] = ahead ? qx[u] : pol.q_fin(qr[u]); }
     double run = 0.0;
 #pragma unroll
     for (int j = CL_DW - 1; j >= 0; j--) {
@@ -556,11 +639,16 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       for (int u = 0; u < 16; u++) carry_m += t16[u];
     }
     if (lane < S) Y[PT_NW * SE + lane] = carry_m;
+    if (pend.n >= 0) {                              // the previous leaf's totals and verdicts, off the critical path
+      cl_wide_consume(x, pend.tag, pend.nv, wout);
+      if (tid == 0) cl_leaf_logic(ts, pend, wout);
+    }
   }
   WPROF_ACC(0);
   __syncthreads();
   PROF_MARK(1);
   TSTAMP(2);
+  if (pend.n >= 0 && ts->abort) { aborted = true; return 0.0; }   // every member takes this exit together
   {
     // C[k][t] for the member's days: local suffix + later waves + later members
     if (lane < S) {
@@ -966,7 +1054,12 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     lp += repl ? dl : 0.0;
     own_g = gv; own_q = qv;
   }
-  pol.gs_fin(vo_x, own_g, own_q, gx);              // outside the branches (vo_x is out of range for non-owners)
+  {
+    const double qn_own = pol.gs_fin(vo_x, own_g, own_q, gx);   // outside the branches (vo_x is out of range for non-owners)
+    // ... and sent ahead to the members that evaluate the next position (word XQ0 + index of the small parameter)
+    const int jrep = arl ? NR + d0 + (nd - 1 - lane) : rslot;
+    xst(x, (pubnext && (arl || repl)) ? 16u * (unsigned)(XQ0 + jrep) : PT_OOB, qn_own);
+  }
   __syncthreads();
   {
     const double carry = lane < S ? X[PT_NW * SE + lane] : 0.0;   // pre[] is already the prefix within the member
@@ -1000,7 +1093,9 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
 template <int CL_DW, class Pol>
 __device__ __forceinline__ double cl_pass(CMp M, CCp CL, cip part, ldp lds, const ClStatic &cst, Xch &x, Pol &pol_io) {
   double v[1 + Pol::NEXTRA];
-  v[0] = cl_pass_partial<CL_DW>(M, CL, part, lds, cst, x, pol_io);
+  const LeafCtx none{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
+  bool aborted = false;
+  v[0] = cl_pass_partial<CL_DW>(M, CL, part, lds, cst, x, pol_io, false, none, (ltp)nullptr, (ldp)nullptr, aborted);
 #pragma unroll
   for (int k = 0; k < Pol::NEXTRA; k++) v[1 + k] = pol_io.extra[k];
   cl_allreduce(v, lds + CL->l_red, x, (int)threadIdx.x);
@@ -1058,6 +1153,7 @@ __device__ __forceinline__ double cl_vop_momentum(ClChain &c, unsigned sP, uint3
   double v[1] = {0.0};
   for (int i = cl_first(c); i < c.e1; i += PT_THREADS) {
     const int si = c.perm[i];
+    if (si < 0) continue;                            // padding element: momentum stays 0
     const double mi = bld(c.st, 8u * i, sM);
     double a, b;
     rng_normal_pair(c.key, iter, purpose, aux, (uint32_t)(si >> 1), a, b);
@@ -1151,7 +1247,7 @@ __device__ __forceinline__ void cl_vop_prekick(ClChain &c, unsigned sq, unsigned
     for (int k = 0; k < CL_UNR; k++) {
       const int i = base + k * PT_THREADS;
       const unsigned o = i < c.e1 ? 8u * i : PT_OOB;
-      q[k] = bld(c.st, o, sq); p[k] = bld(c.st, o, sp); g[k] = bld(c.st, o, sg); m[k] = bld(c.st, o, sM);
+      q[k] = bld_s(c.st, o, sq); p[k] = bld(c.st, o, sp); g[k] = bld(c.st, o, sg); m[k] = bld(c.st, o, sM);
     }
 #pragma unroll
     for (int k = 0; k < CL_UNR; k++) {
@@ -1194,7 +1290,7 @@ __device__ __forceinline__ void cl_transition_begin(ClChain &c, uint32_t iter) {
       for (int k = 0; k < CL_UNR; k++) {
         const int i = base + k * PT_THREADS;
         const unsigned o = i < c.e1 ? 8u * i : PT_OOB;
-        q[k] = bld(c.st, o, c.soff(V_QC)); p[k] = bld(c.st, o, c.soff(V_PC));
+        q[k] = bld_s(c.st, o, c.soff(V_QC)); p[k] = bld(c.st, o, c.soff(V_PC));
       }
 #pragma unroll
       for (int k = 0; k < CL_UNR; k++) {
@@ -1230,6 +1326,11 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
     bool valid = true;
     const int nleaf = 1 << depth;
     ldp wpart = c.lds + c.CL->l_wide, wout = c.lds + c.CL->l_wout;
+    // Consecutive leaves of the subtree are software-pipelined: a leaf sends its totals (log density, kinetic energy,
+    // U-turn dot products) and the next leaf starts at once; the totals are collected and the verdicts taken inside
+    // that next pass (cl_pass_partial, `pend`).  Only the last leaf of the doubling waits for its own totals.
+    LeafCtx pend{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
+    int prev_leaf = 0, prev_outq = 0;
     for (int n = 0; n < nleaf; n++) {
       if (tid == 0) {
         unsigned pm = ts->pmask, qm = ts->qmask;
@@ -1238,22 +1339,25 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
       }
       __syncthreads();
       const double e = dir ? eps : -eps;
-      const int inq = ts->nextq[dir], outq = ts->out_q;   // slots of this leaf's position and of the one it produces
+      const int inq = n == 0 ? ts->nextq[dir] : prev_outq, outq = ts->out_q;   // slots of this leaf's position and of the one it produces
       const int leaf = ts->leaf_id;
       const unsigned s_leaf = c.soff(V_POOLP + leaf);
       const int m = __builtin_ctz(~(unsigned)n);  // levels merged at this leaf
       const bool top = n == nleaf - 1;            // then m == depth
+      // (for an odd leaf the level-1 partner is the previous leaf: its momentum slot is known without its verdicts)
       ClLeapPolicy lp{c.st, c.soff(V_POOLQ + inq), c.soff(V_POOLQ + outq), c.soff(V_PH0 + dir), c.soff(V_MINV),
-                      s_leaf, 0.5 * e, e, c.soff(V_POOLP + (m >= 1 ? ts->pend_beg[0] : 0)), m == 1 ? c.soff(V_RHOLEV + 1) : c.soff(V_SCR0 + 1),
+                      s_leaf, 0.5 * e, e, c.soff(V_POOLP + (m >= 1 ? prev_leaf : 0)), m == 1 ? c.soff(V_RHOLEV + 1) : c.soff(V_SCR0 + 1),
                       m >= 1, {0.0, 0.0, 0.0}};
       if (tid >= PT_THREADS - 64) {
         // the uniforms of this leaf's accept steps depend on nothing computed here: the last wave draws them
-        // now (one lane per level) instead of thread 0 drawing them one after the other after the reduction
+        // now (one lane per level) instead of thread 0 drawing them one after the other
         const int j = tid - (PT_THREADS - 64) + 1;
-        if (j <= m) ts->u_sub[j] = rng_uniform(c.key, iter, RNG_SUB_ACCEPT, 0, ((uint32_t)depth << 24) | ((uint32_t)j << 16) | (uint32_t)(n >> j));
+        if (j <= m) ts->u_sub[n & 1][j] = rng_uniform(c.key, iter, RNG_SUB_ACCEPT, 0, ((uint32_t)depth << 24) | ((uint32_t)j << 16) | (uint32_t)(n >> j));
         if (j == 64 && top) ts->u_top = rng_uniform(c.key, iter, RNG_TOP_ACCEPT, 0, (uint32_t)depth);
       }
-      const double lpp = cl_pass_partial<CL_DW>(c.M, c.CL, c.part, c.lds, c.cst, c.x, lp, n < nleaf - 1);
+      bool aborted = false;
+      const double lpp = cl_pass_partial<CL_DW>(c.M, c.CL, c.part, c.lds, c.cst, c.x, lp, n < nleaf - 1, pend, ts, wout, aborted);
+      if (aborted) { valid = false; c.x.x1e = 0; break; }   // the previous leaf ended the trajectory: this one is dropped unseen
       CPROF_START(c);
       CPROF_COUNT(c, PF_LEAVES);
       // One all-reduce per leaf: log density, kinetic energy and the six dot products of every U-turn check
@@ -1274,9 +1378,9 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
       }
       if (m > 1 || top) { drain_vmem(); __syncthreads(); }   // the leaf's momentum is read back with another thread map
       for (int j = 2; j <= m; j++) {
-        const int ib = ts->pend_beg[j - 1], ie = ts->pend_end[j - 1], cb = j == 1 ? leaf : ts->pend_beg[j - 2];
-        const unsigned a_rho = j == 1 ? c.soff(V_POOLP + ib) : c.soff(V_RHOLEV + j - 1);
-        const unsigned b_rho = j == 1 ? c.soff(V_POOLP + leaf) : c.soff(V_SCR0 + ((j - 1) & 1));
+        const int ib = ts->pend_beg[j - 1], ie = ts->pend_end[j - 1], cb = ts->pend_beg[j - 2];
+        const unsigned a_rho = c.soff(V_RHOLEV + j - 1);
+        const unsigned b_rho = c.soff(V_SCR0 + ((j - 1) & 1));
         const unsigned out = j == m ? c.soff(V_RHOLEV + j) : c.soff(V_SCR0 + (j & 1));
         cl_vop_merge_partial(c, c.soff(V_POOLP + ib), c.soff(V_POOLP + ie), a_rho, c.soff(V_POOLP + cb), c.soff(V_POOLP + leaf), b_rho, out,
                              wpart + (2 + 6 * (j - 1)) * PT_NW);
@@ -1289,64 +1393,20 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
                              c.soff(V_RHOTOP), wpart + (2 + 6 * m) * PT_NW);
       }
       CPROF_MARK(c, PF_MERGE);
-      cl_allreduce_wide(wpart, 2 + 6 * (m + (top ? 1 : 0)), wout, c.x, CPROFPTR(c));
-      CPROF_START(c);
-      if (tid == 0) {
-        const double H0 = ts->H0, lpv = wout[0];
-        double h = 0.5 * wout[1] - lpv;
-        if (isnan(h)) h = INFINITY;
-        const int div = (h - H0 > 1000.0) ? 1 : ts->divergent;
-        ts->divergent = div;
-        const double wgt = H0 - h;
-        ts->sum_metro += wgt > 0 ? 1.0 : exp(wgt);
-        ts->n_leap += 1;
-        ts->nextq[dir] = outq;                    // the next leaf of this end evaluates the position just written
-        int cur_beg = leaf, cur_prop = inq, abort = div;   // the leaf's own position is its subtree's first proposal
-        const int cur_end = leaf;
-        double cur_lsw = wgt;
-        const double cur_lp = lpv, cur_h = h;
-        unsigned qm = ts->qmask, pm = ts->pmask;
-        ts->q_lp[inq] = cur_lp; ts->q_h[inq] = cur_h;
-        for (int j = 1; j <= m && !abort; j++) {
-          const int ib = ts->pend_beg[j - 1], ie = ts->pend_end[j - 1], cb = cur_beg;
-          ldp d = wout + 2 + 6 * (j - 1);
-          const bool persist = d[0] > 0 && d[1] > 0 && d[2] > 0 && d[3] > 0 && d[4] > 0 && d[5] > 0;
-          const double lsw_sub = d_lse(ts->pend_lsw[j - 1], cur_lsw);
-          bool take_final;
-          if (cur_lsw > lsw_sub) take_final = true;
-          else take_final = ts->u_sub[j] < exp(cur_lsw - lsw_sub);
-          if (take_final) pool_free(qm, ts->pend_prop[j - 1]);
-          else { pool_free(qm, cur_prop); cur_prop = ts->pend_prop[j - 1]; }
-          if (ie != ib) pool_free(pm, ie);
-          if (cb != cur_end) pool_free(pm, cb);
-          cur_beg = ib;
-          cur_lsw = lsw_sub;
-          abort = !persist;
-        }
-        if (!abort) {
-          const int prop = cur_prop;
-          ts->pend_beg[m] = cur_beg; ts->pend_end[m] = cur_end; ts->pend_lsw[m] = cur_lsw; ts->pend_prop[m] = prop;
-          if (top) {
-            ldp d = wout + 2 + 6 * m;
-            const bool persist = d[0] > 0 && d[1] > 0 && d[2] > 0 && d[3] > 0 && d[4] > 0 && d[5] > 0;
-            ts->depth = depth + 1;
-            const double lsw_sub = cur_lsw, lsw = ts->lsw;
-            bool accept;
-            if (lsw_sub > lsw) accept = true;
-            else accept = ts->u_top < exp(lsw_sub - lsw);
-            if (accept) { pool_free(qm, ts->sample_qid); ts->sample_qid = prop; }
-            else pool_free(qm, prop);
-            ts->lsw = d_lse(lsw, lsw_sub);
-            if (!persist) ts->stop = 1;
-          }
-        }
-        ts->qmask = qm; ts->pmask = pm;
-        ts->abort = abort;
+      const int nv = 2 + 6 * (m + (top ? 1 : 0));
+      const unsigned tag = cl_wide_publish(wpart, nv, c.x, CPROFPTR(c));
+      const LeafCtx cur{n, m, top ? 1 : 0, depth, dir, leaf, inq, outq, nv, tag};
+      prev_leaf = leaf; prev_outq = outq;
+      if (!top) { pend = cur; CPROF_MARK(c, PF_LEAF_SCALAR); continue; }
+      // last leaf of the doubling: its verdicts are needed before anything else can start
+      if (tid < 64) {
+        cl_wide_consume(c.x, tag, nv, wout);
+        if (tid == 0) cl_leaf_logic(ts, cur, wout);
       }
       __syncthreads();
       CPROF_MARK(c, PF_LEAF_SCALAR);
-      if (ts->abort) { valid = false; c.x.x1e = 0; break; }   // an X1 sent ahead is simply never read
-      if (top) cl_vop_copy<false>(c, c.soff(V_PF0 + dir), c.soff(V_POOLP + leaf));   // the last leaf is the new end point
+      if (ts->abort) { valid = false; c.x.x1e = 0; break; }
+      cl_vop_copy<false>(c, c.soff(V_PF0 + dir), c.soff(V_POOLP + leaf));   // the last leaf is the new end point
       CPROF_MARK(c, PF_COPYQ);
     }
     if (!valid) break;
@@ -1428,7 +1488,7 @@ __device__ __forceinline__ void cl_adapt_after_transition(ClChain &c, uint32_t i
   if (in_window) { // welford_var_estimator::add_sample
     const double n = sc->wf_n;
     for (int i = cl_first(c); i < c.e1; i += PT_THREADS) {
-      const double q = bld(c.st, 8u * i, sQ), mo = bld(c.st, 8u * i, sMean), delta = q - mo, mn = mo + delta / n;
+      const double q = bld_s(c.st, 8u * i, sQ), mo = bld(c.st, 8u * i, sMean), delta = q - mo, mn = mo + delta / n;
       bst(c.st, 8u * i, sMean, mn);
       bst(c.st, 8u * i, sM2, bld(c.st, 8u * i, sM2) + (q - mn) * delta);
     }

@@ -205,13 +205,13 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_logprob_grad(const DevModel *
   const int D = M->D, Dpad = R->Dpad;
   const rsrc_t rs = make_rsrc(scratch, 2u * (unsigned)Dpad * 8u);
   for (int b = 0; b < n; b++) {
-    for (int i = c.e0 + c.tid; i < c.e1; i += PT_THREADS) bst_s(rs, 8u * i, 0, as_g(q)[(size_t)b * D + c.perm[i]]);
+    for (int i = c.e0 + c.tid; i < c.e1; i += PT_THREADS) { const int si = c.perm[i]; bst_s(rs, 8u * i, 0, si >= 0 ? as_g(q)[(size_t)b * D + si] : 0.0); }
     cl_sync(c.x, c.red());
     ClPlainPolicy pol{rs, rs, 0u, (unsigned)Dpad * 8u, {0}};
     const double v = cl_pass<CL_DW>(M, CL, c.part, c.lds, c.cst, c.x, pol);
     drain_vmem();
     __syncthreads();
-    for (int i = c.e0 + c.tid; i < c.e1; i += PT_THREADS) as_g(grad)[(size_t)b * D + c.perm[i]] = bld(rs, 8u * i, (unsigned)Dpad * 8u);
+    for (int i = c.e0 + c.tid; i < c.e1; i += PT_THREADS) { const int si = c.perm[i]; if (si >= 0) as_g(grad)[(size_t)b * D + si] = bld(rs, 8u * i, (unsigned)Dpad * 8u); }
     if (blockIdx.x == 0 && c.tid == 0) lp[b] = v;
     cl_sync(c.x, c.red());
   }
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_init(const DevModel *Mg, cons
   const double radius = R->init_radius;
   for (uint32_t attempt = 0; attempt < 100 && !ok; attempt++) {
     for (int i = c.e0 + tid; i < c.e1; i += PT_THREADS) {
-      const int si = c.perm[i];
-      bst_s(c.st, 8u * i, sQ, q0 ? as_g(q0)[(size_t)chain * c.D + si] : radius * (2.0 * rng_uniform(c.key, PT_ITER_PRE, RNG_INITS, attempt, (uint32_t)si) - 1.0));
+      const int si = c.perm[i];                      // < 0: padding element, stays 0
+      if (si >= 0) bst_s(c.st, 8u * i, sQ, q0 ? as_g(q0)[(size_t)chain * c.D + si] : radius * (2.0 * rng_uniform(c.key, PT_ITER_PRE, RNG_INITS, attempt, (uint32_t)si) - 1.0));
     }
     cl_sync(c.x, c.red());
     ClPlainPolicy pol{c.st, c.st, sQ, sG, {0}};
@@ -282,9 +282,10 @@ __device__ __forceinline__ void cl_transition_end(ClChain &c, CRp R, int chain, 
   }
   const unsigned s_src = c.soff(V_POOLQ + ts->sample_qid), sQ = c.soff(V_QC);
   for (int i = c.e0 + tid; i < c.e1; i += PT_THREADS) {
-    const double v = bld(c.st, 8u * i, s_src);
+    const double v = bld_s(c.st, 8u * i, s_src);   // positions are read with sc1 loads (see potus_cluster.hpp)
     bst_s(c.st, 8u * i, sQ, v);
-    if (save) row[POTUS_N_SAMPLER_COLS + c.perm[i]] = v;
+    const int si = c.perm[i];
+    if (save && si >= 0) row[POTUS_N_SAMPLER_COLS + si] = v;
   }
   cl_sync(c.x, c.red());
   if (tid == 0) {
@@ -295,6 +296,40 @@ __device__ __forceinline__ void cl_transition_end(ClChain &c, CRp R, int chain, 
   __syncthreads();
   if (tid == 0) c.sc->iter = it + 1;
   __syncthreads();
+}
+
+// The once-per-transition parts are separate functions, as in the one-workgroup sampler (cold_transition_*): the
+// kernel proper then holds one copy of the model pass (the leaf of the tree) instead of four, and the only state that
+// crosses a call is the exchange counter.  Arguments of a non-inlined function arrive in vector registers; everything
+// wave-uniform is rebuilt from them here.
+template <int CL_DW>
+__device__ __noinline__ unsigned cl_cold_transition_begin(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, int chain_, int m_,
+                                                          unsigned launch_, unsigned epoch_, uint32_t iter_) {
+  CMp M = (CMp)uni_ptr(Mg);
+  CCp CL = (CCp)uni_ptr(CLg);
+  CRp R = (CRp)uni_ptr(Rg);
+  ClChain c = make_clchain(M, CL, R, (int)uni32((unsigned)chain_), (int)uni32((unsigned)m_), uni32(launch_));
+  c.x.epoch = uni32(epoch_);
+  c.cst = cl_load_static(CL, c.part);
+  CPROF_START(c);
+  cl_transition_begin<CL_DW>(c, uni32(iter_));
+  CPROF_MARK(c, PF_INITCOPY);
+  return c.x.epoch;
+}
+template <int CL_DW>
+__device__ __noinline__ unsigned cl_cold_transition_end(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, int chain_, int m_,
+                                                        unsigned launch_, unsigned epoch_, uint32_t iter_) {
+  CMp M = (CMp)uni_ptr(Mg);
+  CCp CL = (CCp)uni_ptr(CLg);
+  CRp R = (CRp)uni_ptr(Rg);
+  const int chain = (int)uni32((unsigned)chain_);
+  ClChain c = make_clchain(M, CL, R, chain, (int)uni32((unsigned)m_), uni32(launch_));
+  c.x.epoch = uni32(epoch_);
+  c.cst = cl_load_static(CL, c.part);
+  CPROF_START(c);
+  cl_transition_end<CL_DW>(c, R, chain, (int)uni32(iter_));
+  CPROF_MARK(c, PF_SAVE);
+  return c.x.epoch;
 }
 
 template <int CL_DW>
@@ -310,13 +345,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_run(const DevModel *Mg, const
   for (int k = 0; k < n_iter; k++) {
     const int it = c.sc->iter;
     if (it >= total) break;
-    CPROF_START(c);
-    cl_transition_begin<CL_DW>(c, (uint32_t)it);
-    CPROF_MARK(c, PF_INITCOPY);
+    c.x.epoch = uni32(cl_cold_transition_begin<CL_DW>(Mg, CLg, Rg, chain, m, launch, c.x.epoch, (uint32_t)it));
     cl_transition_tree<CL_DW>(c, (uint32_t)it);
-    CPROF_START(c);
-    cl_transition_end<CL_DW>(c, R, chain, it);
-    CPROF_MARK(c, PF_SAVE);
+    c.x.epoch = uni32(cl_cold_transition_end<CL_DW>(Mg, CLg, Rg, chain, m, launch, c.x.epoch, (uint32_t)it));
   }
 #ifdef POTUS_PROF
   if (R->prof) for (int i = c.tid; i < PT_NPROF; i += PT_THREADS) as_g(R->prof)[((size_t)chain * CL->K + m) * PT_NPROF + i] += c.prof[i];
@@ -829,7 +860,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   const int DW = (T + K - 1) / K <= 3 * PT_NW ? 4 : 8;
   const int maxdays = PT_NW * DW;
   sp->cl_dw = DW;
-  C.XW = (XP_P + C.NR + 7) & ~7;
+  C.XW = (std::max(XP_P + C.NR, XQ0 + C.NREP) + 7) & ~7;
   if (P > 65535 || M.M > 255 || M.Pop > 255) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode packs pollster/mode/population indices in 16/8/8 bits");
   if (C.NREP > 2 * PT_THREADS) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: %d small parameters (> %d)", C.NREP, 2 * PT_THREADS);
   if ((C.NR + K - 1) / K > PT_THREADS - 128 - 3) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: too many pollsters for K = %d", K);
@@ -859,7 +890,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   if (groups_for(lo, &cut) > K) return fail(POTUS_ERR_UNSUPPORTED, "T = %d days do not fit %d members of at most %d days", T, K, maxdays);
   while ((int)cut.size() < K + 1) cut.push_back(T);   // members without days still own a share of the small vectors
 
-  std::vector<int> part((size_t)K * CP_N, 0), sched, perm(L.D, -1);
+  std::vector<int> part((size_t)K * CP_N, 0), sched, perm;   // perm: internal index -> Stan index, -1 for padding
   std::vector<double> wts;
   int e = 0, npmax = 0, nsubmax = 0;
   for (int m = 0; m < K; m++) {
@@ -868,14 +899,19 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
     const int r0 = (int)((long long)C.NR * m / K), nr = (int)((long long)C.NR * (m + 1) / K) - r0;
     pt_[CP_D0] = d0; pt_[CP_ND] = nd; pt_[CP_P0] = p0; pt_[CP_NP] = np; pt_[CP_E0] = e; pt_[CP_R0] = r0; pt_[CP_NR] = nr;
     npmax = std::max(npmax, np);
-    // internal order: days of raw_mu_b | noise of own polls | own days of raw_e_bias | share of the small vectors
-    for (int tl = 0; tl < nd; tl++) for (int k = 0; k < S; k++) perm[e + k + S * tl] = L.o_Z + k + S * (d0 + tl);
-    e += S * nd;
-    for (int il = 0; il < np; il++) perm[e + il] = sp->h_pq[p0 + il];
-    e += np;
-    if (full) { for (int tl = 0; tl < nd; tl++) perm[e + tl] = L.o_ze + d0 + tl; e += nd; }
-    for (int j = 0; j < nr; j++) { const int r = r0 + j; perm[e + j] = r < S ? L.o_zT + r : r < 2 * S ? L.o_zb + (r - S) : L.o_c + (r - 2 * S); }
-    e += nr;
+    // internal order: days of raw_mu_b | noise of own polls | pad | own days of raw_e_bias | share of the small
+    // vectors | pad.  The two blocks start on 128-byte lines: no cache line has two writers (members sit on
+    // different compute units, possibly different XCDs) or mixes plain stores (first block: read only by the owner)
+    // with write-through stores (second block: read by every member).
+    auto pad16 = [&]() { while (perm.size() % 16) perm.push_back(-1); };
+    for (int tl = 0; tl < nd; tl++) for (int k = 0; k < S; k++) perm.push_back(L.o_Z + k + S * (d0 + tl));
+    for (int il = 0; il < np; il++) perm.push_back(sp->h_pq[p0 + il]);
+    pad16();
+    pt_[CP_E_SH] = (int)perm.size();
+    if (full) for (int tl = 0; tl < nd; tl++) perm.push_back(L.o_ze + d0 + tl);
+    for (int j = 0; j < nr; j++) { const int r = r0 + j; perm.push_back(r < S ? L.o_zT + r : r < 2 * S ? L.o_zb + (r - S) : L.o_c + (r - 2 * S)); }
+    pad16();
+    e = (int)perm.size();
     pt_[CP_NE] = e - pt_[CP_E0];
 
     // the member's days are dealt to the waves as contiguous ranges of at most CL_DW days, balanced by
@@ -982,14 +1018,21 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
     pt_[CP_O_WT] = (int)wts.size();
     wts.insert(wts.end(), sub_wt.begin(), sub_wt.end());
   }
-  if (e != L.D) return fail(POTUS_ERR_STATE, "internal: cluster layout covers %d of %d parameters", e, L.D);
+  const int Dint = e;   // internal length of a vector (parameters + padding)
+  C.Dint = Dint;
   for (int k = 0; k < 16; k++) { sched.push_back(0); wts.push_back(0.0); }
   C.npmax = npmax; C.nsubmax = nsubmax;
 
-  std::vector<int> iperm(L.D);
-  for (int i = 0; i < L.D; i++) { if (perm[i] < 0 || perm[i] >= L.D) return fail(POTUS_ERR_STATE, "internal: bad permutation"); iperm[perm[i]] = i; }
-  std::vector<int> rep_pos(C.NREP);
-  for (int j = 0; j < C.NREP; j++) rep_pos[j] = iperm[j < S ? L.o_zT + j : j < 2 * S ? L.o_zb + (j - S) : L.o_c + (j - 2 * S)];
+  std::vector<int> iperm(L.D, -1);
+  for (int i = 0; i < Dint; i++) { if (perm[i] >= L.D) return fail(POTUS_ERR_STATE, "internal: bad permutation"); if (perm[i] >= 0) iperm[perm[i]] = i; }
+  for (int i = 0; i < L.D; i++) if (iperm[i] < 0) return fail(POTUS_ERR_STATE, "internal: cluster layout misses parameter %d", i);
+  std::vector<int> rep_pos(C.NREP), rep_owner(C.NREP);
+  for (int j = 0; j < C.NREP; j++) {
+    rep_pos[j] = iperm[j < S ? L.o_zT + j : j < 2 * S ? L.o_zb + (j - S) : L.o_c + (j - 2 * S)];
+    int mo = 0;
+    while (mo < K - 1 && rep_pos[j] >= part[(size_t)mo * CP_N + CP_E0] + part[(size_t)mo * CP_N + CP_NE]) mo++;   // owner = member whose element range holds it
+    rep_owner[j] = mo;
+  }
   std::vector<double> rep_scale(C.NR, 1.0);
   for (int i = 0; i < P; i++) rep_scale[2 * S + i] = d->sigma_c;
   if (full) {
@@ -1008,7 +1051,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   C.l_tab = take((npmax + 64) / 2 + 2); C.l_ru = take(npmax + 2);
   C.l_wide = take(CL_WIDE * PT_NW); C.l_wout = take(CL_WIDE);
   C.l_X = take(12 * M.SE);
-  C.l_Y = take(std::max(PT_NW * M.SE, nsubmax));
+  C.l_Y = take(std::max((PT_NW + 1) * M.SE, nsubmax));   // + the row of carries from later members
   C.l_r = take(npmax + 2);
   C.l_rep = take(C.NREP + 2);
   C.l_bT = take(M.SE); C.l_pb = take(M.SE); C.l_e = take(T); C.l_c1 = take(T); C.l_c2 = take(T); C.l_c3 = take(T);
@@ -1021,7 +1064,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
 
   int rc;
   if ((rc = upload(sp, part, &C.part)) || (rc = upload(sp, sched, &C.sched)) || (rc = upload(sp, wts, &C.wt)) ||
-      (rc = upload(sp, rep_pos, &C.rep_pos)) || (rc = upload(sp, rep_scale, &C.rep_scale)) || (rc = upload(sp, perm, &C.perm)))
+      (rc = upload(sp, rep_pos, &C.rep_pos)) || (rc = upload(sp, rep_owner, &C.rep_owner)) || (rc = upload(sp, rep_scale, &C.rep_scale)) || (rc = upload(sp, perm, &C.perm)))
     return rc;
   void *pc = nullptr;
   HIP_TRY(hipMalloc(&pc, sizeof(ClModel)));
@@ -1150,7 +1193,7 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   R.init_buffer = ib; R.term_buffer = tb; R.window = bw;
   R.delta = o->delta; R.gamma = o->gamma; R.kappa = o->kappa; R.t0 = o->t0; R.stepsize = o->stepsize; R.init_radius = o->init_radius;
   R.seed_lo = (unsigned)(o->seed & 0xFFFFFFFFu); R.seed_hi = (unsigned)(o->seed >> 32);
-  R.Dpad = (sp->L.D + 7) & ~7;
+  R.Dpad = sp->K > 1 ? ((sp->CL.Dint + 15) & ~15) : ((sp->L.D + 7) & ~7);
   R.row = POTUS_N_SAMPLER_COLS + sp->L.D;
   R.n_save_max = o->num_samples + (o->save_warmup ? o->num_warmup : 0);
   void *p = nullptr;
@@ -1359,10 +1402,11 @@ int potus_get_adaptation(int handle, double *stepsize, double *inv_metric) {
     if (stepsize) stepsize[c] = sc[c].nom_eps;
     if (inv_metric) {
       double *dst = inv_metric + (size_t)c * sp->L.D;
-      HIP_TRY(hipMemcpy(dst, sp->R.state + ((size_t)c * V_COUNT + V_MINV) * sp->R.Dpad, (size_t)sp->L.D * 8, hipMemcpyDeviceToHost));
-      if (sp->K > 1) {   // the cluster keeps its vectors in internal order
-        std::vector<double> tmp(dst, dst + sp->L.D);
-        for (int i = 0; i < sp->L.D; i++) dst[sp->h_perm[i]] = tmp[i];
+      if (sp->K == 1) HIP_TRY(hipMemcpy(dst, sp->R.state + ((size_t)c * V_COUNT + V_MINV) * sp->R.Dpad, (size_t)sp->L.D * 8, hipMemcpyDeviceToHost));
+      if (sp->K > 1) {   // the cluster keeps its vectors in internal order (with padding)
+        std::vector<double> tmp(sp->CL.Dint);
+        HIP_TRY(hipMemcpy(tmp.data(), sp->R.state + ((size_t)c * V_COUNT + V_MINV) * sp->R.Dpad, (size_t)sp->CL.Dint * 8, hipMemcpyDeviceToHost));
+        for (int i = 0; i < sp->CL.Dint; i++) if (sp->h_perm[i] >= 0) dst[sp->h_perm[i]] = tmp[i];
       }
     }
   }
@@ -1541,6 +1585,18 @@ int potus_debug_profile(int handle, double *out) {
   (void)hipSetDevice(sp->device);
   if (hipMemcpy(out, sp->R.prof, sizeof(double) * PT_NPROF * sp->R.chains * sp->K, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return PT_NPROF;
+}
+
+// Development aid: the whole state block [chains][V_COUNT][Dpad] (internal element order) and every replica of the
+// chain scalars as raw bytes.  which = 0: sizes only (out[0] = V_COUNT, out[1] = Dpad, out[2] = sizeof scalars * replicas).
+int potus_debug_state(int handle, int which, double *out, unsigned char *scal) {
+  Sampler *sp = get(handle);
+  if (!sp || !out) return 0;
+  (void)hipSetDevice(sp->device);
+  if (which == 0) { out[0] = V_COUNT; out[1] = sp->R.Dpad; out[2] = (double)(sizeof(ChainScalars) * sp->R.chains * sp->K); return 1; }
+  if (hipMemcpy(out, sp->R.state, sizeof(double) * V_COUNT * sp->R.Dpad * sp->R.chains, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  if (scal && hipMemcpy(scal, sp->R.scal, sizeof(ChainScalars) * sp->R.chains * sp->K, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  return 1;
 }
 
 // ---------------------------------------------------------------- .C() wrappers

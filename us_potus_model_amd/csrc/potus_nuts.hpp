@@ -30,7 +30,7 @@
 extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
 
 #define PT_MAXD 12
-#define PT_NPP (2 * PT_MAXD + 4)
+#define PT_NPP (2 * PT_MAXD + 6)
 #define PT_NPQ (PT_MAXD + 6)
 
 enum { RNG_MOMENTUM = 0, RNG_DIRECTION = 1, RNG_TOP_ACCEPT = 2, RNG_SUB_ACCEPT = 3, RNG_INIT_EPS = 4, RNG_INITS = 5 };
@@ -93,7 +93,7 @@ struct TS { // transition state, LDS
   double pend_lsw[PT_MAXD + 1];
   double q_lp[PT_NPQ], q_h[PT_NPQ];
   double accept_stat, out_lp, out_h, delta_H;
-  double u_sub[PT_MAXD + 1], u_top;   // cluster mode: uniforms of the leaf's accept steps, drawn ahead by idle lanes
+  double u_sub[2][PT_MAXD + 1], u_top;   // cluster mode: uniforms of a leaf's accept steps, drawn ahead by idle lanes (by leaf parity)
   int pend_beg[PT_MAXD + 1], pend_end[PT_MAXD + 1], pend_prop[PT_MAXD + 1];
   int cur_beg, cur_end, cur_prop;
   unsigned pmask, qmask;
