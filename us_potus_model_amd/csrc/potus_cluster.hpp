@@ -125,15 +125,21 @@ __device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], c
   bool all = true;
 #pragma unroll
   for (int u = 0; u < NB; u++) { done[u] = __all(vo[u] == PT_OOB || (w[u][2] == x.epoch && w[u][3] == x.launch)); all = all && done[u]; }
-  // words that were not there yet are fetched again together; words already in hand are not re-read (an
-  // out-of-range offset costs no memory traffic), so a spinning wave does not flood the memory pipeline
+  // Words that were not there yet are fetched again (words already in hand are not re-read, so a spinning wave
+  // does not flood the memory pipeline).  The re-fetch must stay an agent-scope (sc1) load: the `volatile` flavour of
+  // the builtin becomes a system-scope load that costs ~2 us per round here.  What keeps the compiler from hoisting
+  // it out of the loop is the laundered offset and the memory clobber.
   for (unsigned spins = 0; !all; spins++) {
     if (spins > CL_SPIN_LIMIT) __builtin_trap();   // a member is missing: fail loudly instead of hanging the GPU
     __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int u = 0; u < NB; u++)
-      if (!done[u]) w[u] = __builtin_amdgcn_raw_buffer_load_b128(x.xb, vo[u], so[u], CL_AUX_SC1 | (int)0x80000000);
+      if (!done[u]) {
+        unsigned v = vo[u];
+        asm volatile("" : "+v"(v));
+        w[u] = __builtin_amdgcn_raw_buffer_load_b128(x.xb, v, so[u], CL_AUX_SC1);
+      }
     all = true;
 #pragma unroll
     for (int u = 0; u < NB; u++) {
@@ -257,57 +263,77 @@ __device__ __forceinline__ void cl_wide_consume(const Xch &x, unsigned tag, int 
 struct LeafCtx { int n, m, top, depth, dir, leaf, inq, outq, nv; unsigned tag; };
 
 // totals: wout[0] = lp, [1] = kinetic, [2 + 6 (j-1) ..] the six dot products of level j, then the top check.
-__device__ __forceinline__ void cl_leaf_logic(ltp ts, const LeafCtx &L, ldp wout) {   // thread 0
+// Run by every lane of wave 0 with identical values (uniform control flow, lane 0 stores): what the verdicts read from
+// LDS is fetched in one round -- the scalars by all lanes, the data of subtree level j by lane j-1 -- and then handed
+// around with v_readlane, instead of some thirty dependent LDS round trips of a single thread.
+__device__ __forceinline__ void cl_leaf_logic(ltp ts, const LeafCtx &L, ldp wout) {   // wave 0
+  const int lane = threadIdx.x & 63;
   const int m = L.m, leaf = L.leaf, inq = L.inq;
-  const double H0 = ts->H0, lpv = wout[0];
-  double h = 0.5 * wout[1] - lpv;
+  const int jl = lane < m ? lane : 0;              // this lane holds level jl + 1
+  const double H0 = ts->H0, lpv = wout[0], kin = wout[1], sum_metro0 = ts->sum_metro, lsw_top = ts->lsw, u_top = ts->u_top;
+  const int div0 = ts->divergent, n_leap0 = ts->n_leap, sample0 = ts->sample_qid;
+  unsigned qm = ts->qmask, pm = ts->pmask;
+  const int l_pb = ts->pend_beg[jl], l_pe = ts->pend_end[jl], l_pp = ts->pend_prop[jl];
+  const double l_pl = ts->pend_lsw[jl], l_us = ts->u_sub[L.n & 1][jl + 1];
+  int l_persist, t_persist;
+  {
+    ldp d = wout + 2 + 6 * jl;
+    const double d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5];
+    ldp e = wout + 2 + 6 * m;                        // the doubling's own check (meaningful for the last leaf)
+    const double e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4], e5 = e[5];
+    l_persist = d0 > 0 && d1 > 0 && d2 > 0 && d3 > 0 && d4 > 0 && d5 > 0;
+    t_persist = e0 > 0 && e1 > 0 && e2 > 0 && e3 > 0 && e4 > 0 && e5 > 0;
+  }
+  double h = 0.5 * kin - lpv;
   if (isnan(h)) h = INFINITY;
-  const int div = (h - H0 > 1000.0) ? 1 : ts->divergent;
-  ts->divergent = div;
+  const int div = (h - H0 > 1000.0) ? 1 : div0;
   const double wgt = H0 - h;
-  ts->sum_metro += wgt > 0 ? 1.0 : exp(wgt);
-  ts->n_leap += 1;
-  ts->nextq[L.dir] = L.outq;                      // the next leaf of this end evaluates the position just written
+  const double sum_metro = sum_metro0 + (wgt > 0 ? 1.0 : exp(wgt));
   int cur_beg = leaf, cur_prop = inq, abort = div;   // the leaf's own position is its subtree's first proposal
   const int cur_end = leaf;
   double cur_lsw = wgt;
-  unsigned qm = ts->qmask, pm = ts->pmask;
-  ts->q_lp[inq] = lpv; ts->q_h[inq] = h;
-  for (int j = 1; j <= m && !abort; j++) {
-    const int ib = ts->pend_beg[j - 1], ie = ts->pend_end[j - 1], cb = cur_beg;
-    ldp d = wout + 2 + 6 * (j - 1);
-    const bool persist = d[0] > 0 && d[1] > 0 && d[2] > 0 && d[3] > 0 && d[4] > 0 && d[5] > 0;
-    const double lsw_sub = d_lse(ts->pend_lsw[j - 1], cur_lsw);
+  for (int j = 1; j <= m && !abort; j++) {           // wave-uniform
+    const int ib = __builtin_amdgcn_readlane(l_pb, j - 1), ie = __builtin_amdgcn_readlane(l_pe, j - 1), pprop = __builtin_amdgcn_readlane(l_pp, j - 1);
+    const int persist = __builtin_amdgcn_readlane(l_persist, j - 1), cb = cur_beg;
+    const double lsw_sub = d_lse(dpp_readlane_d(l_pl, j - 1), cur_lsw);
     bool take_final;
     if (cur_lsw > lsw_sub) take_final = true;
-    else take_final = ts->u_sub[L.n & 1][j] < exp(cur_lsw - lsw_sub);
-    if (take_final) pool_free(qm, ts->pend_prop[j - 1]);
-    else { pool_free(qm, cur_prop); cur_prop = ts->pend_prop[j - 1]; }
+    else take_final = dpp_readlane_d(l_us, j - 1) < exp(cur_lsw - lsw_sub);
+    if (take_final) pool_free(qm, pprop);
+    else { pool_free(qm, cur_prop); cur_prop = pprop; }
     if (ie != ib) pool_free(pm, ie);
     if (cb != cur_end) pool_free(pm, cb);
     cur_beg = ib;
     cur_lsw = lsw_sub;
     abort = !persist;
   }
-  if (!abort) {
-    const int prop = cur_prop;
-    ts->pend_beg[m] = cur_beg; ts->pend_end[m] = cur_end; ts->pend_lsw[m] = cur_lsw; ts->pend_prop[m] = prop;
-    if (L.top) {
-      ldp d = wout + 2 + 6 * m;
-      const bool persist = d[0] > 0 && d[1] > 0 && d[2] > 0 && d[3] > 0 && d[4] > 0 && d[5] > 0;
-      ts->depth = L.depth + 1;
-      const double lsw_sub = cur_lsw, lsw = ts->lsw;
-      bool accept;
-      if (lsw_sub > lsw) accept = true;
-      else accept = ts->u_top < exp(lsw_sub - lsw);
-      if (accept) { pool_free(qm, ts->sample_qid); ts->sample_qid = prop; }
-      else pool_free(qm, prop);
-      ts->lsw = d_lse(lsw, lsw_sub);
-      if (!persist) ts->stop = 1;
-    }
+  int depth_new = -1, stop_new = 0, sample_new = sample0;
+  double lsw_new = lsw_top;
+  if (!abort && L.top) {
+    depth_new = L.depth + 1;
+    const double lsw_sub = cur_lsw;
+    bool accept;
+    if (lsw_sub > lsw_top) accept = true;
+    else accept = u_top < exp(lsw_sub - lsw_top);
+    if (accept) { pool_free(qm, sample0); sample_new = cur_prop; }
+    else pool_free(qm, cur_prop);
+    lsw_new = d_lse(lsw_top, lsw_sub);
+    stop_new = !t_persist;
   }
-  ts->qmask = qm; ts->pmask = pm;
-  ts->abort = abort;
+  if (lane == 0) {
+    ts->divergent = div; ts->sum_metro = sum_metro; ts->n_leap = n_leap0 + 1;
+    ts->nextq[L.dir] = L.outq;                      // the next leaf of this end evaluates the position just written
+    ts->q_lp[inq] = lpv; ts->q_h[inq] = h;
+    if (!abort) {
+      ts->pend_beg[m] = cur_beg; ts->pend_end[m] = cur_end; ts->pend_lsw[m] = cur_lsw; ts->pend_prop[m] = cur_prop;
+      if (L.top) {
+        ts->depth = depth_new; ts->sample_qid = sample_new; ts->lsw = lsw_new;
+        if (stop_new) ts->stop = 1;
+      }
+    }
+    ts->qmask = qm; ts->pmask = pm;
+    ts->abort = abort;
+  }
 }
 __device__ __forceinline__ void cl_sync(Xch &x, ldp red) {
   double v[1] = {0.0};
@@ -624,6 +650,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // suffix totals of the members that own later days: fetched once per workgroup (wave 0, which has
   // nothing else to do here) and handed to the other waves through LDS
   if (w == 0) {
+    WPROF_PT(27);
     double carry_m = 0.0;
     for (int mm0 = m + 1; mm0 < K; mm0 += 16) {
       double t16[16];
@@ -639,9 +666,12 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       for (int u = 0; u < 16; u++) carry_m += t16[u];
     }
     if (lane < S) Y[PT_NW * SE + lane] = carry_m;
+    WPROF_PT(28);
     if (pend.n >= 0) {                              // the previous leaf's totals and verdicts, off the critical path
       cl_wide_consume(x, pend.tag, pend.nv, wout);
-      if (tid == 0) cl_leaf_logic(ts, pend, wout);
+      WPROF_PT(29);
+      cl_leaf_logic(ts, pend, wout);
+      WPROF_PT(30);
     }
   }
   WPROF_ACC(0);
@@ -1401,7 +1431,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
       // last leaf of the doubling: its verdicts are needed before anything else can start
       if (tid < 64) {
         cl_wide_consume(c.x, tag, nv, wout);
-        if (tid == 0) cl_leaf_logic(ts, cur, wout);
+        cl_leaf_logic(ts, cur, wout);
       }
       __syncthreads();
       CPROF_MARK(c, PF_LEAF_SCALAR);

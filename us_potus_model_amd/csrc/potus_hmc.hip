@@ -868,7 +868,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
 
   // contiguous day ranges: minimise the largest cost (a day = S elements of vector work, a poll = a
   // 51-term dot + a gather) with at most CL_MAXDAYS days each
-  const int cw_day = getenv("POTUS_CW_DAY") ? atoi(getenv("POTUS_CW_DAY")) : S, cw_poll = getenv("POTUS_CW_POLL") ? atoi(getenv("POTUS_CW_POLL")) : 4;
+  const int cw_day = getenv("POTUS_CW_DAY") ? atoi(getenv("POTUS_CW_DAY")) : S, cw_poll = getenv("POTUS_CW_POLL") ? atoi(getenv("POTUS_CW_POLL")) : 10;
   auto groups_for = [&](int B, std::vector<int> *cut) {
     int g = 0, t = 0;
     if (cut) cut->assign(1, 0);
@@ -898,6 +898,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
     const int d0 = cut[m], nd = cut[m + 1] - cut[m], p0 = dp[d0], np = dp[d0 + nd] - p0;
     const int r0 = (int)((long long)C.NR * m / K), nr = (int)((long long)C.NR * (m + 1) / K) - r0;
     pt_[CP_D0] = d0; pt_[CP_ND] = nd; pt_[CP_P0] = p0; pt_[CP_NP] = np; pt_[CP_E0] = e; pt_[CP_R0] = r0; pt_[CP_NR] = nr;
+    if (getenv("POTUS_CL_VERBOSE")) fprintf(stderr, "cluster member %2d: days [%3d, %3d) = %2d, polls %4d, small-vector slots %3d\n", m, d0, d0 + nd, nd, np, nr);
     npmax = std::max(npmax, np);
     // internal order: days of raw_mu_b | noise of own polls | pad | own days of raw_e_bias | share of the small
     // vectors | pad.  The two blocks start on 128-byte lines: no cache line has two writers (members sit on
