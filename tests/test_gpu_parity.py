@@ -45,6 +45,34 @@ def test_log_prob_grad_matches_oracle_and_golden(cases, name, cus):
     h.close()
 
 
+def test_stress_shape_log_prob_grad_and_first_transitions():
+    """BASELINE configs[4] sizes (51 states x 600 days x 10 000 polls, D = 41 610; diagonal metric): beyond the
+    one-workgroup kernels (T > 256), so the library must pick a cluster by itself and refuse cus_per_chain = 1."""
+    from us_potus_model_amd import synthetic
+    data = synthetic.stress()
+    with pytest.raises(sampler.PotusError, match="T = 600"):
+        Handle(data, "full", chains=1, cus_per_chain=1)
+    iters = 3
+    h = Handle(data, "full", chains=2, num_warmup=iters, num_samples=0, save_warmup=1, seed=5)
+    assert h.D == 41610 and h.cus_per_chain in (16, 32)     # chosen by the library (LDS of the poll-heavy members)
+    m = OracleModel(data, "full")
+    rng = np.random.default_rng(5)
+    q = np.vstack([np.zeros((1, h.D)), rng.uniform(-2, 2, (2, h.D)), 0.2 * rng.standard_normal((2, h.D))])
+    lp, grad = h.log_prob_grad(q)
+    for i in range(q.shape[0]):
+        lpo, go = m.log_prob_grad(q[i])
+        assert abs(lp[i] - lpo) <= LP_RTOL * abs(lpo), (i, lp[i], lpo)
+        assert np.abs(grad[i] - go).max() <= GRAD_RTOL * np.abs(go).max(), i
+    h.init(); h.run(iters)
+    d = h.draws()
+    o = m.default_opts(num_warmup=iters, num_samples=0, save_warmup=1, seed=5, fast_grad=1)
+    for c in (0, 1):
+        ref = m.sample_chain(c + 1, o)[0]
+        assert np.array_equal(d[c][:, 3:6], ref[:, 3:6]), (c, d[c][:, :7], ref[:, :7])   # depth, n_leapfrog, divergent
+        assert np.allclose(d[c][:, 7:], ref[:, 7:], rtol=1e-6, atol=1e-7)
+    h.close()
+
+
 @pytest.mark.parametrize("cus", [1, 16])
 def test_log_prob_grad_is_deterministic_and_batched(cases, cus):
     data, variant = cases["2016"]

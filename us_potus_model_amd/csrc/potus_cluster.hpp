@@ -591,7 +591,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   if (w == 1) {
     if (full) {
       // e_bias (stan:91-93): d[t] = e[t]-mu_e = rho d[t-1] + sigma_rho z[t].  Each lane owns four consecutive
-      // days (T <= 256); affine scan across lanes on the DPP path.  The three tangent recurrences that turn the
+      // days of a round of 256; affine scan across lanes on the DPP path.  The three tangent recurrences that turn the
       // adjoint sums of mu_e_bias / rho_e_bias into per-day dot products,
       //   c1[t] = rho c1[t-1] + 1, c2[t] = rho c2[t-1] + d[t-1], c3[t] = rho c3[t-1] + z[t]   (c.[0] = 0),
       // are only needed in phase E2 and run in phase C on an idle wave.
@@ -601,26 +601,31 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       const double mue = 0.02 * xm, rho = d_inv_logit(xr);
       const double srho = sqrt(1.0 - rho * rho) * sigma_e;
       constexpr int PER = 4;
-      const int ta = lane * PER;
-      double z[PER];
+      double d_in = 0.0;                                 // d[base - 1]
+      for (int base = 0; base < T; base += 64 * PER) {   // one round unless T > 256
+        const int ta = base + lane * PER;
+        double z[PER];
 #pragma unroll
-      for (int u = 0; u < PER; u++) z[u] = ze[min(ta + u, T - 1)];
-      ISSUE_FENCE();
-      double A = 1.0, Bd[1] = {0.0};
+        for (int u = 0; u < PER; u++) z[u] = ze[min(ta + u, T - 1)];
+        ISSUE_FENCE();
+        double A = 1.0, Bd[1] = {0.0};
 #pragma unroll
-      for (int u = 0; u < PER; u++) {
-        const int t = ta + u;
-        const bool in = t < T, first = t == 0;
-        const double An = first ? 0.0 : rho * A, Bn = first ? z[u] * sigma_e - mue : rho * Bd[0] + srho * z[u];
-        A = in ? An : A; Bd[0] = in ? Bn : Bd[0];
-      }
-      dpp_scan_affine(A, Bd);
-      double d = dpp_prev_lane(Bd[0], 0.0);
+        for (int u = 0; u < PER; u++) {
+          const int t = ta + u;
+          const bool in = t < T, first = t == 0;
+          const double An = first ? 0.0 : rho * A, Bn = first ? z[u] * sigma_e - mue : rho * Bd[0] + srho * z[u];
+          A = in ? An : A; Bd[0] = in ? Bn : Bd[0];
+        }
+        dpp_scan_affine(A, Bd);
+        double d = dpp_prev_lane(A, 1.0) * d_in + dpp_prev_lane(Bd[0], 0.0);   // composite of the lanes before this one
 #pragma unroll
-      for (int u = 0; u < PER; u++) {
-        const int t = ta + u;
-        d = t == 0 ? z[u] * sigma_e - mue : rho * d + srho * z[u];
-        if (t < T) s_e[t] = d + mue;
+        for (int u = 0; u < PER; u++) {
+          const int t = ta + u;
+          const double dn = t == 0 ? z[u] * sigma_e - mue : rho * d + srho * z[u];
+          d = t < T ? dn : d;
+          if (t < T) s_e[t] = d + mue;
+        }
+        d_in = dpp_readlane_d(d, 63);
       }
       if (lane == 0) { s_scal[SC_MUE] = mue; s_scal[SC_RHO] = rho; s_scal[SC_SRHO] = srho; s_scal[SC_XMUE] = xm; s_scal[SC_XRHO] = xr; }
     }
@@ -727,28 +732,34 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       const double rho = s_scal[SC_RHO], mue = s_scal[SC_MUE], sigma_e = M->sigma_e;
       ldp ze = s_mid + (M->o_ze - o_c);
       constexpr int PER = 4;
-      const int ta = lane * PER;
-      double z[PER], dp[PER];
+      double c1_in = 0.0, c2_in = 0.0, c3_in = 0.0;
+      for (int base = 0; base < T; base += 64 * PER) {   // one round unless T > 256
+        const int ta = base + lane * PER;
+        double z[PER], dp[PER];
 #pragma unroll
-      for (int u = 0; u < PER; u++) { const int t = ta + u; z[u] = ze[min(t, T - 1)]; dp[u] = s_e[min(max(t - 1, 0), T - 1)] - mue; }
-      ISSUE_FENCE();
-      double A2 = 1.0, Bc[3] = {0.0, 0.0, 0.0};
+        for (int u = 0; u < PER; u++) { const int t = ta + u; z[u] = ze[min(t, T - 1)]; dp[u] = s_e[min(max(t - 1, 0), T - 1)] - mue; }
+        ISSUE_FENCE();
+        double A2 = 1.0, Bc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-      for (int u = 0; u < PER; u++) {
-        const int t = ta + u;
-        const bool in = t < T, first = t == 0;
-        const double An = first ? 0.0 : rho * A2;
-        const double B1 = first ? 0.0 : rho * Bc[0] + 1.0, B2 = first ? 0.0 : rho * Bc[1] + dp[u], B3 = first ? 0.0 : rho * Bc[2] + z[u];
-        A2 = in ? An : A2; Bc[0] = in ? B1 : Bc[0]; Bc[1] = in ? B2 : Bc[1]; Bc[2] = in ? B3 : Bc[2];
-      }
-      dpp_scan_affine(A2, Bc);
-      double c1 = dpp_prev_lane(Bc[0], 0.0), c2 = dpp_prev_lane(Bc[1], 0.0), c3 = dpp_prev_lane(Bc[2], 0.0);
+        for (int u = 0; u < PER; u++) {
+          const int t = ta + u;
+          const bool in = t < T, first = t == 0;
+          const double An = first ? 0.0 : rho * A2;
+          const double B1 = first ? 0.0 : rho * Bc[0] + 1.0, B2 = first ? 0.0 : rho * Bc[1] + dp[u], B3 = first ? 0.0 : rho * Bc[2] + z[u];
+          A2 = in ? An : A2; Bc[0] = in ? B1 : Bc[0]; Bc[1] = in ? B2 : Bc[1]; Bc[2] = in ? B3 : Bc[2];
+        }
+        dpp_scan_affine(A2, Bc);
+        const double Ap = dpp_prev_lane(A2, 1.0);
+        double c1 = Ap * c1_in + dpp_prev_lane(Bc[0], 0.0), c2 = Ap * c2_in + dpp_prev_lane(Bc[1], 0.0), c3 = Ap * c3_in + dpp_prev_lane(Bc[2], 0.0);
 #pragma unroll
-      for (int u = 0; u < PER; u++) {
-        const int t = ta + u;
-        const bool first = t == 0;
-        c1 = first ? 0.0 : rho * c1 + 1.0; c2 = first ? 0.0 : rho * c2 + dp[u]; c3 = first ? 0.0 : rho * c3 + z[u];
-        if (t < T) { s_c1[t] = c1; s_c2[t] = c2; s_c3[t] = c3; }
+        for (int u = 0; u < PER; u++) {
+          const int t = ta + u;
+          const bool first = t == 0, in = t < T;
+          const double n1 = first ? 0.0 : rho * c1 + 1.0, n2 = first ? 0.0 : rho * c2 + dp[u], n3 = first ? 0.0 : rho * c3 + z[u];
+          c1 = in ? n1 : c1; c2 = in ? n2 : c2; c3 = in ? n3 : c3;
+          if (in) { s_c1[t] = c1; s_c2[t] = c2; s_c3[t] = c3; }
+        }
+        c1_in = dpp_readlane_d(c1, 63); c2_in = dpp_readlane_d(c2, 63); c3_in = dpp_readlane_d(c3, 63);
       }
       if (lane == 0) {
         // what the owner of rho_e_bias needs in phase F: Jacobian + prior of rho (stan:63,124), d sigma_rho / d rho

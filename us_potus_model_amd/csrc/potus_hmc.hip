@@ -617,6 +617,7 @@ struct Sampler {
   double sigma_ns = 0, sigma_nn = 0;
   std::vector<void *> allocs;
   size_t lds_bytes = 0;
+  std::string k1_unsupported;   // why the one-workgroup kernels cannot run this model (empty: they can); cluster mode may still
   bool inited = false;
   double last_ms = 0;
   long long last_leapfrogs = 0;
@@ -662,7 +663,8 @@ int build_model(Sampler *sp, const potus_data *d) {
   DevModel &M = sp->M;
   const Layout &L = sp->L;
   if (S + 1 > 64) return fail(POTUS_ERR_UNSUPPORTED, "S = %d: this kernel maps states to the 64 lanes of a wave (S <= 63)", S);
-  if (T > PT_NW * PT_CH) return fail(POTUS_ERR_UNSUPPORTED, "T = %d: the LDS-resident kernel handles T <= %d days", T, PT_NW * PT_CH);
+  auto k1_fail = [&](const char *fmt, auto... args) { char buf[256]; std::snprintf(buf, sizeof buf, fmt, args...); if (sp->k1_unsupported.empty()) sp->k1_unsupported = buf; };
+  if (T > PT_NW * PT_CH) k1_fail("T = %d: one workgroup per chain handles T <= %d days", T, PT_NW * PT_CH);
   M.S = S; M.T = T; M.P = d->P; M.M = full ? d->M : 0; M.Pop = full ? d->Pop : 0; M.Ns = Ns; M.Nn = Nn; M.Npoll = Ns + Nn;
   M.D = L.D; M.full = full;
   M.SE = S + 1; M.SP = S | 1; M.TP = T | 1;
@@ -728,7 +730,7 @@ int build_model(Sampler *sp, const potus_data *d) {
     const int nt = day_ptr[t + 1] - day_ptr[t];
     for (int wv = 0; wv < PT_NW; wv++)
       if (wt[wv].size() < 64 && npolls_w[wv] + nt <= 256 && (wmin < 0 || load[wv] < load[wmin])) wmin = wv;
-    if (wmin < 0) return fail(POTUS_ERR_UNSUPPORTED, "poll schedule does not fit: more than %d polls", 256 * PT_NW);
+    if (wmin < 0) { k1_fail("poll schedule of one workgroup per chain does not fit: more than %d polls or %d polled days", 256 * PT_NW, 64 * PT_NW); break; }
     npolls_w[wmin] += nt;
     wt[wmin].push_back(t);
     load[wmin] += day_ptr[t + 1] - day_ptr[t] + 2;
@@ -739,10 +741,10 @@ int build_model(Sampler *sp, const potus_data *d) {
     for (size_t j = 0; j < wt[wv].size(); j++) {
       const int t = wt[wv][j];
       wd_t[wv * 64 + j] = t; wd_a[wv * 64 + j] = day_ptr[t]; wd_b[wv * 64 + j] = day_ptr[t + 1];
-      for (int i = day_ptr[t]; i < day_ptr[t + 1]; i++, e++) wpk[wv * 64 + e / 4] |= ps[i] << (8 * (e % 4));
+      for (int i = day_ptr[t]; i < day_ptr[t + 1]; i++, e++) if (e < 256) wpk[wv * 64 + e / 4] |= ps[i] << (8 * (e % 4));
     }
   }
-  for (int t = 0; t < T; t++) if (day_ptr[t + 1] > day_ptr[t]) daymask[t / PT_CH] |= (int)(1u << (t % PT_CH));
+  for (int t = 0; t < T && t < PT_NW * PT_CH; t++) if (day_ptr[t + 1] > day_ptr[t]) daymask[t / PT_CH] |= (int)(1u << (t % PT_CH));
 
   // two-level segment sums: level-1 tasks of <= PT_SUBLEN polls (padded with the zero slot Npoll),
   // level-2 one thread per segment
@@ -794,8 +796,7 @@ int build_model(Sampler *sp, const potus_data *d) {
 #endif
   M.lds_doubles = o;
   sp->lds_bytes = (size_t)o * 8 + sizeof(TS) + 16;
-  if (sp->lds_bytes > 160 * 1024)
-    return fail(POTUS_ERR_UNSUPPORTED, "model needs %zu bytes of LDS per workgroup (> 160 KiB): T=%d, polls=%d", sp->lds_bytes, T, Np);
+  if (sp->lds_bytes > 160 * 1024) k1_fail("one workgroup per chain needs %zu bytes of LDS (> 160 KiB): T=%d, polls=%d", sp->lds_bytes, T, Np);
 
   int rc;
   // pack: mat = Lw_ext | LT_t | LB_t | LT | LB | prior | w
@@ -855,7 +856,6 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   C.K = K;
   C.NR = 2 * S + P + (full ? M.M + M.Pop + 2 : 0);
   C.NREP = 2 * S + M.nmid;
-  C.NDP = CL_MAXDAYS + 1;
   // days per wave: 4 (at most 32 days per member) when that leaves room to balance the members by polls, else 8
   const int DW = (T + K - 1) / K <= 3 * PT_NW ? 4 : 8;
   const int maxdays = PT_NW * DW;
@@ -1044,6 +1044,11 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
 
   int o = 0;
   auto take = [&](int n) { const int a = o; o += (n + 1) & ~1; return a; };
+  {
+    int ndmax = 1;
+    for (int m = 0; m < K; m++) ndmax = std::max(ndmax, part[(size_t)m * CP_N + CP_ND]);
+    C.NDP = ndmax | 1;   // odd row stride of the member's C[state][local day] block
+  }
   C.l_C = take(std::max(S * C.NDP, 12 * M.SE));
   C.l_Lw = take((M.SE + 1) * M.SP);
   C.l_LT = take(S * M.SP); C.l_LB = take(S * M.SP); C.l_w = take(M.SE); C.l_prior = take(M.SE);
@@ -1171,15 +1176,29 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   sp->device = o->device; sp->opts = *o; sp->L = make_layout(d);
   auto bail = [&](int code) { for (void *p : sp->allocs) (void)hipFree(p); delete sp; return code; };
   if ((rc = build_model(sp, d))) return bail(rc);
-  if ((rc = set_lds_attr(sp))) return bail(rc);
+  if (sp->k1_unsupported.empty() && (rc = set_lds_attr(sp))) return bail(rc);
   {
     // workgroups (CUs) per chain: 0 = as many as fit the device, in {16, 8, 1}; chains * K blocks must be co-resident
     const int ncu = prop.multiProcessorCount;
     int K = o->cus_per_chain;
     if (K < 0 || K > CL_MAXK) return bail(fail(POTUS_ERR_ARG, "cus_per_chain must be in [0,%d]", CL_MAXK));
-    if (K == 0) K = o->chains * 16 <= ncu ? 16 : o->chains * 8 <= ncu ? 8 : 1;
+    if (K == 0) {
+      K = o->chains * 16 <= ncu ? 16 : o->chains * 8 <= ncu ? 8 : 1;
+      // models beyond the one-workgroup kernels (T > 256, > 2048 polls) need a cluster; long campaigns need more members
+      if (K == 1 && !sp->k1_unsupported.empty()) K = 8;
+      while (K > 1 && d->T > K * CL_MAXDAYS && 2 * K <= CL_MAXK) K *= 2;
+      if (K > 1 && o->chains * K > ncu)
+        return bail(fail(POTUS_ERR_UNSUPPORTED, "%s, and %d chains x %d compute units do not fit the %d of the device",
+                         sp->k1_unsupported.empty() ? "T needs more members per chain" : sp->k1_unsupported.c_str(), o->chains, K, ncu));
+    } else if (K == 1 && !sp->k1_unsupported.empty())
+      return bail(fail(POTUS_ERR_UNSUPPORTED, "%s; use cus_per_chain = 0 or >= 8", sp->k1_unsupported.c_str()));
     if (K > 1 && o->chains * K > ncu) return bail(fail(POTUS_ERR_ARG, "chains * cus_per_chain = %d exceeds the %d compute units of the device", o->chains * K, ncu));
-    if (K > 1 && (rc = build_cluster(sp, d, K))) return bail(rc);
+    if (K > 1) {
+      rc = build_cluster(sp, d, K);
+      // chosen by the library: a member whose polls do not fit its LDS gets half of them with twice the members
+      while (rc == POTUS_ERR_UNSUPPORTED && o->cus_per_chain == 0 && 2 * K <= CL_MAXK && o->chains * 2 * K <= ncu) { K *= 2; rc = build_cluster(sp, d, K); }
+      if (rc) return bail(rc);
+    }
   }
   if (hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&sp->ev0) != hipSuccess ||
       hipEventCreate(&sp->ev1) != hipSuccess)
