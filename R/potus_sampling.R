@@ -28,10 +28,12 @@ potus_load <- function(path) dyn.load(path)
   }
 }
 
+# gpus: device ids; the chains are dealt to them in contiguous blocks (chain ids, hence RNG streams and draws, do not
+# depend on the number of GPUs) and all devices advance together under potus_R_run_many.
 potus_sample <- function(data, variant = c("full", "no_mode_adjustment"), seed = 1843, chains = 4,
                          parallel_chains = chains, iter_warmup = 1000, iter_sampling = 1000, refresh = 100,
                          adapt_delta = 0.8, max_treedepth = 10, init = 2, device = 0, chain_id_offset = 0,
-                         save_warmup = FALSE) {
+                         save_warmup = FALSE, gpus = device) {
   variant <- match.arg(variant)
   full <- variant == "full"
   iv <- function(x, n) if (is.null(x)) integer(max(n, 1)) else as.integer(x)
@@ -43,38 +45,55 @@ potus_sample <- function(data, variant = c("full", "no_mode_adjustment"), seed =
                          data$sigma_measure_noise_national, data$sigma_measure_noise_state,
                          if (full) data$sigma_e_bias else 0, data$random_walk_scale, data$mu_b_T_scale,
                          data$polling_bias_scale))
-  res <- .C("potus_R_create", dims,
-            iv(data$state, Ns), iv(data$day_state, Ns), iv(data$day_national, Nn), iv(data$poll_state, Ns),
-            iv(data$poll_national, Nn), iv(data$poll_mode_state, Ns), iv(data$poll_mode_national, Nn),
-            iv(data$poll_pop_state, Ns), iv(data$poll_pop_national, Nn),
-            iv(data$n_democrat_national, Nn), iv(data$n_two_share_national, Nn),
-            iv(data$n_democrat_state, Ns), iv(data$n_two_share_state, Ns),
-            dv(data$unadjusted_national, Nn), dv(data$unadjusted_state, Ns),
-            as.double(data$mu_b_prior), as.double(data$state_weights), scalars,
-            as.double(data$state_covariance_0),           # column-major, as R stores it
-            as.integer(c(chains, chain_id_offset, iter_warmup, iter_sampling, max_treedepth, device,
-                         as.integer(save_warmup), seed)),
-            as.double(c(adapt_delta, 0.05, 0.75, 10, 1, init)),
-            handle = integer(1), status = integer(1))
-  .potus_check(res$status)
-  h <- res$handle
-  .potus_check(.C("potus_R_init", h, status = integer(1))$status)
+  gpus <- as.integer(gpus)
+  per <- rep(chains %/% length(gpus), length(gpus)) + (seq_along(gpus) <= chains %% length(gpus))   # chains per device
+  first <- cumsum(c(0L, per))[seq_along(per)]
+  handles <- integer(0); counts <- integer(0)
+  for (g in seq_along(gpus)) {
+    if (per[g] == 0L) next
+    res <- .C("potus_R_create", dims,
+              iv(data$state, Ns), iv(data$day_state, Ns), iv(data$day_national, Nn), iv(data$poll_state, Ns),
+              iv(data$poll_national, Nn), iv(data$poll_mode_state, Ns), iv(data$poll_mode_national, Nn),
+              iv(data$poll_pop_state, Ns), iv(data$poll_pop_national, Nn),
+              iv(data$n_democrat_national, Nn), iv(data$n_two_share_national, Nn),
+              iv(data$n_democrat_state, Ns), iv(data$n_two_share_state, Ns),
+              dv(data$unadjusted_national, Nn), dv(data$unadjusted_state, Ns),
+              as.double(data$mu_b_prior), as.double(data$state_weights), scalars,
+              as.double(data$state_covariance_0),           # column-major, as R stores it
+              as.integer(c(per[g], chain_id_offset + first[g], iter_warmup, iter_sampling, max_treedepth, gpus[g],
+                           as.integer(save_warmup), seed)),
+              as.double(c(adapt_delta, 0.05, 0.75, 10, 1, init)),
+              handle = integer(1), status = integer(1))
+    .potus_check(res$status)
+    .potus_check(.C("potus_R_init", res$handle, status = integer(1))$status)
+    handles <- c(handles, res$handle); counts <- c(counts, per[g])
+  }
   total <- iter_warmup + iter_sampling
   done <- 0L
   chunk <- if (is.null(refresh) || refresh <= 0) total else as.integer(refresh)
   while (done < total) {                     # chunked so that R can print progress / be interrupted
     n <- min(chunk, total - done)
-    .potus_check(.C("potus_R_run", h, as.integer(n), status = integer(1))$status)
+    .potus_check(.C("potus_R_run_many", as.integer(handles), length(handles), as.integer(n), status = integer(1))$status)
     done <- done + n
     message(sprintf("Iteration: %5d / %d [%3d%%]  (%s)", done, total, as.integer(100 * done / total),
                     if (done <= iter_warmup) "Warmup" else "Sampling"))
   }
-  info <- .C("potus_R_num_columns", h, D = integer(1), n_cols = integer(1), status = integer(1))
+  info <- .C("potus_R_num_columns", handles[1], D = integer(1), n_cols = integer(1), status = integer(1))
   .potus_check(info$status)
-  structure(list(handle = h, D = info$D, n_cols = info$n_cols, chains = chains,
+  structure(list(handle = handles[1], handles = handles, chains_per_handle = counts, D = info$D, n_cols = info$n_cols, chains = chains,
                  n_saved = iter_sampling + if (save_warmup) iter_warmup else 0L, data = data, variant = variant,
                  model_name = if (full) "poll_model_2020_model" else "poll_model_2020_no_mode_adjustment_model"),
             class = "potus_fit")
+}
+
+# rstan::sampling() surface (final_2016.R:525-529, scripts/deprecated/R/Refactored/poll_run_v9.R:387-390): `iter` counts
+# warm-up + sampling, `warmup` defaults to iter / 2, control = list(adapt_delta =, max_treedepth =).
+potus_sampling <- function(data, variant = c("full", "no_mode_adjustment"), chains = 4, iter = 2000, warmup = floor(iter / 2),
+                           seed = 1843, refresh = max(iter %/% 10, 1), init = 2, control = list(), gpus = 0L, ...) {
+  potus_sample(data, variant = match.arg(variant), seed = seed, chains = chains, iter_warmup = warmup, iter_sampling = iter - warmup,
+               refresh = refresh, init = if (is.numeric(init)) init else 2,
+               adapt_delta = if (is.null(control$adapt_delta)) 0.8 else control$adapt_delta,
+               max_treedepth = if (is.null(control$max_treedepth)) 10 else control$max_treedepth, gpus = gpus, ...)
 }
 
 # column ranges of the CmdStan row, 0-based [begin, end): same arithmetic as _abi.column_layout
@@ -99,21 +118,26 @@ potus_extract <- function(fit, name) {
   b <- .potus_layout(fit)[[name]]
   if (is.null(b)) stop("unknown parameter ", name)
   n <- b$end - b$begin
-  res <- .C("potus_R_write_array", fit$handle, as.integer(b$begin), as.integer(b$end),
-            out = double(fit$n_saved * fit$chains * n), status = integer(1))
-  .potus_check(res$status)
-  a <- aperm(array(res$out, c(n, fit$chains, fit$n_saved)), c(3, 2, 1))   # [iter, chain, col]
-  a <- matrix(aperm(a, c(1, 2, 3)), fit$n_saved * fit$chains, n)          # chain-major merge
+  parts <- lapply(seq_along(fit$handles), function(g) {
+    ch <- fit$chains_per_handle[g]
+    res <- .C("potus_R_write_array", fit$handles[g], as.integer(b$begin), as.integer(b$end),
+              out = double(fit$n_saved * ch * n), status = integer(1))
+    .potus_check(res$status)
+    a <- aperm(array(res$out, c(n, ch, fit$n_saved)), c(3, 2, 1))         # [iter, chain, col]
+    matrix(a, fit$n_saved * ch, n)                                          # chain-major merge of this device's chains
+  })
+  a <- do.call(rbind, parts)                                                # devices hold consecutive chain ids
   if (length(b$dims)) array(a, c(nrow(a), b$dims)) else as.vector(a)
 }
 
 potus_output_files <- function(fit, dir, basename = "poll_model_2020") {
-  .potus_check(.C("potus_R_write_stan_csv", fit$handle, as.character(dir), as.character(basename), status = integer(1))$status)
-  file.path(dir, sprintf("%s-%d.csv", basename, seq_len(fit$chains)))
+  for (h in fit$handles) .potus_check(.C("potus_R_write_stan_csv", h, as.character(dir), as.character(basename), status = integer(1))$status)
+  file.path(dir, sprintf("%s-%d.csv", basename, seq_len(fit$chains)))       # files are numbered by chain id
 }
 
 # Posterior summaries of predicted_score computed on the device (replaces final_2016.R:708-762 and :799-823:
 # no 8000 x 12954 array ever reaches R).  ev: electoral votes per state in state order (states2012$ev).
+# (Single-device fits; with gpus = several devices the summaries are per device: pool with potus_extract instead.)
 # Returns list(state = array [T, S, 4] (low, high, mean, prob), national = [T, 4],
 #              electoral_votes = [T, 5] (mean, median, high, low, prob >= 270)).
 potus_summary <- function(fit, ev) {
@@ -125,4 +149,4 @@ potus_summary <- function(fit, ev) {
        national = t(matrix(r$natl, nrow = 4)), electoral_votes = t(matrix(r$ev_out, nrow = 5)))
 }
 
-potus_free <- function(fit) invisible(.C("potus_R_destroy", fit$handle, status = integer(1)))
+potus_free <- function(fit) invisible(lapply(fit$handles, function(h) .C("potus_R_destroy", h, status = integer(1))))

@@ -146,6 +146,13 @@ int potus_init(int handle, const double *q0);
  * Blocks until done.  R calls this in chunks of `refresh` iterations. */
 int potus_run(int handle, int n_iter);
 
+/* The same for several handles at once: all launches are issued before any is waited for, so the
+ * handles of different GPUs (shards of one posterior, BASELINE configs[2]) or of different posteriors on
+ * one GPU (the 2008 / 2012 / 2016 backtests, configs[3]) run concurrently under a single host thread --
+ * R has only one.  No reference counterpart: cmdstanr gets its concurrency from one OS process per chain
+ * (final_2016.R:536 parallel_chains).  Handles that cannot be co-resident on their device run in turn. */
+int potus_run_many(const int *handles, int n_handles, int n_iter);
+
 /* Progress / accounting. */
 int potus_iterations_done(int handle, int *n);
 int potus_total_leapfrogs(int handle, long long *n); /* sum over chains and iterations so far */
@@ -202,6 +209,7 @@ void potus_R_create(int *dims /*[8]: N_nat,N_state,T,S,P,M,Pop,variant*/,
                     int *handle, int *status);
 void potus_R_init(int *handle, int *status);
 void potus_R_run(int *handle, int *n_iter, int *status);
+void potus_R_run_many(int *handles, int *n_handles, int *n_iter, int *status);
 void potus_R_num_columns(int *handle, int *D, int *n_cols, int *status);
 void potus_R_write_array(int *handle, int *col_begin, int *col_end, double *out, int *status);
 void potus_R_write_stan_csv(int *handle, char **dir, char **basename, int *status);

@@ -142,6 +142,36 @@ def test_launch_boundaries_do_not_change_the_draws_across_a_window_end(cases, cu
         assert np.array_equal(out[0], d)
 
 
+@pytest.mark.parametrize("cus", [0, 1])
+def test_three_backtests_concurrently_give_the_bytes_of_separate_runs(cases, cus):
+    """BASELINE configs[3] on one GPU: the 2008, 2012 and 2016 posteriors advance together under potus_run_many
+    (one host thread, as R has) and every chain is the chain it would have been alone."""
+    from us_potus_model_amd import run_many
+    kw = dict(chains=4, num_warmup=12, num_samples=4, seed=77, cus_per_chain=cus)
+    alone, together, hs = [], [], []
+    t_alone = 0.0
+    for name in ("2008", "2012", "2016"):
+        data, variant = cases[name]
+        h = Handle(data, variant, **kw); h.init(); h.run(7); h.run(9)
+        t_alone += h.last_run_timing()[0]
+        alone.append(h.draws().copy()); h.close()
+    for name in ("2008", "2012", "2016"):
+        data, variant = cases[name]
+        h = Handle(data, variant, **kw); h.init(); hs.append(h)
+    run_many(hs, 7); run_many(hs, 9)
+    t_together = max(h.last_run_timing()[0] for h in hs)
+    with pytest.raises(sampler.PotusError, match="twice"):
+        run_many([hs[0], hs[0]], 1)
+    k16 = hs[0].cus_per_chain
+    for h in hs:
+        together.append(h.draws().copy()); h.close()
+    for a, b in zip(alone, together):
+        assert np.array_equal(a, b)
+    if cus == 0:
+        assert k16 == 16                                 # 3 x 4 chains x 16 CUs = 192 of 256: one group
+        assert t_together < 0.8 * t_alone, (t_together, t_alone)
+
+
 @pytest.mark.parametrize("cus", [1, 16])
 def test_same_seed_same_bytes_and_chain_ids(cases, cus):
     data, variant = cases["small_full"]

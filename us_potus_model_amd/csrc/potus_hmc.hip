@@ -1339,20 +1339,16 @@ int potus_init(int handle, const double *q0) {
   return 0;
 }
 
-int potus_run(int handle, int n_iter) {
-  Sampler *sp = get(handle);
-  if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
-  if (!sp->inited) return fail(POTUS_ERR_STATE, "potus_init must be called before potus_run");
-  if (n_iter <= 0) return 0;
-  std::unique_lock<std::mutex> cluster_lock(g_cluster_mu, std::defer_lock);
-  if (sp->K > 1) cluster_lock.lock();
+namespace {
+// potus_run in two halves, so that several samplers can be in flight at once
+struct RunTicket { Sampler *sp; int handle; long long before; int it0; };
+int run_launch(RunTicket &t, int n_iter) {
+  Sampler *sp = t.sp;
   HIP_TRY(hipSetDevice(sp->device));
-  long long before = 0, after = 0;
-  potus_total_leapfrogs(handle, &before);
-  int it0 = 0; potus_iterations_done(handle, &it0);
+  potus_total_leapfrogs(t.handle, &t.before);
+  potus_iterations_done(t.handle, &t.it0);
   HIP_TRY(hipEventRecord(sp->ev0, sp->stream));
-  if (sp->K > 1)
-  {
+  if (sp->K > 1) {
     const unsigned lid = ++sp->launch_id;
     if (sp->cl_dw == 4)
       hipLaunchKernelGGL(k_cl_run<4>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
@@ -1360,21 +1356,86 @@ int potus_run(int handle, int n_iter) {
     else
       hipLaunchKernelGGL(k_cl_run<8>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
                          (const ClModel *)sp->dCL, (const RunParams *)sp->dR, n_iter, lid);
-  }
-  else
+  } else
     hipLaunchKernelGGL(k_run, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, n_iter);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(sp->ev1, sp->stream));
+  return 0;
+}
+int run_finish(RunTicket &t) {
+  Sampler *sp = t.sp;
+  HIP_TRY(hipSetDevice(sp->device));
   HIP_TRY(hipStreamSynchronize(sp->stream));
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, sp->ev0, sp->ev1));
-  potus_total_leapfrogs(handle, &after);
-  sp->last_ms = ms; sp->last_leapfrogs = after - before;
-  int it1 = 0; potus_iterations_done(handle, &it1);
+  long long after = 0;
+  potus_total_leapfrogs(t.handle, &after);
+  sp->last_ms = ms; sp->last_leapfrogs = after - t.before;
+  int it1 = 0; potus_iterations_done(t.handle, &it1);
   // split elapsed time between warm-up and sampling in proportion to iterations (for the CSV footer)
   const int nw = sp->R.num_warmup;
-  const int w_it = std::max(0, std::min(it1, nw) - std::min(it0, nw)), tot = std::max(1, it1 - it0);
+  const int w_it = std::max(0, std::min(it1, nw) - std::min(t.it0, nw)), tot = std::max(1, it1 - t.it0);
   sp->warm_ms += ms * w_it / tot; sp->samp_ms += ms * (tot - w_it) / tot;
+  return 0;
+}
+} // namespace
+
+int potus_run(int handle, int n_iter) {
+  Sampler *sp = get(handle);
+  if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
+  if (!sp->inited) return fail(POTUS_ERR_STATE, "potus_init must be called before potus_run");
+  if (n_iter <= 0) return 0;
+  std::unique_lock<std::mutex> cluster_lock(g_cluster_mu, std::defer_lock);
+  if (sp->K > 1) cluster_lock.lock();
+  RunTicket t{sp, handle, 0, 0};
+  int rc = run_launch(t, n_iter);
+  if (rc) return rc;
+  return run_finish(t);
+}
+
+// Several samplers at once (the three backtests of BASELINE configs[3] on one GPU, or the shards of one posterior on
+// the GPUs of a node, driven from a single host thread such as R's): all launches of a group are issued before any is
+// waited for.  The workgroups of a cluster launch wait for each other, so every cluster launch in flight on a device
+// must be resident in full: a group takes cluster samplers only while their workgroups fit the compute units of their
+// device, XCD by XCD (workgroups are dealt round-robin to the eight XCDs); the rest runs in the next group.
+int potus_run_many(const int *handles, int n_handles, int n_iter) {
+  if (!handles || n_handles < 0) return fail(POTUS_ERR_ARG, "potus_run_many: null handle list");
+  if (n_iter <= 0 || n_handles == 0) return 0;
+  std::vector<RunTicket> todo;
+  for (int i = 0; i < n_handles; i++) {
+    Sampler *sp = get(handles[i]);
+    if (!sp) return fail(POTUS_ERR_STATE, "potus_run_many: bad handle %d", handles[i]);
+    if (!sp->inited) return fail(POTUS_ERR_STATE, "potus_init must be called before potus_run_many");
+    for (int j = 0; j < i; j++) if (handles[j] == handles[i]) return fail(POTUS_ERR_ARG, "potus_run_many: handle %d listed twice", handles[i]);
+    todo.push_back(RunTicket{sp, handles[i], 0, 0});
+  }
+  std::lock_guard<std::mutex> cluster_lock(g_cluster_mu);
+  std::vector<char> done(todo.size(), 0);
+  size_t n_done = 0;
+  while (n_done < todo.size()) {
+    std::vector<size_t> group;
+    std::vector<std::pair<int, int>> used;   // (device, XCD rows in use)
+    for (size_t i = 0; i < todo.size(); i++) {
+      if (done[i]) continue;
+      Sampler *sp = todo[i].sp;
+      if (sp->K > 1) {
+        int ncu = 0;
+        HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, sp->device));
+        const int rows = (sp->R.chains * sp->K + 7) / 8, cap = ncu / 8;
+        auto it = std::find_if(used.begin(), used.end(), [&](const std::pair<int, int> &u) { return u.first == sp->device; });
+        const int have = it == used.end() ? 0 : it->second;
+        if (have > 0 && have + rows > cap) continue;    // next group (a sampler alone always fits: checked at create)
+        if (it == used.end()) used.push_back({sp->device, rows}); else it->second += rows;
+      }
+      group.push_back(i);
+    }
+    int rc = 0;
+    size_t launched = 0;
+    for (; launched < group.size() && !rc; launched++) rc = run_launch(todo[group[launched]], n_iter);
+    for (size_t k = 0; k < launched; k++) { const int r2 = run_finish(todo[group[k]]); if (!rc) rc = r2; }
+    if (rc) return rc;
+    for (size_t gi : group) { done[gi] = 1; n_done++; }
+  }
   return 0;
 }
 
@@ -1644,6 +1705,7 @@ void potus_R_create(int *dims, int *state, int *day_state, int *day_national, in
 }
 void potus_R_init(int *handle, int *status) { *status = potus_init(*handle, nullptr); }
 void potus_R_run(int *handle, int *n_iter, int *status) { *status = potus_run(*handle, *n_iter); }
+void potus_R_run_many(int *handles, int *n_handles, int *n_iter, int *status) { *status = potus_run_many(handles, *n_handles, *n_iter); }
 void potus_R_num_columns(int *handle, int *D, int *n_cols, int *status) {
   Sampler *sp = get(*handle);
   if (!sp) { *status = fail(POTUS_ERR_STATE, "bad handle"); return; }

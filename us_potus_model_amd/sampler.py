@@ -62,6 +62,7 @@ def load_library():
     L.potus_log_prob_grad.argtypes = [C.c_int, dp, C.c_int, dp, dp]
     L.potus_init.argtypes = [C.c_int, dp]
     L.potus_run.argtypes = [C.c_int, C.c_int]
+    L.potus_run_many.argtypes = [ip, C.c_int, C.c_int]
     L.potus_iterations_done.argtypes = [C.c_int, ip]
     L.potus_total_leapfrogs.argtypes = [C.c_int, C.POINTER(C.c_longlong)]
     L.potus_chain_status.argtypes = [C.c_int, ip, ip]
@@ -79,10 +80,10 @@ def load_library():
 
 EXPORTS = [
     "potus_version", "potus_last_error", "potus_default_opts", "potus_num_params", "potus_num_columns",
-    "potus_column_name", "potus_create", "potus_destroy", "potus_cus_per_chain", "potus_log_prob_grad", "potus_init", "potus_run",
+    "potus_column_name", "potus_create", "potus_destroy", "potus_cus_per_chain", "potus_log_prob_grad", "potus_init", "potus_run", "potus_run_many",
     "potus_iterations_done", "potus_total_leapfrogs", "potus_chain_status", "potus_get_adaptation",
     "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_stan_csv",
-    "potus_last_run_timing", "potus_posterior_summary", "potus_R_create", "potus_R_init", "potus_R_run", "potus_R_num_columns",
+    "potus_last_run_timing", "potus_posterior_summary", "potus_R_create", "potus_R_init", "potus_R_run", "potus_R_run_many", "potus_R_num_columns",
     "potus_R_write_array", "potus_R_write_stan_csv", "potus_R_posterior_summary", "potus_R_last_error", "potus_R_destroy",
 ]
 
@@ -218,6 +219,15 @@ class Handle:
         _check(self.L, self.L.potus_write_stan_csv(self.h, str(directory).encode(), basename.encode()))
         off = self.opts.chain_id_offset
         return [str(Path(directory) / f"{basename}-{off + c + 1}.csv") for c in range(self.opts.chains)]
+
+
+def run_many(handles, n_iter):
+    """potus_run_many: advance several handles (other posteriors, other GPUs) concurrently from one host thread."""
+    if not handles:
+        return
+    L = handles[0].L
+    ids = (C.c_int * len(handles))(*[h.h for h in handles])
+    _check(L, L.potus_run_many(ids, len(handles), int(n_iter)))
 
 
 class StanFit:
