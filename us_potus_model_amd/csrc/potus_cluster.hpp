@@ -503,9 +503,9 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
 // pubnext: the position this pass writes is the one the next pass evaluates (consecutive leaves of a subtree),
 // so the suffix totals of that position (exchange X1 of the NEXT pass) are published here, as soon as the
 // epilogue has produced it; the next pass then finds x.x1e set and does not wait for its X1 at all.
-// pend: a leaf whose totals (exchange pend.tag) have been sent but not looked at: wave 0 collects them while the
-// other waves work on phase B, thread 0 takes its verdicts (cl_leaf_logic), and if they end the trajectory the pass
-// stops right after the phase-B barrier, before it has stored anything (aborted = true).  This takes the wait for
+// pend: a leaf whose totals (exchange pend.tag) have been sent but not looked at: an otherwise idle wave collects them
+// in phase C and takes the verdicts (cl_leaf_logic); if they end the trajectory the pass stops at the phase-C barrier
+// (aborted = true).  This takes the wait for
 // the leaf's all-reduce and the serial bookkeeping off the critical path of consecutive leaves.
 template <int CL_DW, class Pol>
 __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_in, ldp lds, const ClStatic &cst, Xch &x, Pol &pol_io,
@@ -672,18 +672,11 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     }
     if (lane < S) Y[PT_NW * SE + lane] = carry_m;
     WPROF_PT(28);
-    if (pend.n >= 0) {                              // the previous leaf's totals and verdicts, off the critical path
-      cl_wide_consume(x, pend.tag, pend.nv, wout);
-      WPROF_PT(29);
-      cl_leaf_logic(ts, pend, wout);
-      WPROF_PT(30);
-    }
   }
   WPROF_ACC(0);
   __syncthreads();
   PROF_MARK(1);
   TSTAMP(2);
-  if (pend.n >= 0 && ts->abort) { aborted = true; return 0.0; }   // every member takes this exit together
   {
     // C[k][t] for the member's days: local suffix + later waves + later members
     if (lane < S) {
@@ -767,6 +760,16 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         s_scal[SC_DSRHO] = sigma_e * (-rho / sqrt(1.0 - rho * rho));
       }
     }
+    if (w == PT_NW - 2 && pend.n >= 0) {
+      // The previous leaf's totals and verdicts, on a wave that has no polls unless the member has more than 384 of
+      // them: the totals were sent a whole phase B ago, so nothing waits here, and the U-turn / accept logic runs
+      // beside the poll arithmetic of the other waves.
+      WPROF_T0B();
+      cl_wide_consume(x, pend.tag, pend.nv, wout);
+      WPROF_PTB(29);
+      cl_leaf_logic(ts, pend, wout);
+      WPROF_PTB(30);
+    }
     for (int i0 = 0; i0 < np; i0 += PT_THREADS) {        // one trip unless a member has more than 512 polls
       const int il = i0 + tid;
       const bool ok = il < np;
@@ -824,6 +827,9 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   __syncthreads();
   PROF_MARK(3);
   TSTAMP(4);
+  // The verdicts ended the trajectory: every member leaves here together.  What this pass has stored so far (the
+  // epilogue of the poll-noise elements) went to slots nobody reads once the trajectory is over.
+  if (pend.n >= 0 && ts->abort) { aborted = true; return 0.0; }
 
   // ---------------- phase D: adjoint of the walk, gC[:,t] = sum_i r_i Lw_ext[s_i,:] summed over days <= t.
   // The member's polls (day order) are cut into PT_NW equal chunks, one per wave, whatever the days: a wave

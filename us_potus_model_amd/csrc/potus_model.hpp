@@ -118,6 +118,7 @@ enum { SC_MUE = 0, SC_RHO, SC_SRHO, SC_XMUE, SC_XRHO, SC_LPRHO, SC_DSRHO, SC_N }
 #define TSTAMP(k) do { if (threadIdx.x == 0 && prof[16] == 3000.0) prof[40 + (k)] = (double)wall_clock64(); } while (0)
 #define WPROF_PT(k) do { if (threadIdx.x == 0) prof[k] += (double)(clock64() - wt0_); } while (0)   // thread 0: time since WPROF_T0
 #define WPROF_T0B() const long long wt0b_ = clock64()
+#define WPROF_PTB(k) do { if ((threadIdx.x & 63) == 0) prof[k] += (double)(clock64() - wt0b_); } while (0)
 #define WPROF_ACCB(ph) do { if ((threadIdx.x & 63) == 0) prof[32 + 8 * (ph) + (threadIdx.x >> 6)] += (double)(clock64() - wt0b_); } while (0)
 #define WPROF_T0C() const long long wt0c_ = clock64()
 #define WPROF_ACCC(ph) do { if ((threadIdx.x & 63) == 0) prof[32 + 8 * (ph) + (threadIdx.x >> 6)] += (double)(clock64() - wt0c_); } while (0)
@@ -125,6 +126,7 @@ enum { SC_MUE = 0, SC_RHO, SC_SRHO, SC_XMUE, SC_XRHO, SC_LPRHO, SC_DSRHO, SC_N }
 #define TSTAMP(k) do { } while (0)
 #define WPROF_PT(k) do { } while (0)
 #define WPROF_T0B() do { } while (0)
+#define WPROF_PTB(k) do { } while (0)
 #define WPROF_ACCB(ph) do { } while (0)
 #define WPROF_T0C() do { } while (0)
 #define WPROF_ACCC(ph) do { } while (0)
