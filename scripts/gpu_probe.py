@@ -67,6 +67,10 @@ for chains in chain_counts:
                 for mm in (0, KCL // 2, KCL - 1):
                     print(f"  phase B, wave 0 of member {mm} (cycles per leaf since barrier 1): own part {out[mm][27]/leaves:.0f}, X1 in {out[mm][28]/leaves:.0f}, "
                           f"; phase C, wave 6: totals of the previous leaf in {out[mm][29]/leaves:.0f}, verdicts {out[mm][30]/leaves:.0f}")
+            if KCL > 1:
+                for mm in (0, KCL // 2, KCL - 1):
+                    print(f"  phase F, thread 0 of member {mm} (cycles per leaf since its X2 wait ended): own slots done {out[mm][52]/leaves:.0f}, barrier {out[mm][53]/leaves:.0f}, "
+                          f"day block stored {out[mm][54]/leaves:.0f}, totals of the next position summed {out[mm][55]/leaves:.0f}")
             passes = leaves + 1e-9
             for k, nm in sub.items():
                 print(f"    [{nm:36s}] {p[k]/passes:10.0f}")

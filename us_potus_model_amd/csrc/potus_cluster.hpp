@@ -1107,7 +1107,9 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     const int jrep = arl ? NR + d0 + (nd - 1 - lane) : rslot;
     xst(x, (pubnext && (arl || repl)) ? 16u * (unsigned)(XQ0 + jrep) : PT_OOB, qn_own);
   }
+  PROF_SUB(52);
   __syncthreads();
+  PROF_SUB(53);
   {
     const double carry = lane < S ? X[PT_NW * SE + lane] : 0.0;   // pre[] is already the prefix within the member
     double nrun = 0.0;                              // suffix total of the next position over the wave's days
@@ -1117,10 +1119,12 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       const double qn = pol.g_fin(voz[j], (t < T - 1 ? pre[j] + carry : 0.0) - zq[j], zq[j], gz[j]);
       nrun += (j < wnd && t < T - 1) ? qn : 0.0;
     }
+    PROF_SUB(54);
     if (pubnext) {                                  // wave-uniform; LDS and a barrier only, the store stays outside
       if (lane < S) Y[w * SE + lane] = nrun;
       __syncthreads();
     }
+    PROF_SUB(55);
   }
   {
     double tot = 0.0;
