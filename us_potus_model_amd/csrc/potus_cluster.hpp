@@ -770,7 +770,8 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       cl_leaf_logic(ts, pend, wout);
       WPROF_PTB(30);
     }
-    for (int i0 = 0; i0 < np; i0 += PT_THREADS) {        // one trip unless a member has more than 512 polls
+    const bool no_polls_here = w == PT_NW - 2 && pend.n >= 0 && np <= 64 * w;   // the verdict wave, when it has no polls: skip the (idle) trip
+    for (int i0 = 0; i0 < (no_polls_here ? 0 : np); i0 += PT_THREADS) {        // one trip unless a member has more than 512 polls
       const int il = i0 + tid;
       const bool ok = il < np;
       const int ic = ok ? il : np;                       // slot np holds zeros: N = y = 0
