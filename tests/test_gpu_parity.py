@@ -45,6 +45,43 @@ def test_log_prob_grad_matches_oracle_and_golden(cases, name, cus):
     h.close()
 
 
+EDGE_SHAPES = {
+    "no_national_polls": dict(S=6, T=24, N_state=70, N_national=0, P=9),
+    "no_state_polls": dict(S=6, T=24, N_state=0, N_national=25, P=9),
+    "one_state": dict(S=1, T=24, N_state=30, N_national=10, P=4),
+    "two_days": dict(S=6, T=2, N_state=20, N_national=5, P=3),
+    "one_pollster": dict(S=6, T=24, N_state=70, N_national=25, P=1),
+    "mostly_unpolled_days": dict(S=6, T=200, N_state=12, N_national=3, P=3),
+    "63_states": dict(S=63, T=30, N_state=200, N_national=20, P=9),
+}
+
+
+@pytest.mark.parametrize("cus", [1, 8, 16])
+@pytest.mark.parametrize("variant", ["full", "no_mode_adjustment"])
+@pytest.mark.parametrize("shape", list(EDGE_SHAPES))
+def test_edge_shapes_match_the_oracle(shape, variant, cus):
+    """Empty and ragged inputs: no national / no state polls, a single state, two days (members without days),
+    a single pollster, campaigns where most days have no poll, the largest S a wave holds."""
+    from us_potus_model_amd import synthetic
+    data = synthetic.make(seed=3, variant=variant, **EDGE_SHAPES[shape])
+    h = Handle(data, variant, chains=2, num_warmup=10, num_samples=0, save_warmup=1, seed=3, cus_per_chain=cus)
+    m = OracleModel(data, variant)
+    q = np.random.default_rng(1).uniform(-2, 2, (3, h.D))
+    lp, g = h.log_prob_grad(q)
+    for i in range(3):
+        lpo, go = m.log_prob_grad(q[i])
+        assert abs(lp[i] - lpo) <= LP_RTOL * max(1.0, abs(lpo)), (i, lp[i], lpo)
+        assert np.abs(g[i] - go).max() <= GRAD_RTOL * np.abs(go).max(), i
+    h.init(); h.run(4)
+    d = h.draws()
+    o = m.default_opts(num_warmup=10, num_samples=0, save_warmup=1, seed=3, fast_grad=1)
+    for c in (0, 1):
+        ref = m.sample_chain(c + 1, o)[0][:4]
+        assert np.array_equal(d[c][:4, 3:6], ref[:, 3:6]), (c, d[c][:4, :7], ref[:, :7])
+        assert np.allclose(d[c][:4, 7:], ref[:, 7:], rtol=1e-6, atol=1e-7)
+    h.close()
+
+
 def test_stress_shape_log_prob_grad_and_first_transitions():
     """BASELINE configs[4] sizes (51 states x 600 days x 10 000 polls, D = 41 610; diagonal metric): beyond the
     one-workgroup kernels (T > 256), so the library must pick a cluster by itself and refuse cus_per_chain = 1."""
@@ -248,6 +285,12 @@ def test_error_paths(cases):
     h.close()
     with pytest.raises(sampler.PotusError, match="max_depth"):
         Handle(data, variant, chains=1, max_depth=40)
+    from us_potus_model_amd import synthetic
+    with pytest.raises(sampler.PotusError, match="at least two"):
+        Handle(synthetic.make(S=6, T=1, N_state=20, N_national=5, P=3, seed=3), "full", chains=1)
+    bad = dict(data); bad["day_state"] = data["day_state"].copy(); bad["day_state"][3] = data["T"] + 1
+    with pytest.raises(sampler.PotusError, match="day_state"):
+        Handle(bad, variant, chains=1)
 
 
 _ORACLE_POSTERIOR = {}

@@ -550,7 +550,9 @@ int validate(const potus_data *d) {
   if (!d) return fail(POTUS_ERR_ARG, "null data");
   if (d->variant != POTUS_VARIANT_FULL && d->variant != POTUS_VARIANT_NO_MODE) return fail(POTUS_ERR_ARG, "unknown variant %d", d->variant);
   const bool full = d->variant == POTUS_VARIANT_FULL;
-  if (d->S < 1 || d->T < 2 || d->P < 1 || d->N_state_polls < 0 || d->N_national_polls < 0) return fail(POTUS_ERR_ARG, "bad sizes");
+  if (d->S < 1 || d->P < 1 || d->N_state_polls < 0 || d->N_national_polls < 0)
+    return fail(POTUS_ERR_ARG, "bad sizes: S = %d, P = %d, N_state_polls = %d, N_national_polls = %d", d->S, d->P, d->N_state_polls, d->N_national_polls);
+  if (d->T < 2) return fail(POTUS_ERR_ARG, "T = %d: the model is a random walk over days, at least two are needed", d->T);
   if (full && (d->M < 1 || d->Pop < 1)) return fail(POTUS_ERR_ARG, "bad sizes M/Pop");
   auto range = [&](const int32_t *v, int n, int lo, int hi, const char *name) {
     if (n > 0 && !v) return fail(POTUS_ERR_ARG, "%s is null", name);
