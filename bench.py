@@ -204,7 +204,7 @@ def main():
                          "note": f"latency-bound at {C} chains ({C * K} of 256 CUs busy): the state of a chain stays in L2, "
                                  "the leapfrog is a chain of dependent exchanges between the CUs of a cluster; see DESIGN.md"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU port is timed beside the single-GPU run only
             line["cpu_baseline"] = cpu_baseline(data, variant, C, args.cpu_budget)
             line["speedup_vs_cpu_port"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
