@@ -164,17 +164,20 @@ def test_adaptation_matches_oracle_through_a_metric_update(cases, cus):
 
 
 @pytest.mark.parametrize("cus", [1, 8, 16])
-def test_launch_boundaries_do_not_change_the_draws_across_a_window_end(cases, cus):
-    """The metric update + init_stepsize of iteration 99 and the transition after it, inside one launch or split
-    over launches in every way, give the same bytes (a once-seen miscompilation of the oversized kernel broke this)."""
-    data, variant = cases["small_full"]
-    kw = dict(chains=1, num_warmup=150, num_samples=0, save_warmup=1, seed=11, cus_per_chain=cus)
+@pytest.mark.parametrize("name,nw,total,splits", [("small_full", 150, 104, ([104], [99, 5], [100, 4], [99, 1, 4], [50, 49, 2, 3])),
+                                                  ("2016", 60, 58, ([58], [53, 5], [54, 4], [53, 1, 4]))])
+def test_launch_boundaries_do_not_change_the_draws_across_a_window_end(cases, name, nw, total, splits, cus):
+    """The metric update + init_stepsize at the end of the first adaptation window and the transition after it, inside
+    one launch or split over launches in every way, give the same bytes (a once-seen miscompilation of the oversized
+    kernel broke this)."""
+    data, variant = cases[name]
+    kw = dict(chains=1, num_warmup=nw, num_samples=0, save_warmup=1, seed=11, cus_per_chain=cus)
     out = []
-    for chunks in ([104], [99, 5], [100, 4], [99, 1, 4], [50, 49, 2, 3]):
+    for chunks in splits:
         h = Handle(data, variant, **kw); h.init()
         for n in chunks:
             h.run(n)
-        out.append(h.draws()[0][:104].copy()); h.close()
+        out.append(h.draws()[0][:total].copy()); h.close()
     for d in out[1:]:
         assert np.array_equal(out[0], d)
 
