@@ -71,6 +71,10 @@ for chains in chain_counts:
                 for mm in (0, KCL // 2, KCL - 1):
                     print(f"  phase F, thread 0 of member {mm} (cycles per leaf since its X2 wait ended): own slots done {out[mm][52]/leaves:.0f}, barrier {out[mm][53]/leaves:.0f}, "
                           f"day block stored {out[mm][54]/leaves:.0f}, totals of the next position summed {out[mm][55]/leaves:.0f}")
+            if KCL > 1:
+                for mm in (0, KCL - 1):
+                    print(f"  previous leaf's totals, member {mm}: first fetch of 16 words {out[mm][56]/leaves:.0f} cycles, needed a re-fetch in {100*out[mm][57]/leaves:.0f} % of the leaves, "
+                          f"{out[mm][58]/leaves:.2f} re-fetch rounds per leaf")
             passes = leaves + 1e-9
             for k, nm in sub.items():
                 print(f"    [{nm:36s}] {p[k]/passes:10.0f}")

@@ -36,6 +36,9 @@
 #define CL_PPR (PT_THREADS / CL_LPP)     // polls per round of the poll phase
 #define CL_MAXK 32
 #define CL_AUX_SC1 16                    // cache-policy bit of the buffer intrinsics: sc1 (agent scope)
+#ifndef CL_AUX_LD
+#define CL_AUX_LD CL_AUX_SC1             // policy of the exchange reader's loads
+#endif
 #define CL_SPIN_LIMIT 8000000u
 
 // fields of one member's part descriptor (ints)
@@ -110,35 +113,56 @@ __device__ __forceinline__ unsigned xch_eslot(const Xch &x, unsigned e, int mm) 
 __device__ __forceinline__ void xst(const Xch &x, unsigned voff, double v) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
   const u32x4 w = {(unsigned)u, (unsigned)(u >> 32), x.epoch + 1u, x.launch};
-  __builtin_amdgcn_raw_buffer_store_b128(w, x.xb, voff, xch_wslot(x, x.m), CL_AUX_SC1);
+  // (soffset through readfirstlane: the exchange counter ends up in a vector register wherever it was updated under a
+  // branch whose condition came out of LDS, and a "divergent" scalar offset costs a waterfall loop around every access)
+  __builtin_amdgcn_raw_buffer_store_b128(w, x.xb, voff, __builtin_amdgcn_readfirstlane(xch_wslot(x, x.m)), CL_AUX_SC1);
 }
 // fetch NB words of the exchange just published (per-lane byte offsets vo, PT_OOB = idle lane -> 0;
 // uniform slot offsets so); spins until every tag of the wave matches
 template <int NB>
-__device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], const unsigned (&so)[NB], double (&out)[NB], unsigned tag = 0) {
+__device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], const unsigned (&so)[NB], double (&out)[NB], unsigned tag = 0, ldp xprof = nullptr) {
   Xch x = x_in;
   if (tag) x.epoch = tag;                          // an exchange other than the latest one
+  x.epoch = __builtin_amdgcn_readfirstlane(x.epoch); x.launch = __builtin_amdgcn_readfirstlane(x.launch);
+#ifdef POTUS_PROF
+  const long long xt0_ = clock64();
+#else
+  (void)xprof;
+#endif
   u32x4 w[NB];
   bool done[NB];                                   // wave-uniform
+#ifdef CL_LD_INV
+  asm volatile(CL_LD_INV ::: "memory");
+#endif
 #pragma unroll
-  for (int u = 0; u < NB; u++) w[u] = __builtin_amdgcn_raw_buffer_load_b128(x.xb, vo[u], so[u], CL_AUX_SC1);
+  for (int u = 0; u < NB; u++) w[u] = __builtin_amdgcn_raw_buffer_load_b128(x.xb, vo[u], __builtin_amdgcn_readfirstlane(so[u]), CL_AUX_LD);
   bool all = true;
 #pragma unroll
   for (int u = 0; u < NB; u++) { done[u] = __all(vo[u] == PT_OOB || (w[u][2] == x.epoch && w[u][3] == x.launch)); all = all && done[u]; }
+#ifdef POTUS_PROF
+  if (xprof && (threadIdx.x & 63) == 0) { xprof[56] += (double)(clock64() - xt0_); xprof[57] += all ? 0.0 : 1.0; }
+#endif
   // Words that were not there yet are fetched again (words already in hand are not re-read, so a spinning wave
   // does not flood the memory pipeline).  The re-fetch must stay an agent-scope (sc1) load: the `volatile` flavour of
   // the builtin becomes a system-scope load that costs ~2 us per round here.  What keeps the compiler from hoisting
   // it out of the loop is the laundered offset and the memory clobber.
   for (unsigned spins = 0; !all; spins++) {
     if (spins > CL_SPIN_LIMIT) __builtin_trap();   // a member is missing: fail loudly instead of hanging the GPU
+#ifdef POTUS_PROF
+    if (xprof && (threadIdx.x & 63) == 0) xprof[58] += 1.0;
+#endif
     __builtin_amdgcn_s_sleep(1);
+#ifdef CL_LD_INV
+    asm volatile(CL_LD_INV ::: "memory");
+#else
     asm volatile("" ::: "memory");
+#endif
 #pragma unroll
     for (int u = 0; u < NB; u++)
       if (!done[u]) {
         unsigned v = vo[u];
         asm volatile("" : "+v"(v));
-        w[u] = __builtin_amdgcn_raw_buffer_load_b128(x.xb, v, so[u], CL_AUX_SC1);
+        w[u] = __builtin_amdgcn_raw_buffer_load_b128(x.xb, v, __builtin_amdgcn_readfirstlane(so[u]), CL_AUX_LD);
       }
     all = true;
 #pragma unroll
@@ -239,7 +263,7 @@ __device__ __forceinline__ unsigned cl_wide_publish(ldp part, int nv, Xch &x, ld
   PROF_MARK(23);
   return x.epoch;
 }
-__device__ __forceinline__ void cl_wide_consume(const Xch &x, unsigned tag, int nv, ldp out) {   // wave 0
+__device__ __forceinline__ void cl_wide_consume(const Xch &x, unsigned tag, int nv, ldp out, ldp xprof = nullptr) {   // one wave
   const int lane = threadIdx.x & 63;
   for (int l0 = 0; l0 < nv; l0 += 64) {
     const int l = l0 + lane;
@@ -249,7 +273,7 @@ __device__ __forceinline__ void cl_wide_consume(const Xch &x, unsigned tag, int 
       unsigned vo[16], so[16];
 #pragma unroll
       for (int u = 0; u < 16; u++) { const int mm = mm0 + u; vo[u] = (mm < x.K && l < nv) ? 16u * (unsigned)l : PT_OOB; so[u] = xch_eslot(x, tag, mm < x.K ? mm : 0); }
-      xld(x, vo, so, t16, tag);
+      xld(x, vo, so, t16, tag, xprof);
 #pragma unroll
       for (int u = 0; u < 16; u++) tot += t16[u];
     }
@@ -494,6 +518,11 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
   __syncthreads();
   return c;
 }
+
+// A scalar read from LDS (or updated under a branch on one) is the same in every lane, but the compiler must assume it
+// is not: branches on it become exec-mask code and every value assigned under them moves to vector registers.  This
+// tells it.
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---------------------------------------------------------------- one pass of the member's share
 // Returns the chain's lp in every thread of every member; pol.extra[] are summed alongside.
@@ -765,7 +794,11 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       // them: the totals were sent a whole phase B ago, so nothing waits here, and the U-turn / accept logic runs
       // beside the poll arithmetic of the other waves.
       WPROF_T0B();
+#ifdef POTUS_PROF
+      cl_wide_consume(x, pend.tag, pend.nv, wout, prof);
+#else
       cl_wide_consume(x, pend.tag, pend.nv, wout);
+#endif
       WPROF_PTB(29);
       cl_leaf_logic(ts, pend, wout);
       WPROF_PTB(30);
@@ -830,7 +863,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   TSTAMP(4);
   // The verdicts ended the trajectory: every member leaves here together.  What this pass has stored so far (the
   // epilogue of the poll-noise elements) went to slots nobody reads once the trajectory is over.
-  if (pend.n >= 0 && ts->abort) { aborted = true; return 0.0; }
+  if (pend.n >= 0 && uni_i(ts->abort)) { aborted = true; return 0.0; }
 
   // ---------------- phase D: adjoint of the walk, gC[:,t] = sum_i r_i Lw_ext[s_i,:] summed over days <= t.
   // The member's polls (day order) are cut into PT_NW equal chunks, one per wave, whatever the days: a wave
@@ -1176,7 +1209,8 @@ struct ClChain {
 #ifdef POTUS_PROF
   ldp prof;
 #endif
-  __device__ __forceinline__ unsigned soff(int slot) const { return (unsigned)slot * (unsigned)Dpad * 8u; }
+  // (slot numbers read from LDS are wave-uniform, but only readfirstlane tells the compiler: see xst)
+  __device__ __forceinline__ unsigned soff(int slot) const { return __builtin_amdgcn_readfirstlane((unsigned)slot * (unsigned)Dpad * 8u); }
   __device__ __forceinline__ ldp red() const { return lds + CL->l_red; }
 };
 
@@ -1363,15 +1397,16 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
   const double eps = ts->eps;
   while (true) {
     __syncthreads();
-    if (ts->depth >= c.max_depth || ts->stop) break;
-    const int depth = ts->depth;
+    if (uni_i(ts->depth) >= c.max_depth || uni_i(ts->stop)) break;
+    const int depth = uni_i(ts->depth);
+    c.x.epoch = uni32(c.x.epoch); c.x.x1e = uni32(c.x.x1e);
     if (tid == 0) {
       ts->dir = rng_uniform(c.key, iter, RNG_DIRECTION, 0, (uint32_t)depth) > 0.5 ? 1 : 0;
       ts->pmask = 0;
       ts->qmask = (1u << ts->sample_qid) | (1u << ts->nextq[0]) | (1u << ts->nextq[1]);
     }
     __syncthreads();
-    const int dir = ts->dir;
+    const int dir = uni_i(ts->dir);
     CPROF_START(c);
     cl_vop_copy<false>(c, c.soff(V_PNEAR), c.soff(V_PF0 + dir));
     CPROF_MARK(c, PF_PNEAR);
@@ -1391,8 +1426,9 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
       }
       __syncthreads();
       const double e = dir ? eps : -eps;
-      const int inq = n == 0 ? ts->nextq[dir] : prev_outq, outq = ts->out_q;   // slots of this leaf's position and of the one it produces
-      const int leaf = ts->leaf_id;
+      const int inq = n == 0 ? uni_i(ts->nextq[dir]) : prev_outq, outq = uni_i(ts->out_q);   // slots of this leaf's position and of the one it produces
+      const int leaf = uni_i(ts->leaf_id);
+      c.x.epoch = uni32(c.x.epoch); c.x.x1e = uni32(c.x.x1e);
       const unsigned s_leaf = c.soff(V_POOLP + leaf);
       const int m = __builtin_ctz(~(unsigned)n);  // levels merged at this leaf
       const bool top = n == nleaf - 1;            // then m == depth
@@ -1430,7 +1466,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
       }
       if (m > 1 || top) { drain_vmem(); __syncthreads(); }   // the leaf's momentum is read back with another thread map
       for (int j = 2; j <= m; j++) {
-        const int ib = ts->pend_beg[j - 1], ie = ts->pend_end[j - 1], cb = ts->pend_beg[j - 2];
+        const int ib = uni_i(ts->pend_beg[j - 1]), ie = uni_i(ts->pend_end[j - 1]), cb = uni_i(ts->pend_beg[j - 2]);
         const unsigned a_rho = c.soff(V_RHOLEV + j - 1);
         const unsigned b_rho = c.soff(V_SCR0 + ((j - 1) & 1));
         const unsigned out = j == m ? c.soff(V_RHOLEV + j) : c.soff(V_SCR0 + (j & 1));
@@ -1439,7 +1475,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
       }
       if (top) {
         // the checks at the end of transition(): old trajectory (init side) against the new subtree
-        const int nb = depth >= 1 ? ts->pend_beg[depth - 1] : leaf;
+        const int nb = depth >= 1 ? uni_i(ts->pend_beg[depth - 1]) : leaf;
         const unsigned n_rho = depth == 0 ? c.soff(V_POOLP + leaf) : c.soff(V_RHOLEV + depth);
         cl_vop_merge_partial(c, c.soff(V_PF1 - dir), c.soff(V_PNEAR), c.soff(V_RHOTOP), c.soff(V_POOLP + nb), c.soff(V_POOLP + leaf), n_rho,
                              c.soff(V_RHOTOP), wpart + (2 + 6 * m) * PT_NW);
@@ -1457,7 +1493,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
       }
       __syncthreads();
       CPROF_MARK(c, PF_LEAF_SCALAR);
-      if (ts->abort) { valid = false; c.x.x1e = 0; break; }
+      if (uni_i(ts->abort)) { valid = false; c.x.x1e = 0; break; }
       cl_vop_copy<false>(c, c.soff(V_PF0 + dir), c.soff(V_POOLP + leaf));   // the last leaf is the new end point
       CPROF_MARK(c, PF_COPYQ);
     }
@@ -1503,7 +1539,7 @@ __device__ __forceinline__ void cl_init_stepsize(ClChain &c, uint32_t iter) {
       }
     }
     __syncthreads();
-    if (ts->done) break;
+    if (uni_i(ts->done)) break;
   }
   __syncthreads();
 }
@@ -1535,7 +1571,7 @@ __device__ __forceinline__ void cl_adapt_after_transition(ClChain &c, uint32_t i
     ts->flag_a = fa; ts->flag_b = fb;
   }
   __syncthreads();
-  const int in_window = ts->flag_a, end_window = ts->flag_b;
+  const int in_window = uni_i(ts->flag_a), end_window = uni_i(ts->flag_b);
   const unsigned sQ = c.soff(V_QC), sMean = c.soff(V_WMEAN), sM2 = c.soff(V_WM2), sMinv = c.soff(V_MINV);
   if (in_window) { // welford_var_estimator::add_sample
     const double n = sc->wf_n;

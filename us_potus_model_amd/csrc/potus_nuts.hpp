@@ -186,7 +186,9 @@ struct Chain {
 #endif
   rsrc_t st;   // buffer resource over this chain's whole state block
   __device__ __forceinline__ gdp vec(int slot) const { return base + (size_t)slot * Dpad; }
-  __device__ __forceinline__ unsigned soff(int slot) const { return (unsigned)slot * (unsigned)Dpad * 8u; }
+  // (slot numbers read from LDS are wave-uniform; readfirstlane tells the compiler, which otherwise wraps every access
+  // with such a scalar offset in a waterfall loop)
+  __device__ __forceinline__ unsigned soff(int slot) const { return __builtin_amdgcn_readfirstlane((unsigned)slot * (unsigned)Dpad * 8u); }
   __device__ __forceinline__ ldp red() const { return lds + M->l_red; }
 };
 #ifdef POTUS_PROF
