@@ -1,12 +1,14 @@
 // Micro-benchmark (development aid): one reader wave fetches 16 rows (51 lanes x 16 bytes each) written by 16 different
 // workgroups of the same XCD (as the cluster's exchange does) or by a single one; sc1 loads, all in flight.
+// prestore = 1 / 2: the reader issues one sc1 / plain store right before the loads (the wait for the loads then also
+// waits for the store's acknowledgement: loads and stores share vmcnt on gfx9-class hardware).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define ROWB 3712u
 
-template <int WRITERS, int AUX, int NLANES>
+template <int WRITERS, int AUX, int NLANES, int PRESTORE>
 __global__ __launch_bounds__(64) void k_batch(double *buf, unsigned *flag, long long *cyc, int iters) {
   rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(buf, 0, 1u << 20, 0x00020000);
   const int lane = threadIdx.x;
@@ -31,6 +33,7 @@ __global__ __launch_bounds__(64) void k_batch(double *buf, unsigned *flag, long 
         while (__hip_atomic_load(flag + 32 * wr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)it) __builtin_amdgcn_s_sleep(2);
       __builtin_amdgcn_s_sleep(40);
       const long long t0 = clock64();
+      if (PRESTORE) { u32x4 z = {(unsigned)it, 1u, 2u, 3u}; __builtin_amdgcn_raw_buffer_store_b128(z, r, lane < NLANES ? 16u * lane : 0xFFFFFF00u, 20 * ROWB, PRESTORE == 1 ? 16 : 0); }
       u32x4 w[16];
 #pragma unroll
       for (int u = 0; u < 16; u++) w[u] = __builtin_amdgcn_raw_buffer_load_b128(r, lane < NLANES ? 16u * lane : 0xFFFFFF00u, u * ROWB, AUX);
@@ -44,16 +47,17 @@ __global__ __launch_bounds__(64) void k_batch(double *buf, unsigned *flag, long 
     if (lane == 0) { cyc[0] = tot / iters; cyc[1] = acc; }
   }
 }
-template <int WRITERS, int AUX, int NLANES> void run(const char *nm) {
+template <int WRITERS, int AUX, int NLANES, int PRESTORE = 0> void run(const char *nm) {
   double *buf; unsigned *flag; long long *cyc;
   hipMalloc(&buf, 1 << 20); hipMemset(buf, 0, 1 << 20); hipMalloc(&flag, 8192); hipMemset(flag, 0, 8192); hipMalloc(&cyc, 16);
-  hipLaunchKernelGGL((k_batch<WRITERS, AUX, NLANES>), dim3(8 * 17), dim3(64), 0, 0, buf, flag, cyc, 300);
+  hipLaunchKernelGGL((k_batch<WRITERS, AUX, NLANES, PRESTORE>), dim3(8 * 17), dim3(64), 0, 0, buf, flag, cyc, 300);
   hipDeviceSynchronize();
   long long c[2]; hipMemcpy(c, cyc, 16, hipMemcpyDeviceToHost);
-  printf("%-8s writers=%2d lanes=%2d: %lld cycles per batch of 16 (fresh words seen: %lld of %d)\n", nm, WRITERS, NLANES, c[0], c[1], 300 * 16);
+  printf("%-8s prestore=%d writers=%2d lanes=%2d: %lld cycles per batch of 16 (fresh words seen: %lld of %d)\n", nm, PRESTORE, WRITERS, NLANES, c[0], c[1], 300 * 16);
   hipFree(buf); hipFree(flag); hipFree(cyc);
 }
 int main() {
+  run<16, 16, 51, 1>("sc1"); run<16, 16, 51, 2>("sc1");
   run<1, 16, 51>("sc1"); run<16, 16, 51>("sc1"); run<16, 16, 20>("sc1"); run<16, 16, 4>("sc1"); run<16, 17, 51>("sc0 sc1"); run<1, 0, 51>("plain"); run<16, 0, 51>("plain");
   return 0;
 }
