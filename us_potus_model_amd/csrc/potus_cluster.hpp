@@ -1041,13 +1041,6 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     }
   }
   // loads that do not depend on the exchange are issued while wave 0 waits
-  typename Pol::GT gz[CL_DW];
-  unsigned voz[CL_DW];
-#pragma unroll
-  for (int j = 0; j < CL_DW; j++) {
-    voz[j] = (lane < S && j < wnd) ? 8u * (unsigned)(e0 + lane + S * (wd0 + j)) : PT_OOB;
-    pol.g_load(voz[j], gz[j]);
-  }
   const bool arl = full && w == 1 && lane < nd;                 // owner of raw_e_bias[d0 + lane]
   // small-vector slots: threads 128.. take the ordinary slots of the member; mu_e_bias and rho_e_bias (the last
   // two slots, whose gradients come from the three tangent sums) go to the last lanes of the last wave of their
@@ -1142,6 +1135,13 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     xst(x, (pubnext && (arl || repl)) ? 16u * (unsigned)(XQ0 + jrep) : PT_OOB, qn_own);
   }
   PROF_SUB(52);
+  typename Pol::GT gz[CL_DW];
+  unsigned voz[CL_DW];
+#pragma unroll
+  for (int j = 0; j < CL_DW; j++) {
+    voz[j] = (lane < S && j < wnd) ? 8u * (unsigned)(e0 + lane + S * (wd0 + j)) : PT_OOB;
+    pol.g_load(voz[j], gz[j]);
+  }
   __syncthreads();
   PROF_SUB(53);
   {
