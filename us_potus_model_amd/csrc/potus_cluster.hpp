@@ -929,29 +929,26 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   TSTAMP(5);
 
   // ---------------- phase E: the owners of the days pick up the running sums; level-2 segment sums
-  double pre[CL_DW];
+  // (the chunk totals X[chunk][state] are turned into exclusive prefixes in place by wave 0, which keeps their sum for
+  // its X2 word; after the barrier every wave looks its days' chunks up instead of carrying the eight prefixes around)
+  int tlast[CL_DW], ch[CL_DW];
+  double cv[CL_DW];
+  double chunk_total = 0.0;
   {
-    double ct[PT_NW], cpre[PT_NW];
-#pragma unroll
-    for (int c = 0; c < PT_NW; c++) ct[c] = X[c * SE + (lane < S ? lane : S)];
-    int tlast[CL_DW], ch[CL_DW];
-    double cv[CL_DW];
 #pragma unroll
     for (int j = 0; j < CL_DW; j++) {
       const int info = __builtin_amdgcn_readlane(cst.s2info, j);
       tlast[j] = (info & 0xff) - 1; ch[j] = info >> 8;
       cv[j] = C[(lane < S ? lane : 0) * NDP + max(tlast[j], 0)];
     }
-    ISSUE_FENCE();
-    double run = 0.0;
+    if (w == 0) {
+      double ct[PT_NW];
+      const int lx = lane < S ? lane : S;
 #pragma unroll
-    for (int c = 0; c < PT_NW; c++) { cpre[c] = run; run += ct[c]; }
+      for (int c = 0; c < PT_NW; c++) ct[c] = X[c * SE + lx];
+      ISSUE_FENCE();
 #pragma unroll
-    for (int j = 0; j < CL_DW; j++) {
-      double cc = cpre[0];
-#pragma unroll
-      for (int c = 1; c < PT_NW; c++) cc = ch[j] == c ? cpre[c] : cc;
-      pre[j] = tlast[j] >= 0 ? cv[j] + cc : 0.0;
+      for (int c = 0; c < PT_NW; c++) { X[c * SE + lx] = chunk_total; chunk_total += ct[c]; }
     }
   }
   {
@@ -976,9 +973,14 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // ---------------- phase E2: payload of X2
   double arA = 1.0, arB = 0.0;                      // wave 1 keeps its per-day adjoint composites for phase F
   double pay = 0.0;                                 // the word this lane publishes (wave 0: prefix total, wave 1: AR words)
-  if (w == 0) {
+  double pre[CL_DW];
 #pragma unroll
-    for (int w2 = 0; w2 < PT_NW; w2++) pay += X[w2 * SE + (lane < S ? lane : S)];
+  for (int j = 0; j < CL_DW; j++) {
+    const double cc = X[ch[j] * SE + (lane < S ? lane : S)];
+    pre[j] = tlast[j] >= 0 ? cv[j] + cc : 0.0;
+  }
+  if (w == 0) {
+    pay = chunk_total;
   } else if (w == 1) {
     if (full) {
       // adjoint of the AR(1) recursion over the member's days (one lane per day): a[t] = ge[t] + rho a[t+1]
