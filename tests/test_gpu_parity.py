@@ -4,6 +4,8 @@ fixtures.  Floating point, so tolerances are stated: log density 1e-11 relative;
 
 Both device paths are covered: cus_per_chain = 1 (one workgroup per chain, potus_model.hpp /
 potus_nuts.hpp) and clusters of 8 and 16 workgroups per chain (potus_cluster.hpp)."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -180,6 +182,25 @@ def test_launch_boundaries_do_not_change_the_draws_across_a_window_end(cases, na
         out.append(h.draws()[0][:total].copy()); h.close()
     for d in out[1:]:
         assert np.array_equal(out[0], d)
+
+
+def test_sample_over_several_devices_equals_one_device(cases, tmp_path):
+    """PotusModel.sample(devices=[...]): the chains are dealt to the devices in blocks and run together; extract(),
+    as_array() and the CSV files are those of a single-device fit (this box has one GPU: both blocks sit on device 0)."""
+    data, variant = cases["small_full"]
+    kw = dict(seed=5, chains=5, iter_warmup=30, iter_sampling=12, refresh=10)
+    one = PotusModel(variant).sample(data, **kw)
+    two = PotusModel(variant).sample(data, devices=[0, 0], **kw)
+    assert two.chains == 5 and len(two._hs) == 2
+    for name in ("mu_b", "predicted_score", "lp__", "raw_polling_bias"):
+        assert np.array_equal(one.extract(name), two.extract(name)), name
+    assert np.array_equal(one.as_array("mu_c"), two.as_array("mu_c"))
+    f1, f2 = one.output_files(tmp_path / "a"), two.output_files(tmp_path / "b")
+    assert [Path(f).name for f in f1] == [Path(f).name for f in f2] and len(f2) == 5
+    for a_, b_ in zip(f1, f2):
+        la = [ln for ln in open(a_) if not ln.startswith("#")]
+        lb = [ln for ln in open(b_) if not ln.startswith("#")]
+        assert la == lb
 
 
 @pytest.mark.parametrize("cus", [0, 1])

@@ -233,12 +233,18 @@ def run_many(handles, n_iter):
 class StanFit:
     """What the scripts use of rstan's stanfit: extract(pars), model_name, sampler params."""
 
-    def __init__(self, handle: Handle, model_name: str):
-        self._h = handle
+    def __init__(self, handle, model_name: str):
+        # one handle, or one per device holding consecutive blocks of chains (PotusModel.sample(devices=...))
+        self._hs = list(handle) if isinstance(handle, (list, tuple)) else [handle]
+        self._h = self._hs[0]
         self.model_name = model_name  # out@model_name, final_2016.R:825
-        self._draws = handle.draws()
+        self._draws = np.concatenate([h.draws() for h in self._hs], axis=0)
         self.n_saved = self._draws.shape[1]
         self.chains = self._draws.shape[0]
+
+    def _write_array(self, a, b):
+        """[iter, chain, b - a] over all devices, chains in id order."""
+        return np.concatenate([h.write_array(a, b, self.n_saved) for h in self._hs], axis=1)
 
     def sampler_params(self):
         """dict of [chains, draws] arrays: lp__, accept_stat__, ... (rstan::get_sampler_params)."""
@@ -264,7 +270,7 @@ class StanFit:
             if name not in self._h.layout:
                 raise KeyError(f"unknown parameter {name!r}")
             a, b, dims = self._h.layout[name]
-            arr = self._h.write_array(a, b, self.n_saved)            # [iter, chain, n]
+            arr = self._write_array(a, b)                            # [iter, chain, n]
             arr = np.transpose(arr, (1, 0, 2)).reshape(self.chains * self.n_saved, b - a)
             if dims:
                 arr = arr.reshape((arr.shape[0],) + tuple(reversed(dims))).transpose(
@@ -280,11 +286,14 @@ class StanFit:
     def as_array(self, pars):
         """as.array(stanfit)[, , pars]: [iterations, chains, columns]."""
         a, b, _ = self._h.layout[pars]
-        return self._h.write_array(a, b, self.n_saved)
+        return self._write_array(a, b)
 
     def output_files(self, directory, basename=None):
         """fit$output_files(): writes CmdStan CSVs for rstan::read_stan_csv (final_2016.R:543)."""
-        return self._h.write_stan_csv(directory, basename or self.model_name.replace("_model", ""))
+        files = []
+        for h in self._hs:                           # files are numbered by global chain id
+            files += h.write_stan_csv(directory, basename or self.model_name.replace("_model", ""))
+        return files
 
 
 class PotusModel:
@@ -301,24 +310,35 @@ class PotusModel:
 
     def sample(self, data, seed=1843, chains=4, parallel_chains=None, iter_warmup=1000, iter_sampling=1000,
                refresh=100, adapt_delta=0.8, max_treedepth=10, init=2.0, save_warmup=False, device=0,
-               chain_id_offset=0, show_messages=False, inits=None):
-        h = Handle(data, self.variant, chains=int(chains), chain_id_offset=int(chain_id_offset),
-                   num_warmup=int(iter_warmup), num_samples=int(iter_sampling), max_depth=int(max_treedepth),
-                   delta=float(adapt_delta), init_radius=float(init), seed=int(seed), device=int(device),
-                   save_warmup=int(bool(save_warmup)))
-        h.init(inits)
+               chain_id_offset=0, show_messages=False, inits=None, devices=None):
+        """`devices`: GPU ids; the chains are dealt to them in consecutive blocks and advance together under
+        potus_run_many (one host thread).  Chain ids -- hence RNG streams and draws -- do not depend on the split."""
+        from . import parallel
+        devs = [int(device)] if devices is None else [int(d) for d in devices]
+        hs, first = [], 0
+        for r, dev in enumerate(devs):
+            off, n_loc = parallel.chain_block(int(chains), r, len(devs))
+            if n_loc == 0:
+                continue
+            h = Handle(data, self.variant, chains=n_loc, chain_id_offset=int(chain_id_offset) + off,
+                       num_warmup=int(iter_warmup), num_samples=int(iter_sampling), max_depth=int(max_treedepth),
+                       delta=float(adapt_delta), init_radius=float(init), seed=int(seed), device=dev,
+                       save_warmup=int(bool(save_warmup)))
+            h.init(None if inits is None else np.asarray(inits)[off:off + n_loc])
+            hs.append(h)
         total = int(iter_warmup) + int(iter_sampling)
         chunk = max(1, int(refresh)) if refresh else total
         done = 0
         while done < total:
             n = min(chunk, total - done)
-            h.run(n)
+            run_many(hs, n)
             done += n
             if show_messages:
                 phase = "Warmup" if done <= iter_warmup else "Sampling"
                 print(f"Iteration: {done:5d} / {total} [{100 * done // total:3d}%]  ({phase})", flush=True)
-        self.last_handle = h
-        return StanFit(h, self.model_name)
+        self.last_handle = hs[0]
+        self.last_handles = hs
+        return StanFit(hs, self.model_name)
 
 
 def sampling(model: PotusModel, data, chains=4, iter=2000, warmup=None, refresh=None, seed=1843, control=None,
