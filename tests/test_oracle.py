@@ -73,6 +73,22 @@ def test_oracle_matches_golden_and_autograd(cases, name):
     assert np.allclose(wa[a - 7:b - 7], aux["eta_n"], rtol=1e-12, atol=1e-13)
 
 
+def test_oracle_matches_autograd_at_the_stress_shape():
+    """BASELINE configs[4] sizes (51 x 600 days x 10 000 polls, D = 41 610): the oracle the GPU test at that size is
+    checked against is itself pinned to the independent torch transcription."""
+    from us_potus_model_amd import synthetic
+    data = synthetic.stress()
+    m = OracleModel(data, "full")
+    assert m.D == 41610
+    q = np.random.default_rng(7).uniform(-1.5, 1.5, m.D)
+    lp, grad = m.log_prob_grad(q)
+    lpf, gradf = m.log_prob_grad(q, fast=True)
+    lpt, gt, _ = st.log_prob_grad(data, q, "full")
+    assert abs(lp - lpt) <= 1e-12 * abs(lpt) and abs(lpf - lpt) <= 1e-12 * abs(lpt)
+    scale = np.abs(gt).max()
+    assert np.abs(grad - gt).max() <= 1e-12 * scale and np.abs(gradf - gt).max() <= 1e-12 * scale
+
+
 @pytest.mark.parametrize("name", ["small_full", "small_nomode"])
 def test_finite_differences(cases, name):
     data, variant = cases[name]
