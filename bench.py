@@ -146,7 +146,8 @@ def main():
             t_warm_end = time.perf_counter()
     pooled = None
     if world > 1:  # the one exchange of the path: pool draws-of-interest over xGMI
-        interest = np.concatenate([h.draws()[:, :, :1],
+        # (lp__ and mu_b[:, T] through write_array: two small column ranges, not the 1 GB draws array)
+        interest = np.concatenate([np.transpose(h.write_array(0, 1, ns), (1, 0, 2)),
                                    np.transpose(h.write_array(a_mu + S * (T - 1), a_mu + S * T, ns), (1, 0, 2))], axis=2)
         pooled = parallel.all_gather_draws(interest, total_chains, device=dev)
     torch.cuda.synchronize()
@@ -160,7 +161,7 @@ def main():
     samp_time = parallel.max_over_ranks(t1 - (t_warm_end or t0), dev)
 
     if pooled is None:
-        pooled = np.concatenate([h.draws()[:, :, :1],
+        pooled = np.concatenate([np.transpose(h.write_array(0, 1, ns), (1, 0, 2)),
                                  np.transpose(h.write_array(a_mu + S * (T - 1), a_mu + S * T, ns), (1, 0, 2))], axis=2)
     st, dv = h.chain_status()
 
