@@ -104,13 +104,20 @@ def main():
     import torch
     from us_potus_model_amd import Handle, dataprep, diagnostics as dg, parallel
 
-    rank, world, local = parallel.init_process_group()
+    # POTUS_DIST_BACKEND=gloo: development aid -- every rank on GPU 0 and CPU tensors in the collectives, to exercise
+    # the N > 1 flow on a one-GPU box (the measured configuration is one rank per GPU over RCCL)
+    dev_backend = os.environ.get("POTUS_DIST_BACKEND")
+    rank, world, local = parallel.init_process_group(dev_backend)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if dev_backend == "gloo":
+        local = 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if dev_backend == "gloo":
+        dev = None                                   # collectives on CPU tensors
 
     data = dataprep.load_npz(ROOT / "tests" / "golden" / "data_2016.npz")["data"]
     variant = "full"
