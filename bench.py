@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=100, help="transitions per kernel launch")
     ap.add_argument("--seed", type=int, default=1843)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-saturated", action="store_true", help="skip the 256-chain reference point")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     args = ap.parse_args()
 
@@ -212,6 +213,24 @@ def main():
                          "note": f"latency-bound at {C} chains ({C * K} of 256 CUs busy): the state of a chain stays in L2, "
                                  "the leapfrog is a chain of dependent exchanges between the CUs of a cluster; see DESIGN.md"},
         }
+        if world == 1 and not args.no_saturated:
+            # The same posterior with the GPU full: 256 chains, one workgroup per chain (k_run).  Not the metric's
+            # configuration -- a reference point for what the kernels deliver when parallelism is not the limit.
+            try:
+                hs = Handle(data, variant, chains=256, num_warmup=60, num_samples=0, seed=args.seed + 7, device=local, cus_per_chain=1)
+                hs.init()
+                ms_s, lf_s = 0.0, 0
+                for _ in range(3):
+                    hs.run(20)
+                    ms1, lf1 = hs.last_run_timing()
+                    ms_s += ms1; lf_s += lf1
+                hs.close()
+                rate = lf_s / (ms_s * 1e-3)
+                line["saturated"] = {"chains": 256, "cus_per_chain": 1, "kernel": "k_run", "iterations": 60, "value": rate, "unit": "leapfrogs/s",
+                                     "roofline_frac": rate * bpl / 1e9 / HBM_PEAK_GBS,
+                                     "note": "short warm-up run of 256 chains on the same posterior; kernel time of the launches"}
+            except Exception as e:                     # never let the side measurement spoil the bench line
+                line["saturated"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and world == 1:   # the CPU port is timed beside the single-GPU run only
             line["cpu_baseline"] = cpu_baseline(data, variant, C, args.cpu_budget)
             line["speedup_vs_cpu_port"] = line["value"] / line["cpu_baseline"]["value"]
