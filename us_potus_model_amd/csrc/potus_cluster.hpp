@@ -94,9 +94,18 @@ template <class P> __device__ __forceinline__ P launder_s(P p) { // keep address
 // Every payload word travels as 16 bytes {value, tag}: tag = (launch id, exchange number).  A reader
 // simply re-loads until the tag is the one it expects, so publishing is a fire-and-forget store and
 // there is no counter, no separate flag and no barrier on the consumer side.  Payload buffers rotate
-// over four slots (exchange number mod 4).  Safe because a member publishes exchange e+3 only after
-// consuming e+1 and e+2, at least one of which is read by every member from every member (only X1 is
-// not, and two X1 are never adjacent): everybody has then published that one, hence finished reading e.
+// over four slots (exchange number mod 4): the slot of exchange e is rewritten by e+4.  With pipelined leaves a pass
+// owns three exchanges -- X2(n) = e, the X1 / small parameters sent ahead for pass n+1 = e+1, X3(n) = e+2 -- and the
+// readers are: X2(n) in pass n phase F; e+1 in pass n+1 phases A and B; X3(n) in pass n+1 phase C.  The writer of e+4
+// (the ahead-exchange of pass n+1, sent from its epilogue) has by then taken the verdicts of leaf n, for which it needed
+// X3(n) of EVERY member; a member sends its X3(n) after its own pass n, i.e. after it has read X2(n).  Likewise e+5 =
+// X3(n+1) follows the writer's own reads of e+1, and the other members read e+1 before they can send the X3(n+1)
+// ... that the writer of e+5's successors wait for.  Spelled out per word range: X1 words of member m are read by
+// the members before m, which send their X2 (needed by m's prefix) afterwards; the small-parameter words are read by
+// all members in phase A, before their X3 of that pass; X3 words are read by all in phase C, before their X2-consuming
+// phase F of the same pass completes and hence before anybody's next X3.  Exchanges outside the tree (all-reduces of
+// the begin / end code) are all-to-all and consumed at once.  A missed assumption would not corrupt data silently:
+// a word overwritten too early carries a newer tag and the reader spins until the watchdog trap.
 struct Xch {
   rsrc_t xb;               // the chain's exchange buffer [4][K][XW] words of 16 bytes
   unsigned epoch;          // exchanges published so far in this launch (identical in every member)
