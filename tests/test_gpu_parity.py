@@ -230,7 +230,7 @@ def test_three_backtests_concurrently_give_the_bytes_of_separate_runs(cases, cus
         assert np.array_equal(a, b)
     if cus == 0:
         assert k16 == 16                                 # 3 x 4 chains x 16 CUs = 192 of 256: one group
-        assert t_together < 0.8 * t_alone, (t_together, t_alone)
+        assert t_together < 0.9 * t_alone, (t_together, t_alone)   # concurrent, not one after the other
 
 
 @pytest.mark.parametrize("cus", [1, 16])
