@@ -567,7 +567,9 @@ typedef struct {
   int D, chain;
   uint32_t iter;
   double (*lpg)(const oracle_model *, const double *, double *);
-  double *minv;    /* inverse metric diagonal */
+  double *minv;    /* inverse metric diagonal (dense: its diagonal, kept for reporting) */
+  int dense;       /* dense_e_metric: Minv (D x D, row-major, symmetric), Lc = its lower Cholesky factor */
+  double *Minv, *Lc, *wf_M2d, *tmpv;
   double eps;      /* epsilon_ used by the current transition */
   double nom_eps;
   pspoint z;
@@ -598,21 +600,44 @@ static void update_potential_gradient(sampler *sp, pspoint *z) {
   z->V = -lp;
   for (int i = 0; i < sp->D; i++) z->g[i] = -z->g[i];
 }
-static double kinetic(const sampler *sp, const pspoint *z) { /* diag_e_metric::T */
-  double s = 0.0; for (int i = 0; i < sp->D; i++) s += sp->minv[i] * z->p[i] * z->p[i]; return 0.5 * s;
+/* M^-1 p: diag_e_metric / dense_e_metric::dtau_dp */
+static void dtau_dp(const sampler *sp, const double *p, double *out) {
+  const int D = sp->D;
+  if (!sp->dense) { for (int i = 0; i < D; i++) out[i] = sp->minv[i] * p[i]; return; }
+  for (int i = 0; i < D; i++) {
+    const double *row = sp->Minv + (size_t)i * D;
+    double s = 0.0; for (int j = 0; j < D; j++) s += row[j] * p[j];
+    out[i] = s;
+  }
+}
+static double kinetic(const sampler *sp, const pspoint *z) { /* diag_e_metric::T / dense_e_metric::T = 0.5 p' M^-1 p */
+  double s = 0.0;
+  if (!sp->dense) { for (int i = 0; i < sp->D; i++) s += sp->minv[i] * z->p[i] * z->p[i]; return 0.5 * s; }
+  dtau_dp(sp, z->p, sp->tmpv);
+  for (int i = 0; i < sp->D; i++) s += z->p[i] * sp->tmpv[i];
+  return 0.5 * s;
 }
 static double hamiltonian(const sampler *sp, const pspoint *z) { return kinetic(sp, z) + z->V; }
-static void sample_p(sampler *sp, pspoint *z, uint32_t purpose, uint32_t aux) { /* diag_e_metric::sample_p */
-  for (int j = 0; 2 * j < sp->D; j++) {
+static void sample_p(sampler *sp, pspoint *z, uint32_t purpose, uint32_t aux) { /* diag_e_metric / dense_e_metric::sample_p */
+  const int D = sp->D;
+  for (int j = 0; 2 * j < D; j++) {
     double a, b; oracle_rng_normal_pair(sp->o->seed, (uint32_t)sp->chain, sp->iter, purpose, aux, (uint32_t)j, &a, &b);
-    z->p[2 * j] = a / sqrt(sp->minv[2 * j]);
-    if (2 * j + 1 < sp->D) z->p[2 * j + 1] = b / sqrt(sp->minv[2 * j + 1]);
+    z->p[2 * j] = a;
+    if (2 * j + 1 < D) z->p[2 * j + 1] = b;
+  }
+  if (!sp->dense) { for (int i = 0; i < D; i++) z->p[i] /= sqrt(sp->minv[i]); return; }
+  /* p = inv_e_metric.llt().matrixU().solve(u): back substitution with U = Lc' */
+  for (int i = D - 1; i >= 0; i--) {
+    double s = z->p[i];
+    for (int j = i + 1; j < D; j++) s -= sp->Lc[(size_t)j * D + i] * z->p[j];
+    z->p[i] = s / sp->Lc[(size_t)i * D + i];
   }
 }
 /* expl_leapfrog::evolve (begin_update_p, update_q, end_update_p) */
 static void evolve(sampler *sp, pspoint *z, double eps) {
   for (int i = 0; i < sp->D; i++) z->p[i] -= 0.5 * eps * z->g[i];
-  for (int i = 0; i < sp->D; i++) z->q[i] += eps * sp->minv[i] * z->p[i];
+  if (!sp->dense) for (int i = 0; i < sp->D; i++) z->q[i] += eps * sp->minv[i] * z->p[i];
+  else { dtau_dp(sp, z->p, sp->tmpv); for (int i = 0; i < sp->D; i++) z->q[i] += eps * sp->tmpv[i]; }
   update_potential_gradient(sp, z);
   for (int i = 0; i < sp->D; i++) z->p[i] -= 0.5 * eps * z->g[i];
 }
@@ -626,7 +651,6 @@ static int criterion(const sampler *sp, const double *psm, const double *psp, co
   double a = 0, b = 0; for (int i = 0; i < sp->D; i++) { a += psp[i] * rho[i]; b += psm[i] * rho[i]; }
   return a > 0 && b > 0;
 }
-static void dtau_dp(const sampler *sp, const double *p, double *out) { for (int i = 0; i < sp->D; i++) out[i] = sp->minv[i] * p[i]; }
 
 /* base_nuts::build_tree.  `node` is the index of this subtree among the subtrees of its level
    inside the current doubling; it only selects the RNG slot of the multinomial draw. */
@@ -810,7 +834,7 @@ static void compute_next_window(sampler *sp) {
 static int learn_variance(sampler *sp, const double *q) {
   const int D = sp->D;
   int in_window = sp->win_counter >= sp->ib && sp->win_counter < sp->nw - sp->tb && sp->win_counter != sp->nw;
-  if (in_window) { /* welford_var_estimator::add_sample */
+  if (in_window && !sp->dense) { /* welford_var_estimator::add_sample */
     sp->wf_n += 1;
     for (int i = 0; i < D; i++) {
       double delta = q[i] - sp->wf_mean[i];
@@ -818,13 +842,38 @@ static int learn_variance(sampler *sp, const double *q) {
       sp->wf_m2[i] += (q[i] - sp->wf_mean[i]) * delta;
     }
   }
+  if (in_window && sp->dense) { /* welford_covar_estimator::add_sample: m2 += (q - m_new) * delta' */
+    sp->wf_n += 1;
+    double *delta = sp->tmpv;
+    for (int i = 0; i < D; i++) { delta[i] = q[i] - sp->wf_mean[i]; sp->wf_mean[i] += delta[i] / sp->wf_n; }
+    for (int i = 0; i < D; i++) {
+      const double di = q[i] - sp->wf_mean[i];
+      double *row = sp->wf_M2d + (size_t)i * D;
+      for (int j = 0; j < D; j++) row[j] += di * delta[j];
+    }
+  }
   int end_window = sp->win_counter == sp->win_next && sp->win_counter != sp->nw;
   if (end_window) {
     compute_next_window(sp);
     double n = sp->wf_n;
-    for (int i = 0; i < D; i++) {
-      double var = sp->wf_m2[i] / (n - 1.0);
-      sp->minv[i] = (n / (n + 5.0)) * var + 1e-3 * (5.0 / (n + 5.0));
+    if (!sp->dense) {
+      for (int i = 0; i < D; i++) {
+        double var = sp->wf_m2[i] / (n - 1.0);
+        sp->minv[i] = (n / (n + 5.0)) * var + 1e-3 * (5.0 / (n + 5.0));
+      }
+    } else { /* covar_adaptation::learn_covariance: covar = n/(n+5) * m2/(n-1) + 1e-3 * 5/(n+5) * I */
+      for (int i = 0; i < D; i++)
+        for (int j = 0; j < D; j++)
+          sp->Minv[(size_t)i * D + j] = (n / (n + 5.0)) * (sp->wf_M2d[(size_t)i * D + j] / (n - 1.0)) + (i == j ? 1e-3 * (5.0 / (n + 5.0)) : 0.0);
+      for (int i = 0; i < D; i++)      /* the estimator's m2 is symmetric up to rounding; the metric must be exactly so */
+        for (int j = 0; j < i; j++) { const double a2 = 0.5 * (sp->Minv[(size_t)i * D + j] + sp->Minv[(size_t)j * D + i]); sp->Minv[(size_t)i * D + j] = a2; sp->Minv[(size_t)j * D + i] = a2; }
+      for (int i = 0; i < D; i++) sp->minv[i] = sp->Minv[(size_t)i * D + i];
+      /* column-major view of a symmetric matrix = the matrix: reuse cholesky_lower (column-major in / out), then transpose to row-major */
+      double *Lcol = (double *)xmalloc(sizeof(double) * (size_t)D * D);
+      if (cholesky_lower(sp->Minv, Lcol, D) != 0) { free(Lcol); return -1; }
+      for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) sp->Lc[(size_t)i * D + j] = Lcol[i + (size_t)j * D];
+      free(Lcol);
+      memset(sp->wf_M2d, 0, sizeof(double) * (size_t)D * D);
     }
     sp->wf_n = 0; memset(sp->wf_mean, 0, sizeof(double) * (size_t)D); memset(sp->wf_m2, 0, sizeof(double) * (size_t)D);
     ++sp->win_counter;
@@ -844,13 +893,27 @@ void oracle_default_opts(oracle_opts *o) {
 
 int oracle_sample_chain(const oracle_model *m, const oracle_opts *o, int chain_id, const double *q0, double *draws,
                         double *adapt_out, long long *total_leapfrogs) {
+  return oracle_sample_chain_metric(m, o, chain_id, q0, draws, adapt_out, total_leapfrogs, NULL);
+}
+
+int oracle_sample_chain_metric(const oracle_model *m, const oracle_opts *o, int chain_id, const double *q0, double *draws,
+                               double *adapt_out, long long *total_leapfrogs, double *metric_out) {
   const int D = m->D;
   sampler sp; memset(&sp, 0, sizeof(sp));
   sp.m = m; sp.o = o; sp.D = D; sp.chain = chain_id; sp.iter = ITER_PRE;
   sp.lpg = o->fast_grad ? oracle_log_prob_grad_fast : oracle_log_prob_grad;
   sp.minv = vec(D); for (int i = 0; i < D; i++) sp.minv[i] = 1.0;
   sp.z = ps_alloc(D);
-  sp.wf_mean = vec(D); sp.wf_m2 = vec(D);
+  sp.wf_mean = vec(D); sp.wf_m2 = vec(D); sp.tmpv = vec(D);
+  memset(sp.wf_mean, 0, sizeof(double) * (size_t)D); memset(sp.wf_m2, 0, sizeof(double) * (size_t)D);
+  sp.dense = o->dense_metric != 0;
+  if (sp.dense) { /* dense_e_point: inv_e_metric_ = identity */
+    sp.Minv = (double *)xmalloc(sizeof(double) * (size_t)D * D); sp.Lc = (double *)xmalloc(sizeof(double) * (size_t)D * D);
+    sp.wf_M2d = (double *)xmalloc(sizeof(double) * (size_t)D * D);
+    memset(sp.Minv, 0, sizeof(double) * (size_t)D * D); memset(sp.Lc, 0, sizeof(double) * (size_t)D * D);
+    memset(sp.wf_M2d, 0, sizeof(double) * (size_t)D * D);
+    for (int i = 0; i < D; i++) { sp.Minv[(size_t)i * D + i] = 1.0; sp.Lc[(size_t)i * D + i] = 1.0; }
+  }
   int rc = 0;
   /* stan::services::util::initialize: U(-R,R) on the unconstrained scale, up to 100 attempts */
   if (q0) memcpy(sp.z.q, q0, sizeof(double) * (size_t)D);
@@ -888,6 +951,7 @@ int oracle_sample_chain(const oracle_model *m, const oracle_opts *o, int chain_i
     if (warm) { /* adapt_diag_e_nuts::transition */
       learn_stepsize(&sp, accept_stat);
       int update = sp.nw >= 20 ? learn_variance(&sp, sp.z.q) : 0;
+      if (update < 0) { rc = POTUS_ERR_STATE; goto done; }   /* adapted covariance not positive definite */
       if (update) {
         init_stepsize(&sp);
         sp.mu = log(10.0 * sp.nom_eps);
@@ -904,9 +968,13 @@ int oracle_sample_chain(const oracle_model *m, const oracle_opts *o, int chain_i
     }
   }
   if (adapt_out) { adapt_out[0] = sp.nom_eps; memcpy(adapt_out + 1, sp.minv, sizeof(double) * (size_t)D); }
+  if (metric_out) {
+    if (sp.dense) memcpy(metric_out, sp.Minv, sizeof(double) * (size_t)D * D);
+    else { memset(metric_out, 0, sizeof(double) * (size_t)D * D); for (int i = 0; i < D; i++) metric_out[(size_t)i * D + i] = sp.minv[i]; }
+  }
 done:
   if (total_leapfrogs) *total_leapfrogs = sp.total_leapfrogs;
-  ps_free(&sp.z); free(sp.minv); free(sp.wf_mean); free(sp.wf_m2);
+  ps_free(&sp.z); free(sp.minv); free(sp.wf_mean); free(sp.wf_m2); free(sp.tmpv); free(sp.Minv); free(sp.Lc); free(sp.wf_M2d);
   return rc;
 }
 

@@ -38,6 +38,8 @@ typedef struct oracle_opts {
   uint64_t seed;
   int32_t fast_grad;   /* 0: literal dense recursion (stan:86); 1: scan/sparse reformulation */
   int32_t save_warmup;
+  int32_t dense_metric; /* 0: diag_e (what the reference runs); 1: dense_e (stan::mcmc::dense_e_metric + covar_adaptation) */
+  int32_t pad_;
 } oracle_opts;
 
 void oracle_default_opts(oracle_opts *o);
@@ -71,6 +73,12 @@ void oracle_rng_normal_pair(uint64_t seed, uint32_t chain, uint32_t iter, uint32
 int oracle_sample_chain(const oracle_model *m, const oracle_opts *o, int chain_id,
                         const double *q0, double *draws, double *adapt_out,
                         long long *total_leapfrogs);
+
+/* the same with the adapted dense inverse metric returned as well (metric_out: D*D row-major, or NULL);
+ * with o->dense_metric = 0 it is filled with diag(minv) */
+int oracle_sample_chain_metric(const oracle_model *m, const oracle_opts *o, int chain_id,
+                               const double *q0, double *draws, double *adapt_out,
+                               long long *total_leapfrogs, double *metric_out);
 
 /* leapfrog micro-benchmark for bench.py's cpu_baseline: n steps from q0 with unit metric */
 double oracle_time_leapfrogs(const oracle_model *m, int n, double eps, int fast_grad, uint64_t seed);

@@ -18,7 +18,7 @@ class OracleOpts(C.Structure):
                 ("init_buffer", C.c_int32), ("term_buffer", C.c_int32), ("window", C.c_int32),
                 ("delta", C.c_double), ("gamma", C.c_double), ("kappa", C.c_double), ("t0", C.c_double),
                 ("stepsize", C.c_double), ("init_radius", C.c_double), ("seed", C.c_uint64),
-                ("fast_grad", C.c_int32), ("save_warmup", C.c_int32)]
+                ("fast_grad", C.c_int32), ("save_warmup", C.c_int32), ("dense_metric", C.c_int32), ("pad_", C.c_int32)]
 
 
 def build():
@@ -47,6 +47,8 @@ def lib():
         L.oracle_default_opts.argtypes = [C.POINTER(OracleOpts)]
         L.oracle_sample_chain.argtypes = [C.c_void_p, C.POINTER(OracleOpts), C.c_int, dp, dp, dp,
                                           C.POINTER(C.c_longlong)]
+        L.oracle_sample_chain_metric.argtypes = [C.c_void_p, C.POINTER(OracleOpts), C.c_int, dp, dp, dp,
+                                                 C.POINTER(C.c_longlong), dp]
         L.oracle_philox.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.oracle_rng_uniform.restype = C.c_double
         L.oracle_rng_uniform.argtypes = [C.c_uint64] + [C.c_uint32] * 5
@@ -114,6 +116,19 @@ class OracleModel:
         if rc:
             raise RuntimeError(f"oracle_sample_chain failed rc={rc}")
         return draws, adapt, nl.value
+
+    def sample_chain_metric(self, chain_id, opts, q0=None):
+        """sample_chain + the adapted inverse metric as a D x D matrix (diag(minv) for the diagonal metric)."""
+        n_saved = opts.num_samples + (opts.num_warmup if opts.save_warmup else 0)
+        draws = np.zeros((n_saved, _abi.N_SAMPLER_COLS + self.D))
+        adapt = np.zeros(1 + self.D)
+        metric = np.zeros((self.D, self.D))
+        nl = C.c_longlong(0)
+        q0p = _dp(np.ascontiguousarray(q0, dtype=np.float64)) if q0 is not None else None
+        rc = self.L.oracle_sample_chain_metric(self.h, C.byref(opts), chain_id, q0p, _dp(draws), _dp(adapt), C.byref(nl), _dp(metric))
+        if rc:
+            raise RuntimeError(f"oracle_sample_chain_metric failed rc={rc}")
+        return draws, adapt, nl.value, metric
 
     def time_leapfrogs(self, n, eps=0.01, fast=False, seed=1):
         return self.L.oracle_time_leapfrogs(self.h, n, eps, int(fast), seed)

@@ -162,6 +162,36 @@ def test_sampler_small_posterior(cases):
     assert np.allclose(a[:5], b[:5], rtol=1e-7, atol=1e-7)
 
 
+def test_dense_metric_oracle(cases):
+    """stan::mcmc::dense_e_metric + covar_adaptation restated (groundwork for BASELINE configs[4]; the device path
+    has the diagonal metric only so far).  Checks: the adapted metric is symmetric positive definite and its diagonal
+    agrees with the diagonal-metric adaptation; the posterior agrees with the diagonal-metric chains within MCSE;
+    with unit metrics (no adaptation windows) both samplers make the same transitions."""
+    from us_potus_model_amd import diagnostics as dg
+    data, variant = cases["small_full"]
+    m = OracleModel(data, variant)
+    # no windows (num_warmup < 20): identity metric both ways -> identical chains
+    o_d = m.default_opts(num_warmup=10, num_samples=10, seed=3, fast_grad=1, dense_metric=0)
+    o_f = m.default_opts(num_warmup=10, num_samples=10, seed=3, fast_grad=1, dense_metric=1)
+    a, b = m.sample_chain(1, o_d)[0], m.sample_chain(1, o_f)[0]
+    assert np.array_equal(a[:, 3:6], b[:, 3:6]) and np.allclose(a[:, 7:], b[:, 7:], rtol=1e-9, atol=1e-12)
+    nw, ns = 150, 100
+    diag, dense, metrics = [], [], []
+    for c in (1, 2):
+        diag.append(m.sample_chain(c, m.default_opts(num_warmup=nw, num_samples=ns, seed=21, fast_grad=1))[0][:, 7:])
+        dr, ad, nl, M = m.sample_chain_metric(c, m.default_opts(num_warmup=nw, num_samples=ns, seed=21, fast_grad=1, dense_metric=1))
+        dense.append(dr[:, 7:]); metrics.append((ad, M))
+    ad, M = metrics[0]
+    assert np.allclose(M, M.T, rtol=0, atol=0) and np.linalg.eigvalsh(M).min() > 0
+    assert np.allclose(np.diag(M), ad[1:])
+    ad_diag = m.sample_chain(1, m.default_opts(num_warmup=nw, num_samples=0, seed=21, fast_grad=1))[1]
+    assert abs(np.median(np.log(np.diag(M) / ad_diag[1:]))) < 0.25        # same scale as the diagonal adaptation
+    diag, dense = np.stack(diag), np.stack(dense)                           # [chain, draw, D]
+    for j in range(0, m.D, 7):
+        mcse = np.sqrt(diag[:, :, j].var() / max(dg.ess_bulk(diag[:, :, j]), 10) + dense[:, :, j].var() / max(dg.ess_bulk(dense[:, :, j]), 10))
+        assert abs(diag[:, :, j].mean() - dense[:, :, j].mean()) < 5 * mcse, j
+
+
 def test_oracle_chains_are_independent_streams(cases):
     data, variant = cases["small_full"]
     m = OracleModel(data, variant)
