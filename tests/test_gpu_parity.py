@@ -393,3 +393,24 @@ def test_posterior_summary_matches_numpy_restatement(cases, name):
         assert np.allclose(got[k], ref[k], rtol=1e-12, atol=1e-12), (k, np.abs(got[k] - ref[k]).max())
     assert np.array_equal(got["state"][..., 3], ref["state"][..., 3])
     h.close()
+
+
+@pytest.mark.gpu
+def test_dense_metric_matvec_building_block():
+    """y = M^-1 p for a batch of chains (potus_dense.hpp, the HBM-bound operation of the dense metric; not yet part of
+    the sampler): against numpy at sizes that exercise partial row blocks and several column tiles, and reproducible."""
+    import ctypes as C
+    L = sampler.load_library()
+    L.potus_dense_matvec_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    rng = np.random.default_rng(4)
+    for chains, D in ((3, 1000), (2, 2049), (1, 16500)):
+        B = rng.standard_normal((chains, D, 8))
+        M = np.einsum("cik,cjk->cij", B, B) / 8 + np.eye(D)[None]          # symmetric positive definite
+        p = rng.standard_normal((chains, D))
+        y1, y2, ms = np.zeros((chains, D)), np.zeros((chains, D)), C.c_double()
+        for y in (y1, y2):
+            rc = L.potus_dense_matvec_probe(0, chains, D, M.ctypes.data, p.ctypes.data, y.ctypes.data, 2, C.byref(ms))
+            assert rc == 0
+        ref = np.einsum("cij,cj->ci", M, p)
+        assert np.abs(y1 - ref).max() <= 1e-12 * np.abs(ref).max() * np.sqrt(D)
+        assert np.array_equal(y1, y2)

@@ -6,6 +6,7 @@
 #include "../../include/potus_hmc.h"
 #include "potus_nuts.hpp"
 #include "potus_cluster.hpp"
+#include "potus_dense.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -1668,6 +1669,40 @@ int potus_debug_profile(int handle, double *out) {
   (void)hipSetDevice(sp->device);
   if (hipMemcpy(out, sp->R.prof, sizeof(double) * PT_NPROF * sp->R.chains * sp->K, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return PT_NPROF;
+}
+
+// Development entry point (not in include/potus_hmc.h): y = M^-1 p for `chains` dense inverse metrics of size D x D on
+// `device` (potus_dense.hpp).  Minv_host == NULL: the matrices are generated on the device (k_dense_fill) -- for rates
+// at sizes whose matrices would take seconds to upload.  Runs the kernel `reps` times; y_host [chains][D] receives the
+// result, *ms the average kernel time (HIP events).  Returns 0 or a POTUS_ERR_* code.
+int potus_dense_matvec_probe(int device, int chains, int D, const double *Minv_host, const double *p_host, double *y_host, int reps, double *ms) {
+  if (chains < 1 || D < 1 || !p_host || !y_host || reps < 1) return fail(POTUS_ERR_ARG, "potus_dense_matvec_probe: bad arguments");
+  HIP_TRY(hipSetDevice(device));
+  const size_t nM = (size_t)chains * D * D, nv = (size_t)chains * D;
+  double *dM = nullptr, *dp = nullptr, *dy = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  auto cleanup = [&]() { if (dM) (void)hipFree(dM); if (dp) (void)hipFree(dp); if (dy) (void)hipFree(dy); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); };
+  if (hipMalloc((void **)&dM, nM * 8) != hipSuccess || hipMalloc((void **)&dp, nv * 8) != hipSuccess || hipMalloc((void **)&dy, nv * 8) != hipSuccess) {
+    cleanup();
+    return fail(POTUS_ERR_DEVICE, "potus_dense_matvec_probe: hipMalloc of %zu bytes failed", nM * 8);
+  }
+  if (Minv_host) { if (hipMemcpy(dM, Minv_host, nM * 8, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(POTUS_ERR_DEVICE, "upload failed"); } }
+  else hipLaunchKernelGGL(k_dense_fill, dim3(4096), dim3(256), 0, 0, dM, D, chains);
+  if (hipMemcpy(dp, p_host, nv * 8, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(POTUS_ERR_DEVICE, "upload failed"); }
+  const size_t lds = (size_t)PD_TILE * 8;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_matvec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+      hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { cleanup(); return fail(POTUS_ERR_DEVICE, "setup failed"); }
+  const dim3 grid((D + PD_ROWS - 1) / PD_ROWS, chains);
+  hipLaunchKernelGGL(k_dense_matvec, grid, dim3(PD_THREADS), lds, 0, (const double *)dM, (const double *)dp, dy, D);   // warm-up
+  (void)hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_dense_matvec, grid, dim3(PD_THREADS), lds, 0, (const double *)dM, (const double *)dp, dy, D);
+  (void)hipEventRecord(e1, 0);
+  if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { cleanup(); return fail(POTUS_ERR_DEVICE, "k_dense_matvec failed"); }
+  float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
+  if (ms) *ms = (double)t / reps;
+  const bool ok = hipMemcpy(y_host, dy, nv * 8, hipMemcpyDeviceToHost) == hipSuccess;
+  cleanup();
+  return ok ? 0 : fail(POTUS_ERR_DEVICE, "download failed");
 }
 
 // Development aid: the whole state block [chains][V_COUNT][Dpad] (internal element order) and every replica of the
