@@ -558,7 +558,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = M->S, T = M->T, SE = M->SE, SP = M->SP, full = M->full, o_c = M->o_c;
   const int NDP = CL->NDP, NR = CL->NR, NREP = CL->NREP;
-  const int d0 = part[CP_D0], nd = part[CP_ND], p0 = part[CP_P0], np = part[CP_NP], e0 = part[CP_E0], r0 = part[CP_R0], nr = part[CP_NR];
+  const int d0 = part[CP_D0], nd = part[CP_ND], np = part[CP_NP], e0 = part[CP_E0], r0 = part[CP_R0], nr = part[CP_NR];
   const int K = x.K, m = x.m;
   const int wd0 = __builtin_amdgcn_readfirstlane(cst.wd0), wnd = __builtin_amdgcn_readfirstlane(cst.wnd);
   ldp C = lds + CL->l_C, Lw = lds + CL->l_Lw, X = lds + CL->l_X, Y = lds + CL->l_Y, r_lds = lds + CL->l_r, ru_lds = lds + CL->l_ru;
