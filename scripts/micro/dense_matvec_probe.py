@@ -30,3 +30,11 @@ for chains, D in ((1, 15098), (8, 15098), (1, 41610), (8, 41610)):
             ok &= abs(row @ p[c] - y[c, i]) <= 1e-10 * max(1.0, abs(y[c, i]))
     gb = chains * D * D * 8 / 1e9
     print(f"chains={chains} D={D}: {ms.value:.3f} ms per mat-vec, {gb / (ms.value * 1e-3):.0f} GB/s = {gb / (ms.value * 1e-3) / 8000:.2f} of 8 TB/s; rows check {'ok' if ok else 'MISMATCH'}")
+
+L.potus_dense_welford_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+for chains, D in ((8, 15098), (4, 41610)):
+    a = np.random.default_rng(2).standard_normal((chains, D)); d = np.random.default_rng(3).standard_normal((chains, D))
+    ms = C.c_double()
+    rc = L.potus_dense_welford_probe(0, chains, D, a.ctypes.data, d.ctypes.data, None, 5, C.byref(ms))
+    gb = chains * D * D * 16 / 1e9
+    print(f"welford update chains={chains} D={D}: rc={rc}, {ms.value:.3f} ms, {gb / (ms.value * 1e-3):.0f} GB/s read+write = {gb / (ms.value * 1e-3) / 8000:.2f} of 8 TB/s")

@@ -414,3 +414,20 @@ def test_dense_metric_matvec_building_block():
         ref = np.einsum("cij,cj->ci", M, p)
         assert np.abs(y1 - ref).max() <= 1e-12 * np.abs(ref).max() * np.sqrt(D)
         assert np.array_equal(y1, y2)
+
+
+@pytest.mark.gpu
+def test_dense_metric_welford_building_block():
+    """welford_covar_estimator::add_sample for a batch of chains (k_dense_welford): m2 += a delta', against numpy."""
+    import ctypes as C
+    L = sampler.load_library()
+    L.potus_dense_welford_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    rng = np.random.default_rng(6)
+    for chains, D in ((3, 1000), (2, 2051)):
+        a, d = rng.standard_normal((chains, D)), rng.standard_normal((chains, D))
+        M2, ms = np.zeros((chains, D, D)), C.c_double()
+        assert L.potus_dense_welford_probe(0, chains, D, a.ctypes.data, d.ctypes.data, M2.ctypes.data, 3, C.byref(ms)) == 0
+        ref = np.zeros((chains, D, D))
+        for _ in range(3):
+            ref = ref + a[:, :, None] * d[:, None, :]
+        assert np.allclose(M2, ref, rtol=1e-14, atol=1e-14)       # the device fuses the multiply-add

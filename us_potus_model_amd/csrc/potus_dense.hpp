@@ -63,6 +63,25 @@ __global__ __launch_bounds__(PD_THREADS) void k_dense_matvec(const double *__res
   }
 }
 
+// welford_covar_estimator::add_sample for a batch of chains: m2 += (q - mean_new) delta', delta = q - mean_old (both
+// D-vectors prepared by the caller: a = q - mean_new, delta).  16 D^2 bytes per chain and warm-up iteration inside the
+// adaptation windows; one workgroup per 8 rows, a thread keeps its column of delta in a register across the rows.
+__global__ __launch_bounds__(256) void k_dense_welford(double *__restrict__ M2 /*[chains][D][D]*/, const double *__restrict__ a /*[chains][D]*/,
+                                                       const double *__restrict__ delta /*[chains][D]*/, int D) {
+  const int chain = blockIdx.y, row0 = blockIdx.x * 8;
+  double *M = M2 + (size_t)chain * D * D;
+  const double *ac = a + (size_t)chain * D, *dc = delta + (size_t)chain * D;
+  double ar[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) ar[r] = row0 + r < D ? ac[row0 + r] : 0.0;
+  for (int j = threadIdx.x; j < D; j += 256) {
+    const double dj = dc[j];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      if (row0 + r < D) { double *e = M + (size_t)(row0 + r) * D + j; *e = *e + ar[r] * dj; }
+  }
+}
+
 // fills a symmetric positive definite test matrix on the device: A[i][j] = exp(-|i-j|/50) * (1 + 0.1 c) + (i == j ? 1 : 0)
 __global__ void k_dense_fill(double *Minv, int D, int chains) {
   const size_t n = (size_t)D * D;

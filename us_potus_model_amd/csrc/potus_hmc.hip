@@ -1705,6 +1705,33 @@ int potus_dense_matvec_probe(int device, int chains, int D, const double *Minv_h
   return ok ? 0 : fail(POTUS_ERR_DEVICE, "download failed");
 }
 
+// Development entry point: `reps` Welford covariance updates m2 += a delta' (k_dense_welford) on a zeroed m2 of
+// `chains` x D x D; M2_host (or NULL) receives the result, *ms the average kernel time.
+int potus_dense_welford_probe(int device, int chains, int D, const double *a_host, const double *delta_host, double *M2_host, int reps, double *ms) {
+  if (chains < 1 || D < 1 || !a_host || !delta_host || reps < 1) return fail(POTUS_ERR_ARG, "potus_dense_welford_probe: bad arguments");
+  HIP_TRY(hipSetDevice(device));
+  const size_t nM = (size_t)chains * D * D, nv = (size_t)chains * D;
+  double *dM = nullptr, *da = nullptr, *dd = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  auto cleanup = [&]() { if (dM) (void)hipFree(dM); if (da) (void)hipFree(da); if (dd) (void)hipFree(dd); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); };
+  if (hipMalloc((void **)&dM, nM * 8) != hipSuccess || hipMalloc((void **)&da, nv * 8) != hipSuccess || hipMalloc((void **)&dd, nv * 8) != hipSuccess ||
+      hipMemset(dM, 0, nM * 8) != hipSuccess || hipMemcpy(da, a_host, nv * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(dd, delta_host, nv * 8, hipMemcpyHostToDevice) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    cleanup();
+    return fail(POTUS_ERR_DEVICE, "potus_dense_welford_probe: device setup failed (%zu bytes)", nM * 8);
+  }
+  const dim3 grid((D + 7) / 8, chains);
+  (void)hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_dense_welford, grid, dim3(256), 0, 0, dM, (const double *)da, (const double *)dd, D);
+  (void)hipEventRecord(e1, 0);
+  if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { cleanup(); return fail(POTUS_ERR_DEVICE, "k_dense_welford failed"); }
+  float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
+  if (ms) *ms = (double)t / reps;
+  const bool ok = !M2_host || hipMemcpy(M2_host, dM, nM * 8, hipMemcpyDeviceToHost) == hipSuccess;
+  cleanup();
+  return ok ? 0 : fail(POTUS_ERR_DEVICE, "download failed");
+}
+
 // Development aid: the whole state block [chains][V_COUNT][Dpad] (internal element order) and every replica of the
 // chain scalars as raw bytes.  which = 0: sizes only (out[0] = V_COUNT, out[1] = Dpad, out[2] = sizeof scalars * replicas).
 int potus_debug_state(int handle, int which, double *out, unsigned char *scal) {
