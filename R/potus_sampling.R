@@ -16,8 +16,9 @@
 #   mu_b <- potus_extract(fit, "mu_b")             # = rstan::extract(out, pars = "mu_b")[[1]]
 #   out  <- rstan::read_stan_csv(potus_output_files(fit, tempdir()))   # the literal plumbing, if a stanfit is needed
 #
-# NOTE: R is not installed in the build image, so this file is exercised only through its C
-# entry points (tests/test_gpu_parity.py drives the same symbols with ctypes).
+# NOTE: R is not installed in the build image, so this file itself has never run; every .C() call below is
+# replayed argument for argument (int* / double* / char** only, outputs through the same buffers) by
+# tests/test_gpu_parity.py::test_r_entry_points_replay_the_shim with ctypes.
 
 potus_load <- function(path) dyn.load(path)
 
@@ -33,7 +34,8 @@ potus_load <- function(path) dyn.load(path)
 potus_sample <- function(data, variant = c("full", "no_mode_adjustment"), seed = 1843, chains = 4,
                          parallel_chains = chains, iter_warmup = 1000, iter_sampling = 1000, refresh = 100,
                          adapt_delta = 0.8, max_treedepth = 10, init = 2, device = 0, chain_id_offset = 0,
-                         save_warmup = FALSE, gpus = device) {
+                         save_warmup = FALSE, gpus = device, cus_per_chain = 0, metric = c("diag_e", "dense_e")) {
+  metric <- match.arg(metric)
   variant <- match.arg(variant)
   full <- variant == "full"
   iv <- function(x, n) if (is.null(x)) integer(max(n, 1)) else as.integer(x)
@@ -61,8 +63,8 @@ potus_sample <- function(data, variant = c("full", "no_mode_adjustment"), seed =
               as.double(data$mu_b_prior), as.double(data$state_weights), scalars,
               as.double(data$state_covariance_0),           # column-major, as R stores it
               as.integer(c(per[g], chain_id_offset + first[g], iter_warmup, iter_sampling, max_treedepth, gpus[g],
-                           as.integer(save_warmup), seed)),
-              as.double(c(adapt_delta, 0.05, 0.75, 10, 1, init)),
+                           as.integer(save_warmup), cus_per_chain, if (metric == "dense_e") 1L else 0L)),
+              as.double(c(adapt_delta, 0.05, 0.75, 10, 1, init, seed)),   # the seed as a double: exact to 2^53
               handle = integer(1), status = integer(1))
     .potus_check(res$status)
     .potus_check(.C("potus_R_init", res$handle, status = integer(1))$status)
@@ -80,8 +82,10 @@ potus_sample <- function(data, variant = c("full", "no_mode_adjustment"), seed =
   }
   info <- .C("potus_R_num_columns", handles[1], D = integer(1), n_cols = integer(1), status = integer(1))
   .potus_check(info$status)
+  saved <- .C("potus_R_saved_count", handles[1], n_saved = integer(1), status = integer(1))   # what the library holds, not what was asked for
+  .potus_check(saved$status)
   structure(list(handle = handles[1], handles = handles, chains_per_handle = counts, D = info$D, n_cols = info$n_cols, chains = chains,
-                 n_saved = iter_sampling + if (save_warmup) iter_warmup else 0L, data = data, variant = variant,
+                 n_saved = saved$n_saved, data = data, variant = variant,
                  model_name = if (full) "poll_model_2020_model" else "poll_model_2020_no_mode_adjustment_model"),
             class = "potus_fit")
 }
@@ -136,17 +140,27 @@ potus_output_files <- function(fit, dir, basename = "poll_model_2020") {
 }
 
 # Posterior summaries of predicted_score computed on the device (replaces final_2016.R:708-762 and :799-823:
-# no 8000 x 12954 array ever reaches R).  ev: electoral votes per state in state order (states2012$ev).
-# (Single-device fits; with gpus = several devices the summaries are per device: pool with potus_extract instead.)
+# no 8000 x 12954 array ever reaches R), pooled over every chain of the fit whatever the number of GPUs.
+# ev: electoral votes per state in state order (states2012$ev).
 # Returns list(state = array [T, S, 4] (low, high, mean, prob), national = [T, 4],
 #              electoral_votes = [T, 5] (mean, median, high, low, prob >= 270)).
 potus_summary <- function(fit, ev) {
   S <- fit$data$S; T <- fit$data$T
-  r <- .C("potus_R_posterior_summary", fit$handle, as.double(ev), state = double(T * S * 4), natl = double(T * 4),
-          ev_out = double(T * 5), status = integer(1))
+  r <- .C("potus_R_posterior_summary", as.integer(fit$handles), length(fit$handles), as.double(ev), state = double(T * S * 4),
+          natl = double(T * 4), ev_out = double(T * 5), status = integer(1))
   .potus_check(r$status)
   list(state = aperm(array(r$state, c(4, T, S)), c(2, 3, 1)),       # C order [s][t][4] -> [t, s, 4]
-       national = t(matrix(r$natl, nrow = 4)), electoral_votes = t(matrix(r$ev_out, nrow = 5)))
+       national = t(matrix(r$natl, nrow = 4)), electoral_votes = t(matrix(r$ev_out, nrow = 5)),
+       state_raw = r$state)
+}
+
+# Backtest scores of final_2016.R:925-945: EV-weighted Brier, unweighted Brier, states called correctly on `day`
+# (1-based; 0 = the last day).  won: 1 where the Democrat carried the state, in state order.
+potus_backtest_scores <- function(fit, summary, ev, won, day = 0L) {
+  r <- .C("potus_R_backtest_scores", summary$state_raw, as.integer(c(fit$data$T, fit$data$S, day)), as.double(ev), as.integer(won),
+          out = double(3), status = integer(1))
+  .potus_check(r$status)
+  c(ev_wtd_brier = r$out[1], unwtd_brier = r$out[2], states_correct = r$out[3])
 }
 
 potus_free <- function(fit) invisible(lapply(fit$handles, function(h) .C("potus_R_destroy", h, status = integer(1))))

@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
-"""Headline benchmark: leapfrog steps/s (and ESS/s) of adaptive NUTS on the 2016 poll model.
+"""Headline benchmark: leapfrog steps/s (and ESS/s) of adaptive NUTS on the poll model.
 
-Workload (BASELINE.json configs[1]): scripts/model/final_2016.R's posterior (51 states x 254
-days, 1619 polls, D = 15 098), 8 chains per MI355X, 1000 warmup + 1000 sampling iterations,
-seed 1843, NUTS diag_e, delta 0.8, max depth 10.  A "step" is one NUTS transition of every
-chain on the GPU; `--steps K` runs K//2 warmup + K - K//2 sampling transitions from a fresh
-initialisation (default K = 2000 = the configuration above).  `--warmup W` runs W untimed
-transitions of a throw-away sampler first (clocks, code objects, allocator).
+Default workload = BASELINE.json configs[1]: scripts/model/final_2016.R's posterior (51 states x 254 days, 1619 polls,
+D = 15 098), 8 chains per MI355X, 1000 warm-up + 1000 sampling iterations, seed 1843, NUTS diag_e, delta 0.8,
+max depth 10.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--chains-per-gpu C]
+A STEP is one launch chunk of `--chunk` (100) NUTS transitions of every chain on the GPU -- the granularity at which
+the reference's own driver reports progress (`refresh`, final_2016.R:11,540).  `--steps K` runs the first K // 2
+chunks as warm-up and the rest as sampling from a fresh initialisation, so the default K = 20 IS the configuration
+above (8 chains x (1000 + 1000)); `--warmup W` first runs W untimed chunks on a throw-away sampler (clocks, code
+objects, allocator).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|3|4]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Each chain runs on a cluster of K workgroups (K compute units of one XCD; K = 16 for 8 chains, see
-potus_cluster.hpp; --cus-per-chain 1 selects the one-workgroup-per-chain kernel instead).
-N > 1: one process per GPU; rank r owns chains [r*C, (r+1)*C) (RNG streams keyed by global chain
-id), no communication while sampling, one RCCL all-gather of the draws-of-interest for pooled
-R-hat / ESS (inside the timed region).  Weak scaling: C chains per GPU whatever N is.
+--config 1/2  2016 backtest, C = 8 chains per GPU (configs[1]; with N GPUs configs[2]: 8 N chains, one RCCL all-gather
+              of the draws-of-interest for pooled R-hat / ESS, device buffers end to end)
+--config 3    2008 + 2012 + 2016 backtests concurrently, 4 chains of each per GPU (32 each over 8 GPUs), three
+              posteriors advancing together under potus_run_many
+--config 4    synthetic stress posterior (51 states x 600 days x 10 000 polls, D = 41 610), dense metric
 
-Rank 0 prints ONE JSON line.  `value` = leapfrogs of all chains on all GPUs / max-over-ranks
-wall time of (init + K transitions [+ all-gather]), inputs already resident in HBM.
+Each chain runs on a cluster of K workgroups (potus_cluster.hpp); --cus-per-chain 1 selects the one-workgroup-per-chain
+kernel.  N > 1: one process per GPU; rank r owns chains [r C, (r + 1) C) (RNG streams keyed by global chain id), no
+communication while sampling.  Weak scaling: C chains per GPU whatever N is.
+
+Rank 0 prints ONE JSON line.  `value` = leapfrogs of all chains on all GPUs / max-over-ranks wall time of
+(init + K chunks [+ all-gather]), inputs already resident in HBM.
 """
 import argparse
 import json
@@ -37,19 +44,21 @@ sys.path.insert(0, str(ROOT / "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def algorithmic_bytes_per_leapfrog(d, variant="full"):
-    """48*D + 36*N_state + 32*N_nat + 24*S^2 + 16*S (diag metric)."""
+def algorithmic_bytes_per_leapfrog(d, variant="full", dense=False):
+    """48 D + 36 N_state + 32 N_nat + 24 S^2 + 16 S (diag metric); + 8 D^2 for the dense metric."""
     from us_potus_model_amd import _abi
     D = _abi.num_params(d, variant)
     S = int(d["S"])
     per_state, per_nat = (36, 32) if variant == "full" else (28, 24)
-    return 48 * D + per_state * int(d["N_state_polls"]) + per_nat * int(d["N_national_polls"]) + 24 * S * S + 16 * S
+    b = 48 * D + per_state * int(d["N_state_polls"]) + per_nat * int(d["N_national_polls"]) + 24 * S * S + 16 * S
+    return b + (8 * D * D if dense else 0)
 
 
 def measured_traffic(kernel):
     """HBM bytes per leapfrog from the committed rocprofv3 PMC passes of this command (profiles/*pmc_traffic.json,
-    written by the recipe in scripts/profile_round.sh): FETCH_SIZE and WRITE_SIZE cannot be collected from inside
-    the benchmark, so the bench line quotes the per-leapfrog figure of the latest committed pass for the same kernel."""
+    scripts/profile_round.sh): FETCH_SIZE and WRITE_SIZE cannot be collected from inside the benchmark, so the bench
+    line quotes the per-leapfrog figure of the latest committed pass for the same kernel -- a committed constant x this
+    run's rate, labelled as such."""
     best = None
     for f in sorted((ROOT / "profiles").glob("*pmc_traffic.json")):
         try:
@@ -61,7 +70,17 @@ def measured_traffic(kernel):
     return best
 
 
-def _cpu_worker(args):
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_nuts_worker(args):
+    data, variant, chain, nw, ns, seed, budget = args
+    from oracle_lib import OracleModel
+    m = OracleModel(data, variant)
+    o = m.default_opts(num_warmup=nw, num_samples=ns, seed=seed, fast_grad=0)
+    _, _, timing = m.sample_chain_timed(chain, o, budget_s=budget)
+    return chain, timing
+
+
+def _cpu_loop_worker(args):
     data, variant, fast, budget = args
     from oracle_lib import OracleModel
     m = OracleModel(data, variant)
@@ -72,38 +91,80 @@ def _cpu_worker(args):
     return n, t
 
 
-def cpu_baseline(data, variant, chains, budget=10.0):
-    """The oracle (a port of the reference's CPU path: literal dense recursion of stan:86 with a
-    hand-written reverse sweep -- no AD tape, so faster than Stan itself) timed on this box's
-    host cores, one chain per core as the reference runs them (final_2016.R:536)."""
+def cpu_baseline(data, variant, chains, seed, nw, ns, gpu_ess_per_leapfrog, budget=20.0, loop_budget=3.0):
+    """the oracle's NUTS (oracle/potus_oracle.c: the literal stan:86 recursion with a hand-written
+    reverse sweep -- no AD tape, so faster than Stan itself -- under the same Stan-2.24 sampler) run as the reference
+    runs its chains, one per host core (final_2016.R:536), with the SAME configuration, seed and chain ids as the GPU
+    run, cut after `budget` seconds: a bounded prefix of the same 8 x (nw + ns) run (the whole of it takes minutes on
+    these cores -- tests/golden/posterior_2016.npz holds one, made in the build container).
+    value = leapfrogs of all chains / wall time.  A prefix of a warm-up has no ESS of its own; ESS/s is derived:
+    same algorithm, same posterior => same ESS per leapfrog as the GPU run just measured, x this rate."""
     procs = max(1, min(chains, os.cpu_count() or 1))
-    out = {}
+    t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(procs) as pool:
-        for key, fast in (("value", 0), ("scan_sparse_value", 1)):
-            res = pool.map(_cpu_worker, [(data, variant, fast, budget if not fast else budget / 2)] * procs)
-            out[key] = float(sum(n / t for n, t in res))
-    return dict(value=out["value"], unit="leapfrogs/s", cores=procs, kind="port",
-                sample=f"{procs} processes x ~{budget:.0f} s of leapfrogs (eps 0.01, unit metric) on the 2016 posterior, "
-                       f"literal stan:86 recursion; scan_sparse_value = same with the reformulated gradient",
-                scan_sparse_value=out["scan_sparse_value"])
+        res = pool.map(_cpu_nuts_worker, [(data, variant, c + 1, nw, ns, seed, budget) for c in range(procs)])
+        loop = {}
+        for key, fast in (("leapfrog_loop_value", 0), ("leapfrog_loop_scan_sparse_value", 1)):
+            r = pool.map(_cpu_loop_worker, [(data, variant, fast, loop_budget)] * procs)
+            loop[key] = float(sum(n / t for n, t in r))
+    wall = time.perf_counter() - t0
+    timing = np.stack([r[1] for r in sorted(res, key=lambda r: r[0])])      # [chain][warm s, samp s, warm lf, samp lf, iterations]
+    rate = float(sum((tm[2] + tm[3]) / (tm[0] + tm[1]) for tm in timing))    # every chain on its own core, at its own rate
+    out = dict(value=rate, unit="leapfrogs/s", cores=procs, kind="port", leapfrogs_per_sec_per_core=rate / procs,
+               sample=f"the first {int(timing[:, 4].min())}-{int(timing[:, 4].max())} iterations of the same run ({procs} chains, ids 1..{procs}, seed {seed}, "
+                      f"{nw} warm-up + {ns} sampling configured) on {procs} host processes, cut after {budget:.0f} s each: "
+                      f"{int(timing[:, 2:4].sum())} leapfrogs; literal stan:86 gradient",
+               seconds=wall, **loop,
+               leapfrog_loop_note="plain leapfrog loops (unit metric, eps 0.01, no tree, no U-turn bookkeeping) of the literal and of the "
+                                  f"scan/sparse gradient, {procs} processes x {loop_budget:.0f} s each: the rate of the arithmetic alone")
+    if gpu_ess_per_leapfrog:
+        out["ess_per_sec"] = gpu_ess_per_leapfrog * rate
+        out["ess_per_sec_note"] = ("derived: ESS per sampling leapfrog of the GPU run above (same algorithm, posterior, seed) x this leapfrog "
+                                   "rate = ESS / sampling time, as the GPU's ess_per_sec; a bounded warm-up prefix has no ESS of its own")
+    full = ROOT / "tests" / "golden" / "posterior_2016.npz"
+    if full.exists() and int(data["T"]) == 254:
+        g = np.load(full)
+        lf, sec = float(g["leapfrogs"].sum()), float(g["seconds"].max())
+        ess = float(min(g["lp__ess_bulk"].min(), g["mu_b_T__ess_bulk"].min(), g["predicted_score_T__ess_bulk"].min()))
+        out["full_run_in_build_container"] = dict(leapfrogs_per_sec=lf / sec, ess_bulk_min=ess, ess_per_sec_total_time=ess / sec, seconds=sec,
+                                                  note="the whole 8 x (1000 + 1000) run of the oracle (scan/sparse gradient) behind tests/golden/posterior_2016.npz, "
+                                                       "8 processes on the build container's 8 vCPUs -- not this box")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+def load_workloads(cfg, chains_per_gpu):
+    """[(name, data, variant, chains per GPU, options)] of the posteriors one GPU runs."""
+    from us_potus_model_amd import dataprep, synthetic
+    gold = ROOT / "tests" / "golden"
+    if cfg in (1, 2):
+        return [("2016", dataprep.load_npz(gold / "data_2016.npz")["data"], "full", chains_per_gpu or 8, {})]
+    if cfg == 3:
+        c = chains_per_gpu or 4
+        return [(y, dataprep.load_npz(gold / f"data_{y}.npz")["data"], v, c, {})
+                for y, v in (("2008", "no_mode_adjustment"), ("2012", "no_mode_adjustment"), ("2016", "full"))]
+    if cfg == 4:
+        from us_potus_model_amd import _abi
+        return [("stress", synthetic.stress(), "full", chains_per_gpu or 4, {"metric": _abi.METRIC_DENSE})]
+    raise SystemExit(f"unknown --config {cfg}")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--chains-per-gpu", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=20, help="launch chunks of --chunk transitions: K // 2 warm-up, the rest sampling")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed chunks on a throw-away sampler")
+    ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs[] index: 1 (default), 2, 3, 4")
+    ap.add_argument("--chains-per-gpu", type=int, default=0, help="per posterior (0 = the configuration's: 8, 8, 4, 4)")
     ap.add_argument("--cus-per-chain", type=int, default=0, help="workgroups per chain (0 = auto: 16, 8 or 1 by what fits)")
-    ap.add_argument("--chunk", type=int, default=100, help="transitions per kernel launch")
+    ap.add_argument("--chunk", type=int, default=0, help="transitions per step (0 = the configuration's: 100; 10 for --config 4)")
     ap.add_argument("--seed", type=int, default=1843)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturated", action="store_true", help="skip the 256-chain reference point")
-    ap.add_argument("--cpu-budget", type=float, default=10.0)
     args = ap.parse_args()
 
     import torch
-    from us_potus_model_amd import Handle, dataprep, diagnostics as dg, parallel
+    from us_potus_model_amd import Handle, diagnostics as dg, parallel, run_many
 
     # POTUS_DIST_BACKEND=gloo: development aid -- every rank on GPU 0 and CPU tensors in the collectives, to exercise
     # the N > 1 flow on a one-GPU box (the measured configuration is one rank per GPU over RCCL)
@@ -117,125 +178,155 @@ def main():
         local = 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if dev_backend == "gloo":
-        dev = None                                   # collectives on CPU tensors
+    coll_dev = None if dev_backend == "gloo" else dev       # collectives on CPU tensors in the development mode
 
-    data = dataprep.load_npz(ROOT / "tests" / "golden" / "data_2016.npz")["data"]
-    variant = "full"
-    C = args.chains_per_gpu
-    total_chains = C * world
-    nw, ns = args.steps // 2, args.steps - args.steps // 2
+    cfg = args.config
+    chunk = args.chunk or (10 if cfg == 4 else 100)
+    work = load_workloads(cfg, args.chains_per_gpu)
+    nw, ns = (args.steps // 2) * chunk, (args.steps - args.steps // 2) * chunk
 
-    if args.warmup > 0:  # untimed: throw-away sampler
-        hw = Handle(data, variant, chains=C, chain_id_offset=rank * C, num_warmup=args.warmup, num_samples=0,
-                    seed=args.seed + 1, device=local, cus_per_chain=args.cus_per_chain)
-        hw.init()
-        hw.run(args.warmup)
-        hw.close()
+    def make(seed, num_warmup, num_samples):
+        hs = []
+        for _, data, variant, C, extra in work:
+            hs.append(Handle(data, variant, chains=C, chain_id_offset=rank * C, num_warmup=num_warmup, num_samples=num_samples,
+                             seed=seed, device=local, cus_per_chain=args.cus_per_chain, **extra))
+        return hs
 
-    h = Handle(data, variant, chains=C, chain_id_offset=rank * C, num_warmup=nw, num_samples=ns, seed=args.seed,
-               device=local, cus_per_chain=args.cus_per_chain)
-    K = h.cus_per_chain
-    S, T = int(data["S"]), int(data["T"])
-    a_mu = h.layout["mu_b"][0]
+    if args.warmup > 0:  # untimed: throw-away samplers
+        hw = make(args.seed + 1, args.warmup * chunk, 0)
+        for h in hw:
+            h.init()
+        for _ in range(args.warmup):
+            run_many(hw, chunk)
+        for h in hw:
+            h.close()
 
+    hs = make(args.seed, nw, ns)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    h.init()
-    done, kernel_ms, t_warm_end = 0, 0.0, None
-    while done < args.steps:
-        n = min(args.chunk, args.steps - done, (nw - done) if done < nw else args.steps)
-        h.run(n)
-        done += n
-        kernel_ms += h.last_run_timing()[0]
-        if done == nw:
+    for h in hs:
+        h.init()
+    kernel_ms, t_warm_end, lf_warm = 0.0, None, 0
+    for step in range(args.steps):
+        run_many(hs, chunk)
+        kernel_ms += max(h.last_run_timing()[0] for h in hs)        # the handles of a step run concurrently
+        if step + 1 == args.steps // 2:
             torch.cuda.synchronize()
             t_warm_end = time.perf_counter()
-    pooled = None
-    if world > 1:  # the one exchange of the path: pool draws-of-interest over xGMI
-        # (lp__ and mu_b[:, T] through write_array: two small column ranges, not the 1 GB draws array)
-        interest = np.concatenate([np.transpose(h.write_array(0, 1, ns), (1, 0, 2)),
-                                   np.transpose(h.write_array(a_mu + S * (T - 1), a_mu + S * T, ns), (1, 0, 2))], axis=2)
-        pooled = parallel.all_gather_draws(interest, total_chains, device=dev)
+            lf_warm = sum(h.total_leapfrogs() for h in hs)
+    # the one exchange of the path: pool the draws-of-interest (lp__ and mu_b[:, T]) of every chain of every GPU.
+    # They are produced on the device (potus_write_array_device), gathered on the device (RCCL all-gather over xGMI) and
+    # only the pooled block comes to the host, for rank 0's R-hat / ESS.
+    pooled = []
+    for (name, data, variant, C, _), h in zip(work, hs):
+        S, T = int(data["S"]), int(data["T"])
+        a_mu = h.layout["mu_b"][0]
+        if ns == 0:
+            pooled.append(None)
+            continue
+        loc = torch.empty((ns, C, 1 + S), dtype=torch.float64, device=dev)
+        tmp = torch.empty((ns, C, 1), dtype=torch.float64, device=dev)
+        h.write_array_device(0, 1, tmp)
+        loc[:, :, :1] = tmp
+        tmp = torch.empty((ns, C, S), dtype=torch.float64, device=dev)
+        h.write_array_device(a_mu + S * (T - 1), a_mu + S * T, tmp)
+        loc[:, :, 1:] = tmp
+        pooled.append(parallel.all_gather_chains(loc, coll_dev))      # [ns, world * C, 1 + S] on every rank
     torch.cuda.synchronize()
     parallel.barrier()
     t1 = time.perf_counter()
 
-    elapsed = parallel.max_over_ranks(t1 - t0, dev)
-    leapfrogs_local = h.total_leapfrogs()
-    leapfrogs = parallel.sum_over_ranks(float(leapfrogs_local), dev)
-    kernel_ms_max = parallel.max_over_ranks(kernel_ms, dev)
-    samp_time = parallel.max_over_ranks(t1 - (t_warm_end or t0), dev)
-
-    if pooled is None:
-        pooled = np.concatenate([np.transpose(h.write_array(0, 1, ns), (1, 0, 2)),
-                                 np.transpose(h.write_array(a_mu + S * (T - 1), a_mu + S * T, ns), (1, 0, 2))], axis=2)
-    st, dv = h.chain_status()
+    elapsed = parallel.max_over_ranks(t1 - t0, coll_dev)
+    lf_local = [h.total_leapfrogs() for h in hs]
+    leapfrogs = parallel.sum_over_ranks(float(sum(lf_local)), coll_dev)
+    kernel_ms_max = parallel.max_over_ranks(kernel_ms, coll_dev)
+    samp_time = parallel.max_over_ranks(t1 - (t_warm_end or t0), coll_dev)
+    status = [h.chain_status() for h in hs]
 
     if rank == 0:
-        ess = None
-        if ns >= 8:
-            ps = 1.0 / (1.0 + np.exp(-pooled[:, :, 1:]))
-            cols = np.concatenate([pooled, ps], axis=2)
-            ess = float(min(dg.ess_bulk(cols[:, :, j]) for j in range(cols.shape[2])))
-            rh = float(max(dg.rhat(cols[:, :, j]) for j in range(cols.shape[2])))
-        bpl = algorithmic_bytes_per_leapfrog(data, variant)
-        achieved = leapfrogs_local * bpl / (kernel_ms * 1e-3) / 1e9  # this rank's kernel, its own stream's events
-        kernel = "k_cl_run" if K > 1 else "k_run"
+        per_post = {}
+        ess_all, rhat_all = [], []
+        for (name, data, variant, C, extra), h, pl, (st, dv) in zip(work, hs, pooled, status):
+            info = {"chains_per_gpu": C, "D": h.D, "S": int(data["S"]), "T": int(data["T"]),
+                    "polls": int(data["N_state_polls"]) + int(data["N_national_polls"]), "cus_per_chain": h.cus_per_chain,
+                    "divergent_transitions": int(sum(dv)), "chain_status": st}
+            if pl is not None and ns >= 8:
+                x = np.transpose(pl.cpu().numpy(), (1, 0, 2))                    # [chain, draw, 1 + S]
+                cols = np.concatenate([x, 1.0 / (1.0 + np.exp(-x[:, :, 1:]))], axis=2)   # + predicted_score[T, :]
+                info["ess_bulk_min"] = float(min(dg.ess_bulk(cols[:, :, j]) for j in range(cols.shape[2])))
+                info["rhat_max"] = float(max(dg.rhat(cols[:, :, j]) for j in range(cols.shape[2])))
+                info["pooled_draws"] = int(cols.shape[0] * cols.shape[1])
+                ess_all.append(info["ess_bulk_min"]); rhat_all.append(info["rhat_max"])
+            per_post[name] = info
+        dense = cfg == 4
+        bpl = [algorithmic_bytes_per_leapfrog(d, v, dense) for _, d, v, _, _ in work]
+        alg_bytes = float(sum(b * n for b, n in zip(bpl, lf_local)))
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9            # this rank's launches, events on the samplers' own streams
+        K = hs[0].cus_per_chain
+        kernel = "k_dn_matvec" if dense else ("k_cl_run" if K > 1 else "k_run")
         tr = measured_traffic(kernel)
-        traffic = tr[1]["hbm_bytes_per_leapfrog"] * leapfrogs_local / (kernel_ms * 1e-3) / 1e9 if tr else None
+        traffic = tr[1]["hbm_bytes_per_leapfrog"] * sum(lf_local) / (kernel_ms * 1e-3) / 1e9 if tr else None
+        C_tot = sum(w[3] for w in work)
+        names = {1: "configs[1]: 2016 backtest", 2: "configs[2]: 2016 backtest, chains sharded over the GPUs",
+                 3: "configs[3]: 2008 + 2012 + 2016 backtests concurrently", 4: "configs[4]: synthetic stress posterior, dense metric"}
         line = {
             "metric": "leapfrog_steps_per_sec", "value": leapfrogs / elapsed, "unit": "leapfrogs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "2016 poll data (fixture built from the reference CSVs, tests/golden/data_2016.npz); random inits",
-            "config": {"workload": "configs[1]: 2016 backtest, adaptive NUTS diag_e, 8 chains per MI355X, "
-                                   f"{nw} warmup + {ns} sampling, seed {args.seed}",
-                       "chains_per_gpu": C, "total_chains": total_chains, "D": h.D, "S": S, "T": T,
-                       "polls": int(data["N_state_polls"]) + int(data["N_national_polls"]),
-                       "cus_per_chain": K,
-                       "parallelism": (f"chains sharded {C}/GPU x {world}, no data-path collective; one all-gather of draws-of-interest; "
-                                       if world > 1 else f"{C} chains; ") +
-                                      (f"each chain on a cluster of {K} workgroups ({C * K} of 256 CUs busy)" if K > 1
+            "data": ("synthetic polls (us_potus_model_amd.synthetic.stress, seed 20201103)" if cfg == 4 else
+                     "poll data of the reference (fixtures built from its CSVs, tests/golden/data_*.npz)") + "; random inits",
+            "config": {"workload": f"{names[cfg]}, adaptive NUTS {'dense_e' if dense else 'diag_e'}, {C_tot} chains per MI355X, "
+                                   f"{nw} warmup + {ns} sampling, seed {args.seed}; a step = one launch chunk of {chunk} transitions",
+                       "step": f"{chunk} NUTS transitions of every chain", "iter_warmup": nw, "iter_sampling": ns,
+                       "chains_per_gpu": C_tot, "total_chains": C_tot * world, "posteriors": per_post,
+                       "parallelism": (f"chains sharded {C_tot}/GPU x {world}, no data-path collective; one RCCL all-gather of the "
+                                       f"draws-of-interest (device buffers); " if world > 1 else f"{C_tot} chains; ") +
+                                      (f"each chain on a cluster of {K} workgroups ({C_tot * K} of 256 CUs busy)" if K > 1
                                        else "one workgroup per chain")},
             "leapfrogs": int(leapfrogs), "seconds": elapsed,
-            "us_per_leapfrog_per_chain": 1e6 * kernel_ms_max * 1e-3 * C / max(leapfrogs_local, 1),
-            "ess_bulk_min": ess, "ess_per_sec": (ess / samp_time) if ess else None, "rhat_max": rh if ess else None,
-            "divergent_transitions": int(sum(dv)), "chain_status": st,
+            "us_per_leapfrog_per_chain": 1e6 * kernel_ms_max * 1e-3 * C_tot / max(sum(lf_local), 1),
+            "ess_bulk_min": min(ess_all) if ess_all else None,
+            "ess_per_sec": (min(ess_all) / samp_time) if ess_all else None,
+            "rhat_max": max(rhat_all) if rhat_all else None, "sampling_seconds": samp_time,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": (f"GB/s over the same launches: {tr[1]['hbm_bytes_per_leapfrog']:.0f} HBM bytes per leapfrog "
-                                          f"(2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/{tr[0]}) x leapfrogs / launch time"
-                                          if tr else "no PMC pass committed for this kernel"),
-                         "kernel": kernel, "algorithmic_bytes_per_leapfrog": bpl,
-                         "leapfrogs_in_launches": int(leapfrogs_local), "launch_ms_total": kernel_ms,
-                         "note": f"latency-bound at {C} chains ({C * K} of 256 CUs busy): the state of a chain stays in L2, "
-                                 "the leapfrog is a chain of dependent exchanges between the CUs of a cluster; see DESIGN.md"},
+                         "traffic_note": (f"NOT measured in this run: {tr[1]['hbm_bytes_per_leapfrog']:.0f} HBM bytes per leapfrog from the committed "
+                                          f"rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE, profiles/{tr[0]}; WRITE_SIZE "
+                                          f"uncalibrated) x this run's leapfrogs / launch time" if tr else "no PMC pass committed for this kernel"),
+                         "kernel": kernel, "algorithmic_bytes_per_leapfrog": bpl if len(bpl) > 1 else bpl[0],
+                         "leapfrogs_in_launches": int(sum(lf_local)), "launch_ms_total": kernel_ms,
+                         "note": (f"latency-bound at {C_tot} chains ({C_tot * K} of 256 CUs busy): the state of a chain stays in L2, a leapfrog "
+                                  "is a chain of dependent phases and exchanges between the CUs of a cluster; see DESIGN.md") if not dense else
+                                 "dense metric: every leapfrog streams the chain's D x D inverse metric"},
         }
-        if world == 1 and not args.no_saturated:
+        if world == 1 and cfg == 1 and not args.no_saturated:
             # The same posterior with the GPU full: 256 chains, one workgroup per chain (k_run).  Not the metric's
             # configuration -- a reference point for what the kernels deliver when parallelism is not the limit.
             try:
-                hs = Handle(data, variant, chains=256, num_warmup=60, num_samples=0, seed=args.seed + 7, device=local, cus_per_chain=1)
-                hs.init()
+                _, data, variant, _, _ = work[0]
+                hsat = Handle(data, variant, chains=256, num_warmup=60, num_samples=0, seed=args.seed + 7, device=local, cus_per_chain=1)
+                hsat.init()
                 ms_s, lf_s = 0.0, 0
                 for _ in range(3):
-                    hs.run(20)
-                    ms1, lf1 = hs.last_run_timing()
+                    hsat.run(20)
+                    ms1, lf1 = hsat.last_run_timing()
                     ms_s += ms1; lf_s += lf1
-                hs.close()
+                hsat.close()
                 rate = lf_s / (ms_s * 1e-3)
                 line["saturated"] = {"chains": 256, "cus_per_chain": 1, "kernel": "k_run", "iterations": 60, "value": rate, "unit": "leapfrogs/s",
-                                     "roofline_frac": rate * bpl / 1e9 / HBM_PEAK_GBS,
+                                     "roofline_frac": rate * bpl[0] / 1e9 / HBM_PEAK_GBS,
                                      "note": "short warm-up run of 256 chains on the same posterior; kernel time of the launches"}
             except Exception as e:                     # never let the side measurement spoil the bench line
                 line["saturated"] = {"error": str(e)[:200]}
-        if not args.no_cpu_baseline and world == 1:   # the CPU port is timed beside the single-GPU run only
-            line["cpu_baseline"] = cpu_baseline(data, variant, C, args.cpu_budget)
+        if not args.no_cpu_baseline and world == 1 and cfg in (1, 2):   # the CPU port is timed beside the single-GPU run only
+            _, data, variant, C, _ = work[0]
+            epl = (line["ess_bulk_min"] / max(sum(lf_local) - lf_warm, 1)) if line["ess_bulk_min"] else None   # per SAMPLING leapfrog
+            line["cpu_baseline"] = cpu_baseline(data, variant, C, args.seed, nw, ns, epl)
             line["speedup_vs_cpu_port"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
-    h.close()
+    for h in hs:
+        h.close()
     parallel.barrier()
     if world > 1:
         import torch.distributed as dist

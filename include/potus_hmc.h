@@ -53,6 +53,9 @@ extern "C" {
 #define POTUS_ERR_STATE 4    /* call order / handle state */
 #define POTUS_ERR_IO 5
 #define POTUS_ERR_UNSUPPORTED 6
+#define POTUS_ERR_STEPSIZE 7 /* base_hmc::init_stepsize ran the step size to 0 or beyond 1e7 (Stan throws there) */
+#define POTUS_ERR_WATCHDOG 8 /* the workgroups of a chain's cluster were not resident together (GPU shared with
+                                another process?): the launch gave up instead of hanging; the handle is dead */
 
 /* The Stan data block (poll_model_2020.stan:1-41) as a C struct.  For the no-mode
  * variant the four poll_mode_* / poll_pop_* pointers, M, Pop, sigma_m, sigma_pop and
@@ -87,7 +90,7 @@ typedef struct potus_data {
 /* Sampler options: the argument surface of cmdstanr's $sample() as used at
  * final_2016.R:533-541 plus the CmdStan 2.24 defaults it implies. */
 typedef struct potus_opts {
-  int32_t chains;          /* chains run by THIS handle (one workgroup each)            */
+  int32_t chains;          /* chains run by THIS handle                                  */
   int32_t chain_id_offset; /* global id of this handle's first chain minus 1; chain c of
                               the handle uses RNG stream chain_id_offset + c + 1, so the
                               draws do not depend on how chains are split over GPUs       */
@@ -106,8 +109,12 @@ typedef struct potus_opts {
                               (lowest latency with few chains; chains * cus_per_chain <= CUs of the device),
                               0 = choose from {16, 8, 1} by what fits.  Draws are reproducible bit for bit
                               for a given value; different values differ in floating-point summation order. */
-  int32_t reserved;
+  int32_t metric;          /* POTUS_METRIC_DIAG (CmdStan's default, what final_2016.R:533-541 runs) or
+                              POTUS_METRIC_DENSE (metric = "dense_e": stan::mcmc::dense_e_metric + covar_adaptation,
+                              BASELINE configs[4]) */
 } potus_opts;
+#define POTUS_METRIC_DIAG 0
+#define POTUS_METRIC_DENSE 1
 
 /* per-draw sampler columns, in CmdStan order */
 #define POTUS_N_SAMPLER_COLS 7 /* lp__,accept_stat__,stepsize__,treedepth__,n_leapfrog__,divergent__,energy__ */
@@ -158,8 +165,10 @@ int potus_iterations_done(int handle, int *n);
 int potus_total_leapfrogs(int handle, long long *n); /* sum over chains and iterations so far */
 int potus_chain_status(int handle, int *status /*[chains]*/, int *n_divergent /*[chains]*/);
 
-/* Adaptation result per chain: step size and diagonal inverse metric. */
+/* Adaptation result per chain: step size and diagonal inverse metric (dense metric: its diagonal). */
 int potus_get_adaptation(int handle, double *stepsize /*[chains]*/, double *inv_metric /*[chains][D]*/);
+/* Dense metric only: the D x D inverse metric of one chain of the handle (row-major = column-major, it is symmetric). */
+int potus_get_dense_metric(int handle, int chain, double *inv_metric /*[D][D]*/);
 
 /* Saved draws on the unconstrained scale: out[chain][iter][7 + D] (host pointer).
  * n_saved = num_samples (+ num_warmup when save_warmup). */
@@ -174,6 +183,9 @@ int potus_draws_device_ptr(int handle, void **dptr, long long *n_doubles);
  * [col_begin, col_end) of the full CmdStan row (0-based, including the 7 sampler
  * columns).  out[iter][chain][col_end-col_begin] -- the as.array(stanfit) layout. */
 int potus_write_array(int handle, int col_begin, int col_end, double *out);
+/* The same rows written into DEVICE memory of the handle's GPU (e.g. the data_ptr() of a torch tensor that an RCCL
+ * all-gather then sends: the draws-of-interest never visit the host). */
+int potus_write_array_device(int handle, int col_begin, int col_end, void *out_device);
 
 /* One CmdStan-format CSV per chain (<dir>/<basename>-<chain>.csv) readable by
  * rstan::read_stan_csv (final_2016.R:543). */
@@ -181,12 +193,20 @@ int potus_write_stan_csv(int handle, const char *dir, const char *basename);
 
 /* Posterior summaries the run scripts build from extract(out, "predicted_score") (final_2016.R:708-762 state and
  * national intervals, :799-823 electoral-college simulation), computed on the device from the saved draws of
- * all chains of the handle (pooled, at most 16 384).  Cell order of state_out: t + T*s (CmdStan's column-major
- * predicted_score[T,S]); quantiles are R's default (type 7).
+ * all chains of the handle (pooled; any number of draws).  Cell order of state_out: t + T*s (CmdStan's column-major
+ * predicted_score[T,S]); quantiles are R's default (type 7); the national vote is weighted.mean(score, state_weights).
  *   state_out [T*S][4] = low (2.5 %), high (97.5 %), mean, P(score > 0.5)
  *   natl_out  [T][4]   = the same for the state_weights-weighted national vote of each draw
  *   ev_out    [T][5]   = mean, median, high, low, P(>= 270) of sum_s ev[s] 1[score > 0.5]      (ev: [S]) */
 int potus_posterior_summary(int handle, const double *ev, double *state_out, double *natl_out, double *ev_out);
+/* The same over the pooled draws of several handles of one posterior (its chains spread over several samplers or
+ * GPUs: potus_run_many); runs on the first handle's GPU. */
+int potus_posterior_summary_many(const int *handles, int n_handles, const double *ev, double *state_out, double *natl_out,
+                                 double *ev_out);
+/* Backtest scores of final_2016.R:925-945 (final_2012.R:918-931, final_2008.R:922-935) from state_out: with p_s =
+ * P(score > 0.5) of state s on `day` (1-based; 0 = last day) and won[s] in {0,1} the outcome,
+ * out[3] = EV-weighted Brier score, unweighted Brier score, states called correctly (round(p) == won). */
+int potus_backtest_scores(const double *state_out, int T, int S, int day, const double *ev, const int *won, double *out);
 
 /* Kernel timing of the most recent potus_run, measured with HIP events on the
  * sampler's own stream: elapsed milliseconds and leapfrogs executed in it. */
@@ -203,9 +223,10 @@ void potus_R_create(int *dims /*[8]: N_nat,N_state,T,S,P,M,Pop,variant*/,
                     sigma_noise_nat,sigma_noise_state,sigma_e_bias,random_walk_scale,
                     mu_b_T_scale,polling_bias_scale*/,
                     double *state_covariance_0,
-                    int *iopts /*[8]: chains,chain_id_offset,num_warmup,num_samples,max_depth,
-                    device,save_warmup,seed*/,
-                    double *dopts /*[6]: delta,gamma,kappa,t0,stepsize,init_radius*/,
+                    int *iopts /*[9]: chains,chain_id_offset,num_warmup,num_samples,max_depth,
+                    device,save_warmup,cus_per_chain,metric*/,
+                    double *dopts /*[7]: delta,gamma,kappa,t0,stepsize,init_radius,seed (an integer < 2^53:
+                    R's own integers have 32 bits)*/,
                     int *handle, int *status);
 void potus_R_init(int *handle, int *status);
 void potus_R_run(int *handle, int *n_iter, int *status);
@@ -213,7 +234,9 @@ void potus_R_run_many(int *handles, int *n_handles, int *n_iter, int *status);
 void potus_R_num_columns(int *handle, int *D, int *n_cols, int *status);
 void potus_R_write_array(int *handle, int *col_begin, int *col_end, double *out, int *status);
 void potus_R_write_stan_csv(int *handle, char **dir, char **basename, int *status);
-void potus_R_posterior_summary(int *handle, double *ev, double *state_out, double *natl_out, double *ev_out, int *status);
+void potus_R_saved_count(int *handle, int *n_saved, int *status);
+void potus_R_posterior_summary(int *handles, int *n_handles, double *ev, double *state_out, double *natl_out, double *ev_out, int *status);
+void potus_R_backtest_scores(double *state_out, int *dims /*[3]: T, S, day*/, double *ev, int *won, double *out /*[3]*/, int *status);
 void potus_R_last_error(char **buf, int *len);
 void potus_R_destroy(int *handle, int *status);
 

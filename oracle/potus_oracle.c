@@ -891,14 +891,36 @@ void oracle_default_opts(oracle_opts *o) {
   o->seed = 1843; o->fast_grad = 0; o->save_warmup = 0;
 }
 
+static int sample_chain_impl(const oracle_model *m, const oracle_opts *o, int chain_id, const double *q0, double *draws,
+                             double *adapt_out, long long *total_leapfrogs, double *metric_out, double *timing, double budget_s);
+
 int oracle_sample_chain(const oracle_model *m, const oracle_opts *o, int chain_id, const double *q0, double *draws,
                         double *adapt_out, long long *total_leapfrogs) {
-  return oracle_sample_chain_metric(m, o, chain_id, q0, draws, adapt_out, total_leapfrogs, NULL);
+  return sample_chain_impl(m, o, chain_id, q0, draws, adapt_out, total_leapfrogs, NULL, NULL, 0.0);
 }
-
 int oracle_sample_chain_metric(const oracle_model *m, const oracle_opts *o, int chain_id, const double *q0, double *draws,
                                double *adapt_out, long long *total_leapfrogs, double *metric_out) {
+  return sample_chain_impl(m, o, chain_id, q0, draws, adapt_out, total_leapfrogs, metric_out, NULL, 0.0);
+}
+/* bench.py's cpu_baseline: the same run with wall-clock seconds and leapfrogs of the two phases,
+ * timing = {warm-up seconds, sampling seconds, warm-up leapfrogs, sampling leapfrogs, iterations done} (initialisation
+ * and the first init_stepsize are counted as warm-up, as CmdStan's "Elapsed Time" does).  budget_s > 0: the run is cut
+ * at the first iteration boundary after that many seconds -- a bounded PREFIX of the configured run (same seed, same
+ * adaptation schedule), for timing only (draws / adapt_out cover the iterations done). */
+int oracle_sample_chain_timed(const oracle_model *m, const oracle_opts *o, int chain_id, double *draws, double *adapt_out,
+                              double *timing, double budget_s) {
+  long long nl = 0;
+  return sample_chain_impl(m, o, chain_id, NULL, draws, adapt_out, &nl, NULL, timing, budget_s);
+}
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+static int sample_chain_impl(const oracle_model *m, const oracle_opts *o, int chain_id, const double *q0, double *draws,
+                             double *adapt_out, long long *total_leapfrogs, double *metric_out, double *timing, double budget_s) {
   const int D = m->D;
+  int iters_done = 0;
+  const double t_start = now_s();
+  double t_warm_end = t_start;
+  long long lf_warm = 0;
   sampler sp; memset(&sp, 0, sizeof(sp));
   sp.m = m; sp.o = o; sp.D = D; sp.chain = chain_id; sp.iter = ITER_PRE;
   sp.lpg = o->fast_grad ? oracle_log_prob_grad_fast : oracle_log_prob_grad;
@@ -958,7 +980,9 @@ int oracle_sample_chain_metric(const oracle_model *m, const oracle_opts *o, int 
         sp.s_bar = 0; sp.x_bar = 0; sp.ad_counter = 0;
       }
       if (it == o->num_warmup - 1) sp.nom_eps = exp(sp.x_bar); /* complete_adaptation */
+      if (it == o->num_warmup - 1) { t_warm_end = now_s(); lf_warm = sp.total_leapfrogs; }
     }
+    iters_done = it + 1;
     if (!warm || o->save_warmup) {
       double *row = draws + (size_t)saved * (POTUS_N_SAMPLER_COLS + D);
       row[0] = -sp.z.V; row[1] = accept_stat; row[2] = eps_used; row[3] = sp.depth; row[4] = sp.n_leapfrog;
@@ -966,11 +990,19 @@ int oracle_sample_chain_metric(const oracle_model *m, const oracle_opts *o, int 
       memcpy(row + POTUS_N_SAMPLER_COLS, sp.z.q, sizeof(double) * (size_t)D);
       saved++;
     }
+    if (budget_s > 0 && now_s() - t_start > budget_s) break;
   }
   if (adapt_out) { adapt_out[0] = sp.nom_eps; memcpy(adapt_out + 1, sp.minv, sizeof(double) * (size_t)D); }
   if (metric_out) {
     if (sp.dense) memcpy(metric_out, sp.Minv, sizeof(double) * (size_t)D * D);
     else { memset(metric_out, 0, sizeof(double) * (size_t)D * D); for (int i = 0; i < D; i++) metric_out[(size_t)i * D + i] = sp.minv[i]; }
+  }
+  if (timing) {
+    const double t_end = now_s();
+    if (o->num_warmup == 0) t_warm_end = t_start;
+    if (iters_done < o->num_warmup) { t_warm_end = t_end; lf_warm = sp.total_leapfrogs; }   /* cut inside the warm-up */
+    timing[0] = t_warm_end - t_start; timing[1] = t_end - t_warm_end;
+    timing[2] = (double)lf_warm; timing[3] = (double)(sp.total_leapfrogs - lf_warm); timing[4] = (double)iters_done;
   }
 done:
   if (total_leapfrogs) *total_leapfrogs = sp.total_leapfrogs;

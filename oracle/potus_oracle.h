@@ -80,6 +80,12 @@ int oracle_sample_chain_metric(const oracle_model *m, const oracle_opts *o, int 
                                const double *q0, double *draws, double *adapt_out,
                                long long *total_leapfrogs, double *metric_out);
 
+/* bench.py's cpu_baseline: oracle_sample_chain with the wall-clock seconds and leapfrogs of the two phases,
+ * timing[5] = {warm-up s, sampling s, warm-up leapfrogs, sampling leapfrogs, iterations done}; budget_s > 0 cuts the
+ * run at the first iteration boundary after that many seconds (a bounded prefix of the configured run) */
+int oracle_sample_chain_timed(const oracle_model *m, const oracle_opts *o, int chain_id, double *draws,
+                              double *adapt_out, double *timing, double budget_s);
+
 /* leapfrog micro-benchmark for bench.py's cpu_baseline: n steps from q0 with unit metric */
 double oracle_time_leapfrogs(const oracle_model *m, int n, double eps, int fast_grad, uint64_t seed);
 

@@ -8,7 +8,7 @@ transcription in tests/stan_transcription.py before anything is written.
 
   python scripts/make_golden.py data        # tests/golden/data_{2016,2012,2008}.npz   (needs /root/reference)
   python scripts/make_golden.py logprob     # tests/golden/logprob_*.npz
-  python scripts/make_golden.py posterior   # tests/golden/posterior_2016.npz (minutes, 8 processes)
+  python scripts/make_golden.py posterior [2016 2012 2008]   # tests/golden/posterior_<year>.npz (minutes each, 8 processes)
 """
 import multiprocessing as mp
 import sys
@@ -87,9 +87,10 @@ def _chain(args):
     return chain, draws, adapt, nl, time.time() - t
 
 
-def make_posterior(chains=8, nw=1000, ns=1000):
+def make_posterior(name="2016", chains=8, nw=1000, ns=1000):
+    """BASELINE configs[1] on the CPU oracle (8 chains x 1000/1000, seed 1843) for one of the three backtests."""
     from oracle_lib import OracleModel
-    data, variant = cases()["2016"]
+    data, variant = cases()[name]
     with mp.Pool(min(chains, mp.cpu_count())) as pool:
         res = pool.map(_chain, [(data, variant, c + 1, nw, ns) for c in range(chains)])
     res.sort(key=lambda r: r[0])
@@ -109,19 +110,19 @@ def make_posterior(chains=8, nw=1000, ns=1000):
     out = dict(stepsize=np.array([r[2][0] for r in res]), leapfrogs=np.array([r[3] for r in res]),
                seconds=np.array([r[4] for r in res]), config=np.array([chains, nw, ns, 1843]),
                sampler_mean=samp.mean(axis=1), treedepth_hist=np.bincount(samp[:, :, 3].astype(int).ravel(), minlength=12))
-    for name, x in (("mu_b_T", mu_bT), ("predicted_score_T", ps_T), ("lp", samp[:, :, :1])):
+    for blk, x in (("mu_b_T", mu_bT), ("predicted_score_T", ps_T), ("lp", samp[:, :, :1])):
         sm = dg.summarise(x)
         pooled = x.reshape(-1, x.shape[-1])
-        out.update({f"{name}__mean": sm["mean"], f"{name}__sd": sm["sd"], f"{name}__mcse": sm["mcse"],
-                    f"{name}__rhat": sm["rhat"], f"{name}__ess_bulk": sm["ess_bulk"],
-                    f"{name}__q025": np.quantile(pooled, 0.025, axis=0), f"{name}__q975": np.quantile(pooled, 0.975, axis=0),
-                    f"{name}__chain_mean": x.mean(axis=1)})
+        out.update({f"{blk}__mean": sm["mean"], f"{blk}__sd": sm["sd"], f"{blk}__mcse": sm["mcse"],
+                    f"{blk}__rhat": sm["rhat"], f"{blk}__ess_bulk": sm["ess_bulk"],
+                    f"{blk}__q025": np.quantile(pooled, 0.025, axis=0), f"{blk}__q975": np.quantile(pooled, 0.975, axis=0),
+                    f"{blk}__chain_mean": x.mean(axis=1)})
     out["predicted_score_T__p_win"] = (ps_T.reshape(-1, S) > 0.5).mean(axis=0)
     w = np.asarray(data["state_weights"])
     nat = ps_T @ w                                                         # [chain, draw]
     out["national__mean"] = nat.mean(); out["national__q025"] = np.quantile(nat, 0.025)
     out["national__q975"] = np.quantile(nat, 0.975); out["national__p_win"] = (nat > 0.5).mean()
-    np.savez_compressed(GOLD / "posterior_2016.npz", **out)
+    np.savez_compressed(GOLD / f"posterior_{name}.npz", **out)
     print("leapfrogs", [r[3] for r in res], "seconds", [round(r[4], 1) for r in res])
     print("national", out["national__mean"], out["national__q025"], out["national__q975"], out["national__p_win"])
     print("rhat max", out["mu_b_T__rhat"].max(), "min bulk ess", out["mu_b_T__ess_bulk"].min(), out["lp__ess_bulk"])
@@ -135,4 +136,5 @@ if __name__ == "__main__":
     if what in ("logprob", "all"):
         make_logprob()
     if what in ("posterior", "all"):
-        make_posterior()
+        for name in (sys.argv[2:] or ["2016", "2012", "2008"]):
+            make_posterior(name)

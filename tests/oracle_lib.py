@@ -49,6 +49,7 @@ def lib():
                                           C.POINTER(C.c_longlong)]
         L.oracle_sample_chain_metric.argtypes = [C.c_void_p, C.POINTER(OracleOpts), C.c_int, dp, dp, dp,
                                                  C.POINTER(C.c_longlong), dp]
+        L.oracle_sample_chain_timed.argtypes = [C.c_void_p, C.POINTER(OracleOpts), C.c_int, dp, dp, dp, C.c_double]
         L.oracle_philox.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.oracle_rng_uniform.restype = C.c_double
         L.oracle_rng_uniform.argtypes = [C.c_uint64] + [C.c_uint32] * 5
@@ -116,6 +117,18 @@ class OracleModel:
         if rc:
             raise RuntimeError(f"oracle_sample_chain failed rc={rc}")
         return draws, adapt, nl.value
+
+    def sample_chain_timed(self, chain_id, opts, budget_s=0.0):
+        """sample_chain + (warm-up seconds, sampling seconds, warm-up leapfrogs, sampling leapfrogs, iterations done):
+        bench.py's cpu_baseline; budget_s > 0 cuts the run at the first iteration boundary after that many seconds."""
+        n_saved = opts.num_samples + (opts.num_warmup if opts.save_warmup else 0)
+        draws = np.zeros((n_saved, _abi.N_SAMPLER_COLS + self.D))
+        adapt = np.zeros(1 + self.D)
+        timing = np.zeros(5)
+        rc = self.L.oracle_sample_chain_timed(self.h, C.byref(opts), chain_id, _dp(draws), _dp(adapt), _dp(timing), float(budget_s))
+        if rc:
+            raise RuntimeError(f"oracle_sample_chain_timed failed rc={rc}")
+        return draws, adapt, timing
 
     def sample_chain_metric(self, chain_id, opts, q0=None):
         """sample_chain + the adapted inverse metric as a D x D matrix (diag(minv) for the diagonal metric)."""

@@ -1,0 +1,322 @@
+"""The boundary as the reference side would drive it, and the reference's published numbers.
+
+* the `.C()` surface: every `potus_R_*` export called with int* / double* / char** arguments exactly as
+  R/potus_sampling.R marshals them (R is not installed here, so ctypes replays the shim call for call) and compared
+  byte for byte with the struct ABI;
+* every posterior number the reference publishes (README.md tables of the 2008 / 2012 / 2016 backtests: 3 x 52 rows
+  of election-day predicted_score, plus the Brier scores), tests/golden/readme_*.csv;
+* summaries over more draws than one LDS sort holds and over several handles; the cluster watchdog.
+"""
+import csv
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD
+from us_potus_model_amd import Handle, PotusModel, _abi, backtest_scores, dataprep, posterior_summary, run_many, sampler
+
+pytestmark = pytest.mark.gpu
+
+IP, DP = C.POINTER(C.c_int), C.POINTER(C.c_double)
+
+
+def _ints(x):
+    a = np.ascontiguousarray(np.asarray(x).reshape(-1), dtype=np.int32)
+    return a, a.ctypes.data_as(IP)
+
+
+def _dbls(x):
+    a = np.ascontiguousarray(np.asarray(x).reshape(-1), dtype=np.float64)
+    return a, a.ctypes.data_as(DP)
+
+
+class RShim:
+    """R/potus_sampling.R replayed with ctypes: only the potus_R_* exports, every argument a pointer, status by pointer."""
+
+    def __init__(self):
+        self.L = sampler.load_library()
+        self.keep = []
+
+    def call(self, name, *args):
+        f = getattr(self.L, name)
+        f.restype = None
+        f(*args)
+
+    def check(self, status):
+        if status.value != 0:
+            buf = C.create_string_buffer(b" " * 512)
+            p = (C.c_char_p * 1)(C.addressof(buf))                     # char **: what .C() passes for a character vector
+            ln = C.c_int(512)
+            self.call("potus_R_last_error", p, C.byref(ln))
+            raise RuntimeError(f"libpotus_hmc error {status.value}: {buf.value.decode().strip()}")
+
+    def sample(self, data, variant, seed, chains, iter_warmup, iter_sampling, refresh, gpus=(0,), cus_per_chain=0, metric="diag_e",
+               chain_id_offset=0, save_warmup=False, adapt_delta=0.8, max_treedepth=10, init=2.0):
+        full = variant == "full"
+        Ns, Nn = int(data["N_state_polls"]), int(data["N_national_polls"])
+        iv = lambda k, n: _ints(data[k] if data.get(k) is not None else np.zeros(max(n, 1)))
+        dv = lambda k, n: _dbls(data[k] if data.get(k) is not None else np.zeros(max(n, 1)))
+        dims = _ints([Nn, Ns, data["T"], data["S"], data["P"], data["M"] if full else 0, data["Pop"] if full else 0, 0 if full else 1])
+        scalars = _dbls([data["sigma_c"], data["sigma_m"] if full else 0, data["sigma_pop"] if full else 0,
+                         data["sigma_measure_noise_national"], data["sigma_measure_noise_state"],
+                         data["sigma_e_bias"] if full else 0, data["random_walk_scale"], data["mu_b_T_scale"], data["polling_bias_scale"]])
+        cov = _dbls(np.asarray(data["state_covariance_0"], dtype=np.float64).T)          # column-major, as R stores it
+        per = [chains // len(gpus) + (1 if g < chains % len(gpus) else 0) for g in range(len(gpus))]
+        first = np.concatenate([[0], np.cumsum(per)])[:len(per)]
+        handles, counts = [], []
+        for g, dev in enumerate(gpus):
+            if per[g] == 0:
+                continue
+            args = [dims, iv("state", Ns), iv("day_state", Ns), iv("day_national", Nn), iv("poll_state", Ns), iv("poll_national", Nn),
+                    iv("poll_mode_state", Ns), iv("poll_mode_national", Nn), iv("poll_pop_state", Ns), iv("poll_pop_national", Nn),
+                    iv("n_democrat_national", Nn), iv("n_two_share_national", Nn), iv("n_democrat_state", Ns), iv("n_two_share_state", Ns),
+                    dv("unadjusted_national", Nn), dv("unadjusted_state", Ns), _dbls(data["mu_b_prior"]), _dbls(data["state_weights"]),
+                    scalars, cov,
+                    _ints([per[g], chain_id_offset + first[g], iter_warmup, iter_sampling, max_treedepth, dev, int(save_warmup), cus_per_chain,
+                           1 if metric == "dense_e" else 0]),
+                    _dbls([adapt_delta, 0.05, 0.75, 10, 1, init, seed])]
+            h, st = C.c_int(-1), C.c_int(-1)
+            self.call("potus_R_create", *[a[1] for a in args], C.byref(h), C.byref(st))
+            self.check(st)
+            self.call("potus_R_init", C.byref(h), C.byref(st))
+            self.check(st)
+            handles.append(h.value); counts.append(per[g])
+        total, done = iter_warmup + iter_sampling, 0
+        chunk = total if not refresh else int(refresh)
+        hv = _ints(handles)
+        while done < total:
+            n = min(chunk, total - done)
+            st = C.c_int(-1)
+            self.call("potus_R_run_many", hv[1], C.byref(C.c_int(len(handles))), C.byref(C.c_int(n)), C.byref(st))
+            self.check(st)
+            done += n
+        D, nc, st = C.c_int(), C.c_int(), C.c_int(-1)
+        self.call("potus_R_num_columns", C.byref(C.c_int(handles[0])), C.byref(D), C.byref(nc), C.byref(st))
+        self.check(st)
+        ns = C.c_int()
+        self.call("potus_R_saved_count", C.byref(C.c_int(handles[0])), C.byref(ns), C.byref(st))
+        self.check(st)
+        return dict(handles=handles, chains_per_handle=counts, D=D.value, n_cols=nc.value, n_saved=ns.value, data=data, variant=variant, chains=chains)
+
+    def write_array(self, fit, begin, end):
+        """potus_extract's loop: [iter, chain, col] per handle, chains concatenated in id order."""
+        parts = []
+        for h, ch in zip(fit["handles"], fit["chains_per_handle"]):
+            out = np.zeros(fit["n_saved"] * ch * (end - begin))
+            st = C.c_int(-1)
+            self.call("potus_R_write_array", C.byref(C.c_int(h)), C.byref(C.c_int(begin)), C.byref(C.c_int(end)), out.ctypes.data_as(DP), C.byref(st))
+            self.check(st)
+            parts.append(out.reshape(fit["n_saved"], ch, end - begin))
+        return np.concatenate(parts, axis=1)
+
+    def summary(self, fit, ev):
+        S, T = int(fit["data"]["S"]), int(fit["data"]["T"])
+        st_, na, eo, st = np.zeros(T * S * 4), np.zeros(T * 4), np.zeros(T * 5), C.c_int(-1)
+        hv = _ints(fit["handles"])
+        self.call("potus_R_posterior_summary", hv[1], C.byref(C.c_int(len(fit["handles"]))), _dbls(ev)[1], st_.ctypes.data_as(DP),
+                  na.ctypes.data_as(DP), eo.ctypes.data_as(DP), C.byref(st))
+        self.check(st)
+        return dict(state_raw=st_, state=st_.reshape(S, T, 4).transpose(1, 0, 2), national=na.reshape(T, 4), electoral_votes=eo.reshape(T, 5))
+
+    def scores(self, fit, summ, ev, won, day=0):
+        out, st = np.zeros(3), C.c_int(-1)
+        self.call("potus_R_backtest_scores", summ["state_raw"].ctypes.data_as(DP), _ints([fit["data"]["T"], fit["data"]["S"], day])[1],
+                  _dbls(ev)[1], _ints(won)[1], out.ctypes.data_as(DP), C.byref(st))
+        self.check(st)
+        return out
+
+    def csv(self, fit, directory, basename):
+        for h in fit["handles"]:
+            st = C.c_int(-1)
+            d = (C.c_char_p * 1)(str(directory).encode()); b = (C.c_char_p * 1)(basename.encode())
+            self.call("potus_R_write_stan_csv", C.byref(C.c_int(h)), d, b, C.byref(st))
+            self.check(st)
+
+    def free(self, fit):
+        for h in fit["handles"]:
+            st = C.c_int(-1)
+            self.call("potus_R_destroy", C.byref(C.c_int(h)), C.byref(st))
+            self.check(st)
+
+
+@pytest.mark.parametrize("name", ["small_full", "small_nomode"])
+def test_r_entry_points_replay_the_shim(cases, name, tmp_path):
+    """potus_R_create -> _init -> _run_many (chunks of `refresh`) -> _num_columns / _saved_count -> _write_array ->
+    _posterior_summary -> _backtest_scores -> _write_stan_csv -> _destroy, with `gpus = c(0, 0)` (two handles),
+    a seed beyond 32 bits and cus_per_chain = 8: the same bytes as the struct ABI, and potus_R_run on its own."""
+    data, variant = cases[name]
+    seed = 2 ** 40 + 1843
+    kw = dict(seed=seed, chains=3, iter_warmup=24, iter_sampling=10, refresh=7)
+    r = RShim()
+    fit = r.sample(data, variant, gpus=(0, 0), cus_per_chain=8, **kw)
+    assert fit["chains_per_handle"] == [2, 1] and fit["n_saved"] == 10
+    ref = PotusModel(variant).sample(data, devices=[0, 0], cus_per_chain=8, **kw)
+    assert ref._hs[0].cus_per_chain == 8 and fit["D"] == ref._hs[0].D and fit["n_cols"] == ref._hs[0].n_cols
+    full = r.write_array(fit, 0, fit["n_cols"])
+    assert np.array_equal(full, ref._write_array(0, fit["n_cols"]))
+    a, b, _ = ref._hs[0].layout["predicted_score"]
+    assert np.array_equal(r.write_array(fit, a, b), full[:, :, a:b])
+    S = int(data["S"])
+    ev = np.arange(3, 3 + S, dtype=np.float64)
+    sm, sm_ref = r.summary(fit, ev), ref.summary(ev)
+    for k in ("state", "national", "electoral_votes"):
+        assert np.array_equal(sm[k], sm_ref[k]), k
+    won = (np.arange(S) % 2).astype(int)
+    sc = r.scores(fit, sm, ev, won)
+    p = sm["state"][-1, :, 3]
+    assert np.isclose(sc[0], np.sum(ev / ev.sum() * (won - p) ** 2)) and np.isclose(sc[1], np.mean((won - p) ** 2))
+    assert sc[2] == np.sum(np.round(p) == won)                       # numpy rounds half to even, as R does
+    assert backtest_scores(sm_ref, ev, won)["states_correct"] == int(sc[2])
+    r.csv(fit, tmp_path, "rshim")
+    ref.output_files(tmp_path / "ref", "rshim")
+    for c in (1, 2, 3):
+        la = [ln for ln in open(tmp_path / f"rshim-{c}.csv") if not ln.startswith("#")]
+        lb = [ln for ln in open(tmp_path / "ref" / f"rshim-{c}.csv") if not ln.startswith("#")]
+        assert la == lb and len(la) == 11
+    # potus_R_run (one handle, no run_many) gives the chain it gives inside run_many; errors come back through *status
+    one = r.sample(data, variant, gpus=(0,), cus_per_chain=8, **{**kw, "chains": 1, "iter_warmup": 0, "iter_sampling": 0, "refresh": 0})
+    st = C.c_int(-1)
+    r.call("potus_R_run", C.byref(C.c_int(one["handles"][0])), C.byref(C.c_int(1)), C.byref(st))
+    assert st.value == 0
+    r.call("potus_R_run", C.byref(C.c_int(12345)), C.byref(C.c_int(1)), C.byref(st))
+    assert st.value == 4                                              # POTUS_ERR_STATE: bad handle
+    with pytest.raises(RuntimeError, match="bad handle"):
+        r.check(st)
+    r.free(one); r.free(fit)
+    with pytest.raises(RuntimeError, match="seed"):
+        r.sample(data, variant, gpus=(0,), **{**kw, "seed": -1})
+
+
+def _readme(year):
+    lines = open(GOLD / f"readme_{year}.csv").read().splitlines()
+    meta = {ln[2:].split(" = ")[0]: float(ln.split(" = ")[1]) for ln in lines if ln.startswith("# ") and " = " in ln}
+    rows = list(csv.DictReader(ln for ln in lines if not ln.startswith("#")))
+    return meta, rows
+
+
+# Tolerances of the README comparison.  The published tables are rounded to 3 decimals and were knitted from saved fits
+# whose script revision cannot be matched to the committed final_*.R; the CPU oracle itself
+# sits within 0.0019 / 0.004 / 0.021 (mean / interval ends / P(win)) of the 2016 table.
+TOL_MEAN, TOL_END, TOL_PROB, TOL_BRIER = 0.01, 0.012, 0.05, 0.006
+
+
+def test_readme_tables_of_the_three_backtests(cases):
+    """Everything the reference publishes about these posteriors: README.md:83-136 (2008), :179-232 (2012),
+    :279-332 (2016) -- election-day mean / 2.5 % / 97.5 % / P(win) of 51 states + the national vote -- and
+    README.md:75,169,260 (Brier scores, states called correctly), against three backtests run concurrently
+    (BASELINE configs[3] on one GPU: 4 chains x 16 CUs each, 1000 + 1000, seed 1843) and summarised on the device."""
+    hs, metas = {}, {}
+    for year in ("2008", "2012", "2016"):
+        data, variant = cases[year]
+        h = Handle(data, variant, chains=4, num_warmup=1000, num_samples=1000, seed=1843)
+        h.init()
+        hs[year] = h
+        metas[year] = dataprep.load_npz(GOLD / f"data_{year}.npz")["meta"]
+    for _ in range(20):
+        run_many(list(hs.values()), 100)
+    report = {}
+    for year, h in hs.items():
+        meta, rows = _readme(year)
+        states, ev = list(metas[year]["states"]), np.asarray(metas[year]["ev_state"], dtype=np.float64)
+        sm = h.posterior_summary(ev)
+        T = int(h.data["T"])
+        worst = dict(mean=0.0, low=0.0, high=0.0, prob=0.0)
+        for r in rows:
+            got = sm["national"][T - 1] if r["state"] == "--" else sm["state"][T - 1, states.index(r["state"])]
+            for k, j in (("low", 0), ("high", 1), ("mean", 2), ("prob", 3)):
+                worst[k] = max(worst[k], abs(got[j] - float(r[k])))
+        won = np.array([int(next(r for r in rows if r["state"] == s)["won_readme"]) for s in states])
+        sc = backtest_scores(sm, ev, won)
+        report[year] = (worst, sc, meta)
+        st, _ = h.chain_status()
+        div = h.write_array(5, 6, 1000)                     # divergent__ of the saved (sampling) draws
+        assert st == [0] * 4 and div.mean() < 0.01, (year, st, div.mean())
+        h.close()
+    print("README deltas:", {y: (w, s) for y, (w, s, _) in report.items()})
+    for year, (worst, sc, meta) in report.items():
+        assert worst["mean"] <= TOL_MEAN and worst["low"] <= TOL_END and worst["high"] <= TOL_END and worst["prob"] <= TOL_PROB, (year, worst)
+        assert abs(sc["ev_wtd_brier"] - meta["ev_wtd_brier"]) <= TOL_BRIER and abs(sc["unwtd_brier"] - meta["unwtd_brier"]) <= TOL_BRIER, (year, sc, meta)
+        assert abs(sc["states_correct"] - meta["states_correct"]) <= 1, (year, sc, meta)
+
+
+def test_summaries_beyond_one_lds_sort_and_over_several_handles(cases):
+    """More pooled draws than one 16 384-element LDS sort holds (the selection over several sorted runs), the chains
+    of the posterior spread over two handles: equal to the numpy restatement of final_2016.R:708-762, 799-823."""
+    import sys
+    sys.path.insert(0, str(GOLD.parent.parent / "oracle"))
+    from posterior_summary_ref import posterior_summary as ref_summary
+    data, variant = cases["small_full"]
+    S, T = int(data["S"]), int(data["T"])
+    ns = 3400
+    hs = [Handle(data, variant, chains=c, chain_id_offset=o, num_warmup=100, num_samples=ns, seed=5) for c, o in ((3, 0), (2, 3))]
+    for h in hs:
+        h.init()
+    run_many(hs, 100 + ns)
+    ev = np.arange(3, 3 + S, dtype=np.float64) * (538.0 / np.arange(3, 3 + S).sum())
+    got = posterior_summary(hs, ev)
+    a, b, _ = hs[0].layout["predicted_score"]
+    ps = np.concatenate([h.write_array(a, b, ns).reshape(-1, S, T) for h in hs]).transpose(0, 2, 1)     # [draw, T, S]
+    assert ps.shape[0] == 5 * ns > 16384
+    ref = ref_summary(ps, data["state_weights"], ev)
+    for k in ("state", "national", "electoral_votes"):
+        assert np.allclose(got[k], ref[k], rtol=1e-12, atol=1e-12), (k, np.abs(got[k] - ref[k]).max())
+    assert np.array_equal(got["state"][..., 3], ref["state"][..., 3])
+    one = hs[0].posterior_summary(ev)                                   # a single handle: one sorted run, straight from LDS
+    ref1 = ref_summary(hs[0].write_array(a, b, ns).reshape(-1, S, T).transpose(0, 2, 1), data["state_weights"], ev)
+    assert np.allclose(one["state"], ref1["state"], rtol=1e-12, atol=1e-12)
+    for h in hs:
+        h.close()
+
+
+def test_handles_are_recycled(cases):
+    data, variant = cases["small_full"]
+    a = Handle(data, variant, chains=1, num_warmup=2, num_samples=2)
+    ha = a.h
+    a.close()
+    b = Handle(data, variant, chains=1, num_warmup=2, num_samples=2)
+    assert b.h == ha
+    b.close()
+
+
+@pytest.mark.timeout(120)
+def test_watchdog_turns_a_missing_member_into_an_error(cases):
+    """A cluster whose members are not all running (here: member 3 leaves at once, as if another process held its
+    compute unit) must not hang or trap: the launch gives up, potus_run reports POTUS_ERR_WATCHDOG, the process and
+    the GPU stay usable."""
+    data, variant = cases["small_full"]
+    os.environ["POTUS_DEBUG_DROP_MEMBER"] = "4"
+    try:
+        h = Handle(data, variant, chains=2, num_warmup=10, num_samples=0, cus_per_chain=8, seed=3)
+    finally:
+        del os.environ["POTUS_DEBUG_DROP_MEMBER"]
+    h.init()
+    with pytest.raises(sampler.PotusError, match="error 8"):
+        h.run(3)
+    h.close()
+    g = Handle(data, variant, chains=2, num_warmup=10, num_samples=0, cus_per_chain=8, seed=3)
+    g.init(); g.run(3)
+    assert np.isfinite(g.draws_saved()) and g.total_leapfrogs() > 0
+    g.close()
+
+
+def test_bench_two_ranks_end_to_end_gloo_development_mode(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), in the development
+    mode that puts both ranks on GPU 0 with gloo collectives: chain blocks keyed by global chain id, potus_run_many
+    per rank, device-side write_array, pooled R-hat / ESS on rank 0, ONE JSON line."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, POTUS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "0", "--chunk", "10",
+           "--chains-per-gpu", "4", "--no-cpu-baseline", "--no-saturated"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=str(ROOT))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["config"]["total_chains"] == 8 and d["config"]["iter_sampling"] == 20
+    assert d["config"]["posteriors"]["2016"]["pooled_draws"] == 8 * 20 and d["leapfrogs"] > 0 and d["roofline"]["frac"] > 0

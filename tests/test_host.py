@@ -127,6 +127,16 @@ pooled = parallel.all_gather_draws(local, total)
 assert pooled.shape == (total, 3, 2), pooled.shape
 for c in range(total):
     assert np.array_equal(pooled[c], 100 * (c + 1) + np.arange(6).reshape(3, 2))
+# the device-side pooling used by bench.py (torch tensors [draw, chain, col]; CPU tensors under gloo)
+import torch
+loc = torch.zeros((4, 3, 2), dtype=torch.float64)
+for c in range(3):
+    loc[:, c, :] = 1000 * rank + 10 * c + torch.arange(8, dtype=torch.float64).reshape(4, 2)
+pl = parallel.all_gather_chains(loc, None)
+assert tuple(pl.shape) == (4, 3 * world, 2)
+for r in range(world):
+    for c in range(3):
+        assert torch.equal(pl[:, 3 * r + c, :], 1000 * r + 10 * c + torch.arange(8, dtype=torch.float64).reshape(4, 2))
 assert parallel.max_over_ranks(float(rank)) == world - 1
 assert parallel.sum_over_ranks(1.0) == world
 parallel.barrier()

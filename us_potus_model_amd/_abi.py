@@ -12,6 +12,8 @@ import numpy as np
 VARIANT_FULL = 0     # scripts/model/poll_model_2020.stan
 VARIANT_NO_MODE = 1  # scripts/model/poll_model_2020_no_mode_adjustment.stan
 VARIANTS = {"full": VARIANT_FULL, "no_mode_adjustment": VARIANT_NO_MODE}
+METRIC_DIAG, METRIC_DENSE = 0, 1
+METRICS = {"diag_e": METRIC_DIAG, "dense_e": METRIC_DENSE}
 N_SAMPLER_COLS = 7
 SAMPLER_COLS = ("lp__", "accept_stat__", "stepsize__", "treedepth__", "n_leapfrog__",
                 "divergent__", "energy__")
@@ -48,7 +50,7 @@ class PotusOpts(C.Structure):
         ("delta", C.c_double), ("gamma", C.c_double), ("kappa", C.c_double), ("t0", C.c_double),
         ("stepsize", C.c_double), ("init_radius", C.c_double),
         ("seed", C.c_uint64), ("device", C.c_int32), ("save_warmup", C.c_int32),
-        ("cus_per_chain", C.c_int32), ("reserved", C.c_int32),
+        ("cus_per_chain", C.c_int32), ("metric", C.c_int32),
     ]
 
 

@@ -106,8 +106,16 @@ template <class P> __device__ __forceinline__ P launder_s(P p) { // keep address
 // phase F of the same pass completes and hence before anybody's next X3.  Exchanges outside the tree (all-reduces of
 // the begin / end code) are all-to-all and consumed at once.  A missed assumption would not corrupt data silently:
 // a word overwritten too early carries a newer tag and the reader spins until the watchdog trap.
+// Watchdog.  The members of a cluster wait for each other, so they must all be resident; the host checks that for what
+// it launches itself (potus_create, potus_run_many), but it cannot see other processes on the GPU.  A wave that has
+// waited CL_SPIN_LIMIT rounds for a word gives up: it raises the chain's watchdog word (the 16 bytes behind the
+// exchange slots, polled by every other spinning wave of the cluster), sets the workgroup's cl_dead flag and ends.
+// Ended waves no longer count at barriers; every loop of the sampler is bounded or tests cl_dead, so the launch
+// drains in about a second, the chain scalars get status POTUS_ERR_WATCHDOG and potus_run returns that error --
+// instead of a trap, which would leave the whole process with a sticky HIP error.
+__shared__ int cl_dead;
 struct Xch {
-  rsrc_t xb;               // the chain's exchange buffer [4][K][XW] words of 16 bytes
+  rsrc_t xb;               // the chain's exchange buffer [4][K][XW] words of 16 bytes (+ the watchdog word)
   unsigned epoch;          // exchanges published so far in this launch (identical in every member)
   unsigned launch;         // launch id (host counter): stale words of earlier launches never match
   unsigned x1e;            // number of an X1 published ahead for the next pass (0 = none), see cl_pass_partial
@@ -118,6 +126,16 @@ struct Xch {
 __device__ __forceinline__ unsigned xch_wslot(const Xch &x, int mm) { return ((((x.epoch + 1u) & 3u) * (unsigned)x.K + (unsigned)mm) * (unsigned)x.XW) * 16u; }
 __device__ __forceinline__ unsigned xch_rslot(const Xch &x, int mm) { return (((x.epoch & 3u) * (unsigned)x.K + (unsigned)mm) * (unsigned)x.XW) * 16u; }
 __device__ __forceinline__ unsigned xch_eslot(const Xch &x, unsigned e, int mm) { return (((e & 3u) * (unsigned)x.K + (unsigned)mm) * (unsigned)x.XW) * 16u; }
+__device__ __forceinline__ unsigned xch_wdoff(const Xch &x) { return 4u * (unsigned)x.K * (unsigned)x.XW * 16u; }
+__device__ __forceinline__ bool xch_watchdog_raised(const Xch &x) {
+  return __builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(x.xb, 0u, __builtin_amdgcn_readfirstlane(xch_wdoff(x)), CL_AUX_SC1)) != 0u;
+}
+__device__ __forceinline__ void xch_give_up(const Xch &x) {
+  __builtin_amdgcn_raw_buffer_store_b32(1u, x.xb, 0u, __builtin_amdgcn_readfirstlane(xch_wdoff(x)), CL_AUX_SC1);
+  cl_dead = 1;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_endpgm();
+}
 // publish one word of the exchange being assembled (voff = 16 * word, or PT_OOB for idle lanes)
 __device__ __forceinline__ void xst(const Xch &x, unsigned voff, double v) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -156,7 +174,8 @@ __device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], c
   // the builtin becomes a system-scope load that costs ~2 us per round here.  What keeps the compiler from hoisting
   // it out of the loop is the laundered offset and the memory clobber.
   for (unsigned spins = 0; !all; spins++) {
-    if (spins > CL_SPIN_LIMIT) __builtin_trap();   // a member is missing: fail loudly instead of hanging the GPU
+    // a member is missing (or another wave of the cluster has already given up): leave instead of hanging the GPU
+    if (spins > CL_SPIN_LIMIT || ((spins & 1023u) == 1023u && xch_watchdog_raised(x))) xch_give_up(x);
 #ifdef POTUS_PROF
     if (xprof && (threadIdx.x & 63) == 0) xprof[58] += 1.0;
 #endif
@@ -473,6 +492,7 @@ __device__ __forceinline__ ClStatic cl_load_static(CCp CL, cip part) {
 }
 // Stage the walk factor and the (pseudo-)states of the member's polls in LDS, once per kernel.
 __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp lds) {
+  if (threadIdx.x == 0) cl_dead = 0;
   ldp Lw = lds + CL->l_Lw;
   gcdp src = as_g(M->mat);
   for (int i = threadIdx.x; i < (M->SE + 1) * M->SP; i += PT_THREADS) Lw[i] = i < M->SE * M->SP ? src[i] : 0.0;   // + a zero row
@@ -1408,7 +1428,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
   const double eps = ts->eps;
   while (true) {
     __syncthreads();
-    if (uni_i(ts->depth) >= c.max_depth || uni_i(ts->stop)) break;
+    if (uni_i(ts->depth) >= c.max_depth || uni_i(ts->stop) || uni_i(cl_dead)) break;
     const int depth = uni_i(ts->depth);
     c.x.epoch = uni32(c.x.epoch); c.x.x1e = uni32(c.x.x1e);
     if (tid == 0) {
@@ -1456,7 +1476,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
       }
       bool aborted = false;
       const double lpp = cl_pass_partial<CL_DW>(c.M, c.CL, c.part, c.lds, c.cst, c.x, lp, n < nleaf - 1, pend, ts, wout, aborted);
-      if (aborted) { valid = false; c.x.x1e = 0; break; }   // the previous leaf ended the trajectory: this one is dropped unseen
+      if (aborted || uni_i(cl_dead)) { valid = false; c.x.x1e = 0; break; }   // the previous leaf ended the trajectory: this one is dropped unseen
       CPROF_START(c);
       CPROF_COUNT(c, PF_LEAVES);
       // One all-reduce per leaf: log density, kinetic energy and the six dot products of every U-turn check
@@ -1545,12 +1565,12 @@ __device__ __forceinline__ void cl_init_stepsize(ClChain &c, uint32_t iter) {
         else {
           const double ne = dirn == 1 ? 2.0 * eps : 0.5 * eps;
           c.sc->nom_eps = ne;
-          if (ne > 1e7 || ne == 0) { ts->done = 1; c.sc->status = 2; } // upstream throws here
+          if (ne > 1e7 || ne == 0) { ts->done = 1; c.sc->status = POTUS_ERR_STEPSIZE; } // upstream throws here
         }
       }
     }
     __syncthreads();
-    if (uni_i(ts->done)) break;
+    if (uni_i(ts->done) || uni_i(cl_dead)) break;
   }
   __syncthreads();
 }

@@ -7,6 +7,7 @@
 #include "potus_nuts.hpp"
 #include "potus_cluster.hpp"
 #include "potus_dense.hpp"
+#include "potus_summary.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -182,7 +183,7 @@ __device__ __forceinline__ ClChain make_clchain(CMp M, CCp CL, CRp R, int chain,
   c.sc = (gsc)(R->scal + (size_t)chain * K + m);
   c.key = RngKey{R->seed_lo, R->seed_hi, (uint32_t)(R->chain_id_offset + chain + 1)};
   c.perm = as_g(CL->perm);
-  c.x.xb = make_rsrc(R->xbuf + (size_t)chain * 8 * K * CL->XW, 4u * (unsigned)K * (unsigned)CL->XW * 16u);
+  c.x.xb = make_rsrc(R->xbuf + (size_t)chain * (8 * K * CL->XW + 16), 4u * (unsigned)K * (unsigned)CL->XW * 16u + 16u);   // + the watchdog word
   c.x.epoch = 0; c.x.launch = launch; c.x.x1e = 0; c.x.K = K; c.x.m = m; c.x.XW = CL->XW;
   c.D = M->D; c.Dpad = Dpad; c.tid = (int)threadIdx.x;
   c.e0 = c.part[CP_E0]; c.e1 = c.e0 + c.part[CP_NE];
@@ -341,15 +342,18 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_run(const DevModel *Mg, const
   const int chain = blockIdx.x % R->chains, m = blockIdx.x / R->chains;
   ClChain c = make_clchain(M, CL, R, chain, m, launch);
   if (c.sc->status != 0) return;
+  if (R->debug_drop_member == m + 1) return;       // test hook: a member that never shows up
   c.cst = cl_setup_lds(M, CL, c.part, c.lds);
   const int total = R->num_warmup + R->num_samples;
   for (int k = 0; k < n_iter; k++) {
     const int it = c.sc->iter;
-    if (it >= total) break;
+    if (it >= total || uni_i(cl_dead)) break;
     c.x.epoch = uni32(cl_cold_transition_begin<CL_DW>(Mg, CLg, Rg, chain, m, launch, c.x.epoch, (uint32_t)it));
     cl_transition_tree<CL_DW>(c, (uint32_t)it);
+    if (uni_i(cl_dead)) break;
     c.x.epoch = uni32(cl_cold_transition_end<CL_DW>(Mg, CLg, Rg, chain, m, launch, c.x.epoch, (uint32_t)it));
   }
+  if (uni_i(cl_dead) && (c.tid & 63) == 0) c.sc->status = POTUS_ERR_WATCHDOG;   // every wave that is still alive
 #ifdef POTUS_PROF
   if (R->prof) for (int i = c.tid; i < PT_NPROF; i += PT_THREADS) as_g(R->prof)[((size_t)chain * CL->K + m) * PT_NPROF + i] += c.prof[i];
 #endif
@@ -362,8 +366,9 @@ struct WAParams {
   const double *draws; // [chains][n_save_max][row]
   int chains, n_save_max, n_saved, row, ncols, col_begin, col_end;
   double *scratch;     // [gridDim.x][ncols]
-  double *out;
+  double *out;         // [n_saved * chains][out_stride], the first col_end - col_begin entries of a row are written
   double sigma_ns, sigma_nn;
+  int out_stride;
 };
 __global__ __launch_bounds__(256) void k_write_array(const DevModel *Mg, WAParams W) {
   const DevModel M = *Mg;
@@ -433,81 +438,8 @@ __global__ __launch_bounds__(256) void k_write_array(const DevModel *Mg, WAParam
     }
     __syncthreads();
     const int nsel = W.col_end - W.col_begin;
-    double *dst = W.out + (size_t)d * nsel;
+    double *dst = W.out + (size_t)d * W.out_stride;
     for (int i = tid; i < nsel; i += 256) dst[i] = row[W.col_begin + i];
-    __syncthreads();
-  }
-}
-
-// ------------------------------------------------------------------------ posterior summaries
-// What the reference scripts compute from rstan::extract(out, "predicted_score") (final_2016.R:708-762 state and
-// national vote intervals, :799-823 electoral-college simulation), on the device, so that 8 000 x 12 954 doubles
-// never travel to R: one workgroup per cell pulls the pooled draws of its cell into LDS, sorts them (bitonic),
-// and emits mean / R type-7 quantiles / exceedance probability.
-//   cell <  T*S            predicted_score[t, s]                 -> low 2.5%, high 97.5%, mean, P(> 0.5)
-//   cell <  T*S + T        national vote: weighted mean over states (state_weights) per draw
-//   cell <  T*S + 2T       Democratic electoral votes sum_s ev[s] 1[p > 0.5] per draw
-//                          -> mean, median, high, low, P(>= 270)
-#define PS_MAXDRAWS 16384
-__device__ __forceinline__ double ps_quantile(const double *x, int n, double p) {   // R quantile(type = 7) on sorted x
-  const double h = (n - 1) * p;
-  const int lo = (int)floor(h);
-  const int hi = min(lo + 1, n - 1);
-  return x[lo] + (h - lo) * (x[hi] - x[lo]);
-}
-__global__ __launch_bounds__(512) void k_posterior_summary(const double *ps /*[nd][T*S], cell = t + T*s*/, int nd, int T, int S,
-                                                            const double *w, const double *ev, double *out_state, double *out_natl,
-                                                            double *out_ev) {
-  extern __shared__ __attribute__((aligned(16))) double xs[];
-  const int tid = threadIdx.x, TS = T * S;
-  int npad = 1;
-  while (npad < nd) npad <<= 1;
-  for (int cell = blockIdx.x; cell < TS + 2 * T; cell += gridDim.x) {
-    const int kind = cell < TS ? 0 : cell < TS + T ? 1 : 2;
-    const int t = kind == 0 ? 0 : (cell - TS) % T;
-    for (int d = tid; d < npad; d += 512) {
-      double v = INFINITY;                                   // padding sorts to the end
-      if (d < nd) {
-        const double *row = ps + (size_t)d * TS;
-        if (kind == 0) v = row[cell];
-        else {
-          v = 0.0;
-          for (int s = 0; s < S; s++) { const double x = row[t + T * s]; v += kind == 1 ? w[s] * x : (x > 0.5 ? ev[s] : 0.0); }
-        }
-      }
-      xs[d] = v;
-    }
-    __syncthreads();
-    for (int k = 2; k <= npad; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < npad; i += 512) {
-          const int l = i ^ j;
-          if (l > i) {
-            const double a = xs[i], b = xs[l];
-            const bool up = (i & k) == 0;
-            if ((a > b) == up) { xs[i] = b; xs[l] = a; }
-          }
-        }
-        __syncthreads();
-      }
-    // mean and exceedance in a fixed order (tree over the sorted values)
-    __shared__ double red[2][512];
-    double sm = 0.0, ex = 0.0;
-    const double thr = kind == 2 ? 270.0 : 0.5;
-    for (int d = tid; d < nd; d += 512) { const double x = xs[d]; sm += x; ex += kind == 2 ? (x >= thr ? 1.0 : 0.0) : (x > thr ? 1.0 : 0.0); }
-    red[0][tid] = sm; red[1][tid] = ex;
-    __syncthreads();
-    for (int off = 256; off > 0; off >>= 1) {
-      if (tid < off) { red[0][tid] += red[0][tid + off]; red[1][tid] += red[1][tid + off]; }
-      __syncthreads();
-    }
-    if (tid == 0) {
-      const double mean = red[0][0] / nd, prob = red[1][0] / nd;
-      const double lo = ps_quantile(xs, nd, 0.025), hi = ps_quantile(xs, nd, 0.975);
-      if (kind == 0) { double *o = out_state + (size_t)cell * 4; o[0] = lo; o[1] = hi; o[2] = mean; o[3] = prob; }
-      else if (kind == 1) { double *o = out_natl + (size_t)t * 4; o[0] = lo; o[1] = hi; o[2] = mean; o[3] = prob; }
-      else { double *o = out_ev + (size_t)t * 5; o[0] = mean; o[1] = ps_quantile(xs, nd, 0.5); o[2] = hi; o[3] = lo; o[4] = prob; }
-    }
     __syncthreads();
   }
 }
@@ -648,6 +580,19 @@ Sampler *get(int h) {
   if (h < 0 || h >= (int)g_handles.size()) return nullptr;
   return g_handles[h];
 }
+
+// One owner for every temporary device buffer of a call: freed on every return path.
+struct DevBufs {
+  std::vector<void *> v;
+  ~DevBufs() { for (void *p : v) (void)hipFree(p); }
+  template <class T> hipError_t alloc(T **p, size_t bytes) {
+    void *q = nullptr;
+    const hipError_t e = hipMalloc(&q, std::max<size_t>(bytes, 8));
+    if (e == hipSuccess) v.push_back(q);
+    *p = static_cast<T *>(q);
+    return e;
+  }
+};
 
 template <class T>
 int upload(Sampler *s, const std::vector<T> &v, const T **dst) {
@@ -871,7 +816,9 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
 
   // contiguous day ranges: minimise the largest cost (a day = S elements of vector work, a poll = a
   // 51-term dot + a gather) with at most CL_MAXDAYS days each
-  const int cw_day = getenv("POTUS_CW_DAY") ? atoi(getenv("POTUS_CW_DAY")) : S, cw_poll = getenv("POTUS_CW_POLL") ? atoi(getenv("POTUS_CW_POLL")) : 10;
+  // (weights measured on the 2016 posterior, scripts/micro/r02_sweep.sh: a poll costs a member about as much as a day --
+  //  dot, binomial term, adjoint gather -- 20.1 us per leapfrog against 21.1 with the earlier 51 : 10)
+  const int cw_day = getenv("POTUS_CW_DAY") ? atoi(getenv("POTUS_CW_DAY")) : 30, cw_poll = getenv("POTUS_CW_POLL") ? atoi(getenv("POTUS_CW_POLL")) : 30;
   auto groups_for = [&](int B, std::vector<int> *cut) {
     int g = 0, t = 0;
     if (cut) cut->assign(1, 0);
@@ -1097,6 +1044,29 @@ int read_scalars(Sampler *sp, std::vector<ChainScalars> &sc) {
   return 0;
 }
 
+// Anything that makes the chains of a handle unusable: a chain whose step-size search ran away (Stan throws there),
+// a cluster launch that gave up waiting for a member (watchdog word raised by the device).
+int check_chains(Sampler *sp) {
+  std::vector<ChainScalars> sc;
+  { const int rc_ = read_scalars(sp, sc); if (rc_) return rc_; }
+  if (sp->K > 1) {
+    const size_t per_chain = 4 * (size_t)sp->K * sp->CL.XW + 8;   // 16-byte words: exchange slots + the watchdog line
+    for (int c = 0; c < sp->R.chains; c++) {
+      unsigned wd = 0;
+      HIP_TRY(hipMemcpy(&wd, (const char *)sp->R.xbuf + ((size_t)c * per_chain + 4 * (size_t)sp->K * sp->CL.XW) * 16, 4, hipMemcpyDeviceToHost));
+      if (wd) return fail(POTUS_ERR_WATCHDOG, "chain %d: the %d workgroups of its cluster were not running together (is another process using GPU %d?); "
+                                              "the launch was abandoned and this handle is no longer usable", c + 1, sp->K, sp->device);
+    }
+  }
+  for (int c = 0; c < sp->R.chains; c++) {
+    if (sc[c].status == POTUS_ERR_INIT) return fail(POTUS_ERR_INIT, "chain %d: no finite initial log density/gradient after 100 attempts", c + 1);
+    if (sc[c].status == POTUS_ERR_STEPSIZE) return fail(POTUS_ERR_STEPSIZE, "chain %d: the step-size search left (0, 1e7) -- the posterior is improper or the gradient is wrong (Stan throws here)", c + 1);
+    if (sc[c].status == POTUS_ERR_WATCHDOG) return fail(POTUS_ERR_WATCHDOG, "chain %d: cluster launch abandoned (watchdog)", c + 1);
+    if (sc[c].status != 0) return fail(POTUS_ERR_STATE, "chain %d: status %d", c + 1, sc[c].status);
+  }
+  return 0;
+}
+
 } // namespace
 
 // ======================================================================== C ABI
@@ -1167,6 +1137,7 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   if (o->chains < 1) return fail(POTUS_ERR_ARG, "chains must be >= 1");
   if (o->max_depth < 1 || o->max_depth > PT_MAXD) return fail(POTUS_ERR_ARG, "max_depth must be in [1,%d]", PT_MAXD);
   if (o->num_warmup < 0 || o->num_samples < 0) return fail(POTUS_ERR_ARG, "negative iteration counts");
+  if (o->metric != POTUS_METRIC_DIAG && o->metric != POTUS_METRIC_DENSE) return fail(POTUS_ERR_ARG, "metric must be POTUS_METRIC_DIAG or POTUS_METRIC_DENSE");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(POTUS_ERR_DEVICE, "no HIP device: libpotus_hmc needs an MI355X (gfx950)");
   if (o->device < 0 || o->device >= ndev) return fail(POTUS_ERR_DEVICE, "device %d out of range (have %d)", o->device, ndev);
@@ -1177,7 +1148,14 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
 
   Sampler *sp = new Sampler();
   sp->device = o->device; sp->opts = *o; sp->L = make_layout(d);
-  auto bail = [&](int code) { for (void *p : sp->allocs) (void)hipFree(p); delete sp; return code; };
+  auto bail = [&](int code) {
+    for (void *p : sp->allocs) (void)hipFree(p);
+    if (sp->ev0) (void)hipEventDestroy(sp->ev0);
+    if (sp->ev1) (void)hipEventDestroy(sp->ev1);
+    if (sp->stream) (void)hipStreamDestroy(sp->stream);
+    delete sp;
+    return code;
+  };
   if ((rc = build_model(sp, d))) return bail(rc);
   if (sp->k1_unsupported.empty() && (rc = set_lds_attr(sp))) return bail(rc);
   {
@@ -1201,6 +1179,14 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
       // chosen by the library: a member whose polls do not fit its LDS gets half of them with twice the members
       while (rc == POTUS_ERR_UNSUPPORTED && o->cus_per_chain == 0 && 2 * K <= CL_MAXK && o->chains * 2 * K <= ncu) { K *= 2; rc = build_cluster(sp, d, K); }
       if (rc) return bail(rc);
+      // the members of a cluster wait for each other: the whole grid has to be resident at once
+      int per_cu = 0;
+      const void *kfn = sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4>) : reinterpret_cast<const void *>(k_cl_run<8>);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, PT_THREADS, sp->cl_lds_bytes) != hipSuccess || per_cu < 1)
+        return bail(fail(POTUS_ERR_DEVICE, "cluster kernel cannot be resident on this device (occupancy query: %d workgroups per compute unit with %zu bytes of LDS)",
+                         per_cu, sp->cl_lds_bytes));
+      if ((long long)o->chains * K > (long long)ncu * per_cu)
+        return bail(fail(POTUS_ERR_ARG, "chains * cus_per_chain = %d workgroups cannot be resident together (%d compute units x %d)", o->chains * K, ncu, per_cu));
     }
   }
   if (hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&sp->ev0) != hipSuccess ||
@@ -1228,8 +1214,9 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   sp->allocs.push_back(p); R.scal = (ChainScalars *)p;
   (void)hipMemset(p, 0, sizeof(ChainScalars) * o->chains * sp->K);
   R.K = sp->K; R.xbuf = nullptr; R.xcnt = nullptr;
+  R.debug_drop_member = getenv("POTUS_DEBUG_DROP_MEMBER") ? atoi(getenv("POTUS_DEBUG_DROP_MEMBER")) : 0;
   if (sp->K > 1) {
-    const size_t xb = (size_t)o->chains * 4 * sp->K * sp->CL.XW * 16;
+    const size_t xb = (size_t)o->chains * (4 * (size_t)sp->K * sp->CL.XW + 8) * 16;   // per chain: 4 exchange slots + a line for the watchdog word
     if (hipMalloc(&p, xb) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for exchange buffers failed"));
     sp->allocs.push_back(p); R.xbuf = (double *)p;
     (void)hipMemset(p, 0, xb);
@@ -1253,8 +1240,10 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   sp->allocs.push_back(p); sp->dR = (RunParams *)p;
   if (hipMemcpy(p, &R, sizeof(RunParams), hipMemcpyHostToDevice) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "upload of run parameters failed"));
   std::lock_guard<std::mutex> lk(g_mu);
-  g_handles.push_back(sp);
-  *handle = (int)g_handles.size() - 1;
+  size_t slot = 0;
+  while (slot < g_handles.size() && g_handles[slot]) slot++;     // handles of destroyed samplers are reused
+  if (slot == g_handles.size()) g_handles.push_back(sp); else g_handles[slot] = sp;
+  *handle = (int)slot;
   return 0;
 }
 
@@ -1282,16 +1271,16 @@ int potus_log_prob_grad(int handle, const double *q, int n, double *lp, double *
   if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
   if (n < 0 || (n > 0 && (!q || !lp || !grad))) return fail(POTUS_ERR_ARG, "null argument");
   if (n == 0) return 0;
-  std::unique_lock<std::mutex> cluster_lock(g_cluster_mu, std::defer_lock);
-  if (sp->K > 1) cluster_lock.lock();
+  std::lock_guard<std::mutex> cluster_lock(g_cluster_mu);
   HIP_TRY(hipSetDevice(sp->device));
   const size_t D = sp->L.D;
+  DevBufs tmp;
   double *dq = nullptr, *dlp = nullptr, *dg = nullptr;
-  HIP_TRY(hipMalloc((void **)&dq, n * D * 8)); HIP_TRY(hipMalloc((void **)&dg, n * D * 8)); HIP_TRY(hipMalloc((void **)&dlp, (size_t)n * 8));
+  HIP_TRY(tmp.alloc(&dq, n * D * 8)); HIP_TRY(tmp.alloc(&dg, n * D * 8)); HIP_TRY(tmp.alloc(&dlp, (size_t)n * 8));
   HIP_TRY(hipMemcpyAsync(dq, q, n * D * 8, hipMemcpyHostToDevice, sp->stream));
   double *dscr = nullptr;
   if (sp->K > 1) {   // the cluster's own pass, on one cluster
-    HIP_TRY(hipMalloc((void **)&dscr, 2 * (size_t)sp->R.Dpad * 8));
+    HIP_TRY(tmp.alloc(&dscr, 2 * (size_t)sp->R.Dpad * 8));
     const unsigned lid = ++sp->launch_id;
     if (sp->cl_dw == 4)
       hipLaunchKernelGGL(k_cl_logprob_grad<4>, dim3(sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
@@ -1307,20 +1296,18 @@ int potus_log_prob_grad(int handle, const double *q, int n, double *lp, double *
   HIP_TRY(hipMemcpyAsync(lp, dlp, (size_t)n * 8, hipMemcpyDeviceToHost, sp->stream));
   HIP_TRY(hipMemcpyAsync(grad, dg, n * D * 8, hipMemcpyDeviceToHost, sp->stream));
   HIP_TRY(hipStreamSynchronize(sp->stream));
-  (void)hipFree(dq); (void)hipFree(dg); (void)hipFree(dlp);
-  if (dscr) (void)hipFree(dscr);
   return 0;
 }
 
 int potus_init(int handle, const double *q0) {
   Sampler *sp = get(handle);
   if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
-  std::unique_lock<std::mutex> cluster_lock(g_cluster_mu, std::defer_lock);
-  if (sp->K > 1) cluster_lock.lock();
+  std::lock_guard<std::mutex> cluster_lock(g_cluster_mu);
   HIP_TRY(hipSetDevice(sp->device));
+  DevBufs tmp;
   double *dq0 = nullptr;
   const size_t bytes = (size_t)sp->R.chains * sp->L.D * 8;
-  if (q0) { HIP_TRY(hipMalloc((void **)&dq0, bytes)); HIP_TRY(hipMemcpyAsync(dq0, q0, bytes, hipMemcpyHostToDevice, sp->stream)); }
+  if (q0) { HIP_TRY(tmp.alloc(&dq0, bytes)); HIP_TRY(hipMemcpyAsync(dq0, q0, bytes, hipMemcpyHostToDevice, sp->stream)); }
   if (sp->K > 1) {
     const unsigned lid = ++sp->launch_id;
     if (sp->cl_dw == 4)
@@ -1333,11 +1320,7 @@ int potus_init(int handle, const double *q0) {
     hipLaunchKernelGGL(k_init, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, (const double *)dq0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(sp->stream));
-  if (dq0) (void)hipFree(dq0);
-  std::vector<ChainScalars> sc;
-  { const int rc_ = read_scalars(sp, sc); if (rc_) return rc_; }
-  for (int c = 0; c < sp->R.chains; c++)
-    if (sc[c].status == POTUS_ERR_INIT) return fail(POTUS_ERR_INIT, "chain %d: no finite initial log density/gradient after 100 attempts", c + 1);
+  { const int rc_ = check_chains(sp); if (rc_) return rc_; }
   sp->inited = true;
   return 0;
 }
@@ -1379,7 +1362,7 @@ int run_finish(RunTicket &t) {
   const int nw = sp->R.num_warmup;
   const int w_it = std::max(0, std::min(it1, nw) - std::min(t.it0, nw)), tot = std::max(1, it1 - t.it0);
   sp->warm_ms += ms * w_it / tot; sp->samp_ms += ms * (tot - w_it) / tot;
-  return 0;
+  return check_chains(sp);
 }
 } // namespace
 
@@ -1388,8 +1371,9 @@ int potus_run(int handle, int n_iter) {
   if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
   if (!sp->inited) return fail(POTUS_ERR_STATE, "potus_init must be called before potus_run");
   if (n_iter <= 0) return 0;
-  std::unique_lock<std::mutex> cluster_lock(g_cluster_mu, std::defer_lock);
-  if (sp->K > 1) cluster_lock.lock();
+  // launches are serialised per process: a cluster launch must find its compute units free, also of the
+  // workgroups of a one-workgroup-per-chain sampler
+  std::lock_guard<std::mutex> cluster_lock(g_cluster_mu);
   RunTicket t{sp, handle, 0, 0};
   int rc = run_launch(t, n_iter);
   if (rc) return rc;
@@ -1417,18 +1401,22 @@ int potus_run_many(const int *handles, int n_handles, int n_iter) {
   size_t n_done = 0;
   while (n_done < todo.size()) {
     std::vector<size_t> group;
-    std::vector<std::pair<int, int>> used;   // (device, XCD rows in use)
+    struct Use { int device, rows, plain; };   // XCD rows held by clusters; one-workgroup samplers in the group
+    std::vector<Use> used;
     for (size_t i = 0; i < todo.size(); i++) {
       if (done[i]) continue;
       Sampler *sp = todo[i].sp;
+      auto it = std::find_if(used.begin(), used.end(), [&](const Use &u) { return u.device == sp->device; });
       if (sp->K > 1) {
         int ncu = 0;
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, sp->device));
         const int rows = (sp->R.chains * sp->K + 7) / 8, cap = ncu / 8;
-        auto it = std::find_if(used.begin(), used.end(), [&](const std::pair<int, int> &u) { return u.first == sp->device; });
-        const int have = it == used.end() ? 0 : it->second;
-        if (have > 0 && have + rows > cap) continue;    // next group (a sampler alone always fits: checked at create)
-        if (it == used.end()) used.push_back({sp->device, rows}); else it->second += rows;
+        if (it != used.end() && (it->plain > 0 || it->rows + rows > cap)) continue;   // next group (a sampler alone always fits: checked at create)
+        if (it == used.end()) used.push_back({sp->device, rows, 0}); else it->rows += rows;
+      } else {
+        // a one-workgroup-per-chain launch may hold every compute unit for seconds: never beside a cluster
+        if (it != used.end() && it->rows > 0) continue;
+        if (it == used.end()) used.push_back({sp->device, 0, 1}); else it->plain += 1;
       }
       group.push_back(i);
     }
@@ -1497,6 +1485,13 @@ int potus_get_adaptation(int handle, double *stepsize, double *inv_metric) {
   return 0;
 }
 
+int potus_get_dense_metric(int handle, int chain, double *inv_metric) {
+  Sampler *sp = get(handle);
+  if (!sp || !inv_metric) return fail(POTUS_ERR_STATE, "bad handle or null output");
+  if (chain < 0 || chain >= sp->R.chains) return fail(POTUS_ERR_ARG, "chain %d out of range", chain);
+  return fail(POTUS_ERR_STATE, "the handle runs the diagonal metric: use potus_get_adaptation");
+}
+
 static int saved_count(Sampler *sp, int *n_saved) {
   std::vector<ChainScalars> sc;
   { const int rc_ = read_scalars(sp, sc); if (rc_) return rc_; }
@@ -1528,20 +1523,23 @@ int potus_draws_device_ptr(int handle, void **dptr, long long *n_doubles) {
   return 0;
 }
 
-static int write_array_range(Sampler *sp, int n_saved, int col_begin, int col_end, double *out) {
+// out: host buffer, or (device_out) a device buffer of the sampler's GPU that receives the rows directly
+static int write_array_range(Sampler *sp, int n_saved, int col_begin, int col_end, double *out, bool device_out = false, int out_stride = 0) {
   const int nsel = col_end - col_begin;
+  if (out_stride <= 0) out_stride = nsel;
   const int ndraw = n_saved * sp->R.chains;
   if (ndraw == 0) return 0;
   const int grid = std::min(ndraw, 512);
+  DevBufs tmp;
   double *scratch = nullptr, *dout = nullptr;
-  HIP_TRY(hipMalloc((void **)&scratch, (size_t)grid * sp->L.ncols * 8));
-  HIP_TRY(hipMalloc((void **)&dout, (size_t)ndraw * nsel * 8));
-  WAParams W{sp->R.draws, sp->R.chains, sp->R.n_save_max, n_saved, sp->R.row, sp->L.ncols, col_begin, col_end, scratch, dout, sp->sigma_ns, sp->sigma_nn};
+  HIP_TRY(tmp.alloc(&scratch, (size_t)grid * sp->L.ncols * 8));
+  if (device_out) dout = out;
+  else HIP_TRY(tmp.alloc(&dout, (size_t)ndraw * nsel * 8));
+  WAParams W{sp->R.draws, sp->R.chains, sp->R.n_save_max, n_saved, sp->R.row, sp->L.ncols, col_begin, col_end, scratch, dout, sp->sigma_ns, sp->sigma_nn, out_stride};
   hipLaunchKernelGGL(k_write_array, dim3(grid), dim3(256), 0, sp->stream, (const DevModel *)sp->dM, W);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(out, dout, (size_t)ndraw * nsel * 8, hipMemcpyDeviceToHost, sp->stream));
+  if (!device_out) HIP_TRY(hipMemcpyAsync(out, dout, (size_t)ndraw * nsel * 8, hipMemcpyDeviceToHost, sp->stream));
   HIP_TRY(hipStreamSynchronize(sp->stream));
-  (void)hipFree(scratch); (void)hipFree(dout);
   return 0;
 }
 
@@ -1555,41 +1553,120 @@ int potus_write_array(int handle, int col_begin, int col_end, double *out) {
   return write_array_range(sp, n_saved, col_begin, col_end, out);
 }
 
-int potus_posterior_summary(int handle, const double *ev, double *state_out, double *natl_out, double *ev_out) {
+// The same rows written straight into a DEVICE buffer of the sampler's GPU (e.g. a torch tensor's data_ptr()): what
+// the RCCL all-gather of the draws-of-interest sends, without a trip through host memory.
+int potus_write_array_device(int handle, int col_begin, int col_end, void *out_device) {
   Sampler *sp = get(handle);
-  if (!sp || !ev || !state_out || !natl_out || !ev_out) return fail(POTUS_ERR_STATE, "bad handle or null argument");
+  if (!sp || !out_device) return fail(POTUS_ERR_STATE, "bad handle or null output");
+  if (col_begin < 0 || col_end > sp->L.ncols || col_begin >= col_end) return fail(POTUS_ERR_ARG, "bad column range [%d,%d) of %d", col_begin, col_end, sp->L.ncols);
   HIP_TRY(hipSetDevice(sp->device));
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, out_device) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != sp->device) {
+    (void)hipGetLastError();
+    return fail(POTUS_ERR_ARG, "potus_write_array_device: the output is not device memory of GPU %d", sp->device);
+  }
   int n_saved = 0, rc = saved_count(sp, &n_saved);
   if (rc) return rc;
-  const int nd = n_saved * sp->R.chains, S = sp->M.S, T = sp->M.T, TS = S * T;
+  return write_array_range(sp, n_saved, col_begin, col_end, (double *)out_device, true);
+}
+
+// Pooled over every saved draw of every listed sampler (the chains of one posterior may sit in several handles, on one
+// GPU or several: PotusModel.sample(devices=...), potus_sampling.R gpus=...).  The work runs on the first handle's GPU;
+// predicted_score blocks of other GPUs are brought over with a peer copy.  Any number of draws (potus_summary.hpp).
+int potus_posterior_summary_many(const int *handles, int n_handles, const double *ev, double *state_out, double *natl_out, double *ev_out) {
+  if (!handles || n_handles < 1 || !ev || !state_out || !natl_out || !ev_out) return fail(POTUS_ERR_ARG, "potus_posterior_summary: null argument");
+  std::vector<Sampler *> sps;
+  std::vector<int> n_saved(n_handles, 0);
+  long long nd = 0;
+  for (int i = 0; i < n_handles; i++) {
+    Sampler *sp = get(handles[i]);
+    if (!sp) return fail(POTUS_ERR_STATE, "potus_posterior_summary: bad handle %d", handles[i]);
+    for (int j = 0; j < i; j++) if (handles[j] == handles[i]) return fail(POTUS_ERR_ARG, "potus_posterior_summary: handle %d listed twice", handles[i]);
+    if (i > 0 && (sp->M.S != sps[0]->M.S || sp->M.T != sps[0]->M.T || sp->L.ncols != sps[0]->L.ncols))
+      return fail(POTUS_ERR_ARG, "potus_posterior_summary: handle %d holds another model than handle %d", handles[i], handles[0]);
+    HIP_TRY(hipSetDevice(sp->device));
+    int rc = saved_count(sp, &n_saved[i]);
+    if (rc) return rc;
+    nd += (long long)n_saved[i] * sp->R.chains;
+    sps.push_back(sp);
+  }
+  Sampler *s0 = sps[0];
+  const int S = s0->M.S, T = s0->M.T, TS = S * T, NC = TS + 2 * T;
   if (nd < 2) return fail(POTUS_ERR_STATE, "posterior summaries need at least two saved draws");
-  if (nd > PS_MAXDRAWS) return fail(POTUS_ERR_UNSUPPORTED, "%d pooled draws: the LDS sort handles up to %d", nd, PS_MAXDRAWS);
-  // predicted_score of every saved draw, on the device: [iter][chain][T*S] (the generated-quantities block)
-  const int col_end = sp->L.ncols, col_begin = col_end - TS;
-  const int grid_w = std::min(nd, 512);
-  double *scratch = nullptr, *dps = nullptr, *dw = nullptr, *dev_ = nullptr, *dout = nullptr;
-  HIP_TRY(hipMalloc((void **)&scratch, (size_t)grid_w * sp->L.ncols * 8));
-  HIP_TRY(hipMalloc((void **)&dps, (size_t)nd * TS * 8));
-  HIP_TRY(hipMalloc((void **)&dw, (size_t)S * 8)); HIP_TRY(hipMalloc((void **)&dev_, (size_t)S * 8));
-  HIP_TRY(hipMalloc((void **)&dout, ((size_t)TS * 4 + (size_t)T * 9) * 8));
-  WAParams W{sp->R.draws, sp->R.chains, sp->R.n_save_max, n_saved, sp->R.row, sp->L.ncols, col_begin, col_end, scratch, dps, sp->sigma_ns, sp->sigma_nn};
-  hipLaunchKernelGGL(k_write_array, dim3(grid_w), dim3(256), 0, sp->stream, (const DevModel *)sp->dM, W);
+  const int col_end = s0->L.ncols, col_begin = col_end - TS;   // predicted_score = the generated-quantities block
+  HIP_TRY(hipSetDevice(s0->device));
+  DevBufs tmp;
+  double *full = nullptr, *cols = nullptr, *dw = nullptr, *dev_ = nullptr, *dout = nullptr, *scr = nullptr;
+  HIP_TRY(tmp.alloc(&full, (size_t)nd * NC * 8));
+  HIP_TRY(tmp.alloc(&cols, (size_t)nd * NC * 8));
+  HIP_TRY(tmp.alloc(&dw, (size_t)S * 8)); HIP_TRY(tmp.alloc(&dev_, (size_t)S * 8));
+  HIP_TRY(tmp.alloc(&dout, ((size_t)TS * 4 + (size_t)T * 9) * 8));
+  long long row0 = 0;
+  for (int i = 0; i < n_handles; i++) {
+    Sampler *sp = sps[i];
+    const long long rows = (long long)n_saved[i] * sp->R.chains;
+    if (rows == 0) continue;
+    double *dst = full + (size_t)row0 * NC;
+    int rc;
+    if (sp->device == s0->device) {
+      if ((rc = write_array_range(sp, n_saved[i], col_begin, col_end, dst, true, NC))) return rc;
+    } else {
+      HIP_TRY(hipSetDevice(sp->device));
+      DevBufs far;                                     // freed on its own device before we go back
+      double *blk = nullptr;
+      HIP_TRY(far.alloc(&blk, (size_t)rows * NC * 8));
+      if ((rc = write_array_range(sp, n_saved[i], col_begin, col_end, blk, true, NC))) return rc;
+      HIP_TRY(hipMemcpyPeer(dst, s0->device, blk, sp->device, (size_t)rows * NC * 8));
+      HIP_TRY(hipSetDevice(s0->device));
+    }
+    row0 += rows;
+  }
+  HIP_TRY(hipSetDevice(s0->device));
+  HIP_TRY(hipMemcpyAsync(dw, s0->h_w.data(), (size_t)S * 8, hipMemcpyHostToDevice, s0->stream));
+  HIP_TRY(hipMemcpyAsync(dev_, ev, (size_t)S * 8, hipMemcpyHostToDevice, s0->stream));
+  hipLaunchKernelGGL(k_ps_derived, dim3((unsigned)std::min<long long>((nd * T + 255) / 256, 65535)), dim3(256), 0, s0->stream, full, nd, T, S,
+                     (const double *)dw, (const double *)dev_);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(dw, sp->h_w.data(), (size_t)S * 8, hipMemcpyHostToDevice, sp->stream));
-  HIP_TRY(hipMemcpyAsync(dev_, ev, (size_t)S * 8, hipMemcpyHostToDevice, sp->stream));
+  hipLaunchKernelGGL(k_ps_transpose, dim3((NC + 63) / 64, (unsigned)((nd + 63) / 64)), dim3(256), 0, s0->stream, (const double *)full, cols, nd, NC);
+  HIP_TRY(hipGetLastError());
   int npad = 1;
-  while (npad < nd) npad <<= 1;
+  while (npad < nd && npad < PS_RUN) npad <<= 1;
   const size_t lds = (size_t)npad * 8;
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_posterior_summary), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = std::min(NC, 1024);
+  if (nd > PS_RUN) HIP_TRY(tmp.alloc(&scr, (size_t)grid * (size_t)nd * 8));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_col_summary), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   double *o_state = dout, *o_natl = dout + (size_t)TS * 4, *o_ev = o_natl + (size_t)T * 4;
-  hipLaunchKernelGGL(k_posterior_summary, dim3(std::min(TS + 2 * T, 4096)), dim3(512), lds, sp->stream, (const double *)dps, nd, T, S,
-                     (const double *)dw, (const double *)dev_, o_state, o_natl, o_ev);
+  hipLaunchKernelGGL(k_col_summary, dim3(grid), dim3(PS_THREADS), lds, s0->stream, (const double *)cols, scr, nd, T, S, o_state, o_natl, o_ev);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(state_out, o_state, (size_t)TS * 4 * 8, hipMemcpyDeviceToHost, sp->stream));
-  HIP_TRY(hipMemcpyAsync(natl_out, o_natl, (size_t)T * 4 * 8, hipMemcpyDeviceToHost, sp->stream));
-  HIP_TRY(hipMemcpyAsync(ev_out, o_ev, (size_t)T * 5 * 8, hipMemcpyDeviceToHost, sp->stream));
-  HIP_TRY(hipStreamSynchronize(sp->stream));
-  (void)hipFree(scratch); (void)hipFree(dps); (void)hipFree(dw); (void)hipFree(dev_); (void)hipFree(dout);
+  HIP_TRY(hipMemcpyAsync(state_out, o_state, (size_t)TS * 4 * 8, hipMemcpyDeviceToHost, s0->stream));
+  HIP_TRY(hipMemcpyAsync(natl_out, o_natl, (size_t)T * 4 * 8, hipMemcpyDeviceToHost, s0->stream));
+  HIP_TRY(hipMemcpyAsync(ev_out, o_ev, (size_t)T * 5 * 8, hipMemcpyDeviceToHost, s0->stream));
+  HIP_TRY(hipStreamSynchronize(s0->stream));
+  return 0;
+}
+
+int potus_posterior_summary(int handle, const double *ev, double *state_out, double *natl_out, double *ev_out) {
+  return potus_posterior_summary_many(&handle, 1, ev, state_out, natl_out, ev_out);
+}
+
+// The backtest scores of final_2016.R:925-945 (final_2012.R:918-931, final_2008.R:922-935) from the state summaries:
+// with p_s = P(score > 0.5) of state s on `day` (1-based; 0 = the last day) and won_s the actual outcome,
+//   out[0] = weighted.mean((won - p)^2, ev / sum(ev)), out[1] = mean((won - p)^2), out[2] = sum(round(p) == won)
+// (R's round(): half to even).  Pure host arithmetic on the output of potus_posterior_summary.
+int potus_backtest_scores(const double *state_out, int T, int S, int day, const double *ev, const int *won, double *out) {
+  if (!state_out || !ev || !won || !out || T < 1 || S < 1 || day < 0 || day > T) return fail(POTUS_ERR_ARG, "potus_backtest_scores: bad argument");
+  const int t = day == 0 ? T - 1 : day - 1;
+  double evsum = 0, a = 0, b = 0;
+  int correct = 0;
+  for (int s = 0; s < S; s++) evsum += ev[s];
+  if (!(evsum > 0)) return fail(POTUS_ERR_ARG, "potus_backtest_scores: electoral votes sum to %g", evsum);
+  for (int s = 0; s < S; s++) {
+    const double p = state_out[((size_t)t + (size_t)T * s) * 4 + 3], d = (double)won[s] - p;
+    a += ev[s] / evsum * d * d;
+    b += d * d;
+    correct += (int)std::nearbyint(p) == won[s];
+  }
+  out[0] = a; out[1] = b / S; out[2] = correct;
   return 0;
 }
 
@@ -1634,10 +1711,18 @@ int potus_write_stan_csv(int handle, const char *dir, const char *basename) {
             sp->R.chain_id_offset + c + 1, o.init_radius, (unsigned long long)o.seed, path.c_str());
     char name[96];
     for (int k = 0; k < ncols; k++) { potus_column_name(&dd, k, name, sizeof name); fprintf(f, k ? ",%s" : "%s", name); }
-    fprintf(f, "\n# Adaptation terminated\n# Step size = %.6g\n# Diagonal elements of inverse mass matrix:\n# ", eps[c]);
-    for (int i = 0; i < D; i++) fprintf(f, i ? ", %.6g" : "%.6g", minv[(size_t)c * D + i]);
     fprintf(f, "\n");
   }
+  // CmdStan writes the adaptation block when warm-up ends: straight after the header without save_warmup, after the
+  // warm-up rows with it
+  auto adaptation_block = [&](int c) {
+    FILE *f = fp[c];
+    fprintf(f, "# Adaptation terminated\n# Step size = %.6g\n# Diagonal elements of inverse mass matrix:\n# ", eps[c]);
+    for (int i = 0; i < D; i++) fprintf(f, i ? ", %.6g" : "%.6g", minv[(size_t)c * D + i]);
+    fprintf(f, "\n");
+  };
+  const int n_warm_rows = sp->opts.save_warmup ? std::min(n_saved, sp->R.num_warmup) : 0;
+  if (n_warm_rows == 0) for (int c = 0; c < chains; c++) adaptation_block(c);
   // stream the rows in blocks of draws: rows come back as [iter][chain][ncols]
   const int blk = 32;
   std::vector<double> rows((size_t)blk * chains * ncols);
@@ -1652,6 +1737,7 @@ int potus_write_stan_csv(int handle, const char *dir, const char *basename) {
         FILE *f = fp[c];
         for (int k = 0; k < ncols; k++) fprintf(f, k ? ",%.6g" : "%.6g", r[k]);
         fputc('\n', f);
+        if (n_warm_rows > 0 && i0 + i == n_warm_rows - 1) adaptation_block(c);
       }
   }
   for (int c = 0; c < chains; c++)
@@ -1763,8 +1849,10 @@ void potus_R_create(int *dims, int *state, int *day_state, int *day_national, in
   d.polling_bias_scale = scalars[8]; d.state_covariance_0 = state_covariance_0;
   potus_opts o; potus_default_opts(&o);
   o.chains = iopts[0]; o.chain_id_offset = iopts[1]; o.num_warmup = iopts[2]; o.num_samples = iopts[3]; o.max_depth = iopts[4];
-  o.device = iopts[5]; o.save_warmup = iopts[6]; o.seed = (uint64_t)(unsigned)iopts[7];
+  o.device = iopts[5]; o.save_warmup = iopts[6]; o.cus_per_chain = iopts[7]; o.metric = iopts[8];
   o.delta = dopts[0]; o.gamma = dopts[1]; o.kappa = dopts[2]; o.t0 = dopts[3]; o.stepsize = dopts[4]; o.init_radius = dopts[5];
+  if (!(dopts[6] >= 0) || dopts[6] > 9007199254740992.0 || dopts[6] != std::floor(dopts[6])) { *status = fail(POTUS_ERR_ARG, "seed must be a non-negative integer below 2^53"); return; }
+  o.seed = (uint64_t)dopts[6];   // R integers are 32 bits wide: the seed travels as a double (exact to 2^53)
   *status = potus_create(&d, &o, handle);
 }
 void potus_R_init(int *handle, int *status) { *status = potus_init(*handle, nullptr); }
@@ -1777,9 +1865,13 @@ void potus_R_num_columns(int *handle, int *D, int *n_cols, int *status) {
 }
 void potus_R_write_array(int *handle, int *col_begin, int *col_end, double *out, int *status) { *status = potus_write_array(*handle, *col_begin, *col_end, out); }
 void potus_R_write_stan_csv(int *handle, char **dir, char **basename, int *status) { *status = potus_write_stan_csv(*handle, dir[0], basename[0]); }
-void potus_R_posterior_summary(int *handle, double *ev, double *state_out, double *natl_out, double *ev_out, int *status) {
-  *status = potus_posterior_summary(*handle, ev, state_out, natl_out, ev_out);
+void potus_R_posterior_summary(int *handles, int *n_handles, double *ev, double *state_out, double *natl_out, double *ev_out, int *status) {
+  *status = potus_posterior_summary_many(handles, *n_handles, ev, state_out, natl_out, ev_out);
 }
+void potus_R_backtest_scores(double *state_out, int *dims /*[3]: T, S, day*/, double *ev, int *won, double *out, int *status) {
+  *status = potus_backtest_scores(state_out, dims[0], dims[1], dims[2], ev, won, out);
+}
+void potus_R_saved_count(int *handle, int *n_saved, int *status) { *status = potus_get_draws(*handle, nullptr, n_saved); }
 void potus_R_last_error(char **buf, int *len) { potus_last_error(buf[0], *len); }
 void potus_R_destroy(int *handle, int *status) { *status = potus_destroy(*handle); }
 

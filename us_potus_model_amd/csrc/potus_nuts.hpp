@@ -74,7 +74,9 @@ struct RunParams {
   double *prof;            // [chains][PT_NPROF] (POTUS_PROF builds) or null
   double *xbuf;            // cluster mode: [chains][2][K][XW] exchange words of 16 bytes {value, tag}
   unsigned *xcnt;          // cluster mode: [chains][64] arrival counters (one cache line apart)
-  int K, pad;              // workgroups per chain (1: potus_nuts.hpp; > 1: potus_cluster.hpp, scal is [chains][K])
+  int K;                   // workgroups per chain (1: potus_nuts.hpp; > 1: potus_cluster.hpp, scal is [chains][K])
+  int debug_drop_member;   // test hook (POTUS_DEBUG_DROP_MEMBER = m + 1): member m of every cluster leaves k_cl_run at once, the
+                           // rest must find out through the watchdog (tests/test_gpu_parity.py)
 };
 
 typedef const RunParams AS_C *CRp;
@@ -519,7 +521,7 @@ __device__ __forceinline__ void init_stepsize(const Chain &c, uint32_t iter) {
         else {
           const double ne = dirn == 1 ? 2.0 * eps : 0.5 * eps;
           c.sc->nom_eps = ne;
-          if (ne > 1e7 || ne == 0) { ts->done = 1; c.sc->status = 2; } // upstream throws here
+          if (ne > 1e7 || ne == 0) { ts->done = 1; c.sc->status = POTUS_ERR_STEPSIZE; } // upstream throws here
         }
       }
     }

@@ -68,6 +68,27 @@ def all_gather_draws(local: np.ndarray, total_chains: int, device=None) -> np.nd
     return np.concatenate(parts, axis=0)
 
 
+def all_gather_chains(local, device=None):
+    """Device-side pooling of draws-of-interest: `local` is a torch tensor [n_draws, C, k] on this rank's GPU (the same
+    C on every rank); returns [n_draws, world * C, k], chains in rank order, on every rank.  With a device the
+    collective is dist.all_gather_into_tensor on device memory (RCCL over xGMI); device=None is the gloo development
+    mode (CPU tensors)."""
+    import torch
+    import torch.distributed as dist
+    _, world, _ = env_rank_world()
+    if world == 1 or not dist.is_initialized():
+        return local
+    if device is None:
+        x = local.cpu().contiguous()
+        out = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(out, x)
+        return torch.cat(out, dim=1)
+    x = local.contiguous()
+    out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x)
+    return out.permute(1, 0, 2, 3).reshape(x.shape[0], world * x.shape[1], x.shape[2])
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_initialized():

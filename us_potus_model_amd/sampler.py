@@ -73,6 +73,10 @@ def load_library():
     L.potus_write_stan_csv.argtypes = [C.c_int, C.c_char_p, C.c_char_p]
     L.potus_last_run_timing.argtypes = [C.c_int, dp, C.POINTER(C.c_longlong)]
     L.potus_posterior_summary.argtypes = [C.c_int, dp, dp, dp, dp]
+    L.potus_posterior_summary_many.argtypes = [ip, C.c_int, dp, dp, dp, dp]
+    L.potus_backtest_scores.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp, ip, dp]
+    L.potus_write_array_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.potus_get_dense_metric.argtypes = [C.c_int, C.c_int, dp]
     L.potus_cus_per_chain.argtypes = [C.c_int, ip]
     _LIB = L
     return L
@@ -82,9 +86,10 @@ EXPORTS = [
     "potus_version", "potus_last_error", "potus_default_opts", "potus_num_params", "potus_num_columns",
     "potus_column_name", "potus_create", "potus_destroy", "potus_cus_per_chain", "potus_log_prob_grad", "potus_init", "potus_run", "potus_run_many",
     "potus_iterations_done", "potus_total_leapfrogs", "potus_chain_status", "potus_get_adaptation",
-    "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_stan_csv",
-    "potus_last_run_timing", "potus_posterior_summary", "potus_R_create", "potus_R_init", "potus_R_run", "potus_R_run_many", "potus_R_num_columns",
-    "potus_R_write_array", "potus_R_write_stan_csv", "potus_R_posterior_summary", "potus_R_last_error", "potus_R_destroy",
+    "potus_get_dense_metric", "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_array_device", "potus_write_stan_csv",
+    "potus_last_run_timing", "potus_posterior_summary", "potus_posterior_summary_many", "potus_backtest_scores",
+    "potus_R_create", "potus_R_init", "potus_R_run", "potus_R_run_many", "potus_R_num_columns", "potus_R_saved_count",
+    "potus_R_write_array", "potus_R_write_stan_csv", "potus_R_posterior_summary", "potus_R_backtest_scores", "potus_R_last_error", "potus_R_destroy",
 ]
 
 
@@ -183,6 +188,11 @@ class Handle:
         _check(self.L, self.L.potus_get_adaptation(self.h, _dp(eps), _dp(minv)))
         return eps, minv
 
+    def draws_saved(self):
+        n = C.c_int()
+        _check(self.L, self.L.potus_get_draws(self.h, None, C.byref(n)))
+        return n.value
+
     def draws(self):
         """[chains, n_saved, 7 + D] on the unconstrained scale."""
         n = C.c_int()
@@ -197,11 +207,27 @@ class Handle:
 
         Returns dict(state=[T,S,4] (low, high, mean, prob), national=[T,4], electoral_votes=[T,5]
         (mean, median, high, low, P(>=270))); `ev` = electoral votes per state, in state order."""
-        S, T = int(self.data["S"]), int(self.data["T"])
-        ev = np.ascontiguousarray(ev, dtype=np.float64).reshape(S)
-        st, na, eo = np.zeros((S, T, 4)), np.zeros((T, 4)), np.zeros((T, 5))
-        _check(self.L, self.L.potus_posterior_summary(self.h, _dp(ev), _dp(st), _dp(na), _dp(eo)))
-        return dict(state=np.ascontiguousarray(st.transpose(1, 0, 2)), national=na, electoral_votes=eo)
+        return posterior_summary([self], ev)
+
+    def write_array_device(self, col_begin, col_end, out_tensor):
+        """write_array straight into a torch tensor on this handle's GPU ([n_saved, chains, col_end - col_begin],
+        float64, contiguous): the buffer an RCCL all-gather sends, no trip through the host."""
+        import torch
+        if not (out_tensor.is_cuda and out_tensor.dtype == torch.float64 and out_tensor.is_contiguous()):
+            raise TypeError("write_array_device needs a contiguous float64 tensor on the GPU")
+        n = C.c_int()
+        _check(self.L, self.L.potus_get_draws(self.h, None, C.byref(n)))
+        if out_tensor.numel() != n.value * self.opts.chains * (col_end - col_begin):
+            raise ValueError(f"tensor has {out_tensor.numel()} elements, {n.value} x {self.opts.chains} x {col_end - col_begin} expected")
+        torch.cuda.current_stream(out_tensor.device).synchronize()      # the library writes on its own stream
+        _check(self.L, self.L.potus_write_array_device(self.h, col_begin, col_end, C.c_void_p(out_tensor.data_ptr())))
+        return out_tensor
+
+    def dense_metric(self, chain=0):
+        """metric = dense_e: the adapted D x D inverse metric of one chain."""
+        out = np.zeros((self.D, self.D))
+        _check(self.L, self.L.potus_get_dense_metric(self.h, int(chain), _dp(out)))
+        return out
 
     def draws_device_ptr(self):
         p, n = C.c_void_p(), C.c_longlong()
@@ -221,6 +247,31 @@ class Handle:
         return [str(Path(directory) / f"{basename}-{off + c + 1}.csv") for c in range(self.opts.chains)]
 
 
+def posterior_summary(handles, ev):
+    """potus_posterior_summary_many: the summaries of final_2016.R:708-762, 799-823 over the pooled draws of every
+    listed handle (the chains of one posterior, on one GPU or several)."""
+    h0 = handles[0]
+    S, T = int(h0.data["S"]), int(h0.data["T"])
+    ev = np.ascontiguousarray(ev, dtype=np.float64).reshape(S)
+    st, na, eo = np.zeros((S, T, 4)), np.zeros((T, 4)), np.zeros((T, 5))
+    ids = (C.c_int * len(handles))(*[h.h for h in handles])
+    _check(h0.L, h0.L.potus_posterior_summary_many(ids, len(handles), _dp(ev), _dp(st), _dp(na), _dp(eo)))
+    return dict(state=np.ascontiguousarray(st.transpose(1, 0, 2)), national=na, electoral_votes=eo)
+
+
+def backtest_scores(summary, ev, won, day=0):
+    """final_2016.R:925-945: (EV-weighted Brier, unweighted Brier, states called correctly) from the `state` block of
+    a posterior summary; `won` = 1 where the Democrat carried the state; day: 1-based, 0 = election day (the last)."""
+    L = load_library()
+    st = np.ascontiguousarray(np.asarray(summary["state"], dtype=np.float64).transpose(1, 0, 2))    # [S][T][4]: cell t + T*s
+    S, T = st.shape[0], st.shape[1]
+    ev = np.ascontiguousarray(ev, dtype=np.float64).reshape(S)
+    w = (C.c_int * S)(*[int(x) for x in won])
+    out = np.zeros(3)
+    _check(L, L.potus_backtest_scores(_dp(st), T, S, int(day), _dp(ev), w, _dp(out)))
+    return dict(ev_wtd_brier=float(out[0]), unwtd_brier=float(out[1]), states_correct=int(out[2]))
+
+
 def run_many(handles, n_iter):
     """potus_run_many: advance several handles (other posteriors, other GPUs) concurrently from one host thread."""
     if not handles:
@@ -238,9 +289,12 @@ class StanFit:
         self._hs = list(handle) if isinstance(handle, (list, tuple)) else [handle]
         self._h = self._hs[0]
         self.model_name = model_name  # out@model_name, final_2016.R:825
-        self._draws = np.concatenate([h.draws() for h in self._hs], axis=0)
-        self.n_saved = self._draws.shape[1]
-        self.chains = self._draws.shape[0]
+        # only the 7 sampler columns come to the host here (through write_array); the unconstrained draws
+        # (chains x draws x D doubles: 1 GB for the 2016 run) stay on the device until unconstrained() asks for them
+        self.n_saved = self._hs[0].draws_saved()
+        self.chains = sum(h.opts.chains for h in self._hs)
+        self._sampler = np.transpose(self._write_array(0, _abi.N_SAMPLER_COLS), (1, 0, 2))       # [chain, draw, 7]
+        self._draws = None
 
     def _write_array(self, a, b):
         """[iter, chain, b - a] over all devices, chains in id order."""
@@ -248,10 +302,17 @@ class StanFit:
 
     def sampler_params(self):
         """dict of [chains, draws] arrays: lp__, accept_stat__, ... (rstan::get_sampler_params)."""
-        return {n: self._draws[:, :, i] for i, n in enumerate(_abi.SAMPLER_COLS)}
+        return {n: self._sampler[:, :, i] for i, n in enumerate(_abi.SAMPLER_COLS)}
 
     def unconstrained(self):
+        """[chains, draws, D] on the unconstrained scale (copied from the devices on first use)."""
+        if self._draws is None:
+            self._draws = np.concatenate([h.draws() for h in self._hs], axis=0)
         return self._draws[:, :, _abi.N_SAMPLER_COLS:]
+
+    def summary(self, ev):
+        """Device-side posterior summaries over all chains of the fit (see posterior_summary)."""
+        return posterior_summary(self._hs, ev)
 
     def extract(self, pars, permuted=False):
         """rstan::extract(out, pars=)[[1]]: array [draws, ...dims], chains merged.
@@ -265,7 +326,7 @@ class StanFit:
         out = {}
         for name in names:
             if name in _abi.SAMPLER_COLS:
-                out[name] = self._draws[:, :, _abi.SAMPLER_COLS.index(name)].reshape(-1)
+                out[name] = self._sampler[:, :, _abi.SAMPLER_COLS.index(name)].reshape(-1)
                 continue
             if name not in self._h.layout:
                 raise KeyError(f"unknown parameter {name!r}")
@@ -310,7 +371,7 @@ class PotusModel:
 
     def sample(self, data, seed=1843, chains=4, parallel_chains=None, iter_warmup=1000, iter_sampling=1000,
                refresh=100, adapt_delta=0.8, max_treedepth=10, init=2.0, save_warmup=False, device=0,
-               chain_id_offset=0, show_messages=False, inits=None, devices=None):
+               chain_id_offset=0, show_messages=False, inits=None, devices=None, metric="diag_e", cus_per_chain=0):
         """`devices`: GPU ids; the chains are dealt to them in consecutive blocks and advance together under
         potus_run_many (one host thread).  Chain ids -- hence RNG streams and draws -- do not depend on the split."""
         from . import parallel
@@ -323,7 +384,7 @@ class PotusModel:
             h = Handle(data, self.variant, chains=n_loc, chain_id_offset=int(chain_id_offset) + off,
                        num_warmup=int(iter_warmup), num_samples=int(iter_sampling), max_depth=int(max_treedepth),
                        delta=float(adapt_delta), init_radius=float(init), seed=int(seed), device=dev,
-                       save_warmup=int(bool(save_warmup)))
+                       save_warmup=int(bool(save_warmup)), metric=_abi.METRICS[metric], cus_per_chain=int(cus_per_chain))
             h.init(None if inits is None else np.asarray(inits)[off:off + n_loc])
             hs.append(h)
         total = int(iter_warmup) + int(iter_sampling)
@@ -348,4 +409,5 @@ def sampling(model: PotusModel, data, chains=4, iter=2000, warmup=None, refresh=
     control = control or {}
     return model.sample(data, seed=seed, chains=chains, iter_warmup=warmup, iter_sampling=iter - warmup,
                         refresh=refresh if refresh is not None else max(iter // 10, 1),
-                        adapt_delta=control.get("adapt_delta", 0.8), max_treedepth=control.get("max_treedepth", 10), **kw)
+                        adapt_delta=control.get("adapt_delta", 0.8), max_treedepth=control.get("max_treedepth", 10),
+                        metric=control.get("metric", "diag_e"), **kw)
