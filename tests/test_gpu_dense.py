@@ -1,0 +1,162 @@
+"""Dense-metric NUTS (metric = dense_e: stan::mcmc::dense_e_metric + covar_adaptation, BASELINE configs[4]) on the
+device, potus_dense.hpp: its pieces against numpy, the sampler against the oracle's dense_e restatement
+(oracle_opts.dense_metric) and against its own saved draws."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle_lib import OracleModel
+from us_potus_model_amd import Handle, _abi, diagnostics as dg, sampler
+
+pytestmark = pytest.mark.gpu
+DP = C.POINTER(C.c_double)
+
+
+def _lib():
+    L = sampler.load_library()
+    L.potus_dense_matvec_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, DP]
+    L.potus_dense_factor_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, DP]
+    return L
+
+
+@pytest.mark.parametrize("chains,D,nrhs", [(3, 1000, 1), (2, 2049, 2), (1, 16500, 3), (2, 1027, 3), (1, 71, 2)])
+def test_dense_matvec_against_numpy(chains, D, nrhs):
+    """[y_r] = M^-1 [x_r] for up to three right-hand sides in one pass over the matrix (k_dn_matvec): partial row blocks,
+    several column tiles, odd D (padded rows); the fused x_0 . M^-1 x_0; reproducible bit for bit."""
+    L = _lib()
+    rng = np.random.default_rng(4)
+    B = rng.standard_normal((chains, D, 8))
+    M = np.einsum("cik,cjk->cij", B, B) / 8 + np.eye(D)[None]          # symmetric positive definite
+    x = rng.standard_normal((chains, nrhs, D))
+    out = []
+    for _ in range(2):
+        y, dot, ms = np.zeros((chains, nrhs, D)), np.zeros(chains), C.c_double()
+        assert L.potus_dense_matvec_probe(0, chains, D, nrhs, M.ctypes.data, x.ctypes.data, y.ctypes.data, dot.ctypes.data, 2, C.byref(ms)) == 0
+        out.append((y, dot))
+    ref = np.einsum("cij,crj->cri", M, x)
+    assert np.abs(out[0][0] - ref).max() <= 1e-12 * np.abs(ref).max() * np.sqrt(D)
+    assert np.allclose(out[0][1], np.einsum("ci,ci->c", x[:, 0], ref[:, 0]), rtol=1e-11)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("chains,D,n", [(2, 300, 40), (1, 1000, 25), (1, 2051, 150)])
+def test_dense_covariance_cholesky_and_solve_against_numpy(chains, D, n):
+    """The window-end pieces on caller data: M^-1 = n/(n+5) cov + 1e-3 5/(n+5) I (covar_adaptation::learn_covariance),
+    its blocked Cholesky factor, and the momentum draw's triangular solve p = L^-T u."""
+    import scipy.linalg as sl
+    L = _lib()
+    rng = np.random.default_rng(7)
+    draws = rng.standard_normal((chains, n, D)) * rng.uniform(0.2, 3.0, (1, 1, D)) + rng.standard_normal((chains, 1, D))
+    u = rng.standard_normal((chains, D))
+    Mi, Lc, p, ms = np.zeros((chains, D, D)), np.zeros((chains, D, D)), np.zeros((chains, D)), (C.c_double * 3)()
+    assert L.potus_dense_factor_probe(0, chains, D, n, draws.ctypes.data, u.ctypes.data, Mi.ctypes.data, Lc.ctypes.data, p.ctypes.data, ms) == 0
+    for c in range(chains):
+        ref = (n / (n + 5.0)) * np.cov(draws[c].T) + 1e-3 * (5.0 / (n + 5.0)) * np.eye(D)
+        assert np.allclose(Mi[c], ref, rtol=1e-10, atol=1e-12 * np.abs(ref).max())
+        assert np.array_equal(Mi[c], Mi[c].T)                                 # exactly symmetric
+        Lref = np.linalg.cholesky(Mi[c])
+        Lg = np.tril(Lc[c])
+        assert np.allclose(Lg, Lref, rtol=1e-8, atol=1e-10 * np.abs(Lref).max())
+        assert np.allclose(Lg @ Lg.T, Mi[c], rtol=1e-10, atol=1e-12 * np.abs(ref).max())
+        pref = sl.solve_triangular(Lg.T, u[c], lower=False)
+        assert np.allclose(p[c], pref, rtol=1e-8, atol=1e-9 * np.abs(pref).max())
+
+
+def _window_metric(draws_window):
+    n = draws_window.shape[0]
+    return (n / (n + 5.0)) * np.cov(draws_window.T) + 1e-3 * (5.0 / (n + 5.0)) * np.eye(draws_window.shape[1])
+
+
+@pytest.mark.parametrize("cus", [1, 8])
+def test_dense_sampler_follows_the_oracle_and_adapts_its_metric(cases, cus):
+    """30 warm-up iterations of the small model (windowed_adaptation rescales to init 4 / window 23 / term 3: the metric
+    is updated after iteration 27): the transitions before the update follow the oracle's dense_e chain (same Philox
+    streams; the unit metric makes M^-1 p exact), the adapted M^-1 is the regularised covariance of the very draws the
+    sampler saved for that window, and it agrees with the oracle's."""
+    data, variant = cases["small_full"]
+    nw = 30
+    h = Handle(data, variant, chains=2, num_warmup=nw, num_samples=0, save_warmup=1, seed=1843, metric=_abi.METRIC_DENSE, cus_per_chain=cus)
+    h.init(); h.run(17); h.run(13)
+    d = h.draws()
+    m = OracleModel(data, variant)
+    o = m.default_opts(num_warmup=nw, num_samples=0, save_warmup=1, seed=1843, fast_grad=1, dense_metric=1)
+    for c in (0, 1):
+        ref, ad, nl, Mref = m.sample_chain_metric(c + 1, o)
+        k = 12
+        assert np.array_equal(d[c][:k, 3:6], ref[:k, 3:6]), (c, d[c][:k, :7], ref[:k, :7])      # depth, n_leapfrog, divergent
+        assert np.allclose(d[c][:k, :3], ref[:k, :3], rtol=1e-6, atol=1e-9)
+        assert np.allclose(d[c][:k, 7:], ref[:k, 7:], rtol=1e-6, atol=1e-7)
+        Mi = h.dense_metric(c)
+        want = _window_metric(d[c][4:27, 7:])                # draws of iterations 4 .. 26 (0-based): the window
+        assert np.allclose(Mi, want, rtol=1e-9, atol=1e-12), np.abs(Mi - want).max()
+        assert np.array_equal(Mi, Mi.T) and np.linalg.eigvalsh(Mi).min() > 0
+        eps, diag = h.adaptation()
+        assert np.allclose(diag[c], np.diag(Mi)) and eps[c] > 0
+        if np.allclose(d[c][:27, 7:], ref[:27, 7:], rtol=1e-5, atol=1e-6):          # still in step with the oracle at the window's end
+            assert np.allclose(Mi, Mref, rtol=1e-3, atol=1e-6 * np.abs(Mref).max())
+            assert np.array_equal(d[c][27:, 3:6], ref[27:, 3:6]) and np.allclose(d[c][27:, 2], ref[27:, 2], rtol=1e-4)   # dense-metric transitions
+    assert np.isfinite(d).all()
+    ms, passes, nbytes, rounds = h.dense_timing()
+    assert passes > 0 and nbytes > 0 and rounds > 0 and ms > 0
+    h.close()
+
+
+def test_dense_sampler_is_reproducible_and_chunk_invariant(cases):
+    data, variant = cases["small_nomode"]
+    kw = dict(chains=3, num_warmup=40, num_samples=10, seed=7, metric=_abi.METRIC_DENSE)
+    a = Handle(data, variant, **kw); a.init(); a.run(50); da = a.draws(); a.close()
+    b = Handle(data, variant, **kw); b.init(); b.run(33); b.run(3); b.run(14); db = b.draws(); b.close()
+    assert np.array_equal(da, db)
+    c = Handle(data, variant, **{**kw, "chains": 1, "chain_id_offset": 2}); c.init(); c.run(50); dc = c.draws(); c.close()
+    assert np.array_equal(da[2], dc[0])
+
+
+def test_dense_posterior_parity_small(cases):
+    """Statistical parity with the oracle's dense_e sampler: pooled means of every unconstrained coordinate within
+    5 combined MCSE; the adapted sampler accepts at the target rate."""
+    from us_potus_model_amd import synthetic
+    # (D = 117 < the 200 draws of the last adaptation window: with fewer draws than dimensions the regularised covariance
+    #  is so ill-conditioned that every transition runs to the maximum tree depth -- in Stan as here)
+    variant = "full"
+    data = synthetic.make(S=4, T=12, N_state=30, N_national=8, P=3, seed=3, variant=variant)
+    nw = ns = 400
+    h = Handle(data, variant, chains=4, num_warmup=nw, num_samples=ns, seed=1843, metric=_abi.METRIC_DENSE)
+    h.init(); h.run(nw + ns)
+    d = h.draws()
+    x = d[:, :, 7:]
+    st, _ = h.chain_status()
+    assert st == [0, 0, 0, 0] and d[:, :, 5].mean() < 0.02
+    assert 0.6 < d[:, :, 1].mean() < 0.97                              # accept_stat__ around delta = 0.8
+    m = OracleModel(data, variant)
+    o = m.default_opts(num_warmup=nw, num_samples=ns, seed=4242, fast_grad=1, dense_metric=1)
+    y = np.stack([m.sample_chain(c, o)[0][:, 7:] for c in (1, 2, 3, 4)])
+    worst = 0.0
+    for j in range(h.D):
+        a, b = x[:, :, j], y[:, :, j]
+        se = np.hypot(a.std() / np.sqrt(dg.ess_mean(a)), b.std() / np.sqrt(dg.ess_mean(b)))
+        worst = max(worst, abs(a.mean() - b.mean()) / se)
+        assert dg.rhat(a) < 1.08
+    assert worst < 5.0, worst
+    h.close()
+
+
+@pytest.mark.parametrize("cus", [0, 1])
+def test_dense_sampler_on_the_2016_posterior(cases, cus):
+    """D = 15 098: 1.8 GB of inverse metric per chain.  40 warm-up iterations cross one window end (covariance of 30
+    draws, 236-block Cholesky, init_stepsize); the metric equals the regularised covariance of the saved window draws."""
+    data, variant = cases["2016"]
+    nw = 40
+    h = Handle(data, variant, chains=2, num_warmup=nw, num_samples=0, save_warmup=1, seed=1843, metric=_abi.METRIC_DENSE, cus_per_chain=cus)
+    assert h.cus_per_chain == (16 if cus == 0 else 1)            # the gradient of a round: the cluster pass or one workgroup per chain
+    h.init(); h.run(nw)
+    d = h.draws()
+    assert np.isfinite(d).all() and (d[:, :, 4] >= 1).all()
+    ib, bw = int(0.15 * nw), nw - int(0.15 * nw) - int(0.1 * nw)
+    Mi = h.dense_metric(1)
+    want = _window_metric(d[1][ib:ib + bw, 7:])
+    assert np.allclose(Mi, want, rtol=1e-9, atol=1e-12), np.abs(Mi - want).max()
+    ms, passes, nbytes, rounds = h.dense_timing()
+    print(f"2016 dense (cus_per_chain {h.cus_per_chain}): {passes} matrix passes, {nbytes / 1e9:.1f} GB in {ms:.1f} ms = {nbytes / ms / 1e9 * 1e3 / 1e3:.2f} TB/s; {rounds} leaf rounds")
+    assert d[:, -3:, 1].mean() > 0.3                                   # transitions under the adapted metric accept
+    h.close()

@@ -112,6 +112,29 @@ def test_stress_shape_log_prob_grad_and_first_transitions():
     h.close()
 
 
+def test_stress_shape_sixteen_chains_on_one_gpu():
+    """BASELINE configs[4] asks for 16 chains per GPU at 51 states x 600 days x 10 000 polls: 16 clusters of 16 compute
+    units (the members keep the two 51 x 51 factors as packed triangles, the poll counts as int32 pairs and the AR(1)
+    tangents of their own days only, which is what makes 600 days / 706 polls per member fit 160 KB of LDS).  First
+    and last chain against the oracle; the rate of the run is printed."""
+    from us_potus_model_amd import synthetic
+    data = synthetic.stress()
+    iters = 3
+    h = Handle(data, "full", chains=16, num_warmup=iters, num_samples=0, save_warmup=1, seed=5)
+    assert h.cus_per_chain == 16 and h.D == 41610
+    h.init(); h.run(iters)
+    d = h.draws()
+    ms, lf = h.last_run_timing()
+    print(f"stress shape, 16 chains x 16 CUs: {lf} leapfrogs in {ms:.1f} ms = {lf / ms * 1e3:.0f} leapfrogs/s, {ms * 1e3 * 16 / lf:.1f} us per leapfrog per chain")
+    m = OracleModel(data, "full")
+    o = m.default_opts(num_warmup=iters, num_samples=0, save_warmup=1, seed=5, fast_grad=1)
+    for c in (0, 15):
+        ref = m.sample_chain(c + 1, o)[0]
+        assert np.array_equal(d[c][:, 3:6], ref[:, 3:6]), (c, d[c][:, :7], ref[:, :7])
+        assert np.allclose(d[c][:, 7:], ref[:, 7:], rtol=1e-6, atol=1e-7)
+    h.close()
+
+
 @pytest.mark.parametrize("cus", [1, 16])
 def test_log_prob_grad_is_deterministic_and_batched(cases, cus):
     data, variant = cases["2016"]
@@ -393,41 +416,3 @@ def test_posterior_summary_matches_numpy_restatement(cases, name):
         assert np.allclose(got[k], ref[k], rtol=1e-12, atol=1e-12), (k, np.abs(got[k] - ref[k]).max())
     assert np.array_equal(got["state"][..., 3], ref["state"][..., 3])
     h.close()
-
-
-@pytest.mark.gpu
-def test_dense_metric_matvec_building_block():
-    """y = M^-1 p for a batch of chains (potus_dense.hpp, the HBM-bound operation of the dense metric; not yet part of
-    the sampler): against numpy at sizes that exercise partial row blocks and several column tiles, and reproducible."""
-    import ctypes as C
-    L = sampler.load_library()
-    L.potus_dense_matvec_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
-    rng = np.random.default_rng(4)
-    for chains, D in ((3, 1000), (2, 2049), (1, 16500)):
-        B = rng.standard_normal((chains, D, 8))
-        M = np.einsum("cik,cjk->cij", B, B) / 8 + np.eye(D)[None]          # symmetric positive definite
-        p = rng.standard_normal((chains, D))
-        y1, y2, ms = np.zeros((chains, D)), np.zeros((chains, D)), C.c_double()
-        for y in (y1, y2):
-            rc = L.potus_dense_matvec_probe(0, chains, D, M.ctypes.data, p.ctypes.data, y.ctypes.data, 2, C.byref(ms))
-            assert rc == 0
-        ref = np.einsum("cij,cj->ci", M, p)
-        assert np.abs(y1 - ref).max() <= 1e-12 * np.abs(ref).max() * np.sqrt(D)
-        assert np.array_equal(y1, y2)
-
-
-@pytest.mark.gpu
-def test_dense_metric_welford_building_block():
-    """welford_covar_estimator::add_sample for a batch of chains (k_dense_welford): m2 += a delta', against numpy."""
-    import ctypes as C
-    L = sampler.load_library()
-    L.potus_dense_welford_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
-    rng = np.random.default_rng(6)
-    for chains, D in ((3, 1000), (2, 2051)):
-        a, d = rng.standard_normal((chains, D)), rng.standard_normal((chains, D))
-        M2, ms = np.zeros((chains, D, D)), C.c_double()
-        assert L.potus_dense_welford_probe(0, chains, D, a.ctypes.data, d.ctypes.data, M2.ctypes.data, 3, C.byref(ms)) == 0
-        ref = np.zeros((chains, D, D))
-        for _ in range(3):
-            ref = ref + a[:, :, None] * d[:, None, :]
-        assert np.allclose(M2, ref, rtol=1e-14, atol=1e-14)       # the device fuses the multiply-add

@@ -199,3 +199,37 @@ def test_oracle_chains_are_independent_streams(cases):
     a, b = m.sample_chain(1, o)[0], m.sample_chain(2, o)[0]
     a2 = m.sample_chain(1, o)[0]
     assert np.array_equal(a, a2) and not np.allclose(a[:, 7:], b[:, 7:])
+
+
+@pytest.mark.parametrize("year", ["2008", "2012", "2016"])
+def test_oracle_posterior_against_everything_the_reference_published(year):
+    """The oracle's pin to the reference: the only outputs of this path the reference publishes are the README tables
+    (election-day predicted_score of 51 states + the nation, README.md:83-136 / 179-232 / 279-332) and the Brier
+    scores (README.md:75,169,260) -- tests/golden/readme_<year>.csv, made by scripts/make_readme_golden.py.  The
+    committed oracle run of the same configuration (8 chains x 1000 + 1000, seed 1843; tests/golden/posterior_<year>.npz,
+    made by scripts/make_golden.py posterior) reproduces all 3 x 52 rows to the third decimal the tables are rounded to
+    (observed worst: mean 0.0019, interval ends 0.0043, P(win) 0.031) and the three scores."""
+    import csv
+    from us_potus_model_amd import dataprep
+    g = np.load(GOLD / f"posterior_{year}.npz")
+    meta = dataprep.load_npz(GOLD / f"data_{year}.npz")["meta"]
+    lines = open(GOLD / f"readme_{year}.csv").read().splitlines()
+    pub = {ln[2:].split(" = ")[0]: float(ln.split(" = ")[1]) for ln in lines if ln.startswith("# ") and " = " in ln}
+    rows = list(csv.DictReader(ln for ln in lines if not ln.startswith("#")))
+    assert len(rows) == 52
+    states = list(meta["states"])
+    for r in rows:
+        if r["state"] == "--":
+            got = (g["national__mean"], g["national__q025"], g["national__q975"], g["national__p_win"])
+        else:
+            i = states.index(r["state"])
+            got = (g["predicted_score_T__mean"][i], g["predicted_score_T__q025"][i], g["predicted_score_T__q975"][i], g["predicted_score_T__p_win"][i])
+        assert abs(got[0] - float(r["mean"])) <= 0.004, (year, r, got)
+        assert abs(got[1] - float(r["low"])) <= 0.007 and abs(got[2] - float(r["high"])) <= 0.007, (year, r, got)
+        assert abs(got[3] - float(r["prob"])) <= 0.045, (year, r, got)
+    ev = np.asarray(meta["ev_state"], dtype=float)
+    p = g["predicted_score_T__p_win"]
+    won = np.array([int(next(r for r in rows if r["state"] == s)["won_readme"]) for s in states])
+    assert abs(np.sum(ev / ev.sum() * (won - p) ** 2) - pub["ev_wtd_brier"]) <= 0.003
+    assert abs(np.mean((won - p) ** 2) - pub["unwtd_brier"]) <= 0.002
+    assert int(np.sum(np.round(p) == won)) == int(pub["states_correct"])

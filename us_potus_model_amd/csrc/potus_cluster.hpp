@@ -497,13 +497,13 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
   gcdp src = as_g(M->mat);
   for (int i = threadIdx.x; i < (M->SE + 1) * M->SP; i += PT_THREADS) Lw[i] = i < M->SE * M->SP ? src[i] : 0.0;   // + a zero row
   {
-    // the two 51 x 51 factors of stan:77,85, row-major with the odd row stride SP
+    // the two 51 x 51 factors of stan:77,85: lower triangles packed row by row (row r starts at r (r + 1) / 2) -- half the
+    // LDS of the square form, which is what lets 16 members hold the 600-day / 10 000-poll shape
     ldp LT = lds + CL->l_LT, LB = lds + CL->l_LB;
-    const int S = M->S, SP = M->SP;
+    const int S = M->S;
     for (int i = threadIdx.x; i < S * S; i += PT_THREADS) {
       const int r = i / S, k = i - r * S;
-      LT[r * SP + k] = src[M->m_LT + i];
-      LB[r * SP + k] = src[M->m_LB + i];
+      if (k <= r) { LT[r * (r + 1) / 2 + k] = src[M->m_LT + i]; LB[r * (r + 1) / 2 + k] = src[M->m_LB + i]; }
     }
     for (int i = threadIdx.x; i < S; i += PT_THREADS) { (lds + CL->l_w)[i] = src[M->m_w + i]; (lds + CL->l_prior)[i] = src[M->m_prior + i]; }
   }
@@ -512,9 +512,11 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
   const int np = part[CP_NP];
   for (int i = threadIdx.x; i < np + 8; i += PT_THREADS) st[i] = i < np ? (unsigned char)ps[i] : (unsigned char)0;
   {
-    // per-poll constants: {state, local day, pollster, mode, population} packed in 64 bits; y, N, unadjusted flag
+    // per-poll constants: {state, local day, pollster, mode, population} packed in 64 bits; the two counts {y, N}
+    // (int32 in the Stan data block) in another 64; the unadjusted flag
     unsigned long long AS_L *pm = (unsigned long long AS_L *)(lds + CL->l_pm);
-    ldp py = lds + CL->l_py, pN = lds + CL->l_pN, pun = lds + CL->l_pun;
+    unsigned long long AS_L *pyn = (unsigned long long AS_L *)(lds + CL->l_py);
+    ldp pun = lds + CL->l_pun;
     const int Npad = M->Npad, p0 = part[CP_P0], d0 = part[CP_D0], full = M->full;
     gcip pi = as_g(M->pi);
     gcdp pd = as_g(M->pd);
@@ -528,7 +530,7 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
         if (full) v |= ((unsigned long long)(unsigned)pi[3 * Npad + g] << 32) | ((unsigned long long)(unsigned)pi[4 * Npad + g] << 40);
         y = pd[g]; N = pd[Npad + g]; un = full ? pd[2 * Npad + g] : 0.0;
       }
-      pm[i] = v; py[i] = y; pN[i] = N; pun[i] = un;
+      pm[i] = v; pyn[i] = (unsigned long long)(unsigned)(int)y | ((unsigned long long)(unsigned)(int)N << 32); pun[i] = un;
     }
     // gather program: per poll (day order) state | local day << 8 | flags << 16
     unsigned AS_L *tab = (unsigned AS_L *)(lds + CL->l_tab);
@@ -693,14 +695,15 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     ldp LT = lds + CL->l_LT, LB = lds + CL->l_LB;
     constexpr int NJ = 11;                        // 6 waves x 11 columns >= 63
     double lt[NJ], lb[NJ], zt[NJ], zb[NJ];
-    const int ls = lane < S ? lane : 0;
+    const int ls = lane < S ? lane : 0, tri = ls * (ls + 1) / 2;
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-      const int k = wj + 6 * j, kc = k < S ? k : 0;
-      lt[j] = LT[ls * SP + kc];                   // L_T[lane][k], stan:85
-      lb[j] = LB[ls * SP + kc];                   // L_B[lane][k], stan:77
-      zt[j] = k < S ? s_zT[kc] : 0.0;
-      zb[j] = k < S ? s_zb[kc] : 0.0;
+      const int k = wj + 6 * j, kc = min(k, ls);   // packed lower triangle: (row ls, column k) is stored for k <= ls
+      const bool in = k <= ls;                     // (hence k < S)
+      lt[j] = LT[tri + kc];                        // L_T[lane][k], stan:85
+      lb[j] = LB[tri + kc];                        // L_B[lane][k], stan:77
+      zt[j] = in ? s_zT[kc] : 0.0;
+      zb[j] = in ? s_zb[kc] : 0.0;
     }
     ISSUE_FENCE();
     double pT = 0.0, pB = 0.0;
@@ -776,7 +779,8 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     const int om = M->o_m - o_c, opop = M->o_pop - o_c;
     const double sigma_c = M->sigma_c, sigma_m = M->sigma_m, sigma_pop = M->sigma_pop, sigma_ns = M->sigma_ns, sigma_nn = M->sigma_nn;
     const unsigned long long AS_L *pm = (const unsigned long long AS_L *)(lds + CL->l_pm);
-    ldp py = lds + CL->l_py, pN = lds + CL->l_pN, pun = lds + CL->l_pun;
+    const unsigned long long AS_L *pyn = (const unsigned long long AS_L *)(lds + CL->l_py);
+    ldp pun = lds + CL->l_pun;
     if (full && w == PT_NW - 1) {
       // the three tangent recurrences of the AR(1) bias (needed in phase E2 only) run here, on the wave that
       // has no polls unless the member has more than 448 of them, instead of lengthening phase B
@@ -808,7 +812,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
           const bool first = t == 0, in = t < T;
           const double n1 = first ? 0.0 : rho * c1 + 1.0, n2 = first ? 0.0 : rho * c2 + dp[u], n3 = first ? 0.0 : rho * c3 + z[u];
           c1 = in ? n1 : c1; c2 = in ? n2 : c2; c3 = in ? n3 : c3;
-          if (in) { s_c1[t] = c1; s_c2[t] = c2; s_c3[t] = c3; }
+          if (in && t >= d0 && t < d0 + nd) { s_c1[t - d0] = c1; s_c2[t - d0] = c2; s_c3[t - d0] = c3; }   // only the member's own days are read (phase E2)
         }
         c1_in = dpp_readlane_d(c1, 63); c2_in = dpp_readlane_d(c2, 63); c3_in = dpp_readlane_d(c3, 63);
       }
@@ -847,7 +851,8 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         const unsigned long long meta = pm[ic];          // memory operation inside the branch
         const int s = (int)(meta & 0xffu), tl = (int)((meta >> 8) & 0xffu), ip = (int)((meta >> 16) & 0xffffu);
         const int im = (int)((meta >> 32) & 0xffu), ipop = (int)((meta >> 40) & 0xffu);
-        const double y = py[ic], N = pN[ic], un = pun[ic];
+        const unsigned long long yn = pyn[ic];
+        const double y = (double)(int)(unsigned)yn, N = (double)(int)(unsigned)(yn >> 32), un = pun[ic];
         const int t = d0 + tl;
         ldp L0 = Lw + s * SP, C0 = C + tl;
         double a0 = 0.0, a1 = 0.0;
@@ -1022,8 +1027,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       arA = in ? rho : 1.0;
       dpp_scan_affine(arA, Bv);
       arB = Bv[0];                                  // a[t] = arB + arA * a[first day of the next member]
-      const int t = d0 + tl;
-      const double S1 = dpp_scan_sum(ge * s_c1[t]), S2 = dpp_scan_sum(ge * s_c2[t]), S3 = dpp_scan_sum(ge * s_c3[t]);
+      const double S1 = dpp_scan_sum(ge * s_c1[tl]), S2 = dpp_scan_sum(ge * s_c2[tl]), S3 = dpp_scan_sum(ge * s_c3[tl]);
       // lane 63 holds the member's composite and the three sums
       const double pv0 = dpp_readlane_d(arA, 63), pv1 = dpp_readlane_d(arB, 63);
       const double pv2 = dpp_readlane_d(S1, 63), pv3 = dpp_readlane_d(S2, 63), pv4 = dpp_readlane_d(S3, 63);
@@ -1042,8 +1046,9 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
       const int s = wj + 6 * j, sc = s < S ? s : 0;
-      lt[j] = LT[sc * SP + lk]; lb[j] = LB[sc * SP + lk];
-      gg[j] = s < S ? s_gs[sc] + s_w[sc] * gnat : 0.0;
+      const int at = sc * (sc + 1) / 2 + min(lk, sc);                // (row s, column lane) of the packed lower triangle
+      lt[j] = LT[at]; lb[j] = LB[at];
+      gg[j] = (s < S && lk <= sc) ? s_gs[sc] + s_w[sc] * gnat : 0.0;
     }
     ISSUE_FENCE();
 #pragma unroll

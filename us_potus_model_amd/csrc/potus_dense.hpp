@@ -1,94 +1,751 @@
-// potus_dense.hpp -- first building block of the dense metric (stan::mcmc::dense_e_metric, BASELINE configs[4]):
-// y = M^-1 p for a batch of chains, each with its own D x D inverse metric (row-major, symmetric, in HBM).
+// potus_dense.hpp -- NUTS with a DENSE metric (stan::mcmc::dense_e_metric + covar_adaptation, `metric = dense_e`,
+// BASELINE configs[4]) on gfx950.
 //
-// This is the one operation of the path that is bound by HBM bandwidth: 8 D^2 bytes per chain and leapfrog (position
-// update, kinetic energy and the p-sharp vectors of the U-turn checks all need M^-1 p).  Not wired into the sampler
-// yet; exported as a development entry point (potus_dense_matvec_probe, not part of include/potus_hmc.h) so that its
-// results and its rate can be checked on their own.
+// With a dense metric every leapfrog needs M^-1 times a momentum: 8 D^2 bytes of matrix per chain and leapfrog (1.8 GB
+// for the 2016 posterior, 13.9 GB at D = 41 610) against 0.85 MB for everything else -- the one part of this path that
+// is bound by HBM bandwidth, and work for the WHOLE chip rather than for the 16 compute units of a chain's cluster.
+// So the dense sampler is not a persistent kernel per chain: it is a sequence of chip-wide launches per leaf,
 //
-// Layout of the work: one workgroup = 64 consecutive rows of one chain (8 waves x 8 rows); a wave streams a row with
-// all 64 lanes (512 contiguous bytes per load instruction, eight loads in flight per lane), p sits in LDS in column
-// tiles of 16 384 doubles (128 KB) so that D = 41 610 needs three tiles.  Sums run in a fixed order (per lane over the
-// columns, DPP across the lanes): same bytes every time.  The full matrix is read although it is symmetric: using
-// a_ij for both y_i and y_j needs cross-workgroup accumulation (atomics or a second pass) and would halve the traffic
-// -- left for when the kernel is part of the sampler.
+//     gradient at the leaf's position  ->  kick (pf = ph + he g, ph' = pf + he g)  ->
+//     k_dn_matvec<2>:  p# = M^-1 pf  and  q' = q + e M^-1 ph'  in ONE pass over the matrix  ->
+//     k_dn_step: the tree logic of base_nuts (one workgroup per chain, state kept in global memory between launches)
+//
+// with all chains of the handle advancing leaf by leaf together; a chain whose transition has ended sits out (its
+// workgroups return at once: the launches are bound by the matrices they stream, so idle chains cost nothing).  The
+// host only counts: it reads one flag per chain after each round to know when the transition is over for everybody.
+// The position update of the NEXT leapfrog of the same trajectory end uses the same signed step, so its half-kicked
+// momentum ph' is known as soon as this leaf's gradient is (the pre-kicked leapfrog of potus_nuts.hpp): both products
+// of a leaf share one read of the matrix, and the arithmetic per leaf is exactly Stan's expl_leapfrog + dtau_dp.
+//
+// Adaptation (covar_adaptation): Stan streams a Welford covariance update per warm-up draw (16 D^2 bytes each).  Here
+// the draws of a window are kept (n x D doubles, n <= 500) and the covariance is formed once at the window's end:
+// the mean by Welford's own recurrence, the sum of outer products as a tiled rank-n update written straight into the
+// inverse metric -- algebraically Welford's m2, no D^2 accumulator at all.  Then an in-place blocked Cholesky
+// factorisation (the momentum draw p = L^-T u needs it), and base_hmc::init_stepsize.
+//
+// Layout: per chain a block of DV_COUNT vectors of LD doubles (Stan's parameter order); M^-1 and its Cholesky factor
+// row-major D x LD with LD = D rounded up to 8 doubles (rows start on 64-byte lines).
 #pragma once
 #include "potus_dpp.hpp"
+#include "potus_nuts.hpp"
 
-#define PD_THREADS 512
-#define PD_ROWS_PER_WAVE 8
-#define PD_ROWS (PD_ROWS_PER_WAVE * (PD_THREADS / 64))
-#define PD_TILE 16384
-#define PD_UNR 8
+#define DN_THREADS 512
+#define DN_ROWS_PER_WAVE 8
+#define DN_ROWS (DN_ROWS_PER_WAVE * (DN_THREADS / 64))   // rows of the matrix per workgroup
+#define DN_LDS_DOUBLES 16384                              // LDS for the right-hand sides: 128 KB
+#define DN_NB 64                                          // block size of the factorisation / triangular solve
+typedef double dn_d2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(PD_THREADS) void k_dense_matvec(const double *__restrict__ Minv /*[chains][D][D]*/,
-                                                             const double *__restrict__ p /*[chains][D]*/,
-                                                             double *__restrict__ y /*[chains][D]*/, int D) {
-  extern __shared__ __attribute__((aligned(16))) double pd_lds[];   // PD_TILE doubles
-  const int chain = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int row0 = blockIdx.x * PD_ROWS + w * PD_ROWS_PER_WAVE;
-  const double *A = Minv + (size_t)chain * D * D;
-  const double *pc = p + (size_t)chain * D;
-  double acc[PD_ROWS_PER_WAVE];
+// vector slots of a chain's dense state block
+enum {
+  DV_QC = 0, DV_GC, DV_G, DV_P0, DV_PH0, DV_PH1, DV_PF0, DV_PF1, DV_PSF0, DV_PSF1, DV_PNEAR, DV_PSNEAR,
+  DV_RHOTOP, DV_SCR0, DV_SCR1, DV_TMPQ, DV_TMPP, DV_MEAN,
+  DV_RHOLEV,                                /* PT_MAXD + 1 */
+  DV_POOLP = DV_RHOLEV + PT_MAXD + 1,      /* leaf momenta */
+  DV_POOLPS = DV_POOLP + PT_NPP,           /* their M^-1 p */
+  DV_POOLQ = DV_POOLPS + PT_NPP,           /* trajectory positions / proposals */
+  DV_COUNT = DV_POOLQ + PT_NPQ
+};
+
+// one right-hand side of a k_dn_matvec launch, per chain (slots are absolute slot numbers, -1 = not used)
+struct DnJob {
+  int x;            // right-hand side
+  int y;            // receives M^-1 x
+  int qin, qout;    // qout = qin + coef * M^-1 x
+  int dot;          // partial sums of dot . (M^-1 x) go to DnParams::partial (job 0 only)
+  int pad;
+  double coef;
+};
+// what the launches of one round do for a chain; written by k_dn_step / k_dn_eps_* of the previous round
+struct DnRound {
+  int active;       // 0: the chain sits this round out
+  int qin;          // position the gradient is evaluated at
+  int gout;         // slot receiving the gradient
+  int ph;           // half-kicked momentum updated by the kick
+  int leaf;         // slot receiving the full-step momentum
+  int aux;          // RNG aux word of the next momentum draw (init_stepsize attempt)
+  double he;        // signed half step
+  DnJob job[3];
+};
+
+struct DnParams {
+  int chains, D, LD, npart;          // npart = row blocks of the matvec = partial sums per chain
+  int sc_stride, pad0;               // the chain scalars of chain c are RunParams::scal[c * sc_stride] (cluster mode keeps K replicas)
+  double *state;                     // [chains][DV_COUNT][LD]
+  double *Minv, *Lc;                 // [chains][D][LD]
+  double *win;                       // [chains][win_cap][LD] draws of the current adaptation window
+  int win_cap, identity;             // identity: the metric is still the unit matrix (before the first window ends)
+  double *partial;                   // [chains][npart]
+  double *lpbuf;                     // [chains]
+  TS *ts;                            // [chains] transition state
+  DnRound *rd;                       // [chains]
+  int *active;                       // [chains] copy of rd[].active for the host
+  int *fail;                         // [1] Cholesky met a non-positive pivot
+};
+
+__device__ __forceinline__ double *dn_vec(const DnParams &P, int chain, int slot) { return P.state + ((size_t)chain * DV_COUNT + slot) * (size_t)P.LD; }
+
+// ---------------------------------------------------------------- M^-1 x for up to three right-hand sides
+// One workgroup = DN_ROWS consecutive rows of one chain (8 waves x 8 rows); a wave streams a row with all 64 lanes,
+// 16 bytes per lane and eight loads in flight (8 KB per wave); the right-hand sides sit in LDS in column tiles.  Every
+// matrix element is loaded once and used NRHS times.  Sums in a fixed order: same bytes every time.
+template <int NRHS>
+__global__ __launch_bounds__(DN_THREADS) void k_dn_matvec(const DnParams P) {
+  extern __shared__ __attribute__((aligned(16))) double dn_lds[];
+  __shared__ double dn_part[DN_THREADS / 64];
+  const int chain = blockIdx.y;
+  const DnRound &rd = P.rd[chain];
+  if (!rd.active) return;
+  constexpr int TILE = (DN_LDS_DOUBLES / NRHS) & ~1023;   // columns per tile (multiple of 64 lanes x 2 x 8 loads)
+  constexpr int UNR = 8;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = P.D, LD = P.LD;
+  const int row0 = blockIdx.x * DN_ROWS + w * DN_ROWS_PER_WAVE;
+  const double *A = P.Minv + (size_t)chain * (size_t)D * (size_t)LD;
+  const double *x[NRHS];
 #pragma unroll
-  for (int r = 0; r < PD_ROWS_PER_WAVE; r++) acc[r] = 0.0;
-  for (int t0 = 0; t0 < D; t0 += PD_TILE) {
-    const int tl = min(PD_TILE, D - t0);
+  for (int r = 0; r < NRHS; r++) x[r] = dn_vec(P, chain, rd.job[r].x);
+  double acc[DN_ROWS_PER_WAVE][NRHS];
+#pragma unroll
+  for (int i = 0; i < DN_ROWS_PER_WAVE; i++)
+#pragma unroll
+    for (int r = 0; r < NRHS; r++) acc[i][r] = 0.0;
+  for (int t0 = 0; t0 < D; t0 += TILE) {
+    const int tl = min(TILE, D - t0), tl2 = (tl + 1) & ~1;
     __syncthreads();
-    for (int j = tid; j < tl; j += PD_THREADS) pd_lds[j] = pc[t0 + j];
+#pragma unroll
+    for (int r = 0; r < NRHS; r++)
+      for (int j = tid; j < tl2; j += DN_THREADS) dn_lds[r * TILE + j] = j < tl ? x[r][t0 + j] : 0.0;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < PD_ROWS_PER_WAVE; r++) {
-      const int row = row0 + r;
-      if (row >= D) break;                         // wave-uniform
-      const double *Ar = A + (size_t)row * D + t0;
-      double s = 0.0;
-      int j = lane;
-      for (; j + 64 * (PD_UNR - 1) < tl; j += 64 * PD_UNR) {
-        double a[PD_UNR];
+    for (int i = 0; i < DN_ROWS_PER_WAVE; i++) {
+      const int row = row0 + i;
+      if (row >= D) break;                                   // wave-uniform
+      const dn_d2 *Ar = (const dn_d2 *)(A + (size_t)row * LD + t0);   // 16-byte aligned: LD and TILE are even
+      double s[NRHS];
 #pragma unroll
-        for (int u = 0; u < PD_UNR; u++) a[u] = __builtin_nontemporal_load(Ar + j + 64 * u);
+      for (int r = 0; r < NRHS; r++) s[r] = 0.0;
+      const int np = tl2 >> 1;                               // pairs in this tile (the padding pair element is x = 0;
+      int j = lane;                                          //  the matrix row is padded to LD >= D + (D & 1))
+      for (; j + 64 * (UNR - 1) < np; j += 64 * UNR) {
+        dn_d2 a[UNR];
 #pragma unroll
-        for (int u = 0; u < PD_UNR; u++) s += a[u] * pd_lds[j + 64 * u];
+        for (int u = 0; u < UNR; u++) a[u] = __builtin_nontemporal_load(Ar + j + 64 * u);
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+#pragma unroll
+          for (int r = 0; r < NRHS; r++) {
+            const dn_d2 xv = *(const dn_d2 *)(dn_lds + r * TILE + 2 * (j + 64 * u));
+            s[r] += a[u][0] * xv[0] + a[u][1] * xv[1];
+          }
+        }
       }
-      for (; j < tl; j += 64) s += __builtin_nontemporal_load(Ar + j) * pd_lds[j];
-      acc[r] += s;
+      for (; j < np; j += 64) {
+        const dn_d2 a = __builtin_nontemporal_load(Ar + j);
+#pragma unroll
+        for (int r = 0; r < NRHS; r++) {
+          const dn_d2 xv = *(const dn_d2 *)(dn_lds + r * TILE + 2 * j);
+          s[r] += a[0] * xv[0] + a[1] * xv[1];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NRHS; r++) acc[i][r] += s[r];
     }
   }
+  // epilogue: row totals (DPP), stores, the position update and the partial sum of dot . (M^-1 x)
+  double dsum = 0.0;
 #pragma unroll
-  for (int r = 0; r < PD_ROWS_PER_WAVE; r++) {
-    const double tot = dpp_wave_sum(acc[r]);
-    const int row = row0 + r;
-    if (lane == 0 && row < D) y[(size_t)chain * D + row] = tot;
+  for (int i = 0; i < DN_ROWS_PER_WAVE; i++) {
+    const int row = row0 + i;
+#pragma unroll
+    for (int r = 0; r < NRHS; r++) {
+      const double tot = dpp_wave_sum(acc[i][r]);
+      if (lane == 0 && row < D) {
+        const DnJob &jb = rd.job[r];
+        if (jb.y >= 0) dn_vec(P, chain, jb.y)[row] = tot;
+        if (jb.qout >= 0) dn_vec(P, chain, jb.qout)[row] = dn_vec(P, chain, jb.qin)[row] + jb.coef * tot;
+        if (r == 0 && jb.dot >= 0) dsum += dn_vec(P, chain, jb.dot)[row] * tot;
+      }
+    }
+  }
+  if (lane == 0) dn_part[w] = dsum;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < DN_THREADS / 64; i++) t += dn_part[i];
+    P.partial[(size_t)chain * P.npart + blockIdx.x] = t;
   }
 }
 
-// welford_covar_estimator::add_sample for a batch of chains: m2 += (q - mean_new) delta', delta = q - mean_old (both
-// D-vectors prepared by the caller: a = q - mean_new, delta).  16 D^2 bytes per chain and warm-up iteration inside the
-// adaptation windows; one workgroup per 8 rows, a thread keeps its column of delta in a register across the rows.
-__global__ __launch_bounds__(256) void k_dense_welford(double *__restrict__ M2 /*[chains][D][D]*/, const double *__restrict__ a /*[chains][D]*/,
-                                                       const double *__restrict__ delta /*[chains][D]*/, int D) {
-  const int chain = blockIdx.y, row0 = blockIdx.x * 8;
-  double *M = M2 + (size_t)chain * D * D;
-  const double *ac = a + (size_t)chain * D, *dc = delta + (size_t)chain * D;
-  double ar[8];
-#pragma unroll
-  for (int r = 0; r < 8; r++) ar[r] = row0 + r < D ? ac[row0 + r] : 0.0;
-  for (int j = threadIdx.x; j < D; j += 256) {
-    const double dj = dc[j];
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-      if (row0 + r < D) { double *e = M + (size_t)(row0 + r) * D + j; *e = *e + ar[r] * dj; }
+// ---------------------------------------------------------------- elementwise pieces of a round
+// pf = ph + he g -> leaf slot; ph' = pf + he g -> ph   (end_update_p of this leaf merged with begin_update_p of the next)
+__global__ __launch_bounds__(256) void k_dn_kick(const DnParams P) {
+  const int chain = blockIdx.y;
+  const DnRound &rd = P.rd[chain];
+  if (!rd.active) return;
+  const double *g = dn_vec(P, chain, rd.gout);
+  double *ph = dn_vec(P, chain, rd.ph), *leaf = dn_vec(P, chain, rd.leaf);
+  const double he = rd.he;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < P.D; i += gridDim.x * 256) {
+    const double pf = ph[i] + he * g[i];
+    leaf[i] = pf;
+    ph[i] = pf + he * g[i];
   }
 }
 
-// fills a symmetric positive definite test matrix on the device: A[i][j] = exp(-|i-j|/50) * (1 + 0.1 c) + (i == j ? 1 : 0)
-__global__ void k_dense_fill(double *Minv, int D, int chains) {
-  const size_t n = (size_t)D * D;
-  for (int c = 0; c < chains; c++)
+// standard normals for a momentum draw, element i = normal (i & 1) of Philox block i >> 1 (the contract shared with
+// the oracle and the diagonal samplers); the triangular solve that follows turns them into p ~ N(0, M)
+__global__ __launch_bounds__(256) void k_dn_normals(const DnParams P, const RunParams *Rg, unsigned iter, unsigned purpose) {
+  const int chain = blockIdx.y;
+  const DnRound &rd = P.rd[chain];
+  if (!rd.active) return;
+  const RngKey key{Rg->seed_lo, Rg->seed_hi, (uint32_t)(Rg->chain_id_offset + chain + 1)};
+  double *p = dn_vec(P, chain, DV_P0);
+  for (int j = blockIdx.x * 256 + threadIdx.x; 2 * j < P.D; j += gridDim.x * 256) {
+    double a, b;
+    rng_normal_pair(key, iter, purpose, (uint32_t)rd.aux, (uint32_t)j, a, b);
+    p[2 * j] = a;
+    if (2 * j + 1 < P.D) p[2 * j + 1] = b;
+  }
+}
+
+// L^T p = u in place on DV_P0 (dense_e_metric::sample_p: p = llt.matrixU().solve(u)), blocked back substitution:
+// for block b from the last to the first: k_dn_trsv_diag solves the DN_NB x DN_NB triangle, k_dn_trsv_update
+// subtracts the block's contribution from every earlier unknown.
+__global__ __launch_bounds__(64) void k_dn_trsv_diag(const DnParams P, int b) {
+  __shared__ double Lb[DN_NB][DN_NB + 1];
+  const int chain = blockIdx.x;
+  if (!P.rd[chain].active) return;
+  const int lane = threadIdx.x, r0 = b * DN_NB, nb = min(DN_NB, P.D - r0);
+  const double *L = P.Lc + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  for (int i = 0; i < nb; i++) Lb[i][lane] = lane <= i ? L[(size_t)(r0 + i) * P.LD + r0 + lane] : 0.0;
+  __syncthreads();
+  double *p = dn_vec(P, chain, DV_P0);
+  double r = lane < nb ? p[r0 + lane] : 0.0;
+  for (int i = nb - 1; i >= 0; i--) {
+    const double pi = __shfl(r, i, 64) / Lb[i][i];
+    if (lane == i) r = pi;
+    else if (lane < i) r -= Lb[i][lane] * pi;
+  }
+  if (lane < nb) p[r0 + lane] = r;
+}
+__global__ __launch_bounds__(256) void k_dn_trsv_update(const DnParams P, int b) {
+  __shared__ double pb[DN_NB];
+  const int chain = blockIdx.y;
+  if (!P.rd[chain].active) return;
+  const int r0 = b * DN_NB, nb = min(DN_NB, P.D - r0);
+  const double *L = P.Lc + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  double *p = dn_vec(P, chain, DV_P0);
+  if (threadIdx.x < DN_NB) pb[threadIdx.x] = (int)threadIdx.x < nb ? p[r0 + threadIdx.x] : 0.0;
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= r0) return;
+  double s = 0.0;
+  for (int i = 0; i < nb; i++) s += L[(size_t)(r0 + i) * P.LD + c] * pb[i];
+  p[c] -= s;
+}
+
+// ---------------------------------------------------------------- the tree logic (base_nuts::transition / build_tree)
+// Same iterative restatement as potus_nuts.hpp / potus_cluster.hpp: a loop over leaves with a cascade of merges, every
+// trajectory position in a slot of the proposal pool, proposals kept by index.  Differences: the state survives
+// between launches in global memory, and p# = M^-1 p is a stored vector per leaf instead of minv * p on the fly.
+struct DnSweep { int a_beg, as_beg, a_end, as_end, a_rho, b_beg, bs_beg, b_end, bs_end, b_rho, out; };
+
+__device__ __forceinline__ bool dn_merge(const DnParams &P, int chain, const DnSweep &s, double *red_) {
+  ldp red = (ldp)red_;
+  const double *ab = dn_vec(P, chain, s.a_beg), *abs_ = dn_vec(P, chain, s.as_beg), *ae = dn_vec(P, chain, s.a_end), *aes = dn_vec(P, chain, s.as_end);
+  const double *ar = dn_vec(P, chain, s.a_rho), *bb = dn_vec(P, chain, s.b_beg), *bbs = dn_vec(P, chain, s.bs_beg), *be = dn_vec(P, chain, s.b_end);
+  const double *bes = dn_vec(P, chain, s.bs_end), *br = dn_vec(P, chain, s.b_rho);
+  double *out = dn_vec(P, chain, s.out);
+  double v[6] = {0, 0, 0, 0, 0, 0};
+  const int tid = threadIdx.x;
+  for (int i = tid; i < P.D; i += DN_THREADS) {
+    const double ra = ar[i], rb = br[i], rs = ra + rb;
+    const double sab = abs_[i], sbe = bes[i];
+    v[0] += sab * rs;                       // p#_beg . rho_subtree
+    v[1] += sbe * rs;                       // p#_end . rho_subtree
+    const double e1 = ra + bb[i];           // rho_init + p_final_beg
+    v[2] += sab * e1;
+    v[3] += bbs[i] * e1;
+    const double e2 = rb + ae[i];           // rho_final + p_init_end
+    v[4] += aes[i] * e2;
+    v[5] += sbe * e2;
+    out[i] = rs;
+  }
+  (void)ab; (void)be;
+  block_sum(v, red, tid);
+  return v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0 && v[4] > 0 && v[5] > 0;
+}
+__device__ __forceinline__ void dn_copy(const DnParams &P, int chain, int dst, int src) {
+  const double *s = dn_vec(P, chain, src);
+  double *d = dn_vec(P, chain, dst);
+  for (int i = threadIdx.x; i < P.D; i += DN_THREADS) d[i] = s[i];
+}
+__device__ __forceinline__ double dn_partial_sum(const DnParams &P, int chain) {   // fixed order over the row blocks
+  double t = 0.0;
+  const double *p = P.partial + (size_t)chain * P.npart;
+  for (int i = 0; i < P.npart; i++) t += p[i];
+  return t;
+}
+
+enum { DN_MODE_BEGIN = 0, DN_MODE_LEAF = 1 };
+
+// called by thread 0: the next leaf of the current doubling
+__device__ __forceinline__ void dn_setup_leaf(TS &ts, DnRound &rd) {
+  unsigned pm = ts.pmask, qm = ts.qmask;
+  const int leaf = pool_alloc(pm, PT_NPP), outq = pool_alloc(qm, PT_NPQ);
+  ts.pmask = pm; ts.qmask = qm;
+  ts.leaf_id = leaf; ts.out_q = outq;
+  const int dir = ts.dir, inq = ts.nextq[dir];
+  const double e = dir ? ts.eps : -ts.eps;
+  rd.active = 1; rd.qin = DV_POOLQ + inq; rd.gout = DV_G; rd.ph = DV_PH0 + dir; rd.leaf = DV_POOLP + leaf; rd.he = 0.5 * e;
+  rd.job[0] = DnJob{DV_POOLP + leaf, DV_POOLPS + leaf, -1, -1, DV_POOLP + leaf, 0, 0.0};          // p# of the leaf, kinetic energy
+  rd.job[1] = DnJob{DV_PH0 + dir, -1, DV_POOLQ + inq, DV_POOLQ + outq, -1, 0, e};                // the next position of this end
+}
+
+__global__ __launch_bounds__(DN_THREADS) void k_dn_step(const DnParams P, const RunParams *Rg, unsigned iter, int mode) {
+  __shared__ TS ts;
+  __shared__ DnRound rd;
+  __shared__ double red[(DN_THREADS / 64) * PT_NRED];
+  __shared__ int sh_flag[4];
+  const int chain = blockIdx.x, tid = threadIdx.x;
+  static_assert(DN_THREADS / 64 == PT_NW, "block_sum is written for PT_NW waves");
+  if (!P.rd[chain].active) return;
+  for (int i = tid; i < (int)(sizeof(TS) / 4); i += DN_THREADS) ((int *)&ts)[i] = ((const int *)&P.ts[chain])[i];
+  for (int i = tid; i < (int)(sizeof(DnRound) / 4); i += DN_THREADS) ((int *)&rd)[i] = ((const int *)&P.rd[chain])[i];
+  __syncthreads();
+  const RngKey key{Rg->seed_lo, Rg->seed_hi, (uint32_t)(Rg->chain_id_offset + chain + 1)};
+  const int max_depth = Rg->max_depth;
+  bool new_doubling = false;
+  if (mode == DN_MODE_BEGIN) {
+    if (tid == 0) {
+      const double kin0 = dn_partial_sum(P, chain), lp0 = P.lpbuf[chain];
+      ts.H0 = 0.5 * kin0 - lp0;
+      ts.lsw = 0.0; ts.sum_metro = 0.0; ts.n_leap = 0; ts.depth = 0; ts.divergent = 0; ts.stop = 0;
+      ts.sample_qid = 0; ts.nextq[1] = 1; ts.nextq[0] = 2;
+      ts.q_lp[0] = lp0; ts.q_h[0] = ts.H0;
+    }
+    dn_copy(P, chain, DV_PSF1, DV_PSF0);      // both ends start at the initial point
+    new_doubling = true;
+    __syncthreads();
+  } else {
+    const int n = ts.m;                        // leaf number inside the doubling (kept in ts.m between launches)
+    const int depth = ts.depth, dir = ts.dir, leaf = ts.leaf_id;
+    if (tid == 0) {
+      const double kin = dn_partial_sum(P, chain), lpv = P.lpbuf[chain], H0 = ts.H0;
+      double h = 0.5 * kin - lpv;
+      if (isnan(h)) h = INFINITY;
+      const int div = (h - H0 > 1000.0) ? 1 : ts.divergent;
+      ts.divergent = div;
+      const double wgt = H0 - h;
+      ts.sum_metro += wgt > 0 ? 1.0 : exp(wgt);
+      ts.n_leap += 1;
+      const int inq = ts.nextq[dir];
+      ts.cur_beg = ts.cur_end = leaf; ts.cur_lsw = wgt; ts.cur_prop = inq;
+      ts.q_lp[inq] = lpv; ts.q_h[inq] = h;
+      ts.nextq[dir] = ts.out_q;               // the next leaf of this end evaluates the position just written
+      ts.abort = div;
+    }
+    __syncthreads();
+    const int m = __builtin_ctz(~(unsigned)n);
+    const bool top = n == (1 << depth) - 1;
+    for (int j = 1; j <= m && !ts.abort; j++) {
+      const int ib = ts.pend_beg[j - 1], ie = ts.pend_end[j - 1], cb = ts.cur_beg, ce = ts.cur_end;
+      const DnSweep s{DV_POOLP + ib, DV_POOLPS + ib, DV_POOLP + ie, DV_POOLPS + ie, j == 1 ? DV_POOLP + ib : DV_RHOLEV + j - 1,
+                      DV_POOLP + cb, DV_POOLPS + cb, DV_POOLP + ce, DV_POOLPS + ce, j == 1 ? DV_POOLP + cb : DV_SCR0 + ((j - 1) & 1),
+                      j == m ? DV_RHOLEV + j : DV_SCR0 + (j & 1)};
+      const bool persist = dn_merge(P, chain, s, red);
+      if (tid == 0) {
+        const double cur_lsw = ts.cur_lsw;
+        const double lsw_sub = d_lse(ts.pend_lsw[j - 1], cur_lsw);
+        bool take_final;
+        if (cur_lsw > lsw_sub) take_final = true;
+        else {
+          const uint32_t slot = ((uint32_t)depth << 24) | ((uint32_t)j << 16) | (uint32_t)(n >> j);
+          take_final = rng_uniform(key, iter, RNG_SUB_ACCEPT, 0, slot) < exp(cur_lsw - lsw_sub);
+        }
+        unsigned qm = ts.qmask, pm = ts.pmask;
+        if (take_final) pool_free(qm, ts.pend_prop[j - 1]);
+        else { pool_free(qm, ts.cur_prop); ts.cur_prop = ts.pend_prop[j - 1]; }
+        if (ie != ib) pool_free(pm, ie);
+        if (cb != ce) pool_free(pm, cb);
+        ts.qmask = qm; ts.pmask = pm;
+        ts.cur_beg = ib;
+        ts.cur_lsw = lsw_sub;
+        ts.abort = !persist;
+      }
+      __syncthreads();
+    }
+    if (!ts.abort) {
+      if (tid == 0) { ts.pend_beg[m] = ts.cur_beg; ts.pend_end[m] = ts.cur_end; ts.pend_lsw[m] = ts.cur_lsw; ts.pend_prop[m] = ts.cur_prop; }
+      __syncthreads();
+      if (top) {
+        // the last leaf is the new end point; then the checks at the end of transition(): old trajectory against the
+        // new subtree (a = old, b = new; the six products are symmetric in the direction, see the note at dn_merge's caller)
+        dn_copy(P, chain, DV_PF0 + dir, DV_POOLP + leaf);
+        dn_copy(P, chain, DV_PSF0 + dir, DV_POOLPS + leaf);
+        __syncthreads();
+        const int nb = ts.pend_beg[depth];
+        const DnSweep s{DV_PF1 - dir, DV_PSF1 - dir, DV_PNEAR, DV_PSNEAR, DV_RHOTOP,
+                        DV_POOLP + nb, DV_POOLPS + nb, DV_POOLP + leaf, DV_POOLPS + leaf, depth == 0 ? DV_POOLP + leaf : DV_RHOLEV + depth, DV_RHOTOP};
+        const bool persist = dn_merge(P, chain, s, red);
+        if (tid == 0) {
+          ts.depth = depth + 1;
+          const double lsw_sub = ts.pend_lsw[depth], lsw = ts.lsw;
+          bool accept;
+          if (lsw_sub > lsw) accept = true;
+          else accept = rng_uniform(key, iter, RNG_TOP_ACCEPT, 0, (uint32_t)depth) < exp(lsw_sub - lsw);
+          unsigned qm = ts.qmask;
+          if (accept) { pool_free(qm, ts.sample_qid); ts.sample_qid = ts.pend_prop[depth]; }
+          else pool_free(qm, ts.pend_prop[depth]);
+          ts.qmask = qm;
+          ts.lsw = d_lse(lsw, lsw_sub);
+          if (!persist) ts.stop = 1;
+        }
+        new_doubling = true;
+        __syncthreads();
+      } else if (tid == 0) {
+        ts.m = n + 1;
+        dn_setup_leaf(ts, rd);
+      }
+    } else if (tid == 0) rd.active = 0;       // divergence or U-turn inside the new subtree: the transition is over
+  }
+  if (new_doubling) {
+    if (tid == 0) {
+      if (ts.depth >= max_depth || ts.stop) { rd.active = 0; sh_flag[0] = 0; }
+      else {
+        ts.dir = rng_uniform(key, iter, RNG_DIRECTION, 0, (uint32_t)ts.depth) > 0.5 ? 1 : 0;
+        ts.pmask = 0;
+        ts.qmask = (1u << ts.sample_qid) | (1u << ts.nextq[0]) | (1u << ts.nextq[1]);
+        ts.m = 0;
+        sh_flag[0] = 1;
+      }
+    }
+    __syncthreads();
+    if (sh_flag[0]) {
+      const int dir = ts.dir;
+      dn_copy(P, chain, DV_PNEAR, DV_PF0 + dir);
+      dn_copy(P, chain, DV_PSNEAR, DV_PSF0 + dir);
+      if (tid == 0) dn_setup_leaf(ts, rd);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < (int)(sizeof(TS) / 4); i += DN_THREADS) ((int *)&P.ts[chain])[i] = ((const int *)&ts)[i];
+  for (int i = tid; i < (int)(sizeof(DnRound) / 4); i += DN_THREADS) ((int *)&P.rd[chain])[i] = ((const int *)&rd)[i];
+  if (tid == 0) P.active[chain] = rd.active;
+}
+
+// ---------------------------------------------------------------- transition begin / end
+// every chain takes part in a transition: (re)arm the round descriptors
+__global__ void k_dn_arm(const DnParams P, const RunParams *Rg, int total_iters) {
+  const int chain = blockIdx.x * blockDim.x + threadIdx.x;
+  if (chain >= P.chains) return;
+  const ChainScalars &sc = Rg->scal[(size_t)chain * P.sc_stride];
+  const int on = sc.status == 0 && sc.iter < total_iters;
+  DnRound &rd = P.rd[chain];
+  rd.active = on; rd.qin = DV_QC; rd.gout = DV_GC; rd.aux = 0;
+  P.active[chain] = on;
+}
+// after the momentum draw and the gradient at the current point (hamiltonian.init): both trajectory ends := the
+// initial point, kicked half a step towards their first leaves; the three products of the begin pass
+__global__ __launch_bounds__(256) void k_dn_begin(const DnParams P, const RunParams *Rg) {
+  const int chain = blockIdx.y;
+  DnRound &rd = P.rd[chain];
+  if (!rd.active) return;
+  const double eps = Rg->scal[(size_t)chain * P.sc_stride].nom_eps;   // sample_stepsize(): no jitter
+  const double *q = dn_vec(P, chain, DV_QC), *g = dn_vec(P, chain, DV_GC), *p = dn_vec(P, chain, DV_P0);
+  double *ph0 = dn_vec(P, chain, DV_PH0), *ph1 = dn_vec(P, chain, DV_PH1), *pf0 = dn_vec(P, chain, DV_PF0), *pf1 = dn_vec(P, chain, DV_PF1);
+  double *rt = dn_vec(P, chain, DV_RHOTOP), *qs = dn_vec(P, chain, DV_POOLQ + 0);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < P.D; i += gridDim.x * 256) {
+    const double pi = p[i], gi = g[i];
+    ph1[i] = pi + 0.5 * eps * gi; ph0[i] = pi - 0.5 * eps * gi;
+    pf0[i] = pi; pf1[i] = pi; rt[i] = pi; qs[i] = q[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    P.ts[chain].eps = eps;
+    rd.job[0] = DnJob{DV_P0, DV_PSF0, -1, -1, DV_P0, 0, 0.0};                 // p# of the initial point, kinetic energy
+    rd.job[1] = DnJob{DV_PH1, -1, DV_POOLQ + 0, DV_POOLQ + 1, -1, 0, eps};    // first position forwards
+    rd.job[2] = DnJob{DV_PH0, -1, DV_POOLQ + 0, DV_POOLQ + 2, -1, 0, -eps};   // first position backwards
+  }
+}
+
+// New sample -> chain position and draws array; step-size adaptation; the draw joins the adaptation window.
+// flags (host-computed from the shared warm-up schedule): bit 0 = inside a window, bit 1 = the window ends here.
+__global__ __launch_bounds__(DN_THREADS) void k_dn_end(const DnParams P, const RunParams *Rg, int it, int flags, int win_n, int total_iters) {
+  const int chain = blockIdx.x, tid = threadIdx.x;
+  ChainScalars &sc = Rg->scal[(size_t)chain * P.sc_stride];
+  if (sc.status != 0 || sc.iter != it || it >= total_iters) return;   // (chains that sat the transition out)
+  TS &ts = P.ts[chain];
+  const bool warm = it < Rg->num_warmup, save = !warm || Rg->save_warmup;
+  const int sample = ts.sample_qid;
+  const double *qs = dn_vec(P, chain, DV_POOLQ + sample);
+  double *Q0 = dn_vec(P, chain, DV_QC);
+  double *row = Rg->draws + ((size_t)chain * Rg->n_save_max + sc.saved) * Rg->row;
+  double *wrow = (flags & 1) ? P.win + ((size_t)chain * P.win_cap + win_n) * (size_t)P.LD : nullptr;
+  for (int i = tid; i < P.D; i += DN_THREADS) {
+    const double v = qs[i];
+    Q0[i] = v;
+    if (save) row[POTUS_N_SAMPLER_COLS + i] = v;
+    if (wrow) wrow[i] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double accept_stat = ts.sum_metro / (double)ts.n_leap;
+    if (save) {
+      row[0] = ts.q_lp[sample]; row[1] = accept_stat; row[2] = ts.eps; row[3] = ts.depth; row[4] = ts.n_leap; row[5] = ts.divergent;
+      row[6] = ts.q_h[sample];
+      sc.saved += 1;
+    }
+    sc.total_leapfrogs += ts.n_leap; sc.n_divergent += ts.divergent; sc.lp_cur = ts.q_lp[sample];
+    if (warm) {   // stepsize_adaptation::learn_stepsize
+      const double cnt = sc.ad_counter + 1;
+      sc.ad_counter = cnt;
+      const double as = accept_stat > 1 ? 1.0 : accept_stat;
+      const double eta = 1.0 / (cnt + Rg->t0);
+      const double s_bar = (1.0 - eta) * sc.s_bar + eta * (Rg->delta - as);
+      sc.s_bar = s_bar;
+      const double x = sc.mu - s_bar * sqrt(cnt) / Rg->gamma;
+      const double x_eta = pow(cnt, -Rg->kappa);
+      sc.x_bar = (1.0 - x_eta) * sc.x_bar + x_eta * x;
+      sc.nom_eps = exp(x);
+      if (!(flags & 2) && it == Rg->num_warmup - 1) sc.nom_eps = exp(sc.x_bar);   // complete_adaptation
+    }
+    sc.iter = it + 1;
+  }
+}
+// after the metric update and init_stepsize at a window's end: restart the step-size adaptation around the new step
+__global__ void k_dn_window_done(const DnParams P, const RunParams *Rg, int it) {
+  const int chain = blockIdx.x * blockDim.x + threadIdx.x;
+  if (chain >= P.chains) return;
+  ChainScalars &sc = Rg->scal[(size_t)chain * P.sc_stride];
+  if (sc.status != 0) return;
+  sc.mu = log(10.0 * sc.nom_eps); sc.s_bar = 0; sc.x_bar = 0; sc.ad_counter = 0;
+  if (it == Rg->num_warmup - 1) sc.nom_eps = exp(sc.x_bar);
+}
+
+// ---------------------------------------------------------------- base_hmc::init_stepsize, one attempt per round
+// round: normals -> solve -> k_dn_eps_prekick -> matvec<2> (H0, first position) -> gradient -> k_dn_kick ->
+// matvec<1> (kinetic energy at the end) -> k_dn_eps_step (direction / done / doubling or halving)
+__global__ void k_dn_eps_arm(const DnParams P, const RunParams *Rg) {
+  const int chain = blockIdx.x * blockDim.x + threadIdx.x;
+  if (chain >= P.chains) return;
+  const ChainScalars &sc = Rg->scal[(size_t)chain * P.sc_stride];
+  const double e0 = sc.nom_eps;
+  const int on = sc.status == 0 && !(e0 == 0 || e0 > 1e7 || isnan(e0));
+  DnRound &rd = P.rd[chain];
+  rd.active = on; rd.aux = 0; rd.qin = DV_QC; rd.gout = DV_GC;
+  P.ts[chain].direction = 0; P.ts[chain].done = 0;
+  P.active[chain] = on;
+}
+__global__ __launch_bounds__(256) void k_dn_eps_prekick(const DnParams P, const RunParams *Rg) {
+  const int chain = blockIdx.y;
+  DnRound &rd = P.rd[chain];
+  if (!rd.active) return;
+  const double eps = Rg->scal[(size_t)chain * P.sc_stride].nom_eps;
+  const double *g = dn_vec(P, chain, DV_GC), *p = dn_vec(P, chain, DV_P0);
+  double *ph = dn_vec(P, chain, DV_PH1);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < P.D; i += gridDim.x * 256) ph[i] = p[i] + 0.5 * eps * g[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    rd.job[0] = DnJob{DV_P0, -1, -1, -1, DV_P0, 0, 0.0};
+    rd.job[1] = DnJob{DV_PH1, -1, DV_QC, DV_TMPQ, -1, 0, eps};
+    rd.qin = DV_TMPQ; rd.gout = DV_G; rd.ph = DV_PH1; rd.leaf = DV_TMPP; rd.he = 0.5 * eps;
+  }
+}
+// between the two matrix passes of an attempt: H0 from the first, the job of the second
+__global__ void k_dn_eps_mid(const DnParams P, const RunParams *Rg) {
+  const int chain = blockIdx.x * blockDim.x + threadIdx.x;
+  if (chain >= P.chains) return;
+  DnRound &rd = P.rd[chain];
+  if (!rd.active) return;
+  P.ts[chain].H0 = 0.5 * dn_partial_sum(P, chain) - Rg->scal[(size_t)chain * P.sc_stride].lp_cur;
+  rd.job[0] = DnJob{DV_TMPP, -1, -1, -1, DV_TMPP, 0, 0.0};
+}
+__global__ void k_dn_eps_step(const DnParams P, const RunParams *Rg) {
+  const int chain = blockIdx.x * blockDim.x + threadIdx.x;
+  if (chain >= P.chains) return;
+  DnRound &rd = P.rd[chain];
+  if (!rd.active) return;
+  TS &ts = P.ts[chain];
+  ChainScalars &sc = Rg->scal[(size_t)chain * P.sc_stride];
+  double h = 0.5 * dn_partial_sum(P, chain) - P.lpbuf[chain];
+  if (isnan(h)) h = INFINITY;
+  const double delta_H = ts.H0 - h, thr = log(0.8), eps = sc.nom_eps;
+  int done = 0;
+  if (rd.aux == 0) ts.direction = delta_H > thr ? 1 : -1;
+  else {
+    const int dirn = ts.direction;
+    if (dirn == 1 && !(delta_H > thr)) done = 1;
+    else if (dirn == -1 && !(delta_H < thr)) done = 1;
+    else {
+      const double ne = dirn == 1 ? 2.0 * eps : 0.5 * eps;
+      sc.nom_eps = ne;
+      if (ne > 1e7 || ne == 0) { done = 1; sc.status = POTUS_ERR_STEPSIZE; }   // upstream throws here
+    }
+  }
+  rd.aux += 1;
+  rd.qin = DV_QC; rd.gout = DV_GC;
+  if (done) rd.active = 0;
+  P.active[chain] = rd.active;
+}
+
+// ---------------------------------------------------------------- covar_adaptation at a window's end
+// mean by welford_covar_estimator's recurrence, draws centred in place
+__global__ __launch_bounds__(256) void k_dn_center(const DnParams P, int n) {
+  const int chain = blockIdx.y;
+  double *W = P.win + (size_t)chain * P.win_cap * (size_t)P.LD;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < P.D; j += gridDim.x * 256) {
+    double m = 0.0;
+    for (int k = 0; k < n; k++) m += (W[(size_t)k * P.LD + j] - m) / (double)(k + 1);
+    for (int k = 0; k < n; k++) W[(size_t)k * P.LD + j] -= m;
+  }
+}
+// M^-1 = n/(n+5) * (sum_k c_k c_k') / (n-1) + 1e-3 * 5/(n+5) * I   (covar_adaptation::learn_covariance), tiles of 64 x 64,
+// lower tiles computed and mirrored so that the matrix is exactly symmetric
+__global__ __launch_bounds__(256) void k_dn_cov(const DnParams P, int n) {
+  __shared__ double a[DN_NB][DN_NB + 1], b[DN_NB][DN_NB + 1];
+  const int I = blockIdx.x, J = blockIdx.y, chain = blockIdx.z;
+  if (J > I) return;
+  const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+  const double *W = P.win + (size_t)chain * P.win_cap * (size_t)P.LD;
+  double *A = P.Minv + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  double c[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int s = 0; s < 4; s++) c[r][s] = 0.0;
+  for (int k0 = 0; k0 < n; k0 += DN_NB) {
+    __syncthreads();
+    for (int e = tid; e < DN_NB * DN_NB; e += 256) {
+      const int k = e >> 6, j = e & 63;
+      const bool ok = k0 + k < n;
+      a[k][j] = (ok && I * DN_NB + j < P.D) ? W[(size_t)(k0 + k) * P.LD + I * DN_NB + j] : 0.0;
+      b[k][j] = (ok && J * DN_NB + j < P.D) ? W[(size_t)(k0 + k) * P.LD + J * DN_NB + j] : 0.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < DN_NB; k++) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) { av[r] = a[k][tr + 16 * r]; bv[r] = b[k][tc + 16 * r]; }
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) c[r][s] += av[r] * bv[s];
+    }
+  }
+  const double nn = (double)n, f = (nn / (nn + 5.0)) / (nn - 1.0), reg = 1e-3 * (5.0 / (nn + 5.0));
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int i = I * DN_NB + tr + 16 * r, j = J * DN_NB + tc + 16 * s;
+      if (i < P.D && j < P.D && (I != J || j <= i)) {
+        const double v = f * c[r][s] + (i == j ? reg : 0.0);
+        A[(size_t)i * P.LD + j] = v;
+        A[(size_t)j * P.LD + i] = v;
+      }
+    }
+}
+
+// Blocked right-looking Cholesky of M^-1 -> lower factor in Lc (row-major; only the lower triangle is meaningful).
+// step kb: k_dn_potrf (diagonal block), k_dn_trsm (the rows below it), k_dn_syrk (trailing update).
+__global__ __launch_bounds__(256) void k_dn_potrf(const DnParams P, int kb) {
+  __shared__ double a[DN_NB][DN_NB + 1];
+  const int chain = blockIdx.x, tid = threadIdx.x, r0 = kb * DN_NB, nb = min(DN_NB, P.D - r0);
+  double *L = P.Lc + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  for (int e = tid; e < DN_NB * DN_NB; e += 256) { const int i = e >> 6, j = e & 63; a[i][j] = (i < nb && j <= i) ? L[(size_t)(r0 + i) * P.LD + r0 + j] : 0.0; }
+  __syncthreads();
+  for (int j = 0; j < nb; j++) {
+    if (tid == 0) {
+      const double d = a[j][j];
+      if (!(d > 0.0)) { *P.fail = 1; a[j][j] = 1.0; } else a[j][j] = sqrt(d);
+    }
+    __syncthreads();
+    const double djj = a[j][j];
+    for (int i = j + 1 + tid; i < nb; i += 256) a[i][j] /= djj;
+    __syncthreads();
+    for (int e = tid; e < (nb - j - 1) * (nb - j - 1); e += 256) {
+      const int i = j + 1 + e / (nb - j - 1), k = j + 1 + e % (nb - j - 1);
+      if (k <= i) a[i][k] -= a[i][j] * a[k][j];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < DN_NB * DN_NB; e += 256) { const int i = e >> 6, j = e & 63; if (i < nb && j < nb) L[(size_t)(r0 + i) * P.LD + r0 + j] = j <= i ? a[i][j] : 0.0; }
+}
+// rows below the diagonal block: X Lkk' = A  ->  forward substitution per row (64 rows per workgroup, staged in LDS)
+__global__ __launch_bounds__(256) void k_dn_trsm(const DnParams P, int kb) {
+  __shared__ double lk[DN_NB][DN_NB + 1], x[DN_NB][DN_NB + 1];
+  const int chain = blockIdx.y, tid = threadIdx.x, c0 = kb * DN_NB, nb = min(DN_NB, P.D - c0);
+  const int r0 = (kb + 1) * DN_NB + blockIdx.x * DN_NB;
+  if (r0 >= P.D) return;
+  double *L = P.Lc + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  for (int e = tid; e < DN_NB * DN_NB; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    lk[i][j] = (i < nb && j <= i) ? L[(size_t)(c0 + i) * P.LD + c0 + j] : 0.0;
+    x[i][j] = (r0 + i < P.D && j < nb) ? L[(size_t)(r0 + i) * P.LD + c0 + j] : 0.0;
+  }
+  __syncthreads();
+  if (tid < DN_NB) {
+    const int r = tid;
+    for (int j = 0; j < nb; j++) {
+      double s = x[r][j];
+      for (int t = 0; t < j; t++) s -= x[r][t] * lk[j][t];
+      x[r][j] = s / lk[j][j];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < DN_NB * DN_NB; e += 256) { const int i = e >> 6, j = e & 63; if (r0 + i < P.D && j < nb) L[(size_t)(r0 + i) * P.LD + c0 + j] = x[i][j]; }
+}
+// trailing update A[I][J] -= L[I][kb] L[J][kb]' for the lower tiles I >= J > kb
+__global__ __launch_bounds__(256) void k_dn_syrk(const DnParams P, int kb) {
+  __shared__ double a[DN_NB][DN_NB + 1], b[DN_NB][DN_NB + 1];
+  const int I = kb + 1 + blockIdx.x, J = kb + 1 + blockIdx.y, chain = blockIdx.z;
+  if (J > I) return;
+  const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15, c0 = kb * DN_NB;
+  double *L = P.Lc + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  for (int e = tid; e < DN_NB * DN_NB; e += 256) {
+    const int i = e >> 6, t = e & 63;
+    a[i][t] = I * DN_NB + i < P.D ? L[(size_t)(I * DN_NB + i) * P.LD + c0 + t] : 0.0;
+    b[i][t] = J * DN_NB + i < P.D ? L[(size_t)(J * DN_NB + i) * P.LD + c0 + t] : 0.0;
+  }
+  __syncthreads();
+  double c[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int s = 0; s < 4; s++) c[r][s] = 0.0;
+  for (int t = 0; t < DN_NB; t++) {
+    double av[4], bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { av[r] = a[tr + 16 * r][t]; bv[r] = b[tc + 16 * r][t]; }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int s = 0; s < 4; s++) c[r][s] += av[r] * bv[s];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int i = I * DN_NB + tr + 16 * r, j = J * DN_NB + tc + 16 * s;
+      if (i < P.D && j < P.D && j <= i) L[(size_t)i * P.LD + j] -= c[r][s];
+    }
+}
+
+// unit metric: M^-1 = L = I
+__global__ void k_dn_identity(const DnParams P) {
+  const int chain = blockIdx.y;
+  double *A = P.Minv + (size_t)chain * (size_t)P.D * (size_t)P.LD, *L = P.Lc + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.D; i += gridDim.x * blockDim.x) { A[(size_t)i * P.LD + i] = 1.0; L[(size_t)i * P.LD + i] = 1.0; }
+}
+// fills a symmetric positive definite test matrix on the device (rates at sizes that would take seconds to upload):
+// A[i][j] = exp(-|i-j|/50) * (1 + 0.1 c) + (i == j ? 1 : 0)
+__global__ void k_dn_fill(const DnParams P) {
+  const size_t n = (size_t)P.D * P.D;
+  for (int c = 0; c < P.chains; c++)
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-      const int i = (int)(e / D), j = (int)(e % D);
+      const int i = (int)(e / P.D), j = (int)(e % P.D);
       const int d = i > j ? i - j : j - i;
-      Minv[(size_t)c * n + e] = exp(-(double)d / 50.0) * (1.0 + 0.1 * c) + (i == j ? 1.0 : 0.0);
+      P.Minv[(size_t)c * P.D * P.LD + (size_t)i * P.LD + j] = exp(-(double)d / 50.0) * (1.0 + 0.1 * c) + (i == j ? 1.0 : 0.0);
     }
 }

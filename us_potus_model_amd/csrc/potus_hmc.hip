@@ -359,6 +359,56 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_run(const DevModel *Mg, const
 #endif
 }
 
+// ------------------------------------------------------------------------ gradient of a dense-metric round (potus_dense.hpp)
+// one workgroup per chain: the position and the slot receiving the gradient come from the chain's round descriptor
+__global__ __launch_bounds__(PT_THREADS) void k_dn_grad1(const DevModel *Mg, const DnParams P) {
+  const int chain = blockIdx.x;
+  const DnRound &rd = P.rd[chain];
+  if (!rd.active) return;
+  CMp M = (CMp)Mg;
+  ldp lds = (ldp)lds_dyn;
+  const PassStatic pst = model_setup_lds(M, lds);
+  const int D = M->D;
+  PlainPolicy pol{make_rsrc(dn_vec(P, chain, rd.qin), 8u * D), make_rsrc(dn_vec(P, chain, rd.gout), 8u * D), 0u, 0u, {0}};
+  const double v = model_pass(M, lds, pst, pol);
+  if (threadIdx.x == 0) P.lpbuf[chain] = v;
+}
+// one cluster per chain (models beyond one workgroup): the position goes into the cluster's internal element order
+// (scratch vectors of the chain's state block), the gradient comes back in Stan's order
+template <int CL_DW>
+__global__ __launch_bounds__(PT_THREADS) void k_dn_gradK(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, const DnParams P, unsigned launch) {
+  CMp M = (CMp)Mg;
+  CCp CL = (CCp)CLg;
+  CRp R = (CRp)Rg;
+  const int chain = blockIdx.x % R->chains, m = blockIdx.x / R->chains;
+  const DnRound &rd = P.rd[chain];
+  if (!rd.active) return;                            // the whole cluster
+  ClChain c = make_clchain(M, CL, R, chain, m, launch);
+  c.cst = cl_setup_lds(M, CL, c.part, c.lds);
+  const double *q = dn_vec(P, chain, rd.qin);
+  double *grad = dn_vec(P, chain, rd.gout);
+  const unsigned sQ = c.soff(V_QA1), sG = c.soff(V_GC);
+  for (int i = c.e0 + c.tid; i < c.e1; i += PT_THREADS) { const int si = c.perm[i]; bst_s(c.st, 8u * i, sQ, si >= 0 ? as_g(q)[si] : 0.0); }
+  cl_sync(c.x, c.red());
+  ClPlainPolicy pol{c.st, c.st, sQ, sG, {0}};
+  const double v = cl_pass<CL_DW>(M, CL, c.part, c.lds, c.cst, c.x, pol);
+  drain_vmem();
+  __syncthreads();
+  for (int i = c.e0 + c.tid; i < c.e1; i += PT_THREADS) { const int si = c.perm[i]; if (si >= 0) as_g(grad)[si] = bld(c.st, 8u * i, sG); }
+  if (m == 0 && c.tid == 0) P.lpbuf[chain] = v;
+}
+// the point found by k_init / k_cl_init (diagonal state block) -> the dense state block, Stan's order
+__global__ void k_dn_import_q(const RunParams *Rg, const DnParams P, const int *perm, int Dint) {
+  const int chain = blockIdx.y;
+  const double *src = Rg->state + ((size_t)chain * V_COUNT + V_QC) * Rg->Dpad;
+  double *dst = dn_vec(P, chain, DV_QC);
+  const int n = perm ? Dint : P.D;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int si = perm ? perm[i] : i;
+    if (si >= 0) dst[si] = src[i];
+  }
+}
+
 // write_array (stan:70-113 transformed parameters, stan:134-140 generated quantities) for saved
 // draws; one 256-thread workgroup per draw builds the full CmdStan row in scratch and copies
 // the requested column range.  out layout: [iter][chain][col_end - col_begin].
@@ -567,6 +617,14 @@ struct Sampler {
   std::vector<int> h_ps, h_pt, h_pp, h_pm, h_ppop, h_pq, h_dayptr, h_perm;   // day-sorted polls (host copies)
   std::vector<double> h_w;    // state_weights
   std::vector<double> h_pu;
+  // dense metric (potus_dense.hpp)
+  bool dense = false;
+  DnParams dn{};
+  int *h_active = nullptr;                 // pinned host copy of the per-chain activity flags
+  int dn_win_counter = 0, dn_win_next = 0, dn_win_size = 0, dn_wf_n = 0;   // host mirror of the warm-up window schedule
+  hipEvent_t mv0 = nullptr, mv1 = nullptr;
+  double mv_ms = 0;                        // time spent in k_dn_matvec (events), matrix passes and bytes streamed
+  long long mv_calls = 0, mv_bytes = 0, dn_rounds = 0;
 };
 
 std::mutex g_mu;
@@ -1001,8 +1059,8 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   }
   C.l_C = take(std::max(S * C.NDP, 12 * M.SE));
   C.l_Lw = take((M.SE + 1) * M.SP);
-  C.l_LT = take(S * M.SP); C.l_LB = take(S * M.SP); C.l_w = take(M.SE); C.l_prior = take(M.SE);
-  C.l_pm = take(npmax + 8); C.l_py = take(npmax + 8); C.l_pN = take(npmax + 8); C.l_pun = take(npmax + 8);
+  C.l_LT = take(S * (S + 1) / 2 + 2); C.l_LB = take(S * (S + 1) / 2 + 2); C.l_w = take(M.SE); C.l_prior = take(M.SE);   // packed lower triangles
+  C.l_pm = take(npmax + 8); C.l_py = take(npmax + 8); C.l_pN = 0; C.l_pun = take(npmax + 8);                             // l_py: {y, N} as two int32
   C.l_sub = take(nsubmax * 4 + 4);
   C.l_tab = take((npmax + 64) / 2 + 2); C.l_ru = take(npmax + 2);
   C.l_wide = take(CL_WIDE * PT_NW); C.l_wout = take(CL_WIDE);
@@ -1010,13 +1068,14 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   C.l_Y = take(std::max((PT_NW + 1) * M.SE, nsubmax));   // + the row of carries from later members
   C.l_r = take(npmax + 2);
   C.l_rep = take(C.NREP + 2);
-  C.l_bT = take(M.SE); C.l_pb = take(M.SE); C.l_e = take(T); C.l_c1 = take(T); C.l_c2 = take(T); C.l_c3 = take(T);
+  C.l_bT = take(M.SE); C.l_pb = take(M.SE); C.l_e = take(T);
+  C.l_c1 = take(CL_MAXDAYS); C.l_c2 = take(CL_MAXDAYS); C.l_c3 = take(CL_MAXDAYS);   // tangent recurrences: the member's own days only
   C.l_gs = take(M.SE); C.l_ge = take(CL_MAXDAYS); C.l_P = take(C.NR + 8); C.l_scal = take(SC_N); C.l_red = take((PT_NW + 1) * PT_NRED);
   C.l_st = take((npmax + 8 + 7) / 8);
   C.l_prof = take(PT_NPROF);
   C.lds_doubles = o;
   sp->cl_lds_bytes = (size_t)o * 8 + sizeof(TS) + 16;
-  if (sp->cl_lds_bytes > 160 * 1024) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode needs %zu bytes of LDS per workgroup", sp->cl_lds_bytes);
+  if (sp->cl_lds_bytes > 160 * 1024 - 64) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode needs %zu bytes of LDS per workgroup", sp->cl_lds_bytes);
 
   int rc;
   if ((rc = upload(sp, part, &C.part)) || (rc = upload(sp, sched, &C.sched)) || (rc = upload(sp, wts, &C.wt)) ||
@@ -1064,6 +1123,235 @@ int check_chains(Sampler *sp) {
     if (sc[c].status == POTUS_ERR_WATCHDOG) return fail(POTUS_ERR_WATCHDOG, "chain %d: cluster launch abandoned (watchdog)", c + 1);
     if (sc[c].status != 0) return fail(POTUS_ERR_STATE, "chain %d: status %d", c + 1, sc[c].status);
   }
+  return 0;
+}
+
+
+// ======================================================================== dense metric: host side (potus_dense.hpp)
+// windowed_adaptation's schedule, shared by every chain: the longest window = capacity of the draw buffer
+int dense_window_capacity(int nw, int ib, int tb, int bw) {
+  if (nw < 20) return 1;
+  int cap = 1, n = 0, counter = 0, next = ib + bw - 1, size = bw;
+  for (int it = 0; it < nw; it++) {
+    const bool in = counter >= ib && counter < nw - tb && counter != nw, end = counter == next && counter != nw;
+    if (in) n++;
+    cap = std::max(cap, n);
+    if (end) {
+      const int last = nw - tb - 1;
+      if (next != last) { size *= 2; next = counter + size; if (next != last && next + 2 * size >= nw - tb) next = last; }
+      n = 0;
+    }
+    counter++;
+  }
+  return cap;
+}
+
+int dense_alloc(Sampler *sp) {
+  DnParams &P = sp->dn;
+  const int D = sp->L.D, chains = sp->R.chains;
+  P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_ROWS - 1) / DN_ROWS; P.sc_stride = sp->K; P.identity = 1;
+  P.win_cap = dense_window_capacity(sp->R.num_warmup, sp->R.init_buffer, sp->R.term_buffer, sp->R.window);
+  const size_t mat = (size_t)chains * D * P.LD * 8, vec = (size_t)chains * DV_COUNT * P.LD * 8, win = (size_t)chains * P.win_cap * P.LD * 8;
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  if (2 * mat + vec + win + (64u << 20) > free_b)
+    return fail(POTUS_ERR_UNSUPPORTED, "dense metric: %d chains x (2 x D^2 + %d window draws + %d vectors) x 8 bytes = %.1f GB, %.1f GB free on GPU %d "
+                                       "(D = %d: %.2f GB per matrix)", chains, P.win_cap, DV_COUNT, (2 * mat + vec + win) / 1e9, free_b / 1e9, sp->device, D, (double)D * P.LD * 8 / 1e9);
+  auto get = [&](void **q, size_t bytes) {
+    if (hipMalloc(q, std::max<size_t>(bytes, 8)) != hipSuccess) return fail(POTUS_ERR_DEVICE, "hipMalloc(%zu) for the dense metric failed", bytes);
+    sp->allocs.push_back(*q);
+    return hipMemset(*q, 0, std::max<size_t>(bytes, 8)) == hipSuccess ? 0 : fail(POTUS_ERR_DEVICE, "hipMemset failed");
+  };
+  int rc;
+  if ((rc = get((void **)&P.state, vec)) || (rc = get((void **)&P.Minv, mat)) || (rc = get((void **)&P.Lc, mat)) || (rc = get((void **)&P.win, win)) ||
+      (rc = get((void **)&P.partial, (size_t)chains * P.npart * 8)) || (rc = get((void **)&P.lpbuf, (size_t)chains * 8)) ||
+      (rc = get((void **)&P.ts, (size_t)chains * sizeof(TS))) || (rc = get((void **)&P.rd, (size_t)chains * sizeof(DnRound))) ||
+      (rc = get((void **)&P.active, (size_t)chains * 4)) || (rc = get((void **)&P.fail, 4)))
+    return rc;
+  HIP_TRY(hipHostMalloc((void **)&sp->h_active, (size_t)chains * sizeof(int)));
+  HIP_TRY(hipEventCreate(&sp->mv0)); HIP_TRY(hipEventCreate(&sp->mv1));
+  for (const void *f : {reinterpret_cast<const void *>(k_dn_matvec<1>), reinterpret_cast<const void *>(k_dn_matvec<2>), reinterpret_cast<const void *>(k_dn_matvec<3>)})
+    HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DN_LDS_DOUBLES * 8));
+  if (sp->K == 1) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_grad1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
+  else for (const void *f : {reinterpret_cast<const void *>(k_dn_gradK<4>), reinterpret_cast<const void *>(k_dn_gradK<8>)})
+    HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
+  hipLaunchKernelGGL(k_dn_identity, dim3((D + 255) / 256, chains), dim3(256), 0, sp->stream, P);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(sp->stream));
+  sp->dn_win_counter = 0; sp->dn_win_size = sp->R.window; sp->dn_win_next = sp->R.init_buffer + sp->R.window - 1; sp->dn_wf_n = 0;
+  return 0;
+}
+
+inline dim3 dn_grid(const Sampler *sp) { return dim3((unsigned)std::min((sp->L.D + 255) / 256, 64), (unsigned)sp->R.chains); }
+
+int dense_grad(Sampler *sp) {
+  if (sp->K == 1)
+    hipLaunchKernelGGL(k_dn_grad1, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, sp->dn);
+  else {
+    const unsigned lid = ++sp->launch_id;
+    if (sp->cl_dw == 4)
+      hipLaunchKernelGGL(k_dn_gradK<4>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
+                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, sp->dn, lid);
+    else
+      hipLaunchKernelGGL(k_dn_gradK<8>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
+                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, sp->dn, lid);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+// one pass over the matrices of the active chains; the pass is timed with events resolved at the next sync point
+int dense_matvec(Sampler *sp, int nrhs) {
+  const dim3 grid((unsigned)sp->dn.npart, (unsigned)sp->R.chains);
+  HIP_TRY(hipEventRecord(sp->mv0, sp->stream));
+  if (nrhs == 1) hipLaunchKernelGGL(k_dn_matvec<1>, grid, dim3(DN_THREADS), DN_LDS_DOUBLES * 8, sp->stream, sp->dn);
+  else if (nrhs == 2) hipLaunchKernelGGL(k_dn_matvec<2>, grid, dim3(DN_THREADS), DN_LDS_DOUBLES * 8, sp->stream, sp->dn);
+  else hipLaunchKernelGGL(k_dn_matvec<3>, grid, dim3(DN_THREADS), DN_LDS_DOUBLES * 8, sp->stream, sp->dn);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(sp->mv1, sp->stream));
+  return 0;
+}
+// sync point of a round: the activity flags come to the host; returns the number of chains still active
+int dense_sync(Sampler *sp, int *n_active, bool timed_matvec) {
+  HIP_TRY(hipMemcpyAsync(sp->h_active, sp->dn.active, (size_t)sp->R.chains * sizeof(int), hipMemcpyDeviceToHost, sp->stream));
+  HIP_TRY(hipStreamSynchronize(sp->stream));
+  int n = 0;
+  for (int c = 0; c < sp->R.chains; c++) n += sp->h_active[c] != 0;
+  if (timed_matvec) {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, sp->mv0, sp->mv1));
+    sp->mv_ms += ms; sp->mv_calls += 1;
+  }
+  *n_active = n;
+  return 0;
+}
+// p ~ N(0, M): standard normals, then L^T p = u (nothing to solve while the metric is the unit matrix)
+int dense_sample_p(Sampler *sp, unsigned iter, unsigned purpose) {
+  hipLaunchKernelGGL(k_dn_normals, dn_grid(sp), dim3(256), 0, sp->stream, sp->dn, (const RunParams *)sp->dR, iter, purpose);
+  HIP_TRY(hipGetLastError());
+  if (!sp->dn.identity) {
+    const int nb = (sp->L.D + DN_NB - 1) / DN_NB;
+    for (int b = nb - 1; b >= 0; b--) {
+      hipLaunchKernelGGL(k_dn_trsv_diag, dim3(sp->R.chains), dim3(64), 0, sp->stream, sp->dn, b);
+      if (b > 0) hipLaunchKernelGGL(k_dn_trsv_update, dim3((b * DN_NB + 255) / 256, sp->R.chains), dim3(256), 0, sp->stream, sp->dn, b);
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+// base_hmc::init_stepsize for every chain of the handle (the point QC, its log density in the chain scalars)
+int dense_init_stepsize(Sampler *sp, unsigned iter) {
+  int rc, n_active = 0;
+  const int cg = (sp->R.chains + 63) / 64;
+  hipLaunchKernelGGL(k_dn_eps_arm, dim3(cg), dim3(64), 0, sp->stream, sp->dn, (const RunParams *)sp->dR);
+  if ((rc = dense_grad(sp))) return rc;                                  // hamiltonian.init at the current point: gradient -> GC
+  if ((rc = dense_sync(sp, &n_active, false))) return rc;
+  for (int attempt = 0; n_active > 0; attempt++) {
+    if (attempt > 200) return fail(POTUS_ERR_STATE, "dense init_stepsize did not terminate");
+    if ((rc = dense_sample_p(sp, iter, RNG_INIT_EPS))) return rc;
+    hipLaunchKernelGGL(k_dn_eps_prekick, dn_grid(sp), dim3(256), 0, sp->stream, sp->dn, (const RunParams *)sp->dR);
+    if ((rc = dense_matvec(sp, 2))) return rc;
+    hipLaunchKernelGGL(k_dn_eps_mid, dim3(cg), dim3(64), 0, sp->stream, sp->dn, (const RunParams *)sp->dR);
+    if ((rc = dense_grad(sp))) return rc;
+    hipLaunchKernelGGL(k_dn_kick, dn_grid(sp), dim3(256), 0, sp->stream, sp->dn);
+    if ((rc = dense_matvec(sp, 1))) return rc;
+    hipLaunchKernelGGL(k_dn_eps_step, dim3(cg), dim3(64), 0, sp->stream, sp->dn, (const RunParams *)sp->dR);
+    HIP_TRY(hipGetLastError());
+    if ((rc = dense_sync(sp, &n_active, false))) return rc;
+  }
+  return 0;
+}
+// covar_adaptation at the end of a window of n draws: covariance -> M^-1, Cholesky factor, new step size
+int dense_window_end(Sampler *sp, int n, unsigned iter) {
+  DnParams &P = sp->dn;
+  const int D = sp->L.D, chains = sp->R.chains, nb = (D + DN_NB - 1) / DN_NB;
+  if (n < 2) return fail(POTUS_ERR_STATE, "adaptation window of %d draws", n);
+  hipLaunchKernelGGL(k_dn_center, dn_grid(sp), dim3(256), 0, sp->stream, P, n);
+  hipLaunchKernelGGL(k_dn_cov, dim3(nb, nb, chains), dim3(256), 0, sp->stream, P, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(P.Lc, P.Minv, (size_t)chains * D * P.LD * 8, hipMemcpyDeviceToDevice, sp->stream));
+  for (int kb = 0; kb < nb; kb++) {
+    hipLaunchKernelGGL(k_dn_potrf, dim3(chains), dim3(256), 0, sp->stream, P, kb);
+    const int rem = nb - kb - 1;
+    if (rem > 0) {
+      hipLaunchKernelGGL(k_dn_trsm, dim3(rem, chains), dim3(256), 0, sp->stream, P, kb);
+      hipLaunchKernelGGL(k_dn_syrk, dim3(rem, rem, chains), dim3(256), 0, sp->stream, P, kb);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  int failed = 0;
+  HIP_TRY(hipMemcpyAsync(&failed, P.fail, 4, hipMemcpyDeviceToHost, sp->stream));
+  HIP_TRY(hipStreamSynchronize(sp->stream));
+  if (failed) return fail(POTUS_ERR_STATE, "the adapted covariance of a chain is not positive definite (window of %d draws)", n);
+  P.identity = 0;
+  int rc;
+  if ((rc = dense_init_stepsize(sp, iter))) return rc;
+  hipLaunchKernelGGL(k_dn_window_done, dim3((chains + 63) / 64), dim3(64), 0, sp->stream, P, (const RunParams *)sp->dR, (int)iter);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+// n_iter transitions of every chain of the handle
+int dense_run(Sampler *sp, int n_iter) {
+  DnParams &P = sp->dn;
+  const int chains = sp->R.chains, total = sp->R.num_warmup + sp->R.num_samples, cg = (chains + 63) / 64;
+  const int nw = sp->R.num_warmup, ib = sp->R.init_buffer, tb = sp->R.term_buffer;
+  std::vector<ChainScalars> sc;
+  int rc;
+  if ((rc = read_scalars(sp, sc))) return rc;
+  int it = sc[0].iter;
+  for (int k = 0; k < n_iter && it < total; k++, it++) {
+    int n_active = 0;
+    hipLaunchKernelGGL(k_dn_arm, dim3(cg), dim3(64), 0, sp->stream, P, (const RunParams *)sp->dR, total);
+    if ((rc = dense_sample_p(sp, (unsigned)it, RNG_MOMENTUM))) return rc;
+    if ((rc = dense_grad(sp))) return rc;                                // hamiltonian.init: gradient at the current point -> GC
+    hipLaunchKernelGGL(k_dn_begin, dn_grid(sp), dim3(256), 0, sp->stream, P, (const RunParams *)sp->dR);
+    if ((rc = dense_matvec(sp, 3))) return rc;
+    hipLaunchKernelGGL(k_dn_step, dim3(chains), dim3(DN_THREADS), 0, sp->stream, P, (const RunParams *)sp->dR, (unsigned)it, (int)DN_MODE_BEGIN);
+    HIP_TRY(hipGetLastError());
+    if ((rc = dense_sync(sp, &n_active, true))) return rc;
+    sp->mv_bytes += (long long)chains * sp->L.D * P.LD * 8;
+    while (n_active > 0) {
+      if ((rc = dense_grad(sp))) return rc;
+      hipLaunchKernelGGL(k_dn_kick, dn_grid(sp), dim3(256), 0, sp->stream, P);
+      if ((rc = dense_matvec(sp, 2))) return rc;
+      hipLaunchKernelGGL(k_dn_step, dim3(chains), dim3(DN_THREADS), 0, sp->stream, P, (const RunParams *)sp->dR, (unsigned)it, (int)DN_MODE_LEAF);
+      HIP_TRY(hipGetLastError());
+      sp->mv_bytes += (long long)n_active * sp->L.D * P.LD * 8;
+      sp->dn_rounds += 1;
+      if ((rc = dense_sync(sp, &n_active, true))) return rc;
+    }
+    // adapt_dense_e_nuts::transition: the warm-up schedule is the same for every chain, so the host keeps its own copy
+    int flags = 0;
+    const bool warm = it < nw;
+    if (warm && nw >= 20) {
+      const int wc = sp->dn_win_counter;
+      if (wc >= ib && wc < nw - tb && wc != nw) flags |= 1;
+      if (wc == sp->dn_win_next && wc != nw) flags |= 2;
+    }
+    hipLaunchKernelGGL(k_dn_end, dim3(chains), dim3(DN_THREADS), 0, sp->stream, P, (const RunParams *)sp->dR, it, flags, sp->dn_wf_n, total);
+    HIP_TRY(hipGetLastError());
+    if (flags & 1) sp->dn_wf_n += 1;
+    if (flags & 2) {
+      if ((rc = dense_window_end(sp, sp->dn_wf_n, (unsigned)it))) return rc;
+      const int last = nw - tb - 1;                                       // windowed_adaptation::compute_next_window
+      if (sp->dn_win_next != last) {
+        sp->dn_win_size *= 2;
+        sp->dn_win_next = sp->dn_win_counter + sp->dn_win_size;
+        if (sp->dn_win_next != last && sp->dn_win_next + 2 * sp->dn_win_size >= nw - tb) sp->dn_win_next = last;
+      }
+      sp->dn_wf_n = 0;
+    }
+    if (warm && nw >= 20) sp->dn_win_counter += 1;
+  }
+  HIP_TRY(hipStreamSynchronize(sp->stream));
+  return 0;
+}
+// potus_init of a dense-metric handle: k_init / k_cl_init have found the initial points and -- the metric being the
+// unit matrix, for which the diagonal and the dense sampler coincide -- the initial step sizes; the points move over
+int dense_import_init(Sampler *sp) {
+  hipLaunchKernelGGL(k_dn_import_q, dim3(64, sp->R.chains), dim3(256), 0, sp->stream, (const RunParams *)sp->dR, sp->dn,
+                     sp->K > 1 ? sp->CL.perm : (const int *)nullptr, sp->K > 1 ? sp->CL.Dint : 0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(sp->stream));
   return 0;
 }
 
@@ -1152,6 +1440,9 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
     for (void *p : sp->allocs) (void)hipFree(p);
     if (sp->ev0) (void)hipEventDestroy(sp->ev0);
     if (sp->ev1) (void)hipEventDestroy(sp->ev1);
+    if (sp->mv0) (void)hipEventDestroy(sp->mv0);
+    if (sp->mv1) (void)hipEventDestroy(sp->mv1);
+    if (sp->h_active) (void)hipHostFree(sp->h_active);
     if (sp->stream) (void)hipStreamDestroy(sp->stream);
     delete sp;
     return code;
@@ -1239,6 +1530,10 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   if (hipMalloc(&p, sizeof(RunParams)) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for run parameters failed"));
   sp->allocs.push_back(p); sp->dR = (RunParams *)p;
   if (hipMemcpy(p, &R, sizeof(RunParams), hipMemcpyHostToDevice) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "upload of run parameters failed"));
+  if (o->metric == POTUS_METRIC_DENSE) {
+    sp->dense = true;
+    if ((rc = dense_alloc(sp))) return bail(rc);
+  }
   std::lock_guard<std::mutex> lk(g_mu);
   size_t slot = 0;
   while (slot < g_handles.size() && g_handles[slot]) slot++;     // handles of destroyed samplers are reused
@@ -1254,6 +1549,9 @@ int potus_destroy(int handle) {
   (void)hipStreamSynchronize(sp->stream);
   for (void *p : sp->allocs) (void)hipFree(p);
   (void)hipEventDestroy(sp->ev0); (void)hipEventDestroy(sp->ev1); (void)hipStreamDestroy(sp->stream);
+  if (sp->mv0) (void)hipEventDestroy(sp->mv0);
+  if (sp->mv1) (void)hipEventDestroy(sp->mv1);
+  if (sp->h_active) (void)hipHostFree(sp->h_active);
   { std::lock_guard<std::mutex> lk(g_mu); g_handles[handle] = nullptr; }
   delete sp;
   return 0;
@@ -1321,6 +1619,7 @@ int potus_init(int handle, const double *q0) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(sp->stream));
   { const int rc_ = check_chains(sp); if (rc_) return rc_; }
+  if (sp->dense) { const int rc_ = dense_import_init(sp); if (rc_) return rc_; }
   sp->inited = true;
   return 0;
 }
@@ -1334,7 +1633,10 @@ int run_launch(RunTicket &t, int n_iter) {
   potus_total_leapfrogs(t.handle, &t.before);
   potus_iterations_done(t.handle, &t.it0);
   HIP_TRY(hipEventRecord(sp->ev0, sp->stream));
-  if (sp->K > 1) {
+  if (sp->dense) {   // a sequence of chip-wide launches driven from here (potus_dense.hpp); it ends synchronised
+    const int rc = dense_run(sp, n_iter);
+    if (rc) return rc;
+  } else if (sp->K > 1) {
     const unsigned lid = ++sp->launch_id;
     if (sp->cl_dw == 4)
       hipLaunchKernelGGL(k_cl_run<4>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
@@ -1407,6 +1709,11 @@ int potus_run_many(const int *handles, int n_handles, int n_iter) {
       if (done[i]) continue;
       Sampler *sp = todo[i].sp;
       auto it = std::find_if(used.begin(), used.end(), [&](const Use &u) { return u.device == sp->device; });
+      if (sp->dense) {   // chip-wide launches driven by the host: a group of its own
+        if (!group.empty()) continue;
+        group.push_back(i);
+        break;
+      }
       if (sp->K > 1) {
         int ncu = 0;
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, sp->device));
@@ -1472,7 +1779,10 @@ int potus_get_adaptation(int handle, double *stepsize, double *inv_metric) {
   { const int rc_ = read_scalars(sp, sc); if (rc_) return rc_; }
   for (int c = 0; c < sp->R.chains; c++) {
     if (stepsize) stepsize[c] = sc[c].nom_eps;
-    if (inv_metric) {
+    if (inv_metric && sp->dense) {   // the diagonal of the dense inverse metric
+      HIP_TRY(hipMemcpy2D(inv_metric + (size_t)c * sp->L.D, 8, sp->dn.Minv + (size_t)c * sp->L.D * sp->dn.LD, (size_t)(sp->dn.LD + 1) * 8, 8, (size_t)sp->L.D,
+                          hipMemcpyDeviceToHost));
+    } else if (inv_metric) {
       double *dst = inv_metric + (size_t)c * sp->L.D;
       if (sp->K == 1) HIP_TRY(hipMemcpy(dst, sp->R.state + ((size_t)c * V_COUNT + V_MINV) * sp->R.Dpad, (size_t)sp->L.D * 8, hipMemcpyDeviceToHost));
       if (sp->K > 1) {   // the cluster keeps its vectors in internal order (with padding)
@@ -1489,7 +1799,23 @@ int potus_get_dense_metric(int handle, int chain, double *inv_metric) {
   Sampler *sp = get(handle);
   if (!sp || !inv_metric) return fail(POTUS_ERR_STATE, "bad handle or null output");
   if (chain < 0 || chain >= sp->R.chains) return fail(POTUS_ERR_ARG, "chain %d out of range", chain);
-  return fail(POTUS_ERR_STATE, "the handle runs the diagonal metric: use potus_get_adaptation");
+  if (!sp->dense) return fail(POTUS_ERR_STATE, "the handle runs the diagonal metric: use potus_get_adaptation");
+  HIP_TRY(hipSetDevice(sp->device));
+  const size_t D = sp->L.D;
+  HIP_TRY(hipMemcpy2D(inv_metric, D * 8, sp->dn.Minv + (size_t)chain * D * sp->dn.LD, (size_t)sp->dn.LD * 8, D * 8, D, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// Dense metric: time spent in the matrix passes (k_dn_matvec, HIP events on the sampler's stream), their number and
+// the bytes of matrix they streamed (active chains x D x LD x 8 per pass), since the handle was created.
+int potus_dense_timing(int handle, double *matvec_ms, long long *passes, long long *bytes, long long *rounds) {
+  Sampler *sp = get(handle);
+  if (!sp || !sp->dense) return fail(POTUS_ERR_STATE, "bad handle or not a dense-metric sampler");
+  if (matvec_ms) *matvec_ms = sp->mv_ms;
+  if (passes) *passes = sp->mv_calls;
+  if (bytes) *bytes = sp->mv_bytes;
+  if (rounds) *rounds = sp->dn_rounds;
+  return 0;
 }
 
 static int saved_count(Sampler *sp, int *n_saved) {
@@ -1705,8 +2031,8 @@ int potus_write_stan_csv(int handle, const char *dir, const char *basename) {
             o.num_samples, o.num_warmup, o.save_warmup);
     fprintf(f, "#     adapt\n#       engaged = 1 (Default)\n#       gamma = %g\n#       delta = %g\n#       kappa = %g\n#       t0 = %g\n#       init_buffer = %d\n#       term_buffer = %d\n#       window = %d\n",
             o.gamma, o.delta, o.kappa, o.t0, sp->R.init_buffer, sp->R.term_buffer, sp->R.window);
-    fprintf(f, "#     algorithm = hmc (Default)\n#       hmc\n#         engine = nuts (Default)\n#           nuts\n#             max_depth = %d\n#         metric = diag_e (Default)\n#         metric_file =  (Default)\n#         stepsize = %g\n#         stepsize_jitter = 0 (Default)\n",
-            o.max_depth, o.stepsize);
+    fprintf(f, "#     algorithm = hmc (Default)\n#       hmc\n#         engine = nuts (Default)\n#           nuts\n#             max_depth = %d\n#         metric = %s\n#         metric_file =  (Default)\n#         stepsize = %g\n#         stepsize_jitter = 0 (Default)\n",
+            o.max_depth, sp->dense ? "dense_e" : "diag_e (Default)", o.stepsize);
     fprintf(f, "# id = %d\n# data\n#   file = (in-memory)\n# init = %g\n# random\n#   seed = %llu\n# output\n#   file = %s\n#   diagnostic_file =  (Default)\n#   refresh = 100 (Default)\n",
             sp->R.chain_id_offset + c + 1, o.init_radius, (unsigned long long)o.seed, path.c_str());
     char name[96];
@@ -1717,6 +2043,15 @@ int potus_write_stan_csv(int handle, const char *dir, const char *basename) {
   // warm-up rows with it
   auto adaptation_block = [&](int c) {
     FILE *f = fp[c];
+    if (sp->dense) {   // CmdStan: "# Elements of inverse mass matrix:" and D rows of D values
+      fprintf(f, "# Adaptation terminated\n# Step size = %.6g\n# Elements of inverse mass matrix:\n", eps[c]);
+      if (D <= 2048) {
+        std::vector<double> mm((size_t)D * D);
+        if (potus_get_dense_metric(handle, c, mm.data()) == 0)
+          for (int i = 0; i < D; i++) { fprintf(f, "# "); for (int j = 0; j < D; j++) fprintf(f, j ? ", %.6g" : "%.6g", mm[(size_t)i * D + j]); fprintf(f, "\n"); }
+      } else fprintf(f, "# (%d x %d matrix omitted from the CSV: potus_get_dense_metric returns it)\n", D, D);
+      return;
+    }
     fprintf(f, "# Adaptation terminated\n# Step size = %.6g\n# Diagonal elements of inverse mass matrix:\n# ", eps[c]);
     for (int i = 0; i < D; i++) fprintf(f, i ? ", %.6g" : "%.6g", minv[(size_t)c * D + i]);
     fprintf(f, "\n");
@@ -1757,65 +2092,134 @@ int potus_debug_profile(int handle, double *out) {
   return PT_NPROF;
 }
 
-// Development entry point (not in include/potus_hmc.h): y = M^-1 p for `chains` dense inverse metrics of size D x D on
-// `device` (potus_dense.hpp).  Minv_host == NULL: the matrices are generated on the device (k_dense_fill) -- for rates
-// at sizes whose matrices would take seconds to upload.  Runs the kernel `reps` times; y_host [chains][D] receives the
-// result, *ms the average kernel time (HIP events).  Returns 0 or a POTUS_ERR_* code.
-int potus_dense_matvec_probe(int device, int chains, int D, const double *Minv_host, const double *p_host, double *y_host, int reps, double *ms) {
-  if (chains < 1 || D < 1 || !p_host || !y_host || reps < 1) return fail(POTUS_ERR_ARG, "potus_dense_matvec_probe: bad arguments");
-  HIP_TRY(hipSetDevice(device));
-  const size_t nM = (size_t)chains * D * D, nv = (size_t)chains * D;
-  double *dM = nullptr, *dp = nullptr, *dy = nullptr;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  auto cleanup = [&]() { if (dM) (void)hipFree(dM); if (dp) (void)hipFree(dp); if (dy) (void)hipFree(dy); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); };
-  if (hipMalloc((void **)&dM, nM * 8) != hipSuccess || hipMalloc((void **)&dp, nv * 8) != hipSuccess || hipMalloc((void **)&dy, nv * 8) != hipSuccess) {
-    cleanup();
-    return fail(POTUS_ERR_DEVICE, "potus_dense_matvec_probe: hipMalloc of %zu bytes failed", nM * 8);
+// Development entry points (not in include/potus_hmc.h) that run single pieces of the dense-metric path on caller data,
+// so that each can be checked against numpy and timed on its own (tests/test_gpu_dense.py, scripts/micro/dense_probe.py).
+namespace {
+struct DenseProbe {   // a DnParams with every chain active, owned buffers
+  DnParams P{};
+  DevBufs bufs;
+  int init(int device, int chains, int D, int win_cap) {
+    HIP_TRY(hipSetDevice(device));
+    P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_ROWS - 1) / DN_ROWS; P.sc_stride = 1; P.win_cap = win_cap; P.identity = 0;
+    const size_t mat = (size_t)chains * D * P.LD * 8;
+    HIP_TRY(bufs.alloc(&P.state, (size_t)chains * DV_COUNT * P.LD * 8)); HIP_TRY(bufs.alloc(&P.Minv, mat)); HIP_TRY(bufs.alloc(&P.Lc, mat));
+    HIP_TRY(bufs.alloc(&P.win, (size_t)chains * std::max(win_cap, 1) * P.LD * 8)); HIP_TRY(bufs.alloc(&P.partial, (size_t)chains * P.npart * 8));
+    HIP_TRY(bufs.alloc(&P.lpbuf, (size_t)chains * 8)); HIP_TRY(bufs.alloc(&P.ts, (size_t)chains * sizeof(TS)));
+    HIP_TRY(bufs.alloc(&P.rd, (size_t)chains * sizeof(DnRound))); HIP_TRY(bufs.alloc(&P.active, (size_t)chains * 4)); HIP_TRY(bufs.alloc(&P.fail, 4));
+    HIP_TRY(hipMemset(P.state, 0, (size_t)chains * DV_COUNT * P.LD * 8)); HIP_TRY(hipMemset(P.Minv, 0, mat)); HIP_TRY(hipMemset(P.Lc, 0, mat));
+    HIP_TRY(hipMemset(P.fail, 0, 4));
+    return 0;
   }
-  if (Minv_host) { if (hipMemcpy(dM, Minv_host, nM * 8, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(POTUS_ERR_DEVICE, "upload failed"); } }
-  else hipLaunchKernelGGL(k_dense_fill, dim3(4096), dim3(256), 0, 0, dM, D, chains);
-  if (hipMemcpy(dp, p_host, nv * 8, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(POTUS_ERR_DEVICE, "upload failed"); }
-  const size_t lds = (size_t)PD_TILE * 8;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_matvec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-      hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { cleanup(); return fail(POTUS_ERR_DEVICE, "setup failed"); }
-  const dim3 grid((D + PD_ROWS - 1) / PD_ROWS, chains);
-  hipLaunchKernelGGL(k_dense_matvec, grid, dim3(PD_THREADS), lds, 0, (const double *)dM, (const double *)dp, dy, D);   // warm-up
-  (void)hipEventRecord(e0, 0);
-  for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_dense_matvec, grid, dim3(PD_THREADS), lds, 0, (const double *)dM, (const double *)dp, dy, D);
-  (void)hipEventRecord(e1, 0);
-  if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { cleanup(); return fail(POTUS_ERR_DEVICE, "k_dense_matvec failed"); }
-  float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
-  if (ms) *ms = (double)t / reps;
-  const bool ok = hipMemcpy(y_host, dy, nv * 8, hipMemcpyDeviceToHost) == hipSuccess;
-  cleanup();
-  return ok ? 0 : fail(POTUS_ERR_DEVICE, "download failed");
+  int set_rounds(const std::vector<DnRound> &r) { HIP_TRY(hipMemcpy(P.rd, r.data(), r.size() * sizeof(DnRound), hipMemcpyHostToDevice)); return 0; }
+};
 }
 
-// Development entry point: `reps` Welford covariance updates m2 += a delta' (k_dense_welford) on a zeroed m2 of
-// `chains` x D x D; M2_host (or NULL) receives the result, *ms the average kernel time.
-int potus_dense_welford_probe(int device, int chains, int D, const double *a_host, const double *delta_host, double *M2_host, int reps, double *ms) {
-  if (chains < 1 || D < 1 || !a_host || !delta_host || reps < 1) return fail(POTUS_ERR_ARG, "potus_dense_welford_probe: bad arguments");
-  HIP_TRY(hipSetDevice(device));
-  const size_t nM = (size_t)chains * D * D, nv = (size_t)chains * D;
-  double *dM = nullptr, *da = nullptr, *dd = nullptr;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  auto cleanup = [&]() { if (dM) (void)hipFree(dM); if (da) (void)hipFree(da); if (dd) (void)hipFree(dd); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); };
-  if (hipMalloc((void **)&dM, nM * 8) != hipSuccess || hipMalloc((void **)&da, nv * 8) != hipSuccess || hipMalloc((void **)&dd, nv * 8) != hipSuccess ||
-      hipMemset(dM, 0, nM * 8) != hipSuccess || hipMemcpy(da, a_host, nv * 8, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(dd, delta_host, nv * 8, hipMemcpyHostToDevice) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
-    cleanup();
-    return fail(POTUS_ERR_DEVICE, "potus_dense_welford_probe: device setup failed (%zu bytes)", nM * 8);
+// y_r = M^-1 x_r (r < nrhs <= 3) for `chains` dense inverse metrics of size D x D.  Minv_host == NULL: the matrices are
+// generated on the device (k_dn_fill) -- for rates at sizes whose matrices would take seconds to upload.  Runs the kernel
+// `reps` times; x_host / y_host are [chains][nrhs][D]; dot_host [chains] receives x_0 . M^-1 x_0; *ms the average
+// kernel time (HIP events).
+int potus_dense_matvec_probe(int device, int chains, int D, int nrhs, const double *Minv_host, const double *x_host, double *y_host, double *dot_host, int reps, double *ms) {
+  if (chains < 1 || D < 1 || nrhs < 1 || nrhs > 3 || !x_host || !y_host || reps < 1) return fail(POTUS_ERR_ARG, "potus_dense_matvec_probe: bad arguments");
+  DenseProbe pr;
+  int rc = pr.init(device, chains, D, 1);
+  if (rc) return rc;
+  DnParams &P = pr.P;
+  if (Minv_host) HIP_TRY(hipMemcpy2D(P.Minv, (size_t)P.LD * 8, Minv_host, (size_t)D * 8, (size_t)D * 8, (size_t)chains * D, hipMemcpyHostToDevice));
+  else hipLaunchKernelGGL(k_dn_fill, dim3(4096), dim3(256), 0, 0, P);
+  std::vector<DnRound> rds(chains);
+  for (int c = 0; c < chains; c++) {
+    DnRound &r = rds[c];
+    std::memset(&r, 0, sizeof r);
+    r.active = 1;
+    for (int k = 0; k < 3; k++) r.job[k] = DnJob{DV_POOLP + k, DV_POOLPS + k, -1, -1, k == 0 ? DV_POOLP : -1, 0, 0.0};
+    for (int k = 0; k < nrhs; k++)
+      HIP_TRY(hipMemcpy(P.state + ((size_t)c * DV_COUNT + DV_POOLP + k) * P.LD, x_host + ((size_t)c * nrhs + k) * D, (size_t)D * 8, hipMemcpyHostToDevice));
   }
-  const dim3 grid((D + 7) / 8, chains);
+  if ((rc = pr.set_rounds(rds))) return rc;
+  for (const void *f : {reinterpret_cast<const void *>(k_dn_matvec<1>), reinterpret_cast<const void *>(k_dn_matvec<2>), reinterpret_cast<const void *>(k_dn_matvec<3>)})
+    HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DN_LDS_DOUBLES * 8));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  const dim3 grid((unsigned)P.npart, (unsigned)chains);
+  auto launch = [&]() {
+    if (nrhs == 1) hipLaunchKernelGGL(k_dn_matvec<1>, grid, dim3(DN_THREADS), DN_LDS_DOUBLES * 8, 0, P);
+    else if (nrhs == 2) hipLaunchKernelGGL(k_dn_matvec<2>, grid, dim3(DN_THREADS), DN_LDS_DOUBLES * 8, 0, P);
+    else hipLaunchKernelGGL(k_dn_matvec<3>, grid, dim3(DN_THREADS), DN_LDS_DOUBLES * 8, 0, P);
+  };
+  launch();   // warm-up
   (void)hipEventRecord(e0, 0);
-  for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_dense_welford, grid, dim3(256), 0, 0, dM, (const double *)da, (const double *)dd, D);
+  for (int r = 0; r < reps; r++) launch();
   (void)hipEventRecord(e1, 0);
-  if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { cleanup(); return fail(POTUS_ERR_DEVICE, "k_dense_welford failed"); }
+  const bool ok = hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;
   float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (!ok) return fail(POTUS_ERR_DEVICE, "k_dn_matvec failed");
   if (ms) *ms = (double)t / reps;
-  const bool ok = !M2_host || hipMemcpy(M2_host, dM, nM * 8, hipMemcpyDeviceToHost) == hipSuccess;
-  cleanup();
-  return ok ? 0 : fail(POTUS_ERR_DEVICE, "download failed");
+  for (int c = 0; c < chains; c++) {
+    for (int k = 0; k < nrhs; k++)
+      HIP_TRY(hipMemcpy(y_host + ((size_t)c * nrhs + k) * D, P.state + ((size_t)c * DV_COUNT + DV_POOLPS + k) * P.LD, (size_t)D * 8, hipMemcpyDeviceToHost));
+    if (dot_host) {
+      std::vector<double> part(P.npart);
+      HIP_TRY(hipMemcpy(part.data(), P.partial + (size_t)c * P.npart, (size_t)P.npart * 8, hipMemcpyDeviceToHost));
+      double t2 = 0; for (double v : part) t2 += v;
+      dot_host[c] = t2;
+    }
+  }
+  return 0;
+}
+
+// covar_adaptation on caller data: draws [chains][n][D] -> M^-1 (covariance of the window, regularised), its lower
+// Cholesky factor, and p = L^-T u for u [chains][D] (the momentum draw's triangular solve).  Outputs [chains][D][D] /
+// [chains][D]; ms[3] = covariance, factorisation, solve (milliseconds).
+int potus_dense_factor_probe(int device, int chains, int D, int n, const double *draws_host, const double *u_host, double *Minv_host, double *L_host,
+                             double *p_host, double *ms) {
+  if (chains < 1 || D < 1 || n < 2 || !draws_host) return fail(POTUS_ERR_ARG, "potus_dense_factor_probe: bad arguments");
+  DenseProbe pr;
+  int rc = pr.init(device, chains, D, n);
+  if (rc) return rc;
+  DnParams &P = pr.P;
+  HIP_TRY(hipMemcpy2D(P.win, (size_t)P.LD * 8, draws_host, (size_t)D * 8, (size_t)D * 8, (size_t)chains * n, hipMemcpyHostToDevice));
+  std::vector<DnRound> rds(chains);
+  for (auto &r : rds) { std::memset(&r, 0, sizeof r); r.active = 1; }
+  if ((rc = pr.set_rounds(rds))) return rc;
+  hipEvent_t ev[4];
+  for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+  const int nb = (D + DN_NB - 1) / DN_NB;
+  const dim3 eg((unsigned)std::min((D + 255) / 256, 64), (unsigned)chains);
+  (void)hipEventRecord(ev[0], 0);
+  hipLaunchKernelGGL(k_dn_center, eg, dim3(256), 0, 0, P, n);
+  hipLaunchKernelGGL(k_dn_cov, dim3(nb, nb, chains), dim3(256), 0, 0, P, n);
+  (void)hipEventRecord(ev[1], 0);
+  HIP_TRY(hipMemcpyAsync(P.Lc, P.Minv, (size_t)chains * D * P.LD * 8, hipMemcpyDeviceToDevice, 0));
+  for (int kb = 0; kb < nb; kb++) {
+    hipLaunchKernelGGL(k_dn_potrf, dim3(chains), dim3(256), 0, 0, P, kb);
+    const int rem = nb - kb - 1;
+    if (rem > 0) {
+      hipLaunchKernelGGL(k_dn_trsm, dim3(rem, chains), dim3(256), 0, 0, P, kb);
+      hipLaunchKernelGGL(k_dn_syrk, dim3(rem, rem, chains), dim3(256), 0, 0, P, kb);
+    }
+  }
+  (void)hipEventRecord(ev[2], 0);
+  if (u_host && p_host) {
+    for (int c = 0; c < chains; c++) HIP_TRY(hipMemcpy(P.state + ((size_t)c * DV_COUNT + DV_P0) * P.LD, u_host + (size_t)c * D, (size_t)D * 8, hipMemcpyHostToDevice));
+    for (int b = nb - 1; b >= 0; b--) {
+      hipLaunchKernelGGL(k_dn_trsv_diag, dim3(chains), dim3(64), 0, 0, P, b);
+      if (b > 0) hipLaunchKernelGGL(k_dn_trsv_update, dim3((b * DN_NB + 255) / 256, chains), dim3(256), 0, 0, P, b);
+    }
+  }
+  (void)hipEventRecord(ev[3], 0);
+  const bool ok = hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;
+  if (ms) for (int k = 0; k < 3; k++) { float t = 0; (void)hipEventElapsedTime(&t, ev[k], ev[k + 1]); ms[k] = t; }
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  if (!ok) return fail(POTUS_ERR_DEVICE, "dense factor kernels failed");
+  int failed = 0;
+  HIP_TRY(hipMemcpy(&failed, P.fail, 4, hipMemcpyDeviceToHost));
+  if (failed) return fail(POTUS_ERR_STATE, "covariance not positive definite");
+  if (Minv_host) HIP_TRY(hipMemcpy2D(Minv_host, (size_t)D * 8, P.Minv, (size_t)P.LD * 8, (size_t)D * 8, (size_t)chains * D, hipMemcpyDeviceToHost));
+  if (L_host) HIP_TRY(hipMemcpy2D(L_host, (size_t)D * 8, P.Lc, (size_t)P.LD * 8, (size_t)D * 8, (size_t)chains * D, hipMemcpyDeviceToHost));
+  if (u_host && p_host)
+    for (int c = 0; c < chains; c++) HIP_TRY(hipMemcpy(p_host + (size_t)c * D, P.state + ((size_t)c * DV_COUNT + DV_P0) * P.LD, (size_t)D * 8, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 // Development aid: the whole state block [chains][V_COUNT][Dpad] (internal element order) and every replica of the

@@ -223,6 +223,14 @@ class Handle:
         _check(self.L, self.L.potus_write_array_device(self.h, col_begin, col_end, C.c_void_p(out_tensor.data_ptr())))
         return out_tensor
 
+    def dense_timing(self):
+        """metric = dense_e: (milliseconds in k_dn_matvec, matrix passes, bytes of matrix streamed, leaf rounds) so far."""
+        L = self.L
+        L.potus_dense_timing.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        ms, n, b, r = C.c_double(), C.c_longlong(), C.c_longlong(), C.c_longlong()
+        _check(L, L.potus_dense_timing(self.h, C.byref(ms), C.byref(n), C.byref(b), C.byref(r)))
+        return ms.value, n.value, b.value, r.value
+
     def dense_metric(self, chain=0):
         """metric = dense_e: the adapted D x D inverse metric of one chain."""
         out = np.zeros((self.D, self.D))
