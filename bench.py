@@ -145,7 +145,7 @@ def load_workloads(cfg, chains_per_gpu):
                 for y, v in (("2008", "no_mode_adjustment"), ("2012", "no_mode_adjustment"), ("2016", "full"))]
     if cfg == 4:
         from us_potus_model_amd import _abi
-        return [("stress", synthetic.stress(), "full", chains_per_gpu or 4, {"metric": _abi.METRIC_DENSE})]
+        return [("stress", synthetic.stress(), "full", chains_per_gpu or 16, {"metric": _abi.METRIC_DENSE})]
     raise SystemExit(f"unknown --config {cfg}")
 
 
@@ -157,7 +157,7 @@ def main():
     ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs[] index: 1 (default), 2, 3, 4")
     ap.add_argument("--chains-per-gpu", type=int, default=0, help="per posterior (0 = the configuration's: 8, 8, 4, 4)")
     ap.add_argument("--cus-per-chain", type=int, default=0, help="workgroups per chain (0 = auto: 16, 8 or 1 by what fits)")
-    ap.add_argument("--chunk", type=int, default=0, help="transitions per step (0 = the configuration's: 100; 10 for --config 4)")
+    ap.add_argument("--chunk", type=int, default=0, help="transitions per step (0 = the configuration's: 100; 1 for --config 4)")
     ap.add_argument("--seed", type=int, default=1843)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturated", action="store_true", help="skip the 256-chain reference point")
@@ -181,15 +181,23 @@ def main():
     coll_dev = None if dev_backend == "gloo" else dev       # collectives on CPU tensors in the development mode
 
     cfg = args.config
-    chunk = args.chunk or (10 if cfg == 4 else 100)
+    chunk = args.chunk or (1 if cfg == 4 else 100)
     work = load_workloads(cfg, args.chains_per_gpu)
     nw, ns = (args.steps // 2) * chunk, (args.steps - args.steps // 2) * chunk
 
     def make(seed, num_warmup, num_samples):
         hs = []
-        for _, data, variant, C, extra in work:
-            hs.append(Handle(data, variant, chains=C, chain_id_offset=rank * C, num_warmup=num_warmup, num_samples=num_samples,
-                             seed=seed, device=local, cus_per_chain=args.cus_per_chain, **extra))
+        for i, (name, data, variant, C, extra) in enumerate(work):
+            while True:
+                try:
+                    hs.append(Handle(data, variant, chains=C, chain_id_offset=rank * C, num_warmup=num_warmup, num_samples=num_samples,
+                                     seed=seed, device=local, cus_per_chain=args.cus_per_chain, **extra))
+                    break
+                except Exception as e:      # the dense metric keeps two D x D matrices per chain: as many chains as the HBM holds
+                    if cfg != 4 or args.chains_per_gpu or C <= 1 or "GB free" not in str(e):
+                        raise
+                    C -= 1
+            work[i] = (name, data, variant, C, extra)
         return hs
 
     if args.warmup > 0:  # untimed: throw-away samplers
@@ -239,6 +247,7 @@ def main():
 
     elapsed = parallel.max_over_ranks(t1 - t0, coll_dev)
     lf_local = [h.total_leapfrogs() for h in hs]
+    dense_t = hs[0].dense_timing() if cfg == 4 else None
     leapfrogs = parallel.sum_over_ranks(float(sum(lf_local)), coll_dev)
     kernel_ms_max = parallel.max_over_ranks(kernel_ms, coll_dev)
     samp_time = parallel.max_over_ranks(t1 - (t_warm_end or t0), coll_dev)
@@ -263,6 +272,8 @@ def main():
         bpl = [algorithmic_bytes_per_leapfrog(d, v, dense) for _, d, v, _, _ in work]
         alg_bytes = float(sum(b * n for b, n in zip(bpl, lf_local)))
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9            # this rank's launches, events on the samplers' own streams
+        if dense:   # the dominant kernel is the matrix pass: bytes of matrix it streamed / its own time (HIP events around every launch)
+            achieved = dense_t[2] / (dense_t[0] * 1e-3) / 1e9
         K = hs[0].cus_per_chain
         kernel = "k_dn_matvec" if dense else ("k_cl_run" if K > 1 else "k_run")
         tr = measured_traffic(kernel)
@@ -296,6 +307,8 @@ def main():
                                           f"uncalibrated) x this run's leapfrogs / launch time" if tr else "no PMC pass committed for this kernel"),
                          "kernel": kernel, "algorithmic_bytes_per_leapfrog": bpl if len(bpl) > 1 else bpl[0],
                          "leapfrogs_in_launches": int(sum(lf_local)), "launch_ms_total": kernel_ms,
+                         **({"matrix_passes": dense_t[1], "matrix_pass_ms_total": dense_t[0], "matrix_bytes_streamed": dense_t[2],
+                             "avg_pass_ms": dense_t[0] / max(dense_t[1], 1), "leaf_rounds": dense_t[3]} if dense else {}),
                          "note": (f"latency-bound at {C_tot} chains ({C_tot * K} of 256 CUs busy): the state of a chain stays in L2, a leapfrog "
                                   "is a chain of dependent phases and exchanges between the CUs of a cluster; see DESIGN.md") if not dense else
                                  "dense metric: every leapfrog streams the chain's D x D inverse metric"},

@@ -212,6 +212,11 @@ int potus_backtest_scores(const double *state_out, int T, int S, int day, const 
  * sampler's own stream: elapsed milliseconds and leapfrogs executed in it. */
 int potus_last_run_timing(int handle, double *ms, long long *leapfrogs);
 
+/* Dense metric only: milliseconds spent in the matrix passes (k_dn_matvec: M^-1 times the momenta of a leaf, HIP events on
+ * the sampler's stream), their number, the bytes of matrix they streamed (active chains x D x LD x 8 each) and the
+ * number of leaf rounds, since potus_create. */
+int potus_dense_timing(int handle, double *matvec_ms, long long *passes, long long *bytes, long long *rounds);
+
 /* ---- .C()-callable wrappers (int* / double* / char** only) ---- */
 void potus_R_create(int *dims /*[8]: N_nat,N_state,T,S,P,M,Pop,variant*/,
                     int *state, int *day_state, int *day_national, int *poll_state,

@@ -1,0 +1,90 @@
+"""Dense-metric path (potus_dense.hpp) on the GPU box: rates of its pieces and of the sampler.
+
+  python scripts/micro/dense_probe.py pieces             matrix pass (1-3 right-hand sides), covariance, Cholesky, solve
+  python scripts/micro/dense_probe.py sampler C N [cus]  2016 posterior, C chains, N warm-up iterations, dense metric
+  python scripts/micro/dense_probe.py stress C N         the same on the configs[4] shape (D = 41 610)
+
+Matrices of `pieces` are generated on the device; bytes of a matrix pass = chains x D x LD x 8.
+"""
+import ctypes as C
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+from us_potus_model_amd import Handle, _abi, dataprep, sampler, synthetic  # noqa: E402
+
+L = sampler.load_library()
+DP = C.POINTER(C.c_double)
+L.potus_dense_matvec_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, DP]
+L.potus_dense_factor_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, DP]
+
+
+def err():
+    buf = C.create_string_buffer(512)
+    L.potus_last_error(buf, 512)
+    return buf.value.decode()
+
+
+def pieces():
+    for chains, D, nrhs in ((1, 15098, 1), (1, 15098, 2), (8, 15098, 2), (8, 15098, 3), (1, 41610, 2), (4, 41610, 2)):
+        x = np.random.default_rng(1).standard_normal((chains, nrhs, D))
+        y, ms = np.zeros((chains, nrhs, D)), C.c_double()
+        rc = L.potus_dense_matvec_probe(0, chains, D, nrhs, None, x.ctypes.data, y.ctypes.data, None, 5, C.byref(ms))
+        if rc:
+            print(f"chains={chains} D={D}: error {rc}: {err()}")
+            continue
+        ok = True                                        # spot check of a few rows against the generator's formula
+        for c in (0, chains - 1):
+            for i in (0, D // 3, D - 1):
+                j = np.arange(D)
+                row = np.exp(-np.abs(i - j) / 50.0) * (1.0 + 0.1 * c) + (j == i)
+                ok &= abs(row @ x[c, nrhs - 1] - y[c, nrhs - 1, i]) <= 1e-10 * max(1.0, abs(y[c, nrhs - 1, i]))
+        gb = chains * D * ((D + 7) & ~7) * 8 / 1e9
+        print(f"matrix pass chains={chains} D={D} nrhs={nrhs}: {ms.value:.3f} ms, {gb / (ms.value * 1e-3):.0f} GB/s = {gb / (ms.value * 1e-3) / 8000:.2f} of 8 TB/s; "
+              f"rows check {'ok' if ok else 'MISMATCH'}", flush=True)
+    for chains, D, n in ((1, 15098, 100), (4, 15098, 500), (1, 41610, 100)):
+        rng = np.random.default_rng(2)
+        draws = rng.standard_normal((chains, n, D))
+        u = rng.standard_normal((chains, D))
+        p, ms = np.zeros((chains, D)), (C.c_double * 3)()
+        t = time.time()
+        rc = L.potus_dense_factor_probe(0, chains, D, n, draws.ctypes.data, u.ctypes.data, None, None, p.ctypes.data, ms)
+        if rc:
+            print(f"factor chains={chains} D={D}: error {rc}: {err()}")
+            continue
+        fl_cov, fl_chol = 2.0 * chains * D * D / 2 * n, chains * D ** 3 / 3.0
+        print(f"window end chains={chains} D={D} n={n}: covariance {ms[0]:.1f} ms ({fl_cov / ms[0] / 1e9:.1f} TFLOP/s), Cholesky {ms[1]:.1f} ms "
+              f"({fl_chol / ms[1] / 1e9:.1f} TFLOP/s), solve {ms[2]:.2f} ms; wall {time.time() - t:.1f} s", flush=True)
+
+
+def run_sampler(data, variant, chains, iters, cus):
+    h = Handle(data, variant, chains=chains, num_warmup=iters, num_samples=0, seed=1843, metric=_abi.METRIC_DENSE, cus_per_chain=cus)
+    h.init()
+    t0 = time.perf_counter()
+    h.run(iters)
+    wall = time.perf_counter() - t0
+    ms, passes, nbytes, rounds = h.dense_timing()
+    lf = h.total_leapfrogs()
+    out = dict(chains=chains, iterations=iters, D=h.D, cus_per_chain=h.cus_per_chain, leapfrogs=lf, wall_s=wall, leapfrogs_per_s=lf / wall,
+               matvec_ms=ms, matvec_passes=passes, matvec_gb=nbytes / 1e9, matvec_tb_per_s=nbytes / ms / 1e9, matvec_frac_of_8tbs=nbytes / ms / 1e9 / 8.0,
+               rounds=rounds, ms_per_round=1e3 * wall / max(rounds, 1), matvec_share_of_wall=ms * 1e-3 / wall)
+    h.close()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "pieces"
+    if what == "pieces":
+        pieces()
+    else:
+        chains, iters = int(sys.argv[2]), int(sys.argv[3])
+        cus = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+        if what == "sampler":
+            run_sampler(dataprep.load_npz(ROOT / "tests" / "golden" / "data_2016.npz")["data"], "full", chains, iters, cus)
+        else:
+            run_sampler(synthetic.stress(), "full", chains, iters, cus)

@@ -86,7 +86,7 @@ EXPORTS = [
     "potus_version", "potus_last_error", "potus_default_opts", "potus_num_params", "potus_num_columns",
     "potus_column_name", "potus_create", "potus_destroy", "potus_cus_per_chain", "potus_log_prob_grad", "potus_init", "potus_run", "potus_run_many",
     "potus_iterations_done", "potus_total_leapfrogs", "potus_chain_status", "potus_get_adaptation",
-    "potus_get_dense_metric", "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_array_device", "potus_write_stan_csv",
+    "potus_get_dense_metric", "potus_dense_timing", "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_array_device", "potus_write_stan_csv",
     "potus_last_run_timing", "potus_posterior_summary", "potus_posterior_summary_many", "potus_backtest_scores",
     "potus_R_create", "potus_R_init", "potus_R_run", "potus_R_run_many", "potus_R_num_columns", "potus_R_saved_count",
     "potus_R_write_array", "potus_R_write_stan_csv", "potus_R_posterior_summary", "potus_R_backtest_scores", "potus_R_last_error", "potus_R_destroy",
