@@ -1,14 +1,14 @@
 // potus_model.hpp -- device-side log-density + gradient of the poll model for gfx950.
 //
-// One 1024-thread workgroup (16 wave64) evaluates log_prob and its gradient for ONE chain.
+// One 512-thread workgroup (8 wave64: PT_NW, two waves per SIMD) evaluates log_prob and its gradient for ONE chain.
 // The model is scripts/model/poll_model_2020.stan:56-131 (and the no_mode_adjustment
 // variant), re-derived for the hardware instead of transcribed:
 //
 //  * the T-1 dependent 51x51 mat-vecs of stan:86 become a suffix sum over days,
 //      mu_b[:,t] = (L_T z_T + prior) + L_W * C[:,t],  C[:,t] = sum_{u=t}^{T-2} Z[:,u]
-//    held in LDS as C[k][t]; wave w owns days [16w,16w+16), lane k owns state k, so the S x T
+//    held in LDS as C[k][t]; wave w owns days [PT_CH w, PT_CH (w+1)) (PT_CH = 32), lane k owns state k, so the S x T
 //    block is read from HBM/L2 with lanes on consecutive addresses (coalesced) and scanned in
-//    registers with one 16-entry carry exchange through LDS;
+//    registers with one carry exchange (one entry per wave) through LDS;
 //  * mu_b is only needed at polled (state,day) cells: one thread per poll does the 51-term
 //    dot  L_W[s,:] . C[:,t]  out of LDS (national polls use the extra row v = L_W^T w);
 //  * the adjoint is the mirror image: per-day gathers  gC[:,t] = sum_i r_i L_W[s_i,:]  (one

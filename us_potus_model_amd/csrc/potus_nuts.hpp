@@ -1,6 +1,6 @@
 // potus_nuts.hpp -- device-resident NUTS with windowed diagonal-metric adaptation.
 //
-// One 1024-thread workgroup runs ONE chain for any number of transitions without returning
+// One 512-thread workgroup (8 wave64, PT_NW) runs ONE chain for any number of transitions without returning
 // to the host: momentum refresh, leapfrogs (fused with the model pass), the multinomial
 // tree with Stan's generalised U-turn checks, step-size dual averaging, Welford variance
 // windows and the step-size re-initialisation all happen inside the kernel.  Chains never
@@ -215,7 +215,7 @@ __device__ __forceinline__ int pool_alloc(unsigned &mask, int n) {
 __device__ __forceinline__ void pool_free(unsigned &mask, int i) { if (i >= 0) mask &= ~(1u << i); }
 
 // ---------------------------------------------------------------- block-wide vector sweeps (all end with a barrier)
-// Each thread handles elements tid, tid+1024, ...; four elements are in flight per trip so the
+// Each thread handles elements tid, tid+PT_THREADS, ...; PT_UNR elements are in flight per trip so the
 // loads of a trip are issued together (the sweeps are latency-, not bandwidth-limited).
 #define PT_UNR 8
 __device__ __forceinline__ int fresh_tid(const Chain &c) { // keeps per-thread index math inside the loop it belongs to
