@@ -178,13 +178,24 @@ def test_adaptation_matches_oracle_through_a_metric_update(cases, cus):
     eps, minv = h.adaptation()
     m = OracleModel(data, variant)
     ref, ad, nl = m.sample_chain(1, m.default_opts(num_warmup=nw, num_samples=0, save_warmup=1, seed=11, fast_grad=1))
-    # chaos amplifies rounding differences over thousands of leapfrogs, so compare what is robust:
     k = 20
     assert np.array_equal(d[:k, 3:6], ref[:k, 3:6]) and np.allclose(d[:k, 2], ref[:k, 2], rtol=1e-6)
-    assert abs(np.log(eps[0] / ad[0])) < 0.5
+    # the metric update itself, exactly: with 150 warm-up iterations there is one window (draws 75 .. 99), and the inverse
+    # metric must be var_adaptation's regularised sample variance of the very draws the sampler saved
+    w = d[75:100, 7:]
+    want = (25 / 30.0) * w.var(axis=0, ddof=1) + 1e-3 * (5 / 30.0)
+    assert np.allclose(minv[0], want, rtol=1e-10, atol=0), np.abs(minv[0] / want - 1).max()
+    # against the oracle: rounding differences are amplified chaotically over thousands of leapfrogs; while the two
+    # chains are still in step at the window's end everything must agree closely, afterwards only what is robust
+    in_step = np.allclose(d[:100, 7:], ref[:100, 7:], rtol=1e-5, atol=1e-6)
+    if in_step:
+        assert np.allclose(minv[0], ad[1:], rtol=1e-4) and np.array_equal(d[100:110, 3:6], ref[100:110, 3:6])
+        assert np.allclose(d[100:110, 2], ref[100:110, 2], rtol=1e-5)          # the step size found by init_stepsize after the update
+    all_in_step = np.allclose(d[:, 7:], ref[:, 7:], rtol=1e-4, atol=1e-5)
+    assert abs(np.log(eps[0] / ad[0])) < (0.05 if all_in_step else 0.5)
     ratio = np.log(minv[0] / ad[1:])
     assert abs(np.median(ratio)) < 0.15 and np.abs(ratio).max() < 2.5
-    assert abs(h.total_leapfrogs() - nl) / nl < 0.5
+    assert abs(h.total_leapfrogs() - nl) / nl < (0.02 if all_in_step else 0.5)
     h.close()
 
 
