@@ -4,7 +4,7 @@
   python scripts/micro/dense_probe.py sampler C N [cus]  2016 posterior, C chains, N warm-up iterations, dense metric
   python scripts/micro/dense_probe.py stress C N         the same on the configs[4] shape (D = 41 610)
 
-Matrices of `pieces` are generated on the device; bytes of a matrix pass = chains x D x LD x 8.
+Matrices of `pieces` are generated on the device; a matrix pass loads the upper-triangle tiles, about 4 D^2 bytes per chain.
 """
 import ctypes as C
 import json
@@ -20,7 +20,7 @@ from us_potus_model_amd import Handle, _abi, dataprep, sampler, synthetic  # noq
 
 L = sampler.load_library()
 DP = C.POINTER(C.c_double)
-L.potus_dense_matvec_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, DP]
+L.potus_dense_matvec_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, DP, C.POINTER(C.c_longlong)]
 L.potus_dense_factor_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, DP]
 
 
@@ -33,8 +33,8 @@ def err():
 def pieces():
     for chains, D, nrhs in ((1, 15098, 1), (1, 15098, 2), (8, 15098, 2), (8, 15098, 3), (1, 41610, 2), (4, 41610, 2)):
         x = np.random.default_rng(1).standard_normal((chains, nrhs, D))
-        y, ms = np.zeros((chains, nrhs, D)), C.c_double()
-        rc = L.potus_dense_matvec_probe(0, chains, D, nrhs, None, x.ctypes.data, y.ctypes.data, None, 5, C.byref(ms))
+        y, ms, nb = np.zeros((chains, nrhs, D)), C.c_double(), C.c_longlong()
+        rc = L.potus_dense_matvec_probe(0, chains, D, nrhs, None, x.ctypes.data, y.ctypes.data, None, 5, C.byref(ms), C.byref(nb))
         if rc:
             print(f"chains={chains} D={D}: error {rc}: {err()}")
             continue
@@ -44,8 +44,9 @@ def pieces():
                 j = np.arange(D)
                 row = np.exp(-np.abs(i - j) / 50.0) * (1.0 + 0.1 * c) + (j == i)
                 ok &= abs(row @ x[c, nrhs - 1] - y[c, nrhs - 1, i]) <= 1e-10 * max(1.0, abs(y[c, nrhs - 1, i]))
-        gb = chains * D * ((D + 7) & ~7) * 8 / 1e9
-        print(f"matrix pass chains={chains} D={D} nrhs={nrhs}: {ms.value:.3f} ms, {gb / (ms.value * 1e-3):.0f} GB/s = {gb / (ms.value * 1e-3) / 8000:.2f} of 8 TB/s; "
+        gb = chains * nb.value / 1e9                     # bytes the pass loads: the upper-triangle tiles (about 4 D^2 per chain)
+        print(f"matrix pass chains={chains} D={D} nrhs={nrhs}: {ms.value:.3f} ms, {gb:.2f} GB loaded -> {gb / (ms.value * 1e-3):.0f} GB/s = "
+              f"{gb / (ms.value * 1e-3) / 8000:.2f} of 8 TB/s ({chains * D * D * 8 / 1e9 / (ms.value * 1e-3):.0f} GB/s in full-matrix terms); "
               f"rows check {'ok' if ok else 'MISMATCH'}", flush=True)
     for chains, D, n in ((1, 15098, 100), (4, 15098, 500), (1, 41610, 100)):
         rng = np.random.default_rng(2)

@@ -15,24 +15,29 @@ DP = C.POINTER(C.c_double)
 
 def _lib():
     L = sampler.load_library()
-    L.potus_dense_matvec_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, DP]
+    L.potus_dense_matvec_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, DP, C.POINTER(C.c_longlong)]
     L.potus_dense_factor_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, DP]
     return L
 
 
-@pytest.mark.parametrize("chains,D,nrhs", [(3, 1000, 1), (2, 2049, 2), (1, 16500, 3), (2, 1027, 3), (1, 71, 2)])
+@pytest.mark.parametrize("chains,D,nrhs", [(3, 1000, 1), (2, 2049, 2), (1, 16500, 3), (2, 1027, 3), (1, 71, 2), (2, 640, 2), (1, 129, 1)])
 def test_dense_matvec_against_numpy(chains, D, nrhs):
-    """[y_r] = M^-1 [x_r] for up to three right-hand sides in one pass over the matrix (k_dn_matvec): partial row blocks,
-    several column tiles, odd D (padded rows); the fused x_0 . M^-1 x_0; reproducible bit for bit."""
+    """[y_r] = M^-1 [x_r] for up to three right-hand sides out of the strict upper triangle + diagonal vector
+    (k_dn_symv + k_dn_symv_finish): partial row blocks, paired blocks with and without a middle one, several column
+    tiles, odd D (padded rows); the lower triangle of the uploaded matrix (where the sampler keeps the Cholesky factor)
+    must not matter; the fused x_0 . M^-1 x_0; reproducible bit for bit."""
     L = _lib()
     rng = np.random.default_rng(4)
     B = rng.standard_normal((chains, D, 8))
     M = np.einsum("cik,cjk->cij", B, B) / 8 + np.eye(D)[None]          # symmetric positive definite
+    Mdev = M + np.tril(rng.standard_normal((chains, D, D)), -1)        # garbage below the diagonal: it is not the metric's
     x = rng.standard_normal((chains, nrhs, D))
     out = []
     for _ in range(2):
         y, dot, ms = np.zeros((chains, nrhs, D)), np.zeros(chains), C.c_double()
-        assert L.potus_dense_matvec_probe(0, chains, D, nrhs, M.ctypes.data, x.ctypes.data, y.ctypes.data, dot.ctypes.data, 2, C.byref(ms)) == 0
+        nb = C.c_longlong()
+        assert L.potus_dense_matvec_probe(0, chains, D, nrhs, Mdev.ctypes.data, x.ctypes.data, y.ctypes.data, dot.ctypes.data, 2, C.byref(ms), C.byref(nb)) == 0
+        assert 4 * D * D * (2 if nrhs == 3 else 1) <= nb.value <= (4 * D * D + 8 * 704 * D) * (2 if nrhs == 3 else 1)   # the upper triangle + at most a band of tile width
         out.append((y, dot))
     ref = np.einsum("cij,crj->cri", M, x)
     assert np.abs(out[0][0] - ref).max() <= 1e-12 * np.abs(ref).max() * np.sqrt(D)

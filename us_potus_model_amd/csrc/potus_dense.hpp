@@ -7,7 +7,7 @@
 // So the dense sampler is not a persistent kernel per chain: it is a sequence of chip-wide launches per leaf,
 //
 //     gradient at the leaf's position  ->  kick (pf = ph + he g, ph' = pf + he g)  ->
-//     k_dn_matvec<2>:  p# = M^-1 pf  and  q' = q + e M^-1 ph'  in ONE pass over the matrix  ->
+//     k_dn_symv<2> + k_dn_symv_finish<2>:  p# = M^-1 pf  and  q' = q + e M^-1 ph'  in ONE pass over the upper triangle  ->
 //     k_dn_step: the tree logic of base_nuts (one workgroup per chain, state kept in global memory between launches)
 //
 // with all chains of the handle advancing leaf by leaf together; a chain whose transition has ended sits out (its
@@ -23,17 +23,25 @@
 // inverse metric -- algebraically Welford's m2, no D^2 accumulator at all.  Then an in-place blocked Cholesky
 // factorisation (the momentum draw p = L^-T u needs it), and base_hmc::init_stepsize.
 //
-// Layout: per chain a block of DV_COUNT vectors of LD doubles (Stan's parameter order); M^-1 and its Cholesky factor
-// row-major D x LD with LD = D rounded up to 8 doubles (rows start on 64-byte lines).
+// ONE matrix per chain holds both what the leapfrog and what the momentum draw need: M^-1 is symmetric, so its strict
+// upper triangle (plus a vector for its diagonal) says everything, and the Cholesky factor L of the same matrix lives in
+// the lower triangle including the diagonal -- the factorisation runs in place on the lower half and never touches the
+// upper one.  The product M^-1 x then reads only the upper triangle: every element a_ij (i < j) serves y_i += a_ij x_j
+// and y_j += a_ij x_i, i.e. 4 D^2 bytes per leapfrog instead of 8 D^2, and 13.9 GB per chain at D = 41 610 instead of
+// 27.7: sixteen chains of the configs[4] shape fit one 288 GB GPU.
+//
+// Layout: per chain a block of DV_COUNT vectors of LD doubles (Stan's parameter order); the matrix row-major D x LD
+// with LD = D rounded up to 8 doubles (rows start on 64-byte lines).
 #pragma once
 #include "potus_dpp.hpp"
 #include "potus_nuts.hpp"
 
 #define DN_THREADS 512
-#define DN_ROWS_PER_WAVE 8
-#define DN_ROWS (DN_ROWS_PER_WAVE * (DN_THREADS / 64))   // rows of the matrix per workgroup
-#define DN_LDS_DOUBLES 16384                              // LDS for the right-hand sides: 128 KB
 #define DN_NB 64                                          // block size of the factorisation / triangular solve
+#define DN_RB 128                                         // rows per workgroup pass of the symmetric product (16 per wave)
+#define DN_CT 512                                         // columns per tile of it (8 per lane)
+#define DN_RG 4                                           // rows of a wave loaded together (16 loads of 16 bytes in flight per lane)
+#define DN_FIN 256                                        // threads of the finishing kernel = elements per partial sum
 typedef double dn_d2 __attribute__((ext_vector_type(2)));
 
 // vector slots of a chain's dense state block
@@ -47,7 +55,7 @@ enum {
   DV_COUNT = DV_POOLQ + PT_NPQ
 };
 
-// one right-hand side of a k_dn_matvec launch, per chain (slots are absolute slot numbers, -1 = not used)
+// one right-hand side of a k_dn_symv launch, per chain (slots are absolute slot numbers, -1 = not used)
 struct DnJob {
   int x;            // right-hand side
   int y;            // receives M^-1 x
@@ -72,7 +80,11 @@ struct DnParams {
   int chains, D, LD, npart;          // npart = row blocks of the matvec = partial sums per chain
   int sc_stride, pad0;               // the chain scalars of chain c are RunParams::scal[c * sc_stride] (cluster mode keeps K replicas)
   double *state;                     // [chains][DV_COUNT][LD]
-  double *Minv, *Lc;                 // [chains][D][LD]
+  double *A;                         // [chains][D][LD]: strict upper triangle = M^-1, lower triangle incl. diagonal = its Cholesky factor
+  double *dg;                        // [chains][LD] diagonal of M^-1
+  double *tpart;                     // [chains][nblk][3][LD] column sums of the symmetric product per block of DN_RB rows
+  double *srow;                      // [chains][3][LD] its row sums
+  int nblk, pad1;                    // blocks of DN_RB rows
   double *win;                       // [chains][win_cap][LD] draws of the current adaptation window
   int win_cap, identity;             // identity: the metric is still the unit matrix (before the first window ends)
   double *partial;                   // [chains][npart]
@@ -86,94 +98,155 @@ struct DnParams {
 __device__ __forceinline__ double *dn_vec(const DnParams &P, int chain, int slot) { return P.state + ((size_t)chain * DV_COUNT + slot) * (size_t)P.LD; }
 
 // ---------------------------------------------------------------- M^-1 x for up to three right-hand sides
-// One workgroup = DN_ROWS consecutive rows of one chain (8 waves x 8 rows); a wave streams a row with all 64 lanes,
-// 16 bytes per lane and eight loads in flight (8 KB per wave); the right-hand sides sit in LDS in column tiles.  Every
-// matrix element is loaded once and used NRHS times.  Sums in a fixed order: same bytes every time.
+// Symmetric product out of the strict upper triangle.  A workgroup takes blocks of DN_RB = 128 rows (16 per wave) -- block
+// b and its mirror nblk-1-b, so that every workgroup streams the same number of elements -- and walks the column tiles
+// (DN_CT = 512) from the block's diagonal to the right edge.  A wave reads its rows' 4 KB segments of the tile (16 bytes
+// per lane, eight rows = 32 loads in flight per lane); every element feeds
+//     the row sums    s_i += a_ij x_j   per lane, kept in registers across ALL tiles and reduced once per row at the end,
+//     the column sums t_j += a_ij x_i   per lane (its 8 columns of the tile), summed over the 8 waves through LDS per
+//                                       tile and stored per (block, column): k_dn_symv_finish adds the blocks in order.
+// Fixed summation order everywhere: same bytes every run.  Traffic besides the triangle: the column sums, written and
+// read once, nblk x D x NRHS doubles = 3 % of the matrix.
+// (job0: the first of the round's jobs this launch serves -- the three products of a transition's first pass go as 2 + 1)
+#define DN_SYMV_LDS(NRHS) ((size_t)((NRHS) * (DN_CT + 2 * DN_RB) + (DN_THREADS / 64) * (NRHS) * DN_CT) * 8)
 template <int NRHS>
-__global__ __launch_bounds__(DN_THREADS) void k_dn_matvec(const DnParams P) {
+__global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int job0) {
   extern __shared__ __attribute__((aligned(16))) double dn_lds[];
-  __shared__ double dn_part[DN_THREADS / 64];
   const int chain = blockIdx.y;
   const DnRound &rd = P.rd[chain];
   if (!rd.active) return;
-  constexpr int TILE = (DN_LDS_DOUBLES / NRHS) & ~1023;   // columns per tile (multiple of 64 lanes x 2 x 8 loads)
-  constexpr int UNR = 8;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int D = P.D, LD = P.LD;
-  const int row0 = blockIdx.x * DN_ROWS + w * DN_ROWS_PER_WAVE;
-  const double *A = P.Minv + (size_t)chain * (size_t)D * (size_t)LD;
+  const int D = P.D, LD = P.LD, nblk = P.nblk;
+  double *xs = dn_lds;                                   // [NRHS][DN_CT]  x over the tile's columns
+  double *xr = xs + NRHS * DN_CT;                        // [NRHS][DN_RB]  x over the block's rows
+  double *sacc = xr + NRHS * DN_RB;                      // [NRHS][DN_RB]  row sums of the block, accumulated over the tiles
+  double *tacc = sacc + NRHS * DN_RB;                    // [8 waves][NRHS][DN_CT]
+  const double *A = P.A + (size_t)chain * (size_t)D * (size_t)LD;
   const double *x[NRHS];
 #pragma unroll
-  for (int r = 0; r < NRHS; r++) x[r] = dn_vec(P, chain, rd.job[r].x);
-  double acc[DN_ROWS_PER_WAVE][NRHS];
-#pragma unroll
-  for (int i = 0; i < DN_ROWS_PER_WAVE; i++)
-#pragma unroll
-    for (int r = 0; r < NRHS; r++) acc[i][r] = 0.0;
-  for (int t0 = 0; t0 < D; t0 += TILE) {
-    const int tl = min(TILE, D - t0), tl2 = (tl + 1) & ~1;
+  for (int r = 0; r < NRHS; r++) x[r] = dn_vec(P, chain, rd.job[job0 + r].x);
+  double *tp = P.tpart + ((size_t)chain * nblk * 3 + job0) * (size_t)LD;   // [block][job][LD]
+  double *sr = P.srow + ((size_t)chain * 3 + job0) * (size_t)LD;
+  const unsigned rowbytes = uni32(8u * (unsigned)LD);
+  for (int side = 0; side < 2; side++) {
+    const int b = side == 0 ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
+    if (side == 1 && b <= (int)blockIdx.x) break;         // odd number of blocks: the middle one once
+    const int r0 = b * DN_RB, wrow0 = r0 + 16 * w;
+    // buffer addressing: the wave's 16 rows are one resource (rows beyond D fall outside it and read as zeros), the row is
+    // a scalar offset, the lane's columns one 32-bit vector offset per load.  (Made wave-uniform explicitly: the compiler
+    // otherwise keeps the descriptor in vector registers and wraps every load in a waterfall loop.)
+    const int wrows = min(16, max(0, D - wrow0));
+    const rsrc_t rsA = make_rsrc(uni_ptr(A + (size_t)wrow0 * LD), uni32((unsigned)wrows * rowbytes));
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < NRHS; r++)
-      for (int j = tid; j < tl2; j += DN_THREADS) dn_lds[r * TILE + j] = j < tl ? x[r][t0 + j] : 0.0;
-    __syncthreads();
+      for (int i = tid; i < DN_RB; i += DN_THREADS) { xr[r * DN_RB + i] = r0 + i < D ? x[r][r0 + i] : 0.0; sacc[r * DN_RB + i] = 0.0; }
+    for (int c0 = (r0 / DN_CT) * DN_CT; c0 < D; c0 += DN_CT) {
+      __syncthreads();                                    // the previous tile's column sums have been read
 #pragma unroll
-    for (int i = 0; i < DN_ROWS_PER_WAVE; i++) {
-      const int row = row0 + i;
-      if (row >= D) break;                                   // wave-uniform
-      const dn_d2 *Ar = (const dn_d2 *)(A + (size_t)row * LD + t0);   // 16-byte aligned: LD and TILE are even
-      double s[NRHS];
+      for (int r = 0; r < NRHS; r++)
+        for (int j = tid; j < DN_CT; j += DN_THREADS) xs[r * DN_CT + j] = c0 + j < D ? x[r][c0 + j] : 0.0;
+      __syncthreads();
+      dn_d2 xc[4][NRHS];
+      double t_acc[4][2][NRHS];
+      unsigned voff[4];
 #pragma unroll
-      for (int r = 0; r < NRHS; r++) s[r] = 0.0;
-      const int np = tl2 >> 1;                               // pairs in this tile (the padding pair element is x = 0;
-      int j = lane;                                          //  the matrix row is padded to LD >= D + (D & 1))
-      for (; j + 64 * (UNR - 1) < np; j += 64 * UNR) {
-        dn_d2 a[UNR];
+      for (int u = 0; u < 4; u++) {
+        voff[u] = 8u * (unsigned)(c0 + 2 * (lane + 64 * u));
 #pragma unroll
-        for (int u = 0; u < UNR; u++) a[u] = __builtin_nontemporal_load(Ar + j + 64 * u);
+        for (int r = 0; r < NRHS; r++) {
+          xc[u][r] = *(const dn_d2 *)(xs + r * DN_CT + 2 * (lane + 64 * u));
+          t_acc[u][0][r] = 0.0; t_acc[u][1][r] = 0.0;
+        }
+      }
+      const bool band = c0 < r0 + DN_RB;                  // the tile overlaps the block's own rows: only j > i counts
+#pragma unroll 1
+      for (int q = 0; q < 16; q += DN_RG) {               // DN_RG rows at a time: 4 DN_RG loads of 16 bytes in flight per lane
+        dn_d2 a[DN_RG][4];
 #pragma unroll
-        for (int u = 0; u < UNR; u++) {
+        for (int k = 0; k < DN_RG; k++)
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            a[k][u] = __builtin_bit_cast(dn_d2, __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[u], (unsigned)(q + k) * rowbytes, 2 /* nt: read once */));
+#pragma unroll
+        for (int k = 0; k < DN_RG; k++) {
+          const int lrow = 16 * w + q + k;
+          const int lim = band ? r0 + lrow : -1;          // no branch: outside the band every column counts
+          double xrow[NRHS], sp[NRHS];
+#pragma unroll
+          for (int r = 0; r < NRHS; r++) { xrow[r] = xr[r * DN_RB + lrow]; sp[r] = 0.0; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int col = c0 + 2 * (lane + 64 * u);
+            const double a0 = col > lim ? a[k][u][0] : 0.0, a1 = col + 1 > lim ? a[k][u][1] : 0.0;
+#pragma unroll
+            for (int r = 0; r < NRHS; r++) {
+              sp[r] += a0 * xc[u][r][0] + a1 * xc[u][r][1];
+              t_acc[u][0][r] += a0 * xrow[r];
+              t_acc[u][1][r] += a1 * xrow[r];
+            }
+          }
+          // the row's sum over this tile: across the lanes by DPP (lane 63 ends up with it), then into the block's row sums
 #pragma unroll
           for (int r = 0; r < NRHS; r++) {
-            const dn_d2 xv = *(const dn_d2 *)(dn_lds + r * TILE + 2 * (j + 64 * u));
-            s[r] += a[u][0] * xv[0] + a[u][1] * xv[1];
+            const double tot = dpp_scan_sum(sp[r]);
+            if (lane == 63) sacc[r * DN_RB + lrow] += tot;
           }
         }
       }
-      for (; j < np; j += 64) {
-        const dn_d2 a = __builtin_nontemporal_load(Ar + j);
+      // column sums of this (block, tile): over the 8 waves in wave order
 #pragma unroll
-        for (int r = 0; r < NRHS; r++) {
-          const dn_d2 xv = *(const dn_d2 *)(dn_lds + r * TILE + 2 * j);
-          s[r] += a[0] * xv[0] + a[1] * xv[1];
-        }
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int r = 0; r < NRHS; r++)
+          *(dn_d2 *)(tacc + ((size_t)w * NRHS + r) * DN_CT + 2 * (lane + 64 * u)) = dn_d2{t_acc[u][0][r], t_acc[u][1][r]};
+      __syncthreads();
+      for (int e = tid; e < NRHS * DN_CT; e += DN_THREADS) {
+        const int r = e / DN_CT, c = e - r * DN_CT;
+        double t = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < DN_THREADS / 64; ww++) t += tacc[((size_t)ww * NRHS + r) * DN_CT + c];
+        if (c0 + c < D) tp[((size_t)b * 3 + r) * LD + c0 + c] = t;
       }
-#pragma unroll
-      for (int r = 0; r < NRHS; r++) acc[i][r] += s[r];
     }
-  }
-  // epilogue: row totals (DPP), stores, the position update and the partial sum of dot . (M^-1 x)
-  double dsum = 0.0;
+    __syncthreads();
 #pragma unroll
-  for (int i = 0; i < DN_ROWS_PER_WAVE; i++) {
-    const int row = row0 + i;
+    for (int r = 0; r < NRHS; r++)
+      for (int i = tid; i < DN_RB; i += DN_THREADS) if (r0 + i < D) sr[(size_t)r * LD + r0 + i] = sacc[r * DN_RB + i];
+  }
+}
+// y_i = diag_i x_i + row sum_i + the column sums of the blocks at or above row i, in block order; then what the round
+// wants done with the products: stores, the position update, partial sums of dot . y (per workgroup, fixed order)
+template <int NRHS>
+__global__ __launch_bounds__(DN_FIN) void k_dn_symv_finish(const DnParams P, int job0) {
+  __shared__ double dn_part[DN_FIN / 64];
+  const int chain = blockIdx.y;
+  const DnRound &rd = P.rd[chain];
+  if (!rd.active) return;
+  const int i = blockIdx.x * DN_FIN + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int LD = P.LD;
+  const double *tp = P.tpart + ((size_t)chain * P.nblk * 3 + job0) * (size_t)LD, *sr = P.srow + ((size_t)chain * 3 + job0) * (size_t)LD;
+  const double *dg = P.dg + (size_t)chain * LD;
+  double dsum = 0.0;
+  if (i < P.D) {
+    const int nb = i / DN_RB + 1;
 #pragma unroll
     for (int r = 0; r < NRHS; r++) {
-      const double tot = dpp_wave_sum(acc[i][r]);
-      if (lane == 0 && row < D) {
-        const DnJob &jb = rd.job[r];
-        if (jb.y >= 0) dn_vec(P, chain, jb.y)[row] = tot;
-        if (jb.qout >= 0) dn_vec(P, chain, jb.qout)[row] = dn_vec(P, chain, jb.qin)[row] + jb.coef * tot;
-        if (r == 0 && jb.dot >= 0) dsum += dn_vec(P, chain, jb.dot)[row] * tot;
-      }
+      const DnJob &jb = rd.job[job0 + r];
+      double y = dg[i] * dn_vec(P, chain, jb.x)[i] + sr[(size_t)r * LD + i];
+      for (int b = 0; b < nb; b++) y += tp[((size_t)b * 3 + r) * LD + i];
+      if (jb.y >= 0) dn_vec(P, chain, jb.y)[i] = y;
+      if (jb.qout >= 0) dn_vec(P, chain, jb.qout)[i] = dn_vec(P, chain, jb.qin)[i] + jb.coef * y;
+      if (job0 + r == 0 && jb.dot >= 0) dsum = dn_vec(P, chain, jb.dot)[i] * y;
     }
   }
-  if (lane == 0) dn_part[w] = dsum;
+  const double tot = dpp_wave_sum(dsum);
+  if (lane == 0) dn_part[w] = tot;
   __syncthreads();
-  if (tid == 0) {
+  if (threadIdx.x == 0 && job0 == 0) {
     double t = 0.0;
 #pragma unroll
-    for (int i = 0; i < DN_THREADS / 64; i++) t += dn_part[i];
+    for (int k = 0; k < DN_FIN / 64; k++) t += dn_part[k];
     P.partial[(size_t)chain * P.npart + blockIdx.x] = t;
   }
 }
@@ -218,7 +291,7 @@ __global__ __launch_bounds__(64) void k_dn_trsv_diag(const DnParams P, int b) {
   const int chain = blockIdx.x;
   if (!P.rd[chain].active) return;
   const int lane = threadIdx.x, r0 = b * DN_NB, nb = min(DN_NB, P.D - r0);
-  const double *L = P.Lc + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  const double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD;
   for (int i = 0; i < nb; i++) Lb[i][lane] = lane <= i ? L[(size_t)(r0 + i) * P.LD + r0 + lane] : 0.0;
   __syncthreads();
   double *p = dn_vec(P, chain, DV_P0);
@@ -235,7 +308,7 @@ __global__ __launch_bounds__(256) void k_dn_trsv_update(const DnParams P, int b)
   const int chain = blockIdx.y;
   if (!P.rd[chain].active) return;
   const int r0 = b * DN_NB, nb = min(DN_NB, P.D - r0);
-  const double *L = P.Lc + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  const double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD;
   double *p = dn_vec(P, chain, DV_P0);
   if (threadIdx.x < DN_NB) pb[threadIdx.x] = (int)threadIdx.x < nb ? p[r0 + threadIdx.x] : 0.0;
   __syncthreads();
@@ -600,20 +673,25 @@ __global__ __launch_bounds__(256) void k_dn_center(const DnParams P, int n) {
     for (int k = 0; k < n; k++) W[(size_t)k * P.LD + j] -= m;
   }
 }
+// The two GEMM-shaped pieces of the window end -- the covariance (a rank-n update) and the trailing update of the
+// factorisation -- run on the fp64 matrix cores: v_mfma_f64_16x16x4_f64, D[16 x 16] += A[16 x 4] B[4 x 16], lane l feeding
+// A[l & 15][l >> 4] and B[l >> 4][l & 15] and holding D[(l >> 4) + 4 v][l & 15], v = 0..3.  A workgroup of four waves owns a
+// 64 x 64 tile: wave w the 16 rows 16 w .. 16 w + 15, four accumulators (the four 16-column blocks), operands out of LDS.
+typedef double dn_d4 __attribute__((ext_vector_type(4)));
+
 // M^-1 = n/(n+5) * (sum_k c_k c_k') / (n-1) + 1e-3 * 5/(n+5) * I   (covar_adaptation::learn_covariance), tiles of 64 x 64,
 // lower tiles computed and mirrored so that the matrix is exactly symmetric
 __global__ __launch_bounds__(256) void k_dn_cov(const DnParams P, int n) {
   __shared__ double a[DN_NB][DN_NB + 1], b[DN_NB][DN_NB + 1];
   const int I = blockIdx.x, J = blockIdx.y, chain = blockIdx.z;
   if (J > I) return;
-  const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 15, kk = lane >> 4;
   const double *W = P.win + (size_t)chain * P.win_cap * (size_t)P.LD;
-  double *A = P.Minv + (size_t)chain * (size_t)P.D * (size_t)P.LD;
-  double c[4][4];
+  double *A = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  double *dg = P.dg + (size_t)chain * P.LD;
+  dn_d4 acc[4];
 #pragma unroll
-  for (int r = 0; r < 4; r++)
-#pragma unroll
-    for (int s = 0; s < 4; s++) c[r][s] = 0.0;
+  for (int cb = 0; cb < 4; cb++) acc[cb] = dn_d4{0.0, 0.0, 0.0, 0.0};
   for (int k0 = 0; k0 < n; k0 += DN_NB) {
     __syncthreads();
     for (int e = tid; e < DN_NB * DN_NB; e += 256) {
@@ -623,26 +701,24 @@ __global__ __launch_bounds__(256) void k_dn_cov(const DnParams P, int n) {
       b[k][j] = (ok && J * DN_NB + j < P.D) ? W[(size_t)(k0 + k) * P.LD + J * DN_NB + j] : 0.0;
     }
     __syncthreads();
-    for (int k = 0; k < DN_NB; k++) {
-      double av[4], bv[4];
+#pragma unroll 4
+    for (int t0 = 0; t0 < DN_NB; t0 += 4) {
+      const double av = a[t0 + kk][16 * w + m];          // A[i][k] = c_k[i]
 #pragma unroll
-      for (int r = 0; r < 4; r++) { av[r] = a[k][tr + 16 * r]; bv[r] = b[k][tc + 16 * r]; }
-#pragma unroll
-      for (int r = 0; r < 4; r++)
-#pragma unroll
-        for (int s = 0; s < 4; s++) c[r][s] += av[r] * bv[s];
+      for (int cb = 0; cb < 4; cb++) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b[t0 + kk][16 * cb + m], acc[cb], 0, 0, 0);
     }
   }
   const double nn = (double)n, f = (nn / (nn + 5.0)) / (nn - 1.0), reg = 1e-3 * (5.0 / (nn + 5.0));
 #pragma unroll
-  for (int r = 0; r < 4; r++)
+  for (int cb = 0; cb < 4; cb++)
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      const int i = I * DN_NB + tr + 16 * r, j = J * DN_NB + tc + 16 * s;
+    for (int v = 0; v < 4; v++) {
+      const int i = I * DN_NB + 16 * w + kk + 4 * v, j = J * DN_NB + 16 * cb + m;
       if (i < P.D && j < P.D && (I != J || j <= i)) {
-        const double v = f * c[r][s] + (i == j ? reg : 0.0);
-        A[(size_t)i * P.LD + j] = v;
-        A[(size_t)j * P.LD + i] = v;
+        const double val = f * acc[cb][v] + (i == j ? reg : 0.0);
+        A[(size_t)i * P.LD + j] = val;           // lower half: what the factorisation starts from (and overwrites with L)
+        A[(size_t)j * P.LD + i] = val;           // upper half: stays, it IS the metric
+        if (i == j) dg[i] = val;
       }
     }
 }
@@ -652,7 +728,7 @@ __global__ __launch_bounds__(256) void k_dn_cov(const DnParams P, int n) {
 __global__ __launch_bounds__(256) void k_dn_potrf(const DnParams P, int kb) {
   __shared__ double a[DN_NB][DN_NB + 1];
   const int chain = blockIdx.x, tid = threadIdx.x, r0 = kb * DN_NB, nb = min(DN_NB, P.D - r0);
-  double *L = P.Lc + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD;
   for (int e = tid; e < DN_NB * DN_NB; e += 256) { const int i = e >> 6, j = e & 63; a[i][j] = (i < nb && j <= i) ? L[(size_t)(r0 + i) * P.LD + r0 + j] : 0.0; }
   __syncthreads();
   for (int j = 0; j < nb; j++) {
@@ -670,7 +746,7 @@ __global__ __launch_bounds__(256) void k_dn_potrf(const DnParams P, int kb) {
     }
     __syncthreads();
   }
-  for (int e = tid; e < DN_NB * DN_NB; e += 256) { const int i = e >> 6, j = e & 63; if (i < nb && j < nb) L[(size_t)(r0 + i) * P.LD + r0 + j] = j <= i ? a[i][j] : 0.0; }
+  for (int e = tid; e < DN_NB * DN_NB; e += 256) { const int i = e >> 6, j = e & 63; if (i < nb && j <= i) L[(size_t)(r0 + i) * P.LD + r0 + j] = a[i][j]; }   // the upper half is M^-1's
 }
 // rows below the diagonal block: X Lkk' = A  ->  forward substitution per row (64 rows per workgroup, staged in LDS)
 __global__ __launch_bounds__(256) void k_dn_trsm(const DnParams P, int kb) {
@@ -678,7 +754,7 @@ __global__ __launch_bounds__(256) void k_dn_trsm(const DnParams P, int kb) {
   const int chain = blockIdx.y, tid = threadIdx.x, c0 = kb * DN_NB, nb = min(DN_NB, P.D - c0);
   const int r0 = (kb + 1) * DN_NB + blockIdx.x * DN_NB;
   if (r0 >= P.D) return;
-  double *L = P.Lc + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD;
   for (int e = tid; e < DN_NB * DN_NB; e += 256) {
     const int i = e >> 6, j = e & 63;
     lk[i][j] = (i < nb && j <= i) ? L[(size_t)(c0 + i) * P.LD + c0 + j] : 0.0;
@@ -696,56 +772,53 @@ __global__ __launch_bounds__(256) void k_dn_trsm(const DnParams P, int kb) {
   __syncthreads();
   for (int e = tid; e < DN_NB * DN_NB; e += 256) { const int i = e >> 6, j = e & 63; if (r0 + i < P.D && j < nb) L[(size_t)(r0 + i) * P.LD + c0 + j] = x[i][j]; }
 }
-// trailing update A[I][J] -= L[I][kb] L[J][kb]' for the lower tiles I >= J > kb
+// trailing update A[I][J] -= L[I][kb] L[J][kb]' for the lower tiles I >= J > kb (fp64 MFMA, see k_dn_cov)
 __global__ __launch_bounds__(256) void k_dn_syrk(const DnParams P, int kb) {
   __shared__ double a[DN_NB][DN_NB + 1], b[DN_NB][DN_NB + 1];
   const int I = kb + 1 + blockIdx.x, J = kb + 1 + blockIdx.y, chain = blockIdx.z;
   if (J > I) return;
-  const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15, c0 = kb * DN_NB;
-  double *L = P.Lc + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 15, kk = lane >> 4, c0 = kb * DN_NB;
+  double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD;
   for (int e = tid; e < DN_NB * DN_NB; e += 256) {
     const int i = e >> 6, t = e & 63;
     a[i][t] = I * DN_NB + i < P.D ? L[(size_t)(I * DN_NB + i) * P.LD + c0 + t] : 0.0;
     b[i][t] = J * DN_NB + i < P.D ? L[(size_t)(J * DN_NB + i) * P.LD + c0 + t] : 0.0;
   }
   __syncthreads();
-  double c[4][4];
+  dn_d4 acc[4];
 #pragma unroll
-  for (int r = 0; r < 4; r++)
+  for (int cb = 0; cb < 4; cb++) acc[cb] = dn_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int t0 = 0; t0 < DN_NB; t0 += 4) {
+    const double av = a[16 * w + m][t0 + kk];            // A[i][t] = L[I rows][kb cols]
 #pragma unroll
-    for (int s = 0; s < 4; s++) c[r][s] = 0.0;
-  for (int t = 0; t < DN_NB; t++) {
-    double av[4], bv[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) { av[r] = a[tr + 16 * r][t]; bv[r] = b[tc + 16 * r][t]; }
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-      for (int s = 0; s < 4; s++) c[r][s] += av[r] * bv[s];
+    for (int cb = 0; cb < 4; cb++) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b[16 * cb + m][t0 + kk], acc[cb], 0, 0, 0);   // B[t][j] = L[J rows][t]
   }
 #pragma unroll
-  for (int r = 0; r < 4; r++)
+  for (int cb = 0; cb < 4; cb++)
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      const int i = I * DN_NB + tr + 16 * r, j = J * DN_NB + tc + 16 * s;
-      if (i < P.D && j < P.D && j <= i) L[(size_t)i * P.LD + j] -= c[r][s];
+    for (int v = 0; v < 4; v++) {
+      const int i = I * DN_NB + 16 * w + kk + 4 * v, j = J * DN_NB + 16 * cb + m;
+      if (i < P.D && j < P.D && j <= i) L[(size_t)i * P.LD + j] -= acc[cb][v];
     }
 }
 
-// unit metric: M^-1 = L = I
+// unit metric: M^-1 = L = I (the matrix buffer is zero apart from the diagonal)
 __global__ void k_dn_identity(const DnParams P) {
   const int chain = blockIdx.y;
-  double *A = P.Minv + (size_t)chain * (size_t)P.D * (size_t)P.LD, *L = P.Lc + (size_t)chain * (size_t)P.D * (size_t)P.LD;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.D; i += gridDim.x * blockDim.x) { A[(size_t)i * P.LD + i] = 1.0; L[(size_t)i * P.LD + i] = 1.0; }
+  double *A = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD, *dg = P.dg + (size_t)chain * P.LD;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.D; i += gridDim.x * blockDim.x) { A[(size_t)i * P.LD + i] = 1.0; dg[i] = 1.0; }
 }
-// fills a symmetric positive definite test matrix on the device (rates at sizes that would take seconds to upload):
-// A[i][j] = exp(-|i-j|/50) * (1 + 0.1 c) + (i == j ? 1 : 0)
+// fills the upper triangle and the diagonal vector with a symmetric positive definite test matrix on the device (rates
+// at sizes that would take seconds to upload): a_ij = exp(-|i-j|/50) * (1 + 0.1 c) + (i == j ? 1 : 0)
 __global__ void k_dn_fill(const DnParams P) {
   const size_t n = (size_t)P.D * P.D;
   for (int c = 0; c < P.chains; c++)
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
       const int i = (int)(e / P.D), j = (int)(e % P.D);
       const int d = i > j ? i - j : j - i;
-      P.Minv[(size_t)c * P.D * P.LD + (size_t)i * P.LD + j] = exp(-(double)d / 50.0) * (1.0 + 0.1 * c) + (i == j ? 1.0 : 0.0);
+      const double v = exp(-(double)d / 50.0) * (1.0 + 0.1 * c) + (i == j ? 1.0 : 0.0);
+      if (j > i) P.A[(size_t)c * P.D * P.LD + (size_t)i * P.LD + j] = v;
+      if (j == i) { P.A[(size_t)c * P.D * P.LD + (size_t)i * P.LD + j] = 1.0; P.dg[(size_t)c * P.LD + i] = v; }
     }
 }

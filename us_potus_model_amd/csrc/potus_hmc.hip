@@ -623,8 +623,8 @@ struct Sampler {
   int *h_active = nullptr;                 // pinned host copy of the per-chain activity flags
   int dn_win_counter = 0, dn_win_next = 0, dn_win_size = 0, dn_wf_n = 0;   // host mirror of the warm-up window schedule
   hipEvent_t mv0 = nullptr, mv1 = nullptr;
-  double mv_ms = 0;                        // time spent in k_dn_matvec (events), matrix passes and bytes streamed
-  long long mv_calls = 0, mv_bytes = 0, dn_rounds = 0;
+  double mv_ms = 0;                        // time spent in the matrix passes (k_dn_symv + finish, events), their number and the bytes they loaded
+  long long mv_calls = 0, mv_bytes = 0, dn_rounds = 0, dn_pass_bytes = 0;
 };
 
 std::mutex g_mu;
@@ -1146,32 +1146,43 @@ int dense_window_capacity(int nw, int ib, int tb, int bw) {
   return cap;
 }
 
+// bytes one pass of the symmetric product loads per chain: the tiles right of (and on) each row block's diagonal
+long long dense_pass_bytes(int D, int LD) {
+  long long n = 0;
+  const int tile_end = std::min(LD, ((D + DN_CT - 1) / DN_CT) * DN_CT);
+  for (int r0 = 0; r0 < D; r0 += DN_RB) n += (long long)std::min(DN_RB, D - r0) * (tile_end - (r0 / DN_CT) * DN_CT);
+  return n * 8;
+}
+
 int dense_alloc(Sampler *sp) {
   DnParams &P = sp->dn;
   const int D = sp->L.D, chains = sp->R.chains;
-  P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_ROWS - 1) / DN_ROWS; P.sc_stride = sp->K; P.identity = 1;
+  P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_FIN - 1) / DN_FIN; P.nblk = (D + DN_RB - 1) / DN_RB; P.sc_stride = sp->K; P.identity = 1;
   P.win_cap = dense_window_capacity(sp->R.num_warmup, sp->R.init_buffer, sp->R.term_buffer, sp->R.window);
   const size_t mat = (size_t)chains * D * P.LD * 8, vec = (size_t)chains * DV_COUNT * P.LD * 8, win = (size_t)chains * P.win_cap * P.LD * 8;
+  const size_t tp = (size_t)chains * P.nblk * 3 * P.LD * 8;
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  if (2 * mat + vec + win + (64u << 20) > free_b)
-    return fail(POTUS_ERR_UNSUPPORTED, "dense metric: %d chains x (2 x D^2 + %d window draws + %d vectors) x 8 bytes = %.1f GB, %.1f GB free on GPU %d "
-                                       "(D = %d: %.2f GB per matrix)", chains, P.win_cap, DV_COUNT, (2 * mat + vec + win) / 1e9, free_b / 1e9, sp->device, D, (double)D * P.LD * 8 / 1e9);
+  if (mat + vec + win + tp + (64u << 20) > free_b)
+    return fail(POTUS_ERR_UNSUPPORTED, "dense metric: %d chains x (D^2 + %d window draws + %d vectors + %d partial vectors) x 8 bytes = %.1f GB, %.1f GB free on GPU %d "
+                                       "(D = %d: %.2f GB per matrix)", chains, P.win_cap, DV_COUNT, 3 * P.nblk, (mat + vec + win + tp) / 1e9, free_b / 1e9, sp->device, D, (double)D * P.LD * 8 / 1e9);
   auto get = [&](void **q, size_t bytes) {
     if (hipMalloc(q, std::max<size_t>(bytes, 8)) != hipSuccess) return fail(POTUS_ERR_DEVICE, "hipMalloc(%zu) for the dense metric failed", bytes);
     sp->allocs.push_back(*q);
-    return hipMemset(*q, 0, std::max<size_t>(bytes, 8)) == hipSuccess ? 0 : fail(POTUS_ERR_DEVICE, "hipMemset failed");
+    // (on the sampler's own stream: it is a non-blocking stream, which a memset on the null stream would not order with)
+    return hipMemsetAsync(*q, 0, std::max<size_t>(bytes, 8), sp->stream) == hipSuccess ? 0 : fail(POTUS_ERR_DEVICE, "hipMemset failed");
   };
   int rc;
-  if ((rc = get((void **)&P.state, vec)) || (rc = get((void **)&P.Minv, mat)) || (rc = get((void **)&P.Lc, mat)) || (rc = get((void **)&P.win, win)) ||
+  if ((rc = get((void **)&P.state, vec)) || (rc = get((void **)&P.A, mat)) || (rc = get((void **)&P.dg, (size_t)chains * P.LD * 8)) || (rc = get((void **)&P.win, win)) ||
+      (rc = get((void **)&P.tpart, tp)) || (rc = get((void **)&P.srow, (size_t)chains * 3 * P.LD * 8)) ||
       (rc = get((void **)&P.partial, (size_t)chains * P.npart * 8)) || (rc = get((void **)&P.lpbuf, (size_t)chains * 8)) ||
       (rc = get((void **)&P.ts, (size_t)chains * sizeof(TS))) || (rc = get((void **)&P.rd, (size_t)chains * sizeof(DnRound))) ||
       (rc = get((void **)&P.active, (size_t)chains * 4)) || (rc = get((void **)&P.fail, 4)))
     return rc;
   HIP_TRY(hipHostMalloc((void **)&sp->h_active, (size_t)chains * sizeof(int)));
   HIP_TRY(hipEventCreate(&sp->mv0)); HIP_TRY(hipEventCreate(&sp->mv1));
-  for (const void *f : {reinterpret_cast<const void *>(k_dn_matvec<1>), reinterpret_cast<const void *>(k_dn_matvec<2>), reinterpret_cast<const void *>(k_dn_matvec<3>)})
-    HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DN_LDS_DOUBLES * 8));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(1)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(2)));
   if (sp->K == 1) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_grad1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
   else for (const void *f : {reinterpret_cast<const void *>(k_dn_gradK<4>), reinterpret_cast<const void *>(k_dn_gradK<8>)})
     HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
@@ -1179,7 +1190,25 @@ int dense_alloc(Sampler *sp) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(sp->stream));
   sp->dn_win_counter = 0; sp->dn_win_size = sp->R.window; sp->dn_win_next = sp->R.init_buffer + sp->R.window - 1; sp->dn_wf_n = 0;
+  sp->dn_pass_bytes = dense_pass_bytes(D, P.LD);
   return 0;
+}
+
+// M^-1 times the round's right-hand sides for the active chains: one pass over the upper triangles (two launches when
+// there are three right-hand sides) and the finishing kernel
+void dense_symv_launch(hipStream_t st, const DnParams &P, int nrhs) {
+  const dim3 grid((unsigned)((P.nblk + 1) / 2), (unsigned)P.chains), fin((unsigned)P.npart, (unsigned)P.chains);
+  if (nrhs == 1) {
+    hipLaunchKernelGGL(k_dn_symv<1>, grid, dim3(DN_THREADS), DN_SYMV_LDS(1), st, P, 0);
+    hipLaunchKernelGGL(k_dn_symv_finish<1>, fin, dim3(DN_FIN), 0, st, P, 0);
+  } else {
+    hipLaunchKernelGGL(k_dn_symv<2>, grid, dim3(DN_THREADS), DN_SYMV_LDS(2), st, P, 0);
+    hipLaunchKernelGGL(k_dn_symv_finish<2>, fin, dim3(DN_FIN), 0, st, P, 0);
+    if (nrhs == 3) {
+      hipLaunchKernelGGL(k_dn_symv<1>, grid, dim3(DN_THREADS), DN_SYMV_LDS(1), st, P, 2);
+      hipLaunchKernelGGL(k_dn_symv_finish<1>, fin, dim3(DN_FIN), 0, st, P, 2);
+    }
+  }
 }
 
 inline dim3 dn_grid(const Sampler *sp) { return dim3((unsigned)std::min((sp->L.D + 255) / 256, 64), (unsigned)sp->R.chains); }
@@ -1201,11 +1230,8 @@ int dense_grad(Sampler *sp) {
 }
 // one pass over the matrices of the active chains; the pass is timed with events resolved at the next sync point
 int dense_matvec(Sampler *sp, int nrhs) {
-  const dim3 grid((unsigned)sp->dn.npart, (unsigned)sp->R.chains);
   HIP_TRY(hipEventRecord(sp->mv0, sp->stream));
-  if (nrhs == 1) hipLaunchKernelGGL(k_dn_matvec<1>, grid, dim3(DN_THREADS), DN_LDS_DOUBLES * 8, sp->stream, sp->dn);
-  else if (nrhs == 2) hipLaunchKernelGGL(k_dn_matvec<2>, grid, dim3(DN_THREADS), DN_LDS_DOUBLES * 8, sp->stream, sp->dn);
-  else hipLaunchKernelGGL(k_dn_matvec<3>, grid, dim3(DN_THREADS), DN_LDS_DOUBLES * 8, sp->stream, sp->dn);
+  dense_symv_launch(sp->stream, sp->dn, nrhs);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(sp->mv1, sp->stream));
   return 0;
@@ -1268,8 +1294,7 @@ int dense_window_end(Sampler *sp, int n, unsigned iter) {
   hipLaunchKernelGGL(k_dn_center, dn_grid(sp), dim3(256), 0, sp->stream, P, n);
   hipLaunchKernelGGL(k_dn_cov, dim3(nb, nb, chains), dim3(256), 0, sp->stream, P, n);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(P.Lc, P.Minv, (size_t)chains * D * P.LD * 8, hipMemcpyDeviceToDevice, sp->stream));
-  for (int kb = 0; kb < nb; kb++) {
+  for (int kb = 0; kb < nb; kb++) {     // in place on the lower triangle; the upper one keeps M^-1
     hipLaunchKernelGGL(k_dn_potrf, dim3(chains), dim3(256), 0, sp->stream, P, kb);
     const int rem = nb - kb - 1;
     if (rem > 0) {
@@ -1308,14 +1333,14 @@ int dense_run(Sampler *sp, int n_iter) {
     hipLaunchKernelGGL(k_dn_step, dim3(chains), dim3(DN_THREADS), 0, sp->stream, P, (const RunParams *)sp->dR, (unsigned)it, (int)DN_MODE_BEGIN);
     HIP_TRY(hipGetLastError());
     if ((rc = dense_sync(sp, &n_active, true))) return rc;
-    sp->mv_bytes += (long long)chains * sp->L.D * P.LD * 8;
+    sp->mv_bytes += (long long)chains * sp->dn_pass_bytes * 2;   // three right-hand sides: the triangle is read twice (2 + 1)
     while (n_active > 0) {
       if ((rc = dense_grad(sp))) return rc;
       hipLaunchKernelGGL(k_dn_kick, dn_grid(sp), dim3(256), 0, sp->stream, P);
       if ((rc = dense_matvec(sp, 2))) return rc;
       hipLaunchKernelGGL(k_dn_step, dim3(chains), dim3(DN_THREADS), 0, sp->stream, P, (const RunParams *)sp->dR, (unsigned)it, (int)DN_MODE_LEAF);
       HIP_TRY(hipGetLastError());
-      sp->mv_bytes += (long long)n_active * sp->L.D * P.LD * 8;
+      sp->mv_bytes += (long long)n_active * sp->dn_pass_bytes;
       sp->dn_rounds += 1;
       if ((rc = dense_sync(sp, &n_active, true))) return rc;
     }
@@ -1534,6 +1559,8 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
     sp->dense = true;
     if ((rc = dense_alloc(sp))) return bail(rc);
   }
+  // the buffers above were cleared on the null stream, the sampler launches on its own non-blocking stream
+  if (hipDeviceSynchronize() != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "device synchronisation after the allocations failed"));
   std::lock_guard<std::mutex> lk(g_mu);
   size_t slot = 0;
   while (slot < g_handles.size() && g_handles[slot]) slot++;     // handles of destroyed samplers are reused
@@ -1780,8 +1807,7 @@ int potus_get_adaptation(int handle, double *stepsize, double *inv_metric) {
   for (int c = 0; c < sp->R.chains; c++) {
     if (stepsize) stepsize[c] = sc[c].nom_eps;
     if (inv_metric && sp->dense) {   // the diagonal of the dense inverse metric
-      HIP_TRY(hipMemcpy2D(inv_metric + (size_t)c * sp->L.D, 8, sp->dn.Minv + (size_t)c * sp->L.D * sp->dn.LD, (size_t)(sp->dn.LD + 1) * 8, 8, (size_t)sp->L.D,
-                          hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(inv_metric + (size_t)c * sp->L.D, sp->dn.dg + (size_t)c * sp->dn.LD, (size_t)sp->L.D * 8, hipMemcpyDeviceToHost));
     } else if (inv_metric) {
       double *dst = inv_metric + (size_t)c * sp->L.D;
       if (sp->K == 1) HIP_TRY(hipMemcpy(dst, sp->R.state + ((size_t)c * V_COUNT + V_MINV) * sp->R.Dpad, (size_t)sp->L.D * 8, hipMemcpyDeviceToHost));
@@ -1802,12 +1828,19 @@ int potus_get_dense_metric(int handle, int chain, double *inv_metric) {
   if (!sp->dense) return fail(POTUS_ERR_STATE, "the handle runs the diagonal metric: use potus_get_adaptation");
   HIP_TRY(hipSetDevice(sp->device));
   const size_t D = sp->L.D;
-  HIP_TRY(hipMemcpy2D(inv_metric, D * 8, sp->dn.Minv + (size_t)chain * D * sp->dn.LD, (size_t)sp->dn.LD * 8, D * 8, D, hipMemcpyDeviceToHost));
+  // the strict upper triangle of the chain's matrix is M^-1's (the lower one holds its Cholesky factor), the diagonal a vector
+  HIP_TRY(hipMemcpy2D(inv_metric, D * 8, sp->dn.A + (size_t)chain * D * sp->dn.LD, (size_t)sp->dn.LD * 8, D * 8, D, hipMemcpyDeviceToHost));
+  std::vector<double> dg(D);
+  HIP_TRY(hipMemcpy(dg.data(), sp->dn.dg + (size_t)chain * sp->dn.LD, D * 8, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < D; i++) {
+    inv_metric[i * D + i] = dg[i];
+    for (size_t j = 0; j < i; j++) inv_metric[i * D + j] = inv_metric[j * D + i];
+  }
   return 0;
 }
 
-// Dense metric: time spent in the matrix passes (k_dn_matvec, HIP events on the sampler's stream), their number and
-// the bytes of matrix they streamed (active chains x D x LD x 8 per pass), since the handle was created.
+// Dense metric: time spent in the matrix passes (k_dn_symv + k_dn_symv_finish, HIP events on the sampler's stream), their number and
+// the bytes of matrix they loaded (active chains x the upper-triangle tiles, about 4 D^2 per pass), since the handle was created.
 int potus_dense_timing(int handle, double *matvec_ms, long long *passes, long long *bytes, long long *rounds) {
   Sampler *sp = get(handle);
   if (!sp || !sp->dense) return fail(POTUS_ERR_STATE, "bad handle or not a dense-metric sampler");
@@ -2100,32 +2133,41 @@ struct DenseProbe {   // a DnParams with every chain active, owned buffers
   DevBufs bufs;
   int init(int device, int chains, int D, int win_cap) {
     HIP_TRY(hipSetDevice(device));
-    P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_ROWS - 1) / DN_ROWS; P.sc_stride = 1; P.win_cap = win_cap; P.identity = 0;
+    P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_FIN - 1) / DN_FIN; P.nblk = (D + DN_RB - 1) / DN_RB; P.sc_stride = 1; P.win_cap = win_cap; P.identity = 0;
     const size_t mat = (size_t)chains * D * P.LD * 8;
-    HIP_TRY(bufs.alloc(&P.state, (size_t)chains * DV_COUNT * P.LD * 8)); HIP_TRY(bufs.alloc(&P.Minv, mat)); HIP_TRY(bufs.alloc(&P.Lc, mat));
+    HIP_TRY(bufs.alloc(&P.state, (size_t)chains * DV_COUNT * P.LD * 8)); HIP_TRY(bufs.alloc(&P.A, mat)); HIP_TRY(bufs.alloc(&P.dg, (size_t)chains * P.LD * 8));
+    HIP_TRY(bufs.alloc(&P.tpart, (size_t)chains * P.nblk * 3 * P.LD * 8)); HIP_TRY(bufs.alloc(&P.srow, (size_t)chains * 3 * P.LD * 8));
     HIP_TRY(bufs.alloc(&P.win, (size_t)chains * std::max(win_cap, 1) * P.LD * 8)); HIP_TRY(bufs.alloc(&P.partial, (size_t)chains * P.npart * 8));
     HIP_TRY(bufs.alloc(&P.lpbuf, (size_t)chains * 8)); HIP_TRY(bufs.alloc(&P.ts, (size_t)chains * sizeof(TS)));
     HIP_TRY(bufs.alloc(&P.rd, (size_t)chains * sizeof(DnRound))); HIP_TRY(bufs.alloc(&P.active, (size_t)chains * 4)); HIP_TRY(bufs.alloc(&P.fail, 4));
-    HIP_TRY(hipMemset(P.state, 0, (size_t)chains * DV_COUNT * P.LD * 8)); HIP_TRY(hipMemset(P.Minv, 0, mat)); HIP_TRY(hipMemset(P.Lc, 0, mat));
+    HIP_TRY(hipMemset(P.state, 0, (size_t)chains * DV_COUNT * P.LD * 8)); HIP_TRY(hipMemset(P.A, 0, mat)); HIP_TRY(hipMemset(P.dg, 0, (size_t)chains * P.LD * 8));
     HIP_TRY(hipMemset(P.fail, 0, 4));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(1)));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(2)));
     return 0;
   }
   int set_rounds(const std::vector<DnRound> &r) { HIP_TRY(hipMemcpy(P.rd, r.data(), r.size() * sizeof(DnRound), hipMemcpyHostToDevice)); return 0; }
 };
 }
 
-// y_r = M^-1 x_r (r < nrhs <= 3) for `chains` dense inverse metrics of size D x D.  Minv_host == NULL: the matrices are
-// generated on the device (k_dn_fill) -- for rates at sizes whose matrices would take seconds to upload.  Runs the kernel
-// `reps` times; x_host / y_host are [chains][nrhs][D]; dot_host [chains] receives x_0 . M^-1 x_0; *ms the average
-// kernel time (HIP events).
-int potus_dense_matvec_probe(int device, int chains, int D, int nrhs, const double *Minv_host, const double *x_host, double *y_host, double *dot_host, int reps, double *ms) {
+// y_r = M^-1 x_r (r < nrhs <= 3) for `chains` dense inverse metrics of size D x D (symmetric; the device keeps the strict
+// upper triangle and the diagonal).  Minv_host == NULL: the matrices are generated on the device (k_dn_fill) -- for rates
+// at sizes whose matrices would take seconds to upload.  Runs the product `reps` times; x_host / y_host are
+// [chains][nrhs][D]; dot_host [chains] receives x_0 . M^-1 x_0; *ms the average time of a pass (HIP events); *pass_bytes
+// the bytes of matrix one pass loads per chain.
+int potus_dense_matvec_probe(int device, int chains, int D, int nrhs, const double *Minv_host, const double *x_host, double *y_host, double *dot_host, int reps,
+                             double *ms, long long *pass_bytes) {
   if (chains < 1 || D < 1 || nrhs < 1 || nrhs > 3 || !x_host || !y_host || reps < 1) return fail(POTUS_ERR_ARG, "potus_dense_matvec_probe: bad arguments");
   DenseProbe pr;
   int rc = pr.init(device, chains, D, 1);
   if (rc) return rc;
   DnParams &P = pr.P;
-  if (Minv_host) HIP_TRY(hipMemcpy2D(P.Minv, (size_t)P.LD * 8, Minv_host, (size_t)D * 8, (size_t)D * 8, (size_t)chains * D, hipMemcpyHostToDevice));
-  else hipLaunchKernelGGL(k_dn_fill, dim3(4096), dim3(256), 0, 0, P);
+  if (Minv_host) {
+    HIP_TRY(hipMemcpy2D(P.A, (size_t)P.LD * 8, Minv_host, (size_t)D * 8, (size_t)D * 8, (size_t)chains * D, hipMemcpyHostToDevice));   // the lower half is ignored
+    std::vector<double> dg((size_t)chains * P.LD, 0.0);
+    for (int c = 0; c < chains; c++) for (int i = 0; i < D; i++) dg[(size_t)c * P.LD + i] = Minv_host[((size_t)c * D + i) * D + i];
+    HIP_TRY(hipMemcpy(P.dg, dg.data(), dg.size() * 8, hipMemcpyHostToDevice));
+  } else hipLaunchKernelGGL(k_dn_fill, dim3(4096), dim3(256), 0, 0, P);
   std::vector<DnRound> rds(chains);
   for (int c = 0; c < chains; c++) {
     DnRound &r = rds[c];
@@ -2136,25 +2178,18 @@ int potus_dense_matvec_probe(int device, int chains, int D, int nrhs, const doub
       HIP_TRY(hipMemcpy(P.state + ((size_t)c * DV_COUNT + DV_POOLP + k) * P.LD, x_host + ((size_t)c * nrhs + k) * D, (size_t)D * 8, hipMemcpyHostToDevice));
   }
   if ((rc = pr.set_rounds(rds))) return rc;
-  for (const void *f : {reinterpret_cast<const void *>(k_dn_matvec<1>), reinterpret_cast<const void *>(k_dn_matvec<2>), reinterpret_cast<const void *>(k_dn_matvec<3>)})
-    HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DN_LDS_DOUBLES * 8));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-  const dim3 grid((unsigned)P.npart, (unsigned)chains);
-  auto launch = [&]() {
-    if (nrhs == 1) hipLaunchKernelGGL(k_dn_matvec<1>, grid, dim3(DN_THREADS), DN_LDS_DOUBLES * 8, 0, P);
-    else if (nrhs == 2) hipLaunchKernelGGL(k_dn_matvec<2>, grid, dim3(DN_THREADS), DN_LDS_DOUBLES * 8, 0, P);
-    else hipLaunchKernelGGL(k_dn_matvec<3>, grid, dim3(DN_THREADS), DN_LDS_DOUBLES * 8, 0, P);
-  };
-  launch();   // warm-up
+  dense_symv_launch(0, P, nrhs);   // warm-up
   (void)hipEventRecord(e0, 0);
-  for (int r = 0; r < reps; r++) launch();
+  for (int r = 0; r < reps; r++) dense_symv_launch(0, P, nrhs);
   (void)hipEventRecord(e1, 0);
   const bool ok = hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;
   float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  if (!ok) return fail(POTUS_ERR_DEVICE, "k_dn_matvec failed");
+  if (!ok) return fail(POTUS_ERR_DEVICE, "k_dn_symv failed");
   if (ms) *ms = (double)t / reps;
+  if (pass_bytes) *pass_bytes = dense_pass_bytes(D, P.LD) * (nrhs == 3 ? 2 : 1);
   for (int c = 0; c < chains; c++) {
     for (int k = 0; k < nrhs; k++)
       HIP_TRY(hipMemcpy(y_host + ((size_t)c * nrhs + k) * D, P.state + ((size_t)c * DV_COUNT + DV_POOLPS + k) * P.LD, (size_t)D * 8, hipMemcpyDeviceToHost));
@@ -2169,8 +2204,9 @@ int potus_dense_matvec_probe(int device, int chains, int D, int nrhs, const doub
 }
 
 // covar_adaptation on caller data: draws [chains][n][D] -> M^-1 (covariance of the window, regularised), its lower
-// Cholesky factor, and p = L^-T u for u [chains][D] (the momentum draw's triangular solve).  Outputs [chains][D][D] /
-// [chains][D]; ms[3] = covariance, factorisation, solve (milliseconds).
+// Cholesky factor (in place, in the lower triangle of the same matrix), and p = L^-T u for u [chains][D] (the momentum
+// draw's triangular solve).  Outputs [chains][D][D] (M^-1 rebuilt from the upper triangle and the diagonal vector; L the
+// lower triangle, zeros above) / [chains][D]; ms[3] = covariance, factorisation, solve (milliseconds).
 int potus_dense_factor_probe(int device, int chains, int D, int n, const double *draws_host, const double *u_host, double *Minv_host, double *L_host,
                              double *p_host, double *ms) {
   if (chains < 1 || D < 1 || n < 2 || !draws_host) return fail(POTUS_ERR_ARG, "potus_dense_factor_probe: bad arguments");
@@ -2190,7 +2226,6 @@ int potus_dense_factor_probe(int device, int chains, int D, int n, const double 
   hipLaunchKernelGGL(k_dn_center, eg, dim3(256), 0, 0, P, n);
   hipLaunchKernelGGL(k_dn_cov, dim3(nb, nb, chains), dim3(256), 0, 0, P, n);
   (void)hipEventRecord(ev[1], 0);
-  HIP_TRY(hipMemcpyAsync(P.Lc, P.Minv, (size_t)chains * D * P.LD * 8, hipMemcpyDeviceToDevice, 0));
   for (int kb = 0; kb < nb; kb++) {
     hipLaunchKernelGGL(k_dn_potrf, dim3(chains), dim3(256), 0, 0, P, kb);
     const int rem = nb - kb - 1;
@@ -2215,8 +2250,18 @@ int potus_dense_factor_probe(int device, int chains, int D, int n, const double 
   int failed = 0;
   HIP_TRY(hipMemcpy(&failed, P.fail, 4, hipMemcpyDeviceToHost));
   if (failed) return fail(POTUS_ERR_STATE, "covariance not positive definite");
-  if (Minv_host) HIP_TRY(hipMemcpy2D(Minv_host, (size_t)D * 8, P.Minv, (size_t)P.LD * 8, (size_t)D * 8, (size_t)chains * D, hipMemcpyDeviceToHost));
-  if (L_host) HIP_TRY(hipMemcpy2D(L_host, (size_t)D * 8, P.Lc, (size_t)P.LD * 8, (size_t)D * 8, (size_t)chains * D, hipMemcpyDeviceToHost));
+  if (Minv_host || L_host) {
+    std::vector<double> buf((size_t)D * D), dg(D);
+    for (int c = 0; c < chains; c++) {
+      HIP_TRY(hipMemcpy2D(buf.data(), (size_t)D * 8, P.A + (size_t)c * D * P.LD, (size_t)P.LD * 8, (size_t)D * 8, (size_t)D, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(dg.data(), P.dg + (size_t)c * P.LD, (size_t)D * 8, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < (size_t)D; i++)
+        for (size_t j = 0; j < (size_t)D; j++) {
+          if (Minv_host) Minv_host[((size_t)c * D + i) * D + j] = i == j ? dg[i] : (i < j ? buf[i * D + j] : buf[j * D + i]);
+          if (L_host) L_host[((size_t)c * D + i) * D + j] = j <= i ? buf[i * D + j] : 0.0;
+        }
+    }
+  }
   if (u_host && p_host)
     for (int c = 0; c < chains; c++) HIP_TRY(hipMemcpy(p_host + (size_t)c * D, P.state + ((size_t)c * DV_COUNT + DV_P0) * P.LD, (size_t)D * 8, hipMemcpyDeviceToHost));
   return 0;
