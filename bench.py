@@ -45,13 +45,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
 def algorithmic_bytes_per_leapfrog(d, variant="full", dense=False):
-    """48 D + 36 N_state + 32 N_nat + 24 S^2 + 16 S (diag metric); + 8 D^2 for the dense metric."""
+    """48 D + 36 N_state + 32 N_nat + 24 S^2 + 16 S (diag metric).  Dense metric: the survey adds
+    8 D^2 (M^-1 read as a full matrix); M^-1 is symmetric and is stored and read as its upper triangle: + 4 D^2."""
     from us_potus_model_amd import _abi
     D = _abi.num_params(d, variant)
     S = int(d["S"])
     per_state, per_nat = (36, 32) if variant == "full" else (28, 24)
     b = 48 * D + per_state * int(d["N_state_polls"]) + per_nat * int(d["N_national_polls"]) + 24 * S * S + 16 * S
-    return b + (8 * D * D if dense else 0)
+    return b + (4 * D * D if dense else 0)
 
 
 def measured_traffic(kernel):
@@ -275,7 +276,7 @@ def main():
         if dense:   # the dominant kernel is the matrix pass: bytes of matrix it streamed / its own time (HIP events around every launch)
             achieved = dense_t[2] / (dense_t[0] * 1e-3) / 1e9
         K = hs[0].cus_per_chain
-        kernel = "k_dn_matvec" if dense else ("k_cl_run" if K > 1 else "k_run")
+        kernel = "k_dn_symv" if dense else ("k_cl_run" if K > 1 else "k_run")
         tr = measured_traffic(kernel)
         traffic = tr[1]["hbm_bytes_per_leapfrog"] * sum(lf_local) / (kernel_ms * 1e-3) / 1e9 if tr else None
         C_tot = sum(w[3] for w in work)
@@ -311,7 +312,8 @@ def main():
                              "avg_pass_ms": dense_t[0] / max(dense_t[1], 1), "leaf_rounds": dense_t[3]} if dense else {}),
                          "note": (f"latency-bound at {C_tot} chains ({C_tot * K} of 256 CUs busy): the state of a chain stays in L2, a leapfrog "
                                   "is a chain of dependent phases and exchanges between the CUs of a cluster; see DESIGN.md") if not dense else
-                                 "dense metric: every leapfrog streams the chain's D x D inverse metric"},
+                                 "dense metric: every leapfrog streams the upper triangle of the chain's D x D inverse metric (4 D^2 bytes; the "
+                                 "survey's 8 D^2 assumed the full matrix); achieved = bytes loaded by the matrix passes / their time"},
         }
         if world == 1 and cfg == 1 and not args.no_saturated:
             # The same posterior with the GPU full: 256 chains, one workgroup per chain (k_run).  Not the metric's

@@ -42,6 +42,7 @@
 #define DN_CT 512                                         // columns per tile of it (8 per lane)
 #define DN_RG 4                                           // rows of a wave loaded together (16 loads of 16 bytes in flight per lane)
 #define DN_FIN 256                                        // threads of the finishing kernel = elements per partial sum
+#define DN_SPLIT_MAX 4                                    // at most this many workgroups share a pair of row blocks
 typedef double dn_d2 __attribute__((ext_vector_type(2)));
 
 // vector slots of a chain's dense state block
@@ -83,8 +84,8 @@ struct DnParams {
   double *A;                         // [chains][D][LD]: strict upper triangle = M^-1, lower triangle incl. diagonal = its Cholesky factor
   double *dg;                        // [chains][LD] diagonal of M^-1
   double *tpart;                     // [chains][nblk][3][LD] column sums of the symmetric product per block of DN_RB rows
-  double *srow;                      // [chains][3][LD] its row sums
-  int nblk, pad1;                    // blocks of DN_RB rows
+  double *srow;                      // [chains][3][DN_SPLIT_MAX][LD] its row sums, per part of the tile range
+  int nblk, split;                   // blocks of DN_RB rows; workgroups sharing a pair of blocks (each takes every split-th tile)
   double *win;                       // [chains][win_cap][LD] draws of the current adaptation window
   int win_cap, identity;             // identity: the metric is still the unit matrix (before the first window ends)
   double *partial;                   // [chains][npart]
@@ -126,11 +127,14 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int jo
 #pragma unroll
   for (int r = 0; r < NRHS; r++) x[r] = dn_vec(P, chain, rd.job[job0 + r].x);
   double *tp = P.tpart + ((size_t)chain * nblk * 3 + job0) * (size_t)LD;   // [block][job][LD]
-  double *sr = P.srow + ((size_t)chain * 3 + job0) * (size_t)LD;
+  // With few chains a pair of blocks per workgroup does not fill the chip: `split` workgroups share a pair, each taking
+  // every split-th column tile; their column sums go to disjoint columns, their row sums to a slot of their own.
+  const int split = P.split, part = (int)blockIdx.x % split, pair = (int)blockIdx.x / split;
+  double *sr = P.srow + (((size_t)chain * 3 + job0) * DN_SPLIT_MAX + part) * (size_t)LD;
   const unsigned rowbytes = uni32(8u * (unsigned)LD);
   for (int side = 0; side < 2; side++) {
-    const int b = side == 0 ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
-    if (side == 1 && b <= (int)blockIdx.x) break;         // odd number of blocks: the middle one once
+    const int b = side == 0 ? pair : nblk - 1 - pair;
+    if (side == 1 && b <= pair) break;                    // odd number of blocks: the middle one once
     const int r0 = b * DN_RB, wrow0 = r0 + 16 * w;
     // buffer addressing: the wave's 16 rows are one resource (rows beyond D fall outside it and read as zeros), the row is
     // a scalar offset, the lane's columns one 32-bit vector offset per load.  (Made wave-uniform explicitly: the compiler
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int jo
 #pragma unroll
     for (int r = 0; r < NRHS; r++)
       for (int i = tid; i < DN_RB; i += DN_THREADS) { xr[r * DN_RB + i] = r0 + i < D ? x[r][r0 + i] : 0.0; sacc[r * DN_RB + i] = 0.0; }
-    for (int c0 = (r0 / DN_CT) * DN_CT; c0 < D; c0 += DN_CT) {
+    for (int c0 = (r0 / DN_CT + part) * DN_CT; c0 < D; c0 += split * DN_CT) {
       __syncthreads();                                    // the previous tile's column sums have been read
 #pragma unroll
       for (int r = 0; r < NRHS; r++)
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int jo
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < NRHS; r++)
-      for (int i = tid; i < DN_RB; i += DN_THREADS) if (r0 + i < D) sr[(size_t)r * LD + r0 + i] = sacc[r * DN_RB + i];
+      for (int i = tid; i < DN_RB; i += DN_THREADS) if (r0 + i < D) sr[(size_t)r * DN_SPLIT_MAX * LD + r0 + i] = sacc[r * DN_RB + i];
   }
 }
 // y_i = diag_i x_i + row sum_i + the column sums of the blocks at or above row i, in block order; then what the round
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(DN_FIN) void k_dn_symv_finish(const DnParams P, int
   if (!rd.active) return;
   const int i = blockIdx.x * DN_FIN + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int LD = P.LD;
-  const double *tp = P.tpart + ((size_t)chain * P.nblk * 3 + job0) * (size_t)LD, *sr = P.srow + ((size_t)chain * 3 + job0) * (size_t)LD;
+  const double *tp = P.tpart + ((size_t)chain * P.nblk * 3 + job0) * (size_t)LD, *sr = P.srow + ((size_t)chain * 3 + job0) * DN_SPLIT_MAX * (size_t)LD;
   const double *dg = P.dg + (size_t)chain * LD;
   double dsum = 0.0;
   if (i < P.D) {
@@ -233,7 +237,8 @@ __global__ __launch_bounds__(DN_FIN) void k_dn_symv_finish(const DnParams P, int
 #pragma unroll
     for (int r = 0; r < NRHS; r++) {
       const DnJob &jb = rd.job[job0 + r];
-      double y = dg[i] * dn_vec(P, chain, jb.x)[i] + sr[(size_t)r * LD + i];
+      double y = dg[i] * dn_vec(P, chain, jb.x)[i];
+      for (int p = 0; p < P.split; p++) y += sr[((size_t)r * DN_SPLIT_MAX + p) * LD + i];
       for (int b = 0; b < nb; b++) y += tp[((size_t)b * 3 + r) * LD + i];
       if (jb.y >= 0) dn_vec(P, chain, jb.y)[i] = y;
       if (jb.qout >= 0) dn_vec(P, chain, jb.qout)[i] = dn_vec(P, chain, jb.qin)[i] + jb.coef * y;

@@ -1146,6 +1146,9 @@ int dense_window_capacity(int nw, int ib, int tb, int bw) {
   return cap;
 }
 
+// workgroups per pair of row blocks: enough of them to keep 256 compute units busy when the chains are few
+int dense_split(int chains, int nblk) { return std::max(1, std::min(DN_SPLIT_MAX, (1024 + chains * ((nblk + 1) / 2) - 1) / (chains * ((nblk + 1) / 2)))); }
+
 // bytes one pass of the symmetric product loads per chain: the tiles right of (and on) each row block's diagonal
 long long dense_pass_bytes(int D, int LD) {
   long long n = 0;
@@ -1159,6 +1162,7 @@ int dense_alloc(Sampler *sp) {
   const int D = sp->L.D, chains = sp->R.chains;
   P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_FIN - 1) / DN_FIN; P.nblk = (D + DN_RB - 1) / DN_RB; P.sc_stride = sp->K; P.identity = 1;
   P.win_cap = dense_window_capacity(sp->R.num_warmup, sp->R.init_buffer, sp->R.term_buffer, sp->R.window);
+  P.split = dense_split(chains, P.nblk);
   const size_t mat = (size_t)chains * D * P.LD * 8, vec = (size_t)chains * DV_COUNT * P.LD * 8, win = (size_t)chains * P.win_cap * P.LD * 8;
   const size_t tp = (size_t)chains * P.nblk * 3 * P.LD * 8;
   size_t free_b = 0, total_b = 0;
@@ -1174,7 +1178,7 @@ int dense_alloc(Sampler *sp) {
   };
   int rc;
   if ((rc = get((void **)&P.state, vec)) || (rc = get((void **)&P.A, mat)) || (rc = get((void **)&P.dg, (size_t)chains * P.LD * 8)) || (rc = get((void **)&P.win, win)) ||
-      (rc = get((void **)&P.tpart, tp)) || (rc = get((void **)&P.srow, (size_t)chains * 3 * P.LD * 8)) ||
+      (rc = get((void **)&P.tpart, tp)) || (rc = get((void **)&P.srow, (size_t)chains * 3 * DN_SPLIT_MAX * P.LD * 8)) ||
       (rc = get((void **)&P.partial, (size_t)chains * P.npart * 8)) || (rc = get((void **)&P.lpbuf, (size_t)chains * 8)) ||
       (rc = get((void **)&P.ts, (size_t)chains * sizeof(TS))) || (rc = get((void **)&P.rd, (size_t)chains * sizeof(DnRound))) ||
       (rc = get((void **)&P.active, (size_t)chains * 4)) || (rc = get((void **)&P.fail, 4)))
@@ -1197,7 +1201,7 @@ int dense_alloc(Sampler *sp) {
 // M^-1 times the round's right-hand sides for the active chains: one pass over the upper triangles (two launches when
 // there are three right-hand sides) and the finishing kernel
 void dense_symv_launch(hipStream_t st, const DnParams &P, int nrhs) {
-  const dim3 grid((unsigned)((P.nblk + 1) / 2), (unsigned)P.chains), fin((unsigned)P.npart, (unsigned)P.chains);
+  const dim3 grid((unsigned)(((P.nblk + 1) / 2) * P.split), (unsigned)P.chains), fin((unsigned)P.npart, (unsigned)P.chains);
   if (nrhs == 1) {
     hipLaunchKernelGGL(k_dn_symv<1>, grid, dim3(DN_THREADS), DN_SYMV_LDS(1), st, P, 0);
     hipLaunchKernelGGL(k_dn_symv_finish<1>, fin, dim3(DN_FIN), 0, st, P, 0);
@@ -2136,7 +2140,8 @@ struct DenseProbe {   // a DnParams with every chain active, owned buffers
     P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_FIN - 1) / DN_FIN; P.nblk = (D + DN_RB - 1) / DN_RB; P.sc_stride = 1; P.win_cap = win_cap; P.identity = 0;
     const size_t mat = (size_t)chains * D * P.LD * 8;
     HIP_TRY(bufs.alloc(&P.state, (size_t)chains * DV_COUNT * P.LD * 8)); HIP_TRY(bufs.alloc(&P.A, mat)); HIP_TRY(bufs.alloc(&P.dg, (size_t)chains * P.LD * 8));
-    HIP_TRY(bufs.alloc(&P.tpart, (size_t)chains * P.nblk * 3 * P.LD * 8)); HIP_TRY(bufs.alloc(&P.srow, (size_t)chains * 3 * P.LD * 8));
+    P.split = dense_split(chains, P.nblk);
+    HIP_TRY(bufs.alloc(&P.tpart, (size_t)chains * P.nblk * 3 * P.LD * 8)); HIP_TRY(bufs.alloc(&P.srow, (size_t)chains * 3 * DN_SPLIT_MAX * P.LD * 8));
     HIP_TRY(bufs.alloc(&P.win, (size_t)chains * std::max(win_cap, 1) * P.LD * 8)); HIP_TRY(bufs.alloc(&P.partial, (size_t)chains * P.npart * 8));
     HIP_TRY(bufs.alloc(&P.lpbuf, (size_t)chains * 8)); HIP_TRY(bufs.alloc(&P.ts, (size_t)chains * sizeof(TS)));
     HIP_TRY(bufs.alloc(&P.rd, (size_t)chains * sizeof(DnRound))); HIP_TRY(bufs.alloc(&P.active, (size_t)chains * 4)); HIP_TRY(bufs.alloc(&P.fail, 4));
