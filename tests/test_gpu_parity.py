@@ -330,6 +330,17 @@ def test_stan_csv_round_trip(cases, tmp_path):
         assert rows.shape == (4, h.n_cols)
         assert np.allclose(rows, full[:, c, :], rtol=2e-5, atol=1e-12)       # %.6g text, as CmdStan writes
         assert any(l.startswith("# Step size") for l in lines) and any("Elapsed Time" in l for l in lines)
+        k_adapt = next(i for i, l in enumerate(lines) if l.startswith("# Adaptation terminated"))
+        k_first = next(i for i, l in enumerate(lines) if l and l[0] in "-0123456789")
+        assert k_adapt < k_first                                       # no warm-up rows saved: the block follows the header
+    h.close()
+    # with save_warmup CmdStan writes the adaptation block when warm-up ends, i.e. after the warm-up rows
+    h = Handle(data, variant, chains=1, num_warmup=10, num_samples=4, seed=8, save_warmup=1)
+    h.init(); h.run(14)
+    lines = open(h.write_stan_csv(tmp_path, "pollw")[0]).read().splitlines()
+    rows_before = sum(1 for l in lines[:next(i for i, l in enumerate(lines) if l.startswith("# Adaptation terminated"))] if l and l[0] in "-0123456789")
+    assert rows_before == 10 and sum(1 for l in lines if l and l[0] in "-0123456789") == 14
+    assert "save_warmup = 1" in "\n".join(lines)
     h.close()
 
 

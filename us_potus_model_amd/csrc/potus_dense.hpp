@@ -219,27 +219,40 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int jo
       for (int i = tid; i < DN_RB; i += DN_THREADS) if (r0 + i < D) sr[(size_t)r * DN_SPLIT_MAX * LD + r0 + i] = sacc[r * DN_RB + i];
   }
 }
-// y_i = diag_i x_i + row sum_i + the column sums of the blocks at or above row i, in block order; then what the round
-// wants done with the products: stores, the position update, partial sums of dot . y (per workgroup, fixed order)
+// y_i = diag_i x_i + row sums_i + the column sums of the blocks at or above row i; then what the round wants done with
+// the products: stores, the position update, partial sums of dot . y.  64 elements per workgroup, four threads per
+// element: thread (i, k) adds the blocks b = k, k + 4, ... (up to 326 of them at D = 41 610: one thread alone would walk
+// them as a chain of dependent loads), then the four are added in order.  Fixed order: same bytes every run.
 template <int NRHS>
 __global__ __launch_bounds__(DN_FIN) void k_dn_symv_finish(const DnParams P, int job0) {
+  __shared__ double quad[NRHS][4][DN_FIN / 4];
   __shared__ double dn_part[DN_FIN / 64];
   const int chain = blockIdx.y;
   const DnRound &rd = P.rd[chain];
   if (!rd.active) return;
-  const int i = blockIdx.x * DN_FIN + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int e = threadIdx.x & (DN_FIN / 4 - 1), k4 = threadIdx.x / (DN_FIN / 4);
+  const int i = blockIdx.x * (DN_FIN / 4) + e, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int LD = P.LD;
   const double *tp = P.tpart + ((size_t)chain * P.nblk * 3 + job0) * (size_t)LD, *sr = P.srow + ((size_t)chain * 3 + job0) * DN_SPLIT_MAX * (size_t)LD;
   const double *dg = P.dg + (size_t)chain * LD;
-  double dsum = 0.0;
   if (i < P.D) {
     const int nb = i / DN_RB + 1;
+#pragma unroll
+    for (int r = 0; r < NRHS; r++) {
+      double t = 0.0;
+      for (int b = k4; b < nb; b += 4) t += tp[((size_t)b * 3 + r) * LD + i];
+      quad[r][k4][e] = t;
+    }
+  }
+  __syncthreads();
+  double dsum = 0.0;
+  if (k4 == 0 && i < P.D) {
 #pragma unroll
     for (int r = 0; r < NRHS; r++) {
       const DnJob &jb = rd.job[job0 + r];
       double y = dg[i] * dn_vec(P, chain, jb.x)[i];
       for (int p = 0; p < P.split; p++) y += sr[((size_t)r * DN_SPLIT_MAX + p) * LD + i];
-      for (int b = 0; b < nb; b++) y += tp[((size_t)b * 3 + r) * LD + i];
+      y += ((quad[r][0][e] + quad[r][1][e]) + quad[r][2][e]) + quad[r][3][e];
       if (jb.y >= 0) dn_vec(P, chain, jb.y)[i] = y;
       if (jb.qout >= 0) dn_vec(P, chain, jb.qout)[i] = dn_vec(P, chain, jb.qin)[i] + jb.coef * y;
       if (job0 + r == 0 && jb.dot >= 0) dsum = dn_vec(P, chain, jb.dot)[i] * y;
@@ -248,12 +261,7 @@ __global__ __launch_bounds__(DN_FIN) void k_dn_symv_finish(const DnParams P, int
   const double tot = dpp_wave_sum(dsum);
   if (lane == 0) dn_part[w] = tot;
   __syncthreads();
-  if (threadIdx.x == 0 && job0 == 0) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < DN_FIN / 64; k++) t += dn_part[k];
-    P.partial[(size_t)chain * P.npart + blockIdx.x] = t;
-  }
+  if (threadIdx.x == 0 && job0 == 0) P.partial[(size_t)chain * P.npart + blockIdx.x] = dn_part[0];   // (k4 == 0 is wave 0)
 }
 
 // ---------------------------------------------------------------- elementwise pieces of a round
@@ -367,6 +375,15 @@ __device__ __forceinline__ double dn_partial_sum(const DnParams &P, int chain) {
   return t;
 }
 
+// the same sum by a whole workgroup (k_dn_step): strided partial sums per thread, then the block tree -- fixed order too
+__device__ __forceinline__ double dn_partial_sum_block(const DnParams &P, int chain, double *red_) {
+  const double *p = P.partial + (size_t)chain * P.npart;
+  double v[1] = {0.0};
+  for (int i = threadIdx.x; i < P.npart; i += DN_THREADS) v[0] += p[i];
+  block_sum(v, (ldp)red_, (int)threadIdx.x);
+  return v[0];
+}
+
 enum { DN_MODE_BEGIN = 0, DN_MODE_LEAF = 1 };
 
 // called by thread 0: the next leaf of the current doubling
@@ -396,9 +413,10 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_step(const DnParams P, const 
   const RngKey key{Rg->seed_lo, Rg->seed_hi, (uint32_t)(Rg->chain_id_offset + chain + 1)};
   const int max_depth = Rg->max_depth;
   bool new_doubling = false;
+  const double kin_pass = dn_partial_sum_block(P, chain, red);   // p . M^-1 p of the pass just finished
   if (mode == DN_MODE_BEGIN) {
     if (tid == 0) {
-      const double kin0 = dn_partial_sum(P, chain), lp0 = P.lpbuf[chain];
+      const double kin0 = kin_pass, lp0 = P.lpbuf[chain];
       ts.H0 = 0.5 * kin0 - lp0;
       ts.lsw = 0.0; ts.sum_metro = 0.0; ts.n_leap = 0; ts.depth = 0; ts.divergent = 0; ts.stop = 0;
       ts.sample_qid = 0; ts.nextq[1] = 1; ts.nextq[0] = 2;
@@ -411,7 +429,7 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_step(const DnParams P, const 
     const int n = ts.m;                        // leaf number inside the doubling (kept in ts.m between launches)
     const int depth = ts.depth, dir = ts.dir, leaf = ts.leaf_id;
     if (tid == 0) {
-      const double kin = dn_partial_sum(P, chain), lpv = P.lpbuf[chain], H0 = ts.H0;
+      const double kin = kin_pass, lpv = P.lpbuf[chain], H0 = ts.H0;
       double h = 0.5 * kin - lpv;
       if (isnan(h)) h = INFINITY;
       const int div = (h - H0 > 1000.0) ? 1 : ts.divergent;

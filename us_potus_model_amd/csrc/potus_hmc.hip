@@ -1160,7 +1160,7 @@ long long dense_pass_bytes(int D, int LD) {
 int dense_alloc(Sampler *sp) {
   DnParams &P = sp->dn;
   const int D = sp->L.D, chains = sp->R.chains;
-  P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_FIN - 1) / DN_FIN; P.nblk = (D + DN_RB - 1) / DN_RB; P.sc_stride = sp->K; P.identity = 1;
+  P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_FIN / 4 - 1) / (DN_FIN / 4); P.nblk = (D + DN_RB - 1) / DN_RB; P.sc_stride = sp->K; P.identity = 1;
   P.win_cap = dense_window_capacity(sp->R.num_warmup, sp->R.init_buffer, sp->R.term_buffer, sp->R.window);
   P.split = dense_split(chains, P.nblk);
   const size_t mat = (size_t)chains * D * P.LD * 8, vec = (size_t)chains * DV_COUNT * P.LD * 8, win = (size_t)chains * P.win_cap * P.LD * 8;
@@ -2137,7 +2137,7 @@ struct DenseProbe {   // a DnParams with every chain active, owned buffers
   DevBufs bufs;
   int init(int device, int chains, int D, int win_cap) {
     HIP_TRY(hipSetDevice(device));
-    P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_FIN - 1) / DN_FIN; P.nblk = (D + DN_RB - 1) / DN_RB; P.sc_stride = 1; P.win_cap = win_cap; P.identity = 0;
+    P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_FIN / 4 - 1) / (DN_FIN / 4); P.nblk = (D + DN_RB - 1) / DN_RB; P.sc_stride = 1; P.win_cap = win_cap; P.identity = 0;
     const size_t mat = (size_t)chains * D * P.LD * 8;
     HIP_TRY(bufs.alloc(&P.state, (size_t)chains * DV_COUNT * P.LD * 8)); HIP_TRY(bufs.alloc(&P.A, mat)); HIP_TRY(bufs.alloc(&P.dg, (size_t)chains * P.LD * 8));
     P.split = dense_split(chains, P.nblk);
