@@ -4,9 +4,9 @@
 // 64 x 64) times the suffix sums C (64 x T).  The sampler never forms that product: mu_b is needed only at the polled
 // (state, day) cells, one 51-term dot each.  This program times both forms of the FORWARD product on one workgroup of
 // 512 threads (every compute unit busy with a copy, as in the one-workgroup-per-chain kernels), operands in LDS:
-//   dense   64 x 64 x Tc on v_mfma_f64_16x16x4_f64 (Tc = a 256-day chunk; T = 600 is 2.34 chunks)
+//   dense   64 x 64 x Tc on v_mfma_f64_16x16x4_f64 (Tc = a 240-day chunk: what fits LDS beside the factor; T = 600 is 2.5 chunks)
 //   sparse  one thread per poll: dot of L_W[s, :] with C[:, t] (the inner loop of phase C)
-// for the 2016 shape (1 619 polls over 254 days) and the configs[4] shape (10 000 polls over 600 days -> 4 267 per chunk).
+// for the 2016 shape (1 619 polls over 254 days -> 1 530 per chunk) and the configs[4] shape (10 000 polls over 600 days -> 4 000 per chunk).
 //
 //   hipcc --offload-arch=gfx950 -O3 scripts/micro/mfma_vs_sparse.hip -o /tmp/mfma_vs_sparse && /tmp/mfma_vs_sparse
 #include <hip/hip_runtime.h>
@@ -16,8 +16,8 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define S 51
 #define SP 65          // LDS row stride of the 64 x 64 factor
-#define TC 256         // days per chunk
-#define TP 257         // LDS row stride of C[k][t]
+#define TC 240         // days per chunk: 64 x 65 + 64 x 241 doubles = 157 KB of LDS
+#define TP 241         // LDS row stride of C[k][t]
 
 __global__ __launch_bounds__(512) void k_dense(const double *Lw, const double *Cin, double *sink, long long *cycles, int reps) {
   extern __shared__ double lds[];
@@ -29,8 +29,8 @@ __global__ __launch_bounds__(512) void k_dense(const double *Lw, const double *C
   double acc_sink = 0.0;
   const long long t0 = clock64();
   for (int r = 0; r < reps; r++) {
-    // output 64 x 256 = 4 x 16 tiles of 16 x 16; wave w takes day blocks 2w, 2w+1 for all four state blocks
-    for (int db = 2 * w; db < 2 * w + 2; db++) {
+    // output 64 x 240 = 4 x 15 tiles of 16 x 16; wave w takes day blocks w and w + 8 for all four state blocks
+    for (int db = w; db < TC / 16; db += 8) {
       d4 acc[4];
       for (int sb = 0; sb < 4; sb++) acc[sb] = d4{0, 0, 0, 0};
       for (int k0 = 0; k0 < 64; k0 += 4) {
@@ -97,7 +97,7 @@ int main() {
   const double dense = avg();
   printf("dense  64 x 64 x %d days on v_mfma_f64_16x16x4_f64: %.0f cycles per workgroup pass (%.1f GFLOP/s per CU at 2.4 GHz)\n", TC, dense,
          2.0 * 64 * 64 * TC / dense * 2.4);
-  for (int npoll : {1619, 4267}) {
+  for (int npoll : {1530, 4000}) {
     std::vector<int> ps(npoll), pt(npoll);
     for (int i = 0; i < npoll; i++) { ps[i] = (i * 37) % (S + 1) % 64; pt[i] = (i * 101) % TC; }
     hipMemcpy(dps, ps.data(), npoll * 4, hipMemcpyHostToDevice); hipMemcpy(dpt, pt.data(), npoll * 4, hipMemcpyHostToDevice);

@@ -165,3 +165,25 @@ def test_dense_sampler_on_the_2016_posterior(cases, cus):
     print(f"2016 dense (cus_per_chain {h.cus_per_chain}): {passes} matrix passes, {nbytes / 1e9:.1f} GB in {ms:.1f} ms = {nbytes / ms / 1e9 * 1e3 / 1e3:.2f} TB/s; {rounds} leaf rounds")
     assert d[:, -3:, 1].mean() > 0.3                                   # transitions under the adapted metric accept
     h.close()
+
+
+def test_dense_sixteen_chains_of_the_stress_shape_fit_one_gpu():
+    """BASELINE configs[4] as specified: 16 chains per GPU, 51 states x 600 days x 10 000 polls, dense metric.  One
+    13.85 GB matrix per chain (M^-1 above the diagonal, its Cholesky factor below) = 222 GB of the 288; the first
+    transition runs (unit metric: it must be the diagonal sampler's first transition)."""
+    from us_potus_model_amd import synthetic
+    data = synthetic.stress()
+    kw = dict(chains=16, num_warmup=1, num_samples=0, save_warmup=1, seed=5)
+    h = Handle(data, "full", metric=_abi.METRIC_DENSE, **kw)
+    assert h.cus_per_chain == 16 and h.D == 41610
+    h.init(); h.run(1)
+    d = h.draws()
+    ms, passes, nbytes, rounds = h.dense_timing()
+    print(f"stress shape, 16 dense chains: {passes} passes, {nbytes / 1e12:.2f} TB in {ms:.0f} ms = {nbytes / ms / 1e9:.2f} TB/s")
+    h.close()
+    g = Handle(data, "full", **kw)
+    g.init(); g.run(1)
+    e = g.draws()
+    g.close()
+    assert np.array_equal(d[:, :, 3:6], e[:, :, 3:6])                    # depth, n_leapfrog, divergent
+    assert np.allclose(d[:, :, 7:], e[:, :, 7:], rtol=1e-9, atol=1e-10) and np.allclose(d[:, :, 0], e[:, :, 0], rtol=1e-10)

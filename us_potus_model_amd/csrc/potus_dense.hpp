@@ -38,7 +38,10 @@
 
 #define DN_THREADS 512
 #define DN_NB 64                                          // block size of the factorisation / triangular solve
-#define DN_RB 128                                         // rows per workgroup pass of the symmetric product (16 per wave)
+#ifndef DN_RB
+#define DN_RB 128                                         // rows per workgroup pass of the symmetric product
+#endif
+#define DN_RW (DN_RB / (DN_THREADS / 64))                 // rows per wave
 #define DN_CT 512                                         // columns per tile of it (8 per lane)
 #define DN_RG 4                                           // rows of a wave loaded together (16 loads of 16 bytes in flight per lane)
 #define DN_FIN 256                                        // threads of the finishing kernel = elements per partial sum
@@ -135,11 +138,11 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int jo
   for (int side = 0; side < 2; side++) {
     const int b = side == 0 ? pair : nblk - 1 - pair;
     if (side == 1 && b <= pair) break;                    // odd number of blocks: the middle one once
-    const int r0 = b * DN_RB, wrow0 = r0 + 16 * w;
-    // buffer addressing: the wave's 16 rows are one resource (rows beyond D fall outside it and read as zeros), the row is
+    const int r0 = b * DN_RB, wrow0 = r0 + DN_RW * w;
+    // buffer addressing: the wave's DN_RW rows are one resource (rows beyond D fall outside it and read as zeros), the row is
     // a scalar offset, the lane's columns one 32-bit vector offset per load.  (Made wave-uniform explicitly: the compiler
     // otherwise keeps the descriptor in vector registers and wraps every load in a waterfall loop.)
-    const int wrows = min(16, max(0, D - wrow0));
+    const int wrows = min(DN_RW, max(0, D - wrow0));
     const rsrc_t rsA = make_rsrc(uni_ptr(A + (size_t)wrow0 * LD), uni32((unsigned)wrows * rowbytes));
     __syncthreads();
 #pragma unroll
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int jo
       }
       const bool band = c0 < r0 + DN_RB;                  // the tile overlaps the block's own rows: only j > i counts
 #pragma unroll 1
-      for (int q = 0; q < 16; q += DN_RG) {               // DN_RG rows at a time: 4 DN_RG loads of 16 bytes in flight per lane
+      for (int q = 0; q < DN_RW; q += DN_RG) {               // DN_RG rows at a time: 4 DN_RG loads of 16 bytes in flight per lane
         dn_d2 a[DN_RG][4];
 #pragma unroll
         for (int k = 0; k < DN_RG; k++)
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int jo
             a[k][u] = __builtin_bit_cast(dn_d2, __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[u], (unsigned)(q + k) * rowbytes, 2 /* nt: read once */));
 #pragma unroll
         for (int k = 0; k < DN_RG; k++) {
-          const int lrow = 16 * w + q + k;
+          const int lrow = DN_RW * w + q + k;
           const int lim = band ? r0 + lrow : -1;          // no branch: outside the band every column counts
           double xrow[NRHS], sp[NRHS];
 #pragma unroll
