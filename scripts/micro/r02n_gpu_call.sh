@@ -1,0 +1,7 @@
+#!/bin/bash
+mkdir -p gpurun_out
+(timeout 900 python -m pytest tests/test_gpu_dense.py -q --tb=short -p no:cacheprovider -s 2>&1 | tail -30) > gpurun_out/r02n_dense.log
+timeout 600 python scripts/micro/dense_probe.py pieces 2>&1 | grep "matrix pass" > gpurun_out/r02n_pieces.log
+timeout 600 python scripts/micro/dense_probe.py sampler 8 30 > gpurun_out/r02n_sampler.log 2>&1
+(timeout 900 python bench.py --config 4 --steps 4 --warmup 0 --no-cpu-baseline 2>gpurun_out/r02n_bench4.err | tail -1) > gpurun_out/r02n_bench_config4.json
+tail -12 gpurun_out/r02n_dense.log; cat gpurun_out/r02n_pieces.log gpurun_out/r02n_sampler.log; cut -c1-200 gpurun_out/r02n_bench_config4.json

@@ -187,3 +187,25 @@ def test_dense_sixteen_chains_of_the_stress_shape_fit_one_gpu():
     g.close()
     assert np.array_equal(d[:, :, 3:6], e[:, :, 3:6])                    # depth, n_leapfrog, divergent
     assert np.allclose(d[:, :, 7:], e[:, :, 7:], rtol=1e-9, atol=1e-10) and np.allclose(d[:, :, 0], e[:, :, 0], rtol=1e-10)
+
+
+def test_dense_product_does_not_depend_on_the_launch_shape():
+    """How the column tiles are dealt to workgroups depends on the number of chains taking part in a launch; a chain's
+    M^-1 x must not (its draws would otherwise depend on what its companions are doing): one chain alone and the same
+    chain among sixteen give the same bytes."""
+    L = _lib()
+    D, nrhs = 4100, 2
+    rng = np.random.default_rng(11)
+    B = rng.standard_normal((D, 8))
+    M1 = (B @ B.T) / 8 + np.eye(D)
+    x1 = rng.standard_normal((nrhs, D))
+    outs = []
+    for chains in (1, 16):
+        M = np.ascontiguousarray(np.broadcast_to(M1, (chains, D, D)))
+        x = np.ascontiguousarray(np.broadcast_to(x1, (chains, nrhs, D)))
+        y, dot, ms, nb = np.zeros((chains, nrhs, D)), np.zeros(chains), C.c_double(), C.c_longlong()
+        assert L.potus_dense_matvec_probe(0, chains, D, nrhs, M.ctypes.data, x.ctypes.data, y.ctypes.data, dot.ctypes.data, 1, C.byref(ms), C.byref(nb)) == 0
+        outs.append((y, dot))
+    assert np.array_equal(outs[0][0][0], outs[1][0][0]) and np.array_equal(outs[1][0][0], outs[1][0][15])
+    assert outs[0][1][0] == outs[1][1][7]
+    assert np.allclose(outs[0][0][0], x1 @ M1, rtol=1e-11, atol=1e-11)

@@ -38,14 +38,12 @@
 
 #define DN_THREADS 512
 #define DN_NB 64                                          // block size of the factorisation / triangular solve
-#ifndef DN_RB
-#define DN_RB 128                                         // rows per workgroup pass of the symmetric product
-#endif
-#define DN_RW (DN_RB / (DN_THREADS / 64))                 // rows per wave
+#define DN_RB 128                                         // rows per block of the symmetric product: the unit of its column sums
+#define DN_RB_MAX 256                                     // a workgroup takes DnParams::rb = 128 or 256 rows at a time (16 or 32 per wave)
 #define DN_CT 512                                         // columns per tile of it (8 per lane)
 #define DN_RG 4                                           // rows of a wave loaded together (16 loads of 16 bytes in flight per lane)
 #define DN_FIN 256                                        // threads of the finishing kernel = elements per partial sum
-#define DN_SPLIT_MAX 4                                    // at most this many workgroups share a pair of row blocks
+#define DN_SPLIT_MAX 8                                    // at most this many workgroups share a pair of row blocks
 typedef double dn_d2 __attribute__((ext_vector_type(2)));
 
 // vector slots of a chain's dense state block
@@ -87,8 +85,10 @@ struct DnParams {
   double *A;                         // [chains][D][LD]: strict upper triangle = M^-1, lower triangle incl. diagonal = its Cholesky factor
   double *dg;                        // [chains][LD] diagonal of M^-1
   double *tpart;                     // [chains][nblk][3][LD] column sums of the symmetric product per block of DN_RB rows
-  double *srow;                      // [chains][3][DN_SPLIT_MAX][LD] its row sums, per part of the tile range
-  int nblk, split;                   // blocks of DN_RB rows; workgroups sharing a pair of blocks (each takes every split-th tile)
+  double *srow;                      // [chains][3][ntile][LD] its row sums per column tile (so that the result does not depend on
+                                     // how the tiles are dealt to workgroups)
+  int nblk, split;                   // blocks of DN_RB rows (allocation); workgroups sharing a pair of blocks (each takes every split-th tile)
+  int rb, ntile;                     // rows a workgroup takes at a time (DN_RB or DN_RB_MAX, fixed per handle by D); column tiles
   double *win;                       // [chains][win_cap][LD] draws of the current adaptation window
   int win_cap, identity;             // identity: the metric is still the unit matrix (before the first window ends)
   double *partial;                   // [chains][npart]
@@ -112,7 +112,7 @@ __device__ __forceinline__ double *dn_vec(const DnParams &P, int chain, int slot
 // Fixed summation order everywhere: same bytes every run.  Traffic besides the triangle: the column sums, written and
 // read once, nblk x D x NRHS doubles = 3 % of the matrix.
 // (job0: the first of the round's jobs this launch serves -- the three products of a transition's first pass go as 2 + 1)
-#define DN_SYMV_LDS(NRHS) ((size_t)((NRHS) * (DN_CT + 2 * DN_RB) + (DN_THREADS / 64) * (NRHS) * DN_CT) * 8)
+#define DN_SYMV_LDS(NRHS) ((size_t)((NRHS) * (DN_CT + 2 * DN_RB_MAX) + (DN_THREADS / 64) * (NRHS) * DN_CT) * 8)
 template <int NRHS>
 __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int job0) {
   extern __shared__ __attribute__((aligned(16))) double dn_lds[];
@@ -120,34 +120,35 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int jo
   const DnRound &rd = P.rd[chain];
   if (!rd.active) return;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int D = P.D, LD = P.LD, nblk = P.nblk;
+  const int D = P.D, LD = P.LD, RB = P.rb, RW = RB / (DN_THREADS / 64), nblk = (D + RB - 1) / RB;
   double *xs = dn_lds;                                   // [NRHS][DN_CT]  x over the tile's columns
-  double *xr = xs + NRHS * DN_CT;                        // [NRHS][DN_RB]  x over the block's rows
-  double *sacc = xr + NRHS * DN_RB;                      // [NRHS][DN_RB]  row sums of the block, accumulated over the tiles
-  double *tacc = sacc + NRHS * DN_RB;                    // [8 waves][NRHS][DN_CT]
+  double *xr = xs + NRHS * DN_CT;                        // [NRHS][RB]  x over the block's rows
+  double *sacc = xr + NRHS * DN_RB_MAX;                  // [NRHS][RB]  row sums of the block, accumulated over the tiles
+  double *tacc = sacc + NRHS * DN_RB_MAX;                // [8 waves][NRHS][DN_CT]
   const double *A = P.A + (size_t)chain * (size_t)D * (size_t)LD;
   const double *x[NRHS];
 #pragma unroll
   for (int r = 0; r < NRHS; r++) x[r] = dn_vec(P, chain, rd.job[job0 + r].x);
-  double *tp = P.tpart + ((size_t)chain * nblk * 3 + job0) * (size_t)LD;   // [block][job][LD]
-  // With few chains a pair of blocks per workgroup does not fill the chip: `split` workgroups share a pair, each taking
-  // every split-th column tile; their column sums go to disjoint columns, their row sums to a slot of their own.
+  double *tp = P.tpart + ((size_t)chain * P.nblk * 3 + job0) * (size_t)LD;   // [block of this launch][job][LD] (room for the DN_RB blocks)
+  // With few active chains a pair of blocks per workgroup does not fill the chip: `split` workgroups share a pair, each
+  // taking every split-th column tile.  Column sums go to disjoint columns, row sums are stored per tile: the finishing
+  // kernel adds both in a fixed order, so a chain's numbers do not depend on split, i.e. on what the other chains do.
   const int split = P.split, part = (int)blockIdx.x % split, pair = (int)blockIdx.x / split;
-  double *sr = P.srow + (((size_t)chain * 3 + job0) * DN_SPLIT_MAX + part) * (size_t)LD;
+  double *sr = P.srow + ((size_t)chain * 3 + job0) * (size_t)P.ntile * (size_t)LD;   // [job][tile][LD]
   const unsigned rowbytes = uni32(8u * (unsigned)LD);
   for (int side = 0; side < 2; side++) {
     const int b = side == 0 ? pair : nblk - 1 - pair;
     if (side == 1 && b <= pair) break;                    // odd number of blocks: the middle one once
-    const int r0 = b * DN_RB, wrow0 = r0 + DN_RW * w;
+    const int r0 = b * RB, wrow0 = r0 + RW * w;
     // buffer addressing: the wave's DN_RW rows are one resource (rows beyond D fall outside it and read as zeros), the row is
     // a scalar offset, the lane's columns one 32-bit vector offset per load.  (Made wave-uniform explicitly: the compiler
     // otherwise keeps the descriptor in vector registers and wraps every load in a waterfall loop.)
-    const int wrows = min(DN_RW, max(0, D - wrow0));
+    const int wrows = min(RW, max(0, D - wrow0));
     const rsrc_t rsA = make_rsrc(uni_ptr(A + (size_t)wrow0 * LD), uni32((unsigned)wrows * rowbytes));
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < NRHS; r++)
-      for (int i = tid; i < DN_RB; i += DN_THREADS) { xr[r * DN_RB + i] = r0 + i < D ? x[r][r0 + i] : 0.0; sacc[r * DN_RB + i] = 0.0; }
+      for (int i = tid; i < RB; i += DN_THREADS) { xr[r * DN_RB_MAX + i] = r0 + i < D ? x[r][r0 + i] : 0.0; sacc[r * DN_RB_MAX + i] = 0.0; }
     for (int c0 = (r0 / DN_CT + part) * DN_CT; c0 < D; c0 += split * DN_CT) {
       __syncthreads();                                    // the previous tile's column sums have been read
 #pragma unroll
@@ -166,9 +167,9 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int jo
           t_acc[u][0][r] = 0.0; t_acc[u][1][r] = 0.0;
         }
       }
-      const bool band = c0 < r0 + DN_RB;                  // the tile overlaps the block's own rows: only j > i counts
+      const bool band = c0 < r0 + RB;                  // the tile overlaps the block's own rows: only j > i counts
 #pragma unroll 1
-      for (int q = 0; q < DN_RW; q += DN_RG) {               // DN_RG rows at a time: 4 DN_RG loads of 16 bytes in flight per lane
+      for (int q = 0; q < RW; q += DN_RG) {               // DN_RG rows at a time: 4 DN_RG loads of 16 bytes in flight per lane
         dn_d2 a[DN_RG][4];
 #pragma unroll
         for (int k = 0; k < DN_RG; k++)
@@ -177,11 +178,11 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int jo
             a[k][u] = __builtin_bit_cast(dn_d2, __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[u], (unsigned)(q + k) * rowbytes, 2 /* nt: read once */));
 #pragma unroll
         for (int k = 0; k < DN_RG; k++) {
-          const int lrow = DN_RW * w + q + k;
+          const int lrow = RW * w + q + k;
           const int lim = band ? r0 + lrow : -1;          // no branch: outside the band every column counts
           double xrow[NRHS], sp[NRHS];
 #pragma unroll
-          for (int r = 0; r < NRHS; r++) { xrow[r] = xr[r * DN_RB + lrow]; sp[r] = 0.0; }
+          for (int r = 0; r < NRHS; r++) { xrow[r] = xr[r * DN_RB_MAX + lrow]; sp[r] = 0.0; }
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const int col = c0 + 2 * (lane + 64 * u);
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int jo
 #pragma unroll
           for (int r = 0; r < NRHS; r++) {
             const double tot = dpp_scan_sum(sp[r]);
-            if (lane == 63) sacc[r * DN_RB + lrow] += tot;
+            if (lane == 63) sacc[r * DN_RB_MAX + lrow] += tot;
           }
         }
       }
@@ -215,17 +216,22 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int jo
         for (int ww = 0; ww < DN_THREADS / 64; ww++) t += tacc[((size_t)ww * NRHS + r) * DN_CT + c];
         if (c0 + c < D) tp[((size_t)b * 3 + r) * LD + c0 + c] = t;
       }
-    }
-    __syncthreads();
+      // the block's row sums over this tile (complete: the barrier above), and the accumulators cleared for the next one
+      // (the barrier at the top of the loop separates this from the next tile's additions)
 #pragma unroll
-    for (int r = 0; r < NRHS; r++)
-      for (int i = tid; i < DN_RB; i += DN_THREADS) if (r0 + i < D) sr[(size_t)r * DN_SPLIT_MAX * LD + r0 + i] = sacc[r * DN_RB + i];
+      for (int r = 0; r < NRHS; r++)
+        for (int i = tid; i < RB; i += DN_THREADS) {
+          if (r0 + i < D) sr[((size_t)r * P.ntile + c0 / DN_CT) * LD + r0 + i] = sacc[r * DN_RB_MAX + i];
+          sacc[r * DN_RB_MAX + i] = 0.0;
+        }
+    }
   }
 }
-// y_i = diag_i x_i + row sums_i + the column sums of the blocks at or above row i; then what the round wants done with
-// the products: stores, the position update, partial sums of dot . y.  64 elements per workgroup, four threads per
-// element: thread (i, k) adds the blocks b = k, k + 4, ... (up to 326 of them at D = 41 610: one thread alone would walk
-// them as a chain of dependent loads), then the four are added in order.  Fixed order: same bytes every run.
+// y_i = diag_i x_i + the row sums of i's block over its column tiles (tile order) + the column sums of the blocks at or
+// above row i (block order); then what the round wants done with the products: stores, the position update, partial sums
+// of dot . y.  64 elements per workgroup, four threads per element: thread (i, k) adds the terms k, k + 4, ... of both
+// series (up to 326 blocks at D = 41 610: one thread alone would walk them as a chain of dependent loads), then the
+// four are added in order.  The order depends on i alone: same bytes every run, whatever the launch shape.
 template <int NRHS>
 __global__ __launch_bounds__(DN_FIN) void k_dn_symv_finish(const DnParams P, int job0) {
   __shared__ double quad[NRHS][4][DN_FIN / 4];
@@ -236,13 +242,15 @@ __global__ __launch_bounds__(DN_FIN) void k_dn_symv_finish(const DnParams P, int
   const int e = threadIdx.x & (DN_FIN / 4 - 1), k4 = threadIdx.x / (DN_FIN / 4);
   const int i = blockIdx.x * (DN_FIN / 4) + e, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int LD = P.LD;
-  const double *tp = P.tpart + ((size_t)chain * P.nblk * 3 + job0) * (size_t)LD, *sr = P.srow + ((size_t)chain * 3 + job0) * DN_SPLIT_MAX * (size_t)LD;
+  const double *tp = P.tpart + ((size_t)chain * P.nblk * 3 + job0) * (size_t)LD;
+  const double *sr = P.srow + ((size_t)chain * 3 + job0) * (size_t)P.ntile * (size_t)LD;
   const double *dg = P.dg + (size_t)chain * LD;
   if (i < P.D) {
-    const int nb = i / DN_RB + 1;
+    const int nb = i / P.rb + 1, t_first = ((i / P.rb) * P.rb) / DN_CT;
 #pragma unroll
     for (int r = 0; r < NRHS; r++) {
       double t = 0.0;
+      for (int tt = t_first + k4; tt < P.ntile; tt += 4) t += sr[((size_t)r * P.ntile + tt) * LD + i];
       for (int b = k4; b < nb; b += 4) t += tp[((size_t)b * 3 + r) * LD + i];
       quad[r][k4][e] = t;
     }
@@ -253,9 +261,7 @@ __global__ __launch_bounds__(DN_FIN) void k_dn_symv_finish(const DnParams P, int
 #pragma unroll
     for (int r = 0; r < NRHS; r++) {
       const DnJob &jb = rd.job[job0 + r];
-      double y = dg[i] * dn_vec(P, chain, jb.x)[i];
-      for (int p = 0; p < P.split; p++) y += sr[((size_t)r * DN_SPLIT_MAX + p) * LD + i];
-      y += ((quad[r][0][e] + quad[r][1][e]) + quad[r][2][e]) + quad[r][3][e];
+      const double y = dg[i] * dn_vec(P, chain, jb.x)[i] + (((quad[r][0][e] + quad[r][1][e]) + quad[r][2][e]) + quad[r][3][e]);
       if (jb.y >= 0) dn_vec(P, chain, jb.y)[i] = y;
       if (jb.qout >= 0) dn_vec(P, chain, jb.qout)[i] = dn_vec(P, chain, jb.qin)[i] + jb.coef * y;
       if (job0 + r == 0 && jb.dot >= 0) dsum = dn_vec(P, chain, jb.dot)[i] * y;

@@ -624,7 +624,7 @@ struct Sampler {
   int dn_win_counter = 0, dn_win_next = 0, dn_win_size = 0, dn_wf_n = 0;   // host mirror of the warm-up window schedule
   hipEvent_t mv0 = nullptr, mv1 = nullptr;
   double mv_ms = 0;                        // time spent in the matrix passes (k_dn_symv + finish, events), their number and the bytes they loaded
-  long long mv_calls = 0, mv_bytes = 0, dn_rounds = 0, dn_pass_bytes = 0;
+  long long mv_calls = 0, mv_bytes = 0, dn_rounds = 0, dn_pass_bytes[2] = {0, 0};   // bytes per pass at DN_RB / DN_RB_MAX rows per workgroup
 };
 
 std::mutex g_mu;
@@ -1146,14 +1146,22 @@ int dense_window_capacity(int nw, int ib, int tb, int bw) {
   return cap;
 }
 
-// workgroups per pair of row blocks: enough of them to keep 256 compute units busy when the chains are few
-int dense_split(int chains, int nblk) { return std::max(1, std::min(DN_SPLIT_MAX, (1024 + chains * ((nblk + 1) / 2) - 1) / (chains * ((nblk + 1) / 2)))); }
+// Shape of one launch of the symmetric product: rows a workgroup takes at a time (256 for large matrices: fewer tiles per
+// byte) and, by the number of chains that take part, workgroups per pair of row blocks (enough to keep 256 compute units
+// busy when the active chains are few; the results do not depend on it).
+void dense_launch_shape(DnParams &P, int active) {
+  active = std::max(active, 1);
+  P.rb = P.D >= 32 * DN_RB_MAX ? DN_RB_MAX : DN_RB;      // by the size of the matrix alone: a chain's numbers must not depend on its companions
+  P.ntile = (P.D + DN_CT - 1) / DN_CT;
+  const int pairs = ((P.D + P.rb - 1) / P.rb + 1) / 2;
+  P.split = std::max(1, std::min(DN_SPLIT_MAX, 256 / (active * pairs)));   // one workgroup per compute unit at a time: fill them once
+}
 
 // bytes one pass of the symmetric product loads per chain: the tiles right of (and on) each row block's diagonal
-long long dense_pass_bytes(int D, int LD) {
+long long dense_pass_bytes(int D, int LD, int rb) {
   long long n = 0;
   const int tile_end = std::min(LD, ((D + DN_CT - 1) / DN_CT) * DN_CT);
-  for (int r0 = 0; r0 < D; r0 += DN_RB) n += (long long)std::min(DN_RB, D - r0) * (tile_end - (r0 / DN_CT) * DN_CT);
+  for (int r0 = 0; r0 < D; r0 += rb) n += (long long)std::min(rb, D - r0) * (tile_end - (r0 / DN_CT) * DN_CT);
   return n * 8;
 }
 
@@ -1162,9 +1170,9 @@ int dense_alloc(Sampler *sp) {
   const int D = sp->L.D, chains = sp->R.chains;
   P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_FIN / 4 - 1) / (DN_FIN / 4); P.nblk = (D + DN_RB - 1) / DN_RB; P.sc_stride = sp->K; P.identity = 1;
   P.win_cap = dense_window_capacity(sp->R.num_warmup, sp->R.init_buffer, sp->R.term_buffer, sp->R.window);
-  P.split = dense_split(chains, P.nblk);
+  dense_launch_shape(P, chains);
   const size_t mat = (size_t)chains * D * P.LD * 8, vec = (size_t)chains * DV_COUNT * P.LD * 8, win = (size_t)chains * P.win_cap * P.LD * 8;
-  const size_t tp = (size_t)chains * P.nblk * 3 * P.LD * 8;
+  const size_t tp = (size_t)chains * (P.nblk + P.ntile) * 3 * P.LD * 8;   // column sums per row block + row sums per column tile
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   if (mat + vec + win + tp + (64u << 20) > free_b)
@@ -1178,7 +1186,7 @@ int dense_alloc(Sampler *sp) {
   };
   int rc;
   if ((rc = get((void **)&P.state, vec)) || (rc = get((void **)&P.A, mat)) || (rc = get((void **)&P.dg, (size_t)chains * P.LD * 8)) || (rc = get((void **)&P.win, win)) ||
-      (rc = get((void **)&P.tpart, tp)) || (rc = get((void **)&P.srow, (size_t)chains * 3 * DN_SPLIT_MAX * P.LD * 8)) ||
+      (rc = get((void **)&P.tpart, (size_t)chains * P.nblk * 3 * P.LD * 8)) || (rc = get((void **)&P.srow, (size_t)chains * 3 * P.ntile * P.LD * 8)) ||
       (rc = get((void **)&P.partial, (size_t)chains * P.npart * 8)) || (rc = get((void **)&P.lpbuf, (size_t)chains * 8)) ||
       (rc = get((void **)&P.ts, (size_t)chains * sizeof(TS))) || (rc = get((void **)&P.rd, (size_t)chains * sizeof(DnRound))) ||
       (rc = get((void **)&P.active, (size_t)chains * 4)) || (rc = get((void **)&P.fail, 4)))
@@ -1194,14 +1202,15 @@ int dense_alloc(Sampler *sp) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(sp->stream));
   sp->dn_win_counter = 0; sp->dn_win_size = sp->R.window; sp->dn_win_next = sp->R.init_buffer + sp->R.window - 1; sp->dn_wf_n = 0;
-  sp->dn_pass_bytes = dense_pass_bytes(D, P.LD);
+  sp->dn_pass_bytes[0] = dense_pass_bytes(D, P.LD, DN_RB); sp->dn_pass_bytes[1] = dense_pass_bytes(D, P.LD, DN_RB_MAX);
   return 0;
 }
 
 // M^-1 times the round's right-hand sides for the active chains: one pass over the upper triangles (two launches when
 // there are three right-hand sides) and the finishing kernel
 void dense_symv_launch(hipStream_t st, const DnParams &P, int nrhs) {
-  const dim3 grid((unsigned)(((P.nblk + 1) / 2) * P.split), (unsigned)P.chains), fin((unsigned)P.npart, (unsigned)P.chains);
+  const int nblk = (P.D + P.rb - 1) / P.rb;
+  const dim3 grid((unsigned)(((nblk + 1) / 2) * P.split), (unsigned)P.chains), fin((unsigned)P.npart, (unsigned)P.chains);
   if (nrhs == 1) {
     hipLaunchKernelGGL(k_dn_symv<1>, grid, dim3(DN_THREADS), DN_SYMV_LDS(1), st, P, 0);
     hipLaunchKernelGGL(k_dn_symv_finish<1>, fin, dim3(DN_FIN), 0, st, P, 0);
@@ -1233,7 +1242,9 @@ int dense_grad(Sampler *sp) {
   return 0;
 }
 // one pass over the matrices of the active chains; the pass is timed with events resolved at the next sync point
-int dense_matvec(Sampler *sp, int nrhs) {
+int dense_matvec(Sampler *sp, int nrhs, int n_active) {
+  dense_launch_shape(sp->dn, n_active);
+  sp->mv_bytes += (long long)n_active * sp->dn_pass_bytes[sp->dn.rb == DN_RB ? 0 : 1] * (nrhs == 3 ? 2 : 1);   // three right-hand sides go as 2 + 1
   HIP_TRY(hipEventRecord(sp->mv0, sp->stream));
   dense_symv_launch(sp->stream, sp->dn, nrhs);
   HIP_TRY(hipGetLastError());
@@ -1279,11 +1290,11 @@ int dense_init_stepsize(Sampler *sp, unsigned iter) {
     if (attempt > 200) return fail(POTUS_ERR_STATE, "dense init_stepsize did not terminate");
     if ((rc = dense_sample_p(sp, iter, RNG_INIT_EPS))) return rc;
     hipLaunchKernelGGL(k_dn_eps_prekick, dn_grid(sp), dim3(256), 0, sp->stream, sp->dn, (const RunParams *)sp->dR);
-    if ((rc = dense_matvec(sp, 2))) return rc;
+    if ((rc = dense_matvec(sp, 2, n_active))) return rc;
     hipLaunchKernelGGL(k_dn_eps_mid, dim3(cg), dim3(64), 0, sp->stream, sp->dn, (const RunParams *)sp->dR);
     if ((rc = dense_grad(sp))) return rc;
     hipLaunchKernelGGL(k_dn_kick, dn_grid(sp), dim3(256), 0, sp->stream, sp->dn);
-    if ((rc = dense_matvec(sp, 1))) return rc;
+    if ((rc = dense_matvec(sp, 1, n_active))) return rc;
     hipLaunchKernelGGL(k_dn_eps_step, dim3(cg), dim3(64), 0, sp->stream, sp->dn, (const RunParams *)sp->dR);
     HIP_TRY(hipGetLastError());
     if ((rc = dense_sync(sp, &n_active, false))) return rc;
@@ -1333,18 +1344,16 @@ int dense_run(Sampler *sp, int n_iter) {
     if ((rc = dense_sample_p(sp, (unsigned)it, RNG_MOMENTUM))) return rc;
     if ((rc = dense_grad(sp))) return rc;                                // hamiltonian.init: gradient at the current point -> GC
     hipLaunchKernelGGL(k_dn_begin, dn_grid(sp), dim3(256), 0, sp->stream, P, (const RunParams *)sp->dR);
-    if ((rc = dense_matvec(sp, 3))) return rc;
+    if ((rc = dense_matvec(sp, 3, chains))) return rc;
     hipLaunchKernelGGL(k_dn_step, dim3(chains), dim3(DN_THREADS), 0, sp->stream, P, (const RunParams *)sp->dR, (unsigned)it, (int)DN_MODE_BEGIN);
     HIP_TRY(hipGetLastError());
     if ((rc = dense_sync(sp, &n_active, true))) return rc;
-    sp->mv_bytes += (long long)chains * sp->dn_pass_bytes * 2;   // three right-hand sides: the triangle is read twice (2 + 1)
     while (n_active > 0) {
       if ((rc = dense_grad(sp))) return rc;
       hipLaunchKernelGGL(k_dn_kick, dn_grid(sp), dim3(256), 0, sp->stream, P);
-      if ((rc = dense_matvec(sp, 2))) return rc;
+      if ((rc = dense_matvec(sp, 2, n_active))) return rc;
       hipLaunchKernelGGL(k_dn_step, dim3(chains), dim3(DN_THREADS), 0, sp->stream, P, (const RunParams *)sp->dR, (unsigned)it, (int)DN_MODE_LEAF);
       HIP_TRY(hipGetLastError());
-      sp->mv_bytes += (long long)n_active * sp->dn_pass_bytes;
       sp->dn_rounds += 1;
       if ((rc = dense_sync(sp, &n_active, true))) return rc;
     }
@@ -2140,8 +2149,8 @@ struct DenseProbe {   // a DnParams with every chain active, owned buffers
     P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_FIN / 4 - 1) / (DN_FIN / 4); P.nblk = (D + DN_RB - 1) / DN_RB; P.sc_stride = 1; P.win_cap = win_cap; P.identity = 0;
     const size_t mat = (size_t)chains * D * P.LD * 8;
     HIP_TRY(bufs.alloc(&P.state, (size_t)chains * DV_COUNT * P.LD * 8)); HIP_TRY(bufs.alloc(&P.A, mat)); HIP_TRY(bufs.alloc(&P.dg, (size_t)chains * P.LD * 8));
-    P.split = dense_split(chains, P.nblk);
-    HIP_TRY(bufs.alloc(&P.tpart, (size_t)chains * P.nblk * 3 * P.LD * 8)); HIP_TRY(bufs.alloc(&P.srow, (size_t)chains * 3 * DN_SPLIT_MAX * P.LD * 8));
+    dense_launch_shape(P, chains);
+    HIP_TRY(bufs.alloc(&P.tpart, (size_t)chains * P.nblk * 3 * P.LD * 8)); HIP_TRY(bufs.alloc(&P.srow, (size_t)chains * 3 * P.ntile * P.LD * 8));
     HIP_TRY(bufs.alloc(&P.win, (size_t)chains * std::max(win_cap, 1) * P.LD * 8)); HIP_TRY(bufs.alloc(&P.partial, (size_t)chains * P.npart * 8));
     HIP_TRY(bufs.alloc(&P.lpbuf, (size_t)chains * 8)); HIP_TRY(bufs.alloc(&P.ts, (size_t)chains * sizeof(TS)));
     HIP_TRY(bufs.alloc(&P.rd, (size_t)chains * sizeof(DnRound))); HIP_TRY(bufs.alloc(&P.active, (size_t)chains * 4)); HIP_TRY(bufs.alloc(&P.fail, 4));
@@ -2194,7 +2203,7 @@ int potus_dense_matvec_probe(int device, int chains, int D, int nrhs, const doub
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (!ok) return fail(POTUS_ERR_DEVICE, "k_dn_symv failed");
   if (ms) *ms = (double)t / reps;
-  if (pass_bytes) *pass_bytes = dense_pass_bytes(D, P.LD) * (nrhs == 3 ? 2 : 1);
+  if (pass_bytes) *pass_bytes = dense_pass_bytes(D, P.LD, P.rb) * (nrhs == 3 ? 2 : 1);
   for (int c = 0; c < chains; c++) {
     for (int k = 0; k < nrhs; k++)
       HIP_TRY(hipMemcpy(y_host + ((size_t)c * nrhs + k) * D, P.state + ((size_t)c * DV_COUNT + DV_POOLPS + k) * P.LD, (size_t)D * 8, hipMemcpyDeviceToHost));
