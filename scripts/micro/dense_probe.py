@@ -3,11 +3,13 @@
   python scripts/micro/dense_probe.py pieces             matrix pass (1-3 right-hand sides), covariance, Cholesky, solve
   python scripts/micro/dense_probe.py sampler C N [cus]  2016 posterior, C chains, N warm-up iterations, dense metric
   python scripts/micro/dense_probe.py stress C N         the same on the configs[4] shape (D = 41 610)
+  python scripts/micro/dense_probe.py active             matrix pass with 1..16 of 16 resident chains active, by tile split
 
 Matrices of `pieces` are generated on the device; a matrix pass loads the upper-triangle tiles, about 4 D^2 bytes per chain.
 """
 import ctypes as C
 import json
+import os
 import sys
 import time
 from pathlib import Path
@@ -28,6 +30,30 @@ def err():
     buf = C.create_string_buffer(512)
     L.potus_last_error(buf, 512)
     return buf.value.decode()
+
+
+ACTIVE_CASES = ("1", "2", "3", "4", "6", "8", "12", "16")      # "n": the first n chains of the handle take part; "a,b,c": those chains
+SPLIT_CASES = (0, 1, 2, 3, 4, 6, 8)
+
+
+def active_sweep():
+    """16 chains of the configs[4] shape resident, a of them active, tile split s: time of one pass."""
+    chains, D, nrhs = 16, 41610, 2
+    x = np.random.default_rng(1).standard_normal((chains, nrhs, D))
+    y, ms, nb = np.zeros((chains, nrhs, D)), C.c_double(), C.c_longlong()
+    for a in ACTIVE_CASES:
+        os.environ["POTUS_PROBE_ACTIVE"] = a
+        n_a = len(a.split(",")) if "," in a else int(a)
+        line = []
+        for s in SPLIT_CASES:
+            if s:
+                os.environ["POTUS_DENSE_SPLIT"] = str(s)
+            else:
+                os.environ.pop("POTUS_DENSE_SPLIT", None)
+            rc = L.potus_dense_matvec_probe(0, chains, D, nrhs, None, x.ctypes.data, y.ctypes.data, None, 3, C.byref(ms), C.byref(nb))
+            line.append(f"{'auto' if not s else s}: {n_a * nb.value / 1e9 / (ms.value * 1e-3) / 8000:.2f}" if rc == 0 else f"{s}: error {err()}")
+        print(f"D={D} resident=16 active={a:>8s} frac of 8 TB/s by split  " + "  ".join(line), flush=True)
+    os.environ.pop("POTUS_PROBE_ACTIVE", None); os.environ.pop("POTUS_DENSE_SPLIT", None)
 
 
 def pieces():
@@ -82,6 +108,12 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "pieces"
     if what == "pieces":
         pieces()
+    elif what == "active":
+        if len(sys.argv) > 2:
+            ACTIVE_CASES = tuple(sys.argv[2].split(":"))
+        if len(sys.argv) > 3:
+            SPLIT_CASES = tuple(int(v) for v in sys.argv[3].split(","))
+        active_sweep()
     else:
         chains, iters = int(sys.argv[2]), int(sys.argv[3])
         cus = int(sys.argv[4]) if len(sys.argv) > 4 else 0

@@ -99,24 +99,34 @@ struct DnParams {
   int *fail;                         // [1] Cholesky met a non-positive pivot
 };
 
+// The chains that take part in a launch of the symmetric product, compacted: idle chains between active ones leave holes in
+// the dispatch order, and the hardware then doubles workgroups up on some compute units while others idle (0.50 instead of
+// 0.73 of the HBM peak with 3 scattered chains of 16; profiles/r02_dense_active_sweep.txt).  n == 0: every chain (blockIdx.y).
+#define DN_ACT_MAX 64
+struct DnActive {
+  int n;
+  int idx[DN_ACT_MAX];
+};
+
 __device__ __forceinline__ double *dn_vec(const DnParams &P, int chain, int slot) { return P.state + ((size_t)chain * DV_COUNT + slot) * (size_t)P.LD; }
 
 // ---------------------------------------------------------------- M^-1 x for up to three right-hand sides
-// Symmetric product out of the strict upper triangle.  A workgroup takes blocks of DN_RB = 128 rows (16 per wave) -- block
-// b and its mirror nblk-1-b, so that every workgroup streams the same number of elements -- and walks the column tiles
-// (DN_CT = 512) from the block's diagonal to the right edge.  A wave reads its rows' 4 KB segments of the tile (16 bytes
-// per lane, eight rows = 32 loads in flight per lane); every element feeds
-//     the row sums    s_i += a_ij x_j   per lane, kept in registers across ALL tiles and reduced once per row at the end,
+// Symmetric product out of the strict upper triangle.  A workgroup takes blocks of P.rb rows (128 or 256: 16 or 32 per
+// wave) -- block b and its mirror nblk-1-b, so that every workgroup streams the same number of elements -- and walks the
+// column tiles (DN_CT = 512) from the block's diagonal to the right edge.  A wave reads its rows' 4 KB segments of the
+// tile (16 bytes per lane, DN_RG rows x 4 loads in flight per lane); every element feeds
+//     the row sums    s_i += a_ij x_j   per lane, reduced per row and tile (DPP) into an LDS accumulator of the block and
+//                                       stored per (tile, row),
 //     the column sums t_j += a_ij x_i   per lane (its 8 columns of the tile), summed over the 8 waves through LDS per
-//                                       tile and stored per (block, column): k_dn_symv_finish adds the blocks in order.
-// Fixed summation order everywhere: same bytes every run.  Traffic besides the triangle: the column sums, written and
-// read once, nblk x D x NRHS doubles = 3 % of the matrix.
+//                                       tile and stored per (block, column): k_dn_symv_finish adds tiles and blocks in order.
+// Fixed summation order everywhere: same bytes every run and for every launch shape.  Traffic besides the triangle: the
+// column and row sums, written and read once = 3-4 % of the matrix.
 // (job0: the first of the round's jobs this launch serves -- the three products of a transition's first pass go as 2 + 1)
 #define DN_SYMV_LDS(NRHS) ((size_t)((NRHS) * (DN_CT + 2 * DN_RB_MAX) + (DN_THREADS / 64) * (NRHS) * DN_CT) * 8)
 template <int NRHS>
-__global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int job0) {
+__global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const DnActive act, int job0) {
   extern __shared__ __attribute__((aligned(16))) double dn_lds[];
-  const int chain = blockIdx.y;
+  const int chain = act.n ? act.idx[blockIdx.y] : (int)blockIdx.y;
   const DnRound &rd = P.rd[chain];
   if (!rd.active) return;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -233,10 +243,10 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, int jo
 // series (up to 326 blocks at D = 41 610: one thread alone would walk them as a chain of dependent loads), then the
 // four are added in order.  The order depends on i alone: same bytes every run, whatever the launch shape.
 template <int NRHS>
-__global__ __launch_bounds__(DN_FIN) void k_dn_symv_finish(const DnParams P, int job0) {
+__global__ __launch_bounds__(DN_FIN) void k_dn_symv_finish(const DnParams P, const DnActive act, int job0) {
   __shared__ double quad[NRHS][4][DN_FIN / 4];
   __shared__ double dn_part[DN_FIN / 64];
-  const int chain = blockIdx.y;
+  const int chain = act.n ? act.idx[blockIdx.y] : (int)blockIdx.y;
   const DnRound &rd = P.rd[chain];
   if (!rd.active) return;
   const int e = threadIdx.x & (DN_FIN / 4 - 1), k4 = threadIdx.x / (DN_FIN / 4);

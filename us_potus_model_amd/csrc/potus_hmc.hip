@@ -1154,7 +1154,18 @@ void dense_launch_shape(DnParams &P, int active) {
   P.rb = P.D >= 32 * DN_RB_MAX ? DN_RB_MAX : DN_RB;      // by the size of the matrix alone: a chain's numbers must not depend on its companions
   P.ntile = (P.D + DN_CT - 1) / DN_CT;
   const int pairs = ((P.D + P.rb - 1) / P.rb + 1) / 2;
-  P.split = std::max(1, std::min(DN_SPLIT_MAX, 256 / (active * pairs)));   // one workgroup per compute unit at a time: fill them once
+  // One 78 KB-LDS workgroup per compute unit at a time: the launch runs in waves of 256 workgroups.  Few, large workgroups are
+  // best (measured: profiles/r02_dense_active_sweep.txt), so: the smallest split whose last wave is at least 90 % full.
+  const int base = active * pairs;
+  P.split = 1;
+  if (const char *e = getenv("POTUS_DENSE_SPLIT")) { P.split = std::max(1, std::min(DN_SPLIT_MAX, atoi(e))); return; }   // development: sweeps of scripts/micro/dense_probe.py
+  double best = 0.0;
+  for (int s = 1; s <= DN_SPLIT_MAX; s++) {
+    const int w = base * s;
+    const double fill = (double)w / (((w + 255) / 256) * 256);
+    if (fill > best + 1e-9) { best = fill; P.split = s; }
+    if (fill >= 0.9) { P.split = s; break; }
+  }
 }
 
 // bytes one pass of the symmetric product loads per chain: the tiles right of (and on) each row block's diagonal
@@ -1208,18 +1219,19 @@ int dense_alloc(Sampler *sp) {
 
 // M^-1 times the round's right-hand sides for the active chains: one pass over the upper triangles (two launches when
 // there are three right-hand sides) and the finishing kernel
-void dense_symv_launch(hipStream_t st, const DnParams &P, int nrhs) {
+void dense_symv_launch(hipStream_t st, const DnParams &P, const DnActive &act, int nrhs) {
   const int nblk = (P.D + P.rb - 1) / P.rb;
-  const dim3 grid((unsigned)(((nblk + 1) / 2) * P.split), (unsigned)P.chains), fin((unsigned)P.npart, (unsigned)P.chains);
+  const unsigned ny = (unsigned)(act.n ? act.n : P.chains);
+  const dim3 grid((unsigned)(((nblk + 1) / 2) * P.split), ny), fin((unsigned)P.npart, ny);
   if (nrhs == 1) {
-    hipLaunchKernelGGL(k_dn_symv<1>, grid, dim3(DN_THREADS), DN_SYMV_LDS(1), st, P, 0);
-    hipLaunchKernelGGL(k_dn_symv_finish<1>, fin, dim3(DN_FIN), 0, st, P, 0);
+    hipLaunchKernelGGL(k_dn_symv<1>, grid, dim3(DN_THREADS), DN_SYMV_LDS(1), st, P, act, 0);
+    hipLaunchKernelGGL(k_dn_symv_finish<1>, fin, dim3(DN_FIN), 0, st, P, act, 0);
   } else {
-    hipLaunchKernelGGL(k_dn_symv<2>, grid, dim3(DN_THREADS), DN_SYMV_LDS(2), st, P, 0);
-    hipLaunchKernelGGL(k_dn_symv_finish<2>, fin, dim3(DN_FIN), 0, st, P, 0);
+    hipLaunchKernelGGL(k_dn_symv<2>, grid, dim3(DN_THREADS), DN_SYMV_LDS(2), st, P, act, 0);
+    hipLaunchKernelGGL(k_dn_symv_finish<2>, fin, dim3(DN_FIN), 0, st, P, act, 0);
     if (nrhs == 3) {
-      hipLaunchKernelGGL(k_dn_symv<1>, grid, dim3(DN_THREADS), DN_SYMV_LDS(1), st, P, 2);
-      hipLaunchKernelGGL(k_dn_symv_finish<1>, fin, dim3(DN_FIN), 0, st, P, 2);
+      hipLaunchKernelGGL(k_dn_symv<1>, grid, dim3(DN_THREADS), DN_SYMV_LDS(1), st, P, act, 2);
+      hipLaunchKernelGGL(k_dn_symv_finish<1>, fin, dim3(DN_FIN), 0, st, P, act, 2);
     }
   }
 }
@@ -1243,10 +1255,16 @@ int dense_grad(Sampler *sp) {
 }
 // one pass over the matrices of the active chains; the pass is timed with events resolved at the next sync point
 int dense_matvec(Sampler *sp, int nrhs, int n_active) {
+  DnActive act;
+  act.n = 0;                                              // every chain, or (from the flags of the last sync point) the active ones, compacted
+  if (n_active < sp->R.chains && sp->R.chains <= DN_ACT_MAX) {
+    for (int c = 0; c < sp->R.chains; c++) if (sp->h_active[c]) act.idx[act.n++] = c;
+    n_active = act.n;
+  }
   dense_launch_shape(sp->dn, n_active);
   sp->mv_bytes += (long long)n_active * sp->dn_pass_bytes[sp->dn.rb == DN_RB ? 0 : 1] * (nrhs == 3 ? 2 : 1);   // three right-hand sides go as 2 + 1
   HIP_TRY(hipEventRecord(sp->mv0, sp->stream));
-  dense_symv_launch(sp->stream, sp->dn, nrhs);
+  dense_symv_launch(sp->stream, sp->dn, act, nrhs);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(sp->mv1, sp->stream));
   return 0;
@@ -2183,10 +2201,20 @@ int potus_dense_matvec_probe(int device, int chains, int D, int nrhs, const doub
     HIP_TRY(hipMemcpy(P.dg, dg.data(), dg.size() * 8, hipMemcpyHostToDevice));
   } else hipLaunchKernelGGL(k_dn_fill, dim3(4096), dim3(256), 0, 0, P);
   std::vector<DnRound> rds(chains);
+  // development: a launch with idle companions (POTUS_PROBE_ACTIVE = n: the first n chains take part; or a list "2,7,11")
+  std::vector<int> act_flag(chains, 1);
+  int n_act = chains;
+  if (const char *e = getenv("POTUS_PROBE_ACTIVE")) {
+    std::fill(act_flag.begin(), act_flag.end(), 0);
+    if (strchr(e, ',')) { for (const char *q = e; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) { const int c = atoi(q); if (c >= 0 && c < chains) act_flag[c] = 1; } }
+    else for (int c = 0; c < std::min(chains, std::max(1, atoi(e))); c++) act_flag[c] = 1;
+    n_act = (int)std::count(act_flag.begin(), act_flag.end(), 1);
+  }
+  dense_launch_shape(P, n_act);
   for (int c = 0; c < chains; c++) {
     DnRound &r = rds[c];
     std::memset(&r, 0, sizeof r);
-    r.active = 1;
+    r.active = act_flag[c];
     for (int k = 0; k < 3; k++) r.job[k] = DnJob{DV_POOLP + k, DV_POOLPS + k, -1, -1, k == 0 ? DV_POOLP : -1, 0, 0.0};
     for (int k = 0; k < nrhs; k++)
       HIP_TRY(hipMemcpy(P.state + ((size_t)c * DV_COUNT + DV_POOLP + k) * P.LD, x_host + ((size_t)c * nrhs + k) * D, (size_t)D * 8, hipMemcpyHostToDevice));
@@ -2194,9 +2222,12 @@ int potus_dense_matvec_probe(int device, int chains, int D, int nrhs, const doub
   if ((rc = pr.set_rounds(rds))) return rc;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-  dense_symv_launch(0, P, nrhs);   // warm-up
+  DnActive act;
+  act.n = 0;
+  if (n_act < chains && chains <= DN_ACT_MAX && !getenv("POTUS_PROBE_NO_COMPACTION")) for (int c = 0; c < chains; c++) if (act_flag[c]) act.idx[act.n++] = c;
+  dense_symv_launch(0, P, act, nrhs);   // warm-up
   (void)hipEventRecord(e0, 0);
-  for (int r = 0; r < reps; r++) dense_symv_launch(0, P, nrhs);
+  for (int r = 0; r < reps; r++) dense_symv_launch(0, P, act, nrhs);
   (void)hipEventRecord(e1, 0);
   const bool ok = hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;
   float t = 0; (void)hipEventElapsedTime(&t, e0, e1);
