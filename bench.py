@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs[] index: 1 (default), 2, 3, 4")
     ap.add_argument("--chains-per-gpu", type=int, default=0, help="per posterior (0 = the configuration's: 8, 8, 4, 4)")
     ap.add_argument("--cus-per-chain", type=int, default=0, help="workgroups per chain (0 = auto: 16, 8 or 1 by what fits)")
+    ap.add_argument("--twin", type=int, default=-1, help="two clusters per chain, one per end of the trajectory: 1, 0, or -1 = the library's choice")
     ap.add_argument("--chunk", type=int, default=0, help="transitions per step (0 = the configuration's: 100; 1 for --config 4)")
     ap.add_argument("--seed", type=int, default=1843)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -180,6 +181,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     coll_dev = None if dev_backend == "gloo" else dev       # collectives on CPU tensors in the development mode
+    twin = 0 if dev_backend == "gloo" else args.twin        # (the ranks of the development mode share one GPU's compute units)
 
     cfg = args.config
     chunk = args.chunk or (1 if cfg == 4 else 100)
@@ -192,7 +194,7 @@ def main():
             while True:
                 try:
                     hs.append(Handle(data, variant, chains=C, chain_id_offset=rank * C, num_warmup=num_warmup, num_samples=num_samples,
-                                     seed=seed, device=local, cus_per_chain=args.cus_per_chain, **extra))
+                                     seed=seed, device=local, cus_per_chain=args.cus_per_chain, twin=twin, **extra))
                     break
                 except Exception as e:      # the dense metric keeps two D x D matrices per chain: as many chains as the HBM holds
                     if cfg != 4 or args.chains_per_gpu or C <= 1 or "GB free" not in str(e):
@@ -260,6 +262,7 @@ def main():
         for (name, data, variant, C, extra), h, pl, (st, dv) in zip(work, hs, pooled, status):
             info = {"chains_per_gpu": C, "D": h.D, "S": int(data["S"]), "T": int(data["T"]),
                     "polls": int(data["N_state_polls"]) + int(data["N_national_polls"]), "cus_per_chain": h.cus_per_chain,
+                    "clusters_per_chain": h.clusters_per_chain,
                     "divergent_transitions": int(sum(dv)), "chain_status": st}
             if pl is not None and ns >= 8:
                 x = np.transpose(pl.cpu().numpy(), (1, 0, 2))                    # [chain, draw, 1 + S]
@@ -275,7 +278,7 @@ def main():
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9            # this rank's launches, events on the samplers' own streams
         if dense:   # the dominant kernel is the matrix pass: bytes of matrix it streamed / its own time (HIP events around every launch)
             achieved = dense_t[2] / (dense_t[0] * 1e-3) / 1e9
-        K = hs[0].cus_per_chain
+        K, sides = hs[0].cus_per_chain, hs[0].clusters_per_chain
         kernel = "k_dn_symv" if dense else ("k_cl_run" if K > 1 else "k_run")
         tr = measured_traffic(kernel)
         traffic = tr[1]["hbm_bytes_per_leapfrog"] * sum(lf_local) / (kernel_ms * 1e-3) / 1e9 if tr else None
@@ -294,7 +297,9 @@ def main():
                        "chains_per_gpu": C_tot, "total_chains": C_tot * world, "posteriors": per_post,
                        "parallelism": (f"chains sharded {C_tot}/GPU x {world}, no data-path collective; one RCCL all-gather of the "
                                        f"draws-of-interest (device buffers); " if world > 1 else f"{C_tot} chains; ") +
-                                      (f"each chain on a cluster of {K} workgroups ({C_tot * K} of 256 CUs busy)" if K > 1
+                                      (f"each chain on two clusters of {K} workgroups, one per end of the NUTS trajectory ({C_tot * K * 2} of 256 CUs busy)"
+                                       if K > 1 and sides == 2 else
+                                       f"each chain on a cluster of {K} workgroups ({C_tot * K} of 256 CUs busy)" if K > 1
                                        else "one workgroup per chain")},
             "leapfrogs": int(leapfrogs), "seconds": elapsed,
             "us_per_leapfrog_per_chain": 1e6 * kernel_ms_max * 1e-3 * C_tot / max(sum(lf_local), 1),

@@ -112,6 +112,12 @@ typedef struct potus_opts {
   int32_t metric;          /* POTUS_METRIC_DIAG (CmdStan's default, what final_2016.R:533-541 runs) or
                               POTUS_METRIC_DENSE (metric = "dense_e": stan::mcmc::dense_e_metric + covar_adaptation,
                               BASELINE configs[4]) */
+  int32_t twin;            /* cluster mode, diagonal metric: 1 = TWO clusters of cus_per_chain workgroups per chain, one per
+                              end of the NUTS trajectory -- the doublings that go forward and those that go backward are
+                              integrated at the same time (2 * chains * cus_per_chain <= CUs of the device); 0 = one
+                              cluster; -1 = the library decides when it also chooses the cluster size (cus_per_chain = 0):
+                              two clusters if they fit.  Same algorithm and RNG streams; accept_stat__ differs from the
+                              one-cluster sampler in the last bits (summed per subtree), hence so do the chains. */
 } potus_opts;
 #define POTUS_METRIC_DIAG 0
 #define POTUS_METRIC_DENSE 1
@@ -138,6 +144,9 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle);
 int potus_destroy(int handle);
 /* Compute units (workgroups) per chain the handle actually runs with (cus_per_chain = 0 resolved). */
 int potus_cus_per_chain(int handle, int *k);
+/* clusters per chain of the handle: 2 when it runs the two ends of the trajectory on a cluster each (potus_opts.twin),
+ * 1 otherwise */
+int potus_clusters_per_chain(int handle, int *n);
 
 /* Parity hook: log-density (with Jacobians, constants dropped as `~` does) and its
  * gradient for n points of the unconstrained space, evaluated by the same device
@@ -228,8 +237,8 @@ void potus_R_create(int *dims /*[8]: N_nat,N_state,T,S,P,M,Pop,variant*/,
                     sigma_noise_nat,sigma_noise_state,sigma_e_bias,random_walk_scale,
                     mu_b_T_scale,polling_bias_scale*/,
                     double *state_covariance_0,
-                    int *iopts /*[9]: chains,chain_id_offset,num_warmup,num_samples,max_depth,
-                    device,save_warmup,cus_per_chain,metric*/,
+                    int *iopts /*[10]: chains,chain_id_offset,num_warmup,num_samples,max_depth,
+                    device,save_warmup,cus_per_chain,metric,twin*/,
                     double *dopts /*[7]: delta,gamma,kappa,t0,stepsize,init_radius,seed (an integer < 2^53:
                     R's own integers have 32 bits)*/,
                     int *handle, int *status);

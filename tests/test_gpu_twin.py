@@ -1,0 +1,141 @@
+"""Twin mode (potus_opts.twin, potus_cluster.hpp): two clusters per chain, one per end of the NUTS trajectory.  The
+forward and the backward doublings of a transition are integrated at the same time; the trajectory-level bookkeeping
+(accept step, rho, U-turn checks across the trajectory) is taken in doubling order by whichever side built the subtree.
+Same algorithm, same RNG streams: the chains must follow the oracle's exactly as the one-cluster sampler does."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_lib import OracleModel
+from us_potus_model_amd import Handle, PotusModel, sampler
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cus", [8, 16])
+@pytest.mark.parametrize("name,iters", [("small_full", 10), ("small_nomode", 8), ("2016", 3), ("2008", 3)])
+def test_twin_follows_the_oracle_chain(cases, name, iters, cus):
+    data, variant = cases[name]
+    h = Handle(data, variant, chains=2, num_warmup=30, num_samples=0, save_warmup=1, seed=1843, cus_per_chain=cus, twin=1)
+    assert h.clusters_per_chain == 2 and h.cus_per_chain == cus
+    h.init()
+    h.run(iters)
+    d = h.draws()[:, :iters]
+    m = OracleModel(data, variant)
+    o = m.default_opts(num_warmup=30, num_samples=0, save_warmup=1, seed=1843, fast_grad=1)
+    for c in (0, 1):
+        ref = m.sample_chain(c + 1, o)[0][:iters]
+        assert np.array_equal(d[c][:, 3:6], ref[:, 3:6]), (name, c, d[c][:, :7], ref[:, :7])   # depth, n_leapfrog, divergent
+        assert np.allclose(d[c][:, :3], ref[:, :3], rtol=1e-6, atol=1e-9), (d[c][:, :3], ref[:, :3])
+        assert np.allclose(d[c][:, 6], ref[:, 6], rtol=1e-8)
+        assert np.allclose(d[c][:, 7:], ref[:, 7:], rtol=1e-6, atol=1e-7)
+    h.close()
+
+
+def test_twin_and_one_cluster_agree_while_in_step(cases):
+    """accept_stat is summed per subtree in twin mode (last bits differ), so the two samplers drift apart chaotically --
+    but not within the first transitions, and never in distribution (test_twin_posterior_parity)."""
+    data, variant = cases["2016"]
+    kw = dict(chains=3, num_warmup=40, num_samples=0, save_warmup=1, seed=99, cus_per_chain=16)
+    out = []
+    for twin in (0, 1):
+        h = Handle(data, variant, twin=twin, **kw)
+        assert h.clusters_per_chain == 1 + twin
+        h.init(); h.run(12)
+        out.append(h.draws()[:, :12].copy())
+        print("twin" if twin else "one cluster", "%d leapfrogs in %.1f ms" % tuple(reversed(h.last_run_timing())))
+        h.close()
+    a, b = out
+    assert np.array_equal(a[:, :, 3:6], b[:, :, 3:6])
+    assert np.allclose(a[:, :, :3], b[:, :, :3], rtol=1e-7, atol=1e-10) and np.allclose(a[:, :, 7:], b[:, :, 7:], rtol=1e-6, atol=1e-8)
+
+
+def test_twin_through_a_metric_update_and_across_launch_boundaries(cases):
+    """150 warm-up iterations: init buffer, the first window end (metric update + init_stepsize, run redundantly by both
+    sides), and the same bytes however the iterations are split over launches."""
+    data, variant = cases["small_full"]
+    nw, total = 150, 110
+    kw = dict(chains=2, num_warmup=nw, num_samples=0, save_warmup=1, seed=11, cus_per_chain=8, twin=1)
+    out = []
+    for chunks in ([110], [99, 1, 10], [50, 49, 2, 9]):
+        h = Handle(data, variant, **kw); h.init()
+        for n in chunks:
+            h.run(n)
+        out.append(h.draws()[:, :total].copy())
+        eps, minv = h.adaptation()
+        h.close()
+    for d in out[1:]:
+        assert np.array_equal(out[0], d)
+    d = out[0][0]
+    m = OracleModel(data, variant)
+    ref, ad, nl = m.sample_chain(1, m.default_opts(num_warmup=nw, num_samples=0, save_warmup=1, seed=11, fast_grad=1))
+    assert np.array_equal(d[:20, 3:6], ref[:20, 3:6]) and np.allclose(d[:20, 2], ref[:20, 2], rtol=1e-6)
+    w = d[75:100, 7:]
+    want = (25 / 30.0) * w.var(axis=0, ddof=1) + 1e-3 * (5 / 30.0)
+    assert np.allclose(minv[0], want, rtol=1e-10, atol=0), np.abs(minv[0] / want - 1).max()
+    if np.allclose(d[:100, 7:], ref[:100, 7:], rtol=1e-5, atol=1e-6):
+        assert np.allclose(minv[0], ad[1:], rtol=1e-4) and np.array_equal(d[100:110, 3:6], ref[100:110, 3:6])
+
+
+def test_twin_is_the_default_when_it_fits_and_only_then(cases):
+    data, variant = cases["small_full"]
+    h = Handle(data, variant, chains=8, num_warmup=10, num_samples=0)
+    assert h.cus_per_chain == 16 and h.clusters_per_chain == 2
+    h.close()
+    h = Handle(data, variant, chains=16, num_warmup=10, num_samples=0)
+    assert h.cus_per_chain == 16 and h.clusters_per_chain == 1
+    h.close()
+    h = Handle(data, variant, chains=2, num_warmup=10, num_samples=0, cus_per_chain=16)       # an explicit size: one cluster unless asked
+    assert h.clusters_per_chain == 1
+    h.close()
+    with pytest.raises(sampler.PotusError):
+        Handle(data, variant, chains=16, num_warmup=10, num_samples=0, cus_per_chain=16, twin=1)
+    with pytest.raises(sampler.PotusError):
+        Handle(data, variant, chains=2, num_warmup=10, num_samples=0, cus_per_chain=1, twin=1)
+    with pytest.raises(sampler.PotusError):
+        Handle(data, variant, chains=2, num_warmup=30, num_samples=0, metric=1, cus_per_chain=8, twin=1)
+
+
+def test_twin_posterior_parity(cases):
+    """A full small run in twin mode against an independent run of the oracle: pooled means of every unconstrained
+    coordinate within 5 combined MCSE (as test_posterior_parity_small)."""
+    from us_potus_model_amd import diagnostics as dg
+    data, variant = cases["small_full"]
+    nw = ns = 400
+    h = Handle(data, variant, chains=4, num_warmup=nw, num_samples=ns, seed=1843, cus_per_chain=8, twin=1)
+    assert h.clusters_per_chain == 2
+    h.init(); h.run(nw + ns)
+    d = h.draws()
+    x = d[:, :, 7:]
+    st, _ = h.chain_status()
+    assert st == [0, 0, 0, 0] and d[:, :, 5].mean() < 0.02 and 0.7 < d[:, :, 1].mean() < 0.95
+    m = OracleModel(data, variant)
+    o = m.default_opts(num_warmup=nw, num_samples=ns, seed=4242, fast_grad=1)
+    y = np.stack([m.sample_chain(c, o)[0][:, 7:] for c in (1, 2, 3, 4)])
+    worst = 0.0
+    for j in range(h.D):
+        a, b = x[:, :, j], y[:, :, j]
+        se = np.hypot(a.std() / np.sqrt(dg.ess_mean(a)), b.std() / np.sqrt(dg.ess_mean(b)))
+        worst = max(worst, abs(a.mean() - b.mean()) / se)
+        assert dg.rhat(a) < 1.08
+    assert worst < 5.0, worst
+    h.close()
+
+
+def test_twin_watchdog(cases):
+    """A member of one side that never shows up: both sides give up, potus_run reports the watchdog error."""
+    data, variant = cases["small_full"]
+    os.environ["POTUS_DEBUG_DROP_MEMBER"] = "4"
+    try:
+        h = Handle(data, variant, chains=2, num_warmup=10, num_samples=0, cus_per_chain=8, twin=1, seed=3)
+    finally:
+        del os.environ["POTUS_DEBUG_DROP_MEMBER"]
+    h.init()
+    with pytest.raises(sampler.PotusError, match="error 8"):
+        h.run(3)
+    h.close()
+    g = Handle(data, variant, chains=2, num_warmup=10, num_samples=0, cus_per_chain=8, twin=1, seed=3)
+    g.init(); g.run(3)
+    assert g.total_leapfrogs() > 0
+    g.close()

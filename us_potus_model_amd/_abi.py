@@ -50,7 +50,7 @@ class PotusOpts(C.Structure):
         ("delta", C.c_double), ("gamma", C.c_double), ("kappa", C.c_double), ("t0", C.c_double),
         ("stepsize", C.c_double), ("init_radius", C.c_double),
         ("seed", C.c_uint64), ("device", C.c_int32), ("save_warmup", C.c_int32),
-        ("cus_per_chain", C.c_int32), ("metric", C.c_int32),
+        ("cus_per_chain", C.c_int32), ("metric", C.c_int32), ("twin", C.c_int32),
     ]
 
 

@@ -313,7 +313,8 @@ __device__ __forceinline__ void cl_wide_consume(const Xch &x, unsigned tag, int 
 // What thread 0 needs to take the verdicts of a leaf once its totals are in (base_nuts::build_tree's bookkeeping):
 // leaf number n of the doubling, m levels of subtrees it closes, whether it is the last leaf (top), its momentum
 // slot, the slots of its position and of the position it produced.  n < 0: nothing pending.
-struct LeafCtx { int n, m, top, depth, dir, leaf, inq, outq, nv; unsigned tag; };
+struct LeafCtx { int n, m, top, depth, dir, leaf, inq, outq, nv; unsigned tag; int ext; };   // ext: word of the totals that says "the other
+                                                                                              // cluster ended the trajectory" (twin mode), or -1
 
 // totals: wout[0] = lp, [1] = kinetic, [2 + 6 (j-1) ..] the six dot products of level j, then the top check.
 // Run by every lane of wave 0 with identical values (uniform control flow, lane 0 stores): what the verdicts read from
@@ -343,6 +344,7 @@ __device__ __forceinline__ void cl_leaf_logic(ltp ts, const LeafCtx &L, ldp wout
   const double wgt = H0 - h;
   const double sum_metro = sum_metro0 + (wgt > 0 ? 1.0 : exp(wgt));
   int cur_beg = leaf, cur_prop = inq, abort = div;   // the leaf's own position is its subtree's first proposal
+  if (L.ext >= 0 && wout[L.ext] > 0.0) abort = 1;    // twin mode: the trajectory ended at the other end, this subtree is dropped
   const int cur_end = leaf;
   double cur_lsw = wgt;
   for (int j = 1; j <= m && !abort; j++) {           // wave-uniform
@@ -1215,7 +1217,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
 template <int CL_DW, class Pol>
 __device__ __forceinline__ double cl_pass(CMp M, CCp CL, cip part, ldp lds, const ClStatic &cst, Xch &x, Pol &pol_io) {
   double v[1 + Pol::NEXTRA];
-  const LeafCtx none{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
+  const LeafCtx none{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0u, -1};
   bool aborted = false;
   v[0] = cl_pass_partial<CL_DW>(M, CL, part, lds, cst, x, pol_io, false, none, (ltp)nullptr, (ldp)nullptr, aborted);
 #pragma unroll
@@ -1254,12 +1256,15 @@ struct ClChain {
 #define CL_UNR 4
 __device__ __forceinline__ int cl_first(const ClChain &c) { int t = c.e0 + c.tid; asm volatile("" : "+v"(t)); return t; }
 
-template <bool SHARED_DST>
+template <bool SHARED_DST, bool SHARED_SRC = false>
 __device__ __forceinline__ void cl_vop_copy(const ClChain &c, unsigned s_dst, unsigned s_src) {
   for (int base = cl_first(c); base < c.e1; base += CL_UNR * PT_THREADS) {
     double v[CL_UNR];
 #pragma unroll
-    for (int k = 0; k < CL_UNR; k++) { const int i = base + k * PT_THREADS; v[k] = bld(c.st, i < c.e1 ? 8u * i : PT_OOB, s_src); }
+    for (int k = 0; k < CL_UNR; k++) {
+      const int i = base + k * PT_THREADS;
+      v[k] = SHARED_SRC ? bld_s(c.st, i < c.e1 ? 8u * i : PT_OOB, s_src) : bld(c.st, i < c.e1 ? 8u * i : PT_OOB, s_src);
+    }
 #pragma unroll
     for (int k = 0; k < CL_UNR; k++) {
       const int i = base + k * PT_THREADS;
@@ -1427,25 +1432,161 @@ __device__ __forceinline__ void cl_transition_begin(ClChain &c, uint32_t iter) {
   cl_vop_prekick(c, c.soff(V_QC), c.soff(V_PC), c.soff(V_GC), c.soff(V_PH0), c.soff(V_POOLQ + ts->nextq[0]), c.soff(V_PF0), -0.5 * eps, -eps);
 }
 
-template <int CL_DW>
-__device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
+// ================================================================ two clusters per chain ("twin" mode)
+// With 8 chains on clusters of 16 half of the 256 compute units idle.  A NUTS trajectory has two ends, and the leapfrog
+// steps at one end do not depend on those at the other: a second cluster per chain integrates the other end at the same
+// time.  Side 1 owns the forward end, side 0 the backward end; each has its own state block, exchange buffer and scalar
+// replicas (block chain + side * chains) and runs the once-per-transition parts (momentum draw, first gradient,
+// adaptation) redundantly -- same inputs, same bits.  The directions of all doublings are known at the start of a
+// transition (counter-based RNG), so a side simply builds, one after the other, the subtrees of the doublings that go its
+// way (build_tree with its internal U-turn checks and multinomial sampling is local to one end), without waiting for the
+// doublings of the other side in between: that is speculation -- if the trajectory ends at an earlier doubling the work is
+// dropped -- on compute units that would idle otherwise.  What is NOT local is the bookkeeping of transition() itself: the
+// accept step of the new subtree's proposal, the sum of momenta over the whole trajectory and the U-turn checks across
+// it.  These "combines" are taken strictly in the order of the doublings by the side that built the subtree:
+//   wait until the combine of the previous doubling is published (a side that finishes doubling d has always been busy
+//   longer than the other side needed for its doublings < d: in practice nothing waits)  ->  accept step, rho_top +=
+//   rho_subtree, the three checks with the OTHER end's momentum (read from the other side's state block)  ->  publish.
+// Trajectory-level state travels as TT_N tagged 16-byte words in the chain's mailbox (RunParams::twbuf), two slots by
+// combine parity; a combine that ends the trajectory also raises the STOP word, which the speculating side polls once
+// per leaf (the flag goes through the leaf's all-reduce, so all members drop out at the same leaf).  At the end of a
+// transition the side that holds the new sample publishes it (QC, write-through), the other side copies it; both publish
+// DONE and wait for each other before the next transition.  Expected gain: the last doubling holds half of the leaves,
+// the earlier ones fall on either side at random: max(forward, backward) = 3/4 of the leaves on average.
+// Floating point: sum_metro is added per subtree instead of leaf by leaf across doublings (accept_stat differs in the
+// last bits from the one-cluster sampler); everything else is the same arithmetic in the same order.
+enum { TT_STOP = 0, TT_DEPTH, TT_LSW, TT_SSIDE, TT_SSLOT, TT_SLP, TT_SH, TT_METRO, TT_NLEAP, TT_DIV, TT_RHOSIDE, TT_N = 12 };
+enum { TWB_TOP = 0 /* [2][16] */, TWB_STOP = 32, TWB_QC = 33, TWB_DONE = 34 /* [2] */, TWB_WD = 36, TWB_WORDS = 40 };
+
+struct Twin {
+  rsrc_t tb;               // the chain's mailbox
+  rsrc_t ost;              // the other side's state block
+  unsigned launch, ittag;  // tags: dword 2 = (iteration + 1) << 6 | (combine number + 1, or 0), dword 3 = launch id
+  int side;
+};
+struct ClTwinArgs {        // what the cold functions of twin mode rebuild their context from
+  const DevModel *Mg;
+  const ClModel *CLg;
+  const RunParams *Rg;
+  int chain, m, side;
+  unsigned launch;
+};
+__device__ __forceinline__ Twin make_twin(CRp R, int chain, int side, unsigned launch, uint32_t iter) {
+  Twin t;
+  t.tb = make_rsrc(R->twbuf + (size_t)chain * TWB_WORDS * 2, TWB_WORDS * 16u);
+  t.ost = make_rsrc(R->state + (size_t)(chain + (1 - side) * R->chains) * V_COUNT * R->Dpad, (unsigned)V_COUNT * (unsigned)R->Dpad * 8u);
+  t.launch = launch; t.ittag = (iter + 1u) << 6; t.side = side;
+  return t;
+}
+// one tagged word (lanes with voff == PT_OOB store nothing)
+__device__ __forceinline__ void tw_st(const Twin &t, unsigned voff, double v, unsigned tag) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const u32x4 w = {(unsigned)u, (unsigned)(u >> 32), tag, t.launch};
+  __builtin_amdgcn_raw_buffer_store_b128(w, t.tb, voff, 0u, CL_AUX_SC1);
+}
+// lane l < n looks at word w0 + l: true when every one carries the tag
+__device__ __forceinline__ bool tw_try(const Twin &t, int w0, int n, unsigned tag, double &val) {
+  const int lane = threadIdx.x & 63;
+  unsigned vo = lane < n ? 16u * (unsigned)(w0 + lane) : PT_OOB;
+  asm volatile("" : "+v"(vo) :: "memory");           // a fresh load every call
+  const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(t.tb, vo, 0u, CL_AUX_SC1);
+  val = __hiloint2double((int)w[1], (int)w[0]);
+  return __all(lane >= n || (w[2] == tag && w[3] == t.launch));
+}
+// the same for a word that later transitions overwrite with a later tag (DONE): any tag from `tag` on will do
+__device__ __forceinline__ bool tw_try_ge(const Twin &t, int w0, unsigned tag) {
+  unsigned vo = 16u * (unsigned)w0;
+  asm volatile("" : "+v"(vo) :: "memory");
+  const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(t.tb, vo, 0u, CL_AUX_SC1);
+  return __all(w[2] >= tag && w[3] == t.launch);
+}
+__device__ __forceinline__ void tw_give_up(const Xch &x, const Twin &t) {
+  __builtin_amdgcn_raw_buffer_store_b32(1u, t.tb, 0u, 16u * TWB_WD, CL_AUX_SC1);
+  xch_give_up(x);
+}
+__device__ __forceinline__ bool tw_dead(const Xch &x, const Twin &t) {
+  return xch_watchdog_raised(x) || __builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(t.tb, 0u, 16u * TWB_WD, CL_AUX_SC1)) != 0u;
+}
+__device__ __forceinline__ void tw_wait(const Xch &x, const Twin &t, int w0, int n, unsigned tag, double &val) {   // one wave
+  for (unsigned spins = 0; !tw_try(t, w0, n, tag, val); spins++) {
+    if (spins > CL_SPIN_LIMIT || ((spins & 1023u) == 1023u && tw_dead(x, t))) tw_give_up(x, t);
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+__device__ __forceinline__ void tw_wait_ge(const Xch &x, const Twin &t, int w0, unsigned tag) {   // one wave
+  for (unsigned spins = 0; !tw_try_ge(t, w0, tag); spins++) {
+    if (spins > CL_SPIN_LIMIT || ((spins & 1023u) == 1023u && tw_dead(x, t))) tw_give_up(x, t);
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+// Wave 0 brings the side's copy of the trajectory-level state to combine number `want` -- or to the final one if the
+// trajectory has ended (want < 0: wait for the end).  No barrier inside.
+__device__ __forceinline__ void tw_catch_up(const Xch &x, const Twin &t, ltp ts, int want) {
+  const int lane = threadIdx.x & 63;
+  double v = 0.0;
+  int seq = -1;
+  bool have = false;
+  for (unsigned spins = 0;; spins++) {
+    if (tw_try(t, TWB_STOP, 1, t.ittag, v)) { seq = (int)readlane_d(v, 0); break; }   // the trajectory is over: number of its last combine
+    if (want >= 0 && tw_try(t, TWB_TOP + 16 * (want & 1), TT_N, t.ittag | (unsigned)(want + 1), v)) { seq = want; have = true; break; }
+    if (spins > CL_SPIN_LIMIT || ((spins & 1023u) == 1023u && tw_dead(x, t))) tw_give_up(x, t);
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (!have) tw_wait(x, t, TWB_TOP + 16 * (seq & 1), TT_N, t.ittag | (unsigned)(seq + 1), v);
+  if (lane < TT_N) ts->tt[lane] = v;
+  if (lane == 0) ts->tw_seq = seq;
+}
+
+template <int CL_DW> __device__ __noinline__ unsigned cl_cold_twin_combine(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, int chain_, int m_, int side_,
+                                                                           unsigned launch_, unsigned epoch_, uint32_t iter_, int depth_, int valid_, int leaf_);
+
+template <int CL_DW, bool TWIN>
+__device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, const ClTwinArgs &ta) {
   ltp ts = c.ts;
   const int tid = c.tid;
   const double eps = ts->eps;
+  int depth = 0;
+  if (TWIN) {
+    // the directions of every doubling of this transition, and the trajectory-level state before the first one
+    if (tid < 64) {
+      const unsigned long long fw = __ballot(tid < c.max_depth && rng_uniform(c.key, iter, RNG_DIRECTION, 0, (uint32_t)(tid < c.max_depth ? tid : 0)) > 0.5);
+      if (tid == 0) {
+        const int id = ts->sample_qid;
+        ts->tw_dirs = (int)(unsigned)fw; ts->tw_seq = 0; ts->tw_over = 0; ts->tw_keep = id;
+        ts->tt[TT_STOP] = 0.0; ts->tt[TT_DEPTH] = 0.0; ts->tt[TT_LSW] = 0.0; ts->tt[TT_SSIDE] = -1.0; ts->tt[TT_SSLOT] = (double)id;
+        ts->tt[TT_SLP] = ts->q_lp[id]; ts->tt[TT_SH] = ts->q_h[id]; ts->tt[TT_METRO] = 0.0; ts->tt[TT_NLEAP] = 0.0; ts->tt[TT_DIV] = 0.0;
+        ts->tt[TT_RHOSIDE] = -1.0; ts->tt[TT_N - 1] = 0.0;
+      }
+    }
+  }
   while (true) {
     __syncthreads();
-    if (uni_i(ts->depth) >= c.max_depth || uni_i(ts->stop) || uni_i(cl_dead)) break;
-    const int depth = uni_i(ts->depth);
+    if (TWIN) {
+      if (uni_i(ts->tw_over) || uni_i(cl_dead)) break;
+      const int dirs = uni_i(ts->tw_dirs);
+      while (depth < c.max_depth && ((dirs >> depth) & 1) != ta.side) depth++;   // the doublings of the other end are not this side's business
+      if (depth >= c.max_depth) break;
+    } else {
+      if (uni_i(ts->depth) >= c.max_depth || uni_i(ts->stop) || uni_i(cl_dead)) break;
+      depth = uni_i(ts->depth);
+    }
     c.x.epoch = uni32(c.x.epoch); c.x.x1e = uni32(c.x.x1e);
     if (tid == 0) {
-      ts->dir = rng_uniform(c.key, iter, RNG_DIRECTION, 0, (uint32_t)depth) > 0.5 ? 1 : 0;
-      ts->pmask = 0;
-      ts->qmask = (1u << ts->sample_qid) | (1u << ts->nextq[0]) | (1u << ts->nextq[1]);
+      if (TWIN) {
+        ts->dir = ta.side;
+        ts->pmask = 0;
+        ts->qmask = (1u << ts->tw_keep) | (1u << ts->nextq[ta.side]);
+        ts->sum_metro = 0.0; ts->n_leap = 0; ts->divergent = 0;     // of this subtree; added to the trajectory's at the combine
+      } else {
+        ts->dir = rng_uniform(c.key, iter, RNG_DIRECTION, 0, (uint32_t)depth) > 0.5 ? 1 : 0;
+        ts->pmask = 0;
+        ts->qmask = (1u << ts->sample_qid) | (1u << ts->nextq[0]) | (1u << ts->nextq[1]);
+      }
     }
     __syncthreads();
     const int dir = uni_i(ts->dir);
     CPROF_START(c);
-    cl_vop_copy<false>(c, c.soff(V_PNEAR), c.soff(V_PF0 + dir));
+    cl_vop_copy<false, TWIN>(c, c.soff(V_PNEAR), c.soff(V_PF0 + dir));   // (twin mode: the end momentum was stored write-through)
     CPROF_MARK(c, PF_PNEAR);
     bool valid = true;
     const int nleaf = 1 << depth;
@@ -1453,7 +1594,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
     // Consecutive leaves of the subtree are software-pipelined: a leaf sends its totals (log density, kinetic energy,
     // U-turn dot products) and the next leaf starts at once; the totals are collected and the verdicts taken inside
     // that next pass (cl_pass_partial, `pend`).  Only the last leaf of the doubling waits for its own totals.
-    LeafCtx pend{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
+    LeafCtx pend{-1, 0, 0, 0, 0, 0, 0, 0, 0, 0u, -1};
     int prev_leaf = 0, prev_outq = 0;
     for (int n = 0; n < nleaf; n++) {
       if (tid == 0) {
@@ -1468,7 +1609,8 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
       c.x.epoch = uni32(c.x.epoch); c.x.x1e = uni32(c.x.x1e);
       const unsigned s_leaf = c.soff(V_POOLP + leaf);
       const int m = __builtin_ctz(~(unsigned)n);  // levels merged at this leaf
-      const bool top = n == nleaf - 1;            // then m == depth
+      const bool last = n == nleaf - 1;           // then m == depth
+      const bool top = !TWIN && last;             // twin mode: the checks across the whole trajectory belong to the combine
       // (for an odd leaf the level-1 partner is the previous leaf: its momentum slot is known without its verdicts)
       ClLeapPolicy lp{c.st, c.soff(V_POOLQ + inq), c.soff(V_POOLQ + outq), c.soff(V_PH0 + dir), c.soff(V_MINV),
                       s_leaf, 0.5 * e, e, c.soff(V_POOLP + (m >= 1 ? prev_leaf : 0)), m == 1 ? c.soff(V_RHOLEV + 1) : c.soff(V_SCR0 + 1),
@@ -1479,9 +1621,18 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
         const int j = tid - (PT_THREADS - 64) + 1;
         if (j <= m) ts->u_sub[n & 1][j] = rng_uniform(c.key, iter, RNG_SUB_ACCEPT, 0, ((uint32_t)depth << 24) | ((uint32_t)j << 16) | (uint32_t)(n >> j));
         if (j == 64 && top) ts->u_top = rng_uniform(c.key, iter, RNG_TOP_ACCEPT, 0, (uint32_t)depth);
+        if (TWIN) {
+          // has the trajectory ended at the other end?  One look per leaf, by this wave while the others start the pass;
+          // the flag travels with the leaf's totals, so every member of this cluster sees the same answer at the same leaf.
+          CRp R = (CRp)uni_ptr(ta.Rg);
+          const Twin t = make_twin(R, ta.chain, ta.side, c.x.launch, iter);
+          double sv;
+          const bool over = tw_try(t, TWB_STOP, 1, t.ittag, sv);
+          if (j == 1) ts->tw_ext = over ? 1 : 0;
+        }
       }
       bool aborted = false;
-      const double lpp = cl_pass_partial<CL_DW>(c.M, c.CL, c.part, c.lds, c.cst, c.x, lp, n < nleaf - 1, pend, ts, wout, aborted);
+      const double lpp = cl_pass_partial<CL_DW>(c.M, c.CL, c.part, c.lds, c.cst, c.x, lp, !last, pend, ts, wout, aborted);
       if (aborted || uni_i(cl_dead)) { valid = false; c.x.x1e = 0; break; }   // the previous leaf ended the trajectory: this one is dropped unseen
       CPROF_START(c);
       CPROF_COUNT(c, PF_LEAVES);
@@ -1489,6 +1640,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
       // this leaf completes (the subtrees of 2, 4, ... leaves that end here, and the whole new subtree against
       // the old trajectory when it is the last leaf of the doubling).  The sweeps only need vectors that are
       // already final; their verdicts are taken after the reduction, exactly in build_tree's order.
+      const int nv0 = 2 + 6 * (m + (top ? 1 : 0)), nv = nv0 + (TWIN ? 1 : 0);
       {
         const int lane = tid & 63, w = tid >> 6;
         const double t0 = dpp_scan_sum(lpp), t1 = dpp_scan_sum(lp.extra[0]);
@@ -1500,6 +1652,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
             for (int k = 0; k < 6; k++) wpart[(2 + k) * PT_NW + w] = (k & 1) ? b : a;
           }
         }
+        if (TWIN && lane == 63) wpart[nv0 * PT_NW + w] = (w == 0 && ts->tw_ext) ? 1.0 : 0.0;
       }
       if (m > 1 || top) { drain_vmem(); __syncthreads(); }   // the leaf's momentum is read back with another thread map
       for (int j = 2; j <= m; j++) {
@@ -1518,11 +1671,10 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
                              c.soff(V_RHOTOP), wpart + (2 + 6 * m) * PT_NW);
       }
       CPROF_MARK(c, PF_MERGE);
-      const int nv = 2 + 6 * (m + (top ? 1 : 0));
       const unsigned tag = cl_wide_publish(wpart, nv, c.x, CPROFPTR(c));
-      const LeafCtx cur{n, m, top ? 1 : 0, depth, dir, leaf, inq, outq, nv, tag};
+      const LeafCtx cur{n, m, top ? 1 : 0, depth, dir, leaf, inq, outq, nv, tag, TWIN ? nv0 : -1};
       prev_leaf = leaf; prev_outq = outq;
-      if (!top) { pend = cur; CPROF_MARK(c, PF_LEAF_SCALAR); continue; }
+      if (!last) { pend = cur; CPROF_MARK(c, PF_LEAF_SCALAR); continue; }
       // last leaf of the doubling: its verdicts are needed before anything else can start
       if (tid < 64) {
         cl_wide_consume(c.x, tag, nv, wout);
@@ -1531,8 +1683,13 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter) {
       __syncthreads();
       CPROF_MARK(c, PF_LEAF_SCALAR);
       if (uni_i(ts->abort)) { valid = false; c.x.x1e = 0; break; }
-      cl_vop_copy<false>(c, c.soff(V_PF0 + dir), c.soff(V_POOLP + leaf));   // the last leaf is the new end point
+      if (!TWIN) cl_vop_copy<false>(c, c.soff(V_PF0 + dir), c.soff(V_POOLP + leaf));   // the last leaf is the new end point
       CPROF_MARK(c, PF_COPYQ);
+    }
+    if (TWIN) {
+      c.x.epoch = uni32(cl_cold_twin_combine<CL_DW>(ta.Mg, ta.CLg, ta.Rg, ta.chain, ta.m, ta.side, ta.launch, c.x.epoch, iter, depth, valid ? 1 : 0, prev_leaf));
+      depth++;
+      continue;
     }
     if (!valid) break;
   }

@@ -173,17 +173,19 @@ __global__ __launch_bounds__(PT_THREADS) void k_run(const DevModel *Mg, const Ru
 
 // ------------------------------------------------------------------------ cluster kernels (potus_cluster.hpp)
 // grid = chains * K; block b works for chain b % chains as member b / chains.
-__device__ __forceinline__ ClChain make_clchain(CMp M, CCp CL, CRp R, int chain, int m, unsigned launch) {
+// (twin mode: side s of a chain works in block chain + s * chains of state, scalars and exchange buffers)
+__device__ __forceinline__ ClChain make_clchain(CMp M, CCp CL, CRp R, int chain, int m, unsigned launch, int side = 0) {
   ldp lds = (ldp)lds_dyn;
   ClChain c;
   const int Dpad = R->Dpad, K = CL->K;
-  double *state = R->state + (size_t)chain * V_COUNT * Dpad;
+  const int blk = chain + side * R->chains;
+  double *state = R->state + (size_t)blk * V_COUNT * Dpad;
   c.M = M; c.CL = CL; c.part = (cip)(CL->part + m * CP_N); c.lds = lds; c.ts = (ltp)(lds + CL->lds_doubles);
   c.st = make_rsrc(state, (unsigned)V_COUNT * (unsigned)Dpad * 8u);
-  c.sc = (gsc)(R->scal + (size_t)chain * K + m);
+  c.sc = (gsc)(R->scal + (size_t)blk * K + m);
   c.key = RngKey{R->seed_lo, R->seed_hi, (uint32_t)(R->chain_id_offset + chain + 1)};
   c.perm = as_g(CL->perm);
-  c.x.xb = make_rsrc(R->xbuf + (size_t)chain * (8 * K * CL->XW + 16), 4u * (unsigned)K * (unsigned)CL->XW * 16u + 16u);   // + the watchdog word
+  c.x.xb = make_rsrc(R->xbuf + (size_t)blk * (8 * K * CL->XW + 16), 4u * (unsigned)K * (unsigned)CL->XW * 16u + 16u);   // + the watchdog word
   c.x.epoch = 0; c.x.launch = launch; c.x.x1e = 0; c.x.K = K; c.x.m = m; c.x.XW = CL->XW;
   c.D = M->D; c.Dpad = Dpad; c.tid = (int)threadIdx.x;
   c.e0 = c.part[CP_E0]; c.e1 = c.e0 + c.part[CP_NE];
@@ -224,8 +226,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_init(const DevModel *Mg, cons
   CMp M = (CMp)Mg;
   CCp CL = (CCp)CLg;
   CRp R = (CRp)Rg;
-  const int chain = blockIdx.x % R->chains, m = blockIdx.x / R->chains;
-  ClChain c = make_clchain(M, CL, R, chain, m, launch);
+  const int chain = blockIdx.x % R->chains, r = blockIdx.x / R->chains, m = r % CL->K, side = r / CL->K;   // side 1: twin mode only
+  ClChain c = make_clchain(M, CL, R, chain, m, launch, side);
   c.cst = cl_setup_lds(M, CL, c.part, c.lds);
   const int tid = c.tid;
   const unsigned sQ = c.soff(V_QC), sG = c.soff(V_GC);
@@ -305,12 +307,12 @@ __device__ __forceinline__ void cl_transition_end(ClChain &c, CRp R, int chain, 
 // crosses a call is the exchange counter.  Arguments of a non-inlined function arrive in vector registers; everything
 // wave-uniform is rebuilt from them here.
 template <int CL_DW>
-__device__ __noinline__ unsigned cl_cold_transition_begin(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, int chain_, int m_,
+__device__ __noinline__ unsigned cl_cold_transition_begin(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, int chain_, int m_, int side_,
                                                           unsigned launch_, unsigned epoch_, uint32_t iter_) {
   CMp M = (CMp)uni_ptr(Mg);
   CCp CL = (CCp)uni_ptr(CLg);
   CRp R = (CRp)uni_ptr(Rg);
-  ClChain c = make_clchain(M, CL, R, (int)uni32((unsigned)chain_), (int)uni32((unsigned)m_), uni32(launch_));
+  ClChain c = make_clchain(M, CL, R, (int)uni32((unsigned)chain_), (int)uni32((unsigned)m_), uni32(launch_), (int)uni32((unsigned)side_));
   c.x.epoch = uni32(epoch_);
   c.cst = cl_load_static(CL, c.part);
   CPROF_START(c);
@@ -334,28 +336,206 @@ __device__ __noinline__ unsigned cl_cold_transition_end(const DevModel *Mg, cons
   return c.x.epoch;
 }
 
+// ------------------------------------------------------------------------ twin mode (potus_cluster.hpp): the cold parts
+// The combine of doubling d by the side that built its subtree (valid: the subtree completed without an internal U-turn
+// or divergence; leaf: momentum slot of its last leaf).  Sets ts->tw_over when the trajectory is over.
 template <int CL_DW>
+__device__ __noinline__ unsigned cl_cold_twin_combine(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, int chain_, int m_, int side_,
+                                                      unsigned launch_, unsigned epoch_, uint32_t iter_, int depth_, int valid_, int leaf_) {
+  CMp M = (CMp)uni_ptr(Mg);
+  CCp CL = (CCp)uni_ptr(CLg);
+  CRp R = (CRp)uni_ptr(Rg);
+  const int chain = (int)uni32((unsigned)chain_), side = (int)uni32((unsigned)side_), d = (int)uni32((unsigned)depth_);
+  const int valid = (int)uni32((unsigned)valid_), leaf = (int)uni32((unsigned)leaf_);
+  const uint32_t iter = uni32(iter_);
+  ClChain c = make_clchain(M, CL, R, chain, (int)uni32((unsigned)m_), uni32(launch_), side);
+  c.x.epoch = uni32(epoch_);
+  const Twin t = make_twin(R, chain, side, c.x.launch, iter);
+  ltp ts = c.ts;
+  const int tid = c.tid;
+  __syncthreads();
+  // 1. the state this combine starts from: published by the combine of doubling d - 1 (or the end of the trajectory)
+  if (uni_i(ts->tw_seq) < d) {
+    if (tid < 64) tw_catch_up(c.x, t, ts, d);
+    __syncthreads();
+  }
+  if (uni_i((int)ts->tt[TT_STOP])) {                 // the trajectory ended before this doubling: the subtree is dropped
+    if (tid == 0) ts->tw_over = 1;
+    __syncthreads();
+    return c.x.epoch;
+  }
+  const int rho_side = uni_i((int)ts->tt[TT_RHOSIDE]), dirs = uni_i(ts->tw_dirs);
+  int stop = 1;
+  if (valid) {
+    // 2. rho_top += rho_subtree and the three checks of transition() across the whole trajectory; the other end's momentum
+    //    and (if the last combine was the other side's) rho_top come from the other side's state block, where they were
+    //    stored write-through before that combine was published.  The subtree's last leaf becomes this side's end point.
+    const bool other_moved = ((side ? ~dirs : dirs) & ((1 << d) - 1)) != 0;
+    const rsrc_t rA = other_moved ? t.ost : c.st, rR = rho_side == 1 - side ? t.ost : c.st;
+    const unsigned sM = c.soff(V_MINV), a_beg = c.soff(V_PF0 + (1 - side)), a_end = c.soff(V_PNEAR), s_rt = c.soff(V_RHOTOP);
+    const unsigned b_beg = c.soff(V_POOLP + uni_i(ts->pend_beg[d])), b_end = c.soff(V_POOLP + leaf);
+    const unsigned b_rho = d == 0 ? c.soff(V_POOLP + leaf) : c.soff(V_RHOLEV + d), s_pf = c.soff(V_PF0 + side);
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    for (int base = cl_first(c); base < c.e1; base += CL_UNR * PT_THREADS) {
+      double mi[CL_UNR], ab[CL_UNR], ae[CL_UNR], ar[CL_UNR], bb[CL_UNR], be[CL_UNR], br[CL_UNR];
+#pragma unroll
+      for (int k = 0; k < CL_UNR; k++) {
+        const int i = base + k * PT_THREADS;
+        const unsigned o = i < c.e1 ? 8u * i : PT_OOB;   // masked elements read zeros and add nothing
+        mi[k] = bld(c.st, o, sM); ab[k] = bld_s(rA, o, a_beg); ae[k] = bld(c.st, o, a_end); ar[k] = bld_s(rR, o, s_rt);
+        bb[k] = bld(c.st, o, b_beg); be[k] = bld(c.st, o, b_end); br[k] = bld(c.st, o, b_rho);
+      }
+#pragma unroll
+      for (int k = 0; k < CL_UNR; k++) {
+        const int i = base + k * PT_THREADS;
+        const unsigned o = i < c.e1 ? 8u * i : PT_OOB;
+        const double rs = ar[k] + br[k];
+        bst_s(c.st, o, s_rt, rs);
+        bst_s(c.st, o, s_pf, be[k]);
+        const double sab = mi[k] * ab[k], sbe = mi[k] * be[k];
+        v[0] += sab * rs;                 // p#_beg . rho
+        v[1] += sbe * rs;                 // p#_end . rho
+        const double e1 = ar[k] + bb[k];  // rho_old + p of the subtree's first leaf
+        v[2] += sab * e1;
+        v[3] += mi[k] * bb[k] * e1;
+        const double e2 = br[k] + ae[k];  // rho_subtree + p of the old end
+        v[4] += mi[k] * ae[k] * e2;
+        v[5] += sbe * e2;
+      }
+    }
+    cl_allreduce(v, c.red(), c.x, tid);   // also: every member's stores above are complete before anything is published
+    const bool persist = v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0 && v[4] > 0 && v[5] > 0;
+    stop = (!persist || d + 1 >= c.max_depth) ? 1 : 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // the subtree's leaves count whether it is valid or not (base_nuts: n_leapfrog_, sum_metro_prob, divergent_)
+    ts->tt[TT_METRO] += ts->sum_metro; ts->tt[TT_NLEAP] += (double)ts->n_leap;
+    if (ts->divergent) ts->tt[TT_DIV] = 1.0;
+    if (valid) {
+      const double lsw_top = ts->tt[TT_LSW], lsw_sub = ts->pend_lsw[d];
+      const int prop = ts->pend_prop[d];
+      bool accept;
+      if (lsw_sub > lsw_top) accept = true;
+      else accept = rng_uniform(c.key, iter, RNG_TOP_ACCEPT, 0, (uint32_t)d) < exp(lsw_sub - lsw_top);
+      if (accept) {
+        ts->tt[TT_SSIDE] = (double)side; ts->tt[TT_SSLOT] = (double)prop; ts->tt[TT_SLP] = ts->q_lp[prop]; ts->tt[TT_SH] = ts->q_h[prop];
+        ts->tw_keep = prop;
+      }
+      ts->tt[TT_LSW] = d_lse(lsw_top, lsw_sub);
+      ts->tt[TT_DEPTH] = (double)(d + 1);
+      ts->tt[TT_RHOSIDE] = (double)side;
+    }
+    ts->tt[TT_STOP] = (double)stop;
+    ts->tw_seq = d + 1; ts->tw_over = stop;
+  }
+  __syncthreads();
+  // 3. publish (member 0): the state after combine d, and the STOP word if the trajectory is over
+  if (c.x.m == 0 && tid < 64) {
+    const double val = ts->tt[tid < TT_N ? tid : 0];
+    tw_st(t, tid < TT_N ? 16u * (unsigned)(TWB_TOP + 16 * ((d + 1) & 1) + tid) : PT_OOB, val, t.ittag | (unsigned)(d + 2));
+    tw_st(t, (stop && tid == 0) ? 16u * (unsigned)TWB_STOP : PT_OOB, (double)(d + 1), t.ittag);
+  }
+  __syncthreads();
+  return c.x.epoch;
+}
+
+// New sample -> this side's chain position (from its own pool or from the other side's QC), draws array (side 0),
+// adaptation (both sides, same inputs), rendezvous with the other side.
+template <int CL_DW>
+__device__ __noinline__ unsigned cl_cold_twin_end(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, int chain_, int m_, int side_,
+                                                  unsigned launch_, unsigned epoch_, uint32_t iter_) {
+  CMp M = (CMp)uni_ptr(Mg);
+  CCp CL = (CCp)uni_ptr(CLg);
+  CRp R = (CRp)uni_ptr(Rg);
+  const int chain = (int)uni32((unsigned)chain_), side = (int)uni32((unsigned)side_), it = (int)uni32(iter_);
+  ClChain c = make_clchain(M, CL, R, chain, (int)uni32((unsigned)m_), uni32(launch_), side);
+  c.x.epoch = uni32(epoch_);
+  c.cst = cl_load_static(CL, c.part);
+  const Twin t = make_twin(R, chain, side, c.x.launch, (uint32_t)it);
+  ltp ts = c.ts;
+  const int tid = c.tid;
+  CPROF_START(c);
+  __syncthreads();
+  if (!uni_i(ts->tw_over)) {                          // this side ran out of doublings of its own: wait for the end
+    if (tid < 64) tw_catch_up(c.x, t, ts, -1);
+    __syncthreads();
+  }
+  const int owner = uni_i((int)ts->tt[TT_SSIDE]), slot = uni_i((int)ts->tt[TT_SSLOT]);
+  if (tid == 0) {
+    ts->n_leap = (int)ts->tt[TT_NLEAP]; ts->divergent = (int)ts->tt[TT_DIV]; ts->depth = (int)ts->tt[TT_DEPTH];
+    ts->accept_stat = ts->tt[TT_METRO] / ts->tt[TT_NLEAP];
+    ts->out_lp = ts->tt[TT_SLP]; ts->out_h = ts->tt[TT_SH];
+    c.sc->total_leapfrogs += ts->n_leap;
+    c.sc->n_divergent += ts->divergent;
+  }
+  __syncthreads();
+  const bool warm = it < R->num_warmup;
+  const bool save = (!warm || R->save_warmup) && side == 0;
+  gdp row = as_g(R->draws) + ((size_t)chain * R->n_save_max + c.sc->saved) * R->row;
+  if (save && tid == 0 && c.x.m == 0) {
+    row[0] = ts->out_lp; row[1] = ts->accept_stat; row[2] = ts->eps; row[3] = ts->depth; row[4] = ts->n_leap;
+    row[5] = ts->divergent; row[6] = ts->out_h;
+  }
+  const unsigned sQ = c.soff(V_QC);
+  if (owner == 1 - side) {
+    if (tid < 64) { double dummy; tw_wait(c.x, t, TWB_QC, 1, t.ittag, dummy); }
+    __syncthreads();
+  }
+  {
+    const rsrc_t rsrc = owner == 1 - side ? t.ost : c.st;
+    const unsigned s_src = owner == 1 - side ? sQ : c.soff(V_POOLQ + slot);
+    for (int i = c.e0 + tid; i < c.e1; i += PT_THREADS) {
+      const double v = bld_s(rsrc, 8u * i, s_src);
+      bst_s(c.st, 8u * i, sQ, v);
+      const int si = c.perm[i];
+      if (save && si >= 0) row[POTUS_N_SAMPLER_COLS + si] = v;
+    }
+  }
+  cl_sync(c.x, c.red());
+  if (owner == side && c.x.m == 0 && tid < 64) tw_st(t, tid == 0 ? 16u * (unsigned)TWB_QC : PT_OOB, 1.0, t.ittag);
+  if (tid == 0) {
+    c.sc->lp_cur = ts->out_lp;
+    if (!warm || R->save_warmup) c.sc->saved += 1;
+  }
+  if (warm) cl_adapt_after_transition<CL_DW>(c, (uint32_t)it);
+  __syncthreads();
+  if (tid == 0) c.sc->iter = it + 1;
+  // Rendezvous: nothing of this transition is read from the other side's memory after this point, and the other side
+  // must have reached the same point before this side's next transition overwrites what it may still be reading.
+  cl_sync(c.x, c.red());
+  if (c.x.m == 0 && tid < 64) tw_st(t, tid == 0 ? 16u * (unsigned)(TWB_DONE + side) : PT_OOB, 1.0, t.ittag);
+  if (tid < 64) tw_wait_ge(c.x, t, TWB_DONE + (1 - side), t.ittag);
+  __syncthreads();
+  CPROF_MARK(c, PF_SAVE);
+  return c.x.epoch;
+}
+
+template <int CL_DW, bool TWIN>
 __global__ __launch_bounds__(PT_THREADS) void k_cl_run(const DevModel *Mg, const ClModel *CLg, const RunParams *Rg, int n_iter, unsigned launch) {
   CMp M = (CMp)Mg;
   CCp CL = (CCp)CLg;
   CRp R = (CRp)Rg;
-  const int chain = blockIdx.x % R->chains, m = blockIdx.x / R->chains;
-  ClChain c = make_clchain(M, CL, R, chain, m, launch);
+  const int chain = blockIdx.x % R->chains, r = blockIdx.x / R->chains;
+  const int m = TWIN ? r % CL->K : r, side = TWIN ? r / CL->K : 0;
+  ClChain c = make_clchain(M, CL, R, chain, m, launch, side);
   if (c.sc->status != 0) return;
   if (R->debug_drop_member == m + 1) return;       // test hook: a member that never shows up
   c.cst = cl_setup_lds(M, CL, c.part, c.lds);
+  const ClTwinArgs ta{Mg, CLg, Rg, chain, m, side, launch};
   const int total = R->num_warmup + R->num_samples;
   for (int k = 0; k < n_iter; k++) {
     const int it = c.sc->iter;
     if (it >= total || uni_i(cl_dead)) break;
-    c.x.epoch = uni32(cl_cold_transition_begin<CL_DW>(Mg, CLg, Rg, chain, m, launch, c.x.epoch, (uint32_t)it));
-    cl_transition_tree<CL_DW>(c, (uint32_t)it);
+    c.x.epoch = uni32(cl_cold_transition_begin<CL_DW>(Mg, CLg, Rg, chain, m, side, launch, c.x.epoch, (uint32_t)it));
+    cl_transition_tree<CL_DW, TWIN>(c, (uint32_t)it, ta);
     if (uni_i(cl_dead)) break;
-    c.x.epoch = uni32(cl_cold_transition_end<CL_DW>(Mg, CLg, Rg, chain, m, launch, c.x.epoch, (uint32_t)it));
+    if (TWIN) c.x.epoch = uni32(cl_cold_twin_end<CL_DW>(Mg, CLg, Rg, chain, m, side, launch, c.x.epoch, (uint32_t)it));
+    else c.x.epoch = uni32(cl_cold_transition_end<CL_DW>(Mg, CLg, Rg, chain, m, launch, c.x.epoch, (uint32_t)it));
   }
   if (uni_i(cl_dead) && (c.tid & 63) == 0) c.sc->status = POTUS_ERR_WATCHDOG;   // every wave that is still alive
 #ifdef POTUS_PROF
-  if (R->prof) for (int i = c.tid; i < PT_NPROF; i += PT_THREADS) as_g(R->prof)[((size_t)chain * CL->K + m) * PT_NPROF + i] += c.prof[i];
+  if (R->prof) for (int i = c.tid; i < PT_NPROF; i += PT_THREADS) as_g(R->prof)[((size_t)(chain + side * R->chains) * CL->K + m) * PT_NPROF + i] += c.prof[i];
 #endif
 }
 
@@ -610,6 +790,8 @@ struct Sampler {
   std::vector<double> LB, LT, LW; // column-major host copies (transformed data)
   // cluster mode (K > 1)
   int K = 1, cl_dw = 8;
+  int twin = 0;             // two clusters per chain (one per end of the trajectory): state, scalars and exchange buffers hold 2 x chains blocks
+  int sides() const { return twin ? 2 : 1; }
   unsigned launch_id = 0;   // tags the exchange words of each launch
   ClModel CL{};
   ClModel *dCL = nullptr;
@@ -1088,7 +1270,8 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   sp->dCL = (ClModel *)pc;
   for (const void *f : {reinterpret_cast<const void *>(k_cl_logprob_grad<4>), reinterpret_cast<const void *>(k_cl_logprob_grad<8>),
                         reinterpret_cast<const void *>(k_cl_init<4>), reinterpret_cast<const void *>(k_cl_init<8>),
-                        reinterpret_cast<const void *>(k_cl_run<4>), reinterpret_cast<const void *>(k_cl_run<8>)})
+                        reinterpret_cast<const void *>(k_cl_run<4, false>), reinterpret_cast<const void *>(k_cl_run<8, false>),
+                        reinterpret_cast<const void *>(k_cl_run<4, true>), reinterpret_cast<const void *>(k_cl_run<8, true>)})
     HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
   sp->K = K;
   return 0;
@@ -1110,9 +1293,12 @@ int check_chains(Sampler *sp) {
   { const int rc_ = read_scalars(sp, sc); if (rc_) return rc_; }
   if (sp->K > 1) {
     const size_t per_chain = 4 * (size_t)sp->K * sp->CL.XW + 8;   // 16-byte words: exchange slots + the watchdog line
-    for (int c = 0; c < sp->R.chains; c++) {
-      unsigned wd = 0;
-      HIP_TRY(hipMemcpy(&wd, (const char *)sp->R.xbuf + ((size_t)c * per_chain + 4 * (size_t)sp->K * sp->CL.XW) * 16, 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < sp->R.chains * sp->sides(); b++) {
+      const int c = b % sp->R.chains;
+      unsigned wd = 0, wt = 0;
+      HIP_TRY(hipMemcpy(&wd, (const char *)sp->R.xbuf + ((size_t)b * per_chain + 4 * (size_t)sp->K * sp->CL.XW) * 16, 4, hipMemcpyDeviceToHost));
+      if (sp->twin) HIP_TRY(hipMemcpy(&wt, (const char *)sp->R.twbuf + ((size_t)c * TWB_WORDS + TWB_WD) * 16, 4, hipMemcpyDeviceToHost));
+      wd |= wt;
       if (wd) return fail(POTUS_ERR_WATCHDOG, "chain %d: the %d workgroups of its cluster were not running together (is another process using GPU %d?); "
                                               "the launch was abandoned and this handle is no longer usable", c + 1, sp->K, sp->device);
     }
@@ -1428,7 +1614,7 @@ void potus_default_opts(potus_opts *o) {
   o->chains = 4; o->chain_id_offset = 0; o->num_warmup = 1000; o->num_samples = 1000; o->max_depth = 10;
   o->init_buffer = 75; o->term_buffer = 50; o->window = 25;
   o->delta = 0.8; o->gamma = 0.05; o->kappa = 0.75; o->t0 = 10; o->stepsize = 1.0; o->init_radius = 2.0;
-  o->seed = 1843; o->device = 0; o->save_warmup = 0; o->cus_per_chain = 0;
+  o->seed = 1843; o->device = 0; o->save_warmup = 0; o->cus_per_chain = 0; o->metric = POTUS_METRIC_DIAG; o->twin = -1;
 }
 
 int potus_num_params(const potus_data *d, int *D) {
@@ -1482,6 +1668,7 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   if (o->max_depth < 1 || o->max_depth > PT_MAXD) return fail(POTUS_ERR_ARG, "max_depth must be in [1,%d]", PT_MAXD);
   if (o->num_warmup < 0 || o->num_samples < 0) return fail(POTUS_ERR_ARG, "negative iteration counts");
   if (o->metric != POTUS_METRIC_DIAG && o->metric != POTUS_METRIC_DENSE) return fail(POTUS_ERR_ARG, "metric must be POTUS_METRIC_DIAG or POTUS_METRIC_DENSE");
+  if (o->twin < -1 || o->twin > 1) return fail(POTUS_ERR_ARG, "twin must be -1 (library's choice), 0 or 1");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(POTUS_ERR_DEVICE, "no HIP device: libpotus_hmc needs an MI355X (gfx950)");
   if (o->device < 0 || o->device >= ndev) return fail(POTUS_ERR_DEVICE, "device %d out of range (have %d)", o->device, ndev);
@@ -1521,6 +1708,7 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
     } else if (K == 1 && !sp->k1_unsupported.empty())
       return bail(fail(POTUS_ERR_UNSUPPORTED, "%s; use cus_per_chain = 0 or >= 8", sp->k1_unsupported.c_str()));
     if (K > 1 && o->chains * K > ncu) return bail(fail(POTUS_ERR_ARG, "chains * cus_per_chain = %d exceeds the %d compute units of the device", o->chains * K, ncu));
+    if (o->twin == 1 && K == 1) return bail(fail(POTUS_ERR_ARG, "twin = 1 needs a cluster per chain (cus_per_chain = 0 or >= 8)"));
     if (K > 1) {
       rc = build_cluster(sp, d, K);
       // chosen by the library: a member whose polls do not fit its LDS gets half of them with twice the members
@@ -1528,12 +1716,23 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
       if (rc) return bail(rc);
       // the members of a cluster wait for each other: the whole grid has to be resident at once
       int per_cu = 0;
-      const void *kfn = sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4>) : reinterpret_cast<const void *>(k_cl_run<8>);
+      const void *kfn = sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4, false>) : reinterpret_cast<const void *>(k_cl_run<8, false>);
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, PT_THREADS, sp->cl_lds_bytes) != hipSuccess || per_cu < 1)
         return bail(fail(POTUS_ERR_DEVICE, "cluster kernel cannot be resident on this device (occupancy query: %d workgroups per compute unit with %zu bytes of LDS)",
                          per_cu, sp->cl_lds_bytes));
       if ((long long)o->chains * K > (long long)ncu * per_cu)
         return bail(fail(POTUS_ERR_ARG, "chains * cus_per_chain = %d workgroups cannot be resident together (%d compute units x %d)", o->chains * K, ncu, per_cu));
+      // Two clusters per chain, one per end of the trajectory (potus_cluster.hpp, twin mode), when the compute units are there:
+      // asked for (twin = 1), or chosen with the cluster size (twin < 0 and cus_per_chain = 0).  Diagonal metric only.
+      const bool twin_fits = o->metric != POTUS_METRIC_DENSE && (long long)o->chains * 2 * K <= (long long)ncu;
+      if (o->twin == 1 && !twin_fits)
+        return bail(fail(POTUS_ERR_ARG, "twin = 1: two clusters of %d per chain need %d compute units (the device has %d) and the diagonal metric", K, o->chains * 2 * K, ncu));
+      const void *kft = sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4, true>) : reinterpret_cast<const void *>(k_cl_run<8, true>);
+      int per_cu_t = 0;
+      if ((o->twin == 1 || (o->twin < 0 && o->cus_per_chain == 0)) && twin_fits &&
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, kft, PT_THREADS, sp->cl_lds_bytes) == hipSuccess && per_cu_t >= 1)
+        sp->twin = 1;
+      else if (o->twin == 1) return bail(fail(POTUS_ERR_DEVICE, "twin = 1: the twin kernel cannot be resident on this device"));
     }
   }
   if (hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&sp->ev0) != hipSuccess ||
@@ -1553,23 +1752,30 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   R.row = POTUS_N_SAMPLER_COLS + sp->L.D;
   R.n_save_max = o->num_samples + (o->save_warmup ? o->num_warmup : 0);
   void *p = nullptr;
-  const size_t state_bytes = (size_t)o->chains * V_COUNT * R.Dpad * sizeof(double);
+  const size_t nblk = (size_t)o->chains * sp->sides();      // twin mode: a block per side
+  const size_t state_bytes = nblk * V_COUNT * R.Dpad * sizeof(double);
   if (hipMalloc(&p, state_bytes) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc(%zu) for chain state failed", state_bytes));
   sp->allocs.push_back(p); R.state = (double *)p;
   (void)hipMemset(p, 0, state_bytes);
-  if (hipMalloc(&p, sizeof(ChainScalars) * o->chains * sp->K) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for chain scalars failed"));
+  if (hipMalloc(&p, sizeof(ChainScalars) * nblk * sp->K) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for chain scalars failed"));
   sp->allocs.push_back(p); R.scal = (ChainScalars *)p;
-  (void)hipMemset(p, 0, sizeof(ChainScalars) * o->chains * sp->K);
-  R.K = sp->K; R.xbuf = nullptr; R.xcnt = nullptr;
+  (void)hipMemset(p, 0, sizeof(ChainScalars) * nblk * sp->K);
+  R.K = sp->K; R.xbuf = nullptr; R.xcnt = nullptr; R.twin = sp->twin; R.twbuf = nullptr;
   R.debug_drop_member = getenv("POTUS_DEBUG_DROP_MEMBER") ? atoi(getenv("POTUS_DEBUG_DROP_MEMBER")) : 0;
   if (sp->K > 1) {
-    const size_t xb = (size_t)o->chains * (4 * (size_t)sp->K * sp->CL.XW + 8) * 16;   // per chain: 4 exchange slots + a line for the watchdog word
+    const size_t xb = nblk * (4 * (size_t)sp->K * sp->CL.XW + 8) * 16;   // per chain (and side): 4 exchange slots + a line for the watchdog word
     if (hipMalloc(&p, xb) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for exchange buffers failed"));
     sp->allocs.push_back(p); R.xbuf = (double *)p;
     (void)hipMemset(p, 0, xb);
     if (hipMalloc(&p, (size_t)o->chains * 64 * sizeof(unsigned)) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for exchange counters failed"));
     sp->allocs.push_back(p); R.xcnt = (unsigned *)p;
     (void)hipMemset(p, 0, (size_t)o->chains * 64 * sizeof(unsigned));
+    if (sp->twin) {
+      const size_t tb = (size_t)o->chains * TWB_WORDS * 16;
+      if (hipMalloc(&p, tb) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for the twin mailboxes failed"));
+      sp->allocs.push_back(p); R.twbuf = (double *)p;
+      (void)hipMemset(p, 0, tb);
+    }
   }
   const size_t draw_bytes = std::max<size_t>((size_t)o->chains * R.n_save_max * R.row, 1) * sizeof(double);
   if (hipMalloc(&p, draw_bytes) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc(%zu) for draws failed", draw_bytes));
@@ -1577,9 +1783,9 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   (void)hipMemset(p, 0, draw_bytes);
 
 #ifdef POTUS_PROF
-  if (hipMalloc(&p, sizeof(double) * PT_NPROF * o->chains * sp->K) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for profile failed"));
+  if (hipMalloc(&p, sizeof(double) * PT_NPROF * nblk * sp->K) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for profile failed"));
   sp->allocs.push_back(p); R.prof = (double *)p;
-  (void)hipMemset(p, 0, sizeof(double) * PT_NPROF * o->chains * sp->K);
+  (void)hipMemset(p, 0, sizeof(double) * PT_NPROF * nblk * sp->K);
 #else
   R.prof = nullptr;
 #endif
@@ -1619,6 +1825,13 @@ int potus_cus_per_chain(int handle, int *k) {
   Sampler *sp = get(handle);
   if (!sp || !k) return fail(POTUS_ERR_STATE, "bad handle");
   *k = sp->K;
+  return 0;
+}
+
+int potus_clusters_per_chain(int handle, int *n) {
+  Sampler *sp = get(handle);
+  if (!sp || !n) return fail(POTUS_ERR_STATE, "bad handle");
+  *n = sp->sides();
   return 0;
 }
 
@@ -1667,10 +1880,10 @@ int potus_init(int handle, const double *q0) {
   if (sp->K > 1) {
     const unsigned lid = ++sp->launch_id;
     if (sp->cl_dw == 4)
-      hipLaunchKernelGGL(k_cl_init<4>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
+      hipLaunchKernelGGL(k_cl_init<4>, dim3(sp->R.chains * sp->K * sp->sides()), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
                          (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq0, lid);
     else
-      hipLaunchKernelGGL(k_cl_init<8>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
+      hipLaunchKernelGGL(k_cl_init<8>, dim3(sp->R.chains * sp->K * sp->sides()), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
                          (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq0, lid);
   } else
     hipLaunchKernelGGL(k_init, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, (const double *)dq0);
@@ -1696,12 +1909,15 @@ int run_launch(RunTicket &t, int n_iter) {
     if (rc) return rc;
   } else if (sp->K > 1) {
     const unsigned lid = ++sp->launch_id;
-    if (sp->cl_dw == 4)
-      hipLaunchKernelGGL(k_cl_run<4>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
-                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, n_iter, lid);
-    else
-      hipLaunchKernelGGL(k_cl_run<8>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
-                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, n_iter, lid);
+    const dim3 grid((unsigned)(sp->R.chains * sp->K * sp->sides()));
+    const DevModel *dM = sp->dM; const ClModel *dCL = sp->dCL; const RunParams *dR = sp->dR;
+    if (sp->twin) {
+      if (sp->cl_dw == 4) hipLaunchKernelGGL((k_cl_run<4, true>), grid, dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, dM, dCL, dR, n_iter, lid);
+      else hipLaunchKernelGGL((k_cl_run<8, true>), grid, dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, dM, dCL, dR, n_iter, lid);
+    } else {
+      if (sp->cl_dw == 4) hipLaunchKernelGGL((k_cl_run<4, false>), grid, dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, dM, dCL, dR, n_iter, lid);
+      else hipLaunchKernelGGL((k_cl_run<8, false>), grid, dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, dM, dCL, dR, n_iter, lid);
+    }
   } else
     hipLaunchKernelGGL(k_run, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, n_iter);
   HIP_TRY(hipGetLastError());
@@ -1775,7 +1991,7 @@ int potus_run_many(const int *handles, int n_handles, int n_iter) {
       if (sp->K > 1) {
         int ncu = 0;
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, sp->device));
-        const int rows = (sp->R.chains * sp->K + 7) / 8, cap = ncu / 8;
+        const int rows = (sp->R.chains * sp->K * sp->sides() + 7) / 8, cap = ncu / 8;
         if (it != used.end() && (it->plain > 0 || it->rows + rows > cap)) continue;   // next group (a sampler alone always fits: checked at create)
         if (it == used.end()) used.push_back({sp->device, rows, 0}); else it->rows += rows;
       } else {
@@ -2343,7 +2559,7 @@ void potus_R_create(int *dims, int *state, int *day_state, int *day_national, in
   d.polling_bias_scale = scalars[8]; d.state_covariance_0 = state_covariance_0;
   potus_opts o; potus_default_opts(&o);
   o.chains = iopts[0]; o.chain_id_offset = iopts[1]; o.num_warmup = iopts[2]; o.num_samples = iopts[3]; o.max_depth = iopts[4];
-  o.device = iopts[5]; o.save_warmup = iopts[6]; o.cus_per_chain = iopts[7]; o.metric = iopts[8];
+  o.device = iopts[5]; o.save_warmup = iopts[6]; o.cus_per_chain = iopts[7]; o.metric = iopts[8]; o.twin = iopts[9];
   o.delta = dopts[0]; o.gamma = dopts[1]; o.kappa = dopts[2]; o.t0 = dopts[3]; o.stepsize = dopts[4]; o.init_radius = dopts[5];
   if (!(dopts[6] >= 0) || dopts[6] > 9007199254740992.0 || dopts[6] != std::floor(dopts[6])) { *status = fail(POTUS_ERR_ARG, "seed must be a non-negative integer below 2^53"); return; }
   o.seed = (uint64_t)dopts[6];   // R integers are 32 bits wide: the seed travels as a double (exact to 2^53)

@@ -75,6 +75,9 @@ struct RunParams {
   double *xbuf;            // cluster mode: [chains][2][K][XW] exchange words of 16 bytes {value, tag}
   unsigned *xcnt;          // cluster mode: [chains][64] arrival counters (one cache line apart)
   int K;                   // workgroups per chain (1: potus_nuts.hpp; > 1: potus_cluster.hpp, scal is [chains][K])
+  int twin;                // cluster mode: two clusters per chain, one per end of the trajectory (state, scal, xbuf hold 2 x chains
+                           // blocks: side s of chain c uses block c + s * chains); twbuf = their mailbox
+  double *twbuf;           // [chains][TWB_WORDS] words of 16 bytes {value, tag}
   int debug_drop_member;   // test hook (POTUS_DEBUG_DROP_MEMBER = m + 1): member m of every cluster leaves k_cl_run at once, the
                            // rest must find out through the watchdog (tests/test_gpu_parity.py)
 };
@@ -103,6 +106,11 @@ struct TS { // transition state, LDS
   int flag_a, flag_b, direction, done;
   int qsel[2];   // which of QA/QB holds the position the next leapfrog of end e evaluates (0 = QA)
   int nextq[2], out_q;   // cluster mode: proposal-pool slots holding the next position of each end / receiving this leaf's output
+  // two clusters per chain (potus_cluster.hpp, "twin" mode): this side's copy of the trajectory-level state (TT_* words) as of
+  // combine number tw_seq; the pool slot it must keep (its latest accepted proposal, or the initial point); the directions
+  // of the transition's doublings (bit j = doubling j goes forward); whether the last combine ended the trajectory
+  double tt[12];
+  int tw_seq, tw_keep, tw_dirs, tw_over, tw_ext, tw_pad;   // tw_ext: the other side's STOP word was up when this leaf started
 };
 typedef TS AS_L *ltp;
 

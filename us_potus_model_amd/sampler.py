@@ -78,13 +78,14 @@ def load_library():
     L.potus_write_array_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.potus_get_dense_metric.argtypes = [C.c_int, C.c_int, dp]
     L.potus_cus_per_chain.argtypes = [C.c_int, ip]
+    L.potus_clusters_per_chain.argtypes = [C.c_int, ip]
     _LIB = L
     return L
 
 
 EXPORTS = [
     "potus_version", "potus_last_error", "potus_default_opts", "potus_num_params", "potus_num_columns",
-    "potus_column_name", "potus_create", "potus_destroy", "potus_cus_per_chain", "potus_log_prob_grad", "potus_init", "potus_run", "potus_run_many",
+    "potus_column_name", "potus_create", "potus_destroy", "potus_cus_per_chain", "potus_clusters_per_chain", "potus_log_prob_grad", "potus_init", "potus_run", "potus_run_many",
     "potus_iterations_done", "potus_total_leapfrogs", "potus_chain_status", "potus_get_adaptation",
     "potus_get_dense_metric", "potus_dense_timing", "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_array_device", "potus_write_stan_csv",
     "potus_last_run_timing", "potus_posterior_summary", "potus_posterior_summary_many", "potus_backtest_scores",
@@ -131,6 +132,8 @@ class Handle:
         k = C.c_int()
         _check(self.L, self.L.potus_cus_per_chain(self.h, C.byref(k)))
         self.cus_per_chain = k.value
+        _check(self.L, self.L.potus_clusters_per_chain(self.h, C.byref(k)))
+        self.clusters_per_chain = k.value          # 2: one cluster per end of the trajectory (opts twin)
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h >= 0:
@@ -379,7 +382,7 @@ class PotusModel:
 
     def sample(self, data, seed=1843, chains=4, parallel_chains=None, iter_warmup=1000, iter_sampling=1000,
                refresh=100, adapt_delta=0.8, max_treedepth=10, init=2.0, save_warmup=False, device=0,
-               chain_id_offset=0, show_messages=False, inits=None, devices=None, metric="diag_e", cus_per_chain=0):
+               chain_id_offset=0, show_messages=False, inits=None, devices=None, metric="diag_e", cus_per_chain=0, twin=-1):
         """`devices`: GPU ids; the chains are dealt to them in consecutive blocks and advance together under
         potus_run_many (one host thread).  Chain ids -- hence RNG streams and draws -- do not depend on the split."""
         from . import parallel
@@ -392,7 +395,7 @@ class PotusModel:
             h = Handle(data, self.variant, chains=n_loc, chain_id_offset=int(chain_id_offset) + off,
                        num_warmup=int(iter_warmup), num_samples=int(iter_sampling), max_depth=int(max_treedepth),
                        delta=float(adapt_delta), init_radius=float(init), seed=int(seed), device=dev,
-                       save_warmup=int(bool(save_warmup)), metric=_abi.METRICS[metric], cus_per_chain=int(cus_per_chain))
+                       save_warmup=int(bool(save_warmup)), metric=_abi.METRICS[metric], cus_per_chain=int(cus_per_chain), twin=int(twin))
             h.init(None if inits is None else np.asarray(inits)[off:off + n_loc])
             hs.append(h)
         total = int(iter_warmup) + int(iter_sampling)
