@@ -55,7 +55,7 @@ def algorithmic_bytes_per_leapfrog(d, variant="full", dense=False):
     return b + (4 * D * D if dense else 0)
 
 
-def measured_traffic(kernel):
+def measured_traffic(kernel, sides=1):
     """HBM bytes per leapfrog from the committed rocprofv3 PMC passes of this command (profiles/*pmc_traffic.json,
     scripts/profile_round.sh): FETCH_SIZE and WRITE_SIZE cannot be collected from inside the benchmark, so the bench
     line quotes the per-leapfrog figure of the latest committed pass for the same kernel -- a committed constant x this
@@ -66,7 +66,7 @@ def measured_traffic(kernel):
             d = json.loads(f.read_text())
         except (OSError, ValueError):
             continue
-        if d.get("kernel") == kernel:
+        if d.get("kernel") == kernel and (kernel != "k_cl_run" or ("two clusters" in d.get("command", "")) == (sides == 2)):
             best = (f.name, d)
     return best
 
@@ -280,7 +280,7 @@ def main():
             achieved = dense_t[2] / (dense_t[0] * 1e-3) / 1e9
         K, sides = hs[0].cus_per_chain, hs[0].clusters_per_chain
         kernel = "k_dn_symv" if dense else ("k_cl_run" if K > 1 else "k_run")
-        tr = measured_traffic(kernel)
+        tr = measured_traffic(kernel, sides)
         traffic = tr[1]["hbm_bytes_per_leapfrog"] * sum(lf_local) / (kernel_ms * 1e-3) / 1e9 if tr else None
         C_tot = sum(w[3] for w in work)
         names = {1: "configs[1]: 2016 backtest", 2: "configs[2]: 2016 backtest, chains sharded over the GPUs",
