@@ -134,7 +134,7 @@ def cpu_baseline(data, variant, chains, seed, nw, ns, gpu_ess_per_leapfrog, budg
 
 
 # ------------------------------------------------------------------------------------------------ workloads
-def load_workloads(cfg, chains_per_gpu):
+def load_workloads(cfg, chains_per_gpu, twin_posteriors=""):
     """[(name, data, variant, chains per GPU, options)] of the posteriors one GPU runs."""
     from us_potus_model_amd import dataprep, synthetic
     gold = ROOT / "tests" / "golden"
@@ -142,7 +142,9 @@ def load_workloads(cfg, chains_per_gpu):
         return [("2016", dataprep.load_npz(gold / "data_2016.npz")["data"], "full", chains_per_gpu or 8, {})]
     if cfg == 3:
         c = chains_per_gpu or 4
-        return [(y, dataprep.load_npz(gold / f"data_{y}.npz")["data"], v, c, {})
+        # three fits side by side: 3 x 4 x 16 = 192 compute units; the 64 left over give ONE of them a second cluster per chain
+        tw = set(twin_posteriors.split(",")) if twin_posteriors else set()
+        return [(y, dataprep.load_npz(gold / f"data_{y}.npz")["data"], v, c, {"twin": 1 if y in tw else 0})
                 for y, v in (("2008", "no_mode_adjustment"), ("2012", "no_mode_adjustment"), ("2016", "full"))]
     if cfg == 4:
         from us_potus_model_amd import _abi
@@ -159,6 +161,7 @@ def main():
     ap.add_argument("--chains-per-gpu", type=int, default=0, help="per posterior (0 = the configuration's: 8, 8, 4, 4)")
     ap.add_argument("--cus-per-chain", type=int, default=0, help="workgroups per chain (0 = auto: 16, 8 or 1 by what fits)")
     ap.add_argument("--twin", type=int, default=-1, help="two clusters per chain, one per end of the trajectory: 1, 0, or -1 = the library's choice")
+    ap.add_argument("--twin-posteriors", default="2016", help="--config 3: the posteriors (comma-separated years) that get two clusters per chain")
     ap.add_argument("--chunk", type=int, default=0, help="transitions per step (0 = the configuration's: 100; 1 for --config 4)")
     ap.add_argument("--seed", type=int, default=1843)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -185,7 +188,7 @@ def main():
 
     cfg = args.config
     chunk = args.chunk or (1 if cfg == 4 else 100)
-    work = load_workloads(cfg, args.chains_per_gpu)
+    work = load_workloads(cfg, args.chains_per_gpu, "" if dev_backend == "gloo" else args.twin_posteriors)
     nw, ns = (args.steps // 2) * chunk, (args.steps - args.steps // 2) * chunk
 
     def make(seed, num_warmup, num_samples):
@@ -194,7 +197,7 @@ def main():
             while True:
                 try:
                     hs.append(Handle(data, variant, chains=C, chain_id_offset=rank * C, num_warmup=num_warmup, num_samples=num_samples,
-                                     seed=seed, device=local, cus_per_chain=args.cus_per_chain, twin=twin, **extra))
+                                     seed=seed, device=local, cus_per_chain=args.cus_per_chain, **{"twin": twin, **extra}))
                     break
                 except Exception as e:      # the dense metric keeps two D x D matrices per chain: as many chains as the HBM holds
                     if cfg != 4 or args.chains_per_gpu or C <= 1 or "GB free" not in str(e):
