@@ -285,6 +285,18 @@ def main():
         kernel = "k_dn_symv" if dense else ("k_cl_run" if K > 1 else "k_run")
         tr = measured_traffic(kernel, sides)
         traffic = tr[1]["hbm_bytes_per_leapfrog"] * sum(lf_local) / (kernel_ms * 1e-3) / 1e9 if tr else None
+        traffic_note = (f"NOT measured in this run: {tr[1]['hbm_bytes_per_leapfrog']:.0f} HBM bytes per leapfrog from the committed "
+                        f"rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE, profiles/{tr[0]}; WRITE_SIZE "
+                        f"uncalibrated) x this run's leapfrogs / launch time" if tr else "no PMC pass committed for this kernel")
+        if dense:   # the matrix pass: HBM reads measured / bytes loaded by construction, from the committed counter pass of the dense sampler
+            for f in sorted((ROOT / "profiles").glob("*dense_pmc_fetch.json")):
+                try:
+                    ratio = json.loads(f.read_text())["ratio_with_finish"]
+                except (OSError, ValueError, KeyError):
+                    continue
+                traffic = achieved * ratio
+                traffic_note = (f"NOT measured in this run: HBM reads of k_dn_symv + k_dn_symv_finish = {ratio:.3f} x the bytes the passes load by "
+                                f"construction (rocprofv3 --pmc FETCH_SIZE pass of the dense sampler, doubled per the guide; profiles/{f.name}) x this run's rate")
         C_tot = sum(w[3] for w in work)
         names = {1: "configs[1]: 2016 backtest", 2: "configs[2]: 2016 backtest, chains sharded over the GPUs",
                  3: "configs[3]: 2008 + 2012 + 2016 backtests concurrently", 4: "configs[4]: synthetic stress posterior, dense metric"}
@@ -311,9 +323,7 @@ def main():
             "rhat_max": max(rhat_all) if rhat_all else None, "sampling_seconds": samp_time,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": (f"NOT measured in this run: {tr[1]['hbm_bytes_per_leapfrog']:.0f} HBM bytes per leapfrog from the committed "
-                                          f"rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE, profiles/{tr[0]}; WRITE_SIZE "
-                                          f"uncalibrated) x this run's leapfrogs / launch time" if tr else "no PMC pass committed for this kernel"),
+                         "traffic_note": traffic_note,
                          "kernel": kernel, "algorithmic_bytes_per_leapfrog": bpl if len(bpl) > 1 else bpl[0],
                          "leapfrogs_in_launches": int(sum(lf_local)), "launch_ms_total": kernel_ms,
                          **({"matrix_passes": dense_t[1], "matrix_pass_ms_total": dense_t[0], "matrix_bytes_streamed": dense_t[2],

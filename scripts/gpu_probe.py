@@ -17,6 +17,7 @@ data = dataprep.load_npz(ROOT / "tests" / "golden" / "data_2016.npz")["data"]
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 chain_counts = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 8, 64, 256]
 KCL = int(os.environ.get("POTUS_K", "1"))
+TWIN = int(os.environ.get("POTUS_TWIN", "0"))          # 1: two clusters per chain (profile rows: side 0's members, then side 1's)
 NAMESK = {0: "A load+suffix", 1: "B matvec/AR + X1", 2: "carry -> C", 3: "C polls", 4: "D gathers/seg1", 5: "E prefix/seg2", 6: "E2 payload parts",
           7: "X2 publish+wait", 18: "F finish grads", 19: "X3 allreduce", 10: "leaf scalar", 11: "merge", 12: "copy q", 13: "p_near",
           9: "begin (all transitions)", 15: "end (all transitions)", 20: "ar:shuffle", 21: "ar:drain", 22: "ar:barrier1", 23: "ar:payload st",
@@ -25,7 +26,7 @@ NAMES1 = {0: "A load+suffix", 1: "B carry/C/AR1", 2: "C polls", 3: "D gathers", 
          8: "momentum", 9: "init copy", 10: "leaf scalar", 11: "merge", 12: "copy q", 13: "p_near", 14: "adapt", 15: "save"}
 NAMES = NAMES1 if KCL == 1 else NAMESK
 for chains in chain_counts:
-    h = Handle(data, "full", chains=chains, num_warmup=iters, num_samples=0, seed=1843, cus_per_chain=KCL)
+    h = Handle(data, "full", chains=chains, num_warmup=iters, num_samples=0, seed=1843, cus_per_chain=KCL, twin=TWIN)
     h.init()
     ms_tot, lf_tot = 0.0, 0
     for _ in range(3):
@@ -37,7 +38,7 @@ for chains in chain_counts:
           f"{ms_tot*1e3*chains/lf_tot:.2f} us/leapfrog/chain", flush=True)
     L = sampler.load_library()
     if hasattr(L, "potus_debug_profile"):
-        out = np.zeros((chains * KCL, 64))
+        out = np.zeros((chains * KCL * (2 if TWIN else 1), 64))
         L.potus_debug_profile.argtypes = [C.c_int, C.POINTER(C.c_double)]
         if L.potus_debug_profile(h.h, out.ctypes.data_as(C.POINTER(C.c_double))):
             p = out[0]

@@ -320,3 +320,27 @@ def test_bench_two_ranks_end_to_end_gloo_development_mode(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["config"]["total_chains"] == 8 and d["config"]["iter_sampling"] == 20
     assert d["config"]["posteriors"]["2016"]["pooled_draws"] == 8 * 20 and d["leapfrogs"] > 0 and d["roofline"]["frac"] > 0
+
+
+def test_rccl_collectives_on_device_buffers_one_rank():
+    """The collectives bench.py issues at N > 1 -- all_gather_into_tensor of the [draws, chains, columns] block, MAX / SUM
+    all-reduces of a double, barrier -- on the "nccl" backend (= RCCL) with device tensors.  One GPU here, so a group of
+    one rank: shapes, dtypes (f64) and devices go through RCCL as they will on the 8-GPU node."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29547', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')\n"
+        "from us_potus_model_amd import parallel\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group(backend='nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "dev = torch.device('cuda', 0)\n"
+        "x = torch.arange(5 * 8 * 52, dtype=torch.float64, device=dev).reshape(5, 8, 52)\n"
+        "y = parallel.all_gather_chains(x, dev)\n"
+        "assert y.shape == (5, 8, 52) and y.device.type == 'cuda' and torch.equal(y, x)\n"
+        "assert parallel.max_over_ranks(3.5, dev) == 3.5 and parallel.sum_over_ranks(2.25, dev) == 2.25\n"
+        "parallel.barrier(); torch.cuda.synchronize(); dist.destroy_process_group(); print('rccl ok')\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(ROOT),
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]

@@ -24,7 +24,7 @@ def _blocks(data, variant):
     return {k: (a - 7, b - 7) for k, (a, b, _) in layout.items() if b - 7 <= D}
 
 
-CUS = [1, 8, 16]
+CUS = [1, 4, 8, 16]
 
 
 @pytest.mark.parametrize("cus", CUS)

@@ -1530,7 +1530,8 @@ __device__ __forceinline__ void tw_catch_up(const Xch &x, const Twin &t, ltp ts,
     if (tw_try(t, TWB_STOP, 1, t.ittag, v)) { seq = (int)readlane_d(v, 0); break; }   // the trajectory is over: number of its last combine
     if (want >= 0 && tw_try(t, TWB_TOP + 16 * (want & 1), TT_N, t.ittag | (unsigned)(want + 1), v)) { seq = want; have = true; break; }
     if (spins > CL_SPIN_LIMIT || ((spins & 1023u) == 1023u && tw_dead(x, t))) tw_give_up(x, t);
-    __builtin_amdgcn_s_sleep(1);
+    if (want < 0) __builtin_amdgcn_s_sleep(16);      // waiting for the other side's last doubling: look at the word every microsecond only
+    else __builtin_amdgcn_s_sleep(1);
   }
   if (!have) tw_wait(x, t, TWB_TOP + 16 * (seq & 1), TT_N, t.ittag | (unsigned)(seq + 1), v);
   if (lane < TT_N) ts->tt[lane] = v;

@@ -1693,12 +1693,13 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   if ((rc = build_model(sp, d))) return bail(rc);
   if (sp->k1_unsupported.empty() && (rc = set_lds_attr(sp))) return bail(rc);
   {
-    // workgroups (CUs) per chain: 0 = as many as fit the device, in {16, 8, 1}; chains * K blocks must be co-resident
+    // workgroups (CUs) per chain: 0 = as many as fit the device, in {16, 8, 4, 1}; chains * K blocks must be co-resident
     const int ncu = prop.multiProcessorCount;
     int K = o->cus_per_chain;
     if (K < 0 || K > CL_MAXK) return bail(fail(POTUS_ERR_ARG, "cus_per_chain must be in [0,%d]", CL_MAXK));
     if (K == 0) {
-      K = o->chains * 16 <= ncu ? 16 : o->chains * 8 <= ncu ? 8 : 1;
+      K = o->chains * 16 <= ncu ? 16 : o->chains * 8 <= ncu ? 8 : o->chains * 4 <= ncu ? 4 : 1;
+      if (K == 4 && d->T > 4 * CL_MAXDAYS) K = 1;      // four members hold up to 256 days
       // models beyond the one-workgroup kernels (T > 256, > 2048 polls) need a cluster; long campaigns need more members
       if (K == 1 && !sp->k1_unsupported.empty()) K = 8;
       while (K > 1 && d->T > K * CL_MAXDAYS && 2 * K <= CL_MAXK) K *= 2;
@@ -2368,7 +2369,7 @@ int potus_debug_profile(int handle, double *out) {
   Sampler *sp = get(handle);
   if (!sp || !sp->R.prof || !out) return 0;
   (void)hipSetDevice(sp->device);
-  if (hipMemcpy(out, sp->R.prof, sizeof(double) * PT_NPROF * sp->R.chains * sp->K, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  if (hipMemcpy(out, sp->R.prof, sizeof(double) * PT_NPROF * sp->R.chains * sp->K * sp->sides(), hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return PT_NPROF;
 }
 

@@ -75,9 +75,9 @@ def all_gather_chains(local, device=None):
     mode (CPU tensors)."""
     import torch
     import torch.distributed as dist
-    _, world, _ = env_rank_world()
-    if world == 1 or not dist.is_initialized():
+    if not dist.is_initialized():
         return local
+    world = dist.get_world_size()           # (a one-rank group still goes through the collective: tests/test_gpu_boundary.py)
     if device is None:
         x = local.cpu().contiguous()
         out = [torch.empty_like(x) for _ in range(world)]
