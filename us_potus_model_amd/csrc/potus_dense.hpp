@@ -122,7 +122,7 @@ __device__ __forceinline__ double *dn_vec(const DnParams &P, int chain, int slot
 // Fixed summation order everywhere: same bytes every run and for every launch shape.  Traffic besides the triangle: the
 // column and row sums, written and read once = 3-4 % of the matrix.
 // (job0: the first of the round's jobs this launch serves -- the three products of a transition's first pass go as 2 + 1)
-#define DN_SYMV_LDS(NRHS) ((size_t)((NRHS) * (2 * DN_CT + 2 * DN_RB_MAX) + 2 * (DN_THREADS / 64) * (NRHS) * DN_CT) * 8)
+#define DN_SYMV_LDS(NRHS) ((size_t)((NRHS) * (DN_CT + 2 * DN_RB_MAX) + (DN_THREADS / 64) * (NRHS) * DN_CT) * 8)
 template <int NRHS>
 __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const DnActive act, int job0) {
   extern __shared__ __attribute__((aligned(16))) double dn_lds[];
@@ -131,13 +131,10 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
   if (!rd.active) return;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = P.D, LD = P.LD, RB = P.rb, RW = RB / (DN_THREADS / 64), nblk = (D + RB - 1) / RB;
-  // x over the tile's columns and the waves' column sums are double-buffered by tile parity: a tile costs two barriers,
-  // the reduction of its column sums runs beside the next tile's first loads, and the next tile's x is fetched (into a
-  // register per thread) while this one streams
-  double *xs2 = dn_lds;                                  // [2][NRHS][DN_CT]  x over the tile's columns
-  double *xr = xs2 + 2 * NRHS * DN_CT;                   // [NRHS][RB]  x over the block's rows
-  double *sacc = xr + NRHS * DN_RB_MAX;                  // [NRHS][RB]  row sums of the block over the current tile
-  double *tacc2 = sacc + NRHS * DN_RB_MAX;               // [2][8 waves][NRHS][DN_CT]
+  double *xs = dn_lds;                                   // [NRHS][DN_CT]  x over the tile's columns
+  double *xr = xs + NRHS * DN_CT;                        // [NRHS][RB]  x over the block's rows
+  double *sacc = xr + NRHS * DN_RB_MAX;                  // [NRHS][RB]  row sums of the block, accumulated over the tiles
+  double *tacc = sacc + NRHS * DN_RB_MAX;                // [8 waves][NRHS][DN_CT]
   const double *A = P.A + (size_t)chain * (size_t)D * (size_t)LD;
   const double *x[NRHS];
 #pragma unroll
@@ -149,8 +146,6 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
   const int split = P.split, part = (int)blockIdx.x % split, pair = (int)blockIdx.x / split;
   double *sr = P.srow + ((size_t)chain * 3 + job0) * (size_t)P.ntile * (size_t)LD;   // [job][tile][LD]
   const unsigned rowbytes = uni32(8u * (unsigned)LD);
-  static_assert(DN_CT == DN_THREADS, "one column of x per thread and tile");
-  int buf = 0;
   for (int side = 0; side < 2; side++) {
     const int b = side == 0 ? pair : nblk - 1 - pair;
     if (side == 1 && b <= pair) break;                    // odd number of blocks: the middle one once
@@ -160,21 +155,16 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
     // otherwise keeps the descriptor in vector registers and wraps every load in a waterfall loop.)
     const int wrows = min(RW, max(0, D - wrow0));
     const rsrc_t rsA = make_rsrc(uni_ptr(A + (size_t)wrow0 * LD), uni32((unsigned)wrows * rowbytes));
-    __syncthreads();                                      // the previous block's last tile is done with xr / sacc
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < NRHS; r++)
       for (int i = tid; i < RB; i += DN_THREADS) { xr[r * DN_RB_MAX + i] = r0 + i < D ? x[r][r0 + i] : 0.0; sacc[r * DN_RB_MAX + i] = 0.0; }
-    const int c_first = (r0 / DN_CT + part) * DN_CT, c_step = split * DN_CT;
-    double xn[NRHS];                                      // x of the NEXT tile's column `tid`
+    for (int c0 = (r0 / DN_CT + part) * DN_CT; c0 < D; c0 += split * DN_CT) {
+      __syncthreads();                                    // the previous tile's column sums have been read
 #pragma unroll
-    for (int r = 0; r < NRHS; r++) xn[r] = c_first + tid < D ? x[r][c_first + tid] : 0.0;
-    for (int c0 = c_first; c0 < D; c0 += c_step, buf ^= 1) {
-      double *xs = xs2 + buf * NRHS * DN_CT, *tacc = tacc2 + (size_t)buf * (DN_THREADS / 64) * NRHS * DN_CT;
-#pragma unroll
-      for (int r = 0; r < NRHS; r++) xs[r * DN_CT + tid] = xn[r];
+      for (int r = 0; r < NRHS; r++)
+        for (int j = tid; j < DN_CT; j += DN_THREADS) xs[r * DN_CT + j] = c0 + j < D ? x[r][c0 + j] : 0.0;
       __syncthreads();
-#pragma unroll
-      for (int r = 0; r < NRHS; r++) xn[r] = (c0 + c_step < D && c0 + c_step + tid < D) ? x[r][c0 + c_step + tid] : 0.0;
       dn_d2 xc[4][NRHS];
       double t_acc[4][2][NRHS];
       unsigned voff[4];
@@ -229,7 +219,6 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
         for (int r = 0; r < NRHS; r++)
           *(dn_d2 *)(tacc + ((size_t)w * NRHS + r) * DN_CT + 2 * (lane + 64 * u)) = dn_d2{t_acc[u][0][r], t_acc[u][1][r]};
       __syncthreads();
-      // (from here to the next tile's barrier: this tile's tacc buffer and sacc are read, the other xs buffer is written)
       for (int e = tid; e < NRHS * DN_CT; e += DN_THREADS) {
         const int r = e / DN_CT, c = e - r * DN_CT;
         double t = 0.0;
@@ -238,7 +227,7 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
         if (c0 + c < D) tp[((size_t)b * 3 + r) * LD + c0 + c] = t;
       }
       // the block's row sums over this tile (complete: the barrier above), and the accumulators cleared for the next one
-      // (the next tile's barrier separates this from its additions)
+      // (the barrier at the top of the loop separates this from the next tile's additions)
 #pragma unroll
       for (int r = 0; r < NRHS; r++)
         for (int i = tid; i < RB; i += DN_THREADS) {
