@@ -106,7 +106,7 @@ template <class P> __device__ __forceinline__ P launder_s(P p) { // keep address
 // all members in phase A, before their X3 of that pass; X3 words are read by all in phase C, before their X2-consuming
 // phase F of the same pass completes and hence before anybody's next X3.  Exchanges outside the tree (all-reduces of
 // the begin / end code) are all-to-all and consumed at once.  A missed assumption would not corrupt data silently:
-// a word overwritten too early carries a newer tag and the reader spins until the watchdog trap.
+// a word overwritten too early carries a newer tag and the reader spins until the watchdog ends the launch.
 // Watchdog.  The members of a cluster wait for each other, so they must all be resident; the host checks that for what
 // it launches itself (potus_create, potus_run_many), but it cannot see other processes on the GPU.  A wave that has
 // waited CL_SPIN_LIMIT rounds for a word gives up: it raises the chain's watchdog word (the 16 bytes behind the
