@@ -267,6 +267,11 @@ def main():
                     "polls": int(data["N_state_polls"]) + int(data["N_national_polls"]), "cus_per_chain": h.cus_per_chain,
                     "clusters_per_chain": h.clusters_per_chain,
                     "divergent_transitions": int(sum(dv)), "chain_status": st}
+            if h.clusters_per_chain == 2:
+                cnt, rb, rf = h.twin_stats()
+                info["twin"] = {"leapfrogs_counted": cnt, "leaves_run_backward_side": rb, "leaves_run_forward_side": rf,
+                                "leaves_run_per_counted": (rb + rf) / max(cnt, 1),
+                                "note": "each side integrates the doublings of its end, those of speculative subtrees that are dropped included"}
             if pl is not None and ns >= 8:
                 x = np.transpose(pl.cpu().numpy(), (1, 0, 2))                    # [chain, draw, 1 + S]
                 cols = np.concatenate([x, 1.0 / (1.0 + np.exp(-x[:, :, 1:]))], axis=2)   # + predicted_score[T, :]

@@ -147,6 +147,9 @@ int potus_cus_per_chain(int handle, int *k);
 /* clusters per chain of the handle: 2 when it runs the two ends of the trajectory on a cluster each (potus_opts.twin),
  * 1 otherwise */
 int potus_clusters_per_chain(int handle, int *n);
+/* twin mode: leapfrogs counted in the trajectories (n_leapfrog__ summed, = potus_total_leapfrogs) and leaves each side has
+ * integrated, those of speculative subtrees that were dropped included -- what the second cluster costs and buys */
+int potus_twin_stats(int handle, long long *counted, long long *run_backward, long long *run_forward);
 
 /* Parity hook: log-density (with Jacobians, constants dropped as `~` does) and its
  * gradient for n points of the unconstrained space, evaluated by the same device

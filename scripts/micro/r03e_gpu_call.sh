@@ -1,0 +1,7 @@
+#!/bin/bash
+mkdir -p gpurun_out
+(timeout 900 python -m pytest tests/test_gpu_twin.py -q --tb=short -p no:cacheprovider --timeout 400 -s 2>&1 | tail -30) > gpurun_out/r03e_twin.log
+(timeout 600 python bench.py --steps 20 --warmup 0 --no-cpu-baseline --no-saturated 2>gpurun_out/r03e_bench.err | tail -1) > gpurun_out/r03e_bench.json
+cat gpurun_out/r03e_twin.log; python -c "
+import json
+d=json.loads([l for l in open('gpurun_out/r03e_bench.json') if l.startswith('{')][0]); print(d['value'], d['config']['posteriors']['2016']['twin'])"

@@ -33,6 +33,48 @@ def test_twin_follows_the_oracle_chain(cases, name, iters, cus):
     h.close()
 
 
+@pytest.mark.parametrize("max_depth", [1, 3, 6])
+def test_twin_with_short_trees(cases, max_depth):
+    """Trees cut by max_depth (every transition ends at the depth limit early in warm-up): the combine that reaches the
+    limit ends the trajectory, the side that is speculating on a later doubling drops it."""
+    data, variant = cases["small_full"]
+    iters = 25
+    kw = dict(num_warmup=30, num_samples=0, save_warmup=1, seed=5, max_depth=max_depth)
+    h = Handle(data, variant, chains=2, cus_per_chain=8, twin=1, **kw)
+    h.init(); h.run(iters)
+    d = h.draws()[:, :iters]
+    m = OracleModel(data, variant)
+    o = m.default_opts(fast_grad=1, **kw)
+    for c in (0, 1):
+        ref = m.sample_chain(c + 1, o)[0][:iters]
+        assert d[c][:, 3].max() <= max_depth
+        k = 12                                      # in step with the oracle at least this long
+        assert np.array_equal(d[c][:k, 3:6], ref[:k, 3:6]), (c, d[c][:k, :7], ref[:k, :7])
+        assert np.allclose(d[c][:k, 7:], ref[:k, 7:], rtol=1e-6, atol=1e-7)
+    h.close()
+
+
+def test_twin_on_the_stress_shape():
+    """configs[4]'s shape (51 states x 600 days x 10 000 polls, D = 41 610) under the diagonal metric: 8 chains take two
+    clusters of 16 each by default; first transitions against the oracle."""
+    from us_potus_model_amd import synthetic
+    data = synthetic.stress()
+    iters = 3
+    h = Handle(data, "full", chains=8, num_warmup=iters, num_samples=0, save_warmup=1, seed=5)
+    assert h.cus_per_chain == 16 and h.clusters_per_chain == 2 and h.D == 41610
+    h.init(); h.run(iters)
+    d = h.draws()
+    ms, lf = h.last_run_timing()
+    print(f"stress shape, 8 chains x 2 x 16 CUs: {lf} leapfrogs in {ms:.1f} ms = {lf / ms * 1e3:.0f} leapfrogs/s, {ms * 1e3 * 8 / lf:.1f} us per leapfrog per chain")
+    m = OracleModel(data, "full")
+    o = m.default_opts(num_warmup=iters, num_samples=0, save_warmup=1, seed=5, fast_grad=1)
+    for c in (0, 7):
+        ref = m.sample_chain(c + 1, o)[0]
+        assert np.array_equal(d[c][:, 3:6], ref[:, 3:6]), (c, d[c][:, :7], ref[:, :7])
+        assert np.allclose(d[c][:, 7:], ref[:, 7:], rtol=1e-6, atol=1e-7)
+    h.close()
+
+
 def test_twin_and_one_cluster_agree_while_in_step(cases):
     """accept_stat is summed per subtree in twin mode (last bits differ), so the two samplers drift apart chaotically --
     but not within the first transitions, and never in distribution (test_twin_posterior_parity)."""
@@ -45,6 +87,10 @@ def test_twin_and_one_cluster_agree_while_in_step(cases):
         h.init(); h.run(12)
         out.append(h.draws()[:, :12].copy())
         print("twin" if twin else "one cluster", "%d leapfrogs in %.1f ms" % tuple(reversed(h.last_run_timing())))
+        if twin:
+            cnt, rb, rf = h.twin_stats()
+            assert cnt == h.total_leapfrogs() and rb + rf >= cnt and max(rb, rf) < cnt      # both ends work, and at the same time
+            print(f"  counted {cnt}, run by the backward side {rb}, by the forward side {rf}")
         h.close()
     a, b = out
     assert np.array_equal(a[:, :, 3:6], b[:, :, 3:6])

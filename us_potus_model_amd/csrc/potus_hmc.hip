@@ -66,7 +66,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_init(const DevModel *Mg, const R
   if (tid == 0) {
     gsc sc = c.sc;
     sc->nom_eps = R->stepsize; sc->mu = log(10.0 * R->stepsize); sc->s_bar = 0; sc->x_bar = 0; sc->ad_counter = 0;
-    sc->wf_n = 0; sc->total_leapfrogs = 0; sc->iter = 0; sc->status = 0; sc->n_divergent = 0; sc->saved = 0;
+    sc->wf_n = 0; sc->total_leapfrogs = 0; sc->iter = 0; sc->status = 0; sc->n_divergent = 0; sc->saved = 0; sc->leaves_run = 0;
     sc->win_counter = 0; sc->win_size = R->window; sc->win_next = R->init_buffer + R->window - 1;
   }
   __syncthreads();
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_init(const DevModel *Mg, cons
   if (tid == 0) {
     gsc sc = c.sc;
     sc->nom_eps = R->stepsize; sc->mu = log(10.0 * R->stepsize); sc->s_bar = 0; sc->x_bar = 0; sc->ad_counter = 0;
-    sc->wf_n = 0; sc->total_leapfrogs = 0; sc->iter = 0; sc->status = 0; sc->n_divergent = 0; sc->saved = 0;
+    sc->wf_n = 0; sc->total_leapfrogs = 0; sc->iter = 0; sc->status = 0; sc->n_divergent = 0; sc->saved = 0; sc->leaves_run = 0;
     sc->win_counter = 0; sc->win_size = R->window; sc->win_next = R->init_buffer + R->window - 1;
   }
   __syncthreads();
@@ -354,6 +354,7 @@ __device__ __noinline__ unsigned cl_cold_twin_combine(const DevModel *Mg, const 
   ltp ts = c.ts;
   const int tid = c.tid;
   __syncthreads();
+  if (tid == 0) c.sc->leaves_run += ts->n_leap;       // whether the subtree ends up in the trajectory or not
   // 1. the state this combine starts from: published by the combine of doubling d - 1 (or the end of the trajectory)
   if (uni_i(ts->tw_seq) < d) {
     if (tid < 64) tw_catch_up(c.x, t, ts, d);
@@ -2033,6 +2034,22 @@ int potus_total_leapfrogs(int handle, long long *n) {
   long long t = 0;
   for (auto &s : sc) t += s.total_leapfrogs;
   *n = t;
+  return 0;
+}
+
+int potus_twin_stats(int handle, long long *counted, long long *run_backward, long long *run_forward) {
+  Sampler *sp = get(handle);
+  if (!sp || !counted || !run_backward || !run_forward) return fail(POTUS_ERR_STATE, "bad handle");
+  if (!sp->twin) return fail(POTUS_ERR_STATE, "potus_twin_stats: the handle runs one cluster per chain");
+  HIP_TRY(hipSetDevice(sp->device));
+  std::vector<ChainScalars> all((size_t)sp->R.chains * sp->K * 2);
+  HIP_TRY(hipMemcpy(all.data(), sp->R.scal, sizeof(ChainScalars) * all.size(), hipMemcpyDeviceToHost));
+  *counted = *run_backward = *run_forward = 0;
+  for (int c = 0; c < sp->R.chains; c++) {
+    *counted += all[(size_t)c * sp->K].total_leapfrogs;
+    *run_backward += all[(size_t)c * sp->K].leaves_run;
+    *run_forward += all[((size_t)sp->R.chains + c) * sp->K].leaves_run;
+  }
   return 0;
 }
 

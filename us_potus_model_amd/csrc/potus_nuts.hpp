@@ -59,7 +59,8 @@ enum { PF_MOMENTUM = 8, PF_INITCOPY, PF_LEAF_SCALAR, PF_MERGE, PF_COPYQ, PF_PNEA
 struct ChainScalars { // persistent per chain, global memory
   double nom_eps, mu, s_bar, x_bar, ad_counter, wf_n, lp_cur;
   long long total_leapfrogs;
-  int iter, win_counter, win_next, win_size, status, n_divergent, saved, pad;
+  int iter, win_counter, win_next, win_size, status, n_divergent, saved;
+  int leaves_run;          // twin mode: leaves this side has integrated, those of dropped (speculative) subtrees included
 };
 typedef ChainScalars AS_G *gsc;
 

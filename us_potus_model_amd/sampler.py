@@ -79,13 +79,14 @@ def load_library():
     L.potus_get_dense_metric.argtypes = [C.c_int, C.c_int, dp]
     L.potus_cus_per_chain.argtypes = [C.c_int, ip]
     L.potus_clusters_per_chain.argtypes = [C.c_int, ip]
+    L.potus_twin_stats.argtypes = [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     _LIB = L
     return L
 
 
 EXPORTS = [
     "potus_version", "potus_last_error", "potus_default_opts", "potus_num_params", "potus_num_columns",
-    "potus_column_name", "potus_create", "potus_destroy", "potus_cus_per_chain", "potus_clusters_per_chain", "potus_log_prob_grad", "potus_init", "potus_run", "potus_run_many",
+    "potus_column_name", "potus_create", "potus_destroy", "potus_cus_per_chain", "potus_clusters_per_chain", "potus_twin_stats", "potus_log_prob_grad", "potus_init", "potus_run", "potus_run_many",
     "potus_iterations_done", "potus_total_leapfrogs", "potus_chain_status", "potus_get_adaptation",
     "potus_get_dense_metric", "potus_dense_timing", "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_array_device", "potus_write_stan_csv",
     "potus_last_run_timing", "potus_posterior_summary", "potus_posterior_summary_many", "potus_backtest_scores",
@@ -225,6 +226,12 @@ class Handle:
         torch.cuda.current_stream(out_tensor.device).synchronize()      # the library writes on its own stream
         _check(self.L, self.L.potus_write_array_device(self.h, col_begin, col_end, C.c_void_p(out_tensor.data_ptr())))
         return out_tensor
+
+    def twin_stats(self):
+        """Twin mode: (leapfrogs counted in the trajectories, leaves integrated by the backward side, by the forward side)."""
+        a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        _check(self.L, self.L.potus_twin_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def dense_timing(self):
         """metric = dense_e: (milliseconds in k_dn_matvec, matrix passes, bytes of matrix streamed, leaf rounds) so far."""
