@@ -97,6 +97,29 @@ def test_twin_and_one_cluster_agree_while_in_step(cases):
     assert np.allclose(a[:, :, :3], b[:, :, :3], rtol=1e-7, atol=1e-10) and np.allclose(a[:, :, 7:], b[:, :, 7:], rtol=1e-6, atol=1e-8)
 
 
+@pytest.mark.parametrize("name", ["small_full", "small_nomode"])
+def test_twin_many_seeds_agree_with_one_cluster(cases, name):
+    """Early warm-up is where the odd cases live (divergent leaves, subtrees that fail their own U-turn check, trees of
+    every depth up to the limit): many seeds, both samplers, the same trees and -- to rounding -- the same draws."""
+    data, variant = cases[name]
+    n_div = depths = 0
+    for seed in range(1, 11):
+        kw = dict(chains=4, num_warmup=40, num_samples=0, save_warmup=1, seed=seed, cus_per_chain=8)
+        out = []
+        for twin in (0, 1):
+            h = Handle(data, variant, twin=twin, **kw)
+            h.init(); h.run(14)
+            out.append(h.draws()[:, :14].copy())
+            h.close()
+        a, b = out
+        assert np.array_equal(a[:, :, 3:6], b[:, :, 3:6]), (seed, a[:, :, 3:6], b[:, :, 3:6])
+        # (rounding differences in accept_stat reach the step size and grow over the thousands of leapfrogs of early warm-up)
+        assert np.allclose(a[:, :, :3], b[:, :, :3], rtol=1e-5, atol=1e-8) and np.allclose(a[:, :, 7:], b[:, :, 7:], rtol=1e-5, atol=1e-7)
+        n_div += int(a[:, :, 5].sum()); depths |= sum(1 << int(v) for v in np.unique(a[:, :, 3]))
+    print(f"{name}: {n_div} divergent transitions, tree depths seen: {[d for d in range(12) if depths >> d & 1]}")
+    assert n_div > 0 and bin(depths).count("1") >= 4
+
+
 def test_twin_through_a_metric_update_and_across_launch_boundaries(cases):
     """150 warm-up iterations: init buffer, the first window end (metric update + init_stepsize, run redundantly by both
     sides), and the same bytes however the iterations are split over launches."""

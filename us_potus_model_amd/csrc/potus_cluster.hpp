@@ -41,6 +41,9 @@
 #define CL_AUX_LD CL_AUX_SC1             // policy of the exchange reader's loads
 #endif
 #define CL_SPIN_LIMIT 8000000u
+#ifndef CL_SPIN_SLEEP
+#define CL_SPIN_SLEEP 1                  // s_sleep argument between two looks at an exchange word that has not arrived
+#endif
 
 // fields of one member's part descriptor (ints)
 enum { CP_D0 = 0, CP_ND, CP_P0, CP_NP, CP_E0, CP_NE, CP_R0, CP_NR, CP_NSUB, CP_NSEG, CP_WB,
@@ -180,7 +183,7 @@ __device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], c
 #ifdef POTUS_PROF
     if (xprof && (threadIdx.x & 63) == 0) xprof[58] += 1.0;
 #endif
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(CL_SPIN_SLEEP);
 #ifdef CL_LD_INV
     asm volatile(CL_LD_INV ::: "memory");
 #else
