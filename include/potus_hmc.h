@@ -116,8 +116,8 @@ typedef struct potus_opts {
                               end of the NUTS trajectory -- the doublings that go forward and those that go backward are
                               integrated at the same time (2 * chains * cus_per_chain <= CUs of the device); 0 = one
                               cluster; -1 = the library decides when it also chooses the cluster size (cus_per_chain = 0):
-                              two clusters if they fit.  Same algorithm and RNG streams; accept_stat__ differs from the
-                              one-cluster sampler in the last bits (summed per subtree), hence so do the chains. */
+                              two clusters if they fit.  Same algorithm, RNG streams and arithmetic: the draws are the
+                              same bytes as with one cluster of the same size. */
 } potus_opts;
 #define POTUS_METRIC_DIAG 0
 #define POTUS_METRIC_DENSE 1

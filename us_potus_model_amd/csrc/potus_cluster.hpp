@@ -1456,8 +1456,10 @@ __device__ __forceinline__ void cl_transition_begin(ClChain &c, uint32_t iter) {
 // transition the side that holds the new sample publishes it (QC, write-through), the other side copies it; both publish
 // DONE and wait for each other before the next transition.  Expected gain: the last doubling holds half of the leaves,
 // the earlier ones fall on either side at random: max(forward, backward) = 3/4 of the leaves on average.
-// Floating point: sum_metro is added per subtree instead of leaf by leaf across doublings (accept_stat differs in the
-// last bits from the one-cluster sampler); everything else is the same arithmetic in the same order.
+// Floating point: the metropolis terms are summed per doubling and then added to the trajectory's sum (the one-cluster
+// sampler does the same, for that reason); everything else is the same arithmetic in the same order, so the two modes
+// produce the same draws bit for bit (the U-turn dot products across the trajectory are reduced over the members in a
+// different order, but only their signs are used).
 enum { TT_STOP = 0, TT_DEPTH, TT_LSW, TT_SSIDE, TT_SSLOT, TT_SLP, TT_SH, TT_METRO, TT_NLEAP, TT_DIV, TT_RHOSIDE, TT_N = 12 };
 enum { TWB_TOP = 0 /* [2][16] */, TWB_STOP = 32, TWB_QC = 33, TWB_DONE = 34 /* [2] */, TWB_WD = 36, TWB_WORDS = 40 };
 
@@ -1585,6 +1587,9 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, co
         ts->dir = rng_uniform(c.key, iter, RNG_DIRECTION, 0, (uint32_t)depth) > 0.5 ? 1 : 0;
         ts->pmask = 0;
         ts->qmask = (1u << ts->sample_qid) | (1u << ts->nextq[0]) | (1u << ts->nextq[1]);
+        // the metropolis terms of a doubling are summed on their own and then added to the trajectory's sum -- the order twin
+        // mode has to use: with it the two modes produce the same bytes
+        ts->metro_base = ts->sum_metro; ts->sum_metro = 0.0;
       }
     }
     __syncthreads();
@@ -1690,6 +1695,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, co
       if (!TWIN) cl_vop_copy<false>(c, c.soff(V_PF0 + dir), c.soff(V_POOLP + leaf));   // the last leaf is the new end point
       CPROF_MARK(c, PF_COPYQ);
     }
+    if (!TWIN && tid == 0) ts->sum_metro += ts->metro_base;   // (the verdicts of the doubling's last leaf are behind a barrier)
     if (TWIN) {
       c.x.epoch = uni32(cl_cold_twin_combine<CL_DW>(ta.Mg, ta.CLg, ta.Rg, ta.chain, ta.m, ta.side, ta.launch, c.x.epoch, iter, depth, valid ? 1 : 0, prev_leaf));
       depth++;

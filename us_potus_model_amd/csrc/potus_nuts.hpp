@@ -111,6 +111,7 @@ struct TS { // transition state, LDS
   // combine number tw_seq; the pool slot it must keep (its latest accepted proposal, or the initial point); the directions
   // of the transition's doublings (bit j = doubling j goes forward); whether the last combine ended the trajectory
   double tt[12];
+  double metro_base;     // cluster mode: the trajectory's sum of metropolis terms before the current doubling
   int tw_seq, tw_keep, tw_dirs, tw_over, tw_ext, tw_pad;   // tw_ext: the other side's STOP word was up when this leaf started
 };
 typedef TS AS_L *ltp;
