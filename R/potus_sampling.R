@@ -18,7 +18,7 @@
 #
 # NOTE: R is not installed in the build image, so this file itself has never run; every .C() call below is
 # replayed argument for argument (int* / double* / char** only, outputs through the same buffers) by
-# tests/test_gpu_parity.py::test_r_entry_points_replay_the_shim with ctypes.
+# tests/test_gpu_boundary.py::test_r_entry_points_replay_the_shim with ctypes.
 
 potus_load <- function(path) dyn.load(path)
 
