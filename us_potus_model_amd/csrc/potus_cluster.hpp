@@ -1526,7 +1526,7 @@ __device__ __forceinline__ void tw_wait_ge(const Xch &x, const Twin &t, int w0, 
 }
 // Wave 0 brings the side's copy of the trajectory-level state to combine number `want` -- or to the final one if the
 // trajectory has ended (want < 0: wait for the end).  No barrier inside.
-__device__ __forceinline__ void tw_catch_up(const Xch &x, const Twin &t, ltp ts, int want) {
+__device__ __forceinline__ void tw_catch_up(const Xch &x, const Twin &t, ltp ts, int want, bool patient = false) {
   const int lane = threadIdx.x & 63;
   double v = 0.0;
   int seq = -1;
@@ -1535,7 +1535,7 @@ __device__ __forceinline__ void tw_catch_up(const Xch &x, const Twin &t, ltp ts,
     if (tw_try(t, TWB_STOP, 1, t.ittag, v)) { seq = (int)readlane_d(v, 0); break; }   // the trajectory is over: number of its last combine
     if (want >= 0 && tw_try(t, TWB_TOP + 16 * (want & 1), TT_N, t.ittag | (unsigned)(want + 1), v)) { seq = want; have = true; break; }
     if (spins > CL_SPIN_LIMIT || ((spins & 1023u) == 1023u && tw_dead(x, t))) tw_give_up(x, t);
-    if (want < 0) __builtin_amdgcn_s_sleep(16);      // waiting for the other side's last doubling: look at the word every microsecond only
+    if (want < 0 || patient) __builtin_amdgcn_s_sleep(32);   // waiting for the other side's doublings: a look every microsecond
     else __builtin_amdgcn_s_sleep(1);
   }
   if (!have) tw_wait(x, t, TWB_TOP + 16 * (seq & 1), TT_N, t.ittag | (unsigned)(seq + 1), v);
@@ -1572,6 +1572,24 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, co
       const int dirs = uni_i(ts->tw_dirs);
       while (depth < c.max_depth && ((dirs >> depth) & 1) != ta.side) depth++;   // the doublings of the other end are not this side's business
       if (depth >= c.max_depth) break;
+      // Speculation is free while the compute units would idle, but it is not useful beyond the depth trajectories reach: a
+      // doubling that none of the last four transitions needed is started only once the trajectory has got there (in the
+      // sampling phase of the 2016 posterior every tree has 8 doublings: the idle side then waits for the end instead of
+      // integrating a ninth subtree that is always dropped, and leaves L2, HBM and power to the busy side).
+      const unsigned sl = (unsigned)uni_i(c.sc->spec_limit);
+      const int spec_limit = (int)max(max(sl & 0xffu, (sl >> 8) & 0xffu), max((sl >> 16) & 0xffu, sl >> 24));
+      if (depth >= spec_limit && uni_i(ts->tw_seq) < depth) {
+        if (tid < 64) {
+          CRp R = (CRp)uni_ptr(ta.Rg);
+          const Twin t = make_twin(R, ta.chain, ta.side, c.x.launch, iter);
+          tw_catch_up(c.x, t, ts, depth, true);
+        }
+        __syncthreads();
+        if (uni_i((int)ts->tt[TT_STOP])) {
+          if (tid == 0) ts->tw_over = 1;
+          continue;                                   // the loop head leaves
+        }
+      }
     } else {
       if (uni_i(ts->depth) >= c.max_depth || uni_i(ts->stop) || uni_i(cl_dead)) break;
       depth = uni_i(ts->depth);

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_init(const DevModel *Mg, const R
   if (tid == 0) {
     gsc sc = c.sc;
     sc->nom_eps = R->stepsize; sc->mu = log(10.0 * R->stepsize); sc->s_bar = 0; sc->x_bar = 0; sc->ad_counter = 0;
-    sc->wf_n = 0; sc->total_leapfrogs = 0; sc->iter = 0; sc->status = 0; sc->n_divergent = 0; sc->saved = 0; sc->leaves_run = 0;
+    sc->wf_n = 0; sc->total_leapfrogs = 0; sc->iter = 0; sc->status = 0; sc->n_divergent = 0; sc->saved = 0; sc->leaves_run = 0; sc->spec_limit = 0x7f7f7f7f;
     sc->win_counter = 0; sc->win_size = R->window; sc->win_next = R->init_buffer + R->window - 1;
   }
   __syncthreads();
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_init(const DevModel *Mg, cons
   if (tid == 0) {
     gsc sc = c.sc;
     sc->nom_eps = R->stepsize; sc->mu = log(10.0 * R->stepsize); sc->s_bar = 0; sc->x_bar = 0; sc->ad_counter = 0;
-    sc->wf_n = 0; sc->total_leapfrogs = 0; sc->iter = 0; sc->status = 0; sc->n_divergent = 0; sc->saved = 0; sc->leaves_run = 0;
+    sc->wf_n = 0; sc->total_leapfrogs = 0; sc->iter = 0; sc->status = 0; sc->n_divergent = 0; sc->saved = 0; sc->leaves_run = 0; sc->spec_limit = 0x7f7f7f7f;
     sc->win_counter = 0; sc->win_size = R->window; sc->win_next = R->init_buffer + R->window - 1;
   }
   __syncthreads();
@@ -471,6 +471,7 @@ __device__ __noinline__ unsigned cl_cold_twin_end(const DevModel *Mg, const ClMo
     ts->out_lp = ts->tt[TT_SLP]; ts->out_h = ts->tt[TT_SH];
     c.sc->total_leapfrogs += ts->n_leap;
     c.sc->n_divergent += ts->divergent;
+    c.sc->spec_limit = (int)(((unsigned)c.sc->spec_limit << 8) | (unsigned)ts->tw_seq);   // doublings of the last four transitions, a byte each
   }
   __syncthreads();
   const bool warm = it < R->num_warmup;

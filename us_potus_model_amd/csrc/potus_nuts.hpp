@@ -61,6 +61,8 @@ struct ChainScalars { // persistent per chain, global memory
   long long total_leapfrogs;
   int iter, win_counter, win_next, win_size, status, n_divergent, saved;
   int leaves_run;          // twin mode: leaves this side has integrated, those of dropped (speculative) subtrees included
+  int spec_limit, pad;     // twin mode: doublings (combines taken) of the last four transitions, a byte each: a doubling beyond their
+                           // maximum is not started ahead of its turn
 };
 typedef ChainScalars AS_G *gsc;
 
