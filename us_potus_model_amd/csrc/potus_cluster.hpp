@@ -1444,7 +1444,8 @@ __device__ __forceinline__ void cl_transition_begin(ClChain &c, uint32_t iter) {
 // transition (counter-based RNG), so a side simply builds, one after the other, the subtrees of the doublings that go its
 // way (build_tree with its internal U-turn checks and multinomial sampling is local to one end), without waiting for the
 // doublings of the other side in between: that is speculation -- if the trajectory ends at an earlier doubling the work is
-// dropped -- on compute units that would idle otherwise.  What is NOT local is the bookkeeping of transition() itself: the
+// dropped -- on compute units that would idle otherwise (bounded: a doubling beyond what the last four transitions needed is
+// not started ahead of its turn).  What is NOT local is the bookkeeping of transition() itself: the
 // accept step of the new subtree's proposal, the sum of momenta over the whole trajectory and the U-turn checks across
 // it.  These "combines" are taken strictly in the order of the doublings by the side that built the subtree:
 //   wait until the combine of the previous doubling is published (a side that finishes doubling d has always been busy
