@@ -146,6 +146,25 @@ def test_twin_through_a_metric_update_and_across_launch_boundaries(cases):
         assert np.allclose(minv[0], ad[1:], rtol=1e-4) and np.array_equal(d[100:110, 3:6], ref[100:110, 3:6])
 
 
+@pytest.mark.parametrize("chains,k", [(9, 14), (10, 12), (11, 11)])
+def test_nine_to_eleven_chains_take_two_smaller_clusters(cases, chains, k):
+    """The library's choice for 9-11 chains: two clusters of 14 / 12 / 11 workgroups per chain instead of one of 16; first
+    transitions of the first and the last chain against the oracle."""
+    data, variant = cases["2016"]
+    iters = 3
+    h = Handle(data, variant, chains=chains, num_warmup=30, num_samples=0, save_warmup=1, seed=1843)
+    assert h.cus_per_chain == k and h.clusters_per_chain == 2
+    h.init(); h.run(iters)
+    d = h.draws()[:, :iters]
+    m = OracleModel(data, variant)
+    o = m.default_opts(num_warmup=30, num_samples=0, save_warmup=1, seed=1843, fast_grad=1)
+    for c in (0, chains - 1):
+        ref = m.sample_chain(c + 1, o)[0][:iters]
+        assert np.array_equal(d[c][:, 3:6], ref[:, 3:6]), (c, d[c][:, :7], ref[:, :7])
+        assert np.allclose(d[c][:, 7:], ref[:, 7:], rtol=1e-6, atol=1e-7)
+    h.close()
+
+
 def test_twin_is_the_default_when_it_fits_and_only_then(cases):
     data, variant = cases["small_full"]
     h = Handle(data, variant, chains=8, num_warmup=10, num_samples=0)

@@ -1704,6 +1704,12 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
     if (K == 0) {
       K = o->chains * 16 <= ncu ? 16 : o->chains * 8 <= ncu ? 8 : o->chains * 4 <= ncu ? 4 : 1;
       if (K == 4 && d->T > 4 * CL_MAXDAYS) K = 1;      // four members hold up to 256 days
+      // 9-11 chains: two clusters of 14, 12 or 11 per chain (17-18 us per leapfrog on the 2016 posterior) beat one cluster of
+      // 16 (21 us) -- as long as the members keep at most 3 days per wave, where the lighter build of the pass applies
+      if (K == 16 && o->twin != 0 && o->metric != POTUS_METRIC_DENSE && o->chains * 32 > ncu) {
+        const int k2 = ncu / (2 * o->chains);
+        if (k2 >= 11 && (d->T + k2 - 1) / k2 <= 3 * PT_NW) K = k2;
+      }
       // models beyond the one-workgroup kernels (T > 256, > 2048 polls) need a cluster; long campaigns need more members
       if (K == 1 && !sp->k1_unsupported.empty()) K = 8;
       while (K > 1 && d->T > K * CL_MAXDAYS && 2 * K <= CL_MAXK) K *= 2;
