@@ -333,7 +333,7 @@ def main():
                          "leapfrogs_in_launches": int(sum(lf_local)), "launch_ms_total": kernel_ms,
                          **({"matrix_passes": dense_t[1], "matrix_pass_ms_total": dense_t[0], "matrix_bytes_streamed": dense_t[2],
                              "avg_pass_ms": dense_t[0] / max(dense_t[1], 1), "leaf_rounds": dense_t[3]} if dense else {}),
-                         "note": (f"latency-bound at {C_tot} chains ({C_tot * K} of 256 CUs busy): the state of a chain stays in L2, a leapfrog "
+                         "note": (f"latency-bound at {C_tot} chains ({C_tot * K * sides} of 256 CUs busy): the state of a chain stays in L2, a leapfrog "
                                   "is a chain of dependent phases and exchanges between the CUs of a cluster; see DESIGN.md") if not dense else
                                  "dense metric: every leapfrog streams the upper triangle of the chain's D x D inverse metric (4 D^2 bytes; the "
                                  "survey's 8 D^2 assumed the full matrix); achieved = bytes loaded by the matrix passes / their time"},
