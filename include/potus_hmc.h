@@ -107,8 +107,8 @@ typedef struct potus_opts {
   int32_t cus_per_chain;   /* compute units (workgroups) cooperating on one chain: 1 = one workgroup per
                               chain (best throughput with >= 64 chains), 2..32 = a cluster per chain
                               (lowest latency with few chains; chains * cus_per_chain <= CUs of the device),
-                              0 = choose from {16, 8, 4, 1} by what fits (11-14 for
-                              9-11 chains, as two clusters each: see twin).  Draws are reproducible bit for bit
+                              0 = choose from {16, 8, 4, 1} by what fits (10-14 for
+                              9-12 chains, as two clusters each: see twin).  Draws are reproducible bit for bit
                               for a given value; different values differ in floating-point summation order. */
   int32_t metric;          /* POTUS_METRIC_DIAG (CmdStan's default, what final_2016.R:533-541 runs) or
                               POTUS_METRIC_DENSE (metric = "dense_e": stan::mcmc::dense_e_metric + covar_adaptation,

@@ -146,9 +146,9 @@ def test_twin_through_a_metric_update_and_across_launch_boundaries(cases):
         assert np.allclose(minv[0], ad[1:], rtol=1e-4) and np.array_equal(d[100:110, 3:6], ref[100:110, 3:6])
 
 
-@pytest.mark.parametrize("chains,k", [(9, 14), (10, 12), (11, 11)])
-def test_nine_to_eleven_chains_take_two_smaller_clusters(cases, chains, k):
-    """The library's choice for 9-11 chains: two clusters of 14 / 12 / 11 workgroups per chain instead of one of 16; first
+@pytest.mark.parametrize("chains,k", [(9, 14), (10, 12), (11, 11), (12, 10)])
+def test_nine_to_twelve_chains_take_two_smaller_clusters(cases, chains, k):
+    """The library's choice for 9-12 chains: two clusters of 14 / 12 / 11 / 10 workgroups per chain instead of one of 16; first
     transitions of the first and the last chain against the oracle."""
     data, variant = cases["2016"]
     iters = 3

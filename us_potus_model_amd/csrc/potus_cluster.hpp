@@ -36,6 +36,7 @@
 #define CL_LPP 4                         // lanes cooperating on one poll's 51-term dot
 #define CL_PPR (PT_THREADS / CL_LPP)     // polls per round of the poll phase
 #define CL_MAXK 32
+#define CL_DW4_MAXAVG 26                 // days per member on average up to which the 4-days-per-wave build of the pass is used
 #define CL_AUX_SC1 16                    // cache-policy bit of the buffer intrinsics: sc1 (agent scope)
 #ifndef CL_AUX_LD
 #define CL_AUX_LD CL_AUX_SC1             // policy of the exchange reader's loads

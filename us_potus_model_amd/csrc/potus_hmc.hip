@@ -1049,7 +1049,9 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   C.NR = 2 * S + P + (full ? M.M + M.Pop + 2 : 0);
   C.NREP = 2 * S + M.nmid;
   // days per wave: 4 (at most 32 days per member) when that leaves room to balance the members by polls, else 8
-  const int DW = (T + K - 1) / K <= 3 * PT_NW ? 4 : 8;
+  // (up to 26 days per member on average: measured with 12 chains on two clusters of 10, profiles/r02_cl_cluster_sizes.txt)
+  const int dw4_max = getenv("POTUS_CL_DW4_MAXAVG") ? atoi(getenv("POTUS_CL_DW4_MAXAVG")) : CL_DW4_MAXAVG;   // development: sweeps
+  const int DW = (T + K - 1) / K <= dw4_max ? 4 : 8;
   const int maxdays = PT_NW * DW;
   sp->cl_dw = DW;
   C.XW = (std::max(XP_P + C.NR, XQ0 + C.NREP) + 7) & ~7;
@@ -1704,11 +1706,11 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
     if (K == 0) {
       K = o->chains * 16 <= ncu ? 16 : o->chains * 8 <= ncu ? 8 : o->chains * 4 <= ncu ? 4 : 1;
       if (K == 4 && d->T > 4 * CL_MAXDAYS) K = 1;      // four members hold up to 256 days
-      // 9-11 chains: two clusters of 14, 12 or 11 per chain (17-18 us per leapfrog on the 2016 posterior) beat one cluster of
-      // 16 (21 us) -- as long as the members keep at most 3 days per wave, where the lighter build of the pass applies
+      // 9-12 chains: two clusters of 14, 12, 11 or 10 per chain (17-20 us per leapfrog on the 2016 posterior) beat one cluster
+      // of 16 (21 us) -- as long as the members keep few enough days for the lighter build of the pass (4 days per wave)
       if (K == 16 && o->twin != 0 && o->metric != POTUS_METRIC_DENSE && o->chains * 32 > ncu) {
         const int k2 = ncu / (2 * o->chains);
-        if (k2 >= 11 && (d->T + k2 - 1) / k2 <= 3 * PT_NW) K = k2;
+        if (k2 >= 10 && (d->T + k2 - 1) / k2 <= CL_DW4_MAXAVG) K = k2;
       }
       // models beyond the one-workgroup kernels (T > 256, > 2048 polls) need a cluster; long campaigns need more members
       if (K == 1 && !sp->k1_unsupported.empty()) K = 8;
