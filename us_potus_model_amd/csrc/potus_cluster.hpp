@@ -1470,6 +1470,7 @@ struct Twin {
   rsrc_t ost;              // the other side's state block
   unsigned launch, ittag;  // tags: dword 2 = (iteration + 1) << 6 | (combine number + 1, or 0), dword 3 = launch id
   int side;
+  const double *tbase;     // the mailbox again, as a pointer (for the cold give-up path)
 };
 struct ClTwinArgs {        // what the cold functions of twin mode rebuild their context from
   const DevModel *Mg;
@@ -1480,9 +1481,11 @@ struct ClTwinArgs {        // what the cold functions of twin mode rebuild their
 };
 __device__ __forceinline__ Twin make_twin(CRp R, int chain, int side, unsigned launch, uint32_t iter) {
   Twin t;
-  t.tb = make_rsrc(R->twbuf + (size_t)chain * TWB_WORDS * 2, TWB_WORDS * 16u);
-  t.ost = make_rsrc(R->state + (size_t)(chain + (1 - side) * R->chains) * V_COUNT * R->Dpad, (unsigned)V_COUNT * (unsigned)R->Dpad * 8u);
-  t.launch = launch; t.ittag = (iter + 1u) << 6; t.side = side;
+  // (everything made wave-uniform explicitly: a descriptor the compiler cannot prove uniform wraps every access in a waterfall loop)
+  t.tbase = uni_ptr(R->twbuf + (size_t)chain * TWB_WORDS * 2);
+  t.tb = make_rsrc(t.tbase, TWB_WORDS * 16u);
+  t.ost = make_rsrc(uni_ptr(R->state + (size_t)(chain + (1 - side) * R->chains) * V_COUNT * R->Dpad), uni32((unsigned)V_COUNT * (unsigned)R->Dpad * 8u));
+  t.launch = uni32(launch); t.ittag = uni32((iter + 1u) << 6); t.side = (int)uni32((unsigned)side);
   return t;
 }
 // one tagged word (lanes with voff == PT_OOB store nothing)
@@ -1508,7 +1511,10 @@ __device__ __forceinline__ bool tw_try_ge(const Twin &t, int w0, unsigned tag) {
   return __all(w[2] >= tag && w[3] == t.launch);
 }
 __device__ __forceinline__ void tw_give_up(const Xch &x, const Twin &t) {
-  __builtin_amdgcn_raw_buffer_store_b32(1u, t.tb, 0u, 16u * TWB_WD, CL_AUX_SC1);
+  // (the descriptor rebuilt from a pointer made uniform here: where the caller's copy has ended up in vector registers the
+  // store would otherwise sit in a waterfall loop)
+  const rsrc_t tb = make_rsrc(uni_ptr(t.tbase), TWB_WORDS * 16u);
+  __builtin_amdgcn_raw_buffer_store_b32(1u, tb, 0u, 16u * TWB_WD, CL_AUX_SC1);
   xch_give_up(x);
 }
 __device__ __forceinline__ bool tw_dead(const Xch &x, const Twin &t) {
