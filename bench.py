@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2, help="untimed chunks on a throw-away sampler")
     ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs[] index: 1 (default), 2, 3, 4")
     ap.add_argument("--chains-per-gpu", type=int, default=0, help="per posterior (0 = the configuration's: 8, 8, 4, 4)")
-    ap.add_argument("--cus-per-chain", type=int, default=0, help="workgroups per chain (0 = auto: 16, 8 or 1 by what fits)")
+    ap.add_argument("--cus-per-chain", type=int, default=0, help="workgroups per chain (0 = the library's choice: 16, 10-14, 8, 4 or 1 by what fits)")
     ap.add_argument("--twin", type=int, default=-1, help="two clusters per chain, one per end of the trajectory: 1, 0, or -1 = the library's choice")
     ap.add_argument("--twin-posteriors", default="2016", help="--config 3: the posteriors (comma-separated years) that get two clusters per chain")
     ap.add_argument("--chunk", type=int, default=0, help="transitions per step (0 = the configuration's: 100; 1 for --config 4)")
