@@ -155,3 +155,32 @@ def test_all_gather_world_size_2_gloo(tmp_path):
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+def test_bench_bookkeeping_on_the_committed_profiles():
+    """bench.py's roofline bookkeeping without a GPU: the algorithmic bytes of the 2016 posterior (SURVEY section 8d:
+    844 784 B per leapfrog), the committed counter passes it quotes for each mode of the cluster kernel, and the bench
+    line committed for the round (one JSON line with the contract's keys, roofline and cpu_baseline)."""
+    import importlib.util
+    import json
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from us_potus_model_amd import dataprep
+    data = dataprep.load_npz(ROOT / "tests" / "golden" / "data_2016.npz")["data"]
+    assert bench.algorithmic_bytes_per_leapfrog(data, "full", False) == 844784
+    D = 15098
+    assert bench.algorithmic_bytes_per_leapfrog(data, "full", True) == 844784 + 4 * D * D
+    one, two = bench.measured_traffic("k_cl_run", 1), bench.measured_traffic("k_cl_run", 2)
+    assert one and two and one[0] != two[0] and "two clusters" in two[1]["command"] and "two clusters" not in one[1]["command"]
+    assert 0.5 < one[1]["hbm_bytes_per_leapfrog"] / 844784 < 0.8 and 0.9 < two[1]["hbm_bytes_per_leapfrog"] / 844784 < 1.3
+    line = json.loads([ln for ln in (ROOT / "profiles" / "r02_bench_line.json").read_text().splitlines() if ln.startswith("{")][0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["metric"] == "leapfrog_steps_per_sec" and line["steps"] == 20 and line["config"]["iter_warmup"] == 1000 and line["config"]["iter_sampling"] == 1000
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["peak"] == 8000.0
+    assert abs(line["value"] - line["leapfrogs"] / line["seconds"]) < 1e-6 * line["value"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1 and line["rhat_max"] < 1.01
