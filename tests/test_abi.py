@@ -14,8 +14,8 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def _has_gpu():
-    import torch
-    return torch.cuda.is_available()
+    from conftest import _has_gpu as has
+    return has()
 
 
 def test_library_exports_every_declared_symbol():

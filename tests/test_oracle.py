@@ -4,7 +4,6 @@ import ctypes as C
 import numpy as np
 import pytest
 
-import stan_transcription as st
 from conftest import GOLD
 from oracle_lib import OracleModel, lib
 from us_potus_model_amd import _abi
@@ -54,6 +53,7 @@ def test_oracle_matches_golden_and_autograd(cases, name):
     # independent torch transcription (autograd) on a fresh point
     q = np.random.default_rng(99).uniform(-1.5, 1.5, m.D)
     lp, grad = m.log_prob_grad(q)
+    import stan_transcription as st      # (torch: imported only by the tests that differentiate the transcription)
     lpt, gt, aux = st.log_prob_grad(data, q, variant)
     assert abs(lp - lpt) <= 1e-12 * abs(lpt)
     assert np.abs(grad - gt).max() <= 1e-12 * np.abs(gt).max()
@@ -83,6 +83,7 @@ def test_oracle_matches_autograd_at_the_stress_shape():
     q = np.random.default_rng(7).uniform(-1.5, 1.5, m.D)
     lp, grad = m.log_prob_grad(q)
     lpf, gradf = m.log_prob_grad(q, fast=True)
+    import stan_transcription as st
     lpt, gt, _ = st.log_prob_grad(data, q, "full")
     assert abs(lp - lpt) <= 1e-12 * abs(lpt) and abs(lpf - lpt) <= 1e-12 * abs(lpt)
     scale = np.abs(gt).max()
