@@ -604,6 +604,8 @@ static void update_potential_gradient(sampler *sp, pspoint *z) {
 static void dtau_dp(const sampler *sp, const double *p, double *out) {
   const int D = sp->D;
   if (!sp->dense) { for (int i = 0; i < D; i++) out[i] = sp->minv[i] * p[i]; return; }
+  /* (rows are independent and each is summed in index order: the threads change nothing in the result) */
+#pragma omp parallel for schedule(static) if (D >= 2048)
   for (int i = 0; i < D; i++) {
     const double *row = sp->Minv + (size_t)i * D;
     double s = 0.0; for (int j = 0; j < D; j++) s += row[j] * p[j];
@@ -780,6 +782,182 @@ static double nuts_transition(sampler *sp) {
   return accept_stat;
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* The same transition with pooled buffers and fused loops (oracle_opts.pooled, diagonal   */
+/* metric): what bench.py's cpu_baseline times.  build_tree above allocates nine vectors    */
+/* and copies three per tree node and walks every vector once per operation, as upstream    */
+/* does; here every level of the recursion owns its vectors for the whole run and the       */
+/* elementwise operations of a leaf / of a merge share one loop each.  Every sum runs over  */
+/* the same terms in the same order, so the draws are the same bits                         */
+/* (tests/test_oracle.py::test_pooled_tree_gives_the_same_draws).                           */
+/* ------------------------------------------------------------------------------------ */
+typedef struct { double *p_init_end, *ps_init_end, *rho_init, *p_final_beg, *ps_final_beg, *rho_final, *q_final; } tree_ws;
+typedef struct {
+  tree_ws lev[16];
+  double *q_fwd, *p_fwd, *g_fwd, *q_bck, *p_bck, *g_bck, *q_sample, *q_propose;
+  double *p_fwd_fwd, *ps_fwd_fwd, *p_fwd_bck, *ps_fwd_bck, *p_bck_fwd, *ps_bck_fwd, *p_bck_bck, *ps_bck_bck, *rho, *rho_fwd, *rho_bck;
+  double V_fwd, V_bck;
+  int ready;
+} tree_pool;
+static tree_pool *pool_make(int D, int max_depth) {
+  tree_pool *tp = (tree_pool *)xmalloc(sizeof(tree_pool));
+  for (int d = 0; d <= max_depth && d < 16; d++) {
+    tree_ws *w = &tp->lev[d];
+    w->p_init_end = vec(D); w->ps_init_end = vec(D); w->rho_init = vec(D); w->p_final_beg = vec(D); w->ps_final_beg = vec(D);
+    w->rho_final = vec(D); w->q_final = vec(D);
+  }
+  double **all[] = {&tp->q_fwd, &tp->p_fwd, &tp->g_fwd, &tp->q_bck, &tp->p_bck, &tp->g_bck, &tp->q_sample, &tp->q_propose, &tp->p_fwd_fwd, &tp->ps_fwd_fwd,
+                    &tp->p_fwd_bck, &tp->ps_fwd_bck, &tp->p_bck_fwd, &tp->ps_bck_fwd, &tp->p_bck_bck, &tp->ps_bck_bck, &tp->rho, &tp->rho_fwd, &tp->rho_bck};
+  for (size_t k = 0; k < sizeof(all) / sizeof(all[0]); k++) *all[k] = vec(D);
+  tp->ready = 1;
+  return tp;
+}
+static void pool_free_all(tree_pool *tp, int max_depth) {
+  if (!tp) return;
+  for (int d = 0; d <= max_depth && d < 16; d++) {
+    tree_ws *w = &tp->lev[d];
+    free(w->p_init_end); free(w->ps_init_end); free(w->rho_init); free(w->p_final_beg); free(w->ps_final_beg); free(w->rho_final); free(w->q_final);
+  }
+  double *all[] = {tp->q_fwd, tp->p_fwd, tp->g_fwd, tp->q_bck, tp->p_bck, tp->g_bck, tp->q_sample, tp->q_propose, tp->p_fwd_fwd, tp->ps_fwd_fwd,
+                   tp->p_fwd_bck, tp->ps_fwd_bck, tp->p_bck_fwd, tp->ps_bck_fwd, tp->p_bck_bck, tp->ps_bck_bck, tp->rho, tp->rho_fwd, tp->rho_bck};
+  for (size_t k = 0; k < sizeof(all) / sizeof(all[0]); k++) free(all[k]);
+  free(tp);
+}
+/* a proposal is a position and its potential: the momentum and gradient of the sample are drawn / evaluated afresh by the
+   next transition (hamiltonian.sample, hamiltonian.init), so upstream's copies of them are never read */
+static int build_tree_pooled(sampler *sp, tree_pool *tp, int depth, int node, double *q_propose, double *VH_propose /* potential, Hamiltonian */, double *psharp_beg,
+                             double *psharp_end, double *rho, double *p_beg, double *p_end, double H0, double sign, int *n_leapfrog,
+                             double *log_sum_weight, double *sum_metro_prob) {
+  const int D = sp->D;
+  if (depth == 0) {
+    const double eps = sign * sp->eps, *minv = sp->minv;
+    double *q = sp->z.q, *p = sp->z.p, *g = sp->z.g;
+    for (int i = 0; i < D; i++) { p[i] -= 0.5 * eps * g[i]; q[i] += eps * minv[i] * p[i]; }   /* begin_update_p, update_q */
+    update_potential_gradient(sp, &sp->z);
+    double kin = 0.0;
+    for (int i = 0; i < D; i++) {                                                              /* end_update_p and the leaf's bookkeeping */
+      p[i] -= 0.5 * eps * g[i];
+      const double pi = p[i], ps = minv[i] * pi;
+      kin += minv[i] * pi * pi;
+      psharp_beg[i] = ps; psharp_end[i] = ps; rho[i] += pi; p_beg[i] = pi; p_end[i] = pi; q_propose[i] = q[i];
+    }
+    ++*n_leapfrog;
+    double h = 0.5 * kin + sp->z.V;
+    if (isnan(h)) h = INFINITY;
+    if ((h - H0) > 1000.0) sp->divergent = 1;
+    *log_sum_weight = log_sum_exp(*log_sum_weight, H0 - h);
+    if (H0 - h > 0) *sum_metro_prob += 1; else *sum_metro_prob += exp(H0 - h);
+    VH_propose[0] = sp->z.V; VH_propose[1] = 0.5 * kin + sp->z.V;
+    return !sp->divergent;
+  }
+  tree_ws *w = &tp->lev[depth];
+  double lsw_init = -INFINITY;
+  memset(w->rho_init, 0, sizeof(double) * (size_t)D);
+  int ok = build_tree_pooled(sp, tp, depth - 1, 2 * node, q_propose, VH_propose, psharp_beg, w->ps_init_end, w->rho_init, p_beg, w->p_init_end, H0,
+                             sign, n_leapfrog, &lsw_init, sum_metro_prob);
+  if (!ok) return 0;
+  double lsw_final = -INFINITY, VH_final[2] = {sp->z.V, 0.0};
+  memset(w->rho_final, 0, sizeof(double) * (size_t)D);
+  ok = build_tree_pooled(sp, tp, depth - 1, 2 * node + 1, w->q_final, VH_final, w->ps_final_beg, psharp_end, w->rho_final, w->p_final_beg, p_end,
+                         H0, sign, n_leapfrog, &lsw_final, sum_metro_prob);
+  if (!ok) return 0;
+  double lsw_subtree = log_sum_exp(lsw_init, lsw_final);
+  *log_sum_weight = log_sum_exp(*log_sum_weight, lsw_subtree);
+  int take = 0;
+  if (lsw_final > lsw_subtree) take = 1;
+  else {
+    double accept = exp(lsw_final - lsw_subtree);
+    uint32_t slot = ((uint32_t)sp->top_depth << 24) | ((uint32_t)depth << 16) | (uint32_t)node;
+    double u = oracle_rng_uniform(sp->o->seed, (uint32_t)sp->chain, sp->iter, RNG_SUB_ACCEPT, 0, slot);
+    if (u < accept) take = 1;
+  }
+  if (take) { memcpy(q_propose, w->q_final, sizeof(double) * (size_t)D); VH_propose[0] = VH_final[0]; VH_propose[1] = VH_final[1]; }
+  /* the three compute_criterion calls in one loop: a_k = p#_end-like . rho_k, b_k = p#_beg-like . rho_k */
+  double a0 = 0, b0 = 0, a1 = 0, b1 = 0, a2 = 0, b2 = 0;
+  const double *ri = w->rho_init, *rf = w->rho_final, *pfb = w->p_final_beg, *pie = w->p_init_end, *sfb = w->ps_final_beg, *sie = w->ps_init_end;
+  for (int i = 0; i < D; i++) {
+    const double rs = ri[i] + rf[i];
+    rho[i] += rs;
+    a0 += psharp_end[i] * rs; b0 += psharp_beg[i] * rs;
+    const double e1 = ri[i] + pfb[i];
+    a1 += sfb[i] * e1; b1 += psharp_beg[i] * e1;
+    const double e2 = rf[i] + pie[i];
+    a2 += psharp_end[i] * e2; b2 += sie[i] * e2;
+  }
+  return (a0 > 0 && b0 > 0) & (a1 > 0 && b1 > 0) & (a2 > 0 && b2 > 0);
+}
+static double nuts_transition_pooled(sampler *sp, tree_pool *tp) {
+  const int D = sp->D;
+  const size_t nb = sizeof(double) * (size_t)D;
+  sp->eps = sp->nom_eps;
+  sample_p(sp, &sp->z, RNG_MOMENTUM, 0);
+  update_potential_gradient(sp, &sp->z);
+  memcpy(tp->q_fwd, sp->z.q, nb); memcpy(tp->p_fwd, sp->z.p, nb); memcpy(tp->g_fwd, sp->z.g, nb); tp->V_fwd = sp->z.V;
+  memcpy(tp->q_bck, sp->z.q, nb); memcpy(tp->p_bck, sp->z.p, nb); memcpy(tp->g_bck, sp->z.g, nb); tp->V_bck = sp->z.V;
+  memcpy(tp->q_sample, sp->z.q, nb);
+  memcpy(tp->q_propose, sp->z.q, nb);
+  double kin0 = 0.0;
+  for (int i = 0; i < D; i++) {
+    const double pi = sp->z.p[i], ps = sp->minv[i] * pi;
+    kin0 += sp->minv[i] * pi * pi;
+    tp->p_fwd_fwd[i] = pi; tp->p_fwd_bck[i] = pi; tp->p_bck_fwd[i] = pi; tp->p_bck_bck[i] = pi; tp->rho[i] = pi;
+    tp->ps_fwd_fwd[i] = ps; tp->ps_fwd_bck[i] = ps; tp->ps_bck_fwd[i] = ps; tp->ps_bck_bck[i] = ps;
+  }
+  double log_sum_weight = 0.0, H0 = 0.5 * kin0 + sp->z.V;
+  double VH_sample[2] = {sp->z.V, H0}, VH_propose[2] = {sp->z.V, H0};
+  int n_leapfrog = 0; double sum_metro_prob = 0.0;
+  sp->depth = 0; sp->divergent = 0;
+  while (sp->depth < sp->o->max_depth) {
+    int valid; double lsw_subtree = -INFINITY;
+    sp->top_depth = sp->depth;
+    double udir = oracle_rng_uniform(sp->o->seed, (uint32_t)sp->chain, sp->iter, RNG_DIRECTION, 0, (uint32_t)sp->depth);
+    if (udir > 0.5) {
+      memcpy(sp->z.q, tp->q_fwd, nb); memcpy(sp->z.p, tp->p_fwd, nb); memcpy(sp->z.g, tp->g_fwd, nb); sp->z.V = tp->V_fwd;
+      memcpy(tp->rho_bck, tp->rho, nb); memset(tp->rho_fwd, 0, nb);
+      memcpy(tp->p_bck_fwd, tp->p_fwd_fwd, nb); memcpy(tp->ps_bck_fwd, tp->ps_fwd_fwd, nb);
+      valid = build_tree_pooled(sp, tp, sp->depth, 0, tp->q_propose, VH_propose, tp->ps_fwd_bck, tp->ps_fwd_fwd, tp->rho_fwd, tp->p_fwd_bck, tp->p_fwd_fwd,
+                                H0, 1.0, &n_leapfrog, &lsw_subtree, &sum_metro_prob);
+      memcpy(tp->q_fwd, sp->z.q, nb); memcpy(tp->p_fwd, sp->z.p, nb); memcpy(tp->g_fwd, sp->z.g, nb); tp->V_fwd = sp->z.V;
+    } else {
+      memcpy(sp->z.q, tp->q_bck, nb); memcpy(sp->z.p, tp->p_bck, nb); memcpy(sp->z.g, tp->g_bck, nb); sp->z.V = tp->V_bck;
+      memcpy(tp->rho_fwd, tp->rho, nb); memset(tp->rho_bck, 0, nb);
+      memcpy(tp->p_fwd_bck, tp->p_bck_bck, nb); memcpy(tp->ps_fwd_bck, tp->ps_bck_bck, nb);
+      valid = build_tree_pooled(sp, tp, sp->depth, 0, tp->q_propose, VH_propose, tp->ps_bck_fwd, tp->ps_bck_bck, tp->rho_bck, tp->p_bck_fwd, tp->p_bck_bck,
+                                H0, -1.0, &n_leapfrog, &lsw_subtree, &sum_metro_prob);
+      memcpy(tp->q_bck, sp->z.q, nb); memcpy(tp->p_bck, sp->z.p, nb); memcpy(tp->g_bck, sp->z.g, nb); tp->V_bck = sp->z.V;
+    }
+    if (!valid) break;
+    ++sp->depth;
+    int take = 0;
+    if (lsw_subtree > log_sum_weight) take = 1;
+    else {
+      double accept = exp(lsw_subtree - log_sum_weight);
+      double u = oracle_rng_uniform(sp->o->seed, (uint32_t)sp->chain, sp->iter, RNG_TOP_ACCEPT, 0, (uint32_t)(sp->depth - 1));
+      if (u < accept) take = 1;
+    }
+    if (take) { memcpy(tp->q_sample, tp->q_propose, nb); VH_sample[0] = VH_propose[0]; VH_sample[1] = VH_propose[1]; }
+    log_sum_weight = log_sum_exp(log_sum_weight, lsw_subtree);
+    double a0 = 0, b0 = 0, a1 = 0, b1 = 0, a2 = 0, b2 = 0;
+    for (int i = 0; i < D; i++) {
+      const double r = tp->rho_bck[i] + tp->rho_fwd[i];
+      tp->rho[i] = r;
+      a0 += tp->ps_fwd_fwd[i] * r; b0 += tp->ps_bck_bck[i] * r;
+      const double e1 = tp->rho_bck[i] + tp->p_fwd_bck[i];
+      a1 += tp->ps_fwd_bck[i] * e1; b1 += tp->ps_bck_bck[i] * e1;
+      const double e2 = tp->rho_fwd[i] + tp->p_bck_fwd[i];
+      a2 += tp->ps_fwd_fwd[i] * e2; b2 += tp->ps_bck_fwd[i] * e2;
+    }
+    if (!((a0 > 0 && b0 > 0) && (a1 > 0 && b1 > 0) && (a2 > 0 && b2 > 0))) break;
+  }
+  sp->n_leapfrog = n_leapfrog;
+  sp->total_leapfrogs += n_leapfrog;
+  double accept_stat = sum_metro_prob / (double)n_leapfrog;
+  /* the new sample: position, potential and Hamiltonian (energy__: upstream evaluates H at the copied sample point, the same
+     expression the leaf evaluated) */
+  memcpy(sp->z.q, tp->q_sample, nb); sp->z.V = VH_sample[0]; sp->energy = VH_sample[1];
+  return accept_stat;
+}
+
 /* base_hmc::init_stepsize */
 static void init_stepsize(sampler *sp) {
   const int D = sp->D;
@@ -936,6 +1114,7 @@ static int sample_chain_impl(const oracle_model *m, const oracle_opts *o, int ch
     memset(sp.wf_M2d, 0, sizeof(double) * (size_t)D * D);
     for (int i = 0; i < D; i++) { sp.Minv[(size_t)i * D + i] = 1.0; sp.Lc[(size_t)i * D + i] = 1.0; }
   }
+  tree_pool *pool = (o->pooled && !sp.dense && o->max_depth < 16) ? pool_make(D, o->max_depth) : NULL;
   int rc = 0;
   /* stan::services::util::initialize: U(-R,R) on the unconstrained scale, up to 100 attempts */
   if (q0) memcpy(sp.z.q, q0, sizeof(double) * (size_t)D);
@@ -968,7 +1147,7 @@ static int sample_chain_impl(const oracle_model *m, const oracle_opts *o, int ch
   for (int it = 0; it < o->num_warmup + o->num_samples; it++) {
     sp.iter = (uint32_t)it;
     int warm = it < o->num_warmup;
-    double accept_stat = nuts_transition(&sp);
+    double accept_stat = pool ? nuts_transition_pooled(&sp, pool) : nuts_transition(&sp);
     double eps_used = sp.eps;
     if (warm) { /* adapt_diag_e_nuts::transition */
       learn_stepsize(&sp, accept_stat);
@@ -1006,8 +1185,37 @@ static int sample_chain_impl(const oracle_model *m, const oracle_opts *o, int ch
   }
 done:
   if (total_leapfrogs) *total_leapfrogs = sp.total_leapfrogs;
+  pool_free_all(pool, o->max_depth);
   ps_free(&sp.z); free(sp.minv); free(sp.wf_mean); free(sp.wf_m2); free(sp.tmpv); free(sp.Minv); free(sp.Lc); free(sp.wf_M2d);
   return rc;
+}
+
+/* Single transitions from given states (tests of the dense sampler at sizes where a whole oracle run is out of reach): transition t
+ * starts at qs[t] with step size eps[t] and RNG iteration iter0 + t, under the metric handed in -- dense: Minv and its lower
+ * Cholesky factor Lc, both D x D row-major (used in place, not copied); diagonal: Minv holds the D diagonal elements, Lc is
+ * ignored.  rows: [n][7 + D] as oracle_sample_chain's draws. */
+int oracle_transitions_from(const oracle_model *m, const oracle_opts *o, int chain_id, int iter0, int n, const double *qs, const double *eps,
+                            const double *Minv, const double *Lc, double *rows) {
+  const int D = m->D;
+  sampler sp; memset(&sp, 0, sizeof(sp));
+  sp.m = m; sp.o = o; sp.D = D; sp.chain = chain_id;
+  sp.lpg = o->fast_grad ? oracle_log_prob_grad_fast : oracle_log_prob_grad;
+  sp.dense = o->dense_metric != 0;
+  sp.minv = vec(D); sp.tmpv = vec(D);
+  if (sp.dense) { sp.Minv = (double *)Minv; sp.Lc = (double *)Lc; for (int i = 0; i < D; i++) sp.minv[i] = Minv[(size_t)i * D + i]; }
+  else memcpy(sp.minv, Minv, sizeof(double) * (size_t)D);
+  sp.z = ps_alloc(D);
+  for (int t = 0; t < n; t++) {
+    sp.iter = (uint32_t)(iter0 + t);
+    sp.nom_eps = eps[t];
+    memcpy(sp.z.q, qs + (size_t)t * D, sizeof(double) * (size_t)D);
+    const double accept_stat = nuts_transition(&sp);
+    double *row = rows + (size_t)t * (POTUS_N_SAMPLER_COLS + D);
+    row[0] = -sp.z.V; row[1] = accept_stat; row[2] = sp.eps; row[3] = sp.depth; row[4] = sp.n_leapfrog; row[5] = sp.divergent; row[6] = sp.energy;
+    memcpy(row + POTUS_N_SAMPLER_COLS, sp.z.q, sizeof(double) * (size_t)D);
+  }
+  ps_free(&sp.z); free(sp.minv); free(sp.tmpv);
+  return 0;
 }
 
 double oracle_time_leapfrogs(const oracle_model *m, int n, double eps, int fast_grad, uint64_t seed) {

@@ -39,7 +39,8 @@ typedef struct oracle_opts {
   int32_t fast_grad;   /* 0: literal dense recursion (stan:86); 1: scan/sparse reformulation */
   int32_t save_warmup;
   int32_t dense_metric; /* 0: diag_e (what the reference runs); 1: dense_e (stan::mcmc::dense_e_metric + covar_adaptation) */
-  int32_t pad_;
+  int32_t pooled;      /* 1 (diagonal metric): pooled buffers and fused loops -- the same draws bit for bit, faster; what
+                          bench.py's cpu_baseline times.  0: the recursion written as upstream writes it */
 } oracle_opts;
 
 void oracle_default_opts(oracle_opts *o);
@@ -85,6 +86,12 @@ int oracle_sample_chain_metric(const oracle_model *m, const oracle_opts *o, int 
  * run at the first iteration boundary after that many seconds (a bounded prefix of the configured run) */
 int oracle_sample_chain_timed(const oracle_model *m, const oracle_opts *o, int chain_id, double *draws,
                               double *adapt_out, double *timing, double budget_s);
+
+/* n single transitions, each from its own given state qs[t] ([n][D]) with step size eps[t] and RNG iteration iter0 + t, under a
+ * given metric (dense: Minv and its lower Cholesky factor Lc, D x D row-major, used in place; diagonal: Minv = the D diagonal
+ * elements).  rows: [n][7 + D]. */
+int oracle_transitions_from(const oracle_model *m, const oracle_opts *o, int chain_id, int iter0, int n, const double *qs,
+                            const double *eps, const double *Minv, const double *Lc, double *rows);
 
 /* leapfrog micro-benchmark for bench.py's cpu_baseline: n steps from q0 with unit metric */
 double oracle_time_leapfrogs(const oracle_model *m, int n, double eps, int fast_grad, uint64_t seed);

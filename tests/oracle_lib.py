@@ -18,7 +18,7 @@ class OracleOpts(C.Structure):
                 ("init_buffer", C.c_int32), ("term_buffer", C.c_int32), ("window", C.c_int32),
                 ("delta", C.c_double), ("gamma", C.c_double), ("kappa", C.c_double), ("t0", C.c_double),
                 ("stepsize", C.c_double), ("init_radius", C.c_double), ("seed", C.c_uint64),
-                ("fast_grad", C.c_int32), ("save_warmup", C.c_int32), ("dense_metric", C.c_int32), ("pad_", C.c_int32)]
+                ("fast_grad", C.c_int32), ("save_warmup", C.c_int32), ("dense_metric", C.c_int32), ("pooled", C.c_int32)]
 
 
 def build():
@@ -50,6 +50,7 @@ def lib():
         L.oracle_sample_chain_metric.argtypes = [C.c_void_p, C.POINTER(OracleOpts), C.c_int, dp, dp, dp,
                                                  C.POINTER(C.c_longlong), dp]
         L.oracle_sample_chain_timed.argtypes = [C.c_void_p, C.POINTER(OracleOpts), C.c_int, dp, dp, dp, C.c_double]
+        L.oracle_transitions_from.argtypes = [C.c_void_p, C.POINTER(OracleOpts), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp]
         L.oracle_philox.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.oracle_rng_uniform.restype = C.c_double
         L.oracle_rng_uniform.argtypes = [C.c_uint64] + [C.c_uint32] * 5
@@ -142,6 +143,20 @@ class OracleModel:
         if rc:
             raise RuntimeError(f"oracle_sample_chain_metric failed rc={rc}")
         return draws, adapt, nl.value, metric
+
+    def transitions_from(self, chain_id, opts, iter0, qs, eps, minv, chol=None):
+        """Single transitions from given states: row t starts at qs[t] with step size eps[t] and RNG iteration iter0 + t under the
+        metric handed in (dense: minv [D, D] and its lower Cholesky factor chol; diagonal: minv [D]).  Returns rows [n, 7 + D]."""
+        qs = np.ascontiguousarray(np.atleast_2d(qs), dtype=np.float64)
+        eps = np.ascontiguousarray(np.atleast_1d(eps), dtype=np.float64)
+        minv = np.ascontiguousarray(minv, dtype=np.float64)
+        n = qs.shape[0]
+        rows = np.zeros((n, _abi.N_SAMPLER_COLS + self.D))
+        cp = _dp(np.ascontiguousarray(chol, dtype=np.float64)) if chol is not None else None
+        rc = self.L.oracle_transitions_from(self.h, C.byref(opts), chain_id, int(iter0), n, _dp(qs), _dp(eps), _dp(minv), cp, _dp(rows))
+        if rc:
+            raise RuntimeError(f"oracle_transitions_from failed rc={rc}")
+        return rows
 
     def time_leapfrogs(self, n, eps=0.01, fast=False, seed=1):
         return self.L.oracle_time_leapfrogs(self.h, n, eps, int(fast), seed)

@@ -234,3 +234,36 @@ def test_oracle_posterior_against_everything_the_reference_published(year):
     assert abs(np.sum(ev / ev.sum() * (won - p) ** 2) - pub["ev_wtd_brier"]) <= 0.003
     assert abs(np.mean((won - p) ** 2) - pub["unwtd_brier"]) <= 0.002
     assert int(np.sum(np.round(p) == won)) == int(pub["states_correct"])
+
+
+@pytest.mark.parametrize("name", ["small_full", "small_nomode"])
+def test_pooled_tree_gives_the_same_draws(cases, name):
+    """oracle_opts.pooled (what bench.py's cpu_baseline times: per-level buffers, fused loops) is the same sampler as the
+    recursion written the way upstream writes it: same draws, sampler columns and adapted metric, bit for bit -- across
+    adaptation windows, divergent leaves and both gradient forms."""
+    data, variant = cases[name]
+    m = OracleModel(data, variant)
+    for fast in (0, 1):
+        kw = dict(num_warmup=120, num_samples=30, seed=11, fast_grad=fast, save_warmup=1)
+        d0, a0, n0 = m.sample_chain(3, m.default_opts(pooled=0, **kw))
+        d1, a1, n1 = m.sample_chain(3, m.default_opts(pooled=1, **kw))
+        assert n0 == n1 and np.array_equal(d0, d1) and np.array_equal(a0, a1)
+        assert d0[:, 3].max() >= 5            # real trees
+
+
+def test_transitions_from_replays_a_chain(cases):
+    """oracle_transitions_from (single transitions from given states under a given metric: the checker of the dense sampler
+    at sizes where a whole oracle run is out of reach) reproduces the rows of the chain it is fed from, diagonal and dense."""
+    data, variant = cases["small_full"]
+    m = OracleModel(data, variant)
+    for dense in (0, 1):
+        o = m.default_opts(num_warmup=40, num_samples=6, seed=5, save_warmup=1, dense_metric=dense)
+        d, adapt, _, metric = m.sample_chain_metric(2, o)
+        # the sampling phase: fixed metric and step size; row t starts from the draw before it
+        qs, eps = d[39:45, 7:], d[40:46, 2]
+        minv = metric if dense else adapt[1:]
+        chol = np.linalg.cholesky(metric) if dense else None
+        rows = m.transitions_from(2, o, 40, qs, eps, minv, chol)
+        assert np.array_equal(rows[:, 3:6], d[40:46, 3:6])
+        np.testing.assert_allclose(rows[:, [0, 1, 6]], d[40:46][:, [0, 1, 6]], rtol=1e-9)
+        np.testing.assert_allclose(rows[:, 7:], d[40:46, 7:], rtol=1e-8, atol=1e-10)
