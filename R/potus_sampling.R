@@ -34,7 +34,9 @@ potus_load <- function(path) dyn.load(path)
 potus_sample <- function(data, variant = c("full", "no_mode_adjustment"), seed = 1843, chains = 4,
                          parallel_chains = chains, iter_warmup = 1000, iter_sampling = 1000, refresh = 100,
                          adapt_delta = 0.8, max_treedepth = 10, init = 2, device = 0, chain_id_offset = 0,
-                         save_warmup = FALSE, gpus = device, cus_per_chain = 0, metric = c("diag_e", "dense_e"), twin = -1) {
+                         save_warmup = FALSE, gpus = device, cus_per_chain = 0, metric = c("diag_e", "dense_e"), twin = -1,
+                         metric_storage = c("f64", "f32")) {
+  metric_storage <- match.arg(metric_storage)
   metric <- match.arg(metric)
   variant <- match.arg(variant)
   full <- variant == "full"
@@ -63,7 +65,8 @@ potus_sample <- function(data, variant = c("full", "no_mode_adjustment"), seed =
               as.double(data$mu_b_prior), as.double(data$state_weights), scalars,
               as.double(data$state_covariance_0),           # column-major, as R stores it
               as.integer(c(per[g], chain_id_offset + first[g], iter_warmup, iter_sampling, max_treedepth, gpus[g],
-                           as.integer(save_warmup), cus_per_chain, if (metric == "dense_e") 1L else 0L, twin)),
+                           as.integer(save_warmup), cus_per_chain, if (metric == "dense_e") 1L else 0L, twin,
+                           if (metric_storage == "f32") 1L else 0L)),
               as.double(c(adapt_delta, 0.05, 0.75, 10, 1, init, seed)),   # the seed as a double: exact to 2^53
               handle = integer(1), status = integer(1))
     .potus_check(res$status)

@@ -76,9 +76,17 @@ def _cpu_nuts_worker(args):
     data, variant, chain, nw, ns, seed, budget = args
     from oracle_lib import OracleModel
     m = OracleModel(data, variant)
-    o = m.default_opts(num_warmup=nw, num_samples=ns, seed=seed, fast_grad=0)
-    _, _, timing = m.sample_chain_timed(chain, o, budget_s=budget)
-    return chain, timing
+    o = m.default_opts(num_warmup=nw, num_samples=ns, seed=seed, fast_grad=1, pooled=1)
+    draws, _, timing = m.sample_chain_timed(chain, o, budget_s=budget)
+    if budget > 0:
+        return chain, timing, None
+    # the columns of the ESS definition: lp__, mu_b[:, T], predicted_score[T, :]
+    from us_potus_model_amd import _abi
+    lay, _ = _abi.column_layout(data, variant)
+    S, T = int(data["S"]), int(data["T"])
+    a = lay["mu_b"][0] - _abi.N_SAMPLER_COLS + S * (T - 1)
+    mu = np.stack([m.write_array(q)[a:a + S] for q in draws[:, _abi.N_SAMPLER_COLS:]])
+    return chain, timing, np.concatenate([draws[:, :1], mu, 1.0 / (1.0 + np.exp(-mu))], axis=1)
 
 
 def _cpu_loop_worker(args):
@@ -92,14 +100,22 @@ def _cpu_loop_worker(args):
     return n, t
 
 
-def cpu_baseline(data, variant, chains, seed, nw, ns, gpu_ess_per_leapfrog, budget=20.0, loop_budget=3.0):
-    """the oracle's NUTS (oracle/potus_oracle.c: the literal stan:86 recursion with a hand-written
-    reverse sweep -- no AD tape, so faster than Stan itself -- under the same Stan-2.24 sampler) run as the reference
-    runs its chains, one per host core (final_2016.R:536), with the SAME configuration, seed and chain ids as the GPU
-    run, cut after `budget` seconds: a bounded prefix of the same 8 x (nw + ns) run (the whole of it takes minutes on
-    these cores -- tests/golden/posterior_2016.npz holds one, made in the build container).
-    value = leapfrogs of all chains / wall time.  A prefix of a warm-up has no ESS of its own; ESS/s is derived:
-    same algorithm, same posterior => same ESS per leapfrog as the GPU run just measured, x this rate."""
+def ess_min(cols):
+    """min bulk-ESS over the columns of [chain, draw, column] (lp__, mu_b[:, T], predicted_score[T, :])."""
+    from us_potus_model_amd import diagnostics as dg
+    return float(min(dg.ess_bulk(cols[:, :, j]) for j in range(cols.shape[2])))
+
+
+def cpu_baseline(data, variant, chains, seed, nw, ns, short, budget=12.0, loop_budget=3.0):
+    """the CPU port (oracle/potus_oracle.c, kind "port": rstan / CmdStan cannot run here) on the box's own host
+    cores, one chain per core as the reference runs its chains (final_2016.R:536), in its fastest form -- the scan/sparse
+    gradient (the GPU's algebra) under the pooled-buffer NUTS (oracle_opts.pooled: same draws as the literal recursion, bit for
+    bit).  Three measurements:
+      value           the first `budget` seconds of the SAME run as the GPU's (8 x (nw + ns), same seed and chain ids): leapfrogs / s;
+      short_config    a COMPLETE short configuration (8 x (150 + 100), same seed) run to the end: leapfrogs / s and the MEASURED
+                      ESS / s of its sampling phase -- main() runs the same configuration on the GPU and puts the two side by side;
+      leapfrog_loop*  plain leapfrog loops without any tree bookkeeping: the rate of the gradient arithmetic alone, an upper bound
+                      for any sampler on these cores."""
     procs = max(1, min(chains, os.cpu_count() or 1))
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(procs) as pool:
@@ -108,33 +124,43 @@ def cpu_baseline(data, variant, chains, seed, nw, ns, gpu_ess_per_leapfrog, budg
         for key, fast in (("leapfrog_loop_value", 0), ("leapfrog_loop_scan_sparse_value", 1)):
             r = pool.map(_cpu_loop_worker, [(data, variant, fast, loop_budget)] * procs)
             loop[key] = float(sum(n / t for n, t in r))
+        snw, sns = short
+        ts0 = time.perf_counter()
+        sres = sorted(pool.map(_cpu_nuts_worker, [(data, variant, c + 1, snw, sns, seed, 0.0) for c in range(procs)]), key=lambda r: r[0])
+        short_wall = time.perf_counter() - ts0
     wall = time.perf_counter() - t0
     timing = np.stack([r[1] for r in sorted(res, key=lambda r: r[0])])      # [chain][warm s, samp s, warm lf, samp lf, iterations]
     rate = float(sum((tm[2] + tm[3]) / (tm[0] + tm[1]) for tm in timing))    # every chain on its own core, at its own rate
+    st = np.stack([r[1] for r in sres])
+    cols = np.stack([r[2] for r in sres])                                    # [chain, draw, 1 + 2 S]
+    s_ess = ess_min(cols)
+    s_secs, s_samp = float((st[:, 0] + st[:, 1]).max()), float(st[:, 1].max())   # the chains run side by side: the slowest sets the time
     out = dict(value=rate, unit="leapfrogs/s", cores=procs, kind="port", leapfrogs_per_sec_per_core=rate / procs,
                sample=f"the first {int(timing[:, 4].min())}-{int(timing[:, 4].max())} iterations of the same run ({procs} chains, ids 1..{procs}, seed {seed}, "
                       f"{nw} warm-up + {ns} sampling configured) on {procs} host processes, cut after {budget:.0f} s each: "
-                      f"{int(timing[:, 2:4].sum())} leapfrogs; literal stan:86 gradient",
+                      f"{int(timing[:, 2:4].sum())} leapfrogs; scan/sparse gradient, pooled-buffer tree (the fastest form of the port)",
                seconds=wall, **loop,
-               leapfrog_loop_note="plain leapfrog loops (unit metric, eps 0.01, no tree, no U-turn bookkeeping) of the literal and of the "
-                                  f"scan/sparse gradient, {procs} processes x {loop_budget:.0f} s each: the rate of the arithmetic alone")
-    if gpu_ess_per_leapfrog:
-        out["ess_per_sec"] = gpu_ess_per_leapfrog * rate
-        out["ess_per_sec_note"] = ("derived: ESS per sampling leapfrog of the GPU run above (same algorithm, posterior, seed) x this leapfrog "
-                                   "rate = ESS / sampling time, as the GPU's ess_per_sec; a bounded warm-up prefix has no ESS of its own")
+               leapfrog_loop_note="plain leapfrog loops (unit metric, eps 0.01, no tree, no U-turn bookkeeping) of the literal stan:86 recursion and of the "
+                                  f"scan/sparse gradient, {procs} processes x {loop_budget:.0f} s each: the rate of the arithmetic alone",
+               short_config=dict(iter_warmup=snw, iter_sampling=sns, chains=procs, seed=seed, leapfrogs=int(st[:, 2:4].sum()), seconds=s_secs,
+                                 sampling_seconds=s_samp, leapfrogs_per_sec=float(st[:, 2:4].sum()) / s_secs, ess_bulk_min=s_ess,
+                                 ess_per_sec_measured=s_ess / s_samp, wall_seconds=short_wall,
+                                 note="a complete run of the port, measured: min bulk-ESS over lp__, mu_b[:, T], predicted_score[T, :] of its own "
+                                      "draws / the sampling time of its slowest chain"),
+               ess_per_sec_measured=s_ess / s_samp)
     full = ROOT / "tests" / "golden" / "posterior_2016.npz"
     if full.exists() and int(data["T"]) == 254:
         g = np.load(full)
         lf, sec = float(g["leapfrogs"].sum()), float(g["seconds"].max())
         ess = float(min(g["lp__ess_bulk"].min(), g["mu_b_T__ess_bulk"].min(), g["predicted_score_T__ess_bulk"].min()))
         out["full_run_in_build_container"] = dict(leapfrogs_per_sec=lf / sec, ess_bulk_min=ess, ess_per_sec_total_time=ess / sec, seconds=sec,
-                                                  note="the whole 8 x (1000 + 1000) run of the oracle (scan/sparse gradient) behind tests/golden/posterior_2016.npz, "
-                                                       "8 processes on the build container's 8 vCPUs -- not this box")
+                                                  note="the whole 8 x (1000 + 1000) run of the oracle (scan/sparse gradient, recursive tree) behind "
+                                                       "tests/golden/posterior_2016.npz, 8 processes on the build container's 8 vCPUs -- not this box")
     return out
 
 
 # ------------------------------------------------------------------------------------------------ workloads
-def load_workloads(cfg, chains_per_gpu, twin_posteriors=""):
+def load_workloads(cfg, chains_per_gpu, twin_posteriors="", storage=0):
     """[(name, data, variant, chains per GPU, options)] of the posteriors one GPU runs."""
     from us_potus_model_amd import dataprep, synthetic
     gold = ROOT / "tests" / "golden"
@@ -148,7 +174,7 @@ def load_workloads(cfg, chains_per_gpu, twin_posteriors=""):
                 for y, v in (("2008", "no_mode_adjustment"), ("2012", "no_mode_adjustment"), ("2016", "full"))]
     if cfg == 4:
         from us_potus_model_amd import _abi
-        return [("stress", synthetic.stress(), "full", chains_per_gpu or 16, {"metric": _abi.METRIC_DENSE})]
+        return [("stress", synthetic.stress(), "full", chains_per_gpu or 16, {"metric": _abi.METRIC_DENSE, "metric_storage": storage})]
     raise SystemExit(f"unknown --config {cfg}")
 
 
@@ -163,6 +189,9 @@ def main():
     ap.add_argument("--twin", type=int, default=-1, help="two clusters per chain, one per end of the trajectory: 1, 0, or -1 = the library's choice")
     ap.add_argument("--twin-posteriors", default="2016", help="--config 3: the posteriors (comma-separated years) that get two clusters per chain")
     ap.add_argument("--chunk", type=int, default=0, help="transitions per step (0 = the configuration's: 100; 1 for --config 4)")
+    ap.add_argument("--warm-steps", type=int, default=-1, help="how many of the --steps are warm-up (-1 = half of them)")
+    ap.add_argument("--metric-storage", default="f64", choices=["f64", "f32"], help="--config 4: storage of the dense inverse metric")
+    ap.add_argument("--max-depth", type=int, default=10)
     ap.add_argument("--seed", type=int, default=1843)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturated", action="store_true", help="skip the 256-chain reference point")
@@ -188,8 +217,9 @@ def main():
 
     cfg = args.config
     chunk = args.chunk or (1 if cfg == 4 else 100)
-    work = load_workloads(cfg, args.chains_per_gpu, "" if dev_backend == "gloo" else args.twin_posteriors)
-    nw, ns = (args.steps // 2) * chunk, (args.steps - args.steps // 2) * chunk
+    work = load_workloads(cfg, args.chains_per_gpu, "" if dev_backend == "gloo" else args.twin_posteriors, 1 if args.metric_storage == "f32" else 0)
+    warm_steps = args.steps // 2 if args.warm_steps < 0 else min(args.warm_steps, args.steps)
+    nw, ns = warm_steps * chunk, (args.steps - warm_steps) * chunk
 
     def make(seed, num_warmup, num_samples):
         hs = []
@@ -197,7 +227,7 @@ def main():
             while True:
                 try:
                     hs.append(Handle(data, variant, chains=C, chain_id_offset=rank * C, num_warmup=num_warmup, num_samples=num_samples,
-                                     seed=seed, device=local, cus_per_chain=args.cus_per_chain, **{"twin": twin, **extra}))
+                                     seed=seed, device=local, cus_per_chain=args.cus_per_chain, max_depth=args.max_depth, **{"twin": twin, **extra}))
                     break
                 except Exception as e:      # the dense metric keeps two D x D matrices per chain: as many chains as the HBM holds
                     if cfg != 4 or args.chains_per_gpu or C <= 1 or "GB free" not in str(e):
@@ -222,10 +252,18 @@ def main():
     for h in hs:
         h.init()
     kernel_ms, t_warm_end, lf_warm = 0.0, None, 0
+    per_step = []                                                   # --config 4: the run chunk by chunk (where the window ends fall)
     for step in range(args.steps):
+        ts0, lf0 = time.perf_counter(), sum(h.total_leapfrogs() for h in hs)
+        dt0 = hs[0].dense_timing() if cfg == 4 else None
         run_many(hs, chunk)
         kernel_ms += max(h.last_run_timing()[0] for h in hs)        # the handles of a step run concurrently
-        if step + 1 == args.steps // 2:
+        if cfg == 4:
+            dt1, at = hs[0].dense_timing(), hs[0].dense_adapt_timing()
+            per_step.append({"iterations": [step * chunk, (step + 1) * chunk], "seconds": time.perf_counter() - ts0,
+                             "leapfrogs": sum(h.total_leapfrogs() for h in hs) - lf0, "matrix_pass_ms": dt1[0] - dt0[0],
+                             "matrix_bytes": dt1[2] - dt0[2], "window_ends_so_far": at["window_ends"]})
+        if step + 1 == warm_steps:
             torch.cuda.synchronize()
             t_warm_end = time.perf_counter()
             lf_warm = sum(h.total_leapfrogs() for h in hs)
@@ -332,12 +370,27 @@ def main():
                          "kernel": kernel, "algorithmic_bytes_per_leapfrog": bpl if len(bpl) > 1 else bpl[0],
                          "leapfrogs_in_launches": int(sum(lf_local)), "launch_ms_total": kernel_ms,
                          **({"matrix_passes": dense_t[1], "matrix_pass_ms_total": dense_t[0], "matrix_bytes_streamed": dense_t[2],
-                             "avg_pass_ms": dense_t[0] / max(dense_t[1], 1), "leaf_rounds": dense_t[3]} if dense else {}),
+                             "avg_pass_ms": dense_t[0] / max(dense_t[1], 1), "leaf_rounds": dense_t[3],
+                             "metric_storage": args.metric_storage} if dense else {}),
                          "note": (f"latency-bound at {C_tot} chains ({C_tot * K * sides} of 256 CUs busy): the state of a chain stays in L2, a leapfrog "
                                   "is a chain of dependent phases and exchanges between the CUs of a cluster; see DESIGN.md") if not dense else
                                  "dense metric: every leapfrog streams the upper triangle of the chain's D x D inverse metric (4 D^2 bytes; the "
                                  "survey's 8 D^2 assumed the full matrix); achieved = bytes loaded by the matrix passes / their time"},
         }
+        if dense:
+            at = hs[0].dense_adapt_timing()
+            adapted = [p for p in per_step if p["window_ends_so_far"] > 0 and p is not next((q for q in per_step if q["window_ends_so_far"] > 0), None)]
+            line["dense"] = {
+                "window_ends": at["window_ends"], "window_end_seconds": (at["cov_ms"] + at["chol_ms"] + at["init_stepsize_ms"]) * 1e-3,
+                "covariance_seconds": at["cov_ms"] * 1e-3, "cholesky_seconds": at["chol_ms"] * 1e-3, "init_stepsize_seconds": at["init_stepsize_ms"] * 1e-3,
+                "cholesky_tflops": (work[0][3] * hs[0].D ** 3 / 3.0 * at["window_ends"]) / max(at["chol_ms"] * 1e-3, 1e-9) / 1e12,
+                "adapted_phase": ({"steps": len(adapted), "leapfrogs": sum(p["leapfrogs"] for p in adapted), "seconds": sum(p["seconds"] for p in adapted),
+                                   "leapfrogs_per_sec": sum(p["leapfrogs"] for p in adapted) / max(sum(p["seconds"] for p in adapted), 1e-9),
+                                   "matrix_pass_TBps": sum(p["matrix_bytes"] for p in adapted) / max(sum(p["matrix_pass_ms"] for p in adapted), 1e-9) / 1e9,
+                                   "matrix_pass_share_of_wall": sum(p["matrix_pass_ms"] for p in adapted) * 1e-3 / max(sum(p["seconds"] for p in adapted), 1e-9),
+                                   "note": "the steps after the one in which the first window ended: transitions under the adapted dense metric"}
+                                  if adapted else None),
+                "per_step": per_step}
         if world == 1 and cfg == 1 and not args.no_saturated:
             # The same posterior with the GPU full: 256 chains, one workgroup per chain (k_run).  Not the metric's
             # configuration -- a reference point for what the kernels deliver when parallelism is not the limit.
@@ -359,9 +412,32 @@ def main():
                 line["saturated"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and world == 1 and cfg in (1, 2):   # the CPU port is timed beside the single-GPU run only
             _, data, variant, C, _ = work[0]
-            epl = (line["ess_bulk_min"] / max(sum(lf_local) - lf_warm, 1)) if line["ess_bulk_min"] else None   # per SAMPLING leapfrog
-            line["cpu_baseline"] = cpu_baseline(data, variant, C, args.seed, nw, ns, epl)
-            line["speedup_vs_cpu_port"] = line["value"] / line["cpu_baseline"]["value"]
+            short = (150, 100)
+            # the same complete short configuration on the GPU (after the timed region), to put measured ESS / s side by side
+            hg = Handle(data, variant, chains=C, num_warmup=short[0], num_samples=short[1], seed=args.seed, device=local, cus_per_chain=args.cus_per_chain, twin=twin)
+            tg0 = time.perf_counter()
+            hg.init(); hg.run(short[0])
+            tg1 = time.perf_counter()
+            hg.run(short[1])
+            tg2 = time.perf_counter()
+            S_, T_ = int(data["S"]), int(data["T"])
+            a_mu = hg.layout["mu_b"][0]
+            mu = np.transpose(hg.write_array(a_mu + S_ * (T_ - 1), a_mu + S_ * T_, short[1]), (1, 0, 2))
+            lpc = np.transpose(hg.write_array(0, 1, short[1]), (1, 0, 2))
+            g_ess = ess_min(np.concatenate([lpc, mu, 1.0 / (1.0 + np.exp(-mu))], axis=2))
+            g_lf = hg.total_leapfrogs()
+            hg.close()
+            cb = cpu_baseline(data, variant, C, args.seed, nw, ns, short)
+            cb["short_config"]["gpu"] = dict(leapfrogs=g_lf, seconds=tg2 - tg0, sampling_seconds=tg2 - tg1, leapfrogs_per_sec=g_lf / (tg2 - tg0),
+                                             ess_bulk_min=g_ess, ess_per_sec_measured=g_ess / (tg2 - tg1))
+            cb["short_config"]["gpu_over_cpu"] = dict(leapfrogs_per_sec=(g_lf / (tg2 - tg0)) / cb["short_config"]["leapfrogs_per_sec"],
+                                                      ess_per_sec=(g_ess / (tg2 - tg1)) / cb["short_config"]["ess_per_sec_measured"],
+                                                      wall=cb["short_config"]["seconds"] / (tg2 - tg0))
+            line["cpu_baseline"] = cb
+            line["speedup_vs_cpu_port"] = line["value"] / cb["value"]
+            line["speedup_vs_cpu_leapfrog_loop"] = line["value"] / cb["leapfrog_loop_scan_sparse_value"]
+            line["speedup_note"] = ("speedup_vs_cpu_port: against the port's NUTS in its fastest form (scan/sparse gradient, pooled tree) on the box's "
+                                    f"{cb['cores']} cores; speedup_vs_cpu_leapfrog_loop: against its bare leapfrog loop, which no CPU sampler can exceed")
         print(json.dumps(line), flush=True)
     for h in hs:
         h.close()

@@ -119,9 +119,16 @@ typedef struct potus_opts {
                               cluster; -1 = the library decides when it also chooses the cluster size (cus_per_chain = 0):
                               two clusters if they fit.  Same algorithm, RNG streams and arithmetic: the draws are the
                               same bytes as with one cluster of the same size. */
+  int32_t metric_storage;  /* dense metric only: POTUS_STORAGE_F64 (Stan's) or POTUS_STORAGE_F32 -- the adapted covariance is
+                              rounded to fp32 and THAT matrix is the metric: its Cholesky factor (fp64) draws the momenta, the
+                              leapfrog multiplies with it (fp64 accumulation), so the sampler stays exact while the matrix pass
+                              of every leapfrog streams 2 D^2 bytes instead of 4 D^2.  A declared deviation from Stan, which
+                              keeps the covariance in fp64; same memory per chain. */
 } potus_opts;
 #define POTUS_METRIC_DIAG 0
 #define POTUS_METRIC_DENSE 1
+#define POTUS_STORAGE_F64 0
+#define POTUS_STORAGE_F32 1
 
 /* per-draw sampler columns, in CmdStan order */
 #define POTUS_N_SAMPLER_COLS 7 /* lp__,accept_stat__,stepsize__,treedepth__,n_leapfrog__,divergent__,energy__ */
@@ -229,6 +236,16 @@ int potus_last_run_timing(int handle, double *ms, long long *leapfrogs);
  * the sampler's stream), their number, the bytes of matrix they streamed (active chains x D x LD x 8 each) and the
  * number of leaf rounds, since potus_create. */
 int potus_dense_timing(int handle, double *matvec_ms, long long *passes, long long *bytes, long long *rounds);
+/* Dense metric only: what the window ends of the warm-up (covar_adaptation::learn_covariance, then base_hmc::init_stepsize) have
+ * cost since potus_create: milliseconds in the covariance, in the blocked Cholesky factorisation and in the step-size search,
+ * and the number of window ends. */
+int potus_dense_adapt_timing(int handle, double *cov_ms, double *chol_ms, double *init_stepsize_ms, int *window_ends);
+/* Dense metric only, verification hook (as potus_log_prob_grad is for the gradient): is the factor L the momentum draw solves
+ * with the Cholesky factor of the inverse metric the leapfrog multiplies with?  For n_probe standard-normal vectors x,
+ * M^-1 x by the sampler's own matrix pass against L (L' x) by plain kernels over the factor, and the momentum draw's blocked
+ * back substitution L' p = u multiplied back:
+ *   out[0] = max ||L L' x - M^-1 x|| / ||M^-1 x||,   out[1] = ||L' p - u|| / ||u||. */
+int potus_dense_check(int handle, int chain, int n_probe, double *out /*[2]*/);
 
 /* ---- .C()-callable wrappers (int* / double* / char** only) ---- */
 void potus_R_create(int *dims /*[8]: N_nat,N_state,T,S,P,M,Pop,variant*/,
@@ -241,8 +258,8 @@ void potus_R_create(int *dims /*[8]: N_nat,N_state,T,S,P,M,Pop,variant*/,
                     sigma_noise_nat,sigma_noise_state,sigma_e_bias,random_walk_scale,
                     mu_b_T_scale,polling_bias_scale*/,
                     double *state_covariance_0,
-                    int *iopts /*[10]: chains,chain_id_offset,num_warmup,num_samples,max_depth,
-                    device,save_warmup,cus_per_chain,metric,twin*/,
+                    int *iopts /*[11]: chains,chain_id_offset,num_warmup,num_samples,max_depth,
+                    device,save_warmup,cus_per_chain,metric,twin,metric_storage*/,
                     double *dopts /*[7]: delta,gamma,kappa,t0,stepsize,init_radius,seed (an integer < 2^53:
                     R's own integers have 32 bits)*/,
                     int *handle, int *status);

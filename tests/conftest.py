@@ -52,3 +52,22 @@ def cases(data_2016):
         "small_full": (synthetic.small("full"), "full"),
         "small_nomode": (synthetic.small("no_mode_adjustment"), "no_mode_adjustment"),
     }
+
+
+def readme_golden(year):
+    """tests/golden/readme_<year>.csv (scripts/make_readme_golden.py): the published figures (`# key = number` lines: Brier scores,
+    states called correctly, RMSE over the 50 states) and the 52 table rows (with the certified result `actual` per state)."""
+    import csv
+    import re
+    lines = open(GOLD / f"readme_{year}.csv").read().splitlines()
+    pub = {m.group(1): float(m.group(2)) for m in (re.match(r"^# (\w+) = ([0-9.eE+-]+)$", ln) for ln in lines) if m}
+    rows = list(csv.DictReader(ln for ln in lines if not ln.startswith("#")))
+    return pub, rows
+
+
+def rmse_ex_dc(states, mean_by_state, rows):
+    """README.Rmd:392-401: sqrt(mean((posterior mean - actual)^2)) over the 50 states, DC left out."""
+    import numpy as np
+    act = {r["state"]: float(r["actual"]) for r in rows if r["state"] != "--"}
+    d = [mean_by_state[i] - act[s] for i, s in enumerate(states) if s != "DC"]
+    return float(np.sqrt(np.mean(np.square(d))))

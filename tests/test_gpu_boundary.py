@@ -53,7 +53,7 @@ class RShim:
             raise RuntimeError(f"libpotus_hmc error {status.value}: {buf.value.decode().strip()}")
 
     def sample(self, data, variant, seed, chains, iter_warmup, iter_sampling, refresh, gpus=(0,), cus_per_chain=0, metric="diag_e", twin=-1,
-               chain_id_offset=0, save_warmup=False, adapt_delta=0.8, max_treedepth=10, init=2.0):
+               metric_storage="f64", chain_id_offset=0, save_warmup=False, adapt_delta=0.8, max_treedepth=10, init=2.0):
         full = variant == "full"
         Ns, Nn = int(data["N_state_polls"]), int(data["N_national_polls"])
         iv = lambda k, n: _ints(data[k] if data.get(k) is not None else np.zeros(max(n, 1)))
@@ -75,7 +75,7 @@ class RShim:
                     dv("unadjusted_national", Nn), dv("unadjusted_state", Ns), _dbls(data["mu_b_prior"]), _dbls(data["state_weights"]),
                     scalars, cov,
                     _ints([per[g], chain_id_offset + first[g], iter_warmup, iter_sampling, max_treedepth, dev, int(save_warmup), cus_per_chain,
-                           1 if metric == "dense_e" else 0, twin]),
+                           1 if metric == "dense_e" else 0, twin, 1 if metric_storage == "f32" else 0]),
                     _dbls([adapt_delta, 0.05, 0.75, 10, 1, init, seed])]
             h, st = C.c_int(-1), C.c_int(-1)
             self.call("potus_R_create", *[a[1] for a in args], C.byref(h), C.byref(st))
@@ -190,16 +190,15 @@ def test_r_entry_points_replay_the_shim(cases, name, tmp_path):
 
 
 def _readme(year):
-    lines = open(GOLD / f"readme_{year}.csv").read().splitlines()
-    meta = {ln[2:].split(" = ")[0]: float(ln.split(" = ")[1]) for ln in lines if ln.startswith("# ") and " = " in ln}
-    rows = list(csv.DictReader(ln for ln in lines if not ln.startswith("#")))
-    return meta, rows
+    from conftest import readme_golden
+    return readme_golden(year)
 
 
-# Tolerances of the README comparison.  The published tables are rounded to 3 decimals and were knitted from saved fits
-# whose script revision cannot be matched to the committed final_*.R; the CPU oracle itself
-# sits within 0.0019 / 0.004 / 0.021 (mean / interval ends / P(win)) of the 2016 table.
-TOL_MEAN, TOL_END, TOL_PROB, TOL_BRIER = 0.01, 0.012, 0.05, 0.006
+# Tolerances of the README comparison: about twice what the device runs have shown (mean 0.0021, interval ends 0.0046,
+# P(win) 0.032 with 4 chains; the oracle's 8 chains: 0.0019 / 0.0043 / 0.031, test_oracle.py).  The published tables are rounded
+# to 3 decimals and were knitted from saved fits whose script revision cannot be matched to the committed final_*.R
+# (BASELINE.md section 3).  RMSE (README.md:79,175,275, seven digits): the oracle sits 0.7-1.3e-4 below the published values.
+TOL_MEAN, TOL_END, TOL_PROB, TOL_BRIER, TOL_RMSE = 0.005, 0.010, 0.045, 0.003, 4e-4
 
 
 def test_readme_tables_of_the_three_backtests(cases):
@@ -229,6 +228,8 @@ def test_readme_tables_of_the_three_backtests(cases):
                 worst[k] = max(worst[k], abs(got[j] - float(r[k])))
         won = np.array([int(next(r for r in rows if r["state"] == s)["won_readme"]) for s in states])
         sc = backtest_scores(sm, ev, won)
+        from conftest import rmse_ex_dc
+        sc["rmse_ex_dc"] = rmse_ex_dc(states, sm["state"][T - 1, :, 2], rows)
         report[year] = (worst, sc, meta)
         st, _ = h.chain_status()
         div = h.write_array(5, 6, 1000)                     # divergent__ of the saved (sampling) draws
@@ -238,7 +239,8 @@ def test_readme_tables_of_the_three_backtests(cases):
     for year, (worst, sc, meta) in report.items():
         assert worst["mean"] <= TOL_MEAN and worst["low"] <= TOL_END and worst["high"] <= TOL_END and worst["prob"] <= TOL_PROB, (year, worst)
         assert abs(sc["ev_wtd_brier"] - meta["ev_wtd_brier"]) <= TOL_BRIER and abs(sc["unwtd_brier"] - meta["unwtd_brier"]) <= TOL_BRIER, (year, sc, meta)
-        assert abs(sc["states_correct"] - meta["states_correct"]) <= 1, (year, sc, meta)
+        assert sc["states_correct"] == int(meta["states_correct"]), (year, sc, meta)
+        assert abs(sc["rmse_ex_dc"] - meta["rmse_ex_dc"]) <= TOL_RMSE, (year, sc, meta)
 
 
 def test_summaries_beyond_one_lds_sort_and_over_several_handles(cases):

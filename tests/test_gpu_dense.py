@@ -209,3 +209,96 @@ def test_dense_product_does_not_depend_on_the_launch_shape():
     assert np.array_equal(outs[0][0][0], outs[1][0][0]) and np.array_equal(outs[1][0][0], outs[1][0][15])
     assert outs[0][1][0] == outs[1][1][7]
     assert np.allclose(outs[0][0][0], x1 @ M1, rtol=1e-11, atol=1e-11)
+
+
+# ---------------------------------------------------------------------------------------------------- round 3
+def _post_window_rows_against_the_oracle(data, variant, h, d, chain, first, count, max_depth, metric, chain_id):
+    """Transitions first .. first + count - 1 of the device chain, each replayed by the oracle FROM THE DEVICE'S OWN STATE: the
+    draw before it, the step size it used (stepsize__ of its own row), the device's inverse metric (potus_get_dense_metric) and
+    that matrix's Cholesky factor.  Nothing can drift: every row is an independent comparison."""
+    m = OracleModel(data, variant)
+    o = m.default_opts(num_warmup=h.opts.num_warmup, num_samples=h.opts.num_samples, seed=int(h.opts.seed), fast_grad=1, dense_metric=1,
+                       max_depth=max_depth)
+    rows = d[chain][first:first + count]
+    qs, eps = d[chain][first - 1:first + count - 1, 7:], rows[:, 2]
+    Lc = np.linalg.cholesky(metric)
+    ref = m.transitions_from(chain_id, o, first, qs, eps, metric, Lc)
+    assert np.array_equal(rows[:, 3:6], ref[:, 3:6]), (rows[:, :7], ref[:, :7])                # treedepth__, n_leapfrog__, divergent__
+    assert np.allclose(rows[:, [0, 1, 6]], ref[:, [0, 1, 6]], rtol=1e-6, atol=1e-8), (rows[:, :7], ref[:, :7])
+    assert np.allclose(rows[:, 7:], ref[:, 7:], rtol=1e-6, atol=1e-7)
+    return ref
+
+
+@pytest.mark.parametrize("storage", [_abi.STORAGE_F64, _abi.STORAGE_F32])
+def test_dense_transitions_after_the_window_match_the_oracle_at_2016_size(cases, storage):
+    """D = 15 098, after the metric update (30 warm-up iterations: window of 23 draws, update after iteration 26; 236-block
+    Cholesky).  The three transitions that follow run under the adapted dense metric -- momenta from the blocked back
+    substitution L' p = u, p# = M^-1 p out of the upper triangle -- and must be the oracle's transitions from the same state
+    under the same matrix: same tree depth, leapfrog count and divergence flag, values to 1e-6.  A wrong k_dn_trsv_*, a wrong
+    p# slot or a wrong tile of the symmetric product at this size cannot pass.  (max_depth 6 keeps the oracle's 63 dense
+    products per transition within a test's time.)  With fp32 storage the device's metric is the rounded matrix and the oracle
+    is handed exactly that."""
+    data, variant = cases["2016"]
+    nw, md = 30, 6
+    h = Handle(data, variant, chains=2, num_warmup=nw, num_samples=0, save_warmup=1, seed=1843, metric=_abi.METRIC_DENSE, max_depth=md,
+               metric_storage=storage)
+    h.init(); h.run(nw)
+    d = h.draws()
+    assert np.isfinite(d).all()
+    Mi = h.dense_metric(1)
+    if storage == _abi.STORAGE_F32:
+        assert np.array_equal(Mi, Mi.astype(np.float32).astype(np.float64))                  # every element is an fp32 number
+        want = (lambda w: (len(w) / (len(w) + 5.0)) * np.cov(w.T) + 1e-3 * (5.0 / (len(w) + 5.0)) * np.eye(w.shape[1]))(d[1][4:27, 7:])
+        assert np.abs(Mi - want).max() <= 6.1e-8 * np.abs(want).max()                        # the window's covariance, rounded
+    assert np.array_equal(Mi, Mi.T)
+    res, solve = h.dense_check(1, 2)
+    assert res < 1e-12 and solve < 1e-9, (res, solve)
+    _post_window_rows_against_the_oracle(data, variant, h, d, 1, 27, 3, md, Mi, 2)
+    h.close()
+
+
+def test_dense_factor_is_the_factor_of_the_metric_at_the_stress_size():
+    """D = 41 610 (BASELINE configs[4]'s shape): 20 warm-up iterations cross a window end (15 draws, 651-block in-place Cholesky
+    of a 13.85 GB matrix).  On the device: L L' x against M^-1 x from the sampler's own matrix pass, and the momentum draw's
+    blocked back substitution multiplied back (potus_dense_check)."""
+    from us_potus_model_amd import synthetic
+    data = synthetic.stress()
+    h = Handle(data, "full", chains=1, num_warmup=20, num_samples=0, save_warmup=1, seed=3, metric=_abi.METRIC_DENSE, max_depth=3)
+    assert h.D == 41610
+    h.init(); h.run(20)
+    t = h.dense_adapt_timing()
+    assert t["window_ends"] == 1 and t["chol_ms"] > 0
+    res, solve = h.dense_check(0, 2)
+    print(f"D = 41610: ||L L' x - M^-1 x|| / ||M^-1 x|| = {res:.2e}, ||L' p - u|| / ||u|| = {solve:.2e}; window end: {t}")
+    assert res < 1e-12 and solve < 1e-9, (res, solve)
+    d = h.draws()
+    assert np.isfinite(d).all() and d[0, 18:, 1].mean() > 0.2
+    h.close()
+
+
+def test_dense_fp32_storage_samples_the_same_posterior(cases):
+    """potus_opts.metric_storage = f32 (M^-1 rounded to fp32 IS the metric; its factor, the momenta and the accumulation stay
+    fp64): the posterior of the small model within 5 combined MCSE of the fp64 dense sampler, and a second potus_init puts a
+    dense handle back at the unit metric and the start of its window schedule (same bytes as a fresh handle)."""
+    from us_potus_model_amd import synthetic
+    data = synthetic.make(S=4, T=12, N_state=30, N_national=8, P=3, seed=3, variant="full")
+    nw = ns = 400
+    runs = {}
+    for st in (_abi.STORAGE_F64, _abi.STORAGE_F32):
+        h = Handle(data, "full", chains=4, num_warmup=nw, num_samples=ns, seed=1843, metric=_abi.METRIC_DENSE, metric_storage=st)
+        h.init(); h.run(nw + ns)
+        runs[st] = h.draws()
+        if st == _abi.STORAGE_F32:
+            assert h.dense_check(0, 2)[0] < 1e-13
+            h.init(); h.run(nw + ns)                           # again from the start
+            assert np.array_equal(runs[st], h.draws())
+        h.close()
+    x, y = runs[_abi.STORAGE_F64][:, :, 7:], runs[_abi.STORAGE_F32][:, :, 7:]
+    assert not np.array_equal(x, y)
+    worst = 0.0
+    for j in range(x.shape[2]):
+        a, b = x[:, :, j], y[:, :, j]
+        se = np.hypot(a.std() / np.sqrt(dg.ess_mean(a)), b.std() / np.sqrt(dg.ess_mean(b)))
+        worst = max(worst, abs(a.mean() - b.mean()) / se)
+    assert worst < 5.0, worst
+    assert abs(runs[_abi.STORAGE_F64][:, :, 1].mean() - runs[_abi.STORAGE_F32][:, :, 1].mean()) < 0.05

@@ -344,6 +344,48 @@ def test_stan_csv_round_trip(cases, tmp_path):
     h.close()
 
 
+@pytest.mark.parametrize("kind", ["diag", "diag_save_warmup", "dense", "dense_save_warmup", "dense_2016"])
+def test_stan_csv_passes_the_strict_reader(cases, tmp_path, kind):
+    """potus_write_stan_csv against tests/stan_csv_reader.py -- what rstan::read_stan_csv (final_2016.R:543) and CmdStan's own
+    grammar of the adaptation block require, restated as assertions (R is not installed here): comment grammar, header, row
+    counts against num_samples / num_warmup / save_warmup, the adaptation block where CmdStan puts it, the inverse metric (one
+    numeric line for diag_e, D lines of D values for dense_e; left out WITHOUT its header line above 2048 parameters), the three
+    Elapsed Time lines; then extract() through the reader equals write_array through the ABI."""
+    from stan_csv_reader import read_stan_csv
+    big = kind == "dense_2016"
+    data, variant = cases["2016" if big else "small_full"]
+    dense, sw = kind.startswith("dense"), kind.endswith("save_warmup")
+    nw, ns, chains = (6, 2, 1) if big else (30, 6, 3)
+    h = Handle(data, variant, chains=chains, num_warmup=nw, num_samples=ns, seed=8, save_warmup=int(sw), metric=_abi.METRIC_DENSE if dense else _abi.METRIC_DIAG,
+               max_depth=4 if big else 10, chain_id_offset=2)
+    h.init(); h.run(nw + ns)
+    files = h.write_stan_csv(tmp_path, "poll_model_2020")
+    fit = read_stan_csv(files)
+    assert fit.model_name == "poll_model_2020" and len(fit.chains) == chains and fit.n_kept == ns and fit.warmup2 == (nw if sw else 0)
+    assert [c.values["chain_id"] for c in fit.chains] == [3 + c for c in range(chains)]
+    assert len(fit.fnames) == h.n_cols and fit.chains[0].values["sampler_t"] == ("NUTS(dense_e)" if dense else "NUTS(diag_e)")
+    S, T = int(data["S"]), int(data["T"])
+    assert fit.dims["raw_mu_b"] == (S, T) and fit.dims["predicted_score"] == (T, S) and fit.dims["mu_e_bias"] == ()
+    eps, minv = h.adaptation()
+    n_saved = ns + (nw if sw else 0)
+    full = h.write_array(0, h.n_cols, n_saved)                                   # [iter, chain, col]
+    for c, ch in enumerate(fit.chains):
+        assert np.isclose(ch.stepsize, eps[c], rtol=1e-5)
+        if dense and not big:
+            assert np.allclose(ch.inv_metric, h.dense_metric(c), rtol=2e-5, atol=1e-12)
+        elif dense:
+            assert ch.inv_metric is None                                          # 15 098 x 15 098 numbers are not text
+        else:
+            assert np.allclose(ch.inv_metric, minv[c], rtol=2e-5)
+        assert np.allclose(ch.rows, full[:, c, :], rtol=2e-5, atol=1e-12)         # %.6g text, as CmdStan writes
+        assert ch.elapsed[0] >= 0 and abs(ch.elapsed[0] + ch.elapsed[1] - ch.elapsed[2]) < 2e-3
+    a, b, _ = h.layout["predicted_score"]
+    ps = fit.extract("predicted_score")                                          # [draws, T, S], chains merged
+    want = np.transpose(full[(nw if sw else 0):, :, a:b], (1, 0, 2)).reshape(chains * ns, S, T).transpose(0, 2, 1)
+    assert ps.shape == (chains * ns, T, S) and np.allclose(ps, want, rtol=2e-5, atol=1e-12)
+    h.close()
+
+
 def test_error_paths(cases):
     data, variant = cases["small_full"]
     h = Handle(data, variant, chains=1, num_warmup=5, num_samples=5)

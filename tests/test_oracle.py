@@ -209,14 +209,12 @@ def test_oracle_posterior_against_everything_the_reference_published(year):
     scores (README.md:75,169,260) -- tests/golden/readme_<year>.csv, made by scripts/make_readme_golden.py.  The
     committed oracle run of the same configuration (8 chains x 1000 + 1000, seed 1843; tests/golden/posterior_<year>.npz,
     made by scripts/make_golden.py posterior) reproduces all 3 x 52 rows to the third decimal the tables are rounded to
-    (observed worst: mean 0.0019, interval ends 0.0043, P(win) 0.031) and the three scores."""
-    import csv
+    (observed worst: mean 0.0019, interval ends 0.0043, P(win) 0.031), the three scores and the RMSE against the certified results."""
+    from conftest import readme_golden, rmse_ex_dc
     from us_potus_model_amd import dataprep
     g = np.load(GOLD / f"posterior_{year}.npz")
     meta = dataprep.load_npz(GOLD / f"data_{year}.npz")["meta"]
-    lines = open(GOLD / f"readme_{year}.csv").read().splitlines()
-    pub = {ln[2:].split(" = ")[0]: float(ln.split(" = ")[1]) for ln in lines if ln.startswith("# ") and " = " in ln}
-    rows = list(csv.DictReader(ln for ln in lines if not ln.startswith("#")))
+    pub, rows = readme_golden(year)
     assert len(rows) == 52
     states = list(meta["states"])
     for r in rows:
@@ -234,6 +232,9 @@ def test_oracle_posterior_against_everything_the_reference_published(year):
     assert abs(np.sum(ev / ev.sum() * (won - p) ** 2) - pub["ev_wtd_brier"]) <= 0.003
     assert abs(np.mean((won - p) ** 2) - pub["unwtd_brier"]) <= 0.002
     assert int(np.sum(np.round(p) == won)) == int(pub["states_correct"])
+    # README.md:79,175,275 -- the only published figures with seven digits: RMSE of the election-day means against the certified
+    # results over the 50 states (observed: 1.3e-4 / 0.8e-4 / 0.7e-4 below the published 0.02318035 / 0.02247233 / 0.02724916)
+    assert abs(rmse_ex_dc(states, g["predicted_score_T__mean"], rows) - pub["rmse_ex_dc"]) <= 3e-4
 
 
 @pytest.mark.parametrize("name", ["small_full", "small_nomode"])

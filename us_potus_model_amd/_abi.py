@@ -14,6 +14,7 @@ VARIANT_NO_MODE = 1  # scripts/model/poll_model_2020_no_mode_adjustment.stan
 VARIANTS = {"full": VARIANT_FULL, "no_mode_adjustment": VARIANT_NO_MODE}
 METRIC_DIAG, METRIC_DENSE = 0, 1
 METRICS = {"diag_e": METRIC_DIAG, "dense_e": METRIC_DENSE}
+STORAGE_F64, STORAGE_F32 = 0, 1
 N_SAMPLER_COLS = 7
 SAMPLER_COLS = ("lp__", "accept_stat__", "stepsize__", "treedepth__", "n_leapfrog__",
                 "divergent__", "energy__")
@@ -50,7 +51,7 @@ class PotusOpts(C.Structure):
         ("delta", C.c_double), ("gamma", C.c_double), ("kappa", C.c_double), ("t0", C.c_double),
         ("stepsize", C.c_double), ("init_radius", C.c_double),
         ("seed", C.c_uint64), ("device", C.c_int32), ("save_warmup", C.c_int32),
-        ("cus_per_chain", C.c_int32), ("metric", C.c_int32), ("twin", C.c_int32),
+        ("cus_per_chain", C.c_int32), ("metric", C.c_int32), ("twin", C.c_int32), ("metric_storage", C.c_int32),
     ]
 
 

@@ -97,7 +97,17 @@ struct DnParams {
   DnRound *rd;                       // [chains]
   int *active;                       // [chains] copy of rd[].active for the host
   int *fail;                         // [1] Cholesky met a non-positive pivot
+  int f32, pad1;                     // potus_opts.metric_storage = f32: M^-1 is kept rounded to fp32 (see dn_f32_row)
 };
+
+// fp32 storage of M^-1 (potus_opts.metric_storage): the matrix pass streams half the bytes.  The rounded matrix IS the metric:
+// the lower triangle of the chain's buffer starts from the rounded values (as doubles) and becomes their Cholesky factor in
+// fp64, so the momentum draw, the kinetic energy and the leapfrog all use exactly the same M^-1 and the sampler stays exact
+// (a declared deviation from Stan, which adapts and stores the covariance in fp64).  Where the floats live: row i of the
+// D x LD buffer holds L's row in doubles [0, i]; its second half is free, so element (i, j), j > i, is the float at index
+// LD + j of the row seen as 2 LD floats -- double index (LD + j) / 2 > i: no overlap, no extra memory.
+__device__ __host__ __forceinline__ float *dn_f32_row(double *A, int LD, int i) { return reinterpret_cast<float *>(A + (size_t)i * LD) + LD; }
+__device__ __host__ __forceinline__ const float *dn_f32_row(const double *A, int LD, int i) { return reinterpret_cast<const float *>(A + (size_t)i * LD) + LD; }
 
 // The chains that take part in a launch of the symmetric product, compacted: idle chains between active ones leave holes in
 // the dispatch order, and the hardware then doubles workgroups up on some compute units while others idle (0.50 instead of
@@ -123,8 +133,9 @@ __device__ __forceinline__ double *dn_vec(const DnParams &P, int chain, int slot
 // column and row sums, written and read once = 3-4 % of the matrix.
 // (job0: the first of the round's jobs this launch serves -- the three products of a transition's first pass go as 2 + 1)
 #define DN_SYMV_LDS(NRHS) ((size_t)((NRHS) * (DN_CT + 2 * DN_RB_MAX) + (DN_THREADS / 64) * (NRHS) * DN_CT) * 8)
-template <int NRHS>
+template <int NRHS, bool F32 = false>
 __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const DnActive act, int job0) {
+  constexpr int NU = F32 ? 2 : 4, NE = F32 ? 4 : 2, RG = F32 ? 2 * DN_RG : DN_RG;   // 16-byte loads per lane and row, elements per load, rows in flight
   extern __shared__ __attribute__((aligned(16))) double dn_lds[];
   const int chain = act.n ? act.idx[blockIdx.y] : (int)blockIdx.y;
   const DnRound &rd = P.rd[chain];
@@ -154,7 +165,10 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
     // a scalar offset, the lane's columns one 32-bit vector offset per load.  (Made wave-uniform explicitly: the compiler
     // otherwise keeps the descriptor in vector registers and wraps every load in a waterfall loop.)
     const int wrows = min(RW, max(0, D - wrow0));
-    const rsrc_t rsA = make_rsrc(uni_ptr(A + (size_t)wrow0 * LD), uni32((unsigned)wrows * rowbytes));
+    // (fp32 storage: the rows' float halves, dn_f32_row; the last row's ends the resource)
+    const rsrc_t rsA = F32 ? make_rsrc(uni_ptr(reinterpret_cast<const char *>(A + (size_t)wrow0 * LD) + 4 * (size_t)LD),
+                                       uni32(wrows > 0 ? (unsigned)(wrows - 1) * rowbytes + 4u * (unsigned)LD : 0u))
+                           : make_rsrc(uni_ptr(A + (size_t)wrow0 * LD), uni32((unsigned)wrows * rowbytes));
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < NRHS; r++)
@@ -165,43 +179,45 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
       for (int r = 0; r < NRHS; r++)
         for (int j = tid; j < DN_CT; j += DN_THREADS) xs[r * DN_CT + j] = c0 + j < D ? x[r][c0 + j] : 0.0;
       __syncthreads();
-      dn_d2 xc[4][NRHS];
-      double t_acc[4][2][NRHS];
-      unsigned voff[4];
+      double xc[NU][NE][NRHS];
+      double t_acc[NU][NE][NRHS];
+      unsigned voff[NU];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        voff[u] = 8u * (unsigned)(c0 + 2 * (lane + 64 * u));
+      for (int u = 0; u < NU; u++) {
+        voff[u] = (F32 ? 4u : 8u) * (unsigned)(c0 + NE * (lane + 64 * u));
 #pragma unroll
-        for (int r = 0; r < NRHS; r++) {
-          xc[u][r] = *(const dn_d2 *)(xs + r * DN_CT + 2 * (lane + 64 * u));
-          t_acc[u][0][r] = 0.0; t_acc[u][1][r] = 0.0;
-        }
+        for (int r = 0; r < NRHS; r++)
+#pragma unroll
+          for (int e = 0; e < NE; e++) { xc[u][e][r] = xs[r * DN_CT + NE * (lane + 64 * u) + e]; t_acc[u][e][r] = 0.0; }
       }
       const bool band = c0 < r0 + RB;                  // the tile overlaps the block's own rows: only j > i counts
 #pragma unroll 1
-      for (int q = 0; q < RW; q += DN_RG) {               // DN_RG rows at a time: 4 DN_RG loads of 16 bytes in flight per lane
-        dn_d2 a[DN_RG][4];
+      for (int q = 0; q < RW; q += RG) {                  // RG rows at a time: 16 loads of 16 bytes in flight per lane
+        u32x4 a[RG][NU];
 #pragma unroll
-        for (int k = 0; k < DN_RG; k++)
+        for (int k = 0; k < RG; k++)
 #pragma unroll
-          for (int u = 0; u < 4; u++)
-            a[k][u] = __builtin_bit_cast(dn_d2, __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[u], (unsigned)(q + k) * rowbytes, 2 /* nt: read once */));
+          for (int u = 0; u < NU; u++)
+            a[k][u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[u], (unsigned)(q + k) * rowbytes, 2 /* nt: read once */);
 #pragma unroll
-        for (int k = 0; k < DN_RG; k++) {
+        for (int k = 0; k < RG; k++) {
           const int lrow = RW * w + q + k;
           const int lim = band ? r0 + lrow : -1;          // no branch: outside the band every column counts
           double xrow[NRHS], sp[NRHS];
 #pragma unroll
           for (int r = 0; r < NRHS; r++) { xrow[r] = xr[r * DN_RB_MAX + lrow]; sp[r] = 0.0; }
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int col = c0 + 2 * (lane + 64 * u);
-            const double a0 = col > lim ? a[k][u][0] : 0.0, a1 = col + 1 > lim ? a[k][u][1] : 0.0;
+          for (int u = 0; u < NU; u++) {
 #pragma unroll
-            for (int r = 0; r < NRHS; r++) {
-              sp[r] += a0 * xc[u][r][0] + a1 * xc[u][r][1];
-              t_acc[u][0][r] += a0 * xrow[r];
-              t_acc[u][1][r] += a1 * xrow[r];
+            for (int e = 0; e < NE; e++) {
+              const int col = c0 + NE * (lane + 64 * u) + e;
+              double av;
+              if (F32) av = (double)__builtin_bit_cast(float, a[k][u][e]);
+              else av = __hiloint2double((int)a[k][u][2 * e + 1], (int)a[k][u][2 * e]);
+              // (fp32: beyond column D a row's float half runs into the next row's doubles, whose halves may read as NaN)
+              const double ae = (col > lim && (!F32 || col < D)) ? av : 0.0;
+#pragma unroll
+              for (int r = 0; r < NRHS; r++) { sp[r] += ae * xc[u][e][r]; t_acc[u][e][r] += ae * xrow[r]; }
             }
           }
           // the row's sum over this tile: across the lanes by DPP (lane 63 ends up with it), then into the block's row sums
@@ -214,10 +230,11 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
       }
       // column sums of this (block, tile): over the 8 waves in wave order
 #pragma unroll
-      for (int u = 0; u < 4; u++)
+      for (int u = 0; u < NU; u++)
 #pragma unroll
         for (int r = 0; r < NRHS; r++)
-          *(dn_d2 *)(tacc + ((size_t)w * NRHS + r) * DN_CT + 2 * (lane + 64 * u)) = dn_d2{t_acc[u][0][r], t_acc[u][1][r]};
+#pragma unroll
+          for (int e = 0; e < NE; e++) tacc[((size_t)w * NRHS + r) * DN_CT + NE * (lane + 64 * u) + e] = t_acc[u][e][r];
       __syncthreads();
       for (int e = tid; e < NRHS * DN_CT; e += DN_THREADS) {
         const int r = e / DN_CT, c = e - r * DN_CT;
@@ -757,9 +774,11 @@ __global__ __launch_bounds__(256) void k_dn_cov(const DnParams P, int n) {
     for (int v = 0; v < 4; v++) {
       const int i = I * DN_NB + 16 * w + kk + 4 * v, j = J * DN_NB + 16 * cb + m;
       if (i < P.D && j < P.D && (I != J || j <= i)) {
-        const double val = f * acc[cb][v] + (i == j ? reg : 0.0);
+        double val = f * acc[cb][v] + (i == j ? reg : 0.0);
+        if (P.f32) val = (double)(float)val;     // the rounded matrix is the metric: the factor below is ITS factor
         A[(size_t)i * P.LD + j] = val;           // lower half: what the factorisation starts from (and overwrites with L)
-        A[(size_t)j * P.LD + i] = val;           // upper half: stays, it IS the metric
+        if (P.f32) { if (i != j) dn_f32_row(A, P.LD, j)[i] = (float)val; }   // upper half as floats in the row's free half
+        else A[(size_t)j * P.LD + i] = val;      // upper half: stays, it IS the metric
         if (i == j) dg[i] = val;
       }
     }
@@ -843,6 +862,29 @@ __global__ __launch_bounds__(256) void k_dn_syrk(const DnParams P, int kb) {
       const int i = I * DN_NB + 16 * w + kk + 4 * v, j = J * DN_NB + 16 * cb + m;
       if (i < P.D && j < P.D && j <= i) L[(size_t)i * P.LD + j] -= acc[cb][v];
     }
+}
+
+// ---------------------------------------------------------------- checks of the factor (potus_dense_check: test hooks)
+// y = L' x and z = L y out of the lower triangle, written for clarity, not speed: with M^-1 x from the sampler's own matrix pass
+// they tell whether L L' is the metric the leapfrog uses, at sizes no host can factor in a test's time.
+__global__ __launch_bounds__(256) void k_dn_chk_ltx(const DnParams P, int chain, int xslot, int yslot) {
+  const double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD, *x = dn_vec(P, chain, xslot);
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= P.D) return;
+  double s = 0.0;
+  for (int i = j; i < P.D; i++) s += L[(size_t)i * P.LD + j] * x[i];
+  dn_vec(P, chain, yslot)[j] = s;
+}
+__global__ __launch_bounds__(256) void k_dn_chk_lx(const DnParams P, int chain, int yslot, int zslot) {
+  __shared__ double red[256];
+  const double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD, *y = dn_vec(P, chain, yslot);
+  const int i = blockIdx.x;
+  double s = 0.0;
+  for (int j = threadIdx.x; j <= i; j += 256) s += L[(size_t)i * P.LD + j] * y[j];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) { if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h]; __syncthreads(); }
+  if (threadIdx.x == 0) dn_vec(P, chain, zslot)[i] = red[0];
 }
 
 // unit metric: M^-1 = L = I (the matrix buffer is zero apart from the diagonal)

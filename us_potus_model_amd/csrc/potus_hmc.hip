@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <charconv>
+#include <chrono>
 #include <thread>
 #include <mutex>
 #include <string>
@@ -811,6 +812,8 @@ struct Sampler {
   hipEvent_t mv0 = nullptr, mv1 = nullptr;
   double mv_ms = 0;                        // time spent in the matrix passes (k_dn_symv + finish, events), their number and the bytes they loaded
   long long mv_calls = 0, mv_bytes = 0, dn_rounds = 0, dn_pass_bytes[2] = {0, 0};   // bytes per pass at DN_RB / DN_RB_MAX rows per workgroup
+  double we_cov_ms = 0, we_chol_ms = 0, we_eps_ms = 0;   // window ends: covariance, factorisation, init_stepsize (host clock around synchronised sections)
+  int we_count = 0;
 };
 
 std::mutex g_mu;
@@ -1373,6 +1376,7 @@ int dense_alloc(Sampler *sp) {
   const int D = sp->L.D, chains = sp->R.chains;
   P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_FIN / 4 - 1) / (DN_FIN / 4); P.nblk = (D + DN_RB - 1) / DN_RB; P.sc_stride = sp->K; P.identity = 1;
   P.win_cap = dense_window_capacity(sp->R.num_warmup, sp->R.init_buffer, sp->R.term_buffer, sp->R.window);
+  P.f32 = sp->opts.metric_storage == POTUS_STORAGE_F32 ? 1 : 0;
   dense_launch_shape(P, chains);
   const size_t mat = (size_t)chains * D * P.LD * 8, vec = (size_t)chains * DV_COUNT * P.LD * 8, win = (size_t)chains * P.win_cap * P.LD * 8;
   const size_t tp = (size_t)chains * (P.nblk + P.ntile) * 3 * P.LD * 8;   // column sums per row block + row sums per column tile
@@ -1398,6 +1402,8 @@ int dense_alloc(Sampler *sp) {
   HIP_TRY(hipEventCreate(&sp->mv0)); HIP_TRY(hipEventCreate(&sp->mv1));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(1)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(2)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(1)));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(2)));
   if (sp->K == 1) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_grad1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
   else for (const void *f : {reinterpret_cast<const void *>(k_dn_gradK<4>), reinterpret_cast<const void *>(k_dn_gradK<8>)})
     HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
@@ -1405,7 +1411,7 @@ int dense_alloc(Sampler *sp) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(sp->stream));
   sp->dn_win_counter = 0; sp->dn_win_size = sp->R.window; sp->dn_win_next = sp->R.init_buffer + sp->R.window - 1; sp->dn_wf_n = 0;
-  sp->dn_pass_bytes[0] = dense_pass_bytes(D, P.LD, DN_RB); sp->dn_pass_bytes[1] = dense_pass_bytes(D, P.LD, DN_RB_MAX);
+  sp->dn_pass_bytes[0] = dense_pass_bytes(D, P.LD, DN_RB) / (P.f32 ? 2 : 1); sp->dn_pass_bytes[1] = dense_pass_bytes(D, P.LD, DN_RB_MAX) / (P.f32 ? 2 : 1);
   return 0;
 }
 
@@ -1415,16 +1421,17 @@ void dense_symv_launch(hipStream_t st, const DnParams &P, const DnActive &act, i
   const int nblk = (P.D + P.rb - 1) / P.rb;
   const unsigned ny = (unsigned)(act.n ? act.n : P.chains);
   const dim3 grid((unsigned)(((nblk + 1) / 2) * P.split), ny), fin((unsigned)P.npart, ny);
-  if (nrhs == 1) {
-    hipLaunchKernelGGL(k_dn_symv<1>, grid, dim3(DN_THREADS), DN_SYMV_LDS(1), st, P, act, 0);
-    hipLaunchKernelGGL(k_dn_symv_finish<1>, fin, dim3(DN_FIN), 0, st, P, act, 0);
-  } else {
-    hipLaunchKernelGGL(k_dn_symv<2>, grid, dim3(DN_THREADS), DN_SYMV_LDS(2), st, P, act, 0);
+  auto one = [&](int job0) {
+    if (P.f32) hipLaunchKernelGGL((k_dn_symv<1, true>), grid, dim3(DN_THREADS), DN_SYMV_LDS(1), st, P, act, job0);
+    else hipLaunchKernelGGL((k_dn_symv<1, false>), grid, dim3(DN_THREADS), DN_SYMV_LDS(1), st, P, act, job0);
+    hipLaunchKernelGGL(k_dn_symv_finish<1>, fin, dim3(DN_FIN), 0, st, P, act, job0);
+  };
+  if (nrhs == 1) one(0);
+  else {
+    if (P.f32) hipLaunchKernelGGL((k_dn_symv<2, true>), grid, dim3(DN_THREADS), DN_SYMV_LDS(2), st, P, act, 0);
+    else hipLaunchKernelGGL((k_dn_symv<2, false>), grid, dim3(DN_THREADS), DN_SYMV_LDS(2), st, P, act, 0);
     hipLaunchKernelGGL(k_dn_symv_finish<2>, fin, dim3(DN_FIN), 0, st, P, act, 0);
-    if (nrhs == 3) {
-      hipLaunchKernelGGL(k_dn_symv<1>, grid, dim3(DN_THREADS), DN_SYMV_LDS(1), st, P, act, 2);
-      hipLaunchKernelGGL(k_dn_symv_finish<1>, fin, dim3(DN_FIN), 0, st, P, act, 2);
-    }
+    if (nrhs == 3) one(2);
   }
 }
 
@@ -1516,9 +1523,14 @@ int dense_window_end(Sampler *sp, int n, unsigned iter) {
   DnParams &P = sp->dn;
   const int D = sp->L.D, chains = sp->R.chains, nb = (D + DN_NB - 1) / DN_NB;
   if (n < 2) return fail(POTUS_ERR_STATE, "adaptation window of %d draws", n);
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  HIP_TRY(hipStreamSynchronize(sp->stream));
+  const double t0 = now();
   hipLaunchKernelGGL(k_dn_center, dn_grid(sp), dim3(256), 0, sp->stream, P, n);
   hipLaunchKernelGGL(k_dn_cov, dim3(nb, nb, chains), dim3(256), 0, sp->stream, P, n);
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(sp->stream));
+  const double t1 = now();
   for (int kb = 0; kb < nb; kb++) {     // in place on the lower triangle; the upper one keeps M^-1
     hipLaunchKernelGGL(k_dn_potrf, dim3(chains), dim3(256), 0, sp->stream, P, kb);
     const int rem = nb - kb - 1;
@@ -1532,9 +1544,11 @@ int dense_window_end(Sampler *sp, int n, unsigned iter) {
   HIP_TRY(hipMemcpyAsync(&failed, P.fail, 4, hipMemcpyDeviceToHost, sp->stream));
   HIP_TRY(hipStreamSynchronize(sp->stream));
   if (failed) return fail(POTUS_ERR_STATE, "the adapted covariance of a chain is not positive definite (window of %d draws)", n);
+  const double t2 = now();
   P.identity = 0;
   int rc;
   if ((rc = dense_init_stepsize(sp, iter))) return rc;
+  sp->we_cov_ms += t1 - t0; sp->we_chol_ms += t2 - t1; sp->we_eps_ms += now() - t2; sp->we_count += 1;
   hipLaunchKernelGGL(k_dn_window_done, dim3((chains + 63) / 64), dim3(64), 0, sp->stream, P, (const RunParams *)sp->dR, (int)iter);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1596,6 +1610,17 @@ int dense_run(Sampler *sp, int n_iter) {
 // potus_init of a dense-metric handle: k_init / k_cl_init have found the initial points and -- the metric being the
 // unit matrix, for which the diagonal and the dense sampler coincide -- the initial step sizes; the points move over
 int dense_import_init(Sampler *sp) {
+  if (!sp->dn.identity || sp->dn_win_counter != 0) {
+    // a second potus_init: back to the unit metric and the start of the window schedule (the upper triangle is what the matrix
+    // pass reads, so the whole matrix goes, not only the flag)
+    DnParams &P = sp->dn;
+    HIP_TRY(hipMemsetAsync(P.A, 0, (size_t)P.chains * P.D * P.LD * 8, sp->stream));
+    HIP_TRY(hipMemsetAsync(P.fail, 0, 4, sp->stream));
+    hipLaunchKernelGGL(k_dn_identity, dim3((P.D + 255) / 256, P.chains), dim3(256), 0, sp->stream, P);
+    HIP_TRY(hipGetLastError());
+    P.identity = 1;
+  }
+  sp->dn_win_counter = 0; sp->dn_win_size = sp->R.window; sp->dn_win_next = sp->R.init_buffer + sp->R.window - 1; sp->dn_wf_n = 0;
   hipLaunchKernelGGL(k_dn_import_q, dim3(64, sp->R.chains), dim3(256), 0, sp->stream, (const RunParams *)sp->dR, sp->dn,
                      sp->K > 1 ? sp->CL.perm : (const int *)nullptr, sp->K > 1 ? sp->CL.Dint : 0);
   HIP_TRY(hipGetLastError());
@@ -1620,7 +1645,7 @@ void potus_default_opts(potus_opts *o) {
   o->chains = 4; o->chain_id_offset = 0; o->num_warmup = 1000; o->num_samples = 1000; o->max_depth = 10;
   o->init_buffer = 75; o->term_buffer = 50; o->window = 25;
   o->delta = 0.8; o->gamma = 0.05; o->kappa = 0.75; o->t0 = 10; o->stepsize = 1.0; o->init_radius = 2.0;
-  o->seed = 1843; o->device = 0; o->save_warmup = 0; o->cus_per_chain = 0; o->metric = POTUS_METRIC_DIAG; o->twin = -1;
+  o->seed = 1843; o->device = 0; o->save_warmup = 0; o->cus_per_chain = 0; o->metric = POTUS_METRIC_DIAG; o->twin = -1; o->metric_storage = POTUS_STORAGE_F64;
 }
 
 int potus_num_params(const potus_data *d, int *D) {
@@ -1675,6 +1700,8 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   if (o->num_warmup < 0 || o->num_samples < 0) return fail(POTUS_ERR_ARG, "negative iteration counts");
   if (o->metric != POTUS_METRIC_DIAG && o->metric != POTUS_METRIC_DENSE) return fail(POTUS_ERR_ARG, "metric must be POTUS_METRIC_DIAG or POTUS_METRIC_DENSE");
   if (o->twin < -1 || o->twin > 1) return fail(POTUS_ERR_ARG, "twin must be -1 (library's choice), 0 or 1");
+  if (o->metric_storage != POTUS_STORAGE_F64 && o->metric_storage != POTUS_STORAGE_F32) return fail(POTUS_ERR_ARG, "metric_storage must be POTUS_STORAGE_F64 or POTUS_STORAGE_F32");
+  if (o->metric_storage == POTUS_STORAGE_F32 && o->metric != POTUS_METRIC_DENSE) return fail(POTUS_ERR_ARG, "metric_storage = f32 applies to the dense metric only");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(POTUS_ERR_DEVICE, "no HIP device: libpotus_hmc needs an MI355X (gfx950)");
   if (o->device < 0 || o->device >= ndev) return fail(POTUS_ERR_DEVICE, "device %d out of range (have %d)", o->device, ndev);
@@ -2105,6 +2132,18 @@ int potus_get_dense_metric(int handle, int chain, double *inv_metric) {
   HIP_TRY(hipSetDevice(sp->device));
   const size_t D = sp->L.D;
   // the strict upper triangle of the chain's matrix is M^-1's (the lower one holds its Cholesky factor), the diagonal a vector
+  if (sp->dn.f32) {   // the upper triangle lives as floats in the second half of each row (dn_f32_row)
+    const size_t LD = sp->dn.LD, rows_at_once = 256;
+    std::vector<double> buf(rows_at_once * LD);
+    for (size_t r0 = 0; r0 < D; r0 += rows_at_once) {
+      const size_t nr = std::min(rows_at_once, D - r0);
+      HIP_TRY(hipMemcpy(buf.data(), sp->dn.A + ((size_t)chain * D + r0) * LD, nr * LD * 8, hipMemcpyDeviceToHost));
+      for (size_t r = 0; r < nr; r++) {
+        const float *f = dn_f32_row(buf.data(), (int)LD, (int)r);
+        for (size_t j = r0 + r + 1; j < D; j++) inv_metric[(r0 + r) * D + j] = (double)f[j];
+      }
+    }
+  } else
   HIP_TRY(hipMemcpy2D(inv_metric, D * 8, sp->dn.A + (size_t)chain * D * sp->dn.LD, (size_t)sp->dn.LD * 8, D * 8, D, hipMemcpyDeviceToHost));
   std::vector<double> dg(D);
   HIP_TRY(hipMemcpy(dg.data(), sp->dn.dg + (size_t)chain * sp->dn.LD, D * 8, hipMemcpyDeviceToHost));
@@ -2124,6 +2163,77 @@ int potus_dense_timing(int handle, double *matvec_ms, long long *passes, long lo
   if (passes) *passes = sp->mv_calls;
   if (bytes) *bytes = sp->mv_bytes;
   if (rounds) *rounds = sp->dn_rounds;
+  return 0;
+}
+
+// Dense metric: what the window ends of the warm-up have cost so far -- milliseconds in the covariance, in the blocked Cholesky
+// factorisation and in the init_stepsize that follows (host clock around synchronised sections), and their number.
+int potus_dense_adapt_timing(int handle, double *cov_ms, double *chol_ms, double *init_stepsize_ms, int *window_ends) {
+  Sampler *sp = get(handle);
+  if (!sp || !sp->dense) return fail(POTUS_ERR_STATE, "bad handle or not a dense-metric sampler");
+  if (cov_ms) *cov_ms = sp->we_cov_ms;
+  if (chol_ms) *chol_ms = sp->we_chol_ms;
+  if (init_stepsize_ms) *init_stepsize_ms = sp->we_eps_ms;
+  if (window_ends) *window_ends = sp->we_count;
+  return 0;
+}
+
+// Dense metric, verification hook (like potus_log_prob_grad): is the factor in the lower triangle the factor of the metric the
+// leapfrog multiplies with?  For n_probe standard-normal vectors x: M^-1 x by the sampler's own matrix pass (upper triangle +
+// diagonal, fp64 or fp32 storage) against L (L' x) by plain kernels over the lower triangle; and the momentum draw's own blocked
+// back substitution L' p = u, checked by multiplying back.  out[0] = max ||L L' x - M^-1 x|| / ||M^-1 x||, out[1] = ||L' p - u|| / ||u||.
+int potus_dense_check(int handle, int chain, int n_probe, double *out) {
+  Sampler *sp = get(handle);
+  if (!sp || !out) return fail(POTUS_ERR_STATE, "bad handle or null output");
+  if (!sp->dense) return fail(POTUS_ERR_STATE, "the handle runs the diagonal metric");
+  if (chain < 0 || chain >= sp->R.chains || n_probe < 1) return fail(POTUS_ERR_ARG, "potus_dense_check: bad chain or probe count");
+  std::lock_guard<std::mutex> cluster_lock(g_cluster_mu);
+  HIP_TRY(hipSetDevice(sp->device));
+  DnParams &P = sp->dn;
+  const int D = P.D, chains = P.chains;
+  std::vector<DnRound> rds(chains);
+  for (int c = 0; c < chains; c++) { std::memset(&rds[c], 0, sizeof(DnRound)); rds[c].active = c == chain; }
+  rds[chain].job[0] = DnJob{DV_TMPP, DV_SCR1, -1, -1, -1, 0, 0.0};              // SCR1 = M^-1 TMPP
+  HIP_TRY(hipMemcpyAsync(P.rd, rds.data(), rds.size() * sizeof(DnRound), hipMemcpyHostToDevice, sp->stream));
+  for (int c = 0; c < chains; c++) sp->h_active[c] = c == chain;
+  std::vector<double> a(D), b(D);
+  auto fetch = [&](int slot, std::vector<double> &v) {
+    return hipMemcpyAsync(v.data(), P.state + ((size_t)chain * DV_COUNT + slot) * P.LD, (size_t)D * 8, hipMemcpyDeviceToHost, sp->stream);
+  };
+  out[0] = out[1] = 0.0;
+  for (int k = 0; k <= n_probe; k++) {
+    // standard normals -> P0; the last round solves L' p = u with the sampler's kernels and multiplies back
+    const bool solve = k == n_probe;
+    rds[chain].aux = k;
+    HIP_TRY(hipMemcpyAsync(&P.rd[chain].aux, &rds[chain].aux, sizeof(int), hipMemcpyHostToDevice, sp->stream));
+    const int id0 = P.identity;
+    if (!solve) P.identity = 1;                                                  // (dense_sample_p: normals only)
+    const int rc = dense_sample_p(sp, 0x7ffffff0u, RNG_INIT_EPS);
+    P.identity = id0;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(P.state + ((size_t)chain * DV_COUNT + DV_TMPP) * P.LD, P.state + ((size_t)chain * DV_COUNT + DV_P0) * P.LD, (size_t)D * 8,
+                           hipMemcpyDeviceToDevice, sp->stream));
+    hipLaunchKernelGGL(k_dn_chk_ltx, dim3((D + 255) / 256), dim3(256), 0, sp->stream, P, chain, (int)DV_TMPP, (int)DV_TMPQ);   // TMPQ = L' TMPP
+    if (solve) {
+      P.identity = 1;
+      const int rc2 = dense_sample_p(sp, 0x7ffffff0u, RNG_INIT_EPS);            // the same normals again: u
+      P.identity = id0;
+      if (rc2) return rc2;
+      HIP_TRY(fetch(DV_TMPQ, a)); HIP_TRY(fetch(DV_P0, b));
+    } else {
+      hipLaunchKernelGGL(k_dn_chk_lx, dim3(D), dim3(256), 0, sp->stream, P, chain, (int)DV_TMPQ, (int)DV_SCR0);                 // SCR0 = L L' x
+      DnActive act; act.n = 1; act.idx[0] = chain;
+      dense_launch_shape(P, 1);
+      dense_symv_launch(sp->stream, P, act, 1);
+      HIP_TRY(fetch(DV_SCR0, a)); HIP_TRY(fetch(DV_SCR1, b));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(sp->stream));
+    double num = 0, den = 0;
+    for (int i = 0; i < D; i++) { num += (a[i] - b[i]) * (a[i] - b[i]); den += b[i] * b[i]; }
+    const double rel = std::sqrt(num / std::max(den, 1e-300));
+    if (solve) out[1] = rel; else out[0] = std::max(out[0], rel);
+  }
   return 0;
 }
 
@@ -2349,22 +2459,38 @@ int potus_write_stan_csv(int handle, const char *dir, const char *basename) {
     fprintf(f, "\n");
   }
   // CmdStan writes the adaptation block when warm-up ends: straight after the header without save_warmup, after the
-  // warm-up rows with it
-  auto adaptation_block = [&](int c) {
-    FILE *f = fp[c];
-    if (sp->dense) {   // CmdStan: "# Elements of inverse mass matrix:" and D rows of D values
-      fprintf(f, "# Adaptation terminated\n# Step size = %.6g\n# Elements of inverse mass matrix:\n", eps[c]);
+  // warm-up rows with it.  The text is prepared here, on the calling thread (the dense metric comes off the device), so that
+  // the writer threads below only copy it.  dense_e: "# Elements of inverse mass matrix:" and D rows of D values, as CmdStan --
+  // up to 2048 parameters; beyond that the matrix is left out TOGETHER WITH its header line (a reader that has seen the
+  // header expects D rows; rstan keeps the block as text, potus_get_dense_metric returns the matrix).
+  std::vector<std::string> adapt_txt(chains);
+  for (int c = 0; c < chains; c++) {
+    std::string &t = adapt_txt[c];
+    char num[64];
+    std::snprintf(num, sizeof num, "# Adaptation terminated\n# Step size = %.6g\n", eps[c]);
+    t = num;
+    auto put_row = [&](const double *v, int n) {
+      t += "# ";
+      for (int j = 0; j < n; j++) { std::snprintf(num, sizeof num, j ? ", %.6g" : "%.6g", v[j]); t += num; }
+      t += "\n";
+    };
+    if (sp->dense) {
       if (D <= 2048) {
         std::vector<double> mm((size_t)D * D);
-        if (potus_get_dense_metric(handle, c, mm.data()) == 0)
-          for (int i = 0; i < D; i++) { fprintf(f, "# "); for (int j = 0; j < D; j++) fprintf(f, j ? ", %.6g" : "%.6g", mm[(size_t)i * D + j]); fprintf(f, "\n"); }
-      } else fprintf(f, "# (%d x %d matrix omitted from the CSV: potus_get_dense_metric returns it)\n", D, D);
-      return;
+        if ((rc = potus_get_dense_metric(handle, c, mm.data()))) { close_all(); return rc; }
+        t += "# Elements of inverse mass matrix:\n";
+        for (int i = 0; i < D; i++) put_row(mm.data() + (size_t)i * D, D);
+      } else {
+        std::snprintf(num, sizeof num, "# (dense inverse metric, %d x %d", D, D);
+        t += num;
+        t += ": left out of the CSV, see potus_get_dense_metric)\n";
+      }
+    } else {
+      t += "# Diagonal elements of inverse mass matrix:\n";
+      put_row(minv.data() + (size_t)c * D, D);
     }
-    fprintf(f, "# Adaptation terminated\n# Step size = %.6g\n# Diagonal elements of inverse mass matrix:\n# ", eps[c]);
-    for (int i = 0; i < D; i++) fprintf(f, i ? ", %.6g" : "%.6g", minv[(size_t)c * D + i]);
-    fprintf(f, "\n");
-  };
+  }
+  auto adaptation_block = [&](int c) { fwrite(adapt_txt[c].data(), 1, adapt_txt[c].size(), fp[c]); };
   const int n_warm_rows = sp->opts.save_warmup ? std::min(n_saved, sp->R.num_warmup) : 0;
   if (n_warm_rows == 0) for (int c = 0; c < chains; c++) adaptation_block(c);
   // stream the rows in blocks of draws: rows come back as [iter][chain][ncols]
@@ -2605,7 +2731,7 @@ void potus_R_create(int *dims, int *state, int *day_state, int *day_national, in
   d.polling_bias_scale = scalars[8]; d.state_covariance_0 = state_covariance_0;
   potus_opts o; potus_default_opts(&o);
   o.chains = iopts[0]; o.chain_id_offset = iopts[1]; o.num_warmup = iopts[2]; o.num_samples = iopts[3]; o.max_depth = iopts[4];
-  o.device = iopts[5]; o.save_warmup = iopts[6]; o.cus_per_chain = iopts[7]; o.metric = iopts[8]; o.twin = iopts[9];
+  o.device = iopts[5]; o.save_warmup = iopts[6]; o.cus_per_chain = iopts[7]; o.metric = iopts[8]; o.twin = iopts[9]; o.metric_storage = iopts[10];
   o.delta = dopts[0]; o.gamma = dopts[1]; o.kappa = dopts[2]; o.t0 = dopts[3]; o.stepsize = dopts[4]; o.init_radius = dopts[5];
   if (!(dopts[6] >= 0) || dopts[6] > 9007199254740992.0 || dopts[6] != std::floor(dopts[6])) { *status = fail(POTUS_ERR_ARG, "seed must be a non-negative integer below 2^53"); return; }
   o.seed = (uint64_t)dopts[6];   // R integers are 32 bits wide: the seed travels as a double (exact to 2^53)

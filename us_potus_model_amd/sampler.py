@@ -88,7 +88,7 @@ EXPORTS = [
     "potus_version", "potus_last_error", "potus_default_opts", "potus_num_params", "potus_num_columns",
     "potus_column_name", "potus_create", "potus_destroy", "potus_cus_per_chain", "potus_clusters_per_chain", "potus_twin_stats", "potus_log_prob_grad", "potus_init", "potus_run", "potus_run_many",
     "potus_iterations_done", "potus_total_leapfrogs", "potus_chain_status", "potus_get_adaptation",
-    "potus_get_dense_metric", "potus_dense_timing", "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_array_device", "potus_write_stan_csv",
+    "potus_get_dense_metric", "potus_dense_timing", "potus_dense_adapt_timing", "potus_dense_check", "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_array_device", "potus_write_stan_csv",
     "potus_last_run_timing", "potus_posterior_summary", "potus_posterior_summary_many", "potus_backtest_scores",
     "potus_R_create", "potus_R_init", "potus_R_run", "potus_R_run_many", "potus_R_num_columns", "potus_R_saved_count",
     "potus_R_write_array", "potus_R_write_stan_csv", "potus_R_posterior_summary", "potus_R_backtest_scores", "potus_R_last_error", "potus_R_destroy",
@@ -241,6 +241,22 @@ class Handle:
         _check(L, L.potus_dense_timing(self.h, C.byref(ms), C.byref(n), C.byref(b), C.byref(r)))
         return ms.value, n.value, b.value, r.value
 
+    def dense_adapt_timing(self):
+        """metric = dense_e: dict(cov_ms, chol_ms, init_stepsize_ms, window_ends) of the warm-up's window ends so far."""
+        L = self.L
+        L.potus_dense_adapt_timing.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        _check(L, L.potus_dense_adapt_timing(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return dict(cov_ms=a.value, chol_ms=b.value, init_stepsize_ms=c.value, window_ends=n.value)
+
+    def dense_check(self, chain=0, n_probe=2):
+        """metric = dense_e: (max ||L L' x - M^-1 x|| / ||M^-1 x|| over n_probe random x, ||L' p - u|| / ||u|| of the momentum solve)."""
+        L = self.L
+        L.potus_dense_check.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        out = np.zeros(2)
+        _check(L, L.potus_dense_check(self.h, int(chain), int(n_probe), _dp(out)))
+        return float(out[0]), float(out[1])
+
     def dense_metric(self, chain=0):
         """metric = dense_e: the adapted D x D inverse metric of one chain."""
         out = np.zeros((self.D, self.D))
@@ -389,7 +405,8 @@ class PotusModel:
 
     def sample(self, data, seed=1843, chains=4, parallel_chains=None, iter_warmup=1000, iter_sampling=1000,
                refresh=100, adapt_delta=0.8, max_treedepth=10, init=2.0, save_warmup=False, device=0,
-               chain_id_offset=0, show_messages=False, inits=None, devices=None, metric="diag_e", cus_per_chain=0, twin=-1):
+               chain_id_offset=0, show_messages=False, inits=None, devices=None, metric="diag_e", cus_per_chain=0, twin=-1,
+               metric_storage="f64"):
         """`devices`: GPU ids; the chains are dealt to them in consecutive blocks and advance together under
         potus_run_many (one host thread).  Chain ids -- hence RNG streams and draws -- do not depend on the split."""
         from . import parallel
@@ -402,7 +419,8 @@ class PotusModel:
             h = Handle(data, self.variant, chains=n_loc, chain_id_offset=int(chain_id_offset) + off,
                        num_warmup=int(iter_warmup), num_samples=int(iter_sampling), max_depth=int(max_treedepth),
                        delta=float(adapt_delta), init_radius=float(init), seed=int(seed), device=dev,
-                       save_warmup=int(bool(save_warmup)), metric=_abi.METRICS[metric], cus_per_chain=int(cus_per_chain), twin=int(twin))
+                       save_warmup=int(bool(save_warmup)), metric=_abi.METRICS[metric], cus_per_chain=int(cus_per_chain), twin=int(twin),
+                       metric_storage={"f64": _abi.STORAGE_F64, "f32": _abi.STORAGE_F32}[metric_storage])
             h.init(None if inits is None else np.asarray(inits)[off:off + n_loc])
             hs.append(h)
         total = int(iter_warmup) + int(iter_sampling)
