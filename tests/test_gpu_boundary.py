@@ -243,6 +243,31 @@ def test_readme_tables_of_the_three_backtests(cases):
         assert abs(sc["rmse_ex_dc"] - meta["rmse_ex_dc"]) <= TOL_RMSE, (year, sc, meta)
 
 
+@pytest.mark.parametrize("what,factor", [("sigma_m", 1.5), ("sigma_pop", 1.5)])
+def test_the_readme_pins_notice_a_wrong_mode_or_population_effect(cases, what, factor):
+    """What the pins to the reference are worth for the parts of the model that election-day predicted_score only feels indirectly
+    (VERDICT r02): with the prior scale of the poll-mode / poll-population effects off by half, the 2016 backtest no longer meets
+    the published EV-weighted Brier score and RMSE within the tolerances test_readme_tables_of_the_three_backtests uses
+    (scripts/pin_sensitivity.py -> profiles/r03_pin_sensitivity.txt lists every scale: of the nine, only the pollster scale
+    sigma_c moves no pin; mu_c rests on the transcription test and finite differences)."""
+    from conftest import rmse_ex_dc
+    data, variant = cases["2016"]
+    d = dict(data)
+    d[what] = float(data[what]) * factor
+    meta_d = dataprep.load_npz(GOLD / "data_2016.npz")["meta"]
+    pub, rows = _readme("2016")
+    states, ev = list(meta_d["states"]), np.asarray(meta_d["ev_state"], dtype=np.float64)
+    h = Handle(d, variant, chains=4, num_warmup=1000, num_samples=1000, seed=1843)
+    h.init(); h.run(2000)
+    sm = h.posterior_summary(ev)
+    h.close()
+    T = int(d["T"])
+    won = np.array([int(next(r for r in rows if r["state"] == s)["won_readme"]) for s in states])
+    sc = backtest_scores(sm, ev, won)
+    assert abs(sc["ev_wtd_brier"] - pub["ev_wtd_brier"]) > TOL_BRIER, sc
+    assert abs(rmse_ex_dc(states, sm["state"][T - 1, :, 2], rows) - pub["rmse_ex_dc"]) > TOL_RMSE, sc
+
+
 def test_summaries_beyond_one_lds_sort_and_over_several_handles(cases):
     """More pooled draws than one 16 384-element LDS sort holds (the selection over several sorted runs), the chains
     of the posterior spread over two handles: equal to the numpy restatement of final_2016.R:708-762, 799-823."""

@@ -48,7 +48,9 @@
 
 // fields of one member's part descriptor (ints)
 enum { CP_D0 = 0, CP_ND, CP_P0, CP_NP, CP_E0, CP_NE, CP_R0, CP_NR, CP_NSUB, CP_NSEG, CP_WB,
-       CP_O_WD, CP_O_MASK, CP_O_SUB, CP_O_SEGPTR, CP_O_SEGKIND, CP_O_SEGIDX, CP_O_WT, CP_E_SH, CP_N = 20 };
+       CP_O_WD, CP_O_MASK, CP_O_SUB, CP_O_SEGPTR, CP_O_SEGKIND, CP_O_SEGIDX, CP_O_WT, CP_E_SH, CP_NCELL, CP_O_CELL, CP_N = 24 };
+#define CL_CELLS_PER_THREAD 2            // (state, day) cells of a member's polls per thread in the adjoint scatter (<= 1024 cells)
+#define CL_G_PAD 16                      // spare doubles behind G: the dump slot of idle scatter threads
 // payload layout of exchange X2 (doubles); X1 and the scalar all-reduces use the first words
 enum { XP_PRE = 0, XP_AR = 64, XP_S = 66, XP_P = 72 };
 // the exchange sent ahead from the epilogue: words [0, S) suffix totals of the next position (X1), [XQ0, XQ0 + NREP) the
@@ -64,6 +66,7 @@ struct ClModel {
   const int *rep_owner;     // [NREP] member that owns each of them
   const double *rep_scale;  // [NR] scale of owned slot r (sigma_c ... ; 1 for zT, zb)
   const int *perm;          // [D] internal index -> Stan index
+  int l_G, GS, GROWS;       // adjoint on the matrix cores (cl_adjoint_mfma): G[pseudo-state][local day], row stride, rows (0: gather walk)
   int l_C, l_Lw, l_LT, l_LB, l_w, l_prior, l_pm, l_py, l_pN, l_pun, l_sub, l_tab, l_ru, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_pb, l_e, l_c1, l_c2, l_c3, l_gs, l_ge, l_P, l_scal, l_red, l_st, l_prof;
   int lds_doubles;
 };
@@ -466,6 +469,7 @@ struct ClStatic {           // per-thread registers that never change during a k
   unsigned rep_xo[2];       // the same parameters as exchange words of their owners (member * XW + XQ0 + index) * 16
   int sg_a, sg_b, sg_kind, sg_index;   // level-2 segment summed by this thread: task range, what the sum feeds
   double scale_r;           // scale of the small-vector slot this thread owns (threads 128 ..)
+  int cellw[CL_CELLS_PER_THREAD];   // adjoint scatter: first poll (10 bits) | polls (6 bits) | offset of the cell in G (16 bits); idle: the dump slot
 };
 
 __device__ __forceinline__ ClStatic cl_load_static(CCp CL, cip part) {
@@ -487,11 +491,16 @@ __device__ __forceinline__ ClStatic cl_load_static(CCp CL, cip part) {
   {
     gcip sch = as_g(CL->sched);
     const int nseg = part[CP_NSEG];
-    const bool ok = tid < nseg;
-    c.sg_a = ok ? sch[part[CP_O_SEGPTR] + tid] : 0;
-    c.sg_b = ok ? sch[part[CP_O_SEGPTR] + tid + 1] : 0;
-    c.sg_kind = ok ? sch[part[CP_O_SEGKIND] + tid] : 3;
-    c.sg_index = ok ? sch[part[CP_O_SEGIDX] + tid] : 0;
+    // with the adjoint on the matrix cores the level-2 sums share a barrier interval with it: the segments go to the upper
+    // waves first (waves 0-3 run the MFMA chains)
+    const int sg = CL->l_G ? ((tid + PT_THREADS / 2) & (PT_THREADS - 1)) : tid;
+    const bool ok = sg < nseg;
+    c.sg_a = ok ? sch[part[CP_O_SEGPTR] + sg] : 0;
+    c.sg_b = ok ? sch[part[CP_O_SEGPTR] + sg + 1] : 0;
+    c.sg_kind = ok ? sch[part[CP_O_SEGKIND] + sg] : 3;
+    c.sg_index = ok ? sch[part[CP_O_SEGIDX] + sg] : 0;
+#pragma unroll
+    for (int h = 0; h < CL_CELLS_PER_THREAD; h++) c.cellw[h] = CL->l_G ? sch[part[CP_O_CELL] + h * PT_THREADS + tid] : 0;
     const int jr = tid - 128;
     c.scale_r = (jr >= 0 && jr < part[CP_NR]) ? as_g(CL->rep_scale)[part[CP_R0] + jr] : 0.0;
   }
@@ -549,6 +558,8 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
     const int n16 = part[CP_NSUB] * PT_SUBLEN;
     for (int i = threadIdx.x; i < n16; i += PT_THREADS) sb[i] = (unsigned short)src_sub[i];
   }
+  // G: zero once; the scatter of every pass rewrites the same cells (the poll structure is static), everything else stays zero
+  if (CL->l_G) for (int i = threadIdx.x; i < CL->GROWS * CL->GS + CL_G_PAD; i += PT_THREADS) (lds + CL->l_G)[i] = 0.0;
   const ClStatic c = cl_load_static(CL, part);
 #ifdef POTUS_PROF
   for (int i = threadIdx.x; i < PT_NPROF; i += PT_THREADS) (lds + CL->l_prof)[i] = 0.0;
@@ -577,6 +588,7 @@ __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstl
 template <int CL_DW, class Pol>
 __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_in, ldp lds, const ClStatic &cst, Xch &x, Pol &pol_io,
                                                   bool pubnext, const LeafCtx &pend, ltp ts, ldp wout, bool &aborted) {
+  constexpr bool MF = CL_DW == 4;                   // the adjoint product on the matrix cores (the 8-days-per-wave build keeps the gather walk)
   Pol pol = pol_io;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
@@ -912,7 +924,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // readlane; lanes < S keep the running sum over the chunk, lane 63 the day's sum of unadjusted * residual
   // (the adjoint input of e_bias[t]).  At the last poll of a day the running values go to LDS; the owners
   // of the days pick them up in phase E.  Level-1 segment sums follow.
-  {
+  if constexpr (!MF) {
     const unsigned AS_L *tab = (const unsigned AS_L *)(lds + CL->l_tab);
     const int lk = lane < S ? lane : 0;
     const int ca = __builtin_amdgcn_readfirstlane(cst.ca), cb = __builtin_amdgcn_readfirstlane(cst.cb);
@@ -943,6 +955,21 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       }
     }
     if (lane < S) X[w * SE + lane] = acc;          // chunk total
+  }
+  if constexpr (MF) {
+    // Adjoint on the matrix cores, step 1: G[pseudo-state][local day] = sum of the residuals of the cell's polls (the polls of a
+    // member are sorted by day, then state: a cell is a run).  One thread per cell; polls of day T are left out (they feed
+    // mu_b_T only, stan:85-86).  Idle threads write the dump slot behind G.
+    ldp G = lds + CL->l_G;
+#pragma unroll
+    for (int h = 0; h < CL_CELLS_PER_THREAD; h++) {
+      if (h == 0 || part[CP_NCELL] > h * PT_THREADS) {     // wave-uniform
+        const int cw = cst.cellw[h], a = cw & 1023, cnt = (cw >> 10) & 63, off = (int)((unsigned)cw >> 16);
+        double sum = r_lds[a];                           // a cell has at least one poll; idle threads read the zero slot np
+        for (int i = 1; i < cnt; i++) sum += r_lds[a + i];
+        G[off] = sum;
+      }
+    }
   }
   {
     const int nsub = part[CP_NSUB], wb = part[CP_WB];   // tasks from wb on sum unadjusted * residual (day sums)
@@ -975,7 +1002,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   int tlast[CL_DW], ch[CL_DW];
   double cv[CL_DW];
   double chunk_total = 0.0;
-  {
+  if constexpr (!MF) {
 #pragma unroll
     for (int j = 0; j < CL_DW; j++) {
       const int info = __builtin_amdgcn_readlane(cst.s2info, j);
@@ -990,6 +1017,55 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       ISSUE_FENCE();
 #pragma unroll
       for (int c = 0; c < PT_NW; c++) { X[c * SE + lx] = chunk_total; chunk_total += ct[c]; }
+    }
+  } else {
+    (void)tlast; (void)ch; (void)cv;
+    // Adjoint on the matrix cores, step 2: gC[k][t] = sum_s Lw_ext[s][k] G[s][t] as 16 x 16 x 4 fp64 MFMA tiles
+    // (v_mfma_f64_16x16x4_f64: lane l feeds A[l & 15][l >> 4] = Lw_ext[4 st + (l >> 4)][16 kt + (l & 15)] and
+    // B[l >> 4][l & 15] = G[4 st + (l >> 4)][16 tt + (l & 15)] and holds D[(l >> 4) + 4 v][l & 15]), wave kt < 4 the 16 columns
+    // k of its tile, the tiles of 16 days one after the other.  What the owners of the days need is the PREFIX over days
+    // (dZ[:, t] = sum_{u <= t} gC[:, u] - Z[:, t]): the days of a tile sit in the 16 lanes of a DPP row, so the prefix is four
+    // row_shr steps on the accumulators, plus the running total of the earlier tiles.  Its cost does not depend on the number
+    // of polls: the member that owns the poll-dense last days no longer sets the pace of the cluster.
+    if (w < 4) {
+      ldp G = lds + CL->l_G;
+      const int GS = CL->GS, nst = CL->GROWS >> 2, g = lane >> 4, n = lane & 15;
+      const int nt = (nd + 15) >> 4;
+      double carry[4] = {0.0, 0.0, 0.0, 0.0};
+      constexpr int NST = 16;                       // up to 64 (pseudo-)states
+      for (int tt = 0; tt < nt; tt++) {             // wave-uniform
+        typedef double d4_t __attribute__((ext_vector_type(4)));
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int h0 = 0; h0 < NST; h0 += 8) {       // eight steps' operands in flight at a time (registers)
+          double av[8], bv[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int st = h0 + u;
+            av[u] = Lw[min(4 * st + g, SE) * SP + 16 * w + n];            // rows beyond the pseudo-state: the zero row of Lw_ext
+            bv[u] = G[min(4 * st + g, 4 * nst - 1) * GS + 16 * tt + n];
+          }
+          ISSUE_FENCE();
+#pragma unroll
+          for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);   // (steps beyond nst multiply zero rows)
+          ISSUE_FENCE();
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          double x = acc[v];
+          x += dpp_fetch<DPP_ROW_SHR(1), 0xf>(0.0, x);
+          x += dpp_fetch<DPP_ROW_SHR(2), 0xf>(0.0, x);
+          x += dpp_fetch<DPP_ROW_SHR(4), 0xf>(0.0, x);
+          x += dpp_fetch<DPP_ROW_SHR(8), 0xf>(0.0, x);
+          x += carry[v];
+          const int k = 16 * w + g + 4 * v, t = 16 * tt + n;
+          if (k < S && t < nd) C[k * NDP + t] = x;
+          // the tile's last day (lane 15 of the row) to every lane of the row: ds_swizzle, lane <- (lane & 0x10) | 0xf
+          const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+          const unsigned lo = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)u, 0x1f0), hi = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)(u >> 32), 0x1f0);
+          carry[v] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        }
+      }
     }
   }
   {
@@ -1015,11 +1091,18 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   double arA = 1.0, arB = 0.0;                      // wave 1 keeps its per-day adjoint composites for phase F
   double pay = 0.0;                                 // the word this lane publishes (wave 0: prefix total, wave 1: AR words)
   double pre[CL_DW];
+  if constexpr (!MF) {
 #pragma unroll
-  for (int j = 0; j < CL_DW; j++) {
-    const double cc = X[ch[j] * SE + (lane < S ? lane : S)];
-    pre[j] = tlast[j] >= 0 ? cv[j] + cc : 0.0;
+    for (int j = 0; j < CL_DW; j++) {
+      const double cc = X[ch[j] * SE + (lane < S ? lane : S)];
+      pre[j] = tlast[j] >= 0 ? cv[j] + cc : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < CL_DW; j++) pre[j] = C[(lane < S ? lane : 0) * NDP + min(wd0 + j, max(nd - 1, 0))];   // (days beyond the wave's: unused)
+    if (w == 0) chunk_total = nd > 0 ? C[(lane < S ? lane : 0) * NDP + nd - 1] : 0.0;
   }
+  ldp C2 = MF ? C + S * NDP : C;                    // where the partial transposed mat-vecs go: with MF the prefix block is still being read
   if (w == 0) {
     pay = chunk_total;
   } else if (w == 1) {
@@ -1060,7 +1143,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     ISSUE_FENCE();
 #pragma unroll
     for (int j = 0; j < NJ; j++) { pT += lt[j] * gg[j]; pB += lb[j] * gg[j]; }
-    if (lane < S) { C[wj * SE + lane] = pT; C[(6 + wj) * SE + lane] = pB; }
+    if (lane < S) { C2[wj * SE + lane] = pT; C2[(6 + wj) * SE + lane] = pB; }
   }
   xst(x, (w == 0 && lane < S) ? 16u * (unsigned)(XP_PRE + lane) : (w == 1 && full && lane < 5) ? 16u * (unsigned)(XP_AR + lane) : PT_OOB, pay);
   __syncthreads();
@@ -1076,7 +1159,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       const int which = rc >= S, k = rc < 2 * S ? rc - which * S : 0;
       double v6[6];
 #pragma unroll
-      for (int w2 = 0; w2 < 6; w2++) v6[w2] = C[(which * 6 + w2) * SE + k];
+      for (int w2 = 0; w2 < 6; w2++) v6[w2] = C2[(which * 6 + w2) * SE + k];
       const double vp = s_P[rc];
       ISSUE_FENCE();
       const double v = rc < 2 * S ? ((((v6[0] + v6[1]) + v6[2]) + v6[3]) + v6[4]) + v6[5] : vp;

@@ -98,6 +98,7 @@ struct DnParams {
   int *active;                       // [chains] copy of rd[].active for the host
   int *fail;                         // [1] Cholesky met a non-positive pivot
   int f32, pad1;                     // potus_opts.metric_storage = f32: M^-1 is kept rounded to fp32 (see dn_f32_row)
+  unsigned long long *act_passes;    // [1] (chain, matrix pass) pairs that really ran: the bytes the passes streamed, whatever the host believed
 };
 
 // fp32 storage of M^-1 (potus_opts.metric_storage): the matrix pass streams half the bytes.  The rounded matrix IS the metric:
@@ -212,8 +213,8 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
             for (int e = 0; e < NE; e++) {
               const int col = c0 + NE * (lane + 64 * u) + e;
               double av;
-              if (F32) av = (double)__builtin_bit_cast(float, a[k][u][e]);
-              else av = __hiloint2double((int)a[k][u][2 * e + 1], (int)a[k][u][2 * e]);
+              if constexpr (F32) av = (double)__builtin_bit_cast(float, a[k][u][e]);
+              else av = __hiloint2double((int)a[k][u][2 * e + 1], (int)a[k][u][2 * e]);   // (constexpr: the other branch would index past the vector)
               // (fp32: beyond column D a row's float half runs into the next row's doubles, whose halves may read as NaN)
               const double ae = (col > lim && (!F32 || col < D)) ? av : 0.0;
 #pragma unroll
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(DN_FIN) void k_dn_symv_finish(const DnParams P, con
   if (lane == 0) dn_part[w] = tot;
   __syncthreads();
   if (threadIdx.x == 0 && job0 == 0) P.partial[(size_t)chain * P.npart + blockIdx.x] = dn_part[0];   // (k4 == 0 is wave 0)
+  if (threadIdx.x == 0 && blockIdx.x == 0 && P.act_passes) atomicAdd(P.act_passes, 1ull);
 }
 
 // ---------------------------------------------------------------- elementwise pieces of a round

@@ -810,6 +810,8 @@ struct Sampler {
   int *h_active = nullptr;                 // pinned host copy of the per-chain activity flags
   int dn_win_counter = 0, dn_win_next = 0, dn_win_size = 0, dn_wf_n = 0;   // host mirror of the warm-up window schedule
   hipEvent_t mv0 = nullptr, mv1 = nullptr;
+  static constexpr int DN_AHEAD = 4;       // leaf rounds the host keeps queued beyond the one whose activity flags it has seen
+  hipEvent_t rv0[DN_AHEAD] = {}, rv1[DN_AHEAD] = {}, rdone[DN_AHEAD] = {};   // per queued round: around its matrix pass, after its flag copy
   double mv_ms = 0;                        // time spent in the matrix passes (k_dn_symv + finish, events), their number and the bytes they loaded
   long long mv_calls = 0, mv_bytes = 0, dn_rounds = 0, dn_pass_bytes[2] = {0, 0};   // bytes per pass at DN_RB / DN_RB_MAX rows per workgroup
   double we_cov_ms = 0, we_chol_ms = 0, we_eps_ms = 0;   // window ends: covariance, factorisation, init_stepsize (host clock around synchronised sections)
@@ -1089,6 +1091,10 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   if (groups_for(lo, &cut) > K) return fail(POTUS_ERR_UNSUPPORTED, "T = %d days do not fit %d members of at most %d days", T, K, maxdays);
   while ((int)cut.size() < K + 1) cut.push_back(T);   // members without days still own a share of the small vectors
 
+  // the adjoint product on the fp64 matrix cores (potus_cluster.hpp, cl_pass_partial): G[pseudo-state][local day], row stride
+  // = 16 mod 32 doubles (the four rows a wave reads per MFMA step fall on disjoint LDS banks)
+  const bool mfma = DW == 4;
+  const int GS = 48, GROWS = 4 * ((M.SE + 3) / 4);
   std::vector<int> part((size_t)K * CP_N, 0), sched, perm;   // perm: internal index -> Stan index, -1 for padding
   std::vector<double> wts;
   int e = 0, npmax = 0, nsubmax = 0;
@@ -1167,6 +1173,27 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
         while (tl >= 0 && dp[d0 + tl + 1] == dp[d0 + tl]) tl--;   // last day with polls at or before this one
         s2info[wv * 64 + j] = tl < 0 ? 0 : ((tl + 1) | (chunk_of(dp[d0 + tl + 1] - 1 - p0) << 8));
       }
+    // adjoint on the matrix cores (4-days-per-wave build): the (state, day) cells of the member's polls -- runs of its
+    // day-then-state sorted polls -- one per thread: first poll | polls << 10 | offset in G << 16; polls of day T stay out
+    // (they feed mu_b_T only, stan:85-86)
+    std::vector<int> cellw((size_t)CL_CELLS_PER_THREAD * PT_THREADS, 0);
+    int ncell = 0;
+    if (mfma) {
+      const int dump = GROWS * GS;
+      if (np >= 1024) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: member %d has %d polls (the adjoint scatter addresses 1023)", m, np);
+      for (auto &cw : cellw) cw = np | (1 << 10) | (dump << 16);
+      for (int il = 0; il < np;) {
+        int j = il + 1;
+        while (j < np && sp->h_pt[p0 + j] == sp->h_pt[p0 + il] && sp->h_ps[p0 + j] == sp->h_ps[p0 + il]) j++;
+        if (sp->h_pt[p0 + il] != T - 1) {
+          if (j - il > 63) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: %d polls of one state on one day (the adjoint scatter takes 63)", j - il);
+          if (ncell >= CL_CELLS_PER_THREAD * PT_THREADS) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: member %d has more than %d polled (state, day) cells", m, CL_CELLS_PER_THREAD * PT_THREADS);
+          cellw[ncell++] = il | ((j - il) << 10) | ((sp->h_ps[p0 + il] * GS + (sp->h_pt[p0 + il] - d0)) << 16);
+        }
+        il = j;
+      }
+    }
+    pt_[CP_NCELL] = ncell;
     std::vector<int> wdays(wd0);
     wdays.insert(wdays.end(), wnd.begin(), wnd.end());
     wdays.insert(wdays.end(), ca.begin(), ca.end());
@@ -1214,6 +1241,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
     pt_[CP_O_WD] = appi(s2info); appi(wdays);
     pt_[CP_O_MASK] = appi(tab); pt_[CP_O_SUB] = appi(sub16); pt_[CP_O_SEGPTR] = appi(seg_ptr);
     pt_[CP_O_SEGKIND] = appi(seg_kind); pt_[CP_O_SEGIDX] = appi(seg_index);
+    pt_[CP_O_CELL] = appi(cellw);
     while (wts.size() % 2) wts.push_back(0.0);
     pt_[CP_O_WT] = (int)wts.size();
     wts.insert(wts.end(), sub_wt.begin(), sub_wt.end());
@@ -1248,7 +1276,8 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
     for (int m = 0; m < K; m++) ndmax = std::max(ndmax, part[(size_t)m * CP_N + CP_ND]);
     C.NDP = ndmax | 1;   // odd row stride of the member's C[state][local day] block
   }
-  C.l_C = take(std::max(S * C.NDP, 12 * M.SE));
+  C.l_C = take(mfma ? S * C.NDP + 12 * M.SE : std::max(S * C.NDP, 12 * M.SE));   // (+ the partial transposed mat-vecs of phase E2 behind the prefix block)
+  C.l_G = mfma ? take(GROWS * GS + CL_G_PAD) : 0; C.GS = GS; C.GROWS = GROWS;
   C.l_Lw = take((M.SE + 1) * M.SP);
   C.l_LT = take(S * (S + 1) / 2 + 2); C.l_LB = take(S * (S + 1) / 2 + 2); C.l_w = take(M.SE); C.l_prior = take(M.SE);   // packed lower triangles
   C.l_pm = take(npmax + 8); C.l_py = take(npmax + 8); C.l_pN = 0; C.l_pun = take(npmax + 8);                             // l_py: {y, N} as two int32
@@ -1396,10 +1425,11 @@ int dense_alloc(Sampler *sp) {
       (rc = get((void **)&P.tpart, (size_t)chains * P.nblk * 3 * P.LD * 8)) || (rc = get((void **)&P.srow, (size_t)chains * 3 * P.ntile * P.LD * 8)) ||
       (rc = get((void **)&P.partial, (size_t)chains * P.npart * 8)) || (rc = get((void **)&P.lpbuf, (size_t)chains * 8)) ||
       (rc = get((void **)&P.ts, (size_t)chains * sizeof(TS))) || (rc = get((void **)&P.rd, (size_t)chains * sizeof(DnRound))) ||
-      (rc = get((void **)&P.active, (size_t)chains * 4)) || (rc = get((void **)&P.fail, 4)))
+      (rc = get((void **)&P.active, (size_t)chains * 4)) || (rc = get((void **)&P.fail, 4)) || (rc = get((void **)&P.act_passes, 8)))
     return rc;
   HIP_TRY(hipHostMalloc((void **)&sp->h_active, (size_t)chains * sizeof(int)));
   HIP_TRY(hipEventCreate(&sp->mv0)); HIP_TRY(hipEventCreate(&sp->mv1));
+  for (int k = 0; k < Sampler::DN_AHEAD; k++) { HIP_TRY(hipEventCreate(&sp->rv0[k])); HIP_TRY(hipEventCreate(&sp->rv1[k])); HIP_TRY(hipEventCreate(&sp->rdone[k])); }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(1)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(2)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(1)));
@@ -1453,7 +1483,7 @@ int dense_grad(Sampler *sp) {
   return 0;
 }
 // one pass over the matrices of the active chains; the pass is timed with events resolved at the next sync point
-int dense_matvec(Sampler *sp, int nrhs, int n_active) {
+int dense_matvec(Sampler *sp, int nrhs, int n_active, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   DnActive act;
   act.n = 0;                                              // every chain, or (from the flags of the last sync point) the active ones, compacted
   if (n_active < sp->R.chains && sp->R.chains <= DN_ACT_MAX) {
@@ -1461,11 +1491,11 @@ int dense_matvec(Sampler *sp, int nrhs, int n_active) {
     n_active = act.n;
   }
   dense_launch_shape(sp->dn, n_active);
-  sp->mv_bytes += (long long)n_active * sp->dn_pass_bytes[sp->dn.rb == DN_RB ? 0 : 1] * (nrhs == 3 ? 2 : 1);   // three right-hand sides go as 2 + 1
-  HIP_TRY(hipEventRecord(sp->mv0, sp->stream));
+  // (the bytes the passes stream are counted on the device, DnParams::act_passes: the host's flags may be a few rounds old)
+  HIP_TRY(hipEventRecord(e0 ? e0 : sp->mv0, sp->stream));
   dense_symv_launch(sp->stream, sp->dn, act, nrhs);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(sp->mv1, sp->stream));
+  HIP_TRY(hipEventRecord(e1 ? e1 : sp->mv1, sp->stream));
   return 0;
 }
 // sync point of a round: the activity flags come to the host; returns the number of chains still active
@@ -1572,14 +1602,40 @@ int dense_run(Sampler *sp, int n_iter) {
     hipLaunchKernelGGL(k_dn_step, dim3(chains), dim3(DN_THREADS), 0, sp->stream, P, (const RunParams *)sp->dR, (unsigned)it, (int)DN_MODE_BEGIN);
     HIP_TRY(hipGetLastError());
     if ((rc = dense_sync(sp, &n_active, true))) return rc;
-    while (n_active > 0) {
-      if ((rc = dense_grad(sp))) return rc;
-      hipLaunchKernelGGL(k_dn_kick, dn_grid(sp), dim3(256), 0, sp->stream, P);
-      if ((rc = dense_matvec(sp, 2, n_active))) return rc;
-      hipLaunchKernelGGL(k_dn_step, dim3(chains), dim3(DN_THREADS), 0, sp->stream, P, (const RunParams *)sp->dR, (unsigned)it, (int)DN_MODE_LEAF);
-      HIP_TRY(hipGetLastError());
-      sp->dn_rounds += 1;
-      if ((rc = dense_sync(sp, &n_active, true))) return rc;
+    // Leaf rounds.  The host does not wait for a round before it queues the next: it keeps DN_AHEAD rounds in flight and looks
+    // at the activity flags of the round that left the queue (they come back with an asynchronous copy behind every round;
+    // flags only ever go from 1 to 0 inside a transition).  Chains that have finished sit rounds out on the device (every
+    // kernel returns at once for them), so the rounds queued past the end of the transition cost a few empty launches --
+    // against a host round trip per leaf with the GPU idle (13 % of the wall time at D = 15 098 before).
+    {
+      constexpr int R = Sampler::DN_AHEAD;
+      long long q = 0;                                  // rounds queued in this transition
+      auto retire = [&](long long r) -> int {           // wait for round r; its pass time; the flags as of then (or later)
+        const int k = (int)(r % R);
+        HIP_TRY(hipEventSynchronize(sp->rdone[k]));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, sp->rv0[k], sp->rv1[k]));
+        sp->mv_ms += ms; sp->mv_calls += 1;
+        int n = 0;
+        for (int c = 0; c < sp->R.chains; c++) n += sp->h_active[c] != 0;
+        n_active = n;
+        return 0;
+      };
+      long long retired = 0;
+      while (n_active > 0) {
+        const int k = (int)(q % R);
+        if ((rc = dense_grad(sp))) return rc;
+        hipLaunchKernelGGL(k_dn_kick, dn_grid(sp), dim3(256), 0, sp->stream, P);
+        if ((rc = dense_matvec(sp, 2, n_active, sp->rv0[k], sp->rv1[k]))) return rc;
+        hipLaunchKernelGGL(k_dn_step, dim3(chains), dim3(DN_THREADS), 0, sp->stream, P, (const RunParams *)sp->dR, (unsigned)it, (int)DN_MODE_LEAF);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(sp->h_active, sp->dn.active, (size_t)sp->R.chains * sizeof(int), hipMemcpyDeviceToHost, sp->stream));
+        HIP_TRY(hipEventRecord(sp->rdone[k], sp->stream));
+        sp->dn_rounds += 1;
+        q++;
+        if (q - retired >= R) { if ((rc = retire(retired))) return rc; retired++; }
+      }
+      while (retired < q) { if ((rc = retire(retired))) return rc; retired++; }
     }
     // adapt_dense_e_nuts::transition: the warm-up schedule is the same for every chain, so the host keeps its own copy
     int flags = 0;
@@ -1718,6 +1774,7 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
     if (sp->ev1) (void)hipEventDestroy(sp->ev1);
     if (sp->mv0) (void)hipEventDestroy(sp->mv0);
     if (sp->mv1) (void)hipEventDestroy(sp->mv1);
+    for (int k = 0; k < Sampler::DN_AHEAD; k++) { if (sp->rv0[k]) (void)hipEventDestroy(sp->rv0[k]); if (sp->rv1[k]) (void)hipEventDestroy(sp->rv1[k]); if (sp->rdone[k]) (void)hipEventDestroy(sp->rdone[k]); }
     if (sp->h_active) (void)hipHostFree(sp->h_active);
     if (sp->stream) (void)hipStreamDestroy(sp->stream);
     delete sp;
@@ -1855,6 +1912,7 @@ int potus_destroy(int handle) {
   (void)hipEventDestroy(sp->ev0); (void)hipEventDestroy(sp->ev1); (void)hipStreamDestroy(sp->stream);
   if (sp->mv0) (void)hipEventDestroy(sp->mv0);
   if (sp->mv1) (void)hipEventDestroy(sp->mv1);
+  for (int k = 0; k < Sampler::DN_AHEAD; k++) { if (sp->rv0[k]) (void)hipEventDestroy(sp->rv0[k]); if (sp->rv1[k]) (void)hipEventDestroy(sp->rv1[k]); if (sp->rdone[k]) (void)hipEventDestroy(sp->rdone[k]); }
   if (sp->h_active) (void)hipHostFree(sp->h_active);
   { std::lock_guard<std::mutex> lk(g_mu); g_handles[handle] = nullptr; }
   delete sp;
@@ -2161,7 +2219,12 @@ int potus_dense_timing(int handle, double *matvec_ms, long long *passes, long lo
   if (!sp || !sp->dense) return fail(POTUS_ERR_STATE, "bad handle or not a dense-metric sampler");
   if (matvec_ms) *matvec_ms = sp->mv_ms;
   if (passes) *passes = sp->mv_calls;
-  if (bytes) *bytes = sp->mv_bytes;
+  if (bytes) {   // (chain, pass) pairs counted by the passes themselves x the bytes a pass loads per chain
+    unsigned long long np_ = 0;
+    HIP_TRY(hipSetDevice(sp->device));
+    HIP_TRY(hipMemcpy(&np_, sp->dn.act_passes, 8, hipMemcpyDeviceToHost));
+    *bytes = (long long)np_ * sp->dn_pass_bytes[sp->dn.rb == DN_RB ? 0 : 1];
+  }
   if (rounds) *rounds = sp->dn_rounds;
   return 0;
 }
