@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--warm-steps", type=int, default=-1, help="how many of the --steps are warm-up (-1 = half of them)")
     ap.add_argument("--metric-storage", default="f64", choices=["f64", "f32"], help="--config 4: storage of the dense inverse metric")
     ap.add_argument("--max-depth", type=int, default=10)
+    ap.add_argument("--gather", default="full", choices=["full", "T"], help="what the all-gather pools: lp__ + all of mu_b (SURVEY 8e) or lp__ + mu_b[:, T] only")
     ap.add_argument("--seed", type=int, default=1843)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturated", action="store_true", help="skip the 256-chain reference point")
@@ -267,24 +268,32 @@ def main():
             torch.cuda.synchronize()
             t_warm_end = time.perf_counter()
             lf_warm = sum(h.total_leapfrogs() for h in hs)
-    # the one exchange of the path: pool the draws-of-interest (lp__ and mu_b[:, T]) of every chain of every GPU.
-    # They are produced on the device (potus_write_array_device), gathered on the device (RCCL all-gather over xGMI) and
-    # only the pooled block comes to the host, for rank 0's R-hat / ESS.
-    pooled = []
+    # The one exchange of the path: pool the draws-of-interest of every chain of every GPU -- lp__ and the whole of
+    # mu_b (S x T per draw: predicted_score is its inverse logit, column for column, and is not sent a second time), 12 955
+    # doubles per draw for 2016 = 0.83 GB per rank with 8 chains x 1000 draws.  They are produced on the device
+    # (potus_write_array_device), gathered on the device (RCCL all-gather over xGMI) and stay there; only the 1 + S columns
+    # R-hat / ESS are taken on (lp__, mu_b[:, T]) come to the host, on rank 0's behalf.  --gather T sends those columns only.
+    pooled, gathered_bytes = [], 0
     for (name, data, variant, C, _), h in zip(work, hs):
         S, T = int(data["S"]), int(data["T"])
         a_mu = h.layout["mu_b"][0]
         if ns == 0:
             pooled.append(None)
             continue
-        loc = torch.empty((ns, C, 1 + S), dtype=torch.float64, device=dev)
+        ncol = S * T if args.gather == "full" else S
+        loc = torch.empty((ns, C, 1 + ncol), dtype=torch.float64, device=dev)
         tmp = torch.empty((ns, C, 1), dtype=torch.float64, device=dev)
         h.write_array_device(0, 1, tmp)
         loc[:, :, :1] = tmp
-        tmp = torch.empty((ns, C, S), dtype=torch.float64, device=dev)
-        h.write_array_device(a_mu + S * (T - 1), a_mu + S * T, tmp)
+        tmp = torch.empty((ns, C, ncol), dtype=torch.float64, device=dev)
+        h.write_array_device(a_mu + (0 if args.gather == "full" else S * (T - 1)), a_mu + S * T, tmp)
         loc[:, :, 1:] = tmp
-        pooled.append(parallel.all_gather_chains(loc, coll_dev))      # [ns, world * C, 1 + S] on every rank
+        del tmp
+        full = parallel.all_gather_chains(loc, coll_dev)                # [ns, world * C, 1 + ncol] on every rank
+        gathered_bytes += loc.numel() * 8
+        sel = torch.cat([full[:, :, :1], full[:, :, 1 + ncol - S:]], dim=2)   # lp__ and mu_b[:, T]
+        pooled.append(sel.contiguous())
+        del full, loc
     torch.cuda.synchronize()
     parallel.barrier()
     t1 = time.perf_counter()
@@ -353,6 +362,7 @@ def main():
                                    f"{nw} warmup + {ns} sampling, seed {args.seed}; a step = one launch chunk of {chunk} transitions",
                        "step": f"{chunk} NUTS transitions of every chain", "iter_warmup": nw, "iter_sampling": ns,
                        "chains_per_gpu": C_tot, "total_chains": C_tot * world, "posteriors": per_post,
+                       "all_gather_bytes_per_rank": gathered_bytes,
                        "parallelism": (f"chains sharded {C_tot}/GPU x {world}, no data-path collective; one RCCL all-gather of the "
                                        f"draws-of-interest (device buffers); " if world > 1 else f"{C_tot} chains; ") +
                                       (f"each chain on two clusters of {K} workgroups, one per end of the NUTS trajectory ({C_tot * K * 2} of 256 CUs busy)"

@@ -1,4 +1,5 @@
 """Throughput at the BASELINE configs[4] shape (51 x 600 days x 10 000 polls, diagonal metric): development probe."""
+import os
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[2]
@@ -7,7 +8,7 @@ from us_potus_model_amd import Handle, synthetic
 data = synthetic.stress()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 for chains in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "8"])]:
-    h = Handle(data, "full", chains=chains, num_warmup=iters, num_samples=0, seed=1843)
+    h = Handle(data, "full", chains=chains, num_warmup=iters, num_samples=0, seed=1843, cus_per_chain=int(os.environ.get("POTUS_K", "0")), twin=0)
     h.init()
     ms_tot, lf_tot = 0.0, 0
     for _ in range(3):

@@ -112,6 +112,42 @@ def test_stress_shape_log_prob_grad_and_first_transitions():
     h.close()
 
 
+def test_stress_shape_with_the_adjoint_on_the_matrix_cores():
+    """The same posterior on clusters of 32 (19 days per member: the 4-days-per-wave build): 16.7 polls per day, so the library
+    takes the build whose adjoint product runs on the fp64 matrix cores (v_mfma_f64_16x16x4_f64 over the member's
+    pseudo-state x day matrix of residual sums, prefix over days on the accumulators) instead of the walk over the polls.  Log
+    density, gradient and the first transitions against the oracle; the walk (POTUS_CL_MFMA = 0) gives the same trees."""
+    import os
+    from us_potus_model_amd import synthetic
+    data = synthetic.stress()
+    iters = 3
+    m = OracleModel(data, "full")
+    rng = np.random.default_rng(6)
+    q = np.vstack([np.zeros((1, 41610)), rng.uniform(-2, 2, (2, 41610)), 0.2 * rng.standard_normal((1, 41610))])
+    ref_lp = [m.log_prob_grad(qi) for qi in q]
+    o = m.default_opts(num_warmup=iters, num_samples=0, save_warmup=1, seed=5, fast_grad=1)
+    ref = m.sample_chain(1, o)[0]
+    old = os.environ.get("POTUS_CL_MFMA")
+    try:
+        for flag in ("1", "0"):
+            os.environ["POTUS_CL_MFMA"] = flag
+            h = Handle(data, "full", chains=1, num_warmup=iters, num_samples=0, save_warmup=1, seed=5, cus_per_chain=32)
+            lp, grad = h.log_prob_grad(q)
+            for i, (lpo, go) in enumerate(ref_lp):
+                assert abs(lp[i] - lpo) <= LP_RTOL * abs(lpo), (flag, i, lp[i], lpo)
+                assert np.abs(grad[i] - go).max() <= GRAD_RTOL * np.abs(go).max(), (flag, i)
+            h.init(); h.run(iters)
+            d = h.draws()
+            assert np.array_equal(d[0][:, 3:6], ref[:, 3:6]), (flag, d[0][:, :7], ref[:, :7])
+            assert np.allclose(d[0][:, 7:], ref[:, 7:], rtol=1e-6, atol=1e-7)
+            h.close()
+    finally:
+        if old is None:
+            os.environ.pop("POTUS_CL_MFMA", None)
+        else:
+            os.environ["POTUS_CL_MFMA"] = old
+
+
 def test_stress_shape_sixteen_chains_on_one_gpu():
     """BASELINE configs[4] asks for 16 chains per GPU at 51 states x 600 days x 10 000 polls: 16 clusters of 16 compute
     units (the members keep the two 51 x 51 factors as packed triangles, the poll counts as int32 pairs and the AR(1)

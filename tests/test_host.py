@@ -137,6 +137,20 @@ assert tuple(pl.shape) == (4, 3 * world, 2)
 for r in range(world):
     for c in range(3):
         assert torch.equal(pl[:, 3 * r + c, :], 1000 * r + 10 * c + torch.arange(8, dtype=torch.float64).reshape(4, 2))
+# pooled posterior summaries (what potus_posterior_summary_many does across GPUs, restated): every rank holds the predicted_score
+# draws of its own chains; after the gather, the summaries of the pooled block are those of all chains together, on every rank
+import sys
+sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+from posterior_summary_ref import posterior_summary
+rng = np.random.default_rng(99)
+allps = 1.0 / (1.0 + np.exp(-rng.standard_normal((50, 2 * world, 3 * 4))))          # [draw, chain, T * S], the same on every rank
+mine = torch.as_tensor(allps[:, 2 * rank:2 * rank + 2, :].copy())
+got = parallel.all_gather_chains(mine, None).numpy()
+assert np.array_equal(got, allps)
+w8, ev = np.array([0.1, 0.2, 0.3, 0.4]), np.array([100.0, 150.0, 200.0, 88.0])
+a = posterior_summary(got.reshape(-1, 3, 4), w8, ev)
+b = posterior_summary(allps.reshape(-1, 3, 4), w8, ev)
+assert all(np.array_equal(a[k], b[k]) for k in a)
 assert parallel.max_over_ranks(float(rank)) == world - 1
 assert parallel.sum_over_ranks(1.0) == world
 parallel.barrier()

@@ -585,10 +585,13 @@ __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstl
 // in phase C and takes the verdicts (cl_leaf_logic); if they end the trajectory the pass stops at the phase-C barrier
 // (aborted = true).  This takes the wait for
 // the leaf's all-reduce and the serial bookkeeping off the critical path of consecutive leaves.
-template <int CL_DW, class Pol>
+template <int CL_TAG, class Pol>
 __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_in, ldp lds, const ClStatic &cst, Xch &x, Pol &pol_io,
                                                   bool pubnext, const LeafCtx &pend, ltp ts, ldp wout, bool &aborted) {
-  constexpr bool MF = CL_DW == 4;                   // the adjoint product on the matrix cores (the 8-days-per-wave build keeps the gather walk)
+  // the builds of the pass (every template above and in potus_hmc.hip just hands the tag down): 4 / 8 = days per wave with the
+  // adjoint as a walk over the polls, 12 = four days per wave with the adjoint product on the matrix cores (MF)
+  constexpr int CL_DW = CL_TAG == 12 ? 4 : CL_TAG;
+  constexpr bool MF = CL_TAG == 12;
   Pol pol = pol_io;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));

@@ -836,10 +836,12 @@ __global__ __launch_bounds__(256) void k_dn_trsm(const DnParams P, int kb) {
   for (int e = tid; e < DN_NB * DN_NB; e += 256) { const int i = e >> 6, j = e & 63; if (r0 + i < P.D && j < nb) L[(size_t)(r0 + i) * P.LD + c0 + j] = x[i][j]; }
 }
 // trailing update A[I][J] -= L[I][kb] L[J][kb]' for the lower tiles I >= J > kb (fp64 MFMA, see k_dn_cov)
-__global__ __launch_bounds__(256) void k_dn_syrk(const DnParams P, int kb) {
+// (jmax: the last block column this launch updates -- the factorisation runs in panels of DN_PANEL block columns: inside a panel
+//  the update after each block column stops at the panel's edge, the rest of the matrix gets the whole panel at once, k_dn_syrk_wide)
+__global__ __launch_bounds__(256) void k_dn_syrk(const DnParams P, int kb, int jmax) {
   __shared__ double a[DN_NB][DN_NB + 1], b[DN_NB][DN_NB + 1];
   const int I = kb + 1 + blockIdx.x, J = kb + 1 + blockIdx.y, chain = blockIdx.z;
-  if (J > I) return;
+  if (J > I || J > jmax) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 15, kk = lane >> 4, c0 = kb * DN_NB;
   double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD;
   for (int e = tid; e < DN_NB * DN_NB; e += 256) {
@@ -887,6 +889,61 @@ __global__ __launch_bounds__(256) void k_dn_chk_lx(const DnParams P, int chain, 
   __syncthreads();
   for (int h = 128; h > 0; h >>= 1) { if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h]; __syncthreads(); }
   if (threadIdx.x == 0) dn_vec(P, chain, zslot)[i] = red[0];
+}
+
+// Trailing update behind a PANEL of nk block columns (c0 = 64 pb .. 64 (pb + nk)): A[I][J] -= L[I][panel] L[J][panel]' for every
+// 128 x 128 tile I >= J behind the panel.  With one block column at a time the update reads and rewrites the whole trailing
+// matrix per 64 columns factored (4 flops per byte moved: 10-11 TFLOP/s, bound by that read-modify-write); with the panel's 256
+// columns per pass and 128 x 128 tiles it is 11 flops per byte.  Four waves, one 64 x 64 quadrant each = 4 x 4 MFMA tiles
+// (v_mfma_f64_16x16x4_f64, operand layout as in k_dn_cov), the panel's columns staged through LDS sixteen at a time, stored
+// [k][row] with a row stride of 16 mod 32 doubles so that the four k-rows a wave reads per step fall on disjoint banks.
+#define DN_PANEL 4
+#define DN_WT 128
+#define DN_WS 144
+__global__ __launch_bounds__(256) void k_dn_syrk_wide(const DnParams P, int pb, int nk) {
+  __shared__ double a[16][DN_WS], b[16][DN_WS];
+  const int r_first = (pb + nk) * DN_NB;                 // first row / column behind the panel
+  const int I0 = r_first + (int)blockIdx.x * DN_WT, J0 = r_first + (int)blockIdx.y * DN_WT, chain = blockIdx.z;
+  if (J0 > I0 || I0 >= P.D) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, n = lane & 15, wr = w >> 1, wc = w & 1;
+  const int c0 = pb * DN_NB, K = min(nk * DN_NB, P.D - c0);
+  double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  dn_d4 acc[4][4];
+#pragma unroll
+  for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++) acc[ti][tj] = dn_d4{0.0, 0.0, 0.0, 0.0};
+  const int lrow = tid >> 1, lk = (tid & 1) * 8;         // staging: thread = (row of the tile, half of the sixteen columns)
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int kk = k0 + lk + u;
+      const bool ok = kk < K;
+      a[lk + u][lrow] = (ok && I0 + lrow < P.D) ? L[(size_t)(I0 + lrow) * P.LD + c0 + kk] : 0.0;
+      b[lk + u][lrow] = (ok && J0 + lrow < P.D) ? L[(size_t)(J0 + lrow) * P.LD + c0 + kk] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) { av[t] = a[4 * st + g][64 * wr + 16 * t + n]; bv[t] = b[4 * st + g][64 * wc + 16 * t + n]; }
+#pragma unroll
+      for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti], bv[tj], acc[ti][tj], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int i = I0 + 64 * wr + 16 * ti + g + 4 * v, j = J0 + 64 * wc + 16 * tj + n;
+        if (i < P.D && j < P.D && j <= i) L[(size_t)i * P.LD + j] -= acc[ti][tj][v];
+      }
 }
 
 // unit metric: M^-1 = L = I (the matrix buffer is zero apart from the diagonal)

@@ -756,6 +756,25 @@ int validate(const potus_data *d) {
   return 0;
 }
 
+// FNV-1a over everything the posterior depends on (sizes, index vectors, counts, flags, prior, weights, covariance, scales)
+unsigned long long hash_data(const potus_data *d) {
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; p && i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+  const bool full = d->variant == POTUS_VARIANT_FULL;
+  const int32_t dims[8] = {d->N_national_polls, d->N_state_polls, d->T, d->S, d->P, full ? d->M : 0, full ? d->Pop : 0, d->variant};
+  mix(dims, sizeof dims);
+  const size_t ns = (size_t)d->N_state_polls * 4, nn = (size_t)d->N_national_polls * 4;
+  mix(d->state, ns); mix(d->day_state, ns); mix(d->day_national, nn); mix(d->poll_state, ns); mix(d->poll_national, nn);
+  if (full) { mix(d->poll_mode_state, ns); mix(d->poll_mode_national, nn); mix(d->poll_pop_state, ns); mix(d->poll_pop_national, nn);
+              mix(d->unadjusted_state, ns * 2); mix(d->unadjusted_national, nn * 2); }
+  mix(d->n_democrat_national, nn); mix(d->n_two_share_national, nn); mix(d->n_democrat_state, ns); mix(d->n_two_share_state, ns);
+  mix(d->mu_b_prior, (size_t)d->S * 8); mix(d->state_weights, (size_t)d->S * 8); mix(d->state_covariance_0, (size_t)d->S * d->S * 8);
+  const double sc[9] = {d->sigma_c, full ? d->sigma_m : 0, full ? d->sigma_pop : 0, d->sigma_measure_noise_national, d->sigma_measure_noise_state,
+                        full ? d->sigma_e_bias : 0, d->random_walk_scale, d->mu_b_T_scale, d->polling_bias_scale};
+  mix(sc, sizeof sc);
+  return h;
+}
+
 // lower Cholesky factor, column-major (cholesky_decompose, stan:52-54)
 bool chol(const std::vector<double> &A, std::vector<double> &L, int n) {
   L.assign((size_t)n * n, 0.0);
@@ -804,6 +823,7 @@ struct Sampler {
   std::vector<int> h_ps, h_pt, h_pp, h_pm, h_ppop, h_pq, h_dayptr, h_perm;   // day-sorted polls (host copies)
   std::vector<double> h_w;    // state_weights
   std::vector<double> h_pu;
+  unsigned long long data_hash = 0;   // FNV-1a over the data block: handles that pool their draws must hold the same posterior
   // dense metric (potus_dense.hpp)
   bool dense = false;
   DnParams dn{};
@@ -820,9 +840,27 @@ struct Sampler {
 
 std::mutex g_mu;
 std::vector<Sampler *> g_handles;
-// Cluster kernels need all their workgroups co-resident (they wait for each other): launches of cluster-mode
-// handles are serialised per process, from launch to completion.
-std::mutex g_cluster_mu;
+// Cluster kernels need all their workgroups co-resident (they wait for each other): whatever launches work on a device --
+// sampler runs, the parity hook, write_array, the posterior summaries, the CSV writer's row kernels -- holds that device's
+// mutex from launch to completion, so host threads driving one handle per GPU run side by side while two calls on one GPU take
+// turns.  potus_run_many locks the devices of its handles in ascending order.
+constexpr int POTUS_MAX_DEVICES = 64;
+std::mutex g_device_mu[POTUS_MAX_DEVICES];
+struct DeviceLocks {
+  std::vector<std::unique_lock<std::mutex>> held;
+  explicit DeviceLocks(std::vector<int> devs) {
+    std::sort(devs.begin(), devs.end());
+    devs.erase(std::unique(devs.begin(), devs.end()), devs.end());
+    for (int d : devs) held.emplace_back(g_device_mu[std::min(std::max(d, 0), POTUS_MAX_DEVICES - 1)]);
+  }
+  explicit DeviceLocks(int dev) : DeviceLocks(std::vector<int>{dev}) {}
+};
+// the caller's HIP device is put back on every return path (the library works on the handles' devices)
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 Sampler *get(int h) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -1058,7 +1096,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   const int dw4_max = getenv("POTUS_CL_DW4_MAXAVG") ? atoi(getenv("POTUS_CL_DW4_MAXAVG")) : CL_DW4_MAXAVG;   // development: sweeps
   const int DW = (T + K - 1) / K <= dw4_max ? 4 : 8;
   const int maxdays = PT_NW * DW;
-  sp->cl_dw = DW;
+  sp->cl_dw = DW;   // (12 once the adjoint goes to the matrix cores, below)
   C.XW = (std::max(XP_P + C.NR, XQ0 + C.NREP) + 7) & ~7;
   if (P > 65535 || M.M > 255 || M.Pop > 255) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode packs pollster/mode/population indices in 16/8/8 bits");
   if (C.NREP > 2 * PT_THREADS) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: %d small parameters (> %d)", C.NREP, 2 * PT_THREADS);
@@ -1093,8 +1131,11 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
 
   // the adjoint product on the fp64 matrix cores (potus_cluster.hpp, cl_pass_partial): G[pseudo-state][local day], row stride
   // = 16 mod 32 doubles (the four rows a wave reads per MFMA step fall on disjoint LDS banks)
-  const bool mfma = DW == 4;
+  // -- for poll-dense posteriors (more than 8 polls per day: the dense product then beats the walk over the polls, measured in
+  // profiles/r03_cl_mfma_adjoint.txt; the reference's own posteriors have 4-6 and keep the walk); POTUS_CL_MFMA = 0 / 1 overrides
+  const bool mfma = DW == 4 && (getenv("POTUS_CL_MFMA") ? atoi(getenv("POTUS_CL_MFMA")) != 0 : Np > 8 * T);
   const int GS = 48, GROWS = 4 * ((M.SE + 3) / 4);
+  if (mfma) sp->cl_dw = 12;
   std::vector<int> part((size_t)K * CP_N, 0), sched, perm;   // perm: internal index -> Stan index, -1 for padding
   std::vector<double> wts;
   int e = 0, npmax = 0, nsubmax = 0;
@@ -1306,14 +1347,18 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   sp->allocs.push_back(pc);
   HIP_TRY(hipMemcpy(pc, &C, sizeof(ClModel), hipMemcpyHostToDevice));
   sp->dCL = (ClModel *)pc;
-  for (const void *f : {reinterpret_cast<const void *>(k_cl_logprob_grad<4>), reinterpret_cast<const void *>(k_cl_logprob_grad<8>),
-                        reinterpret_cast<const void *>(k_cl_init<4>), reinterpret_cast<const void *>(k_cl_init<8>),
-                        reinterpret_cast<const void *>(k_cl_run<4, false>), reinterpret_cast<const void *>(k_cl_run<8, false>),
-                        reinterpret_cast<const void *>(k_cl_run<4, true>), reinterpret_cast<const void *>(k_cl_run<8, true>)})
+  for (const void *f : {reinterpret_cast<const void *>(k_cl_logprob_grad<4>), reinterpret_cast<const void *>(k_cl_logprob_grad<8>), reinterpret_cast<const void *>(k_cl_logprob_grad<12>),
+                        reinterpret_cast<const void *>(k_cl_init<4>), reinterpret_cast<const void *>(k_cl_init<8>), reinterpret_cast<const void *>(k_cl_init<12>),
+                        reinterpret_cast<const void *>(k_cl_run<4, false>), reinterpret_cast<const void *>(k_cl_run<8, false>), reinterpret_cast<const void *>(k_cl_run<12, false>),
+                        reinterpret_cast<const void *>(k_cl_run<4, true>), reinterpret_cast<const void *>(k_cl_run<8, true>), reinterpret_cast<const void *>(k_cl_run<12, true>)})
     HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
   sp->K = K;
   return 0;
 }
+
+// The builds of the cluster pass (template tag of potus_cluster.hpp): 4 = four days per wave, 8 = eight days per wave, 12 = four
+// days per wave with the adjoint product on the fp64 matrix cores (poll-dense posteriors).
+#define CL_DISPATCH(tag, CALL) do { if ((tag) == 4) { CALL(4); } else if ((tag) == 12) { CALL(12); } else { CALL(8); } } while (0)
 
 // replica 0 of every chain's scalars
 int read_scalars(Sampler *sp, std::vector<ChainScalars> &sc) {
@@ -1368,6 +1413,28 @@ int dense_window_capacity(int nw, int ib, int tb, int bw) {
     counter++;
   }
   return cap;
+}
+
+// Blocked Cholesky factorisation in place on the lower triangles of the chains' matrices, in panels of DN_PANEL block columns:
+// inside a panel potrf / trsm / narrow update per block column, behind it one wide update (k_dn_syrk_wide).
+void dense_cholesky_launch(hipStream_t st, const DnParams &P, int chains) {
+  const int nb = (P.D + DN_NB - 1) / DN_NB;
+  for (int pb = 0; pb < nb; pb += DN_PANEL) {
+    const int nk = std::min(DN_PANEL, nb - pb), last = pb + nk - 1;
+    for (int kb = pb; kb <= last; kb++) {
+      hipLaunchKernelGGL(k_dn_potrf, dim3(chains), dim3(256), 0, st, P, kb);
+      const int rem = nb - kb - 1;
+      if (rem > 0) {
+        hipLaunchKernelGGL(k_dn_trsm, dim3(rem, chains), dim3(256), 0, st, P, kb);
+        if (last > kb) hipLaunchKernelGGL(k_dn_syrk, dim3(rem, last - kb, chains), dim3(256), 0, st, P, kb, last);
+      }
+    }
+    const int behind = P.D - (pb + nk) * DN_NB;
+    if (behind > 0) {
+      const int nt = (behind + DN_WT - 1) / DN_WT;
+      hipLaunchKernelGGL(k_dn_syrk_wide, dim3(nt, nt, chains), dim3(256), 0, st, P, pb, nk);
+    }
+  }
 }
 
 // Shape of one launch of the symmetric product: rows a workgroup takes at a time (256 for large matrices: fewer tiles per
@@ -1435,7 +1502,7 @@ int dense_alloc(Sampler *sp) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(1)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(2)));
   if (sp->K == 1) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_grad1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
-  else for (const void *f : {reinterpret_cast<const void *>(k_dn_gradK<4>), reinterpret_cast<const void *>(k_dn_gradK<8>)})
+  else for (const void *f : {reinterpret_cast<const void *>(k_dn_gradK<4>), reinterpret_cast<const void *>(k_dn_gradK<8>), reinterpret_cast<const void *>(k_dn_gradK<12>)})
     HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
   hipLaunchKernelGGL(k_dn_identity, dim3((D + 255) / 256, chains), dim3(256), 0, sp->stream, P);
   HIP_TRY(hipGetLastError());
@@ -1472,12 +1539,10 @@ int dense_grad(Sampler *sp) {
     hipLaunchKernelGGL(k_dn_grad1, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, sp->dn);
   else {
     const unsigned lid = ++sp->launch_id;
-    if (sp->cl_dw == 4)
-      hipLaunchKernelGGL(k_dn_gradK<4>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
-                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, sp->dn, lid);
-    else
-      hipLaunchKernelGGL(k_dn_gradK<8>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
-                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, sp->dn, lid);
+#define POTUS_CALL(TAG) hipLaunchKernelGGL(k_dn_gradK<TAG>, dim3(sp->R.chains * sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM, \
+                                           (const ClModel *)sp->dCL, (const RunParams *)sp->dR, sp->dn, lid)
+    CL_DISPATCH(sp->cl_dw, POTUS_CALL);
+#undef POTUS_CALL
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1561,14 +1626,7 @@ int dense_window_end(Sampler *sp, int n, unsigned iter) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(sp->stream));
   const double t1 = now();
-  for (int kb = 0; kb < nb; kb++) {     // in place on the lower triangle; the upper one keeps M^-1
-    hipLaunchKernelGGL(k_dn_potrf, dim3(chains), dim3(256), 0, sp->stream, P, kb);
-    const int rem = nb - kb - 1;
-    if (rem > 0) {
-      hipLaunchKernelGGL(k_dn_trsm, dim3(rem, chains), dim3(256), 0, sp->stream, P, kb);
-      hipLaunchKernelGGL(k_dn_syrk, dim3(rem, rem, chains), dim3(256), 0, sp->stream, P, kb);
-    }
-  }
+  dense_cholesky_launch(sp->stream, P, chains);   // in place on the lower triangle; the upper one keeps M^-1
   HIP_TRY(hipGetLastError());
   int failed = 0;
   HIP_TRY(hipMemcpyAsync(&failed, P.fail, 4, hipMemcpyDeviceToHost, sp->stream));
@@ -1768,6 +1826,7 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
 
   Sampler *sp = new Sampler();
   sp->device = o->device; sp->opts = *o; sp->L = make_layout(d);
+  sp->data_hash = hash_data(d);
   auto bail = [&](int code) {
     for (void *p : sp->allocs) (void)hipFree(p);
     if (sp->ev0) (void)hipEventDestroy(sp->ev0);
@@ -1786,6 +1845,7 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
     // workgroups (CUs) per chain: 0 = as many as fit the device, in {16, 8, 4, 1}; chains * K blocks must be co-resident
     const int ncu = prop.multiProcessorCount;
     int K = o->cus_per_chain;
+    bool k_lowered_for_twin = false;
     if (K < 0 || K > CL_MAXK) return bail(fail(POTUS_ERR_ARG, "cus_per_chain must be in [0,%d]", CL_MAXK));
     if (K == 0) {
       K = o->chains * 16 <= ncu ? 16 : o->chains * 8 <= ncu ? 8 : o->chains * 4 <= ncu ? 4 : 1;
@@ -1794,7 +1854,7 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
       // of 16 (21 us) -- as long as the members keep few enough days for the lighter build of the pass (4 days per wave)
       if (K == 16 && o->twin != 0 && o->metric != POTUS_METRIC_DENSE && o->chains * 32 > ncu) {
         const int k2 = ncu / (2 * o->chains);
-        if (k2 >= 10 && (d->T + k2 - 1) / k2 <= CL_DW4_MAXAVG) K = k2;
+        if (k2 >= 10 && (d->T + k2 - 1) / k2 <= CL_DW4_MAXAVG) { K = k2; k_lowered_for_twin = true; }
       }
       // models beyond the one-workgroup kernels (T > 256, > 2048 polls) need a cluster; long campaigns need more members
       if (K == 1 && !sp->k1_unsupported.empty()) K = 8;
@@ -1813,7 +1873,8 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
       if (rc) return bail(rc);
       // the members of a cluster wait for each other: the whole grid has to be resident at once
       int per_cu = 0;
-      const void *kfn = sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4, false>) : reinterpret_cast<const void *>(k_cl_run<8, false>);
+      const void *kfn = sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4, false>) : sp->cl_dw == 12 ? reinterpret_cast<const void *>(k_cl_run<12, false>)
+                                       : reinterpret_cast<const void *>(k_cl_run<8, false>);
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, PT_THREADS, sp->cl_lds_bytes) != hipSuccess || per_cu < 1)
         return bail(fail(POTUS_ERR_DEVICE, "cluster kernel cannot be resident on this device (occupancy query: %d workgroups per compute unit with %zu bytes of LDS)",
                          per_cu, sp->cl_lds_bytes));
@@ -1824,12 +1885,16 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
       const bool twin_fits = o->metric != POTUS_METRIC_DENSE && (long long)o->chains * 2 * K <= (long long)ncu;
       if (o->twin == 1 && !twin_fits)
         return bail(fail(POTUS_ERR_ARG, "twin = 1: two clusters of %d per chain need %d compute units (the device has %d) and the diagonal metric", K, o->chains * 2 * K, ncu));
-      const void *kft = sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4, true>) : reinterpret_cast<const void *>(k_cl_run<8, true>);
+      const void *kft = sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4, true>) : sp->cl_dw == 12 ? reinterpret_cast<const void *>(k_cl_run<12, true>)
+                                       : reinterpret_cast<const void *>(k_cl_run<8, true>);
       int per_cu_t = 0;
       if ((o->twin == 1 || (o->twin < 0 && o->cus_per_chain == 0)) && twin_fits &&
           hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, kft, PT_THREADS, sp->cl_lds_bytes) == hipSuccess && per_cu_t >= 1)
         sp->twin = 1;
       else if (o->twin == 1) return bail(fail(POTUS_ERR_DEVICE, "twin = 1: the twin kernel cannot be resident on this device"));
+      if (!sp->twin && k_lowered_for_twin) {   // the smaller clusters were chosen for the sake of the second one: without it, back to 16
+        if ((rc = build_cluster(sp, d, 16))) return bail(rc);
+      }
     }
   }
   if (hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&sp->ev0) != hipSuccess ||
@@ -1938,7 +2003,7 @@ int potus_log_prob_grad(int handle, const double *q, int n, double *lp, double *
   if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
   if (n < 0 || (n > 0 && (!q || !lp || !grad))) return fail(POTUS_ERR_ARG, "null argument");
   if (n == 0) return 0;
-  std::lock_guard<std::mutex> cluster_lock(g_cluster_mu);
+  DeviceLocks lock(sp->device);
   HIP_TRY(hipSetDevice(sp->device));
   const size_t D = sp->L.D;
   DevBufs tmp;
@@ -1949,12 +2014,10 @@ int potus_log_prob_grad(int handle, const double *q, int n, double *lp, double *
   if (sp->K > 1) {   // the cluster's own pass, on one cluster
     HIP_TRY(tmp.alloc(&dscr, 2 * (size_t)sp->R.Dpad * 8));
     const unsigned lid = ++sp->launch_id;
-    if (sp->cl_dw == 4)
-      hipLaunchKernelGGL(k_cl_logprob_grad<4>, dim3(sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
-                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq, dlp, dg, n, dscr, lid);
-    else
-      hipLaunchKernelGGL(k_cl_logprob_grad<8>, dim3(sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
-                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq, dlp, dg, n, dscr, lid);
+#define POTUS_CALL(TAG) hipLaunchKernelGGL(k_cl_logprob_grad<TAG>, dim3(sp->K), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM, \
+                                           (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq, dlp, dg, n, dscr, lid)
+    CL_DISPATCH(sp->cl_dw, POTUS_CALL);
+#undef POTUS_CALL
   } else {
     const int grid = std::min(n, 1024);
     hipLaunchKernelGGL(k_logprob_grad, dim3(grid), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const double *)dq, dlp, dg, n);
@@ -1969,7 +2032,7 @@ int potus_log_prob_grad(int handle, const double *q, int n, double *lp, double *
 int potus_init(int handle, const double *q0) {
   Sampler *sp = get(handle);
   if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
-  std::lock_guard<std::mutex> cluster_lock(g_cluster_mu);
+  DeviceLocks lock(sp->device);
   HIP_TRY(hipSetDevice(sp->device));
   DevBufs tmp;
   double *dq0 = nullptr;
@@ -1977,12 +2040,10 @@ int potus_init(int handle, const double *q0) {
   if (q0) { HIP_TRY(tmp.alloc(&dq0, bytes)); HIP_TRY(hipMemcpyAsync(dq0, q0, bytes, hipMemcpyHostToDevice, sp->stream)); }
   if (sp->K > 1) {
     const unsigned lid = ++sp->launch_id;
-    if (sp->cl_dw == 4)
-      hipLaunchKernelGGL(k_cl_init<4>, dim3(sp->R.chains * sp->K * sp->sides()), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
-                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq0, lid);
-    else
-      hipLaunchKernelGGL(k_cl_init<8>, dim3(sp->R.chains * sp->K * sp->sides()), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM,
-                         (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq0, lid);
+#define POTUS_CALL(TAG) hipLaunchKernelGGL(k_cl_init<TAG>, dim3(sp->R.chains * sp->K * sp->sides()), dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, (const DevModel *)sp->dM, \
+                                           (const ClModel *)sp->dCL, (const RunParams *)sp->dR, (const double *)dq0, lid)
+    CL_DISPATCH(sp->cl_dw, POTUS_CALL);
+#undef POTUS_CALL
   } else
     hipLaunchKernelGGL(k_init, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, (const double *)dq0);
   HIP_TRY(hipGetLastError());
@@ -2009,13 +2070,10 @@ int run_launch(RunTicket &t, int n_iter) {
     const unsigned lid = ++sp->launch_id;
     const dim3 grid((unsigned)(sp->R.chains * sp->K * sp->sides()));
     const DevModel *dM = sp->dM; const ClModel *dCL = sp->dCL; const RunParams *dR = sp->dR;
-    if (sp->twin) {
-      if (sp->cl_dw == 4) hipLaunchKernelGGL((k_cl_run<4, true>), grid, dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, dM, dCL, dR, n_iter, lid);
-      else hipLaunchKernelGGL((k_cl_run<8, true>), grid, dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, dM, dCL, dR, n_iter, lid);
-    } else {
-      if (sp->cl_dw == 4) hipLaunchKernelGGL((k_cl_run<4, false>), grid, dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, dM, dCL, dR, n_iter, lid);
-      else hipLaunchKernelGGL((k_cl_run<8, false>), grid, dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, dM, dCL, dR, n_iter, lid);
-    }
+#define POTUS_CALL(TAG) do { if (sp->twin) hipLaunchKernelGGL((k_cl_run<TAG, true>), grid, dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, dM, dCL, dR, n_iter, lid); \
+                             else hipLaunchKernelGGL((k_cl_run<TAG, false>), grid, dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, dM, dCL, dR, n_iter, lid); } while (0)
+    CL_DISPATCH(sp->cl_dw, POTUS_CALL);
+#undef POTUS_CALL
   } else
     hipLaunchKernelGGL(k_run, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, n_iter);
   HIP_TRY(hipGetLastError());
@@ -2047,7 +2105,7 @@ int potus_run(int handle, int n_iter) {
   if (n_iter <= 0) return 0;
   // launches are serialised per process: a cluster launch must find its compute units free, also of the
   // workgroups of a one-workgroup-per-chain sampler
-  std::lock_guard<std::mutex> cluster_lock(g_cluster_mu);
+  DeviceLocks lock(sp->device);
   RunTicket t{sp, handle, 0, 0};
   int rc = run_launch(t, n_iter);
   if (rc) return rc;
@@ -2070,7 +2128,9 @@ int potus_run_many(const int *handles, int n_handles, int n_iter) {
     for (int j = 0; j < i; j++) if (handles[j] == handles[i]) return fail(POTUS_ERR_ARG, "potus_run_many: handle %d listed twice", handles[i]);
     todo.push_back(RunTicket{sp, handles[i], 0, 0});
   }
-  std::lock_guard<std::mutex> cluster_lock(g_cluster_mu);
+  std::vector<int> devs;
+  for (const RunTicket &t : todo) devs.push_back(t.sp->device);
+  DeviceLocks lock(devs);
   std::vector<char> done(todo.size(), 0);
   size_t n_done = 0;
   while (n_done < todo.size()) {
@@ -2250,7 +2310,7 @@ int potus_dense_check(int handle, int chain, int n_probe, double *out) {
   if (!sp || !out) return fail(POTUS_ERR_STATE, "bad handle or null output");
   if (!sp->dense) return fail(POTUS_ERR_STATE, "the handle runs the diagonal metric");
   if (chain < 0 || chain >= sp->R.chains || n_probe < 1) return fail(POTUS_ERR_ARG, "potus_dense_check: bad chain or probe count");
-  std::lock_guard<std::mutex> cluster_lock(g_cluster_mu);
+  DeviceLocks lock(sp->device);
   HIP_TRY(hipSetDevice(sp->device));
   DnParams &P = sp->dn;
   const int D = P.D, chains = P.chains;
@@ -2355,6 +2415,7 @@ int potus_write_array(int handle, int col_begin, int col_end, double *out) {
   Sampler *sp = get(handle);
   if (!sp || !out) return fail(POTUS_ERR_STATE, "bad handle or null output");
   if (col_begin < 0 || col_end > sp->L.ncols || col_begin >= col_end) return fail(POTUS_ERR_ARG, "bad column range [%d,%d) of %d", col_begin, col_end, sp->L.ncols);
+  DeviceLocks lock(sp->device);
   HIP_TRY(hipSetDevice(sp->device));
   int n_saved = 0, rc = saved_count(sp, &n_saved);
   if (rc) return rc;
@@ -2367,6 +2428,7 @@ int potus_write_array_device(int handle, int col_begin, int col_end, void *out_d
   Sampler *sp = get(handle);
   if (!sp || !out_device) return fail(POTUS_ERR_STATE, "bad handle or null output");
   if (col_begin < 0 || col_end > sp->L.ncols || col_begin >= col_end) return fail(POTUS_ERR_ARG, "bad column range [%d,%d) of %d", col_begin, col_end, sp->L.ncols);
+  DeviceLocks lock(sp->device);
   HIP_TRY(hipSetDevice(sp->device));
   hipPointerAttribute_t at;
   if (hipPointerGetAttributes(&at, out_device) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != sp->device) {
@@ -2384,14 +2446,23 @@ int potus_write_array_device(int handle, int col_begin, int col_end, void *out_d
 int potus_posterior_summary_many(const int *handles, int n_handles, const double *ev, double *state_out, double *natl_out, double *ev_out) {
   if (!handles || n_handles < 1 || !ev || !state_out || !natl_out || !ev_out) return fail(POTUS_ERR_ARG, "potus_posterior_summary: null argument");
   std::vector<Sampler *> sps;
-  std::vector<int> n_saved(n_handles, 0);
+  std::vector<int> n_saved(n_handles, 0), devs;
   long long nd = 0;
   for (int i = 0; i < n_handles; i++) {
     Sampler *sp = get(handles[i]);
     if (!sp) return fail(POTUS_ERR_STATE, "potus_posterior_summary: bad handle %d", handles[i]);
+    devs.push_back(sp->device);
+  }
+  DeviceGuard guard;                                   // whatever happens below, the caller's device comes back
+  DeviceLocks lock(devs);
+  for (int i = 0; i < n_handles; i++) {
+    Sampler *sp = get(handles[i]);
     for (int j = 0; j < i; j++) if (handles[j] == handles[i]) return fail(POTUS_ERR_ARG, "potus_posterior_summary: handle %d listed twice", handles[i]);
-    if (i > 0 && (sp->M.S != sps[0]->M.S || sp->M.T != sps[0]->M.T || sp->L.ncols != sps[0]->L.ncols))
-      return fail(POTUS_ERR_ARG, "potus_posterior_summary: handle %d holds another model than handle %d", handles[i], handles[0]);
+    // pooling is for the chains of ONE posterior: same shape, same variant, same data (its hash) -- the first handle's state
+    // weights are the ones the national vote is taken with
+    if (i > 0 && (sp->M.S != sps[0]->M.S || sp->M.T != sps[0]->M.T || sp->L.ncols != sps[0]->L.ncols || sp->M.full != sps[0]->M.full ||
+                  sp->data_hash != sps[0]->data_hash))
+      return fail(POTUS_ERR_ARG, "potus_posterior_summary: handle %d holds another posterior than handle %d (pooled summaries are for the chains of one)", handles[i], handles[0]);
     HIP_TRY(hipSetDevice(sp->device));
     int rc = saved_count(sp, &n_saved[i]);
     if (rc) return rc;
@@ -2424,6 +2495,9 @@ int potus_posterior_summary_many(const int *handles, int n_handles, const double
       double *blk = nullptr;
       HIP_TRY(far.alloc(&blk, (size_t)rows * NC * 8));
       if ((rc = write_array_range(sp, n_saved[i], col_begin, col_end, blk, true, NC))) return rc;
+      // (hipMemcpyPeer stages through the host when the two GPUs have no peer access; with it, the copy goes over xGMI)
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, s0->device, sp->device) == hipSuccess && can) { (void)hipSetDevice(s0->device); (void)hipDeviceEnablePeerAccess(sp->device, 0); (void)hipGetLastError(); (void)hipSetDevice(sp->device); }
       HIP_TRY(hipMemcpyPeer(dst, s0->device, blk, sp->device, (size_t)rows * NC * 8));
       HIP_TRY(hipSetDevice(s0->device));
     }
@@ -2490,8 +2564,8 @@ int potus_last_run_timing(int handle, double *ms, long long *leapfrogs) {
 int potus_write_stan_csv(int handle, const char *dir, const char *basename) {
   Sampler *sp = get(handle);
   if (!sp || !dir || !basename) return fail(POTUS_ERR_STATE, "bad handle or null path");
-  HIP_TRY(hipSetDevice(sp->device));
-  int n_saved = 0, rc = saved_count(sp, &n_saved);
+  int n_saved = 0, rc = 0;
+  { DeviceLocks lock0(sp->device); HIP_TRY(hipSetDevice(sp->device)); rc = saved_count(sp, &n_saved); }
   if (rc) return rc;
   const int chains = sp->R.chains, ncols = sp->L.ncols, D = sp->L.D;
   std::vector<double> eps(chains), minv((size_t)chains * D);
@@ -2517,6 +2591,8 @@ int potus_write_stan_csv(int handle, const char *dir, const char *basename) {
             o.max_depth, sp->dense ? "dense_e" : "diag_e (Default)", o.stepsize);
     fprintf(f, "# id = %d\n# data\n#   file = (in-memory)\n# init = %g\n# random\n#   seed = %llu\n# output\n#   file = %s\n#   diagnostic_file =  (Default)\n#   refresh = 100 (Default)\n",
             sp->R.chain_id_offset + c + 1, o.init_radius, (unsigned long long)o.seed, path.c_str());
+    // (not CmdStan's: what the library resolved cus_per_chain = 0 / twin = -1 to -- draws are reproducible bit for bit for a given pair)
+    fprintf(f, "# potus_hmc\n#   cus_per_chain = %d\n#   clusters_per_chain = %d\n#   metric_storage = %s\n", sp->K, sp->sides(), sp->dense && sp->dn.f32 ? "f32" : "f64");
     char name[96];
     for (int k = 0; k < ncols; k++) { potus_column_name(&dd, k, name, sizeof name); fprintf(f, k ? ",%s" : "%s", name); }
     fprintf(f, "\n");
@@ -2563,7 +2639,8 @@ int potus_write_stan_csv(int handle, const char *dir, const char *basename) {
   for (int i0 = 0; i0 < n_saved; i0 += blk) {
     const int nb = std::min(blk, n_saved - i0);
     view.R.draws = sp->R.draws + (size_t)i0 * sp->R.row;
-    if ((rc = write_array_range(&view, nb, 0, ncols, rows.data()))) { close_all(); return rc; }
+    { DeviceLocks lockb(sp->device); rc = write_array_range(&view, nb, 0, ncols, rows.data()); }
+    if (rc) { close_all(); return rc; }
     // one host thread per chain (up to the cores there are) turns its rows into text: "%.6g" through std::to_chars -- the same
     // characters as printf, a third faster, and the 347 M numbers of the 2016 fit (8 x 1000 x 43 360) no longer go through
     // one thread
@@ -2722,14 +2799,7 @@ int potus_dense_factor_probe(int device, int chains, int D, int n, const double 
   hipLaunchKernelGGL(k_dn_center, eg, dim3(256), 0, 0, P, n);
   hipLaunchKernelGGL(k_dn_cov, dim3(nb, nb, chains), dim3(256), 0, 0, P, n);
   (void)hipEventRecord(ev[1], 0);
-  for (int kb = 0; kb < nb; kb++) {
-    hipLaunchKernelGGL(k_dn_potrf, dim3(chains), dim3(256), 0, 0, P, kb);
-    const int rem = nb - kb - 1;
-    if (rem > 0) {
-      hipLaunchKernelGGL(k_dn_trsm, dim3(rem, chains), dim3(256), 0, 0, P, kb);
-      hipLaunchKernelGGL(k_dn_syrk, dim3(rem, rem, chains), dim3(256), 0, 0, P, kb);
-    }
-  }
+  dense_cholesky_launch(0, P, chains);
   (void)hipEventRecord(ev[2], 0);
   if (u_host && p_host) {
     for (int c = 0; c < chains; c++) HIP_TRY(hipMemcpy(P.state + ((size_t)c * DV_COUNT + DV_P0) * P.LD, u_host + (size_t)c * D, (size_t)D * 8, hipMemcpyHostToDevice));
