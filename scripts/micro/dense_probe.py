@@ -89,15 +89,15 @@ def pieces():
               f"({fl_chol / ms[1] / 1e9:.1f} TFLOP/s), solve {ms[2]:.2f} ms; wall {time.time() - t:.1f} s", flush=True)
 
 
-def run_sampler(data, variant, chains, iters, cus):
-    h = Handle(data, variant, chains=chains, num_warmup=iters, num_samples=0, seed=1843, metric=_abi.METRIC_DENSE, cus_per_chain=cus)
+def run_sampler(data, variant, chains, iters, cus, storage=0):
+    h = Handle(data, variant, chains=chains, num_warmup=iters, num_samples=0, seed=1843, metric=_abi.METRIC_DENSE, cus_per_chain=cus, metric_storage=storage)
     h.init()
     t0 = time.perf_counter()
     h.run(iters)
     wall = time.perf_counter() - t0
     ms, passes, nbytes, rounds = h.dense_timing()
     lf = h.total_leapfrogs()
-    out = dict(chains=chains, iterations=iters, D=h.D, cus_per_chain=h.cus_per_chain, leapfrogs=lf, wall_s=wall, leapfrogs_per_s=lf / wall,
+    out = dict(metric_storage="f32" if storage else "f64", window_end=h.dense_adapt_timing(), chains=chains, iterations=iters, D=h.D, cus_per_chain=h.cus_per_chain, leapfrogs=lf, wall_s=wall, leapfrogs_per_s=lf / wall,
                matvec_ms=ms, matvec_passes=passes, matvec_gb=nbytes / 1e9, matvec_tb_per_s=nbytes / ms / 1e9, matvec_frac_of_8tbs=nbytes / ms / 1e9 / 8.0,
                rounds=rounds, ms_per_round=1e3 * wall / max(rounds, 1), matvec_share_of_wall=ms * 1e-3 / wall)
     h.close()
@@ -117,7 +117,8 @@ if __name__ == "__main__":
     else:
         chains, iters = int(sys.argv[2]), int(sys.argv[3])
         cus = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+        storage = 1 if len(sys.argv) > 5 and sys.argv[5] == "f32" else 0
         if what == "sampler":
-            run_sampler(dataprep.load_npz(ROOT / "tests" / "golden" / "data_2016.npz")["data"], "full", chains, iters, cus)
+            run_sampler(dataprep.load_npz(ROOT / "tests" / "golden" / "data_2016.npz")["data"], "full", chains, iters, cus, storage)
         else:
-            run_sampler(synthetic.stress(), "full", chains, iters, cus)
+            run_sampler(synthetic.stress(), "full", chains, iters, cus, storage)

@@ -41,6 +41,9 @@
 #ifndef CL_AUX_LD
 #define CL_AUX_LD CL_AUX_SC1             // policy of the exchange reader's loads
 #endif
+#ifndef CL_X3_IN_B
+#define CL_X3_IN_B 0                     // 1: the previous leaf's totals are collected in phase B by a wave that is done early there (see phase C)
+#endif
 #define CL_SPIN_LIMIT 8000000u
 #ifndef CL_SPIN_SLEEP
 #define CL_SPIN_SLEEP 1                  // s_sleep argument between two looks at an exchange word that has not arrived
@@ -734,6 +737,12 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     const int sx = lane < S ? lane : S;
     X[wj * SE + sx] = pT;
     X[(6 + wj) * SE + sx] = pB;
+#if CL_X3_IN_B
+    // The previous leaf's totals (exchange pend.tag, sent before this pass began) are fetched here, by a wave that finishes
+    // its share of the mat-vecs 1.5-2 k cycles before wave 0 has the suffix totals: an L2 round trip under load costs about
+    // 2 k cycles, which the verdict wave of phase C used to pay on the critical path of that phase.
+    if (w == 3 && pend.n >= 0) cl_wide_consume(x, pend.tag, pend.nv, wout);
+#endif
   }
   // suffix totals of the members that own later days: fetched once per workgroup (wave 0, which has
   // nothing else to do here) and handed to the other waves through LDS
@@ -849,10 +858,12 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       // them: the totals were sent a whole phase B ago, so nothing waits here, and the U-turn / accept logic runs
       // beside the poll arithmetic of the other waves.
       WPROF_T0B();
+#if !CL_X3_IN_B
 #ifdef POTUS_PROF
       cl_wide_consume(x, pend.tag, pend.nv, wout, prof);
 #else
       cl_wide_consume(x, pend.tag, pend.nv, wout);
+#endif
 #endif
       WPROF_PTB(29);
       cl_leaf_logic(ts, pend, wout);

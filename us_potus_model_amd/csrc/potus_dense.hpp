@@ -213,7 +213,8 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
             for (int e = 0; e < NE; e++) {
               const int col = c0 + NE * (lane + 64 * u) + e;
               double av;
-              if constexpr (F32) av = (double)__builtin_bit_cast(float, a[k][u][e]);
+              // (through a scalar: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index, hipcc 7.2)
+              if constexpr (F32) { const unsigned wv = a[k][u][e]; av = (double)__uint_as_float(wv); }
               else av = __hiloint2double((int)a[k][u][2 * e + 1], (int)a[k][u][2 * e]);   // (constexpr: the other branch would index past the vector)
               // (fp32: beyond column D a row's float half runs into the next row's doubles, whose halves may read as NaN)
               const double ae = (col > lim && (!F32 || col < D)) ? av : 0.0;
@@ -914,16 +915,24 @@ __global__ __launch_bounds__(256) void k_dn_syrk_wide(const DnParams P, int pb, 
 #pragma unroll
     for (int tj = 0; tj < 4; tj++) acc[ti][tj] = dn_d4{0.0, 0.0, 0.0, 0.0};
   const int lrow = tid >> 1, lk = (tid & 1) * 8;         // staging: thread = (row of the tile, half of the sixteen columns)
+  const bool oka = I0 + lrow < P.D, okb = J0 + lrow < P.D;
+  const double *ga = L + (size_t)(oka ? I0 + lrow : 0) * P.LD + c0 + lk, *gb = L + (size_t)(okb ? J0 + lrow : 0) * P.LD + c0 + lk;
+  double ra[8], rb[8];                                   // the next sixteen columns travel in registers while the matrix cores work
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const bool ok = k0 + lk + u < K;
+      ra[u] = (ok && oka) ? ga[k0 + u] : 0.0;
+      rb[u] = (ok && okb) ? gb[k0 + u] : 0.0;
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < K; k0 += 16) {
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int kk = k0 + lk + u;
-      const bool ok = kk < K;
-      a[lk + u][lrow] = (ok && I0 + lrow < P.D) ? L[(size_t)(I0 + lrow) * P.LD + c0 + kk] : 0.0;
-      b[lk + u][lrow] = (ok && J0 + lrow < P.D) ? L[(size_t)(J0 + lrow) * P.LD + c0 + kk] : 0.0;
-    }
+    for (int u = 0; u < 8; u++) { a[lk + u][lrow] = ra[u]; b[lk + u][lrow] = rb[u]; }
     __syncthreads();
+    if (k0 + 16 < K) fetch(k0 + 16);
 #pragma unroll
     for (int st = 0; st < 4; st++) {
       double av[4], bv[4];
