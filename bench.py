@@ -339,7 +339,7 @@ def main():
         traffic = tr[1]["hbm_bytes_per_leapfrog"] * sum(lf_local) / (kernel_ms * 1e-3) / 1e9 if tr else None
         traffic_note = (f"NOT measured in this run: {tr[1]['hbm_bytes_per_leapfrog']:.0f} HBM bytes per leapfrog from the committed "
                         f"rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE, profiles/{tr[0]}; WRITE_SIZE "
-                        f"uncalibrated) x this run's leapfrogs / launch time" if tr else "no PMC pass committed for this kernel")
+                        f"calibrated at 1.000 counted bytes per stored byte, profiles/r03_write_size_calibration.txt) x this run's leapfrogs / launch time" if tr else "no PMC pass committed for this kernel")
         if dense:   # the matrix pass: HBM reads measured / bytes loaded by construction, from the committed counter pass of the dense sampler
             for f in sorted((ROOT / "profiles").glob("*dense_pmc_fetch.json")):
                 try:

@@ -189,7 +189,7 @@ def test_bench_bookkeeping_on_the_committed_profiles():
     one, two = bench.measured_traffic("k_cl_run", 1), bench.measured_traffic("k_cl_run", 2)
     assert one and two and one[0] != two[0] and "two clusters" in two[1]["command"] and "two clusters" not in one[1]["command"]
     assert 0.5 < one[1]["hbm_bytes_per_leapfrog"] / 844784 < 0.8 and 0.9 < two[1]["hbm_bytes_per_leapfrog"] / 844784 < 1.3
-    line = json.loads([ln for ln in (ROOT / "profiles" / "r02_bench_line.json").read_text().splitlines() if ln.startswith("{")][0])
+    line = json.loads([ln for ln in (ROOT / "profiles" / "r03_bench_line.json").read_text().splitlines() if ln.startswith("{")][0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
         assert k in line, k
@@ -197,4 +197,10 @@ def test_bench_bookkeeping_on_the_committed_profiles():
     r = line["roofline"]
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["peak"] == 8000.0
     assert abs(line["value"] - line["leapfrogs"] / line["seconds"]) < 1e-6 * line["value"]
-    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1 and line["rhat_max"] < 1.01
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and line["rhat_max"] < 1.01
+    # the CPU side is measured, not derived: a complete short configuration run to the end on both sides
+    sc = cb["short_config"]
+    assert sc["ess_per_sec_measured"] > 0 and sc["gpu"]["ess_per_sec_measured"] > sc["ess_per_sec_measured"] and cb["ess_per_sec_measured"] == sc["ess_per_sec_measured"]
+    assert abs(line["speedup_vs_cpu_port"] - line["value"] / cb["value"]) < 1e-9 and line["speedup_vs_cpu_leapfrog_loop"] < line["speedup_vs_cpu_port"]
+    assert line["config"]["all_gather_bytes_per_rank"] == 1000 * 8 * (1 + 51 * 254) * 8            # lp__ + all of mu_b

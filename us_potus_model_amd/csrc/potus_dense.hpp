@@ -901,7 +901,7 @@ __global__ __launch_bounds__(256) void k_dn_chk_lx(const DnParams P, int chain, 
 #define DN_PANEL 4
 #define DN_WT 128
 #define DN_WS 144
-__global__ __launch_bounds__(256) void k_dn_syrk_wide(const DnParams P, int pb, int nk) {
+__global__ __launch_bounds__(256, 2) void k_dn_syrk_wide(const DnParams P, int pb, int nk) {   // (two workgroups per compute unit: one tile's read-modify-write tail under the other's products)
   __shared__ double a[16][DN_WS], b[16][DN_WS];
   const int r_first = (pb + nk) * DN_NB;                 // first row / column behind the panel
   const int I0 = r_first + (int)blockIdx.x * DN_WT, J0 = r_first + (int)blockIdx.y * DN_WT, chain = blockIdx.z;
