@@ -225,7 +225,7 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
           // the row's sum over this tile: across the lanes by DPP (lane 63 ends up with it), then into the block's row sums
 #pragma unroll
           for (int r = 0; r < NRHS; r++) {
-            const double tot = dpp_scan_sum(sp[r]);
+            const double tot = dpp_scan_sum(sp[r]);   // (measured: without it the fp64 pass is no faster, the fp32 pass 6 %: r03_dense_storage_study.txt)
             if (lane == 63) sacc[r * DN_RB_MAX + lrow] += tot;
           }
         }
