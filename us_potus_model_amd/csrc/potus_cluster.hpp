@@ -41,6 +41,19 @@
 #ifndef CL_AUX_LD
 #define CL_AUX_LD CL_AUX_SC1             // policy of the exchange reader's loads
 #endif
+// experiments on the fixed build (all measured slower together: r03_cl_fixed_layout_build.txt); 0 = off
+#ifndef CL_FX_FULL
+#define CL_FX_FULL 1                     // the fixed build serves the full model only: `full` is a constant there (-4.6 % / -1.3 %)
+#endif
+#ifndef CL_FX_K16
+#define CL_FX_K16 0
+#endif
+#ifndef CL_FX_XW
+#define CL_FX_XW 0
+#endif
+#ifndef CL_FX_BATCH
+#define CL_FX_BATCH 0
+#endif
 #ifndef CL_X3_IN_B
 #define CL_X3_IN_B 0                     // 1: the previous leaf's totals are collected in phase B by a wave that is done early there (see phase C)
 #endif
@@ -74,6 +87,59 @@ struct ClModel {
   int lds_doubles;
 };
 typedef const ClModel AS_C *CCp;
+
+// The fourth build of the pass (tag 16): what the reference's posteriors look like on clusters of 16 -- 51 states, at most 32 days
+// and 256 polls per member -- with the LDS LAYOUT FIXED AT COMPILE TIME.  Every LDS address of the pass is then an immediate
+// (DS instructions carry a 16-bit offset) instead of a base kept in a scalar register, and the state count is a constant: the
+// kernel keeps ~150 wave-uniform values alive for 102 scalar registers, and one instruction in ten of the dynamic build
+// restores one of them from a vector-register lane.  The host lays the member's LDS out with these very numbers
+// (build_cluster) when the model fits the capacities; anything else takes the dynamic builds.
+constexpr int cl_ev(int n) { return (n + 1) & ~1; }   // LDS blocks start on 16-byte boundaries (build_cluster's `take`)
+struct ClFixed {
+  static constexpr int S = 51, SE = 52, SP = 51, NDP = 33;
+  static constexpr int NPCAP = 256, NSUBCAP = 384, NREPCAP = 768, NRCAP = 512, TCAP = 320;   // polls, level-1 tasks per member; small parameters; slots; days
+  static constexpr int KMAX = 16;                    // members per cluster: every loop over the members is a single batch of sixteen tagged words
+  static constexpr int XW = 832;                     // exchange words per member: max(XP_P + NRCAP, XQ0 + NREPCAP) = max(72 + 512, 64 + 768)
+  // and the full model (poll_model_2020.stan: mode / population effects, AR(1) bias); the no_mode_adjustment variant takes the dynamic build
+  static constexpr int l_G = 0, GS = 48, GROWS = 52;
+  static constexpr int l_C = 0;
+  static constexpr int l_Lw = l_C + cl_ev(S * NDP > 12 * SE ? S * NDP : 12 * SE);
+  static constexpr int l_LT = l_Lw + cl_ev((SE + 1) * SP);
+  static constexpr int l_LB = l_LT + cl_ev(S * (S + 1) / 2 + 2);
+  static constexpr int l_w = l_LB + cl_ev(S * (S + 1) / 2 + 2);
+  static constexpr int l_prior = l_w + cl_ev(SE);
+  static constexpr int l_pm = l_prior + cl_ev(SE);
+  static constexpr int l_py = l_pm + cl_ev(NPCAP + 8);
+  static constexpr int l_pun = l_py + cl_ev(NPCAP + 8);
+  static constexpr int l_sub = l_pun + cl_ev(NPCAP + 8);
+  static constexpr int l_tab = l_sub + cl_ev(NSUBCAP * 4 + 4);
+  static constexpr int l_ru = l_tab + cl_ev((NPCAP + 64) / 2 + 2);
+  static constexpr int l_wide = l_ru + cl_ev(NPCAP + 2);
+  static constexpr int l_wout = l_wide + cl_ev(96 * PT_NW);
+  static constexpr int l_X = l_wout + cl_ev(96);
+  static constexpr int l_Y = l_X + cl_ev(12 * SE);
+  static constexpr int l_r = l_Y + cl_ev((PT_NW + 1) * SE > NSUBCAP ? (PT_NW + 1) * SE : NSUBCAP);
+  static constexpr int l_rep = l_r + cl_ev(NPCAP + 2);
+  static constexpr int l_bT = l_rep + cl_ev(NREPCAP + 2);
+  static constexpr int l_pb = l_bT + cl_ev(SE);
+  static constexpr int l_e = l_pb + cl_ev(SE);
+  static constexpr int l_c1 = l_e + cl_ev(TCAP);
+  static constexpr int l_c2 = l_c1 + cl_ev(CL_MAXDAYS);
+  static constexpr int l_c3 = l_c2 + cl_ev(CL_MAXDAYS);
+  static constexpr int l_gs = l_c3 + cl_ev(CL_MAXDAYS);
+  static constexpr int l_ge = l_gs + cl_ev(SE);
+  static constexpr int l_P = l_ge + cl_ev(CL_MAXDAYS);
+  static constexpr int l_scal = l_P + cl_ev(NRCAP + 8);
+  static constexpr int l_red = l_scal + cl_ev(SC_N);
+  static constexpr int l_st = l_red + cl_ev((PT_NW + 1) * PT_NRED);
+  static constexpr int l_prof = l_st + cl_ev((NPCAP + 8 + 7) / 8);
+  static constexpr int lds_doubles = l_prof + cl_ev(PT_NPROF);
+};
+template <int TAG> struct ClTag {
+  static constexpr int DW = (TAG == 12 || TAG == 16) ? 4 : TAG;      // days per wave
+  static constexpr bool MF = TAG == 12;                               // adjoint product on the matrix cores
+  static constexpr bool FX = TAG == 16;                               // LDS layout and state count fixed at compile time
+};
 typedef const int AS_C *cip;
 
 __device__ __forceinline__ double bld_s(rsrc_t r, unsigned voff, unsigned soff) {
@@ -593,8 +659,9 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
                                                   bool pubnext, const LeafCtx &pend, ltp ts, ldp wout, bool &aborted) {
   // the builds of the pass (every template above and in potus_hmc.hip just hands the tag down): 4 / 8 = days per wave with the
   // adjoint as a walk over the polls, 12 = four days per wave with the adjoint product on the matrix cores (MF)
-  constexpr int CL_DW = CL_TAG == 12 ? 4 : CL_TAG;
-  constexpr bool MF = CL_TAG == 12;
+  constexpr int CL_DW = ClTag<CL_TAG>::DW;
+  constexpr bool MF = ClTag<CL_TAG>::MF, FX = ClTag<CL_TAG>::FX;
+#define LAY(f) (FX ? (int)ClFixed::f : CL->f)
   Pol pol = pol_io;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
@@ -603,20 +670,21 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   cip part = launder_s(part_in);
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int S = M->S, T = M->T, SE = M->SE, SP = M->SP, full = M->full, o_c = M->o_c;
-  const int NDP = CL->NDP, NR = CL->NR, NREP = CL->NREP;
+  if constexpr (FX) { lds = (ldp)lds_dyn; if (CL_FX_XW) x.XW = ClFixed::XW; if (CL_FX_K16) x.K = 16; }   // the LDS base is a link-time constant; the exchange stride a compile-time one (the host uses the same number)
+  const int S = FX ? (int)ClFixed::S : M->S, T = M->T, SE = FX ? (int)ClFixed::SE : M->SE, SP = FX ? (int)ClFixed::SP : M->SP, full = (FX && CL_FX_FULL) ? 1 : M->full, o_c = M->o_c;
+  const int NDP = FX ? (int)ClFixed::NDP : CL->NDP, NR = CL->NR, NREP = CL->NREP;
   const int d0 = part[CP_D0], nd = part[CP_ND], np = part[CP_NP], e0 = part[CP_E0], r0 = part[CP_R0], nr = part[CP_NR];
-  const int K = x.K, m = x.m;
+  const int K = (FX && CL_FX_K16) ? 16 : x.K, m = x.m;
   const int wd0 = __builtin_amdgcn_readfirstlane(cst.wd0), wnd = __builtin_amdgcn_readfirstlane(cst.wnd);
-  ldp C = lds + CL->l_C, Lw = lds + CL->l_Lw, X = lds + CL->l_X, Y = lds + CL->l_Y, r_lds = lds + CL->l_r, ru_lds = lds + CL->l_ru;
-  ldp s_rep = lds + CL->l_rep;
+  ldp C = lds + LAY(l_C), Lw = lds + LAY(l_Lw), X = lds + LAY(l_X), Y = lds + LAY(l_Y), r_lds = lds + LAY(l_r), ru_lds = lds + LAY(l_ru);
+  ldp s_rep = lds + LAY(l_rep);
   ldp s_zT = s_rep, s_zb = s_rep + S, s_mid = s_rep + 2 * S;
-  ldp s_bT = lds + CL->l_bT, s_pb = lds + CL->l_pb, s_e = lds + CL->l_e, s_c1 = lds + CL->l_c1, s_c2 = lds + CL->l_c2, s_c3 = lds + CL->l_c3;
-  ldp s_gs = lds + CL->l_gs, s_ge = lds + CL->l_ge, s_P = lds + CL->l_P, s_scal = lds + CL->l_scal, red = lds + CL->l_red;
+  ldp s_bT = lds + LAY(l_bT), s_pb = lds + LAY(l_pb), s_e = lds + LAY(l_e), s_c1 = lds + LAY(l_c1), s_c2 = lds + LAY(l_c2), s_c3 = lds + LAY(l_c3);
+  ldp s_gs = lds + LAY(l_gs), s_ge = lds + LAY(l_ge), s_P = lds + LAY(l_P), s_scal = lds + LAY(l_scal), red = lds + LAY(l_red);
   const int e_noise = e0 + S * nd, e_ze = part[CP_E_SH], e_rep = e_ze + (full ? nd : 0);   // the shared block starts on its own line
   double lp = 0.0;
 #ifdef POTUS_PROF
-  ldp prof = lds + CL->l_prof;
+  ldp prof = lds + LAY(l_prof);
 #endif
   PROF_START();
   TSTAMP(0);
@@ -717,7 +785,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   } else if (w >= 2) {
     // partial products of the two 51 x 51 factors: wave w-2 takes columns k = w-2, w+4, ...
     const int wj = w - 2;
-    ldp LT = lds + CL->l_LT, LB = lds + CL->l_LB;
+    ldp LT = lds + LAY(l_LT), LB = lds + LAY(l_LB);
     constexpr int NJ = 11;                        // 6 waves x 11 columns >= 63
     double lt[NJ], lb[NJ], zt[NJ], zb[NJ];
     const int ls = lane < S ? lane : 0, tri = ls * (ls + 1) / 2;
@@ -749,7 +817,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   if (w == 0) {
     WPROF_PT(27);
     double carry_m = 0.0;
-    for (int mm0 = m + 1; mm0 < K; mm0 += 16) {
+    for (int mm0 = m + 1, bt = 0; mm0 < K && (!(FX && CL_FX_BATCH) || bt < 1); mm0 += 16, bt++) {   // (FX: at most sixteen members, one batch)
       double t16[16];
       unsigned vo[16], so[16];
 #pragma unroll
@@ -790,11 +858,11 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     if (lane < S) {
 #pragma unroll
       for (int w2 = 0; w2 < 6; w2++) { bT += X[w2 * SE + lane]; pb += X[(6 + w2) * SE + lane]; }
-      bT += (lds + CL->l_prior)[lane];
+      bT += (lds + LAY(l_prior))[lane];
       s_bT[lane] = bT;
       s_pb[lane] = pb;
     }
-    const double ww = lane < S ? (lds + CL->l_w)[lane] : 0.0;
+    const double ww = lane < S ? (lds + LAY(l_w))[lane] : 0.0;
     const double nb = dpp_scan_sum(ww * bT), npb = dpp_scan_sum(ww * pb);   // stan:79 and the national average of mu_b[:,T]
     if (lane == 63) { s_bT[S] = nb; s_pb[S] = npb; }
   }
@@ -809,9 +877,9 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   {
     const int om = M->o_m - o_c, opop = M->o_pop - o_c;
     const double sigma_c = M->sigma_c, sigma_m = M->sigma_m, sigma_pop = M->sigma_pop, sigma_ns = M->sigma_ns, sigma_nn = M->sigma_nn;
-    const unsigned long long AS_L *pm = (const unsigned long long AS_L *)(lds + CL->l_pm);
-    const unsigned long long AS_L *pyn = (const unsigned long long AS_L *)(lds + CL->l_py);
-    ldp pun = lds + CL->l_pun;
+    const unsigned long long AS_L *pm = (const unsigned long long AS_L *)(lds + LAY(l_pm));
+    const unsigned long long AS_L *pyn = (const unsigned long long AS_L *)(lds + LAY(l_py));
+    ldp pun = lds + LAY(l_pun);
     if (full && w == PT_NW - 1) {
       // the three tangent recurrences of the AR(1) bias (needed in phase E2 only) run here, on the wave that
       // has no polls unless the member has more than 448 of them, instead of lengthening phase B
@@ -939,7 +1007,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // (the adjoint input of e_bias[t]).  At the last poll of a day the running values go to LDS; the owners
   // of the days pick them up in phase E.  Level-1 segment sums follow.
   if constexpr (!MF) {
-    const unsigned AS_L *tab = (const unsigned AS_L *)(lds + CL->l_tab);
+    const unsigned AS_L *tab = (const unsigned AS_L *)(lds + LAY(l_tab));
     const int lk = lane < S ? lane : 0;
     const int ca = __builtin_amdgcn_readfirstlane(cst.ca), cb = __builtin_amdgcn_readfirstlane(cst.cb);
     double acc = 0.0;
@@ -974,7 +1042,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     // Adjoint on the matrix cores, step 1: G[pseudo-state][local day] = sum of the residuals of the cell's polls (the polls of a
     // member are sorted by day, then state: a cell is a run).  One thread per cell; polls of day T are left out (they feed
     // mu_b_T only, stan:85-86).  Idle threads write the dump slot behind G.
-    ldp G = lds + CL->l_G;
+    ldp G = lds + LAY(l_G);
 #pragma unroll
     for (int h = 0; h < CL_CELLS_PER_THREAD; h++) {
       if (h == 0 || part[CP_NCELL] > h * PT_THREADS) {     // wave-uniform
@@ -987,7 +1055,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   }
   {
     const int nsub = part[CP_NSUB], wb = part[CP_WB];   // tasks from wb on sum unadjusted * residual (day sums)
-    const u32x4 AS_L *sb = (const u32x4 AS_L *)(lds + CL->l_sub);
+    const u32x4 AS_L *sb = (const u32x4 AS_L *)(lds + LAY(l_sub));
     for (int sub0 = 0; sub0 < nsub; sub0 += PT_THREADS) {
       const int sub = sub0 + tid;
       const bool ok = sub < nsub;
@@ -1042,7 +1110,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     // row_shr steps on the accumulators, plus the running total of the earlier tiles.  Its cost does not depend on the number
     // of polls: the member that owns the poll-dense last days no longer sets the pace of the cluster.
     if (w < 4) {
-      ldp G = lds + CL->l_G;
+      ldp G = lds + LAY(l_G);
       const int GS = CL->GS, nst = CL->GROWS >> 2, g = lane >> 4, n = lane & 15;
       const int nt = (nd + 15) >> 4;
       double carry[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1141,7 +1209,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     // dbT[s] = dpolling_bias[s] = residuals of state s + w_s * national residuals (this member's polls
     // only: the products are linear, the owners add the K partials); C region is free now
     const int wj = w - 2;
-    ldp LT = lds + CL->l_LT, LB = lds + CL->l_LB, s_w = lds + CL->l_w;
+    ldp LT = lds + LAY(l_LT), LB = lds + LAY(l_LB), s_w = lds + LAY(l_w);
     double pT = 0.0, pB = 0.0;
     const double gnat = s_gs[S];
     constexpr int NJ = 11;
@@ -1203,7 +1271,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // wave 1 finishes raw_e_bias, the owners of small-vector slots finish theirs; then the S x T block
   if (w == 0) {
     double carry_m = 0.0;
-    for (int mm0 = 0; mm0 < m; mm0 += 16) {
+    for (int mm0 = 0, bt = 0; mm0 < m && (!(FX && CL_FX_BATCH) || bt < 1); mm0 += 16, bt++) {
       double t16[16];
       unsigned vo[16], so[16];
 #pragma unroll
@@ -1245,7 +1313,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     double sum = 0.0;
     const unsigned v1 = is_mue ? 16u * (unsigned)XP_S : is_rho ? 16u * (unsigned)(XP_S + 1) : is_s3 ? 16u * (unsigned)(XP_S + 2)
                         : repl ? 16u * (unsigned)(XP_P + rslot) : PT_OOB;
-    for (int mm0 = 0; mm0 < K; mm0 += 16) {
+    for (int mm0 = 0, bt = 0; mm0 < K && (!(FX && CL_FX_BATCH) || bt < 1); mm0 += 16, bt++) {
       double t16[16];
       unsigned vo[16], so[16];
 #pragma unroll
@@ -1315,6 +1383,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   (void)red;
   return lp;
 }
+#undef LAY
 template <int CL_DW, class Pol>
 __device__ __forceinline__ double cl_pass(CMp M, CCp CL, cip part, ldp lds, const ClStatic &cst, Xch &x, Pol &pol_io) {
   double v[1 + Pol::NEXTRA];
@@ -1653,7 +1722,8 @@ template <int CL_DW> __device__ __noinline__ unsigned cl_cold_twin_combine(const
 
 template <int CL_DW, bool TWIN>
 __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, const ClTwinArgs &ta) {
-  ltp ts = c.ts;
+  constexpr bool FX = ClTag<CL_DW>::FX;              // (the template argument is the build's tag)
+  ltp ts = FX ? (ltp)((ldp)lds_dyn + ClFixed::lds_doubles) : c.ts;
   const int tid = c.tid;
   const double eps = ts->eps;
   int depth = 0;
@@ -1722,7 +1792,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, co
     CPROF_MARK(c, PF_PNEAR);
     bool valid = true;
     const int nleaf = 1 << depth;
-    ldp wpart = c.lds + c.CL->l_wide, wout = c.lds + c.CL->l_wout;
+    ldp wpart = FX ? (ldp)lds_dyn + ClFixed::l_wide : c.lds + c.CL->l_wide, wout = FX ? (ldp)lds_dyn + ClFixed::l_wout : c.lds + c.CL->l_wout;
     // Consecutive leaves of the subtree are software-pipelined: a leaf sends its totals (log density, kinetic energy,
     // U-turn dot products) and the next leaf starts at once; the totals are collected and the verdicts taken inside
     // that next pass (cl_pass_partial, `pend`).  Only the last leaf of the doubling waits for its own totals.

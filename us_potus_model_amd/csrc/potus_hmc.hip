@@ -1335,6 +1335,25 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   C.l_st = take((npmax + 8 + 7) / 8);
   C.l_prof = take(PT_NPROF);
   C.lds_doubles = o;
+  // The build with the layout fixed at compile time (tag 16, ClFixed): 51 states, members of at most 32 days / 256 polls / 384
+  // level-1 tasks, the walk for the adjoint.  The numbers above are replaced by ClFixed's -- the kernel uses them as immediates.
+  {
+    int ndmax = 1;
+    for (int m = 0; m < K; m++) ndmax = std::max(ndmax, part[(size_t)m * CP_N + CP_ND]);
+    const bool fits = DW == 4 && !mfma && full && (CL_FX_K16 ? K == 16 : K <= ClFixed::KMAX) && std::max(XP_P + C.NR, XQ0 + C.NREP) <= ClFixed::XW && S == ClFixed::S && M.SE == ClFixed::SE && M.SP == ClFixed::SP && ndmax <= ClFixed::NDP - 1 && npmax <= ClFixed::NPCAP &&
+                      nsubmax <= ClFixed::NSUBCAP && C.NREP <= ClFixed::NREPCAP && C.NR <= ClFixed::NRCAP && T <= ClFixed::TCAP && (int)SC_N <= 8;
+    if (fits && !(getenv("POTUS_CL_DYNAMIC") && atoi(getenv("POTUS_CL_DYNAMIC")))) {
+      C.NDP = ClFixed::NDP; C.XW = ClFixed::XW;
+      C.l_C = ClFixed::l_C; C.l_G = 0; C.l_Lw = ClFixed::l_Lw; C.l_LT = ClFixed::l_LT; C.l_LB = ClFixed::l_LB; C.l_w = ClFixed::l_w; C.l_prior = ClFixed::l_prior;
+      C.l_pm = ClFixed::l_pm; C.l_py = ClFixed::l_py; C.l_pun = ClFixed::l_pun; C.l_sub = ClFixed::l_sub; C.l_tab = ClFixed::l_tab; C.l_ru = ClFixed::l_ru;
+      C.l_wide = ClFixed::l_wide; C.l_wout = ClFixed::l_wout; C.l_X = ClFixed::l_X; C.l_Y = ClFixed::l_Y; C.l_r = ClFixed::l_r; C.l_rep = ClFixed::l_rep;
+      C.l_bT = ClFixed::l_bT; C.l_pb = ClFixed::l_pb; C.l_e = ClFixed::l_e; C.l_c1 = ClFixed::l_c1; C.l_c2 = ClFixed::l_c2; C.l_c3 = ClFixed::l_c3;
+      C.l_gs = ClFixed::l_gs; C.l_ge = ClFixed::l_ge; C.l_P = ClFixed::l_P; C.l_scal = ClFixed::l_scal; C.l_red = ClFixed::l_red; C.l_st = ClFixed::l_st;
+      C.l_prof = ClFixed::l_prof; C.lds_doubles = ClFixed::lds_doubles;
+      o = ClFixed::lds_doubles;
+      sp->cl_dw = 16;
+    }
+  }
   sp->cl_lds_bytes = (size_t)o * 8 + sizeof(TS) + 16;
   if (sp->cl_lds_bytes > 160 * 1024 - 64) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode needs %zu bytes of LDS per workgroup", sp->cl_lds_bytes);
 
@@ -1348,6 +1367,8 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   HIP_TRY(hipMemcpy(pc, &C, sizeof(ClModel), hipMemcpyHostToDevice));
   sp->dCL = (ClModel *)pc;
   for (const void *f : {reinterpret_cast<const void *>(k_cl_logprob_grad<4>), reinterpret_cast<const void *>(k_cl_logprob_grad<8>), reinterpret_cast<const void *>(k_cl_logprob_grad<12>),
+                        reinterpret_cast<const void *>(k_cl_logprob_grad<16>), reinterpret_cast<const void *>(k_cl_init<16>),
+                        reinterpret_cast<const void *>(k_cl_run<16, false>), reinterpret_cast<const void *>(k_cl_run<16, true>),
                         reinterpret_cast<const void *>(k_cl_init<4>), reinterpret_cast<const void *>(k_cl_init<8>), reinterpret_cast<const void *>(k_cl_init<12>),
                         reinterpret_cast<const void *>(k_cl_run<4, false>), reinterpret_cast<const void *>(k_cl_run<8, false>), reinterpret_cast<const void *>(k_cl_run<12, false>),
                         reinterpret_cast<const void *>(k_cl_run<4, true>), reinterpret_cast<const void *>(k_cl_run<8, true>), reinterpret_cast<const void *>(k_cl_run<12, true>)})
@@ -1357,8 +1378,9 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
 }
 
 // The builds of the cluster pass (template tag of potus_cluster.hpp): 4 = four days per wave, 8 = eight days per wave, 12 = four
-// days per wave with the adjoint product on the fp64 matrix cores (poll-dense posteriors).
-#define CL_DISPATCH(tag, CALL) do { if ((tag) == 4) { CALL(4); } else if ((tag) == 12) { CALL(12); } else { CALL(8); } } while (0)
+// days per wave with the adjoint product on the fp64 matrix cores (poll-dense posteriors), 16 = four days per wave, 51 states, LDS
+// layout fixed at compile time (ClFixed: the reference's posteriors on clusters of 16).
+#define CL_DISPATCH(tag, CALL) do { if ((tag) == 16) { CALL(16); } else if ((tag) == 4) { CALL(4); } else if ((tag) == 12) { CALL(12); } else { CALL(8); } } while (0)
 
 // replica 0 of every chain's scalars
 int read_scalars(Sampler *sp, std::vector<ChainScalars> &sc) {
@@ -1502,7 +1524,7 @@ int dense_alloc(Sampler *sp) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(1)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(2)));
   if (sp->K == 1) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_grad1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
-  else for (const void *f : {reinterpret_cast<const void *>(k_dn_gradK<4>), reinterpret_cast<const void *>(k_dn_gradK<8>), reinterpret_cast<const void *>(k_dn_gradK<12>)})
+  else for (const void *f : {reinterpret_cast<const void *>(k_dn_gradK<4>), reinterpret_cast<const void *>(k_dn_gradK<8>), reinterpret_cast<const void *>(k_dn_gradK<12>), reinterpret_cast<const void *>(k_dn_gradK<16>)})
     HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
   hipLaunchKernelGGL(k_dn_identity, dim3((D + 255) / 256, chains), dim3(256), 0, sp->stream, P);
   HIP_TRY(hipGetLastError());
@@ -1873,8 +1895,8 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
       if (rc) return bail(rc);
       // the members of a cluster wait for each other: the whole grid has to be resident at once
       int per_cu = 0;
-      const void *kfn = sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4, false>) : sp->cl_dw == 12 ? reinterpret_cast<const void *>(k_cl_run<12, false>)
-                                       : reinterpret_cast<const void *>(k_cl_run<8, false>);
+      const void *kfn = sp->cl_dw == 16 ? reinterpret_cast<const void *>(k_cl_run<16, false>) : sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4, false>)
+                        : sp->cl_dw == 12 ? reinterpret_cast<const void *>(k_cl_run<12, false>) : reinterpret_cast<const void *>(k_cl_run<8, false>);
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, PT_THREADS, sp->cl_lds_bytes) != hipSuccess || per_cu < 1)
         return bail(fail(POTUS_ERR_DEVICE, "cluster kernel cannot be resident on this device (occupancy query: %d workgroups per compute unit with %zu bytes of LDS)",
                          per_cu, sp->cl_lds_bytes));
@@ -1885,8 +1907,8 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
       const bool twin_fits = o->metric != POTUS_METRIC_DENSE && (long long)o->chains * 2 * K <= (long long)ncu;
       if (o->twin == 1 && !twin_fits)
         return bail(fail(POTUS_ERR_ARG, "twin = 1: two clusters of %d per chain need %d compute units (the device has %d) and the diagonal metric", K, o->chains * 2 * K, ncu));
-      const void *kft = sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4, true>) : sp->cl_dw == 12 ? reinterpret_cast<const void *>(k_cl_run<12, true>)
-                                       : reinterpret_cast<const void *>(k_cl_run<8, true>);
+      const void *kft = sp->cl_dw == 16 ? reinterpret_cast<const void *>(k_cl_run<16, true>) : sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4, true>)
+                        : sp->cl_dw == 12 ? reinterpret_cast<const void *>(k_cl_run<12, true>) : reinterpret_cast<const void *>(k_cl_run<8, true>);
       int per_cu_t = 0;
       if ((o->twin == 1 || (o->twin < 0 && o->cus_per_chain == 0)) && twin_fits &&
           hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, kft, PT_THREADS, sp->cl_lds_bytes) == hipSuccess && per_cu_t >= 1)
