@@ -228,10 +228,45 @@ def test_adaptation_matches_oracle_through_a_metric_update(cases, cus):
         assert np.allclose(minv[0], ad[1:], rtol=1e-4) and np.array_equal(d[100:110, 3:6], ref[100:110, 3:6])
         assert np.allclose(d[100:110, 2], ref[100:110, 2], rtol=1e-5)          # the step size found by init_stepsize after the update
     all_in_step = np.allclose(d[:, 7:], ref[:, 7:], rtol=1e-4, atol=1e-5)
+    # init_stepsize doubles or halves from nearly the same start: whatever the two chains have drifted apart by iteration 100, the
+    # step sizes right after the window end are a few doublings apart at most (a wrong gradient there shows as 1e-4 and less)
+    assert abs(np.log(d[100, 2] / ref[100, 2])) < np.log(8.0) + 1e-9, (d[100, 2], ref[100, 2])
     assert abs(np.log(eps[0] / ad[0])) < (0.05 if all_in_step else 0.5)
     ratio = np.log(minv[0] / ad[1:])
     assert abs(np.median(ratio)) < 0.15 and np.abs(ratio).max() < 2.5
     assert abs(h.total_leapfrogs() - nl) / nl < (0.02 if all_in_step else 0.5)
+    h.close()
+
+
+@pytest.mark.parametrize("twin", [0, 1])
+@pytest.mark.parametrize("name", ["2016", "2012", "small_nomode"])
+def test_the_gradient_kept_at_a_window_end_is_the_gradient_of_the_point(cases, name, twin):
+    """One workgroup (or two) per chain: at a window end the sampler re-evaluates log density and gradient at the chain's point
+    before init_stepsize.  That pass is a separately inlined copy of the model pass (cold_transition_end); in round 3 it was found
+    to hand garbage to the S x T block of the gradient on the 2016 posterior (a register spilled under an empty EXEC mask,
+    scripts/check_spill_exec.py), which collapsed the step size after every metric update.  Checked directly on the device state:
+    the vector kept as the gradient equals potus_log_prob_grad of the vector kept as the point, and the step size that
+    init_stepsize finds from it is a sane one."""
+    import ctypes
+    data, variant = cases[name]
+    nw = 40                                            # windows: init buffer 6, one window ending with iteration 35
+    h = Handle(data, variant, chains=3, num_warmup=nw, num_samples=0, save_warmup=1, seed=99, cus_per_chain=1, twin=twin)
+    h.init(); h.run(35)
+    eps_before = np.array(h.adaptation()[0])
+    h.run(1)                                           # iteration 35: metric update, gradient refresh, init_stepsize
+    lib = h.L
+    lib.potus_debug_state.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.potus_debug_state.restype = ctypes.c_int
+    sz = np.zeros(3)
+    assert lib.potus_debug_state(h.h, 0, sz.ctypes.data_as(ctypes.c_void_p), None)
+    st = np.zeros((3 * (1 + twin), int(sz[0]), int(sz[1])))
+    assert lib.potus_debug_state(h.h, 1, st.ctypes.data_as(ctypes.c_void_p), None)
+    for b in range(st.shape[0]):                       # every chain, both sides
+        q, g_kept = st[b, 0, :h.D], st[b, 1, :h.D]     # V_QC, V_GC
+        lp, g = h.log_prob_grad(q)
+        assert np.array_equal(g[0], g_kept), (b, np.abs(g[0] - g_kept).max())
+    eps_after = np.array(h.adaptation()[0])
+    assert (np.abs(np.log(eps_after / eps_before)) < np.log(64.0)).all(), (eps_before, eps_after)
     h.close()
 
 

@@ -179,8 +179,6 @@ def test_twin_is_the_default_when_it_fits_and_only_then(cases):
     with pytest.raises(sampler.PotusError):
         Handle(data, variant, chains=16, num_warmup=10, num_samples=0, cus_per_chain=16, twin=1)
     with pytest.raises(sampler.PotusError):
-        Handle(data, variant, chains=2, num_warmup=10, num_samples=0, cus_per_chain=1, twin=1)
-    with pytest.raises(sampler.PotusError):
         Handle(data, variant, chains=2, num_warmup=30, num_samples=0, metric=1, cus_per_chain=8, twin=1)
 
 

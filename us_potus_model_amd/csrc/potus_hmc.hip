@@ -6,6 +6,7 @@
 #include "../../include/potus_hmc.h"
 #include "potus_nuts.hpp"
 #include "potus_cluster.hpp"
+#include "potus_nuts_twin.hpp"
 #include "potus_dense.hpp"
 #include "potus_summary.hpp"
 
@@ -36,15 +37,17 @@ __global__ __launch_bounds__(PT_THREADS) void k_logprob_grad(const DevModel *Mg,
   }
 }
 
-__device__ __forceinline__ Chain make_chain(CMp M, CRp R, int chain) {
+// (two workgroups per chain, potus_nuts_twin.hpp: side s of a chain works in block chain + s * chains of state and scalars)
+__device__ __forceinline__ Chain make_chain(CMp M, CRp R, int chain, int side = 0) {
   ldp lds = (ldp)lds_dyn;
   Chain c;
   const int Dpad = R->Dpad;
-  double *state = R->state + (size_t)chain * V_COUNT * Dpad;
+  const int blk = chain + side * R->chains;
+  double *state = R->state + (size_t)blk * V_COUNT * Dpad;
   c.M = M; c.lds = lds; c.ts = (ltp)(lds + M->lds_doubles);
   c.base = as_g(state);
   c.st = make_rsrc(state, (unsigned)V_COUNT * (unsigned)Dpad * 8u);
-  c.sc = (gsc)(R->scal + chain);
+  c.sc = (gsc)(R->scal + blk);
   c.key = RngKey{R->seed_lo, R->seed_hi, (uint32_t)(R->chain_id_offset + chain + 1)};
   c.D = M->D; c.Dpad = Dpad; c.tid = (int)threadIdx.x; c.max_depth = R->max_depth; c.num_warmup = R->num_warmup;
   c.init_buffer = R->init_buffer; c.term_buffer = R->term_buffer;
@@ -60,8 +63,8 @@ __device__ __forceinline__ Chain make_chain(CMp M, CRp R, int chain) {
 __global__ __launch_bounds__(PT_THREADS) void k_init(const DevModel *Mg, const RunParams *Rg, const double *q0) {
   CMp M = (CMp)Mg;
   CRp R = (CRp)Rg;
-  const int chain = blockIdx.x;
-  Chain c = make_chain(M, R, chain);
+  const int chain = blockIdx.x % R->chains, side = blockIdx.x / R->chains;   // side 1: two workgroups per chain only
+  Chain c = make_chain(M, R, chain, side);
   c.pst = model_setup_lds(M, c.lds);
   const int tid = c.tid;
   gdp Q0 = c.vec(V_QC), G0 = c.vec(V_GC), minv = c.vec(V_MINV), mean = c.vec(V_WMEAN), m2 = c.vec(V_WM2);
@@ -98,10 +101,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_init(const DevModel *Mg, const R
 
 // The once-per-transition work is kept out of line so that the register allocator only sees the
 // tree loop (leaves + merges) in the kernel body.  Arguments are re-made wave-uniform on entry.
-__device__ __noinline__ void cold_transition_begin(const DevModel *Mg, const RunParams *Rg, int chain, uint32_t iter) {
+__device__ __noinline__ void cold_transition_begin(const DevModel *Mg, const RunParams *Rg, int chain, uint32_t iter, int side = 0) {
   CMp M = (CMp)uni_ptr(Mg);
   CRp R = (CRp)uni_ptr(Rg);
-  Chain c = make_chain(M, R, (int)uni32((unsigned)chain));
+  Chain c = make_chain(M, R, (int)uni32((unsigned)chain), (int)uni32((unsigned)side));
   c.pst = model_load_static(M);
   transition_begin(c, uni32(iter));
 }
@@ -172,6 +175,208 @@ __global__ __launch_bounds__(PT_THREADS) void k_run(const DevModel *Mg, const Ru
 #ifdef POTUS_PROF
   if (R->prof) for (int i = c.tid; i < PT_NPROF; i += PT_THREADS) as_g(R->prof)[(size_t)chain * PT_NPROF + i] += c.prof[i];
 #endif
+}
+
+
+// ------------------------------------------------------------------------ two workgroups per chain (potus_nuts_twin.hpp): the cold parts
+// The combine of doubling d by the side that built its subtree (valid: the subtree completed without an internal U-turn or
+// divergence and was not dropped).  Sets ts->tw_over when the trajectory is over.  Follows cl_cold_twin_combine below.
+__device__ __noinline__ void cold_twin1_combine(const DevModel *Mg, const RunParams *Rg, int chain_, int side_, unsigned launch_, uint32_t iter_,
+                                                int depth_, int valid_) {
+  CMp M = (CMp)uni_ptr(Mg);
+  CRp R = (CRp)uni_ptr(Rg);
+  const int chain = (int)uni32((unsigned)chain_), side = (int)uni32((unsigned)side_), d = (int)uni32((unsigned)depth_);
+  const int valid = (int)uni32((unsigned)valid_);
+  const uint32_t iter = uni32(iter_);
+  Chain c = make_chain(M, R, chain, side);
+  const Xch x = tw1_watch(R, chain + side * R->chains, launch_);
+  const Twin t = make_twin(R, chain, side, x.launch, iter);
+  ltp ts = c.ts;
+  const int tid = c.tid;
+  __syncthreads();
+  if (tid == 0) c.sc->leaves_run += ts->n_leap;       // whether the subtree ends up in the trajectory or not
+  // 1. the state this combine starts from: published by the combine of doubling d - 1 (or the end of the trajectory)
+  if (uni_i(ts->tw_seq) < d) {
+    if (tid < 64) tw_catch_up(x, t, ts, d);
+    __syncthreads();
+  }
+  if (uni_i((int)ts->tt[TT_STOP])) {                 // the trajectory ended before this doubling: the subtree is dropped
+    if (tid == 0) ts->tw_over = 1;
+    __syncthreads();
+    return;
+  }
+  const int rho_side = uni_i((int)ts->tt[TT_RHOSIDE]), dirs = uni_i(ts->tw_dirs);
+  int stop = 1;
+  if (valid) {
+    // 2. rho_top += rho_subtree and the three checks of transition() across the whole trajectory; the other end's momentum
+    //    and (if the last combine was the other side's) rho_top come from the other side's state block, where they were
+    //    stored write-through before that combine was published.  The subtree's last leaf becomes this side's end point.
+    const bool other_moved = ((side ? ~dirs : dirs) & ((1 << d) - 1)) != 0;
+    const rsrc_t rA = other_moved ? t.ost : c.st, rR = rho_side == 1 - side ? t.ost : c.st;
+    const int leaf = uni_i(ts->pend_end[d]);
+    const unsigned sM = c.soff(V_MINV), a_beg = c.soff(V_PF0 + (1 - side)), a_end = c.soff(V_PNEAR), s_rt = c.soff(V_RHOTOP);
+    const unsigned b_beg = c.soff(V_POOLP + uni_i(ts->pend_beg[d])), b_end = c.soff(V_POOLP + leaf);
+    const unsigned b_rho = d == 0 ? c.soff(V_POOLP + leaf) : c.soff(V_RHOLEV + d), s_pf = c.soff(V_PF0 + side);
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    const int tid0 = fresh_tid(c);
+    for (int base = tid0; base < c.D; base += PT_UNR * PT_THREADS) {
+      double mi[PT_UNR], ab[PT_UNR], ae[PT_UNR], ar[PT_UNR], bb[PT_UNR], be[PT_UNR], br[PT_UNR];
+#pragma unroll
+      for (int k = 0; k < PT_UNR; k++) {
+        const int i = base + k * PT_THREADS;
+        const unsigned o = i < c.D ? 8u * i : PT_OOB;   // masked elements read zeros and add nothing
+        mi[k] = bld(c.st, o, sM); ab[k] = bld_s(rA, o, a_beg); ae[k] = bld(c.st, o, a_end); ar[k] = bld_s(rR, o, s_rt);
+        bb[k] = bld(c.st, o, b_beg); be[k] = bld(c.st, o, b_end); br[k] = bld(c.st, o, b_rho);
+      }
+#pragma unroll
+      for (int k = 0; k < PT_UNR; k++) {
+        const int i = base + k * PT_THREADS;
+        const unsigned o = i < c.D ? 8u * i : PT_OOB;
+        const double rs = ar[k] + br[k];
+        bst_s(c.st, o, s_rt, rs);
+        bst_s(c.st, o, s_pf, be[k]);
+        const double sab = mi[k] * ab[k], sbe = mi[k] * be[k];
+        v[0] += sab * rs;                 // p#_beg . rho
+        v[1] += sbe * rs;                 // p#_end . rho
+        const double e1 = ar[k] + bb[k];  // rho_old + p of the subtree's first leaf
+        v[2] += sab * e1;
+        v[3] += mi[k] * bb[k] * e1;
+        const double e2 = br[k] + ae[k];  // rho_subtree + p of the old end
+        v[4] += mi[k] * ae[k] * e2;
+        v[5] += sbe * e2;
+      }
+    }
+    drain_vmem();                         // the stores above are complete before anything is published (barriers in block_sum)
+    block_sum(v, c.red(), tid0);
+    const bool persist = v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0 && v[4] > 0 && v[5] > 0;
+    stop = (!persist || d + 1 >= c.max_depth) ? 1 : 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // the subtree's leaves count whether it is valid or not (base_nuts: n_leapfrog_, sum_metro_prob, divergent_)
+    ts->tt[TT_METRO] += ts->sum_metro; ts->tt[TT_NLEAP] += (double)ts->n_leap;
+    if (ts->divergent) ts->tt[TT_DIV] = 1.0;
+    if (valid) {
+      const double lsw_top = ts->tt[TT_LSW], lsw_sub = ts->pend_lsw[d];
+      const int prop = ts->pend_prop[d];
+      bool accept;
+      if (lsw_sub > lsw_top) accept = true;
+      else accept = rng_uniform(c.key, iter, RNG_TOP_ACCEPT, 0, (uint32_t)d) < exp(lsw_sub - lsw_top);
+      if (accept) {
+        ts->tt[TT_SSIDE] = (double)side; ts->tt[TT_SSLOT] = (double)prop; ts->tt[TT_SLP] = ts->q_lp[prop]; ts->tt[TT_SH] = ts->q_h[prop];
+        ts->tw_keep = prop;
+      }
+      ts->tt[TT_LSW] = d_lse(lsw_top, lsw_sub);
+      ts->tt[TT_DEPTH] = (double)(d + 1);
+      ts->tt[TT_RHOSIDE] = (double)side;
+    }
+    ts->tt[TT_STOP] = (double)stop;
+    ts->tw_seq = d + 1; ts->tw_over = stop;
+  }
+  __syncthreads();
+  // 3. publish: the state after combine d, and the STOP word if the trajectory is over
+  if (tid < 64) {
+    const double val = ts->tt[tid < TT_N ? tid : 0];
+    tw_st(t, tid < TT_N ? 16u * (unsigned)(TWB_TOP + 16 * ((d + 1) & 1) + tid) : PT_OOB, val, t.ittag | (unsigned)(d + 2));
+    tw_st(t, (stop && tid == 0) ? 16u * (unsigned)TWB_STOP : PT_OOB, (double)(d + 1), t.ittag);
+  }
+  __syncthreads();
+}
+
+// New sample -> this side's chain position (from its own pool or from the other side's QC), draws array (side 0),
+// adaptation (both sides, same inputs, same bits), rendezvous with the other side.  Follows cl_cold_twin_end below.
+__device__ __noinline__ void cold_twin1_end(const DevModel *Mg, const RunParams *Rg, int chain_, int side_, unsigned launch_, uint32_t iter_) {
+  CMp M = (CMp)uni_ptr(Mg);
+  CRp R = (CRp)uni_ptr(Rg);
+  const int chain = (int)uni32((unsigned)chain_), side = (int)uni32((unsigned)side_), it = (int)uni32(iter_);
+  Chain c = make_chain(M, R, chain, side);
+  c.pst = model_load_static(M);
+  const Xch x = tw1_watch(R, chain + side * R->chains, launch_);
+  const Twin t = make_twin(R, chain, side, x.launch, (uint32_t)it);
+  ltp ts = c.ts;
+  const int tid = c.tid;
+  __syncthreads();
+  if (!uni_i(ts->tw_over)) {                          // this side ran out of doublings of its own: wait for the end
+    if (tid < 64) tw_catch_up(x, t, ts, -1);
+    __syncthreads();
+  }
+  const int owner = uni_i((int)ts->tt[TT_SSIDE]), slot = uni_i((int)ts->tt[TT_SSLOT]);
+  if (tid == 0) {
+    ts->n_leap = (int)ts->tt[TT_NLEAP]; ts->divergent = (int)ts->tt[TT_DIV]; ts->depth = (int)ts->tt[TT_DEPTH];
+    ts->accept_stat = ts->tt[TT_METRO] / ts->tt[TT_NLEAP];
+    ts->out_lp = ts->tt[TT_SLP]; ts->out_h = ts->tt[TT_SH];
+    c.sc->total_leapfrogs += ts->n_leap;
+    c.sc->n_divergent += ts->divergent;
+    c.sc->spec_limit = (int)(((unsigned)c.sc->spec_limit << 8) | (unsigned)ts->tw_seq);   // doublings of the last four transitions, a byte each
+  }
+  __syncthreads();
+  const bool warm = it < R->num_warmup;
+  const bool save = (!warm || R->save_warmup) && side == 0;
+  gdp row = as_g(R->draws) + ((size_t)chain * R->n_save_max + c.sc->saved) * R->row;
+  if (save && tid == 0) {
+    row[0] = ts->out_lp; row[1] = ts->accept_stat; row[2] = ts->eps; row[3] = ts->depth; row[4] = ts->n_leap;
+    row[5] = ts->divergent; row[6] = ts->out_h;
+  }
+  const unsigned sQ = c.soff(V_QC);
+  if (owner == 1 - side) {
+    if (tid < 64) { double dummy; tw_wait(x, t, TWB_QC, 1, t.ittag, dummy); }
+    __syncthreads();
+  }
+  {
+    // The side that holds the sample publishes it in V_SCR1 (write-through; free until the next transition's merges, which
+    // start after the rendezvous below) and keeps QC itself a plainly stored vector, as in the one-workgroup sampler: what
+    // reads QC later (Welford update, the model pass of the next transition) uses plain loads.
+    const bool remote = owner == 1 - side;
+    const unsigned s_src = remote ? c.soff(V_SCR1) : c.soff(V_POOLQ + slot), s_pub = c.soff(V_SCR1);
+    for (int i = tid; i < c.D; i += PT_THREADS) {
+      const double v = remote ? bld_s(t.ost, 8u * i, s_src) : bld(c.st, 8u * i, s_src);
+      bst(c.st, 8u * i, sQ, v);
+      if (owner == side) bst_s(c.st, 8u * i, s_pub, v);
+      if (save) row[POTUS_N_SAMPLER_COLS + i] = v;
+    }
+  }
+  drain_vmem();
+  __syncthreads();
+  if (owner == side && tid < 64) tw_st(t, tid == 0 ? 16u * (unsigned)TWB_QC : PT_OOB, 1.0, t.ittag);
+  if (tid == 0) {
+    c.sc->lp_cur = ts->out_lp;
+    if (!warm || R->save_warmup) c.sc->saved += 1;
+  }
+  if (warm) adapt_after_transition(c, (uint32_t)it, c.vec(V_QC));
+  __syncthreads();
+  if (tid == 0) c.sc->iter = it + 1;
+  // Rendezvous: nothing of this transition is read from the other side's memory after this point, and the other side
+  // must have reached the same point before this side's next transition overwrites what it may still be reading.
+  drain_vmem();
+  __syncthreads();
+  if (tid < 64) {
+    tw_st(t, tid == 0 ? 16u * (unsigned)(TWB_DONE + side) : PT_OOB, 1.0, t.ittag);
+    tw_wait_ge(x, t, TWB_DONE + (1 - side), t.ittag);
+  }
+  __syncthreads();
+}
+
+// grid = 2 * chains; block b works for chain b % chains on side b / chains.  Both sides must be resident together.
+__global__ __launch_bounds__(PT_THREADS) void k_run_twin(const DevModel *Mg, const RunParams *Rg, int n_iter, unsigned launch) {
+  CMp M = (CMp)Mg;
+  CRp R = (CRp)Rg;
+  const int chain = blockIdx.x % R->chains, side = blockIdx.x / R->chains;
+  Chain c = make_chain(M, R, chain, side);
+  if (c.sc->status != 0) return;
+  if (threadIdx.x == 0) cl_dead = 0;
+  c.pst = model_setup_lds(M, c.lds);
+  const Xch x = tw1_watch(R, chain + side * R->chains, launch);
+  const Tw1Args ta{Mg, Rg, chain, side, launch};
+  const int total = R->num_warmup + R->num_samples;
+  for (int k = 0; k < n_iter; k++) {
+    const int it = c.sc->iter;
+    if (it >= total || uni_i(cl_dead)) break;
+    cold_transition_begin(Mg, Rg, chain, (uint32_t)it, side);
+    transition_tree_twin(c, x, ta, (uint32_t)it);
+    if (uni_i(cl_dead)) break;
+    cold_twin1_end(Mg, Rg, chain, side, launch, (uint32_t)it);
+  }
+  if (uni_i(cl_dead) && (c.tid & 63) == 0) c.sc->status = POTUS_ERR_WATCHDOG;   // every wave that is still alive
 }
 
 // ------------------------------------------------------------------------ cluster kernels (potus_cluster.hpp)
@@ -816,6 +1021,7 @@ struct Sampler {
   int K = 1, cl_dw = 8;
   int twin = 0;             // two clusters per chain (one per end of the trajectory): state, scalars and exchange buffers hold 2 x chains blocks
   int sides() const { return twin ? 2 : 1; }
+  bool coop() const { return K > 1 || twin; }   // workgroups that wait for each other: the whole grid must be resident
   unsigned launch_id = 0;   // tags the exchange words of each launch
   ClModel CL{};
   ClModel *dCL = nullptr;
@@ -1076,6 +1282,7 @@ int set_lds_attr(Sampler *sp) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_logprob_grad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_run_twin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
   return 0;
 }
 
@@ -1396,16 +1603,16 @@ int read_scalars(Sampler *sp, std::vector<ChainScalars> &sc) {
 int check_chains(Sampler *sp) {
   std::vector<ChainScalars> sc;
   { const int rc_ = read_scalars(sp, sc); if (rc_) return rc_; }
-  if (sp->K > 1) {
-    const size_t per_chain = 4 * (size_t)sp->K * sp->CL.XW + 8;   // 16-byte words: exchange slots + the watchdog line
+  if (sp->coop()) {
+    const size_t per_chain = 4 * (size_t)sp->K * sp->CL.XW + 8;   // 16-byte words: exchange slots + the watchdog line (K = 1: XW = 0)
     for (int b = 0; b < sp->R.chains * sp->sides(); b++) {
       const int c = b % sp->R.chains;
       unsigned wd = 0, wt = 0;
       HIP_TRY(hipMemcpy(&wd, (const char *)sp->R.xbuf + ((size_t)b * per_chain + 4 * (size_t)sp->K * sp->CL.XW) * 16, 4, hipMemcpyDeviceToHost));
       if (sp->twin) HIP_TRY(hipMemcpy(&wt, (const char *)sp->R.twbuf + ((size_t)c * TWB_WORDS + TWB_WD) * 16, 4, hipMemcpyDeviceToHost));
       wd |= wt;
-      if (wd) return fail(POTUS_ERR_WATCHDOG, "chain %d: the %d workgroups of its cluster were not running together (is another process using GPU %d?); "
-                                              "the launch was abandoned and this handle is no longer usable", c + 1, sp->K, sp->device);
+      if (wd) return fail(POTUS_ERR_WATCHDOG, "chain %d: the %d workgroups working for it were not running together (is another process using GPU %d?); "
+                                              "the launch was abandoned and this handle is no longer usable", c + 1, sp->K * sp->sides(), sp->device);
     }
   }
   for (int c = 0; c < sp->R.chains; c++) {
@@ -1887,7 +2094,19 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
     } else if (K == 1 && !sp->k1_unsupported.empty())
       return bail(fail(POTUS_ERR_UNSUPPORTED, "%s; use cus_per_chain = 0 or >= 8", sp->k1_unsupported.c_str()));
     if (K > 1 && o->chains * K > ncu) return bail(fail(POTUS_ERR_ARG, "chains * cus_per_chain = %d exceeds the %d compute units of the device", o->chains * K, ncu));
-    if (o->twin == 1 && K == 1) return bail(fail(POTUS_ERR_ARG, "twin = 1 needs a cluster per chain (cus_per_chain = 0 or >= 8)"));
+    if (K == 1) {
+      // Two workgroups per chain, one per end of the trajectory (potus_nuts_twin.hpp), when the compute units are there: asked
+      // for (twin = 1), or chosen with the size (twin < 0 and cus_per_chain = 0: 65-128 chains on 256 compute units).  Both
+      // sides of every chain wait for each other: the whole grid has to be resident at once.  Diagonal metric only.
+      int per_cu = 0;
+      const bool fits = o->metric != POTUS_METRIC_DENSE &&
+                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_run_twin), PT_THREADS, sp->lds_bytes) == hipSuccess &&
+                        per_cu >= 1 && 2ll * o->chains <= (long long)ncu * per_cu;
+      if (o->twin == 1 && !fits)
+        return bail(fail(POTUS_ERR_ARG, "twin = 1: two workgroups per chain need %d resident workgroups (the device holds %d) and the diagonal metric",
+                         2 * o->chains, ncu * std::max(per_cu, 0)));
+      if ((o->twin == 1 || (o->twin < 0 && o->cus_per_chain == 0)) && fits) sp->twin = 1;
+    }
     if (K > 1) {
       rc = build_cluster(sp, d, K);
       // chosen by the library: a member whose polls do not fit its LDS gets half of them with twice the members
@@ -1946,7 +2165,7 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   (void)hipMemset(p, 0, sizeof(ChainScalars) * nblk * sp->K);
   R.K = sp->K; R.xbuf = nullptr; R.xcnt = nullptr; R.twin = sp->twin; R.twbuf = nullptr;
   R.debug_drop_member = getenv("POTUS_DEBUG_DROP_MEMBER") ? atoi(getenv("POTUS_DEBUG_DROP_MEMBER")) : 0;
-  if (sp->K > 1) {
+  if (sp->coop()) {
     const size_t xb = nblk * (4 * (size_t)sp->K * sp->CL.XW + 8) * 16;   // per chain (and side): 4 exchange slots + a line for the watchdog word
     if (hipMalloc(&p, xb) != hipSuccess) return bail(fail(POTUS_ERR_DEVICE, "hipMalloc for exchange buffers failed"));
     sp->allocs.push_back(p); R.xbuf = (double *)p;
@@ -2067,7 +2286,7 @@ int potus_init(int handle, const double *q0) {
     CL_DISPATCH(sp->cl_dw, POTUS_CALL);
 #undef POTUS_CALL
   } else
-    hipLaunchKernelGGL(k_init, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, (const double *)dq0);
+    hipLaunchKernelGGL(k_init, dim3(sp->R.chains * sp->sides()), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, (const double *)dq0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(sp->stream));
   { const int rc_ = check_chains(sp); if (rc_) return rc_; }
@@ -2096,7 +2315,10 @@ int run_launch(RunTicket &t, int n_iter) {
                              else hipLaunchKernelGGL((k_cl_run<TAG, false>), grid, dim3(PT_THREADS), sp->cl_lds_bytes, sp->stream, dM, dCL, dR, n_iter, lid); } while (0)
     CL_DISPATCH(sp->cl_dw, POTUS_CALL);
 #undef POTUS_CALL
-  } else
+  } else if (sp->twin)
+    hipLaunchKernelGGL(k_run_twin, dim3(2 * sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, n_iter,
+                       ++sp->launch_id);
+  else
     hipLaunchKernelGGL(k_run, dim3(sp->R.chains), dim3(PT_THREADS), sp->lds_bytes, sp->stream, (const DevModel *)sp->dM, (const RunParams *)sp->dR, n_iter);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(sp->ev1, sp->stream));
@@ -2168,7 +2390,7 @@ int potus_run_many(const int *handles, int n_handles, int n_iter) {
         group.push_back(i);
         break;
       }
-      if (sp->K > 1) {
+      if (sp->coop()) {
         int ncu = 0;
         HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, sp->device));
         const int rows = (sp->R.chains * sp->K * sp->sides() + 7) / 8, cap = ncu / 8;
@@ -2861,9 +3083,10 @@ int potus_debug_state(int handle, int which, double *out, unsigned char *scal) {
   Sampler *sp = get(handle);
   if (!sp || !out) return 0;
   (void)hipSetDevice(sp->device);
-  if (which == 0) { out[0] = V_COUNT; out[1] = sp->R.Dpad; out[2] = (double)(sizeof(ChainScalars) * sp->R.chains * sp->K); return 1; }
-  if (hipMemcpy(out, sp->R.state, sizeof(double) * V_COUNT * sp->R.Dpad * sp->R.chains, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-  if (scal && hipMemcpy(scal, sp->R.scal, sizeof(ChainScalars) * sp->R.chains * sp->K, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  const size_t nblk = (size_t)sp->R.chains * sp->sides();   // (two clusters / workgroups per chain: side 1's blocks follow side 0's)
+  if (which == 0) { out[0] = V_COUNT; out[1] = sp->R.Dpad; out[2] = (double)(sizeof(ChainScalars) * nblk * sp->K); return 1; }
+  if (hipMemcpy(out, sp->R.state, sizeof(double) * V_COUNT * sp->R.Dpad * nblk, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  if (scal && hipMemcpy(scal, sp->R.scal, sizeof(ChainScalars) * nblk * sp->K, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return 1;
 }
 

@@ -298,11 +298,17 @@ __device__ __forceinline__ double model_pass(CMp M_in, ldp lds, const PassStatic
     const int sx = lane < S ? lane : S;         // X rows are SE = S+1 wide
     X[w * SE + sx] = pT;
     X[(PT_NW + w) * SE + sx] = pB;
-    for (int i = tid + PT_THREADS; i < nmid; i += PT_THREADS) { // only when there are more than 1024 such parameters
-      const int idx = o_c + i;
-      const double v = pol.q(idx);
-      s_mid[i] = v;
-      if (!(full && (idx == o_mue || idx == o_rho))) lp -= 0.5 * v * v;
+    // Only with more than PT_THREADS such parameters.  Uniform trip count and masked lanes instead of a per-lane loop: the exit
+    // block of a divergent loop that no lane enters is where hipcc 7.2 once put the spill of a register that is live across it,
+    // executed with an empty EXEC mask (scripts/check_spill_exec.py).
+    for (int i0 = PT_THREADS; i0 < nmid; i0 += PT_THREADS) {
+      const int i = i0 + tid, idx = o_c + i;
+      const bool ok = i < nmid;
+      typename Pol::QT qx;
+      pol.q_load(ok ? 8u * (unsigned)idx : PT_OOB, qx);
+      const double v = pol.q_fin(0u, qx);      // 0 on masked lanes
+      s_mid[ok ? i : nmid] = v;
+      lp -= (full && (idx == o_mue || idx == o_rho)) ? 0.0 : 0.5 * v * v;
     }
   }
   double cs[PT_CH], zq[PT_CH];   // suffix sums; positions (kept in registers until phase F)

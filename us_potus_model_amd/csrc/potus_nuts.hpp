@@ -391,6 +391,9 @@ __device__ __forceinline__ void transition_tree(const Chain &c, uint32_t iter) {
       ts->dir = rng_uniform(c.key, iter, RNG_DIRECTION, 0, (uint32_t)depth) > 0.5 ? 1 : 0;
       ts->pmask = 0;
       ts->qmask = 1u << ts->sample_qid;
+      // the metropolis terms of a doubling are summed on their own and then added to the trajectory's sum -- the order the
+      // two-workgroup form (potus_nuts_twin.hpp) has to use: with it the two produce the same bytes
+      ts->metro_base = ts->sum_metro; ts->sum_metro = 0.0;
     }
     __syncthreads();
     const int dir = ts->dir;
@@ -477,6 +480,7 @@ __device__ __forceinline__ void transition_tree(const Chain &c, uint32_t iter) {
       if (ts->copy_q_id >= 0) vop_copy(c, c.soff(V_POOLQ + ts->copy_q_id), c.soff((sel ? V_QB0 : V_QA0) + dir));
       CPROF_MARK(c, PF_COPYQ);
     }
+    if (tid == 0) ts->sum_metro += ts->metro_base;
     if (!valid) break;
     // merge the finished subtree with the old trajectory (the checks at the end of transition())
     const int nb = ts->pend_beg[depth], ne = ts->pend_end[depth];
