@@ -406,17 +406,25 @@ def main():
             # configuration -- a reference point for what the kernels deliver when parallelism is not the limit.
             try:
                 _, data, variant, _, _ = work[0]
-                hsat = Handle(data, variant, chains=256, num_warmup=60, num_samples=0, seed=args.seed + 7, device=local, cus_per_chain=1)
-                hsat.init()
-                ms_s, lf_s = 0.0, 0
-                for _ in range(3):
-                    hsat.run(20)
-                    ms1, lf1 = hsat.last_run_timing()
-                    ms_s += ms1; lf_s += lf1
-                hsat.close()
-                rate = lf_s / (ms_s * 1e-3)
+
+                def short_run(chains, twin_):
+                    hsat = Handle(data, variant, chains=chains, num_warmup=60, num_samples=0, seed=args.seed + 7, device=local, cus_per_chain=1, twin=twin_)
+                    hsat.init()
+                    ms_s, lf_s = 0.0, 0
+                    for _ in range(3):
+                        hsat.run(20)
+                        ms1, lf1 = hsat.last_run_timing()
+                        ms_s += ms1; lf_s += lf1
+                    hsat.close()
+                    return lf_s / (ms_s * 1e-3)
+
+                rate = short_run(256, 0)
+                r128 = [short_run(128, t) for t in (0, 1)]
                 line["saturated"] = {"chains": 256, "cus_per_chain": 1, "kernel": "k_run", "iterations": 60, "value": rate, "unit": "leapfrogs/s",
                                      "roofline_frac": rate * bpl[0] / 1e9 / HBM_PEAK_GBS,
+                                     "chains_128": {"one_workgroup_per_chain": r128[0], "two_workgroups_per_chain": r128[1], "kernel": "k_run / k_run_twin",
+                                                    "roofline_frac": max(r128) * bpl[0] / 1e9 / HBM_PEAK_GBS,
+                                                    "note": "65-128 chains: the library's choice is two workgroups per chain, one per end of the trajectory"},
                                      "note": "short warm-up run of 256 chains on the same posterior; kernel time of the launches"}
             except Exception as e:                     # never let the side measurement spoil the bench line
                 line["saturated"] = {"error": str(e)[:200]}

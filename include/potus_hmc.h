@@ -108,7 +108,7 @@ typedef struct potus_opts {
                               chain (best throughput with >= 64 chains), 2..32 = a cluster per chain
                               (lowest latency with few chains; chains * cus_per_chain <= CUs of the device),
                               0 = choose from {16, 8, 4, 1} by what fits (10-14 for
-                              9-12 chains, as two clusters each: see twin).  Draws are reproducible bit for bit
+                              9-12 chains, as two clusters each, and 1 with two workgroups per chain for 65-128 chains: see twin).  Draws are reproducible bit for bit
                               for a given value; different values differ in floating-point summation order. */
   int32_t metric;          /* POTUS_METRIC_DIAG (CmdStan's default, what final_2016.R:533-541 runs) or
                               POTUS_METRIC_DENSE (metric = "dense_e": stan::mcmc::dense_e_metric + covar_adaptation,
@@ -118,7 +118,9 @@ typedef struct potus_opts {
                               integrated at the same time (2 * chains * cus_per_chain <= CUs of the device); 0 = one
                               cluster; -1 = the library decides when it also chooses the cluster size (cus_per_chain = 0):
                               two clusters if they fit.  Same algorithm, RNG streams and arithmetic: the draws are the
-                              same bytes as with one cluster of the same size. */
+                              same bytes as with one cluster of the same size.  With cus_per_chain = 1 the "cluster" is one
+                              workgroup: two workgroups per chain (2 * chains <= resident workgroups of the device; what
+                              the library picks for 65-128 chains on 256 compute units). */
   int32_t metric_storage;  /* dense metric only: POTUS_STORAGE_F64 (Stan's) or POTUS_STORAGE_F32 -- the adapted covariance is
                               rounded to fp32 and THAT matrix is the metric: its Cholesky factor (fp64) draws the momenta, the
                               leapfrog multiplies with it (fp64 accumulation), so the sampler stays exact while the matrix pass
