@@ -161,18 +161,27 @@ __device__ __forceinline__ void rng_normal_pair(const RngKey &K, uint32_t iter, 
 //     ph' = pf + he*g          half-kicked momentum for the next leaf -> PH
 //     q'  = q + e*minv*ph'     position the next leaf evaluates -> the other ping-pong buffer
 // The arithmetic per leaf is exactly Stan's; only the order of stores differs.
+// A leaf that completes a pair (odd leaf of its subtree) also does the pair's U-turn check here, where its momentum is in
+// registers: with p' the previous leaf's momentum, rho = p' + pf goes to the slot the level-1 merge would have written, and the six
+// dot products of that merge collapse to two (begin = end = rho of a one-leaf subtree): extra[1] = p'.M^-1.rho, extra[2] =
+// pf.M^-1.rho.  That removes half of the merge sweeps (7 vector loads each, a quarter of the one-workgroup leaf's time).
 struct LeapPolicy {
   rsrc_t r;                          // the chain's state block
   unsigned sQc, sQn, sPH, sM, sL;    // byte offsets: position (this leaf / next), PH, inverse metric, leaf slot
   double he, e;
-  static constexpr int NEXTRA = 1;
-  static constexpr int GB = 8;
-  double extra[1];
+  unsigned sPrev, sRho;              // the previous leaf's momentum slot, the slot receiving rho of the pair
+  int pair;                          // 1: this leaf completes a pair (else nothing is read from sPrev or written to sRho)
+  static constexpr int NEXTRA = 3;
+#ifndef POTUS_LEAP_GB
+#define POTUS_LEAP_GB 4
+#endif
+  static constexpr int GB = POTUS_LEAP_GB;
+  double extra[3];
   struct QT { double q; };
-  struct GT { double p, m; };
+  struct GT { double p, m, pp; };
   __device__ __forceinline__ void q_load(unsigned vo, QT &t) { t.q = bld(r, vo, sQc); }
   __device__ __forceinline__ double q_fin(unsigned, QT &t) { return t.q; }
-  __device__ __forceinline__ void g_load(unsigned vo, GT &t) { t.p = bld(r, vo, sPH); t.m = bld(r, vo, sM); }
+  __device__ __forceinline__ void g_load(unsigned vo, GT &t) { t.p = bld(r, vo, sPH); t.m = bld(r, vo, sM); t.pp = bld(r, pair ? vo : PT_OOB, sPrev); }
   __device__ __forceinline__ void g_fin(unsigned vo, double v, double q, const GT &t) {
     const double pf = t.p + he * v;
     bst(r, vo, sL, pf);
@@ -180,6 +189,10 @@ struct LeapPolicy {
     bst(r, vo, sPH, ph);
     bst(r, vo, sQn, q + e * t.m * ph);
     extra[0] += t.m * pf * pf;   // masked-off elements loaded m = 0
+    const double rs = t.pp + pf; // (the order vop_merge adds them in: rho_init + rho_final)
+    bst(r, pair ? vo : PT_OOB, sRho, rs);
+    extra[1] += t.m * t.pp * rs;
+    extra[2] += t.m * pf * rs;
   }
   __device__ __forceinline__ double q(int i) { return bld(r, 8u * i, sQc); }
   __device__ __forceinline__ void g(int i, double v, double q) { GT t; g_load(8u * i, t); g_fin(8u * i, v, q, t); }
@@ -408,8 +421,10 @@ __device__ __forceinline__ void transition_tree(const Chain &c, uint32_t iter) {
       const double e = dir ? eps : -eps;
       const int sel = ts->qsel[dir];              // buffer holding this leaf's position
       const unsigned s_leaf = c.soff(V_POOLP + ts->leaf_id);
+      const int pair = n & 1, m_leaf = __builtin_ctz(~(unsigned)n);
       LeapPolicy lp{c.st, c.soff((sel ? V_QB0 : V_QA0) + dir), c.soff((sel ? V_QA0 : V_QB0) + dir), c.soff(V_PH0 + dir), c.soff(V_MINV),
-                    s_leaf, 0.5 * e, e, {0.0}};
+                    s_leaf, 0.5 * e, e, c.soff(V_POOLP + (pair ? ts->pend_beg[0] : ts->leaf_id)), m_leaf == 1 ? c.soff(V_RHOLEV + 1) : c.soff(V_SCR1),
+                    pair, {0.0, 0.0, 0.0}};
       const double lpv = model_pass(c.M, c.lds, c.pst, lp);
       CPROF_START(c);
       CPROF_COUNT(c, PF_LEAVES);
@@ -437,8 +452,9 @@ __device__ __forceinline__ void transition_tree(const Chain &c, uint32_t iter) {
         const unsigned a_rho = j == 1 ? c.soff(V_POOLP + ib) : c.soff(V_RHOLEV + j - 1);
         const unsigned b_rho = j == 1 ? c.soff(V_POOLP + cb) : c.soff(V_SCR0 + ((j - 1) & 1));
         const unsigned out = j == m ? c.soff(V_RHOLEV + j) : c.soff(V_SCR0 + (j & 1));
-        const bool persist = vop_merge(c, c.soff(V_POOLP + ib), c.soff(V_POOLP + ie), a_rho, c.soff(V_POOLP + cb),
-                                       c.soff(V_POOLP + ce), b_rho, out);
+        // (level 1 came out of the leaf's epilogue: begin = end = rho on both sides, so v0 = v2 = v4 and v1 = v3 = v5)
+        const bool persist = j == 1 ? (lp.extra[1] > 0 && lp.extra[2] > 0)
+                                    : vop_merge(c, c.soff(V_POOLP + ib), c.soff(V_POOLP + ie), a_rho, c.soff(V_POOLP + cb), c.soff(V_POOLP + ce), b_rho, out);
         CPROF_COUNT(c, PF_MERGES);
         if (tid == 0) {
           const double cur_lsw = ts->cur_lsw;
@@ -523,7 +539,7 @@ __device__ __forceinline__ void init_stepsize(const Chain &c, uint32_t iter) {
     const double kin0 = vop_momentum(c, c.soff(V_PC), iter, RNG_INIT_EPS, attempt);
     const double H0 = 0.5 * kin0 - lp0;
     vop_prekick(c, c.soff(V_QC), c.soff(V_PC), c.soff(V_GC), c.soff(V_PH1), c.soff(V_QA1), c.soff(V_PF1), 0.5 * eps, eps);
-    LeapPolicy lp{c.st, c.soff(V_QA1), c.soff(V_QB1), c.soff(V_PH1), c.soff(V_MINV), c.soff(V_SCR0), 0.5 * eps, eps, {0.0}};
+    LeapPolicy lp{c.st, c.soff(V_QA1), c.soff(V_QB1), c.soff(V_PH1), c.soff(V_MINV), c.soff(V_SCR0), 0.5 * eps, eps, c.soff(V_SCR0), c.soff(V_SCR1), 0, {0.0, 0.0, 0.0}};
     const double lpv = model_pass(c.M, c.lds, c.pst, lp);
     if (tid == 0) {
       double h = 0.5 * lp.extra[0] - lpv;

@@ -113,8 +113,10 @@ __device__ __forceinline__ void transition_tree_twin(const Chain &c, const Xch &
       const double e = dir ? eps : -eps;
       const int sel = ts->qsel[dir];              // buffer holding this leaf's position
       const unsigned s_leaf = c.soff(V_POOLP + ts->leaf_id);
+      const int pair = n & 1, m_leaf = __builtin_ctz(~(unsigned)n);
       LeapPolicy lp{c.st, c.soff((sel ? V_QB0 : V_QA0) + dir), c.soff((sel ? V_QA0 : V_QB0) + dir), c.soff(V_PH0 + dir), c.soff(V_MINV),
-                    s_leaf, 0.5 * e, e, {0.0}};
+                    s_leaf, 0.5 * e, e, c.soff(V_POOLP + (pair ? ts->pend_beg[0] : ts->leaf_id)), m_leaf == 1 ? c.soff(V_RHOLEV + 1) : c.soff(V_SCR1),
+                    pair, {0.0, 0.0, 0.0}};
       const double lpv = model_pass(c.M, c.lds, c.pst, lp);
       if (tid == 0) {
         const double H0 = ts->H0;
@@ -139,8 +141,8 @@ __device__ __forceinline__ void transition_tree_twin(const Chain &c, const Xch &
         const unsigned a_rho = j == 1 ? c.soff(V_POOLP + ib) : c.soff(V_RHOLEV + j - 1);
         const unsigned b_rho = j == 1 ? c.soff(V_POOLP + cb) : c.soff(V_SCR0 + ((j - 1) & 1));
         const unsigned out = j == m ? c.soff(V_RHOLEV + j) : c.soff(V_SCR0 + (j & 1));
-        const bool persist = vop_merge(c, c.soff(V_POOLP + ib), c.soff(V_POOLP + ie), a_rho, c.soff(V_POOLP + cb),
-                                       c.soff(V_POOLP + ce), b_rho, out);
+        const bool persist = j == 1 ? (lp.extra[1] > 0 && lp.extra[2] > 0)      // (level 1 came out of the leaf's epilogue)
+                                    : vop_merge(c, c.soff(V_POOLP + ib), c.soff(V_POOLP + ie), a_rho, c.soff(V_POOLP + cb), c.soff(V_POOLP + ce), b_rho, out);
         if (tid == 0) {
           const double cur_lsw = ts->cur_lsw;
           const double lsw_sub = d_lse(ts->pend_lsw[j - 1], cur_lsw);
