@@ -270,6 +270,34 @@ def test_the_gradient_kept_at_a_window_end_is_the_gradient_of_the_point(cases, n
     h.close()
 
 
+@pytest.mark.parametrize("cus,twin", [(16, 0), (16, 1), (8, 0)])
+def test_the_gradient_kept_at_a_window_end_in_cluster_mode(cases, cus, twin):
+    """The same check on the cluster kernels (their window-end pass is inlined into cl_cold_transition_end / cl_cold_twin_end):
+    the chain's vectors are kept in internal order there, so the permutation is recovered from the inverse metric, which
+    potus_get_adaptation hands out in Stan's order and whose entries are all different after a metric update."""
+    import ctypes
+    data, variant = cases["2016"]
+    h = Handle(data, variant, chains=2, num_warmup=40, num_samples=0, save_warmup=1, seed=99, cus_per_chain=cus, twin=twin)
+    h.init(); h.run(36)                                # iteration 35 ends the first window
+    lib = h.L
+    lib.potus_debug_state.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.potus_debug_state.restype = ctypes.c_int
+    sz = np.zeros(3)
+    assert lib.potus_debug_state(h.h, 0, sz.ctypes.data_as(ctypes.c_void_p), None)
+    st = np.zeros((2 * (1 + twin), int(sz[0]), int(sz[1])))
+    assert lib.potus_debug_state(h.h, 1, st.ctypes.data_as(ctypes.c_void_p), None)
+    minv = np.asarray(h.adaptation()[1])
+    for b in range(st.shape[0]):
+        c = b % 2
+        where = {v: i for i, v in enumerate(st[b, 11])}          # V_MINV, internal order (with padding)
+        assert len(set(minv[c])) == h.D
+        perm = np.array([where[v] for v in minv[c]])             # Stan index -> internal position
+        q, g_kept = st[b, 0, perm], st[b, 1, perm]               # V_QC, V_GC
+        lp, g = h.log_prob_grad(q)
+        assert np.allclose(g[0], g_kept, rtol=1e-12, atol=1e-12), (b, np.abs(g[0] - g_kept).max())
+    h.close()
+
+
 @pytest.mark.parametrize("cus", [1, 8, 16])
 @pytest.mark.parametrize("name,nw,total,splits", [("small_full", 150, 104, ([104], [99, 5], [100, 4], [99, 1, 4], [50, 49, 2, 3])),
                                                   ("2016", 60, 58, ([58], [53, 5], [54, 4], [53, 1, 4]))])
