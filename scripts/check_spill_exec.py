@@ -15,7 +15,11 @@ redefined before the mask widens served the narrowed region itself and is let th
 the instructions after branches.  Prologue / epilogue saves of callee-saved registers are plain stores at full EXEC and do
 not match.  Exit status 1 if anything is flagged:
 
-    python scripts/check_spill_exec.py [path/to/libpotus_hmc.so]
+    python scripts/check_spill_exec.py [path/to/libpotus_hmc.so] [--deep]
+
+--deep adds a flow-based check (deep_scan): the regions of narrowed EXEC open at every spill instruction are tracked along
+the code, and a reload is reported when no store to its slot ran in a context with at least the reload's lanes.  Both
+checks report the round-2 library's cold_transition_end and nothing in the current one.
 """
 import re
 import subprocess
@@ -109,14 +113,89 @@ def scan(body):
     return hits
 
 
+def slot(op, ops):
+    """(base, offset) of a scratch access."""
+    parts = [x.strip() for x in ops.split(",")]
+    addr = parts[1:] if op.startswith("scratch_load") else [parts[0]] + parts[2:]
+    m = re.search(r"offset:(\d+)", ops)
+    base = " ".join(a.split(" offset")[0] for a in addr)
+    return base, int(m.group(1)) if m else 0
+
+
+def deep_scan(body):
+    """Second, flow-based check.  Every narrowing of EXEC that saves the old mask (s_*_saveexec, or s_mov sX, exec followed by
+    s_mov exec, sY) opens a region, the instruction that ORs the saved mask back closes it; the regions open at an instruction
+    form its context (a tuple of region ids), carried along fall-through and forward branches.  A reload of a spill slot is
+    covered if some store to that slot ran in a context that is a prefix of the reload's, i.e. with at least its lanes; a
+    reload with no such store is reported.  Lanes that leave a loop (s_andn2 exec, exec, sX) do not open a region: they have
+    been through the loop's first trip.  Whole-wave saves (s_or_saveexec sX, -1) are skipped."""
+    state_at = {}                     # forward branch target -> (context, saved)
+    ctx, saved, wwm, dead = (), {}, False, False
+    stores, loads = {}, []
+    for addr, op, ops in body:
+        if addr in state_at:
+            c2, s2 = state_at.pop(addr)
+            if dead or len(c2) < len(ctx):
+                ctx, saved = c2, dict(s2) if dead else {**saved, **s2}
+            dead = False
+        if dead:
+            continue
+        o = [x.strip() for x in ops.split(",")]
+        if op.startswith("s_or_saveexec") and o[-1] == "-1":
+            wwm = True
+        elif wwm and op == "s_mov_b64" and o[0] == "exec":
+            wwm = False
+        elif wwm:
+            pass
+        elif op.startswith("s_and_saveexec"):
+            saved[o[0]] = ctx
+            ctx = ctx + (addr,)
+        elif op.startswith("s_or_saveexec") or op.startswith("s_andn2_saveexec"):      # the switch to the else side of a region
+            saved[o[0]] = saved.get(o[1], ctx[:-1])
+        elif op == "s_mov_b64" and o[1:] == ["exec"]:
+            saved[o[0]] = ctx
+        elif op == "s_mov_b64" and o[0] == "exec":
+            ctx = saved[o[1]] if o[1] in saved and len(saved[o[1]]) <= len(ctx) else ctx + (addr,)
+        elif op == "s_or_b64" and o[0] == "exec" and len(o) == 3 and o[1] == "exec":
+            if o[2] in saved and len(saved[o[2]]) < len(ctx):
+                ctx = saved[o[2]]
+        elif op.startswith("scratch_store"):
+            stores.setdefault(slot(op, ops), []).append((addr, ctx))
+        elif op.startswith("scratch_load"):
+            loads.append((addr, slot(op, ops), ctx, ops))
+        elif re.match(r"s_(mov|and|or|xor|andn2|orn2|cselect|not)_b64", op) and o[0].startswith("s[") and o[0] in saved and not (op == "s_xor_b64" and "exec" in o):
+            del saved[o[0]]                                                             # the register no longer holds that mask
+        if op.startswith("s_cbranch") or op == "s_branch":
+            t = branch_target(addr, ops)
+            if t is not None and t > addr and t not in state_at:
+                state_at[t] = (ctx, dict(saved))
+        if op in ("s_branch", "s_setpc_b64", "s_endpgm"):
+            dead = True
+    hits = []
+    for addr, sl, ctx, ops in loads:
+        st = stores.get(sl, [])
+        if st and not any(c == ctx[:len(c)] for _, c in st):
+            hits.append((addr, sl, len(ctx), [(hex(a), len(c)) for a, c in st][:4]))
+    return hits
+
+
 def main():
-    lib = Path(sys.argv[1]) if len(sys.argv) > 1 else Path(__file__).resolve().parent.parent / "us_potus_model_amd" / "libpotus_hmc.so"
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    lib = Path(args[0]) if args else Path(__file__).resolve().parent.parent / "us_potus_model_amd" / "libpotus_hmc.so"
     bad = 0
-    for name, body in functions(disassemble(lib)):
+    text = disassemble(lib)
+    for name, body in functions(text):
         for (a, op, ops), (a2, op2, ops2) in scan(body):
             print(f"{name[:72]}: {op} {ops}  at {a:#x}, EXEC widened at {a2:#x} by {op2} {ops2}")
             bad += 1
     print(f"{bad} spill instruction(s) under a narrowed EXEC mask")
+    if "--deep" in sys.argv:
+        n = 0
+        for name, body in functions(text):
+            for addr, sl, depth, st in deep_scan(body):
+                print(f"{name[:72]}: reload of slot {sl} at {addr:#x} (depth {depth}) has no store in a context at least as wide; stores (address, depth): {st}")
+                n += 1
+        print(f"{n} reload(s) not covered by a store with at least their lanes (flow-based check; review by hand)")
     return 1 if bad else 0
 
 

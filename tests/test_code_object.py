@@ -24,8 +24,12 @@ def test_no_spill_runs_under_a_narrowed_exec_mask():
     g.build()
     chk = _load("check_spill_exec")
     lib = ROOT / "us_potus_model_amd" / "libpotus_hmc.so"
-    hits = [(name, a, b) for name, body in chk.functions(chk.disassemble(lib)) for a, b in chk.scan(body)]
+    text = chk.disassemble(lib)
+    hits = [(name, a, b) for name, body in chk.functions(text) for a, b in chk.scan(body)]
     assert not hits, hits[:5]
+    # the flow-based check: every reload of a spill slot has a store to that slot that ran with at least its lanes
+    deep = [(name, h) for name, body in chk.functions(text) for h in chk.deep_scan(body)]
+    assert not deep, deep[:5]
 
 
 def test_the_scanner_sees_the_shape_it_is_looking_for():
@@ -42,3 +46,10 @@ def test_the_scanner_sees_the_shape_it_is_looking_for():
           (0x14, "s_and_saveexec_b64", "s[4:5], vcc"), (0x18, "scratch_load_dwordx2", "v[8:9], off, off offset:76"),
           (0x20, "global_load_dwordx2", "v[8:9], v9, s[8:9] offset:448"), (0x28, "s_or_b64", "exec, exec, s[4:5]"), (0x2c, "s_endpgm", "")]
     assert chk.scan(ok) == []
+    # the flow-based check on the same shapes: the reload at full EXEC of a slot stored inside the guard's region is reported,
+    # a reload inside the region of a slot stored before it is not
+    bad = body[:-1] + [(0x24, "scratch_load_dword", "v212, off, s32 offset:728"), (0x2c, "s_endpgm", "")]
+    assert [h[0] for h in chk.deep_scan(bad)] == [0x24]
+    fine = [(0x00, "scratch_store_dword", "off, v53, s32 offset:728")] + [(a + 8, op, ops) for a, op, ops in body[:3]] + \
+           [(0x14, "scratch_load_dword", "v212, off, s32 offset:728"), (0x1c, "s_or_b64", "exec, exec, s[6:7]"), (0x20, "s_endpgm", "")]
+    assert chk.deep_scan(fine) == []
