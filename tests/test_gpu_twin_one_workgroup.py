@@ -110,3 +110,24 @@ def test_the_library_picks_two_workgroups_for_65_to_128_chains(cases):
         assert np.array_equal(d[c][:, 3:6], ref[:, 3:6]), (c, d[c][:, :7], ref[:, :7])
         assert np.allclose(d[c][:, 7:], ref[:, 7:], rtol=1e-6, atol=1e-7)
     h.close()
+
+
+def test_two_workgroup_handles_run_beside_a_cluster_handle(cases):
+    """potus_run_many: a handle with two workgroups per chain holds its 2 x chains workgroups for the whole launch, as a cluster
+    does -- it is grouped by the compute units it needs (here 70 x 2 workgroups + 2 clusters of 16 fit one device together)
+    and gives the bytes of a run on its own."""
+    from us_potus_model_amd import sampler
+    data, variant = cases["small_full"]
+    kw1 = dict(chains=70, num_warmup=20, num_samples=4, seed=31, save_warmup=1)
+    kw2 = dict(chains=2, num_warmup=20, num_samples=4, seed=32, save_warmup=1, cus_per_chain=16, twin=0)
+    alone = []
+    for kw in (kw1, kw2):
+        h = Handle(data, variant, **kw); h.init(); h.run(24)
+        alone.append(h.draws().copy()); h.close()
+    a, b = Handle(data, variant, **kw1), Handle(data, variant, **kw2)
+    assert a.cus_per_chain == 1 and a.clusters_per_chain == 2 and b.cus_per_chain == 16
+    a.init(); b.init()
+    for n in (10, 14):
+        sampler.run_many([a, b], n)
+    assert np.array_equal(a.draws(), alone[0]) and np.array_equal(b.draws(), alone[1])
+    a.close(); b.close()
