@@ -54,6 +54,9 @@
 #ifndef CL_FX_BATCH
 #define CL_FX_BATCH 0
 #endif
+#ifndef CL_X1_IN_A
+#define CL_X1_IN_A 0                     // 1: the suffix totals sent ahead by the previous leaf are fetched in phase A (see there; measured slower)
+#endif
 #ifndef CL_X3_IN_B
 #define CL_X3_IN_B 0                     // 1: the previous leaf's totals are collected in phase B by a wave that is done early there (see phase C)
 #endif
@@ -709,6 +712,29 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       const int tl = wd0 + j;
       pol.q_load((lane < S && j < wnd) ? 8u * (unsigned)(e0 + lane + S * tl) : PT_OOB, qt[j]);
     }
+#if CL_X1_IN_A
+    // The suffix totals of the members that own later days travel with the same exchange as the small vectors above (sent ahead
+    // by the previous leaf): wave 0 fetches them here, next to the loads of phase A, instead of on its own in phase B, where the
+    // round trip was the longest thing of the phase (4.2 k cycles on wave 0 against 2.2-2.6 k on the others).  Measured: 21.1
+    // against 19.5 us per leaf, 16.5 against 15.8 with two clusters (profiles/r03_cl_fixed_layout_build.txt) -- off.
+    if (w == 0 && ahead) {
+      double carry_a = 0.0;
+      for (int mm0 = m + 1; mm0 < K; mm0 += 16) {
+        double t16[16];
+        unsigned vo[16], so[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const int mm = mm0 + u;
+          vo[u] = (mm < K && lane < S) ? 16u * (unsigned)lane : PT_OOB;
+          so[u] = xch_eslot(x, x.x1e, mm < K ? mm : 0);
+        }
+        xld(x, vo, so, t16, x.x1e);
+#pragma unroll
+        for (int u = 0; u < 16; u++) carry_a += t16[u];
+      }
+      if (lane < S) Y[PT_NW * SE + lane] = carry_a;
+    }
+#endif
     for (int i = tid; i < NR + 8; i += PT_THREADS) s_P[i] = 0.0;   // accumulators that this member's polls may not cover
     if (tid < SE) s_gs[tid] = 0.0;
     if (tid >= 64 && tid < 64 + CL_MAXDAYS) s_ge[tid - 64] = 0.0;
@@ -740,6 +766,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   }
   x.epoch += x.x1e == 0 ? 1u : 0u;                // X1 is on its way (or was sent by the previous pass)
   const unsigned x1tag = x.x1e ? x.x1e : x.epoch;
+  const bool x1_early = CL_X1_IN_A && x.x1e != 0; // (then wave 0 took the totals in phase A)
   x.x1e = 0;
   if (w == 1) {
     if (full) {
@@ -814,7 +841,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   }
   // suffix totals of the members that own later days: fetched once per workgroup (wave 0, which has
   // nothing else to do here) and handed to the other waves through LDS
-  if (w == 0) {
+  if (w == 0 && !x1_early) {
     WPROF_PT(27);
     double carry_m = 0.0;
     for (int mm0 = m + 1, bt = 0; mm0 < K && (!(FX && CL_FX_BATCH) || bt < 1); mm0 += 16, bt++) {   // (FX: at most sixteen members, one batch)
