@@ -157,6 +157,15 @@ int potus_cus_per_chain(int handle, int *k);
 /* clusters per chain of the handle: 2 when it runs the two ends of the trajectory on a cluster each (potus_opts.twin),
  * 1 otherwise */
 int potus_clusters_per_chain(int handle, int *n);
+/* How potus_create resolves cus_per_chain = 0 and twin = -1, as pure functions of the sizes (no device needed; the reference has
+ * no counterpart: CmdStan runs one process per chain, scripts/model/final_2016.R:533-541 `parallel_chains`).
+ * potus_plan_cus_per_chain: the first plan for the workgroups per chain (potus_create may still double it when a member's polls
+ * do not fit its LDS); one_workgroup_ok = 0 for models beyond the one-workgroup kernels (T > 256 or > 2 048 polls);
+ * *lowered_for_twin = 1 when 10-14 was chosen instead of 16 so that a second cluster per chain fits.
+ * potus_plan_sides: 1 or 2 clusters (K > 1) / workgroups (K = 1) per chain; resident_per_cu = workgroups of the kernel a compute
+ * unit holds (1 for these kernels on gfx950). */
+int potus_plan_cus_per_chain(int chains, int T, int n_cus, int cus_per_chain, int twin, int metric, int one_workgroup_ok, int *K, int *lowered_for_twin);
+int potus_plan_sides(int chains, int K, int n_cus, int resident_per_cu, int cus_per_chain, int twin, int metric, int *sides);
 /* twin mode: leapfrogs counted in the trajectories (n_leapfrog__ summed, = potus_total_leapfrogs) and leaves each side has
  * integrated, those of speculative subtrees that were dropped included -- what the second cluster costs and buys */
 int potus_twin_stats(int handle, long long *counted, long long *run_backward, long long *run_forward);

@@ -204,3 +204,34 @@ def test_bench_bookkeeping_on_the_committed_profiles():
     assert sc["ess_per_sec_measured"] > 0 and sc["gpu"]["ess_per_sec_measured"] > sc["ess_per_sec_measured"] and cb["ess_per_sec_measured"] == sc["ess_per_sec_measured"]
     assert abs(line["speedup_vs_cpu_port"] - line["value"] / cb["value"]) < 1e-9 and line["speedup_vs_cpu_leapfrog_loop"] < line["speedup_vs_cpu_port"]
     assert line["config"]["all_gather_bytes_per_rank"] == 1000 * 8 * (1 + 51 * 254) * 8            # lp__ + all of mu_b
+
+
+def test_layout_plan_for_every_chain_count():
+    """How potus_create resolves cus_per_chain = 0 / twin = -1 (potus_plan_cus_per_chain, potus_plan_sides: the product's own code, no
+    device needed): 256 compute units, the reference's 2016 campaign of 254 days."""
+    from us_potus_model_amd import sampler
+    want = {1: (16, 2), 4: (16, 2), 8: (16, 2), 9: (14, 2), 10: (12, 2), 11: (11, 2), 12: (10, 2), 13: (16, 1), 16: (16, 1), 17: (8, 1),
+            32: (8, 1), 33: (4, 1), 64: (4, 1), 65: (1, 2), 128: (1, 2), 129: (1, 1), 256: (1, 1), 1000: (1, 1)}
+    for chains, kw in want.items():
+        assert sampler.plan_layout(chains, 254) == kw, (chains, sampler.plan_layout(chains, 254))
+    # explicit sizes: one cluster / workgroup unless a second one is asked for; a second one that does not fit is refused
+    assert sampler.plan_layout(2, 254, cus_per_chain=16) == (16, 1) and sampler.plan_layout(2, 254, cus_per_chain=16, twin=1) == (16, 2)
+    assert sampler.plan_layout(100, 254, cus_per_chain=1) == (1, 1) and sampler.plan_layout(100, 254, cus_per_chain=1, twin=1) == (1, 2)
+    assert sampler.plan_layout(8, 254, twin=0) == (16, 1) and sampler.plan_layout(9, 254, twin=0) == (16, 1) and sampler.plan_layout(70, 254, twin=0) == (1, 1)
+    for bad in (dict(chains=16, cus_per_chain=16, twin=1), dict(chains=129, cus_per_chain=1, twin=1), dict(chains=17, cus_per_chain=16),
+                dict(chains=2, cus_per_chain=33), dict(chains=2, cus_per_chain=8, twin=1, metric="dense_e"), dict(chains=2, twin=2)):
+        with pytest.raises(sampler.PotusError):
+            sampler.plan_layout(T=254, **bad)
+    # the dense metric never takes a second cluster; a smaller device changes the plan with its compute units
+    assert sampler.plan_layout(8, 254, metric="dense_e") == (16, 1) and sampler.plan_layout(70, 254, metric="dense_e") == (1, 1)
+    assert sampler.plan_layout(8, 254, n_cus=128) == (16, 1) and sampler.plan_layout(4, 254, n_cus=128) == (16, 2) and sampler.plan_layout(40, 254, n_cus=128) == (1, 2)
+    # campaigns the one-workgroup kernels cannot hold (T > 256): a cluster with enough members for the days, or a refusal
+    assert sampler.plan_layout(8, 600, one_workgroup_ok=False) == (16, 2) and sampler.plan_layout(16, 600, one_workgroup_ok=False) == (16, 1)
+    assert sampler.plan_layout(12, 600, one_workgroup_ok=False) == (16, 1) and sampler.plan_layout(4, 1500, one_workgroup_ok=False) == (32, 2)
+    with pytest.raises(sampler.PotusError):
+        sampler.plan_layout(20, 600, one_workgroup_ok=False)                       # 600 days need 16 members: 20 x 16 do not fit
+    assert sampler.plan_layout(40, 300, one_workgroup_ok=True) == (1, 2)          # four members hold 256 days at most: one workgroup each
+    with pytest.raises(sampler.PotusError):
+        sampler.plan_layout(40, 600, one_workgroup_ok=False)                       # 40 chains x 8 compute units do not fit
+    with pytest.raises(sampler.PotusError):
+        sampler.plan_layout(2, 600, cus_per_chain=1, one_workgroup_ok=False)

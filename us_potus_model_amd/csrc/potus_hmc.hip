@@ -2034,6 +2034,56 @@ int potus_column_name(const potus_data *d, int col, char *buf, int len) {
   return fail(POTUS_ERR_ARG, "column %d out of range", col);
 }
 
+// ---------------------------------------------------------------- how many workgroups work for a chain (pure functions)
+// The first plan for cus_per_chain (potus_create may still double it when a member's polls do not fit its LDS):
+// 0 = as many compute units per chain as fit the device, out of {16, 8, 4, 1}; 9-12 chains on 256 compute units get 14 / 12 /
+// 11 / 10 so that a second cluster per chain fits (*lowered_for_twin = 1: back to 16 if the second cluster is not taken).
+int potus_plan_cus_per_chain(int chains, int T, int n_cus, int cus_per_chain, int twin, int metric, int one_workgroup_ok, int *K_out, int *lowered_for_twin) {
+  if (!K_out || !lowered_for_twin) return fail(POTUS_ERR_ARG, "potus_plan_cus_per_chain: null output");
+  if (chains < 1 || n_cus < 1 || T < 1) return fail(POTUS_ERR_ARG, "potus_plan_cus_per_chain: chains, T and the number of compute units must be positive");
+  int K = cus_per_chain;
+  *lowered_for_twin = 0;
+  if (K < 0 || K > CL_MAXK) return fail(POTUS_ERR_ARG, "cus_per_chain must be in [0,%d]", CL_MAXK);
+  if (K == 0) {
+    K = chains * 16 <= n_cus ? 16 : chains * 8 <= n_cus ? 8 : chains * 4 <= n_cus ? 4 : 1;
+    if (K == 4 && T > 4 * CL_MAXDAYS) K = 1;      // four members hold up to 256 days
+    // 9-12 chains: two clusters of 14, 12, 11 or 10 per chain (17-20 us per leapfrog on the 2016 posterior) beat one cluster
+    // of 16 (21 us) -- as long as the members keep few enough days for the lighter build of the pass (4 days per wave)
+    if (K == 16 && twin != 0 && metric != POTUS_METRIC_DENSE && chains * 32 > n_cus) {
+      const int k2 = n_cus / (2 * chains);
+      if (k2 >= 10 && (T + k2 - 1) / k2 <= CL_DW4_MAXAVG) { K = k2; *lowered_for_twin = 1; }
+    }
+    // models beyond the one-workgroup kernels (T > 256, > 2048 polls) need a cluster; long campaigns need more members
+    if (K == 1 && !one_workgroup_ok) K = 8;
+    while (K > 1 && T > K * CL_MAXDAYS && 2 * K <= CL_MAXK) K *= 2;
+    if (K > 1 && chains * K > n_cus)
+      return fail(POTUS_ERR_UNSUPPORTED, "%s, and %d chains x %d compute units do not fit the %d of the device",
+                  one_workgroup_ok ? "T needs more members per chain" : "the model needs a cluster per chain", chains, K, n_cus);
+  } else if (K == 1 && !one_workgroup_ok)
+    return fail(POTUS_ERR_UNSUPPORTED, "the model is beyond the one-workgroup kernels; use cus_per_chain = 0 or >= 8");
+  if (K > 1 && chains * K > n_cus) return fail(POTUS_ERR_ARG, "chains * cus_per_chain = %d exceeds the %d compute units of the device", chains * K, n_cus);
+  *K_out = K;
+  return 0;
+}
+
+// One or two clusters (K > 1) / workgroups (K = 1) per chain, one per end of the trajectory: two when asked for (twin = 1) or when
+// the library chooses the size as well (twin < 0 and cus_per_chain = 0), the metric is diagonal and 2 * chains * K workgroups are
+// resident together (resident_per_cu: workgroups of the kernel a compute unit holds).  twin = 1 that does not fit is an error.
+int potus_plan_sides(int chains, int K, int n_cus, int resident_per_cu, int cus_per_chain, int twin, int metric, int *sides) {
+  if (!sides) return fail(POTUS_ERR_ARG, "potus_plan_sides: null output");
+  if (twin < -1 || twin > 1) return fail(POTUS_ERR_ARG, "twin must be -1 (library's choice), 0 or 1");
+  const bool fits = metric != POTUS_METRIC_DENSE && resident_per_cu >= 1 &&
+                    2ll * chains * K <= (long long)n_cus * (K == 1 ? resident_per_cu : 1);
+  if (twin == 1 && !fits) {
+    if (K == 1)
+      return fail(POTUS_ERR_ARG, "twin = 1: two workgroups per chain need %d resident workgroups (the device holds %d) and the diagonal metric",
+                  2 * chains, n_cus * std::max(resident_per_cu, 0));
+    return fail(POTUS_ERR_ARG, "twin = 1: two clusters of %d per chain need %d compute units (the device has %d) and the diagonal metric", K, chains * 2 * K, n_cus);
+  }
+  *sides = ((twin == 1 || (twin < 0 && cus_per_chain == 0)) && fits) ? 2 : 1;
+  return 0;
+}
+
 int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   if (!o || !handle) return fail(POTUS_ERR_ARG, "null argument");
   int rc = validate(d);
@@ -2071,41 +2121,24 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   if ((rc = build_model(sp, d))) return bail(rc);
   if (sp->k1_unsupported.empty() && (rc = set_lds_attr(sp))) return bail(rc);
   {
-    // workgroups (CUs) per chain: 0 = as many as fit the device, in {16, 8, 4, 1}; chains * K blocks must be co-resident
+    // workgroups (CUs) per chain and sides: potus_plan_cus_per_chain / potus_plan_sides (pure functions, below; tested without a GPU)
     const int ncu = prop.multiProcessorCount;
-    int K = o->cus_per_chain;
-    bool k_lowered_for_twin = false;
-    if (K < 0 || K > CL_MAXK) return bail(fail(POTUS_ERR_ARG, "cus_per_chain must be in [0,%d]", CL_MAXK));
-    if (K == 0) {
-      K = o->chains * 16 <= ncu ? 16 : o->chains * 8 <= ncu ? 8 : o->chains * 4 <= ncu ? 4 : 1;
-      if (K == 4 && d->T > 4 * CL_MAXDAYS) K = 1;      // four members hold up to 256 days
-      // 9-12 chains: two clusters of 14, 12, 11 or 10 per chain (17-20 us per leapfrog on the 2016 posterior) beat one cluster
-      // of 16 (21 us) -- as long as the members keep few enough days for the lighter build of the pass (4 days per wave)
-      if (K == 16 && o->twin != 0 && o->metric != POTUS_METRIC_DENSE && o->chains * 32 > ncu) {
-        const int k2 = ncu / (2 * o->chains);
-        if (k2 >= 10 && (d->T + k2 - 1) / k2 <= CL_DW4_MAXAVG) { K = k2; k_lowered_for_twin = true; }
+    int K = 0, lowered = 0;
+    if ((rc = potus_plan_cus_per_chain(o->chains, d->T, ncu, o->cus_per_chain, o->twin, o->metric, sp->k1_unsupported.empty() ? 1 : 0, &K, &lowered))) {
+      if (rc == POTUS_ERR_UNSUPPORTED && !sp->k1_unsupported.empty()) {
+        const std::string first = g_err;
+        return bail(fail(rc, "%s (%s)", sp->k1_unsupported.c_str(), first.c_str()));
       }
-      // models beyond the one-workgroup kernels (T > 256, > 2048 polls) need a cluster; long campaigns need more members
-      if (K == 1 && !sp->k1_unsupported.empty()) K = 8;
-      while (K > 1 && d->T > K * CL_MAXDAYS && 2 * K <= CL_MAXK) K *= 2;
-      if (K > 1 && o->chains * K > ncu)
-        return bail(fail(POTUS_ERR_UNSUPPORTED, "%s, and %d chains x %d compute units do not fit the %d of the device",
-                         sp->k1_unsupported.empty() ? "T needs more members per chain" : sp->k1_unsupported.c_str(), o->chains, K, ncu));
-    } else if (K == 1 && !sp->k1_unsupported.empty())
-      return bail(fail(POTUS_ERR_UNSUPPORTED, "%s; use cus_per_chain = 0 or >= 8", sp->k1_unsupported.c_str()));
-    if (K > 1 && o->chains * K > ncu) return bail(fail(POTUS_ERR_ARG, "chains * cus_per_chain = %d exceeds the %d compute units of the device", o->chains * K, ncu));
+      return bail(rc);
+    }
+    const bool k_lowered_for_twin = lowered != 0;
     if (K == 1) {
-      // Two workgroups per chain, one per end of the trajectory (potus_nuts_twin.hpp), when the compute units are there: asked
-      // for (twin = 1), or chosen with the size (twin < 0 and cus_per_chain = 0: 65-128 chains on 256 compute units).  Both
-      // sides of every chain wait for each other: the whole grid has to be resident at once.  Diagonal metric only.
-      int per_cu = 0;
-      const bool fits = o->metric != POTUS_METRIC_DENSE &&
-                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_run_twin), PT_THREADS, sp->lds_bytes) == hipSuccess &&
-                        per_cu >= 1 && 2ll * o->chains <= (long long)ncu * per_cu;
-      if (o->twin == 1 && !fits)
-        return bail(fail(POTUS_ERR_ARG, "twin = 1: two workgroups per chain need %d resident workgroups (the device holds %d) and the diagonal metric",
-                         2 * o->chains, ncu * std::max(per_cu, 0)));
-      if ((o->twin == 1 || (o->twin < 0 && o->cus_per_chain == 0)) && fits) sp->twin = 1;
+      // Two workgroups per chain, one per end of the trajectory (potus_nuts_twin.hpp): both sides of every chain wait for each
+      // other, so the whole grid has to be resident at once
+      int per_cu = 0, sides = 1;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_run_twin), PT_THREADS, sp->lds_bytes) != hipSuccess) per_cu = 0;
+      if ((rc = potus_plan_sides(o->chains, 1, ncu, per_cu, o->cus_per_chain, o->twin, o->metric, &sides))) return bail(rc);
+      sp->twin = sides == 2;
     }
     if (K > 1) {
       rc = build_cluster(sp, d, K);
@@ -2123,14 +2156,13 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
         return bail(fail(POTUS_ERR_ARG, "chains * cus_per_chain = %d workgroups cannot be resident together (%d compute units x %d)", o->chains * K, ncu, per_cu));
       // Two clusters per chain, one per end of the trajectory (potus_cluster.hpp, twin mode), when the compute units are there:
       // asked for (twin = 1), or chosen with the cluster size (twin < 0 and cus_per_chain = 0).  Diagonal metric only.
-      const bool twin_fits = o->metric != POTUS_METRIC_DENSE && (long long)o->chains * 2 * K <= (long long)ncu;
-      if (o->twin == 1 && !twin_fits)
-        return bail(fail(POTUS_ERR_ARG, "twin = 1: two clusters of %d per chain need %d compute units (the device has %d) and the diagonal metric", K, o->chains * 2 * K, ncu));
+      int sides_plan = 1;
+      if ((rc = potus_plan_sides(o->chains, K, ncu, 1, o->cus_per_chain, o->twin, o->metric, &sides_plan))) return bail(rc);
+      const bool twin_fits = sides_plan == 2;      // asked for or chosen, and the compute units are there
       const void *kft = sp->cl_dw == 16 ? reinterpret_cast<const void *>(k_cl_run<16, true>) : sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4, true>)
                         : sp->cl_dw == 12 ? reinterpret_cast<const void *>(k_cl_run<12, true>) : reinterpret_cast<const void *>(k_cl_run<8, true>);
       int per_cu_t = 0;
-      if ((o->twin == 1 || (o->twin < 0 && o->cus_per_chain == 0)) && twin_fits &&
-          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, kft, PT_THREADS, sp->cl_lds_bytes) == hipSuccess && per_cu_t >= 1)
+      if (twin_fits && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, kft, PT_THREADS, sp->cl_lds_bytes) == hipSuccess && per_cu_t >= 1)
         sp->twin = 1;
       else if (o->twin == 1) return bail(fail(POTUS_ERR_DEVICE, "twin = 1: the twin kernel cannot be resident on this device"));
       if (!sp->twin && k_lowered_for_twin) {   // the smaller clusters were chosen for the sake of the second one: without it, back to 16

@@ -79,6 +79,8 @@ def load_library():
     L.potus_get_dense_metric.argtypes = [C.c_int, C.c_int, dp]
     L.potus_cus_per_chain.argtypes = [C.c_int, ip]
     L.potus_clusters_per_chain.argtypes = [C.c_int, ip]
+    L.potus_plan_cus_per_chain.argtypes = [C.c_int] * 7 + [ip, ip]
+    L.potus_plan_sides.argtypes = [C.c_int] * 7 + [ip]
     L.potus_twin_stats.argtypes = [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     _LIB = L
     return L
@@ -86,7 +88,7 @@ def load_library():
 
 EXPORTS = [
     "potus_version", "potus_last_error", "potus_default_opts", "potus_num_params", "potus_num_columns",
-    "potus_column_name", "potus_create", "potus_destroy", "potus_cus_per_chain", "potus_clusters_per_chain", "potus_twin_stats", "potus_log_prob_grad", "potus_init", "potus_run", "potus_run_many",
+    "potus_column_name", "potus_create", "potus_destroy", "potus_cus_per_chain", "potus_clusters_per_chain", "potus_plan_cus_per_chain", "potus_plan_sides", "potus_twin_stats", "potus_log_prob_grad", "potus_init", "potus_run", "potus_run_many",
     "potus_iterations_done", "potus_total_leapfrogs", "potus_chain_status", "potus_get_adaptation",
     "potus_get_dense_metric", "potus_dense_timing", "potus_dense_adapt_timing", "potus_dense_check", "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_array_device", "potus_write_stan_csv",
     "potus_last_run_timing", "potus_posterior_summary", "potus_posterior_summary_many", "potus_backtest_scores",
@@ -304,6 +306,20 @@ def backtest_scores(summary, ev, won, day=0):
     out = np.zeros(3)
     _check(L, L.potus_backtest_scores(_dp(st), T, S, int(day), _dp(ev), w, _dp(out)))
     return dict(ev_wtd_brier=float(out[0]), unwtd_brier=float(out[1]), states_correct=int(out[2]))
+
+
+def plan_layout(chains, T, n_cus=256, cus_per_chain=0, twin=-1, metric="diag_e", one_workgroup_ok=True):
+    """(workgroups per chain, clusters / workgroups per chain side count) as potus_create would first plan them for a device of
+    n_cus compute units -- potus_plan_cus_per_chain + potus_plan_sides, no device needed."""
+    L = load_library()
+    k, low, sides = C.c_int(0), C.c_int(0), C.c_int(0)
+    m = _abi.METRICS[metric] if isinstance(metric, str) else int(metric)
+    _check(L, L.potus_plan_cus_per_chain(chains, T, n_cus, cus_per_chain, twin, m, int(bool(one_workgroup_ok)), C.byref(k), C.byref(low)))
+    _check(L, L.potus_plan_sides(chains, k.value, n_cus, 1, cus_per_chain, twin, m, C.byref(sides)))
+    K = k.value
+    if sides.value == 1 and low.value:
+        K = 16                                      # the smaller clusters were chosen for the sake of the second one
+    return K, sides.value
 
 
 def run_many(handles, n_iter):
