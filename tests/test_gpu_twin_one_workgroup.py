@@ -131,3 +131,25 @@ def test_two_workgroup_handles_run_beside_a_cluster_handle(cases):
         sampler.run_many([a, b], n)
     assert np.array_equal(a.draws(), alone[0]) and np.array_equal(b.draws(), alone[1])
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("side", [0, 1])
+def test_two_workgroups_watchdog(cases, side):
+    """A side that never shows up (the test hook of the cluster sampler, here per side): the other side gives up waiting for its
+    combines after a few seconds, potus_run reports the watchdog error instead of hanging, and the device is usable afterwards."""
+    import os
+    from us_potus_model_amd import sampler
+    data, variant = cases["small_full"]
+    os.environ["POTUS_DEBUG_DROP_MEMBER"] = str(side + 1)
+    try:
+        h = Handle(data, variant, chains=2, num_warmup=10, num_samples=0, cus_per_chain=1, twin=1, seed=3)
+    finally:
+        del os.environ["POTUS_DEBUG_DROP_MEMBER"]
+    h.init()
+    with pytest.raises(sampler.PotusError, match="error 8"):
+        h.run(3)
+    h.close()
+    g = Handle(data, variant, chains=2, num_warmup=10, num_samples=0, cus_per_chain=1, twin=1, seed=3)
+    g.init(); g.run(3)
+    assert g.total_leapfrogs() > 0
+    g.close()

@@ -363,6 +363,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_run_twin(const DevModel *Mg, con
   const int chain = blockIdx.x % R->chains, side = blockIdx.x / R->chains;
   Chain c = make_chain(M, R, chain, side);
   if (c.sc->status != 0) return;
+  if (R->debug_drop_member == side + 1) return;    // test hook: a side that never shows up
   if (threadIdx.x == 0) cl_dead = 0;
   c.pst = model_setup_lds(M, c.lds);
   const Xch x = tw1_watch(R, chain + side * R->chains, launch);
