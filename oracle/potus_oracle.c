@@ -1218,6 +1218,30 @@ int oracle_transitions_from(const oracle_model *m, const oracle_opts *o, int cha
   return 0;
 }
 
+/* base_hmc::init_stepsize from a given state (tests of the device samplers' window ends): the heuristic as adapt_diag_e_nuts /
+ * adapt_dense_e_nuts run it after a metric update -- at point q, starting from step size eps0, under the metric handed in (as for
+ * oracle_transitions_from), with the momentum draws of RNG iteration `iter` (the iteration whose transition ended the window;
+ * ITER_PRE = 0xFFFFFFFF for the search before the first transition).  Returns the step size found. */
+double oracle_init_stepsize_from(const oracle_model *m, const oracle_opts *o, int chain_id, uint32_t iter, const double *q, double eps0,
+                                 const double *Minv, const double *Lc) {
+  const int D = m->D;
+  sampler sp; memset(&sp, 0, sizeof(sp));
+  sp.m = m; sp.o = o; sp.D = D; sp.chain = chain_id; sp.iter = iter;
+  sp.lpg = o->fast_grad ? oracle_log_prob_grad_fast : oracle_log_prob_grad;
+  sp.dense = o->dense_metric != 0;
+  sp.minv = vec(D); sp.tmpv = vec(D);
+  if (sp.dense) { sp.Minv = (double *)Minv; sp.Lc = (double *)Lc; for (int i = 0; i < D; i++) sp.minv[i] = Minv[(size_t)i * D + i]; }
+  else memcpy(sp.minv, Minv, sizeof(double) * (size_t)D);
+  sp.z = ps_alloc(D);
+  memcpy(sp.z.q, q, sizeof(double) * (size_t)D);
+  update_potential_gradient(&sp, &sp.z);
+  sp.nom_eps = eps0;
+  init_stepsize(&sp);
+  const double eps = sp.nom_eps;
+  ps_free(&sp.z); free(sp.minv); free(sp.tmpv);
+  return eps;
+}
+
 double oracle_time_leapfrogs(const oracle_model *m, int n, double eps, int fast_grad, uint64_t seed) {
   const int D = m->D;
   oracle_opts o; oracle_default_opts(&o); o.seed = seed;

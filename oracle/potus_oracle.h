@@ -93,6 +93,11 @@ int oracle_sample_chain_timed(const oracle_model *m, const oracle_opts *o, int c
 int oracle_transitions_from(const oracle_model *m, const oracle_opts *o, int chain_id, int iter0, int n, const double *qs,
                             const double *eps, const double *Minv, const double *Lc, double *rows);
 
+/* base_hmc::init_stepsize at point q from step size eps0 under the given metric (Minv / Lc as for oracle_transitions_from), with the
+ * momentum draws of RNG iteration iter: what the adaptive samplers run after every metric update.  Returns the step size. */
+double oracle_init_stepsize_from(const oracle_model *m, const oracle_opts *o, int chain_id, uint32_t iter, const double *q, double eps0,
+                                 const double *Minv, const double *Lc);
+
 /* leapfrog micro-benchmark for bench.py's cpu_baseline: n steps from q0 with unit metric */
 double oracle_time_leapfrogs(const oracle_model *m, int n, double eps, int fast_grad, uint64_t seed);
 

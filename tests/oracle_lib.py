@@ -51,6 +51,8 @@ def lib():
                                                  C.POINTER(C.c_longlong), dp]
         L.oracle_sample_chain_timed.argtypes = [C.c_void_p, C.POINTER(OracleOpts), C.c_int, dp, dp, dp, C.c_double]
         L.oracle_transitions_from.argtypes = [C.c_void_p, C.POINTER(OracleOpts), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp]
+        L.oracle_init_stepsize_from.restype = C.c_double
+        L.oracle_init_stepsize_from.argtypes = [C.c_void_p, C.POINTER(OracleOpts), C.c_int, C.c_uint32, dp, C.c_double, dp, dp]
         L.oracle_philox.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.oracle_rng_uniform.restype = C.c_double
         L.oracle_rng_uniform.argtypes = [C.c_uint64] + [C.c_uint32] * 5
@@ -157,6 +159,13 @@ class OracleModel:
         if rc:
             raise RuntimeError(f"oracle_transitions_from failed rc={rc}")
         return rows
+
+    def init_stepsize_from(self, chain_id, opts, iteration, q, eps0, minv, chol=None):
+        """base_hmc::init_stepsize at q from eps0 under the given metric, momentum draws of RNG iteration `iteration`."""
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        minv = np.ascontiguousarray(minv, dtype=np.float64)
+        cp = _dp(np.ascontiguousarray(chol, dtype=np.float64)) if chol is not None else None
+        return self.L.oracle_init_stepsize_from(self.h, C.byref(opts), chain_id, int(iteration) & 0xFFFFFFFF, _dp(q), float(eps0), _dp(minv), cp)
 
     def time_leapfrogs(self, n, eps=0.01, fast=False, seed=1):
         return self.L.oracle_time_leapfrogs(self.h, n, eps, int(fast), seed)

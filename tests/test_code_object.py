@@ -53,3 +53,24 @@ def test_the_scanner_sees_the_shape_it_is_looking_for():
     fine = [(0x00, "scratch_store_dword", "off, v53, s32 offset:728")] + [(a + 8, op, ops) for a, op, ops in body[:3]] + \
            [(0x14, "scratch_load_dword", "v212, off, s32 offset:728"), (0x1c, "s_or_b64", "exec, exec, s[6:7]"), (0x20, "s_endpgm", "")]
     assert chk.deep_scan(fine) == []
+
+
+def test_no_valu_write_follows_a_wide_buffer_store_onto_its_data_registers():
+    """scripts/check_store_hazard.py: a buffer store of more than 64 bits reads its data registers after it has issued, and hipcc
+    7.2 pads the pair only for stores without a register soffset.  Round 4 lost the low dword of exchange words that way (one word
+    in ~10^5: gradients wrong in the ninth digit, runs not reproducible); xst / tw_st now carry their own wait states."""
+    import __graft_entry__ as g
+    g.build()
+    chk = _load("check_store_hazard")
+    stores, hits = chk.scan(chk.disassemble(ROOT / "us_potus_model_amd" / "libpotus_hmc.so"))
+    assert stores > 100 and not hits, hits[:5]
+
+
+def test_the_store_hazard_scanner_sees_the_shape():
+    chk = _load("check_store_hazard")
+    bad = "0000000000001000 <k>:\n\tbuffer_store_dwordx4 v[2:5], v6, s[88:91], s1 offen sc1  // 0\n\tv_cndmask_b32_e32 v2, v159, v132, vcc  // 8\n"
+    assert len(chk.scan(bad)[1]) == 1
+    padded = "0000000000001000 <k>:\n\tbuffer_store_dwordx4 v[2:5], v6, s[88:91], s1 offen sc1  // 0\n\ts_nop 1  // 8\n\tv_cndmask_b32_e32 v2, v159, v132, vcc  // c\n"
+    other = "0000000000001000 <k>:\n\tbuffer_store_dwordx4 v[2:5], v6, s[88:91], s1 offen sc1  // 0\n\tv_mov_b32_e32 v7, v1  // 8\n"
+    narrow = "0000000000001000 <k>:\n\tbuffer_store_dwordx2 v[2:3], v6, s[88:91], s1 offen sc1  // 0\n\tv_mov_b32_e32 v2, v1  // 8\n"
+    assert chk.scan(padded)[1] == [] and chk.scan(other)[1] == [] and chk.scan(narrow)[1] == []

@@ -202,39 +202,121 @@ def test_nuts_follows_the_oracle_chain(cases, name, iters, cus):
     h.close()
 
 
-@pytest.mark.parametrize("cus", [1, 16])
-def test_adaptation_matches_oracle_through_a_metric_update(cases, cus):
-    """150 warmup iterations cover init buffer, first window end (metric update + init_stepsize)."""
+def _adaptation_replayed_from_the_device_rows(data, variant, h, chain, seed, replay_rows):
+    """Stan 2.24 adapt_diag_e_nuts restated from the device chain's OWN saved warm-up rows, one transition at a time, so that nothing
+    can drift (the technique of test_gpu_dense._post_window_rows_against_the_oracle, for the diagonal samplers):
+      * the step size of every transition = exp(x) of stepsize_adaptation::learn_stepsize fed with the accept_stat__ of the rows
+        before it (restarted after a metric update with mu = log(10 eps));
+      * at the end of a window the inverse metric = var_adaptation's regularised variance of the very draws saved for that window,
+        and the step size that follows = base_hmc::init_stepsize run by the ORACLE from the device's draw, that metric and the
+        step size learn_stepsize had just proposed (same Philox momenta);
+      * the step size kept after the warm-up = exp(x_bar);
+      * the transitions named in replay_rows are the oracle's transitions from the device's previous draw, step size and metric:
+        same tree depth, leapfrog count and divergence flag, values to 1e-6.
+    Covers warm-ups whose windows all lie inside the saved rows (save_warmup = 1)."""
+    o_ = h.opts
+    nw = o_.num_warmup
+    d = h.draws()[chain]
+    eps_final, minv_final = h.adaptation()
+    eps_final, minv_final = eps_final[chain], np.asarray(minv_final[chain])
+    D = h.D
+    m = OracleModel(data, variant)
+    o = m.default_opts(num_warmup=nw, num_samples=o_.num_samples, seed=seed, fast_grad=1, max_depth=o_.max_depth)
+    chain_id = o_.chain_id_offset + chain + 1
+    ib, tb, bw = o_.init_buffer, o_.term_buffer, o_.window          # windowed_adaptation's constructor
+    if nw >= 20 and ib + bw + tb > nw:
+        ib, tb = int(0.15 * nw), int(0.1 * nw)
+        bw = nw - (ib + tb)
+    win_size, win_next = bw, ib + bw - 1
+    delta, gamma, kappa, t0 = o_.delta, o_.gamma, o_.kappa, o_.t0
+    # the very first search: from the initial point (U(-2,2), Philox index = Stan index, first attempt) with the unit metric
+    q_init = np.array([o_.init_radius * (2.0 * m.L.oracle_rng_uniform(seed, chain_id, 0xFFFFFFFF, 5, 0, i) - 1.0) for i in range(D)])
+    minv = np.ones(D)
+    eps0 = m.init_stepsize_from(chain_id, o, 0xFFFFFFFF, q_init, o_.stepsize, minv)
+    assert d[0, 2] == eps0, (d[0, 2], eps0)
+    mu, s_bar, x_bar, cnt = np.log(10.0 * o_.stepsize), 0.0, 0.0, 0.0   # (services: set_mu(log(10 * stepsize)) precedes the first search)
+    wf = []                                                          # draws of the current window
+    metric_at = {}                                                   # first row that ran under the metric
+    next_eps = eps0
+    for it in range(nw):
+        assert abs(d[it, 2] / next_eps - 1.0) < 1e-12, (it, d[it, 2], next_eps)
+        metric_at[it] = minv
+        cnt += 1.0                                                   # learn_stepsize
+        a = min(1.0, d[it, 1])
+        eta = 1.0 / (cnt + t0)
+        s_bar = (1.0 - eta) * s_bar + eta * (delta - a)
+        x = mu - s_bar * np.sqrt(cnt) / gamma
+        x_eta = cnt ** (-kappa)
+        x_bar = (1.0 - x_eta) * x_bar + x_eta * x
+        next_eps = np.exp(x)
+        if nw >= 20:                                                 # learn_variance
+            if ib <= it < nw - tb:
+                wf.append(d[it, 7:])
+            if it == win_next:
+                n = float(len(wf))
+                want = (n / (n + 5.0)) * np.var(np.array(wf), axis=0, ddof=1) + 1e-3 * (5.0 / (n + 5.0))
+                wf = []
+                last = nw - tb - 1                                   # compute_next_window
+                if win_next != last:
+                    win_size *= 2
+                    win_next = it + win_size
+                    if win_next != last and win_next + 2 * win_size >= nw - tb:
+                        win_next = last
+                later_update = win_next > it and win_next < nw
+                if not later_update:                                 # the last metric update: the device still holds it
+                    assert np.allclose(minv_final, want, rtol=1e-9, atol=0), np.abs(minv_final / want - 1).max()
+                    minv = minv_final
+                else:
+                    minv = want
+                next_eps = m.init_stepsize_from(chain_id, o, it, d[it, 7:], next_eps, minv)
+                mu, s_bar, x_bar, cnt = np.log(10.0 * next_eps), 0.0, 0.0, 0.0
+    assert abs(eps_final / np.exp(x_bar) - 1.0) < 1e-12, (eps_final, np.exp(x_bar))   # complete_adaptation
+    for it in range(nw, len(d)):                                     # sampling: the adapted step size and metric
+        assert d[it, 2] == eps_final
+        metric_at[it] = minv_final
+    for first, count in replay_rows:
+        for it in range(first, first + count):
+            ref = m.transitions_from(chain_id, o, it, d[it - 1, 7:], d[it, 2], metric_at[it])[0]
+            assert np.array_equal(d[it, 3:6], ref[3:6]), (it, d[it, :7], ref[:7])                  # treedepth__, n_leapfrog__, divergent__
+            assert np.allclose(d[it, [0, 1, 6]], ref[[0, 1, 6]], rtol=1e-6, atol=1e-8), (it, d[it, :7], ref[:7])
+            assert np.allclose(d[it, 7:], ref[7:], rtol=1e-6, atol=1e-7), (it, np.abs(d[it, 7:] - ref[7:]).max())
+
+
+@pytest.mark.parametrize("cus,twin", [(1, 0), (1, 1), (16, 0), (16, 1)])
+def test_adaptation_matches_oracle_through_a_metric_update(cases, cus, twin):
+    """150 warm-up iterations of the small model: init buffer, one window (draws 75 .. 99), metric update + init_stepsize, term
+    buffer -- every step size, the metric and the transitions around the window end replayed from the device's own rows."""
     data, variant = cases["small_full"]
     nw = 150
-    h = Handle(data, variant, chains=1, num_warmup=nw, num_samples=0, save_warmup=1, seed=11, cus_per_chain=cus)
+    h = Handle(data, variant, chains=2, num_warmup=nw, num_samples=0, save_warmup=1, seed=11, cus_per_chain=cus, twin=twin)
     h.init()
     h.run(nw)
-    d = h.draws()[0]
-    eps, minv = h.adaptation()
+    d = h.draws()
+    # against the oracle's own chain while rounding differences have not been amplified: the first transitions are the same
     m = OracleModel(data, variant)
     ref, ad, nl = m.sample_chain(1, m.default_opts(num_warmup=nw, num_samples=0, save_warmup=1, seed=11, fast_grad=1))
     k = 20
-    assert np.array_equal(d[:k, 3:6], ref[:k, 3:6]) and np.allclose(d[:k, 2], ref[:k, 2], rtol=1e-6)
-    # the metric update itself, exactly: with 150 warm-up iterations there is one window (draws 75 .. 99), and the inverse
-    # metric must be var_adaptation's regularised sample variance of the very draws the sampler saved
-    w = d[75:100, 7:]
-    want = (25 / 30.0) * w.var(axis=0, ddof=1) + 1e-3 * (5 / 30.0)
-    assert np.allclose(minv[0], want, rtol=1e-10, atol=0), np.abs(minv[0] / want - 1).max()
-    # against the oracle: rounding differences are amplified chaotically over thousands of leapfrogs; while the two
-    # chains are still in step at the window's end everything must agree closely, afterwards only what is robust
-    in_step = np.allclose(d[:100, 7:], ref[:100, 7:], rtol=1e-5, atol=1e-6)
-    if in_step:
-        assert np.allclose(minv[0], ad[1:], rtol=1e-4) and np.array_equal(d[100:110, 3:6], ref[100:110, 3:6])
-        assert np.allclose(d[100:110, 2], ref[100:110, 2], rtol=1e-5)          # the step size found by init_stepsize after the update
-    all_in_step = np.allclose(d[:, 7:], ref[:, 7:], rtol=1e-4, atol=1e-5)
-    # init_stepsize doubles or halves from nearly the same start: whatever the two chains have drifted apart by iteration 100, the
-    # step sizes right after the window end are a few doublings apart at most (a wrong gradient there shows as 1e-4 and less)
-    assert abs(np.log(d[100, 2] / ref[100, 2])) < np.log(8.0) + 1e-9, (d[100, 2], ref[100, 2])
-    assert abs(np.log(eps[0] / ad[0])) < (0.05 if all_in_step else 0.5)
-    ratio = np.log(minv[0] / ad[1:])
-    assert abs(np.median(ratio)) < 0.15 and np.abs(ratio).max() < 2.5
-    assert abs(h.total_leapfrogs() - nl) / nl < (0.02 if all_in_step else 0.5)
+    assert np.array_equal(d[0][:k, 3:6], ref[:k, 3:6]) and np.allclose(d[0][:k, 2], ref[:k, 2], rtol=1e-6)
+    for c in (0, 1):
+        _adaptation_replayed_from_the_device_rows(data, variant, h, c, 11, [(1, 3), (74, 3), (98, 8), (147, 3)])
+    h.close()
+
+
+@pytest.mark.parametrize("cus,twin", [(1, 0), (1, 1), (16, 0), (16, 1)])
+@pytest.mark.parametrize("name", ["2016", "2012"])
+def test_diag_transitions_after_the_window_match_the_oracle_at_2016_size(cases, name, cus, twin):
+    """The headline path, pinned per transition: 40 warm-up iterations of the 2016 / 2012 posteriors (init buffer
+    6, one window of 30 draws ending with iteration 35, metric update, init_stepsize, term buffer) on every form of the diagonal
+    sampler -- k_run, k_run_twin, k_cl_run<., false>, k_cl_run<., true>.  The three transitions after the window end (and three
+    before it) are the oracle's transitions from the device's own draw, step size and diagonal inverse metric; every step size of
+    the warm-up is dual averaging's / init_stepsize's from the device's own accept_stat__ column."""
+    data, variant = cases[name]
+    nw = 40
+    h = Handle(data, variant, chains=2, num_warmup=nw, num_samples=2, save_warmup=1, seed=1843, cus_per_chain=cus, twin=twin)
+    h.init()
+    h.run(nw + 2)
+    assert np.isfinite(h.draws()).all()
+    _adaptation_replayed_from_the_device_rows(data, variant, h, 1, 1843, [(33, 3), (36, 3), (40, 2)])
     h.close()
 
 

@@ -58,7 +58,13 @@
 #define CL_X1_IN_A 0                     // 1: the suffix totals sent ahead by the previous leaf are fetched in phase A (see there; measured slower)
 #endif
 #ifndef CL_X3_IN_B
-#define CL_X3_IN_B 0                     // 1: the previous leaf's totals are collected in phase B by a wave that is done early there (see phase C)
+#define CL_X3_IN_B 1                     // 1: the previous leaf's totals are collected in phase B by a wave that is done early there (see phase C)
+#endif
+#ifndef CL_E2_BARRIER
+#define CL_E2_BARRIER 0
+#endif
+#ifndef CL_VC
+#define CL_VC 0                          // 1: no separate carry step between phases B and C (the later members' suffix totals enter through vc[s], see phase B); measured slower: the fetch wave also carries the 52 x 51 product (profiles/r04_cl_fold.txt)
 #endif
 #define CL_SPIN_LIMIT 8000000u
 #ifndef CL_SPIN_SLEEP
@@ -85,58 +91,73 @@ struct ClModel {
   const int *rep_owner;     // [NREP] member that owns each of them
   const double *rep_scale;  // [NR] scale of owned slot r (sigma_c ... ; 1 for zT, zb)
   const int *perm;          // [D] internal index -> Stan index
-  int l_G, GS, GROWS;       // adjoint on the matrix cores (cl_adjoint_mfma): G[pseudo-state][local day], row stride, rows (0: gather walk)
-  int l_C, l_Lw, l_LT, l_LB, l_w, l_prior, l_pm, l_py, l_pN, l_pun, l_sub, l_tab, l_ru, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_pb, l_e, l_c1, l_c2, l_c3, l_gs, l_ge, l_P, l_scal, l_red, l_st, l_prof;
+  int GS, GROWS;            // adjoint on the matrix cores (cl_adjoint_mfma): G[pseudo-state][local day], row stride, rows (l_G = 0: gather walk)
+  int l_C, l_G, l_Lw, l_prior, l_pm, l_py, l_pun, l_sub, l_tab, l_ru, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_e, l_c1, l_c2, l_c3, l_ge, l_P, l_scal, l_red, l_st, l_prof;
   int lds_doubles;
 };
 typedef const ClModel AS_C *CCp;
+
+#define CL_WIDE 96                       // widest all-reduce of a leaf (cl_wide_publish): 2 + 6 * (levels + 1) + 1 words
+// A member's LDS layout (offsets in doubles) as ONE function of the capacities, used by the host for the dynamic builds
+// (build_cluster: the posterior's own sizes) and at compile time for the fixed build below -- the two cannot drift apart.
+struct ClLay {
+  int l_C, l_G, l_Lw, l_prior, l_pm, l_py, l_pun, l_sub, l_tab, l_ru, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_e, l_c1, l_c2, l_c3, l_ge, l_P, l_scal, l_red, l_st, l_prof;
+  int total;
+};
+constexpr int cl_ev(int n) { return (n + 1) & ~1; }   // LDS blocks start on 16-byte boundaries
+constexpr ClLay cl_layout(int S, int SE, int SP, int NDP, int npcap, int nsubcap, int nrepcap, int nrcap, int tcap, int g_doubles) {
+  ClLay L{};
+  int o = 0;
+  L.l_C = o; o += cl_ev(S * NDP);                         // C[state][local day]: suffix sums, then the adjoint's running sums
+  L.l_G = g_doubles ? o : 0; o += cl_ev(g_doubles);       // G[pseudo-state][local day] (matrix-core build only)
+  L.l_Lw = o; o += cl_ev((SE + 1) * SP);                  // the walk's factor, the row v = L_W' w and a zero row
+  L.l_prior = o; o += cl_ev(SE);
+  L.l_pm = o; o += cl_ev(npcap + 8);                      // per-poll constants: {state, day, pollster, mode, population}
+  L.l_py = o; o += cl_ev(npcap + 8);                      // {y, N} as two int32
+  L.l_pun = o; o += cl_ev(npcap + 8);
+  L.l_sub = o; o += cl_ev(nsubcap * 4 + 4);               // level-1 task lists, 16-bit entries
+  L.l_tab = o; o += cl_ev((npcap + 64) / 2 + 2);          // gather program words
+  L.l_ru = o; o += cl_ev(npcap + 2);
+  L.l_wide = o; o += cl_ev(CL_WIDE * PT_NW);
+  L.l_wout = o; o += cl_ev(CL_WIDE);
+  L.l_X = o; o += cl_ev((PT_NW + 1) * SE);
+  L.l_Y = o; o += cl_ev((PT_NW + 1) * SE > nsubcap ? (PT_NW + 1) * SE : nsubcap);
+  L.l_r = o; o += cl_ev(npcap + 2);
+  L.l_rep = o; o += cl_ev(nrepcap + 2);
+  L.l_bT = o; o += cl_ev(SE);
+  L.l_e = o; o += cl_ev(tcap);
+  L.l_c1 = o; o += cl_ev(CL_MAXDAYS);                     // tangent recurrences of the AR(1) bias: the member's own days only
+  L.l_c2 = o; o += cl_ev(CL_MAXDAYS);
+  L.l_c3 = o; o += cl_ev(CL_MAXDAYS);
+  L.l_ge = o; o += cl_ev(CL_MAXDAYS);
+  L.l_P = o; o += cl_ev(nrcap + 8);
+  L.l_scal = o; o += cl_ev(SC_N);
+  L.l_red = o; o += cl_ev((PT_NW + 1) * PT_NRED);
+  L.l_st = o; o += cl_ev((npcap + 8 + 7) / 8);
+  L.l_prof = o; o += cl_ev(PT_NPROF);
+  L.total = o;
+  return L;
+}
 
 // The fourth build of the pass (tag 16): what the reference's posteriors look like on clusters of 16 -- 51 states, at most 32 days
 // and 256 polls per member -- with the LDS LAYOUT FIXED AT COMPILE TIME.  Every LDS address of the pass is then an immediate
 // (DS instructions carry a 16-bit offset) instead of a base kept in a scalar register, and the state count is a constant: the
 // kernel keeps ~150 wave-uniform values alive for 102 scalar registers, and one instruction in ten of the dynamic build
-// restores one of them from a vector-register lane.  The host lays the member's LDS out with these very numbers
-// (build_cluster) when the model fits the capacities; anything else takes the dynamic builds.
-constexpr int cl_ev(int n) { return (n + 1) & ~1; }   // LDS blocks start on 16-byte boundaries (build_cluster's `take`)
+// restores one of them from a vector-register lane.  The host lays the member's LDS out with the same function and these
+// capacities (build_cluster) when the model fits them; anything else takes the dynamic builds.
 struct ClFixed {
   static constexpr int S = 51, SE = 52, SP = 51, NDP = 33;
   static constexpr int NPCAP = 256, NSUBCAP = 384, NREPCAP = 768, NRCAP = 512, TCAP = 320;   // polls, level-1 tasks per member; small parameters; slots; days
   static constexpr int KMAX = 16;                    // members per cluster: every loop over the members is a single batch of sixteen tagged words
   static constexpr int XW = 832;                     // exchange words per member: max(XP_P + NRCAP, XQ0 + NREPCAP) = max(72 + 512, 64 + 768)
   // and the full model (poll_model_2020.stan: mode / population effects, AR(1) bias); the no_mode_adjustment variant takes the dynamic build
-  static constexpr int l_G = 0, GS = 48, GROWS = 52;
-  static constexpr int l_C = 0;
-  static constexpr int l_Lw = l_C + cl_ev(S * NDP > 12 * SE ? S * NDP : 12 * SE);
-  static constexpr int l_LT = l_Lw + cl_ev((SE + 1) * SP);
-  static constexpr int l_LB = l_LT + cl_ev(S * (S + 1) / 2 + 2);
-  static constexpr int l_w = l_LB + cl_ev(S * (S + 1) / 2 + 2);
-  static constexpr int l_prior = l_w + cl_ev(SE);
-  static constexpr int l_pm = l_prior + cl_ev(SE);
-  static constexpr int l_py = l_pm + cl_ev(NPCAP + 8);
-  static constexpr int l_pun = l_py + cl_ev(NPCAP + 8);
-  static constexpr int l_sub = l_pun + cl_ev(NPCAP + 8);
-  static constexpr int l_tab = l_sub + cl_ev(NSUBCAP * 4 + 4);
-  static constexpr int l_ru = l_tab + cl_ev((NPCAP + 64) / 2 + 2);
-  static constexpr int l_wide = l_ru + cl_ev(NPCAP + 2);
-  static constexpr int l_wout = l_wide + cl_ev(96 * PT_NW);
-  static constexpr int l_X = l_wout + cl_ev(96);
-  static constexpr int l_Y = l_X + cl_ev(12 * SE);
-  static constexpr int l_r = l_Y + cl_ev((PT_NW + 1) * SE > NSUBCAP ? (PT_NW + 1) * SE : NSUBCAP);
-  static constexpr int l_rep = l_r + cl_ev(NPCAP + 2);
-  static constexpr int l_bT = l_rep + cl_ev(NREPCAP + 2);
-  static constexpr int l_pb = l_bT + cl_ev(SE);
-  static constexpr int l_e = l_pb + cl_ev(SE);
-  static constexpr int l_c1 = l_e + cl_ev(TCAP);
-  static constexpr int l_c2 = l_c1 + cl_ev(CL_MAXDAYS);
-  static constexpr int l_c3 = l_c2 + cl_ev(CL_MAXDAYS);
-  static constexpr int l_gs = l_c3 + cl_ev(CL_MAXDAYS);
-  static constexpr int l_ge = l_gs + cl_ev(SE);
-  static constexpr int l_P = l_ge + cl_ev(CL_MAXDAYS);
-  static constexpr int l_scal = l_P + cl_ev(NRCAP + 8);
-  static constexpr int l_red = l_scal + cl_ev(SC_N);
-  static constexpr int l_st = l_red + cl_ev((PT_NW + 1) * PT_NRED);
-  static constexpr int l_prof = l_st + cl_ev((NPCAP + 8 + 7) / 8);
-  static constexpr int lds_doubles = l_prof + cl_ev(PT_NPROF);
+  static constexpr int GS = 48, GROWS = 52;
+  static constexpr ClLay L = cl_layout(S, SE, SP, NDP, NPCAP, NSUBCAP, NREPCAP, NRCAP, TCAP, 0);
+#define CLF(f) static constexpr int f = L.f
+  CLF(l_C); CLF(l_G); CLF(l_Lw); CLF(l_prior); CLF(l_pm); CLF(l_py); CLF(l_pun); CLF(l_sub); CLF(l_tab); CLF(l_ru); CLF(l_wide); CLF(l_wout); CLF(l_X); CLF(l_Y);
+  CLF(l_r); CLF(l_rep); CLF(l_bT); CLF(l_e); CLF(l_c1); CLF(l_c2); CLF(l_c3); CLF(l_ge); CLF(l_P); CLF(l_scal); CLF(l_red); CLF(l_st); CLF(l_prof);
+#undef CLF
+  static constexpr int lds_doubles = L.total;
 };
 template <int TAG> struct ClTag {
   static constexpr int DW = (TAG == 12 || TAG == 16) ? 4 : TAG;      // days per wave
@@ -194,6 +215,22 @@ template <class P> __device__ __forceinline__ P launder_s(P p) { // keep address
 // drains in about a second, the chain scalars get status POTUS_ERR_WATCHDOG and potus_run returns that error --
 // instead of a trap, which would leave the whole process with a sticky HIP error.
 __shared__ int cl_dead;
+// A buffer store of more than 64 bits reads its data registers AFTER it has issued, and hipcc 7.2 pads the pair "store, VALU write
+// of a data register" only when the store has no register soffset (LLVM's createsVALUHazard) -- every store of an exchange word
+// has one.  Found in round 4: once the 51 x 51 mat-vecs had left the pass, the word of a slot partial was followed directly by
+// `v_cndmask v2, ...` (the next LDS address, in the register that held the value's low dword) and one word in ~10^5 arrived with a
+// foreign low dword: a gradient wrong in its ninth digit, runs no longer reproducible.  The wait states are written by hand, in a
+// statement that names the data registers so that nothing can be scheduled onto them before it;
+// scripts/check_store_hazard.py scans every build for the shape (tests/test_code_object.py).
+#define STORE128_PAD(w) asm volatile("s_nop 1" :: "v"(w) : "memory")
+#ifndef CL_SEAL
+#define CL_SEAL 0
+#endif
+#if CL_SEAL
+#define XCH_SEAL(launch, lo, hi) ((launch) ^ (lo) ^ (((hi) << 7) | ((hi) >> 25)))   // experiment: the fourth dword also vouches for the value's two dwords
+#else
+#define XCH_SEAL(launch, lo, hi) (launch)
+#endif
 struct Xch {
   rsrc_t xb;               // the chain's exchange buffer [4][K][XW] words of 16 bytes (+ the watchdog word)
   unsigned epoch;          // exchanges published so far in this launch (identical in every member)
@@ -219,10 +256,11 @@ __device__ __forceinline__ void xch_give_up(const Xch &x) {
 // publish one word of the exchange being assembled (voff = 16 * word, or PT_OOB for idle lanes)
 __device__ __forceinline__ void xst(const Xch &x, unsigned voff, double v) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-  const u32x4 w = {(unsigned)u, (unsigned)(u >> 32), x.epoch + 1u, x.launch};
+  const u32x4 w = {(unsigned)u, (unsigned)(u >> 32), x.epoch + 1u, XCH_SEAL(x.launch, (unsigned)u, (unsigned)(u >> 32))};
   // (soffset through readfirstlane: the exchange counter ends up in a vector register wherever it was updated under a
   // branch whose condition came out of LDS, and a "divergent" scalar offset costs a waterfall loop around every access)
   __builtin_amdgcn_raw_buffer_store_b128(w, x.xb, voff, __builtin_amdgcn_readfirstlane(xch_wslot(x, x.m)), CL_AUX_SC1);
+  STORE128_PAD(w);
 }
 // fetch NB words of the exchange just published (per-lane byte offsets vo, PT_OOB = idle lane -> 0;
 // uniform slot offsets so); spins until every tag of the wave matches
@@ -245,7 +283,7 @@ __device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], c
   for (int u = 0; u < NB; u++) w[u] = __builtin_amdgcn_raw_buffer_load_b128(x.xb, vo[u], __builtin_amdgcn_readfirstlane(so[u]), CL_AUX_LD);
   bool all = true;
 #pragma unroll
-  for (int u = 0; u < NB; u++) { done[u] = __all(vo[u] == PT_OOB || (w[u][2] == x.epoch && w[u][3] == x.launch)); all = all && done[u]; }
+  for (int u = 0; u < NB; u++) { done[u] = __all(vo[u] == PT_OOB || (w[u][2] == x.epoch && w[u][3] == XCH_SEAL(x.launch, w[u][0], w[u][1]))); all = all && done[u]; }
 #ifdef POTUS_PROF
   if (xprof && (threadIdx.x & 63) == 0) { xprof[56] += (double)(clock64() - xt0_); xprof[57] += all ? 0.0 : 1.0; }
 #endif
@@ -275,7 +313,7 @@ __device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], c
     all = true;
 #pragma unroll
     for (int u = 0; u < NB; u++) {
-      if (!done[u]) done[u] = __all(vo[u] == PT_OOB || (w[u][2] == x.epoch && w[u][3] == x.launch));
+      if (!done[u]) done[u] = __all(vo[u] == PT_OOB || (w[u][2] == x.epoch && w[u][3] == XCH_SEAL(x.launch, w[u][0], w[u][1])));
       all = all && done[u];
     }
   }
@@ -339,7 +377,6 @@ __device__ __forceinline__ void cl_allreduce(double (&v)[N], ldp red, Xch &x, in
 // All-reduce of nv <= CL_WIDE values whose per-wave partial sums sit in LDS (part[v * PT_NW + wave]), in two halves
 // so that the wait can be taken later: cl_wide_publish sends this member's sums and returns the exchange number;
 // cl_wide_consume (wave 0 only, no barrier) collects the totals into out[0 .. nv) (LDS), bit-identical everywhere.
-#define CL_WIDE 96
 __device__ __forceinline__ unsigned cl_wide_publish(ldp part, int nv, Xch &x, ldp prof = nullptr) {
   (void)prof;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -581,20 +618,17 @@ __device__ __forceinline__ ClStatic cl_load_static(CCp CL, cip part) {
 // Stage the walk factor and the (pseudo-)states of the member's polls in LDS, once per kernel.
 __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp lds) {
   if (threadIdx.x == 0) cl_dead = 0;
+#ifdef CL_POISON_LDS
+  // development: whatever a kernel reads from LDS before writing it shows up as NaN instead of depending on the previous kernel
+  for (int i = threadIdx.x; i < CL->lds_doubles; i += PT_THREADS) lds[i] = __builtin_nan("");
+  __syncthreads();
+#endif
   ldp Lw = lds + CL->l_Lw;
   gcdp src = as_g(M->mat);
   for (int i = threadIdx.x; i < (M->SE + 1) * M->SP; i += PT_THREADS) Lw[i] = i < M->SE * M->SP ? src[i] : 0.0;   // + a zero row
-  {
-    // the two 51 x 51 factors of stan:77,85: lower triangles packed row by row (row r starts at r (r + 1) / 2) -- half the
-    // LDS of the square form, which is what lets 16 members hold the 600-day / 10 000-poll shape
-    ldp LT = lds + CL->l_LT, LB = lds + CL->l_LB;
-    const int S = M->S;
-    for (int i = threadIdx.x; i < S * S; i += PT_THREADS) {
-      const int r = i / S, k = i - r * S;
-      if (k <= r) { LT[r * (r + 1) / 2 + k] = src[M->m_LT + i]; LB[r * (r + 1) / 2 + k] = src[M->m_LB + i]; }
-    }
-    for (int i = threadIdx.x; i < S; i += PT_THREADS) { (lds + CL->l_w)[i] = src[M->m_w + i]; (lds + CL->l_prior)[i] = src[M->m_prior + i]; }
-  }
+  // mu_b_prior and, in the pseudo-state's entry, its national average (stan:85,87).  The factors of mu_b_T and of the polling
+  // bias (stan:77,85) are not staged: they are aT and aB times the walk's factor (DevModel::aT), see phase B.
+  for (int i = threadIdx.x; i < M->SE; i += PT_THREADS) (lds + CL->l_prior)[i] = src[M->m_priorx + i];
   unsigned char AS_L *st = (unsigned char AS_L *)(lds + CL->l_st);
   gcip ps = as_g(M->pi) + part[CP_P0];
   const int np = part[CP_NP];
@@ -682,8 +716,8 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   ldp C = lds + LAY(l_C), Lw = lds + LAY(l_Lw), X = lds + LAY(l_X), Y = lds + LAY(l_Y), r_lds = lds + LAY(l_r), ru_lds = lds + LAY(l_ru);
   ldp s_rep = lds + LAY(l_rep);
   ldp s_zT = s_rep, s_zb = s_rep + S, s_mid = s_rep + 2 * S;
-  ldp s_bT = lds + LAY(l_bT), s_pb = lds + LAY(l_pb), s_e = lds + LAY(l_e), s_c1 = lds + LAY(l_c1), s_c2 = lds + LAY(l_c2), s_c3 = lds + LAY(l_c3);
-  ldp s_gs = lds + LAY(l_gs), s_ge = lds + LAY(l_ge), s_P = lds + LAY(l_P), s_scal = lds + LAY(l_scal), red = lds + LAY(l_red);
+  ldp s_bT = lds + LAY(l_bT), s_e = lds + LAY(l_e), s_c1 = lds + LAY(l_c1), s_c2 = lds + LAY(l_c2), s_c3 = lds + LAY(l_c3);
+  ldp s_ge = lds + LAY(l_ge), s_P = lds + LAY(l_P), s_scal = lds + LAY(l_scal), red = lds + LAY(l_red);
   const int e_noise = e0 + S * nd, e_ze = part[CP_E_SH], e_rep = e_ze + (full ? nd : 0);   // the shared block starts on its own line
   double lp = 0.0;
 #ifdef POTUS_PROF
@@ -736,7 +770,6 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     }
 #endif
     for (int i = tid; i < NR + 8; i += PT_THREADS) s_P[i] = 0.0;   // accumulators that this member's polls may not cover
-    if (tid < SE) s_gs[tid] = 0.0;
     if (tid >= 64 && tid < 64 + CL_MAXDAYS) s_ge[tid - 64] = 0.0;
 #pragma unroll
     for (int u = 0; u < 2; u++) { const int j = tid + u * PT_THREADS; s_rep[j < NREP ? j : NREP] = ahead ? qx[u] : pol.q_fin(qr[u]); }
@@ -809,36 +842,37 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       }
       if (lane == 0) { s_scal[SC_MUE] = mue; s_scal[SC_RHO] = rho; s_scal[SC_SRHO] = srho; s_scal[SC_XMUE] = xm; s_scal[SC_XRHO] = xr; }
     }
-  } else if (w >= 2) {
-    // partial products of the two 51 x 51 factors: wave w-2 takes columns k = w-2, w+4, ...
-    const int wj = w - 2;
-    ldp LT = lds + LAY(l_LT), LB = lds + LAY(l_LB);
-    constexpr int NJ = 11;                        // 6 waves x 11 columns >= 63
-    double lt[NJ], lb[NJ], zt[NJ], zb[NJ];
-    const int ls = lane < S ? lane : 0, tri = ls * (ls + 1) / 2;
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      const int k = wj + 6 * j, kc = min(k, ls);   // packed lower triangle: (row ls, column k) is stored for k <= ls
-      const bool in = k <= ls;                     // (hence k < S)
-      lt[j] = LT[tri + kc];                        // L_T[lane][k], stan:85
-      lb[j] = LB[tri + kc];                        // L_B[lane][k], stan:77
-      zt[j] = in ? s_zT[kc] : 0.0;
-      zb[j] = in ? s_zb[kc] : 0.0;
-    }
-    ISSUE_FENCE();
-    double pT = 0.0, pB = 0.0;
-#pragma unroll
-    for (int j = 0; j < NJ; j++) { pT += lt[j] * zt[j]; pB += lb[j] * zb[j]; }
-    const int sx = lane < S ? lane : S;
-    X[wj * SE + sx] = pT;
-    X[(6 + wj) * SE + sx] = pB;
-#if CL_X3_IN_B
-    // The previous leaf's totals (exchange pend.tag, sent before this pass began) are fetched here, by a wave that finishes
-    // its share of the mat-vecs 1.5-2 k cycles before wave 0 has the suffix totals: an L2 round trip under load costs about
-    // 2 k cycles, which the verdict wave of phase C used to pay on the critical path of that phase.
-    if (w == 3 && pend.n >= 0) cl_wide_consume(x, pend.tag, pend.nv, wout);
-#endif
   }
+#if CL_X3_IN_B
+  // The previous leaf's totals (exchange pend.tag, sent before this pass began) are fetched here by a wave that has nothing else
+  // to do in this phase: an L2 round trip under load costs about 2 k cycles, which the verdict wave of phase C used to pay on
+  // the critical path of that phase.  (Round 3 tried this while waves 2-7 still carried the 51 x 51 mat-vecs of mu_b_T and
+  // the polling bias here and lost; those products are gone, see the carry step below.)
+  if (w == 2 && pend.n >= 0) cl_wide_consume(x, pend.tag, pend.nv, wout);
+#endif
+  // mu_b[:, t] = prior + L_T z_T + L_W C[:, t] and polling_bias = L_B z_b (stan:77,85-86) enter a poll's predictor only as
+  // prior[s] + L_W[s, :] . (aT z_T + aB z_b + C[:, t]): the three factors are one matrix times three scalars (stan:42-55).  So
+  // u = aT z_T + aB z_b is folded into the suffix sums and no 51 x 51 product is left in the forward pass (rounds 1-3 computed
+  // L_T z_T and L_B z_b here on six waves out of packed triangles in LDS, bound by LDS bandwidth).
+  const double aT = M->aT, aB = M->aB;
+#if CL_VC
+  // C[k][t] of the member's days WITHOUT the carry of the members that own later days: local suffix + later waves + u.  The
+  // carry enters the predictors through vc[s] = L_W_ext[s, :] . carry (wave 0, below), so nothing here waits for the exchange.
+  if (lane < S) {
+    double cy[PT_NW];
+#pragma unroll
+    for (int w2 = 0; w2 < PT_NW; w2++) cy[w2] = Y[w2 * SE + lane];
+    const double zt = s_zT[lane], zb = s_zb[lane];
+    ISSUE_FENCE();
+    double carry = aT * zt + aB * zb;
+#pragma unroll
+    for (int w2 = 0; w2 < PT_NW; w2++) carry += w2 > w ? cy[w2] : 0.0;
+#pragma unroll
+    for (int j = 0; j < CL_DW; j++) {
+      if (j < wnd) C[lane * NDP + wd0 + j] = cs[j] + carry;
+    }
+  }
+#endif
   // suffix totals of the members that own later days: fetched once per workgroup (wave 0, which has
   // nothing else to do here) and handed to the other waves through LDS
   if (w == 0 && !x1_early) {
@@ -857,21 +891,43 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
 #pragma unroll
       for (int u = 0; u < 16; u++) carry_m += t16[u];
     }
+#if CL_VC
+    // vc[s] = L_W_ext[s, :] . carry for every (pseudo-)state: lane s, the carry's elements handed around with v_readlane
+    {
+      const int ls = lane < SE ? lane : SE;            // row SE of the staged factor is zero
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      for (int k0 = 0; k0 < S; k0 += 17) {             // S = 51: three batches of seventeen terms
+        double l[17];
+#pragma unroll
+        for (int j = 0; j < 17; j++) l[j] = Lw[ls * SP + min(k0 + j, S - 1)];
+        ISSUE_FENCE();
+#pragma unroll
+        for (int j = 0; j < 17; j++) {
+          const double c = k0 + j < S ? readlane_d(carry_m, min(k0 + j, 63)) : 0.0;
+          if (j % 3 == 0) a0 += l[j] * c; else if (j % 3 == 1) a1 += l[j] * c; else a2 += l[j] * c;
+        }
+      }
+      if (lane < SE) s_bT[lane] = (lds + LAY(l_prior))[lane] + ((a0 + a1) + a2);
+    }
+#else
     if (lane < S) Y[PT_NW * SE + lane] = carry_m;
+#endif
     WPROF_PT(28);
   }
   WPROF_ACC(0);
+#if !CL_VC
   __syncthreads();
   PROF_MARK(1);
   TSTAMP(2);
   {
-    // C[k][t] for the member's days: local suffix + later waves + later members
+    // C[k][t] for the member's days: local suffix + later waves + later members + u
     if (lane < S) {
       double cy[PT_NW + 1];
 #pragma unroll
       for (int w2 = 0; w2 <= PT_NW; w2++) cy[w2] = Y[w2 * SE + lane];
+      const double zt = s_zT[lane], zb = s_zb[lane];
       ISSUE_FENCE();
-      double carry = cy[PT_NW];
+      double carry = cy[PT_NW] + (aT * zt + aB * zb);
 #pragma unroll
       for (int w2 = 0; w2 < PT_NW; w2++) carry += w2 > w ? cy[w2] : 0.0;
 #pragma unroll
@@ -880,19 +936,11 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       }
     }
   }
-  if (w == PT_NW - 1) {
-    double bT = 0.0, pb = 0.0;
-    if (lane < S) {
-#pragma unroll
-      for (int w2 = 0; w2 < 6; w2++) { bT += X[w2 * SE + lane]; pb += X[(6 + w2) * SE + lane]; }
-      bT += (lds + LAY(l_prior))[lane];
-      s_bT[lane] = bT;
-      s_pb[lane] = pb;
-    }
-    const double ww = lane < S ? (lds + LAY(l_w))[lane] : 0.0;
-    const double nb = dpp_scan_sum(ww * bT), npb = dpp_scan_sum(ww * pb);   // stan:79 and the national average of mu_b[:,T]
-    if (lane == 63) { s_bT[S] = nb; s_pb[S] = npb; }
-  }
+  if (tid < SE) s_bT[tid] = (lds + LAY(l_prior))[tid];
+#else
+  PROF_MARK(1);
+  TSTAMP(2);
+#endif
   if (tid == 0) { r_lds[np] = 0.0; ru_lds[np] = 0.0; }
   __syncthreads();
   PROF_MARK(2);
@@ -1007,7 +1055,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         const double dot = a0 + a1;
         const double sg = s == S ? sigma_nn : sigma_ns;
         zn = pol.q_fin(qt);
-        double eta = s_bT[s] + s_pb[s] + sg * zn + sigma_c * s_mid[ip] + dot;
+        double eta = s_bT[s] + sg * zn + sigma_c * s_mid[ip] + dot;   // s_bT: prior (+ the later members' part of the walk, CL_VC)
         if (full) eta += sigma_m * s_mid[om + im] + sigma_pop * s_mid[opop + ipop] + un * s_e[t];
         // binomial_logit with one exp, one log1p, one division:  e = exp(-|eta|), l = log1p(e)
         const double ex = exp(-fabs(eta)), l1 = log1p(ex), pr = (eta >= 0.0 ? 1.0 : ex) / (1.0 + ex);
@@ -1051,7 +1099,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
           const int pu = p0 + u;                    // < 64; lanes beyond the chunk hold the zero slot
           e8[u] = (unsigned)__builtin_amdgcn_readlane((int)ev, pu);
           r8[u] = readlane_d(rv, pu);
-          l8[u] = Lw[(int)(e8[u] & 0xffu) * SP + lk];   // polls of day T point at the zero row (stan:86: they feed mu_b_T only)
+          l8[u] = Lw[(int)(e8[u] & 0xffu) * SP + lk];   // (the polls of day T too: their running sum feeds mu_b_T and the polling bias only, phase E2)
         }
         ISSUE_FENCE();
 #pragma unroll
@@ -1067,8 +1115,8 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   }
   if constexpr (MF) {
     // Adjoint on the matrix cores, step 1: G[pseudo-state][local day] = sum of the residuals of the cell's polls (the polls of a
-    // member are sorted by day, then state: a cell is a run).  One thread per cell; polls of day T are left out (they feed
-    // mu_b_T only, stan:85-86).  Idle threads write the dump slot behind G.
+    // member are sorted by day, then state: a cell is a run).  One thread per cell (the cells of day T included: the prefix of that
+    // day feeds mu_b_T and the polling bias only, phase E2).  Idle threads write the dump slot behind G.
     ldp G = lds + LAY(l_G);
 #pragma unroll
     for (int h = 0; h < CL_CELLS_PER_THREAD; h++) {
@@ -1124,6 +1172,8 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
 #pragma unroll
       for (int c = 0; c < PT_NW; c++) ct[c] = X[c * SE + lx];
       ISSUE_FENCE();
+#pragma unroll
+      for (int c = 0; c < PT_NW; c++) ct[c] = lane < S ? ct[c] : 0.0;
 #pragma unroll
       for (int c = 0; c < PT_NW; c++) { X[c * SE + lx] = chunk_total; chunk_total += ct[c]; }
     }
@@ -1189,7 +1239,6 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       for (int u = 0; u < 8; u++) sum += j0 + u < sg_b ? yy[u] : 0.0;
     }
     if (sg_kind == 0) s_P[sg_index] = sum;          // pollster / mode / population partial (slot index)
-    else if (sg_kind == 1) s_gs[sg_index] = sum;    // residual sum of (pseudo-)state
     else if (sg_kind == 2) s_ge[sg_index] = sum;    // sum of unadjusted * residual over a local day
   }
   __syncthreads();
@@ -1204,14 +1253,14 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
 #pragma unroll
     for (int j = 0; j < CL_DW; j++) {
       const double cc = X[ch[j] * SE + (lane < S ? lane : S)];
-      pre[j] = tlast[j] >= 0 ? cv[j] + cc : 0.0;
+      pre[j] = (tlast[j] >= 0 && lane < S) ? cv[j] + cc : 0.0;   // (lanes beyond the states: column S of X is never written; their value
+                                                               //  would meet a zero metric element in the epilogue, and NaN * 0 is NaN)
     }
   } else {
 #pragma unroll
     for (int j = 0; j < CL_DW; j++) pre[j] = C[(lane < S ? lane : 0) * NDP + min(wd0 + j, max(nd - 1, 0))];   // (days beyond the wave's: unused)
     if (w == 0) chunk_total = nd > 0 ? C[(lane < S ? lane : 0) * NDP + nd - 1] : 0.0;
   }
-  ldp C2 = MF ? C + S * NDP : C;                    // where the partial transposed mat-vecs go: with MF the prefix block is still being read
   if (w == 0) {
     pay = chunk_total;
   } else if (w == 1) {
@@ -1226,53 +1275,39 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       arA = in ? rho : 1.0;
       dpp_scan_affine(arA, Bv);
       arB = Bv[0];                                  // a[t] = arB + arA * a[first day of the next member]
-      const double S1 = dpp_scan_sum(ge * s_c1[tl]), S2 = dpp_scan_sum(ge * s_c2[tl]), S3 = dpp_scan_sum(ge * s_c3[tl]);
+      // (a member without days never writes its tangents: no product with whatever LDS holds there)
+      const double t1 = in ? s_c1[tl] : 0.0, t2 = in ? s_c2[tl] : 0.0, t3 = in ? s_c3[tl] : 0.0;
+      const double S1 = dpp_scan_sum(ge * t1), S2 = dpp_scan_sum(ge * t2), S3 = dpp_scan_sum(ge * t3);
       // lane 63 holds the member's composite and the three sums
       const double pv0 = dpp_readlane_d(arA, 63), pv1 = dpp_readlane_d(arB, 63);
       const double pv2 = dpp_readlane_d(S1, 63), pv3 = dpp_readlane_d(S2, 63), pv4 = dpp_readlane_d(S3, 63);
       pay = lane == 0 ? pv0 : lane == 1 ? pv1 : lane == 2 ? pv2 : lane == 3 ? pv3 : pv4;   // XP_S = XP_AR + 2
     }
-  } else {
-    // dbT[s] = dpolling_bias[s] = residuals of state s + w_s * national residuals (this member's polls
-    // only: the products are linear, the owners add the K partials); C region is free now
-    const int wj = w - 2;
-    ldp LT = lds + LAY(l_LT), LB = lds + LAY(l_LB), s_w = lds + LAY(l_w);
-    double pT = 0.0, pB = 0.0;
-    const double gnat = s_gs[S];
-    constexpr int NJ = 11;
-    double lt[NJ], lb[NJ], gg[NJ];
-    const int lk = lane < S ? lane : 0;
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      const int s = wj + 6 * j, sc = s < S ? s : 0;
-      const int at = sc * (sc + 1) / 2 + min(lk, sc);                // (row s, column lane) of the packed lower triangle
-      lt[j] = LT[at]; lb[j] = LB[at];
-      gg[j] = (s < S && lk <= sc) ? s_gs[sc] + s_w[sc] * gnat : 0.0;
-    }
-    ISSUE_FENCE();
-#pragma unroll
-    for (int j = 0; j < NJ; j++) { pT += lt[j] * gg[j]; pB += lb[j] * gg[j]; }
-    if (lane < S) { C2[wj * SE + lane] = pT; C2[(6 + wj) * SE + lane] = pB; }
   }
+  // The gradients of raw_mu_b_T and raw_polling_bias need L_T' g and L_B' g with g[s] = the residuals of state s + w_s * the
+  // national residuals (stan:77,85).  Both factors are multiples of the walk's, and L_W_ext' g = the adjoint of the walk summed
+  // over ALL the polls = the sum over the members of the prefix totals published here (the polls of the last day included: they
+  // take their real row of the factor in the gather, and the prefix of that day is not used, stan:86).  So the owners of those
+  // slots add up the words XP_PRE + k instead of partial transposed mat-vecs, which rounds 1-3 computed here on six waves.
   xst(x, (w == 0 && lane < S) ? 16u * (unsigned)(XP_PRE + lane) : (w == 1 && full && lane < 5) ? 16u * (unsigned)(XP_AR + lane) : PT_OOB, pay);
+#if CL_E2_BARRIER == 1
   __syncthreads();
+#elif CL_E2_BARRIER == 2
+  drain_vmem();
+#elif CL_E2_BARRIER == 3
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
   PROF_MARK(6);
   TSTAMP(7);
   {
-    // slot partials: every thread publishes one slot (two with more than 512 slots); no branch around the stores
+    // slot partials of the pollster / mode / population effects: every thread publishes one slot (two with more than 512
+    // slots); no branch around the stores
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int rr = tid + h * PT_THREADS;
-      const bool ok = rr < NR;
-      const int rc = ok ? rr : 0;
-      const int which = rc >= S, k = rc < 2 * S ? rc - which * S : 0;
-      double v6[6];
-#pragma unroll
-      for (int w2 = 0; w2 < 6; w2++) v6[w2] = C2[(which * 6 + w2) * SE + k];
-      const double vp = s_P[rc];
-      ISSUE_FENCE();
-      const double v = rc < 2 * S ? ((((v6[0] + v6[1]) + v6[2]) + v6[3]) + v6[4]) + v6[5] : vp;
-      xst(x, ok ? 16u * (unsigned)(XP_P + rr) : PT_OOB, v);
+      const bool ok = rr >= 2 * S && rr < NR;
+      const double vp = s_P[ok ? rr : 2 * S];
+      xst(x, ok ? 16u * (unsigned)(XP_P + rr) : PT_OOB, vp);
     }
   }
   // loads that do not depend on the exchange are issued while wave 0 waits
@@ -1339,7 +1374,8 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     // owned slots of the small vectors: sum the K partials in member order
     double sum = 0.0;
     const unsigned v1 = is_mue ? 16u * (unsigned)XP_S : is_rho ? 16u * (unsigned)(XP_S + 1) : is_s3 ? 16u * (unsigned)(XP_S + 2)
-                        : repl ? 16u * (unsigned)(XP_P + rslot) : PT_OOB;
+                        : !repl ? PT_OOB : rslot < 2 * S ? 16u * (unsigned)(XP_PRE + (rslot < S ? rslot : rslot - S))   // L_W_ext' g, see phase E2
+                        : 16u * (unsigned)(XP_P + rslot);
     for (int mm0 = 0, bt = 0; mm0 < K && (!(FX && CL_FX_BATCH) || bt < 1); mm0 += 16, bt++) {
       double t16[16];
       unsigned vo[16], so[16];
@@ -1686,6 +1722,7 @@ __device__ __forceinline__ void tw_st(const Twin &t, unsigned voff, double v, un
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
   const u32x4 w = {(unsigned)u, (unsigned)(u >> 32), tag, t.launch};
   __builtin_amdgcn_raw_buffer_store_b128(w, t.tb, voff, 0u, CL_AUX_SC1);
+  STORE128_PAD(w);
 }
 // lane l < n looks at word w0 + l: true when every one carries the tag
 __device__ __forceinline__ bool tw_try(const Twin &t, int w0, int n, unsigned tag, double &val) {

@@ -1246,6 +1246,13 @@ int build_model(Sampler *sp, const potus_data *d) {
   auto app = [&](const std::vector<double> &v) { const int off = (int)mat.size(); mat.insert(mat.end(), v.begin(), v.end()); return off; };
   M.m_LTt = app(LT_t); M.m_LBt = app(LB_t); M.m_LT = app(LTr); M.m_LB = app(LBr);
   M.m_prior = app(std::vector<double>(d->mu_b_prior, d->mu_b_prior + S)); M.m_w = app(w);
+  {
+    std::vector<double> px(d->mu_b_prior, d->mu_b_prior + S);
+    double nat = 0; for (int s = 0; s < S; s++) nat += w[s] * px[s];   // stan:87 applied to the prior part of mu_b
+    px.push_back(nat); px.push_back(0.0);
+    M.m_priorx = app(px);
+  }
+  M.aT = d->mu_b_T_scale / d->random_walk_scale; M.aB = d->polling_bias_scale / d->random_walk_scale;
   M.Npad = (Np + 15) & ~15;
   std::vector<int> pi((size_t)6 * M.Npad, 0);
   std::vector<double> pdv((size_t)4 * M.Npad, 0.0);
@@ -1414,7 +1421,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
     for (int il = 0; il < np; il++) {
       const int g = p0 + il, tl = sp->h_pt[g] - d0;
       const bool dayend = il == np - 1 || sp->h_pt[g + 1] != sp->h_pt[g];
-      tab[il] = (sp->h_pt[g] == T - 1 ? M.SE : sp->h_ps[g]) | (tl << 8) | ((dayend ? 1 : 0) << 16);   // day T: the zero row
+      tab[il] = sp->h_ps[g] | (tl << 8) | ((dayend ? 1 : 0) << 16);
     }
     for (int wv = 0; wv < PT_NW; wv++)
       for (int j = 0; j < wnd[wv]; j++) {
@@ -1423,8 +1430,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
         s2info[wv * 64 + j] = tl < 0 ? 0 : ((tl + 1) | (chunk_of(dp[d0 + tl + 1] - 1 - p0) << 8));
       }
     // adjoint on the matrix cores (4-days-per-wave build): the (state, day) cells of the member's polls -- runs of its
-    // day-then-state sorted polls -- one per thread: first poll | polls << 10 | offset in G << 16; polls of day T stay out
-    // (they feed mu_b_T only, stan:85-86)
+    // day-then-state sorted polls -- one per thread: first poll | polls << 10 | offset in G << 16
     std::vector<int> cellw((size_t)CL_CELLS_PER_THREAD * PT_THREADS, 0);
     int ncell = 0;
     if (mfma) {
@@ -1434,7 +1440,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
       for (int il = 0; il < np;) {
         int j = il + 1;
         while (j < np && sp->h_pt[p0 + j] == sp->h_pt[p0 + il] && sp->h_ps[p0 + j] == sp->h_ps[p0 + il]) j++;
-        if (sp->h_pt[p0 + il] != T - 1) {
+        {
           if (j - il > 63) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: %d polls of one state on one day (the adjoint scatter takes 63)", j - il);
           if (ncell >= CL_CELLS_PER_THREAD * PT_THREADS) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode: member %d has more than %d polled (state, day) cells", m, CL_CELLS_PER_THREAD * PT_THREADS);
           cellw[ncell++] = il | ((j - il) << 10) | ((sp->h_ps[p0 + il] * GS + (sp->h_pt[p0 + il] - d0)) << 16);
@@ -1474,7 +1480,6 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
       add_group(M.M, 0, 2 * S + P, false, [&](int i) { return sp->h_pm[i]; });
       add_group(M.Pop, 0, 2 * S + P + M.M, false, [&](int i) { return sp->h_ppop[i]; });
     }
-    add_group(S + 1, 1, 0, false, [&](int i) { return sp->h_ps[i]; });
     const int wb = nsub;   // tasks from here on sum unadjusted * residual
     if (full) add_group(nd, 2, 0, false, [&](int i) { return sp->h_pt[i] - d0; });
     seg_ptr.push_back(nsub);
@@ -1511,6 +1516,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
     rep_owner[j] = mo;
   }
   std::vector<double> rep_scale(C.NR, 1.0);
+  for (int i = 0; i < S; i++) { rep_scale[i] = M.aT; rep_scale[S + i] = M.aB; }   // L_T = aT L_W, L_B = aB L_W (DevModel::aT)
   for (int i = 0; i < P; i++) rep_scale[2 * S + i] = d->sigma_c;
   if (full) {
     for (int i = 0; i < M.M; i++) rep_scale[2 * S + P + i] = d->sigma_m;
@@ -1518,50 +1524,28 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   }
   sp->h_perm = perm;
 
-  int o = 0;
-  auto take = [&](int n) { const int a = o; o += (n + 1) & ~1; return a; };
-  {
-    int ndmax = 1;
-    for (int m = 0; m < K; m++) ndmax = std::max(ndmax, part[(size_t)m * CP_N + CP_ND]);
-    C.NDP = ndmax | 1;   // odd row stride of the member's C[state][local day] block
-  }
-  C.l_C = take(mfma ? S * C.NDP + 12 * M.SE : std::max(S * C.NDP, 12 * M.SE));   // (+ the partial transposed mat-vecs of phase E2 behind the prefix block)
-  C.l_G = mfma ? take(GROWS * GS + CL_G_PAD) : 0; C.GS = GS; C.GROWS = GROWS;
-  C.l_Lw = take((M.SE + 1) * M.SP);
-  C.l_LT = take(S * (S + 1) / 2 + 2); C.l_LB = take(S * (S + 1) / 2 + 2); C.l_w = take(M.SE); C.l_prior = take(M.SE);   // packed lower triangles
-  C.l_pm = take(npmax + 8); C.l_py = take(npmax + 8); C.l_pN = 0; C.l_pun = take(npmax + 8);                             // l_py: {y, N} as two int32
-  C.l_sub = take(nsubmax * 4 + 4);
-  C.l_tab = take((npmax + 64) / 2 + 2); C.l_ru = take(npmax + 2);
-  C.l_wide = take(CL_WIDE * PT_NW); C.l_wout = take(CL_WIDE);
-  C.l_X = take(12 * M.SE);
-  C.l_Y = take(std::max((PT_NW + 1) * M.SE, nsubmax));   // + the row of carries from later members
-  C.l_r = take(npmax + 2);
-  C.l_rep = take(C.NREP + 2);
-  C.l_bT = take(M.SE); C.l_pb = take(M.SE); C.l_e = take(T);
-  C.l_c1 = take(CL_MAXDAYS); C.l_c2 = take(CL_MAXDAYS); C.l_c3 = take(CL_MAXDAYS);   // tangent recurrences: the member's own days only
-  C.l_gs = take(M.SE); C.l_ge = take(CL_MAXDAYS); C.l_P = take(C.NR + 8); C.l_scal = take(SC_N); C.l_red = take((PT_NW + 1) * PT_NRED);
-  C.l_st = take((npmax + 8 + 7) / 8);
-  C.l_prof = take(PT_NPROF);
-  C.lds_doubles = o;
+  int ndmax = 1;
+  for (int m = 0; m < K; m++) ndmax = std::max(ndmax, part[(size_t)m * CP_N + CP_ND]);
+  C.NDP = ndmax | 1;   // odd row stride of the member's C[state][local day] block
+  C.GS = GS; C.GROWS = GROWS;
+  ClLay lay = cl_layout(S, M.SE, M.SP, C.NDP, npmax, nsubmax, C.NREP, C.NR, T, mfma ? GROWS * GS + CL_G_PAD : 0);
   // The build with the layout fixed at compile time (tag 16, ClFixed): 51 states, members of at most 32 days / 256 polls / 384
-  // level-1 tasks, the walk for the adjoint.  The numbers above are replaced by ClFixed's -- the kernel uses them as immediates.
+  // level-1 tasks, the walk for the adjoint.  The layout is then the same function of ClFixed's capacities -- the numbers the
+  // kernel uses as immediates.
   {
-    int ndmax = 1;
-    for (int m = 0; m < K; m++) ndmax = std::max(ndmax, part[(size_t)m * CP_N + CP_ND]);
     const bool fits = DW == 4 && !mfma && full && (CL_FX_K16 ? K == 16 : K <= ClFixed::KMAX) && std::max(XP_P + C.NR, XQ0 + C.NREP) <= ClFixed::XW && S == ClFixed::S && M.SE == ClFixed::SE && M.SP == ClFixed::SP && ndmax <= ClFixed::NDP - 1 && npmax <= ClFixed::NPCAP &&
                       nsubmax <= ClFixed::NSUBCAP && C.NREP <= ClFixed::NREPCAP && C.NR <= ClFixed::NRCAP && T <= ClFixed::TCAP && (int)SC_N <= 8;
     if (fits && !(getenv("POTUS_CL_DYNAMIC") && atoi(getenv("POTUS_CL_DYNAMIC")))) {
       C.NDP = ClFixed::NDP; C.XW = ClFixed::XW;
-      C.l_C = ClFixed::l_C; C.l_G = 0; C.l_Lw = ClFixed::l_Lw; C.l_LT = ClFixed::l_LT; C.l_LB = ClFixed::l_LB; C.l_w = ClFixed::l_w; C.l_prior = ClFixed::l_prior;
-      C.l_pm = ClFixed::l_pm; C.l_py = ClFixed::l_py; C.l_pun = ClFixed::l_pun; C.l_sub = ClFixed::l_sub; C.l_tab = ClFixed::l_tab; C.l_ru = ClFixed::l_ru;
-      C.l_wide = ClFixed::l_wide; C.l_wout = ClFixed::l_wout; C.l_X = ClFixed::l_X; C.l_Y = ClFixed::l_Y; C.l_r = ClFixed::l_r; C.l_rep = ClFixed::l_rep;
-      C.l_bT = ClFixed::l_bT; C.l_pb = ClFixed::l_pb; C.l_e = ClFixed::l_e; C.l_c1 = ClFixed::l_c1; C.l_c2 = ClFixed::l_c2; C.l_c3 = ClFixed::l_c3;
-      C.l_gs = ClFixed::l_gs; C.l_ge = ClFixed::l_ge; C.l_P = ClFixed::l_P; C.l_scal = ClFixed::l_scal; C.l_red = ClFixed::l_red; C.l_st = ClFixed::l_st;
-      C.l_prof = ClFixed::l_prof; C.lds_doubles = ClFixed::lds_doubles;
-      o = ClFixed::lds_doubles;
+      lay = ClFixed::L;
       sp->cl_dw = 16;
     }
   }
+  C.l_C = lay.l_C; C.l_G = lay.l_G; C.l_Lw = lay.l_Lw; C.l_prior = lay.l_prior; C.l_pm = lay.l_pm; C.l_py = lay.l_py; C.l_pun = lay.l_pun;
+  C.l_sub = lay.l_sub; C.l_tab = lay.l_tab; C.l_ru = lay.l_ru; C.l_wide = lay.l_wide; C.l_wout = lay.l_wout; C.l_X = lay.l_X; C.l_Y = lay.l_Y;
+  C.l_r = lay.l_r; C.l_rep = lay.l_rep; C.l_bT = lay.l_bT; C.l_e = lay.l_e; C.l_c1 = lay.l_c1; C.l_c2 = lay.l_c2; C.l_c3 = lay.l_c3; C.l_ge = lay.l_ge;
+  C.l_P = lay.l_P; C.l_scal = lay.l_scal; C.l_red = lay.l_red; C.l_st = lay.l_st; C.l_prof = lay.l_prof; C.lds_doubles = lay.total;
+  const int o = lay.total;
   sp->cl_lds_bytes = (size_t)o * 8 + sizeof(TS) + 16;
   if (sp->cl_lds_bytes > 160 * 1024 - 64) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode needs %zu bytes of LDS per workgroup", sp->cl_lds_bytes);
 

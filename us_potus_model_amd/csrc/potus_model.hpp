@@ -77,9 +77,14 @@ struct DevModel {
   int o_zT, o_Z, o_c, o_m, o_pop, o_mue, o_rho, o_ze, o_nn, o_ns, o_zb;
   int nmid;                 // o_nn - o_c : parameters between the S x T block and the noise blocks
   double sigma_c, sigma_m, sigma_pop, sigma_e, sigma_ns, sigma_nn;
+  // stan:42-55: the three covariances are one matrix times three scalars, so cholesky_ss_cov_mu_b_T = aT * cholesky_ss_cov_mu_b_walk
+  // and cholesky_ss_cov_poll_bias = aB * cholesky_ss_cov_mu_b_walk (aT = mu_b_T_scale / random_walk_scale, aB = polling_bias_scale /
+  // random_walk_scale).  The cluster pass (potus_cluster.hpp) uses that: L_T z_T + L_B z_b + L_W C[:,t] = L_W (aT z_T + aB z_b + C[:,t]).
+  double aT, aB;
   // Static data is packed into three buffers so that the descriptor costs few scalar registers.
-  const double *mat;        // Lw_ext [SE][SP] | LT_t [k][s] | LB_t [k][s] | LT [s][k] | LB [s][k] | prior [S] | w [S]
+  const double *mat;        // Lw_ext [SE][SP] | LT_t [k][s] | LB_t [k][s] | LT [s][k] | LB [s][k] | prior [S] | w [S] | prior_ext [S + 1]
   int m_LTt, m_LBt, m_LT, m_LB, m_prior, m_w;   // offsets into mat (Lw_ext at 0)
+  int m_priorx;             // prior [S] followed by its national average sum_s w_s prior_s (the pseudo-state's entry)
   //   Lw_ext rows 0..S-1: L_W (zeros above the diagonal); row S: v = L_W^T w
   const int *pi;            // polls sorted by day, struct of arrays with stride Npad:
   const double *pd;         //   pi: ps | pt | pp | pm | ppop | pqidx      pd: py | pn | punadj | psig
