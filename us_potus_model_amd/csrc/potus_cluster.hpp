@@ -57,8 +57,13 @@
 #ifndef CL_X1_IN_A
 #define CL_X1_IN_A 0                     // 1: the suffix totals sent ahead by the previous leaf are fetched in phase A (see there; measured slower)
 #endif
+#ifndef CL_VERDICT_IN_D
+#define CL_VERDICT_IN_D 0                // 1: the previous leaf's totals are fetched in phase C (idle wave) and its verdicts taken in phase D, on the last wave,
+                                         //    which then has no chunk of the adjoint gather (CL_NCHUNK = PT_NW - 1): neither phase B nor phase C carries them
+#endif
+#define CL_NCHUNK (CL_VERDICT_IN_D ? PT_NW - 1 : PT_NW)   // chunks the member's polls are cut into for the adjoint gather (host: build_cluster)
 #ifndef CL_X3_IN_B
-#define CL_X3_IN_B 1                     // 1: the previous leaf's totals are collected in phase B by a wave that is done early there (see phase C)
+#define CL_X3_IN_B (CL_VERDICT_IN_D ? 0 : 1)                     // 1: the previous leaf's totals are collected in phase B by a wave that is done early there (see phase C)
 #endif
 #ifndef CL_E2_BARRIER
 #define CL_E2_BARRIER 0
@@ -374,7 +379,8 @@ __device__ __forceinline__ void cl_allreduce(double (&v)[N], ldp red, Xch &x, in
   for (int k = 0; k < N; k++) v[k] = red[PT_NW * N + k];
   PROF_MARK(26);
 }
-// All-reduce of nv <= CL_WIDE values whose per-wave partial sums sit in LDS (part[v * PT_NW + wave]), in two halves
+#define WP(v, w) ((w) * CL_WIDE + (v))   // per-wave partial sums of value v: a row per wave, so that lane v reads its eight partials from eight conflict-free rows
+// All-reduce of nv <= CL_WIDE values whose per-wave partial sums sit in LDS (part[WP(v, wave)]), in two halves
 // so that the wait can be taken later: cl_wide_publish sends this member's sums and returns the exchange number;
 // cl_wide_consume (wave 0 only, no barrier) collects the totals into out[0 .. nv) (LDS), bit-identical everywhere.
 __device__ __forceinline__ unsigned cl_wide_publish(ldp part, int nv, Xch &x, ldp prof = nullptr) {
@@ -389,7 +395,7 @@ __device__ __forceinline__ unsigned cl_wide_publish(ldp part, int nv, Xch &x, ld
     const bool ok = w == 0 && lane < nv;
     double p8[PT_NW];
 #pragma unroll
-    for (int i = 0; i < PT_NW; i++) p8[i] = part[(ok ? lane : 0) * PT_NW + i];
+    for (int i = 0; i < PT_NW; i++) p8[i] = part[WP(ok ? lane : 0, i)];
     ISSUE_FENCE();
     double s = 0.0;
 #pragma unroll
@@ -401,7 +407,7 @@ __device__ __forceinline__ unsigned cl_wide_publish(ldp part, int nv, Xch &x, ld
     const bool ok = w == 0 && l < nv;
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < PT_NW; i++) s += part[(ok ? l : 0) * PT_NW + i];
+    for (int i = 0; i < PT_NW; i++) s += part[WP(ok ? l : 0, i)];
     xst(x, ok ? 16u * (unsigned)l : PT_OOB, s);
   }
   x.epoch++;
@@ -1009,7 +1015,9 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
 #endif
 #endif
       WPROF_PTB(29);
+#if !CL_VERDICT_IN_D
       cl_leaf_logic(ts, pend, wout);
+#endif
       WPROF_PTB(30);
     }
     const bool no_polls_here = w == PT_NW - 2 && pend.n >= 0 && np <= 64 * w;   // the verdict wave, when it has no polls: skip the (idle) trip
@@ -1073,7 +1081,9 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   TSTAMP(4);
   // The verdicts ended the trajectory: every member leaves here together.  What this pass has stored so far (the
   // epilogue of the poll-noise elements) went to slots nobody reads once the trajectory is over.
+#if !CL_VERDICT_IN_D
   if (pend.n >= 0 && uni_i(ts->abort)) { aborted = true; return 0.0; }
+#endif
 
   // ---------------- phase D: adjoint of the walk, gC[:,t] = sum_i r_i Lw_ext[s_i,:] summed over days <= t.
   // The member's polls (day order) are cut into PT_NW equal chunks, one per wave, whatever the days: a wave
@@ -1081,6 +1091,10 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // readlane; lanes < S keep the running sum over the chunk, lane 63 the day's sum of unadjusted * residual
   // (the adjoint input of e_bias[t]).  At the last poll of a day the running values go to LDS; the owners
   // of the days pick them up in phase E.  Level-1 segment sums follow.
+#if CL_VERDICT_IN_D
+  // the previous leaf's verdicts (its totals were collected in phase C): the last wave has no chunk of the gather below
+  if (w == PT_NW - 1 && pend.n >= 0) cl_leaf_logic(ts, pend, wout);
+#endif
   if constexpr (!MF) {
     const unsigned AS_L *tab = (const unsigned AS_L *)(lds + LAY(l_tab));
     const int lk = lane < S ? lane : 0;
@@ -1152,6 +1166,11 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   __syncthreads();
   PROF_MARK(4);
   TSTAMP(5);
+#if CL_VERDICT_IN_D
+  // The verdicts ended the trajectory: every member leaves here together (what this pass has stored so far -- the epilogue of the
+  // poll-noise elements -- went to slots nobody reads once the trajectory is over).
+  if (pend.n >= 0 && uni_i(ts->abort)) { aborted = true; return 0.0; }
+#endif
 
   // ---------------- phase E: the owners of the days pick up the running sums; level-2 segment sums
   // (the chunk totals X[chunk][state] are turned into exclusive prefixes in place by wave 0, which keeps their sum for
@@ -1557,10 +1576,10 @@ __device__ __forceinline__ bool cl_vop_merge(ClChain &c, unsigned a_beg, unsigne
   cl_allreduce(v, c.red(), c.x, c.tid, CPROFPTR(c));
   return v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0 && v[4] > 0 && v[5] > 0;
 }
-// Same sweep, but the six dot products stay per-wave partial sums in LDS (part[(6 slot + k) * PT_NW + wave]);
+// Same sweep, but the six dot products stay per-wave partial sums in LDS (part[WP(v0 + k, wave)]);
 // the leaf's single all-reduce adds them over the cluster.
 __device__ __forceinline__ void cl_vop_merge_partial(ClChain &c, unsigned a_beg, unsigned a_end, unsigned a_rho, unsigned b_beg, unsigned b_end,
-                                                     unsigned b_rho, unsigned out, ldp part) {
+                                                     unsigned b_rho, unsigned out, ldp part, int v0) {
   const unsigned sM = c.soff(V_MINV);
   double v[6] = {0, 0, 0, 0, 0, 0};
   for (int base = cl_first(c); base < c.e1; base += CL_UNR * PT_THREADS) {
@@ -1592,7 +1611,7 @@ __device__ __forceinline__ void cl_vop_merge_partial(ClChain &c, unsigned a_beg,
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     const double t = dpp_scan_sum(v[k]);
-    if (lane == 63) part[k * PT_NW + w] = t;
+    if (lane == 63) part[WP(v0 + k, w)] = t;
   }
   // the sweep of the next level reads the vector `out` with a different thread-to-element map only through
   // the same element index i -> same thread: no barrier needed between consecutive sweeps
@@ -1910,15 +1929,15 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, co
       {
         const int lane = tid & 63, w = tid >> 6;
         const double t0 = dpp_scan_sum(lpp), t1 = dpp_scan_sum(lp.extra[0]);
-        if (lane == 63) { wpart[0 * PT_NW + w] = t0; wpart[1 * PT_NW + w] = t1; }
+        if (lane == 63) { wpart[WP(0, w)] = t0; wpart[WP(1, w)] = t1; }
         if (m >= 1) {                               // level 1 came out of the epilogue: v0 = v2 = v4, v1 = v3 = v5
           const double a = dpp_scan_sum(lp.extra[1]), b = dpp_scan_sum(lp.extra[2]);
           if (lane == 63) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) wpart[(2 + k) * PT_NW + w] = (k & 1) ? b : a;
+            for (int k = 0; k < 6; k++) wpart[WP(2 + k, w)] = (k & 1) ? b : a;
           }
         }
-        if (TWIN && lane == 63) wpart[nv0 * PT_NW + w] = (w == 0 && ts->tw_ext) ? 1.0 : 0.0;
+        if (TWIN && lane == 63) wpart[WP(nv0, w)] = (w == 0 && ts->tw_ext) ? 1.0 : 0.0;
       }
       if (m > 1 || top) { drain_vmem(); __syncthreads(); }   // the leaf's momentum is read back with another thread map
       for (int j = 2; j <= m; j++) {
@@ -1927,14 +1946,14 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, co
         const unsigned b_rho = c.soff(V_SCR0 + ((j - 1) & 1));
         const unsigned out = j == m ? c.soff(V_RHOLEV + j) : c.soff(V_SCR0 + (j & 1));
         cl_vop_merge_partial(c, c.soff(V_POOLP + ib), c.soff(V_POOLP + ie), a_rho, c.soff(V_POOLP + cb), c.soff(V_POOLP + leaf), b_rho, out,
-                             wpart + (2 + 6 * (j - 1)) * PT_NW);
+                             wpart, 2 + 6 * (j - 1));
       }
       if (top) {
         // the checks at the end of transition(): old trajectory (init side) against the new subtree
         const int nb = depth >= 1 ? uni_i(ts->pend_beg[depth - 1]) : leaf;
         const unsigned n_rho = depth == 0 ? c.soff(V_POOLP + leaf) : c.soff(V_RHOLEV + depth);
         cl_vop_merge_partial(c, c.soff(V_PF1 - dir), c.soff(V_PNEAR), c.soff(V_RHOTOP), c.soff(V_POOLP + nb), c.soff(V_POOLP + leaf), n_rho,
-                             c.soff(V_RHOTOP), wpart + (2 + 6 * m) * PT_NW);
+                             c.soff(V_RHOTOP), wpart, 2 + 6 * m);
       }
       CPROF_MARK(c, PF_MERGE);
       const unsigned tag = cl_wide_publish(wpart, nv, c.x, CPROFPTR(c));

@@ -1416,8 +1416,8 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
     // adjoint gather: equal chunks of the member's polls per wave; program word per poll; what the owner of
     // each day reads back (last polled day <= it, chunk of that day's last poll)
     std::vector<int> ca(PT_NW), cb(PT_NW), tab(np), s2info(PT_THREADS, 0);
-    for (int wv = 0; wv < PT_NW; wv++) { ca[wv] = (int)((long long)np * wv / PT_NW); cb[wv] = (int)((long long)np * (wv + 1) / PT_NW); }
-    auto chunk_of = [&](int il) { int c = 0; while (c < PT_NW - 1 && il >= cb[c]) c++; return c; };
+    for (int wv = 0; wv < PT_NW; wv++) { ca[wv] = (int)((long long)np * std::min(wv, CL_NCHUNK) / CL_NCHUNK); cb[wv] = (int)((long long)np * std::min(wv + 1, CL_NCHUNK) / CL_NCHUNK); }
+    auto chunk_of = [&](int il) { int c = 0; while (c < CL_NCHUNK - 1 && il >= cb[c]) c++; return c; };
     for (int il = 0; il < np; il++) {
       const int g = p0 + il, tl = sp->h_pt[g] - d0;
       const bool dayend = il == np - 1 || sp->h_pt[g + 1] != sp->h_pt[g];
