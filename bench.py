@@ -16,6 +16,8 @@ objects, allocator).
 
 --config 1/2  2016 backtest, C = 8 chains per GPU (configs[1]; with N GPUs configs[2]: 8 N chains, one RCCL all-gather
               of the draws-of-interest for pooled R-hat / ESS, device buffers end to end)
+--config 0    the reference's own sampler calls as scripted (6 chains x (500 + 500), seed 1843: final_2016.R, final_2012.R, final_2008.R;
+              BASELINE's 4 x 500), each run to completion on the GPU and on the CPU port, side by side (one GPU)
 --config 3    2008 + 2012 + 2016 backtests concurrently, 4 chains of each per GPU (32 each over 8 GPUs), three
               posteriors advancing together under potus_run_many
 --config 4    synthetic stress posterior (51 states x 600 days x 10 000 polls, D = 41 610), dense metric
@@ -159,6 +161,67 @@ def cpu_baseline(data, variant, chains, seed, nw, ns, short, budget=12.0, loop_b
     return out
 
 
+# ------------------------------------------------------------------------------------------------ configs[0]
+def reference_sampler_calls(local, seed, cus_per_chain, twin, max_depth, cpu=True):
+    """BASELINE configs[0]: the reference's own sampler calls as they are scripted, each run to completion on the GPU and on the CPU
+    port, side by side -- scripts/model/final_2016.R:6-11,533-541 (6 chains x (500 + 500), seed 1843, refresh 50), the same call of
+    final_2012.R:558-569 and final_2008.R:562-573 (no_mode_adjustment model), and BASELINE's own wording of configs[0] (4 chains x 500
+    iterations "via rstan": rstan's iter includes the warm-up, final_2016.R:525-529 -> 250 + 250).  The GPU advances in chunks of
+    `refresh` transitions, as the R loop over potus_run would (R/potus_sampling.R)."""
+    import torch
+    from us_potus_model_amd import Handle, dataprep
+    gold = ROOT / "tests" / "golden"
+    calls = [("final_2016.R:533-541 as scripted", "2016", "full", 6, 500, 500), ("BASELINE configs[0]: 4 chains x 500 iterations (rstan: 250 + 250)", "2016", "full", 4, 250, 250),
+             ("final_2012.R:558-569 as scripted", "2012", "no_mode_adjustment", 6, 500, 500), ("final_2008.R:562-573 as scripted", "2008", "no_mode_adjustment", 6, 500, 500)]
+    out = []
+    for label, year, variant, chains, nw, ns in calls:
+        data = dataprep.load_npz(gold / f"data_{year}.npz")["data"]
+        S, T = int(data["S"]), int(data["T"])
+        refresh = max(ns // 10, 1)
+        hw = Handle(data, variant, chains=chains, num_warmup=refresh, num_samples=0, seed=seed + 1, device=local, cus_per_chain=cus_per_chain, twin=twin, max_depth=max_depth)
+        hw.init(); hw.run(refresh); hw.close()                       # untimed: code objects, clocks
+        h = Handle(data, variant, chains=chains, num_warmup=nw, num_samples=ns, seed=seed, device=local, cus_per_chain=cus_per_chain, twin=twin, max_depth=max_depth)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        h.init()
+        for _ in range(nw // refresh):
+            h.run(refresh)
+        t1 = time.perf_counter()
+        for _ in range(ns // refresh):
+            h.run(refresh)
+        t2 = time.perf_counter()
+        a_mu = h.layout["mu_b"][0]
+        mu = np.transpose(h.write_array(a_mu + S * (T - 1), a_mu + S * T, ns), (1, 0, 2))
+        lpc = np.transpose(h.write_array(0, 1, ns), (1, 0, 2))
+        cols = np.concatenate([lpc, mu, 1.0 / (1.0 + np.exp(-mu))], axis=2)
+        g_ess, g_lf = ess_min(cols), h.total_leapfrogs()
+        st, dv = h.chain_status()
+        run = {"call": label, "posterior": year, "variant": variant, "chains": chains, "iter_warmup": nw, "iter_sampling": ns, "seed": seed, "D": h.D,
+               "gpu": {"seconds": t2 - t0, "sampling_seconds": t2 - t1, "leapfrogs": g_lf, "leapfrogs_per_sec": g_lf / (t2 - t0), "ess_bulk_min": g_ess,
+                       "ess_per_sec": g_ess / (t2 - t1), "divergent_transitions": int(sum(dv)), "cus_per_chain": h.cus_per_chain,
+                       "clusters_per_chain": h.clusters_per_chain, "mean_predicted_score_T": cols[:, :, 1 + S:].mean(axis=(0, 1)).tolist()}}
+        h.close()
+        if cpu:
+            procs = max(1, min(chains, os.cpu_count() or 1))
+            tc0 = time.perf_counter()
+            with mp.get_context("spawn").Pool(procs) as pool:
+                res = sorted(pool.map(_cpu_nuts_worker, [(data, variant, c + 1, nw, ns, seed, 0.0) for c in range(chains)]), key=lambda r: r[0])
+            wall = time.perf_counter() - tc0
+            tm = np.stack([r[1] for r in res])
+            ccols = np.stack([r[2] for r in res])
+            c_ess = ess_min(ccols)
+            c_secs, c_samp = float((tm[:, 0] + tm[:, 1]).max()), float(tm[:, 1].max())
+            run["cpu_port"] = {"seconds": c_secs, "sampling_seconds": c_samp, "wall_seconds_with_process_start": wall, "leapfrogs": int(tm[:, 2:4].sum()),
+                               "leapfrogs_per_sec": float(tm[:, 2:4].sum()) / c_secs, "ess_bulk_min": c_ess, "ess_per_sec": c_ess / c_samp, "cores": procs,
+                               "kind": "port", "mean_predicted_score_T": ccols[:, :, 1 + S:].mean(axis=(0, 1)).tolist(),
+                               "note": "oracle/potus_oracle.c, scan/sparse gradient, pooled-buffer tree, one chain per host process: the same run (seed, chain ids) to completion"}
+            run["gpu_over_cpu"] = {"wall": c_secs / (t2 - t0), "leapfrogs_per_sec": run["gpu"]["leapfrogs_per_sec"] / run["cpu_port"]["leapfrogs_per_sec"],
+                                   "ess_per_sec": run["gpu"]["ess_per_sec"] / run["cpu_port"]["ess_per_sec"],
+                                   "max_abs_diff_of_mean_predicted_score_T": float(np.abs(np.array(run["gpu"]["mean_predicted_score_T"]) - np.array(run["cpu_port"]["mean_predicted_score_T"])).max())}
+        out.append(run)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ workloads
 def load_workloads(cfg, chains_per_gpu, twin_posteriors="", storage=0):
     """[(name, data, variant, chains per GPU, options)] of the posteriors one GPU runs."""
@@ -183,7 +246,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20, help="launch chunks of --chunk transitions: K // 2 warm-up, the rest sampling")
     ap.add_argument("--warmup", type=int, default=2, help="untimed chunks on a throw-away sampler")
-    ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs[] index: 1 (default), 2, 3, 4")
+    ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs[] index: 1 (default), 0, 2, 3, 4")
     ap.add_argument("--chains-per-gpu", type=int, default=0, help="per posterior (0 = the configuration's: 8, 8, 4, 4)")
     ap.add_argument("--cus-per-chain", type=int, default=0, help="workgroups per chain (0 = the library's choice: 16, 10-14, 8, 4 or 1 by what fits)")
     ap.add_argument("--twin", type=int, default=-1, help="two clusters per chain, one per end of the trajectory: 1, 0, or -1 = the library's choice")
@@ -217,6 +280,20 @@ def main():
     twin = 0 if dev_backend == "gloo" else args.twin        # (the ranks of the development mode share one GPU's compute units)
 
     cfg = args.config
+    if cfg == 0:
+        if world != 1:
+            raise SystemExit("--config 0 (the reference's own sampler calls, GPU and CPU port side by side) runs on one GPU")
+        runs = reference_sampler_calls(local, args.seed, args.cus_per_chain, args.twin, args.max_depth, cpu=not args.no_cpu_baseline)
+        r0 = runs[0]
+        print(json.dumps({"metric": "leapfrog_steps_per_sec", "value": r0["gpu"]["leapfrogs_per_sec"], "unit": "leapfrogs/s", "n_gpus": 1, "steps": 20, "warmup": 1,
+                          "ms_per_step": 1e3 * r0["gpu"]["seconds"] / 20, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                          "data": "poll data of the reference (fixtures built from its CSVs, tests/golden/data_*.npz); random inits",
+                          "config": {"workload": "configs[0]: the reference's sampler calls as scripted (final_2016.R:533-541: 6 chains x (500 + 500), seed 1843; final_2012.R, "
+                                                 "final_2008.R likewise; BASELINE's 4 x 500), each run to completion on the MI355X and on the CPU port; value = the 2016 call on the GPU; "
+                                                 "a step = `refresh` = 50 transitions"},
+                          "runs": runs}), flush=True)
+        parallel.barrier()
+        return
     chunk = args.chunk or (1 if cfg == 4 else 100)
     work = load_workloads(cfg, args.chains_per_gpu, "" if dev_backend == "gloo" else args.twin_posteriors, 1 if args.metric_storage == "f32" else 0)
     warm_steps = args.steps // 2 if args.warm_steps < 0 else min(args.warm_steps, args.steps)
@@ -273,12 +350,13 @@ def main():
     # doubles per draw for 2016 = 0.83 GB per rank with 8 chains x 1000 draws.  They are produced on the device
     # (potus_write_array_device), gathered on the device (RCCL all-gather over xGMI) and stay there; only the 1 + S columns
     # R-hat / ESS are taken on (lp__, mu_b[:, T]) come to the host, on rank 0's behalf.  --gather T sends those columns only.
-    pooled, gathered_bytes = [], 0
+    pooled, gathered_bytes, dev_diag = [], 0, []
     for (name, data, variant, C, _), h in zip(work, hs):
         S, T = int(data["S"]), int(data["T"])
         a_mu = h.layout["mu_b"][0]
         if ns == 0:
             pooled.append(None)
+            dev_diag.append(None)
             continue
         ncol = S * T if args.gather == "full" else S
         loc = torch.empty((ns, C, 1 + ncol), dtype=torch.float64, device=dev)
@@ -291,6 +369,15 @@ def main():
         del tmp
         full = parallel.all_gather_chains(loc, coll_dev)                # [ns, world * C, 1 + ncol] on every rank
         gathered_bytes += loc.numel() * 8
+        # what the gather is for: rank-normalised split R-hat and bulk ESS of EVERY gathered column over the pooled chains, on the
+        # device (potus_diagnostics_device, csrc/potus_diag.hpp), inside the timed region
+        td0 = time.perf_counter()
+        if ns >= 8 and full.is_cuda:
+            from us_potus_model_amd import device_diagnostics_of_block
+            rh, es = device_diagnostics_of_block(full.contiguous())
+            dev_diag.append({"rhat": rh, "ess_bulk": es, "seconds": time.perf_counter() - td0, "columns": int(full.shape[2]), "S": S})
+        else:
+            dev_diag.append(None)
         sel = torch.cat([full[:, :, :1], full[:, :, 1 + ncol - S:]], dim=2)   # lp__ and mu_b[:, T]
         pooled.append(sel.contiguous())
         del full, loc
@@ -309,7 +396,7 @@ def main():
     if rank == 0:
         per_post = {}
         ess_all, rhat_all = [], []
-        for (name, data, variant, C, extra), h, pl, (st, dv) in zip(work, hs, pooled, status):
+        for (name, data, variant, C, extra), h, pl, (st, dv), dd in zip(work, hs, pooled, status, dev_diag):
             info = {"chains_per_gpu": C, "D": h.D, "S": int(data["S"]), "T": int(data["T"]),
                     "polls": int(data["N_state_polls"]) + int(data["N_national_polls"]), "cus_per_chain": h.cus_per_chain,
                     "clusters_per_chain": h.clusters_per_chain,
@@ -319,7 +406,20 @@ def main():
                 info["twin"] = {"leapfrogs_counted": cnt, "leaves_run_backward_side": rb, "leaves_run_forward_side": rf,
                                 "leaves_run_per_counted": (rb + rf) / max(cnt, 1),
                                 "note": "each side integrates the doublings of its end, those of speculative subtrees that are dropped included"}
-            if pl is not None and ns >= 8:
+            if dd is not None:
+                # The metric's ESS: min bulk-ESS over lp__, mu_b[:, T], predicted_score[T, :].  predicted_score is a monotone
+                # map of mu_b column for column, so its ranks -- and rank-normalised ESS / R-hat -- are mu_b's: the set is lp__ and the
+                # last S gathered columns (--gather full: the last day of the S x T block; --gather T: all of them).
+                Sd = dd["S"]
+                sel = np.r_[0, np.arange(dd["columns"] - Sd, dd["columns"])]
+                info["ess_bulk_min"] = float(np.nanmin(dd["ess_bulk"][sel]))
+                info["rhat_max"] = float(np.nanmax(dd["rhat"][sel]))
+                info["pooled_draws"] = int(ns * C * world)
+                info["device_diagnostics"] = {"columns": dd["columns"], "seconds": dd["seconds"], "ess_bulk_min_all_columns": float(np.nanmin(dd["ess_bulk"])),
+                                              "ess_bulk_median_all_columns": float(np.nanmedian(dd["ess_bulk"])), "rhat_max_all_columns": float(np.nanmax(dd["rhat"])),
+                                              "note": "potus_diagnostics_device over every gathered column (lp__ + mu_b), pooled chains of all ranks, inside the timed region"}
+                ess_all.append(info["ess_bulk_min"]); rhat_all.append(info["rhat_max"])
+            elif pl is not None and ns >= 8:                                     # development mode (collectives on CPU tensors): the numpy restatement
                 x = np.transpose(pl.cpu().numpy(), (1, 0, 2))                    # [chain, draw, 1 + S]
                 cols = np.concatenate([x, 1.0 / (1.0 + np.exp(-x[:, :, 1:]))], axis=2)   # + predicted_score[T, :]
                 info["ess_bulk_min"] = float(min(dg.ess_bulk(cols[:, :, j]) for j in range(cols.shape[2])))
@@ -358,9 +458,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": ("synthetic polls (us_potus_model_amd.synthetic.stress, seed 20201103)" if cfg == 4 else
                      "poll data of the reference (fixtures built from its CSVs, tests/golden/data_*.npz)") + "; random inits",
-            "config": {"workload": f"{names[cfg]}, adaptive NUTS {'dense_e' if dense else 'diag_e'}, {C_tot} chains per MI355X, "
+            "config": {"workload": f"{names[2 if (cfg == 1 and world > 1) else cfg]}, adaptive NUTS {'dense_e' if dense else 'diag_e'}, {C_tot} chains per MI355X, "
                                    f"{nw} warmup + {ns} sampling, seed {args.seed}; a step = one launch chunk of {chunk} transitions",
                        "step": f"{chunk} NUTS transitions of every chain", "iter_warmup": nw, "iter_sampling": ns,
+                       "baseline_config_index": 2 if (cfg == 1 and world > 1) else cfg,
                        "chains_per_gpu": C_tot, "total_chains": C_tot * world, "posteriors": per_post,
                        "all_gather_bytes_per_rank": gathered_bytes,
                        "parallelism": (f"chains sharded {C_tot}/GPU x {world}, no data-path collective; one RCCL all-gather of the "

@@ -239,6 +239,15 @@ int potus_posterior_summary_many(const int *handles, int n_handles, const double
  * out[3] = EV-weighted Brier score, unweighted Brier score, states called correctly (round(p) == won). */
 int potus_backtest_scores(const double *state_out, int T, int S, int day, const double *ev, const int *won, double *out);
 
+/* Cross-chain diagnostics on the device: rank-normalised split R-hat and bulk ESS (Vehtari et al. 2021; the definitions bench.py's
+ * ESS/s uses) of the columns [col_begin, col_end) of the output row, over the pooled chains of several handles of ONE posterior
+ * (equal numbers of saved draws).  The reference has no counterpart (final_2016.R:543-556 never looks at a diagnostic); the
+ * all-gather of BASELINE.json's north_star exists "to pool draws for R-hat / ESS".  rhat_out, ess_bulk_out: [col_end - col_begin]. */
+int potus_diagnostics(const int *handles, int n_handles, int col_begin, int col_end, double *rhat_out, double *ess_bulk_out);
+/* The same for a block that already sits in DEVICE memory of GPU `device`: block[draw][chain][column] -- the layout
+ * potus_write_array_device produces and an RCCL all-gather of it keeps.  rhat_out, ess_bulk_out: host arrays [n_cols]. */
+int potus_diagnostics_device(int device, const void *block, long long n_draws, int n_chains, int n_cols, double *rhat_out, double *ess_bulk_out);
+
 /* Kernel timing of the most recent potus_run, measured with HIP events on the
  * sampler's own stream: elapsed milliseconds and leapfrogs executed in it. */
 int potus_last_run_timing(int handle, double *ms, long long *leapfrogs);

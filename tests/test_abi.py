@@ -26,6 +26,14 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"libpotus_hmc.so does not export {name}"
     assert b"gfx950" in L.potus_version()
+    # ... and the other way round: every potus_* symbol the library exports is declared, in the boundary header or -- the
+    # development / verification hooks the tests use -- in include/potus_hmc_debug.h
+    import subprocess
+    dbg = set(re.findall(r"\b(potus_[A-Za-z_0-9]+)\s*\(", (ROOT / "include" / "potus_hmc_debug.h").read_text()))
+    assert not (dbg & declared), dbg & declared
+    nm = subprocess.run(["nm", "-D", "--defined-only", str(sampler.lib_path())], check=True, capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.split()[-1].startswith("potus_") and ln.split()[-2] in ("T", "t")}
+    assert exported == declared | dbg, exported ^ (declared | dbg)
 
 
 def test_struct_layout_matches_header():

@@ -371,3 +371,77 @@ def test_rccl_collectives_on_device_buffers_one_rank():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(ROOT),
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert out.returncode == 0 and "rccl ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+# ---------------------------------------------------------------------------------------------------- round 4: diagnostics on the device
+def _device_block(block):
+    """a host array copied to device memory through the HIP runtime (no torch): returns (pointer, free)"""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    p = C.c_void_p()
+    assert hip.hipMalloc(C.byref(p), block.nbytes) == 0
+    assert hip.hipMemcpy(p, block.ctypes.data_as(C.c_void_p), block.nbytes, 1) == 0     # hipMemcpyHostToDevice
+    return p, lambda: hip.hipFree(p)
+
+
+def _numpy_diagnostics(block):
+    """us_potus_model_amd/diagnostics.py (the CPU restatement) column by column: block [draws, chains, columns]"""
+    from us_potus_model_amd import diagnostics as dg
+    x = np.transpose(block, (1, 0, 2))
+    return (np.array([dg.rhat(x[:, :, j]) for j in range(x.shape[2])]), np.array([dg.ess_bulk(x[:, :, j]) for j in range(x.shape[2])]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("draws,chains,ncols", [(301, 4, 37), (1000, 8, 70), (500, 40, 3), (8, 2, 5)])
+def test_device_diagnostics_match_the_numpy_restatement(draws, chains, ncols):
+    """potus_diagnostics_device against diagnostics.py to 1e-10: AR(1) columns of every autocorrelation from -0.6 to 0.98 (Geyer's
+    sequence stops anywhere between lag 2 and a few hundred), chains with different means and scales (R-hat well above 1), a column
+    with runs of tied draws (a sampler that keeps its point; ranks by position), a constant-shift column, an odd number of draws
+    (the middle one is dropped by the split), 40 x 500 = 20 000 pooled draws (more than one LDS sort: order statistics across runs)."""
+    rng = np.random.default_rng(draws + chains)
+    blk = np.zeros((draws, chains, ncols))
+    for j in range(ncols):
+        rho = np.linspace(-0.6, 0.98, ncols)[j]
+        e = rng.standard_normal((draws, chains))
+        x = np.zeros((draws, chains))
+        x[0] = e[0]
+        for t in range(1, draws):
+            x[t] = rho * x[t - 1] + np.sqrt(1 - rho * rho) * e[t]
+        if j % 5 == 1:
+            x = x * (1.0 + 0.5 * np.arange(chains)) + 0.7 * np.arange(chains)            # chains that disagree
+        if j % 5 == 2:
+            x = np.repeat(x[::3], 3, axis=0)[:draws]                                      # every draw three times in a row: ties
+        if j % 5 == 3:
+            x = np.round(x, 1)                                                            # heavy ties across chains too
+        blk[:, :, j] = x
+    L = sampler.load_library()
+    p, free = _device_block(blk)
+    rhat, ess = np.zeros(ncols), np.zeros(ncols)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rc = L.potus_diagnostics_device(0, p, draws, chains, ncols, dp(rhat), dp(ess))
+    free()
+    assert rc == 0
+    r_ref, e_ref = _numpy_diagnostics(blk)
+    assert np.allclose(rhat, r_ref, rtol=1e-10, atol=0, equal_nan=True), np.nanmax(np.abs(rhat / r_ref - 1))
+    assert np.allclose(ess, e_ref, rtol=1e-10, atol=0, equal_nan=True), np.nanmax(np.abs(ess / e_ref - 1))
+
+
+@pytest.mark.gpu
+def test_device_diagnostics_over_the_chains_of_several_handles(cases):
+    """potus_diagnostics pools the chains of the listed handles (chain ids 1-3 and 4-5 of one posterior): lp__ and a block of mu_b
+    columns against diagnostics.py on the same rows fetched with potus_write_array."""
+    from us_potus_model_amd import device_diagnostics
+    data, variant = cases["small_full"]
+    hs = [Handle(data, variant, chains=c, chain_id_offset=off, num_warmup=100, num_samples=60, seed=3, cus_per_chain=k) for c, off, k in ((3, 0, 1), (2, 3, 4))]
+    for h in hs:
+        h.init(); h.run(160)
+    a = hs[0].layout["mu_b"][0]
+    for cb, ce in ((0, 1), (a, a + 40)):
+        rhat, ess = device_diagnostics(hs, cb, ce)
+        blk = np.concatenate([h.write_array(cb, ce, 60) for h in hs], axis=1)            # [draws, chains, columns]
+        r_ref, e_ref = _numpy_diagnostics(blk)
+        assert np.allclose(rhat, r_ref, rtol=1e-10, equal_nan=True) and np.allclose(ess, e_ref, rtol=1e-10, equal_nan=True)
+    for h in hs:
+        h.close()

@@ -9,6 +9,7 @@
 #include "potus_nuts_twin.hpp"
 #include "potus_dense.hpp"
 #include "potus_summary.hpp"
+#include "potus_diag.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -2790,6 +2791,111 @@ int potus_posterior_summary_many(const int *handles, int n_handles, const double
 
 int potus_posterior_summary(int handle, const double *ev, double *state_out, double *natl_out, double *ev_out) {
   return potus_posterior_summary_many(&handle, 1, ev, state_out, natl_out, ev_out);
+}
+
+// ---------------------------------------------------------------------------------------------- diagnostics (potus_diag.hpp)
+namespace {
+// cols [NC][C][n] on the current device -> rhat / bulk ESS per column (host arrays)
+int diagnostics_of_columns(hipStream_t stream, const double *cols, long long n, int C, int NC, double *rhat_out, double *ess_out) {
+  if (2 * C > DG_MAXCH) return fail(POTUS_ERR_UNSUPPORTED, "potus_diagnostics: %d chains pooled (at most %d)", C, DG_MAXCH / 2);
+  const long long N = 2ll * C * (n / 2);
+  DevBufs tmp;
+  double *zbuf = nullptr, *dout = nullptr;
+  unsigned long long *rkey = nullptr;
+  unsigned *ridx = nullptr;
+  const int grid = std::min(NC, 1024);
+  HIP_TRY(tmp.alloc(&zbuf, (size_t)grid * 2 * (size_t)std::max<long long>(N, 1) * 8));
+  if (N > DG_RUN) { HIP_TRY(tmp.alloc(&rkey, (size_t)grid * (size_t)N * 8)); HIP_TRY(tmp.alloc(&ridx, (size_t)grid * (size_t)N * 4)); }
+  HIP_TRY(tmp.alloc(&dout, (size_t)NC * 2 * 8));
+  int npad = 1;
+  while (npad < N && npad < DG_RUN) npad <<= 1;
+  const size_t lds = (size_t)npad * 12;                // keys + split indices
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dg_column), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  DgParams P{cols, zbuf, rkey, ridx, dout, dout + NC, n, C, NC};
+  hipLaunchKernelGGL(k_dg_column, dim3(grid), dim3(DG_THREADS), lds, stream, P);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(rhat_out, dout, (size_t)NC * 8, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(ess_out, dout + NC, (size_t)NC * 8, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  return 0;
+}
+} // namespace
+
+int potus_diagnostics_device(int device, const void *block, long long n_draws, int n_chains, int n_cols, double *rhat_out, double *ess_bulk_out) {
+  if (!block || !rhat_out || !ess_bulk_out || n_draws < 1 || n_chains < 1 || n_cols < 1) return fail(POTUS_ERR_ARG, "potus_diagnostics_device: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(POTUS_ERR_DEVICE, "potus_diagnostics_device: no HIP device %d", device);
+  DeviceGuard guard;
+  DeviceLocks lock(device);
+  HIP_TRY(hipSetDevice(device));
+  DevBufs tmp;
+  double *cols = nullptr;
+  HIP_TRY(tmp.alloc(&cols, (size_t)n_draws * n_chains * n_cols * 8));
+  hipLaunchKernelGGL(k_dg_transpose, dim3((n_cols + 63) / 64, (unsigned)((n_draws + 63) / 64), n_chains), dim3(256), 0, 0, (const double *)block, cols, n_draws, n_chains,
+                     n_cols, n_chains, 0);
+  HIP_TRY(hipGetLastError());
+  return diagnostics_of_columns(0, cols, n_draws, n_chains, n_cols, rhat_out, ess_bulk_out);
+}
+
+int potus_diagnostics(const int *handles, int n_handles, int col_begin, int col_end, double *rhat_out, double *ess_bulk_out) {
+  if (!handles || n_handles < 1 || !rhat_out || !ess_bulk_out) return fail(POTUS_ERR_ARG, "potus_diagnostics: null argument");
+  std::vector<Sampler *> sps;
+  std::vector<int> devs;
+  for (int i = 0; i < n_handles; i++) {
+    Sampler *sp = get(handles[i]);
+    if (!sp) return fail(POTUS_ERR_STATE, "bad handle %d", handles[i]);
+    for (int j = 0; j < i; j++) if (handles[j] == handles[i]) return fail(POTUS_ERR_ARG, "potus_diagnostics: handle %d listed twice", handles[i]);
+    sps.push_back(sp); devs.push_back(sp->device);
+  }
+  Sampler *s0 = sps[0];
+  if (col_begin < 0 || col_end > s0->L.ncols || col_begin >= col_end) return fail(POTUS_ERR_ARG, "potus_diagnostics: columns [%d, %d) of %d", col_begin, col_end, s0->L.ncols);
+  DeviceGuard guard;
+  DeviceLocks lock(devs);
+  int n_saved = -1, Ctot = 0;
+  for (size_t i = 0; i < sps.size(); i++) {
+    Sampler *sp = sps[i];
+    if (i > 0 && (sp->L.ncols != s0->L.ncols || sp->M.full != s0->M.full || sp->data_hash != s0->data_hash))
+      return fail(POTUS_ERR_ARG, "potus_diagnostics: handle %d holds another posterior than handle %d (R-hat / ESS pool the chains of one)", handles[i], handles[0]);
+    HIP_TRY(hipSetDevice(sp->device));
+    int ns = 0, rc = saved_count(sp, &ns);
+    if (rc) return rc;
+    if (n_saved >= 0 && ns != n_saved) return fail(POTUS_ERR_STATE, "potus_diagnostics: handle %d has saved %d draws per chain, handle %d has %d", handles[i], ns, handles[0], n_saved);
+    n_saved = ns; Ctot += sp->R.chains;
+  }
+  if (n_saved < 4) return fail(POTUS_ERR_STATE, "R-hat / ESS need at least four saved draws per chain");
+  const int NC = col_end - col_begin;
+  HIP_TRY(hipSetDevice(s0->device));
+  DevBufs tmp;
+  double *cols = nullptr;
+  HIP_TRY(tmp.alloc(&cols, (size_t)n_saved * Ctot * NC * 8));
+  int coff = 0;
+  for (size_t i = 0; i < sps.size(); i++) {
+    Sampler *sp = sps[i];
+    const int C = sp->R.chains;
+    DevBufs blkbuf;
+    double *blk = nullptr;
+    int rc;
+    HIP_TRY(hipSetDevice(s0->device));
+    HIP_TRY(blkbuf.alloc(&blk, (size_t)n_saved * C * NC * 8));
+    if (sp->device == s0->device) {
+      if ((rc = write_array_range(sp, n_saved, col_begin, col_end, blk, true, NC))) return rc;
+      HIP_TRY(hipStreamSynchronize(sp->stream));
+    } else {
+      HIP_TRY(hipSetDevice(sp->device));
+      DevBufs far;
+      double *fb = nullptr;
+      HIP_TRY(far.alloc(&fb, (size_t)n_saved * C * NC * 8));
+      if ((rc = write_array_range(sp, n_saved, col_begin, col_end, fb, true, NC))) return rc;
+      HIP_TRY(hipStreamSynchronize(sp->stream));
+      HIP_TRY(hipMemcpyPeer(blk, s0->device, fb, sp->device, (size_t)n_saved * C * NC * 8));
+      HIP_TRY(hipSetDevice(s0->device));
+    }
+    hipLaunchKernelGGL(k_dg_transpose, dim3((NC + 63) / 64, (unsigned)((n_saved + 63) / 64), C), dim3(256), 0, s0->stream, (const double *)blk, cols, (long long)n_saved, C, NC, Ctot, coff);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s0->stream));
+    coff += C;
+  }
+  return diagnostics_of_columns(s0->stream, cols, n_saved, Ctot, NC, rhat_out, ess_bulk_out);
 }
 
 // The backtest scores of final_2016.R:925-945 (final_2012.R:918-931, final_2008.R:922-935) from the state summaries:

@@ -76,6 +76,8 @@ def load_library():
     L.potus_posterior_summary_many.argtypes = [ip, C.c_int, dp, dp, dp, dp]
     L.potus_backtest_scores.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp, ip, dp]
     L.potus_write_array_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.potus_diagnostics.argtypes = [ip, C.c_int, C.c_int, C.c_int, dp, dp]
+    L.potus_diagnostics_device.argtypes = [C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_int, dp, dp]
     L.potus_get_dense_metric.argtypes = [C.c_int, C.c_int, dp]
     L.potus_cus_per_chain.argtypes = [C.c_int, ip]
     L.potus_clusters_per_chain.argtypes = [C.c_int, ip]
@@ -92,6 +94,7 @@ EXPORTS = [
     "potus_iterations_done", "potus_total_leapfrogs", "potus_chain_status", "potus_get_adaptation",
     "potus_get_dense_metric", "potus_dense_timing", "potus_dense_adapt_timing", "potus_dense_check", "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_array_device", "potus_write_stan_csv",
     "potus_last_run_timing", "potus_posterior_summary", "potus_posterior_summary_many", "potus_backtest_scores",
+    "potus_diagnostics", "potus_diagnostics_device",
     "potus_R_create", "potus_R_init", "potus_R_run", "potus_R_run_many", "potus_R_num_columns", "potus_R_saved_count",
     "potus_R_write_array", "potus_R_write_stan_csv", "potus_R_posterior_summary", "potus_R_backtest_scores", "potus_R_last_error", "potus_R_destroy",
 ]
@@ -293,6 +296,31 @@ def posterior_summary(handles, ev):
     ids = (C.c_int * len(handles))(*[h.h for h in handles])
     _check(h0.L, h0.L.potus_posterior_summary_many(ids, len(handles), _dp(ev), _dp(st), _dp(na), _dp(eo)))
     return dict(state=np.ascontiguousarray(st.transpose(1, 0, 2)), national=na, electoral_votes=eo)
+
+
+def device_diagnostics(handles, col_begin, col_end):
+    """potus_diagnostics: rank-normalised split R-hat and bulk ESS of columns [col_begin, col_end) of the output row over the pooled
+    chains of the listed handles (one posterior), computed on the first handle's GPU.  Returns (rhat, ess_bulk), each [col_end - col_begin]."""
+    h0 = handles[0]
+    n = int(col_end) - int(col_begin)
+    rhat, ess = np.zeros(n), np.zeros(n)
+    ids = (C.c_int * len(handles))(*[h.h for h in handles])
+    _check(h0.L, h0.L.potus_diagnostics(ids, len(handles), int(col_begin), int(col_end), _dp(rhat), _dp(ess)))
+    return rhat, ess
+
+
+def device_diagnostics_of_block(block):
+    """potus_diagnostics_device on a torch tensor [draws, chains, columns] (float64, contiguous, on a GPU) -- e.g. the result of the
+    all-gather of potus_write_array_device blocks.  Returns (rhat, ess_bulk) as numpy arrays [columns]."""
+    import torch
+    if not (block.is_cuda and block.dtype == torch.float64 and block.is_contiguous() and block.dim() == 3):
+        raise TypeError("device_diagnostics_of_block needs a contiguous float64 [draws, chains, columns] tensor on the GPU")
+    L = load_library()
+    nd, nc, ncol = (int(x) for x in block.shape)
+    rhat, ess = np.zeros(ncol), np.zeros(ncol)
+    torch.cuda.current_stream(block.device).synchronize()
+    _check(L, L.potus_diagnostics_device(int(block.device.index or 0), C.c_void_p(block.data_ptr()), nd, nc, ncol, _dp(rhat), _dp(ess)))
+    return rhat, ess
 
 
 def backtest_scores(summary, ev, won, day=0):
