@@ -88,7 +88,10 @@ typedef struct potus_data {
 } potus_data;
 
 /* Sampler options: the argument surface of cmdstanr's $sample() as used at
- * final_2016.R:533-541 plus the CmdStan 2.24 defaults it implies. */
+ * final_2016.R:533-541 plus the CmdStan 2.24 defaults it implies.
+ * ALWAYS start from potus_default_opts(): fields are appended over time (metric_storage came with library version 0.4 in what used
+ * to be tail padding), and a struct filled field by field by a caller built against an older header leaves them undefined;
+ * potus_version() names the version the header must match. */
 typedef struct potus_opts {
   int32_t chains;          /* chains run by THIS handle                                  */
   int32_t chain_id_offset; /* global id of this handle's first chain minus 1; chain c of
@@ -120,7 +123,10 @@ typedef struct potus_opts {
                               two clusters if they fit.  Same algorithm, RNG streams and arithmetic: the draws are the
                               same bytes as with one cluster of the same size.  With cus_per_chain = 1 the "cluster" is one
                               workgroup: two workgroups per chain (2 * chains <= resident workgroups of the device; what
-                              the library picks for 65-128 chains on 256 compute units). */
+                              the library picks for 65-128 chains on 256 compute units).  Every form with more than one
+                              workgroup per chain needs ALL its workgroups resident together, i.e. the GPU to itself: beside
+                              another process the launch ends with POTUS_ERR_WATCHDOG after ~1-3 s and the handle is dead (ask
+                              for twin = 0, cus_per_chain = 1 on a shared GPU). */
   int32_t metric_storage;  /* dense metric only: POTUS_STORAGE_F64 (Stan's) or POTUS_STORAGE_F32 -- the adapted covariance is
                               rounded to fp32 and THAT matrix is the metric: its Cholesky factor (fp64) draws the momenta, the
                               leapfrog multiplies with it (fp64 accumulation), so the sampler stays exact while the matrix pass
@@ -264,7 +270,10 @@ int potus_dense_adapt_timing(int handle, double *cov_ms, double *chol_ms, double
  * with the Cholesky factor of the inverse metric the leapfrog multiplies with?  For n_probe standard-normal vectors x,
  * M^-1 x by the sampler's own matrix pass against L (L' x) by plain kernels over the factor, and the momentum draw's blocked
  * back substitution L' p = u multiplied back:
- *   out[0] = max ||L L' x - M^-1 x|| / ||M^-1 x||,   out[1] = ||L' p - u|| / ||u||. */
+ *   out[0] = max ||L L' x - M^-1 x|| / ||M^-1 x||,   out[1] = ||L' p - u|| / ||u||.
+ * Only BETWEEN runs of an initialised handle whose last window end succeeded (POTUS_ERR_STATE otherwise): the check uses the
+ * sampler's own scratch vectors (momentum, temporaries) and round descriptors of every chain, which the next potus_run re-arms;
+ * its passes are not part of potus_dense_timing's counts. */
 int potus_dense_check(int handle, int chain, int n_probe, double *out /*[2]*/);
 
 /* ---- .C()-callable wrappers (int* / double* / char** only) ---- */

@@ -27,6 +27,26 @@ def _has_gpu():
         return False
 
 
+def gpu_count():
+    """HIP devices visible (0 without a GPU); asked of the HIP runtime itself, not of torch"""
+    import ctypes
+    import os
+    if not os.path.exists("/dev/kfd"):
+        return 0
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_int(0)
+        return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+def second_device():
+    """the ordinal multi-device tests put their second block of chains on: device 1 where the box has one (the driver's 8-GPU node),
+    else device 0 again (the code path is then exercised with both blocks on one GPU)"""
+    return 1 if gpu_count() >= 2 else 0
+
+
 def pytest_collection_modifyitems(config, items):
     if _has_gpu():
         return

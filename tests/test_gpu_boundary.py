@@ -277,7 +277,9 @@ def test_summaries_beyond_one_lds_sort_and_over_several_handles(cases):
     data, variant = cases["small_full"]
     S, T = int(data["S"]), int(data["T"])
     ns = 3400
-    hs = [Handle(data, variant, chains=c, chain_id_offset=o, num_warmup=100, num_samples=ns, seed=5) for c, o in ((3, 0), (2, 3))]
+    from conftest import second_device
+    hs = [Handle(data, variant, chains=c, chain_id_offset=o, num_warmup=100, num_samples=ns, seed=5, device=dev)
+          for c, o, dev in ((3, 0, 0), (2, 3, second_device()))]                # two GPUs wherever the box has them: the peer copy of the pooled summary
     for h in hs:
         h.init()
     run_many(hs, 100 + ns)
@@ -434,7 +436,9 @@ def test_device_diagnostics_over_the_chains_of_several_handles(cases):
     columns against diagnostics.py on the same rows fetched with potus_write_array."""
     from us_potus_model_amd import device_diagnostics
     data, variant = cases["small_full"]
-    hs = [Handle(data, variant, chains=c, chain_id_offset=off, num_warmup=100, num_samples=60, seed=3, cus_per_chain=k) for c, off, k in ((3, 0, 1), (2, 3, 4))]
+    from conftest import second_device
+    hs = [Handle(data, variant, chains=c, chain_id_offset=off, num_warmup=100, num_samples=60, seed=3, cus_per_chain=k, device=dev)
+          for c, off, k, dev in ((3, 0, 1, 0), (2, 3, 4, second_device()))]
     for h in hs:
         h.init(); h.run(160)
     a = hs[0].layout["mu_b"][0]
@@ -445,3 +449,28 @@ def test_device_diagnostics_over_the_chains_of_several_handles(cases):
         assert np.allclose(rhat, r_ref, rtol=1e-10, equal_nan=True) and np.allclose(ess, e_ref, rtol=1e-10, equal_nan=True)
     for h in hs:
         h.close()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_rccl_on_two_gpus():
+    """bench.py --gpus 2 exactly as the driver launches it -- torch.distributed.run, one rank per GPU, backend "nccl" (= RCCL over
+    xGMI): chains sharded by global chain id, the device-side all-gather of lp__ + mu_b, pooled R-hat / ESS on the device, ONE JSON
+    line labelled configs[2].  Needs two GPUs: skipped on the one-GPU boxes of the build rounds, run by an 8-GPU driver box."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT, gpu_count
+    if gpu_count() < 2:
+        pytest.skip("one GPU on this box: the two-rank RCCL run needs two")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29551", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("POTUS_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29551", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--chunk", "20", "--no-cpu-baseline", "--no-saturated"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(ROOT))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["total_chains"] == 16 and d["config"]["baseline_config_index"] == 2 and "configs[2]" in d["config"]["workload"]
+    post = d["config"]["posteriors"]["2016"]
+    assert post["pooled_draws"] == 16 * 20 and post["device_diagnostics"]["columns"] == 12955 and d["leapfrogs"] > 0

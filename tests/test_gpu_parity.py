@@ -401,11 +401,13 @@ def test_launch_boundaries_do_not_change_the_draws_across_a_window_end(cases, na
 
 def test_sample_over_several_devices_equals_one_device(cases, tmp_path):
     """PotusModel.sample(devices=[...]): the chains are dealt to the devices in blocks and run together; extract(),
-    as_array() and the CSV files are those of a single-device fit (this box has one GPU: both blocks sit on device 0)."""
+    as_array() and the CSV files are those of a single-device fit.  The second block goes to device 1 when the box has two GPUs (the
+    driver's 8-GPU node: potus_run_many across devices, peer copies), else to device 0 again."""
     data, variant = cases["small_full"]
     kw = dict(seed=5, chains=5, iter_warmup=30, iter_sampling=12, refresh=10)
     one = PotusModel(variant).sample(data, **kw)
-    two = PotusModel(variant).sample(data, devices=[0, 0], **kw)
+    from conftest import second_device
+    two = PotusModel(variant).sample(data, devices=[0, second_device()], **kw)       # two GPUs wherever the box has them
     assert two.chains == 5 and len(two._hs) == 2
     for name in ("mu_b", "predicted_score", "lp__", "raw_polling_bias"):
         assert np.array_equal(one.extract(name), two.extract(name)), name

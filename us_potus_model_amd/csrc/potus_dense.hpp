@@ -99,6 +99,7 @@ struct DnParams {
   int *fail;                         // [1] Cholesky met a non-positive pivot
   int f32, pad1;                     // potus_opts.metric_storage = f32: M^-1 is kept rounded to fp32 (see dn_f32_row)
   unsigned long long *act_passes;    // [1] (chain, matrix pass) pairs that really ran: the bytes the passes streamed, whatever the host believed
+  int count_passes;                  // this launch belongs to the timed set (transitions); init_stepsize / verification passes are neither timed nor counted
 };
 
 // fp32 storage of M^-1 (potus_opts.metric_storage): the matrix pass streams half the bytes.  The rounded matrix IS the metric:
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(DN_FIN) void k_dn_symv_finish(const DnParams P, con
   if (lane == 0) dn_part[w] = tot;
   __syncthreads();
   if (threadIdx.x == 0 && job0 == 0) P.partial[(size_t)chain * P.npart + blockIdx.x] = dn_part[0];   // (k4 == 0 is wave 0)
-  if (threadIdx.x == 0 && blockIdx.x == 0 && P.act_passes) atomicAdd(P.act_passes, 1ull);
+  if (threadIdx.x == 0 && blockIdx.x == 0 && P.act_passes && P.count_passes) atomicAdd(P.act_passes, 1ull);
 }
 
 // ---------------------------------------------------------------- elementwise pieces of a round

@@ -1041,6 +1041,7 @@ struct Sampler {
   static constexpr int DN_AHEAD = 4;       // leaf rounds the host keeps queued beyond the one whose activity flags it has seen
   hipEvent_t rv0[DN_AHEAD] = {}, rv1[DN_AHEAD] = {}, rdone[DN_AHEAD] = {};   // per queued round: around its matrix pass, after its flag copy
   double mv_ms = 0;                        // time spent in the matrix passes (k_dn_symv + finish, events), their number and the bytes they loaded
+  int mv_launches_pending = 0;             // matrix passes between the event pair of the last timed dense_matvec (the first pass of a transition: two)
   long long mv_calls = 0, mv_bytes = 0, dn_rounds = 0, dn_pass_bytes[2] = {0, 0};   // bytes per pass at DN_RB / DN_RB_MAX rows per workgroup
   double we_cov_ms = 0, we_chol_ms = 0, we_eps_ms = 0;   // window ends: covariance, factorisation, init_stepsize (host clock around synchronised sections)
   int we_count = 0;
@@ -1763,7 +1764,7 @@ int dense_grad(Sampler *sp) {
   return 0;
 }
 // one pass over the matrices of the active chains; the pass is timed with events resolved at the next sync point
-int dense_matvec(Sampler *sp, int nrhs, int n_active, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+int dense_matvec(Sampler *sp, int nrhs, int n_active, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, bool timed = true) {
   DnActive act;
   act.n = 0;                                              // every chain, or (from the flags of the last sync point) the active ones, compacted
   if (n_active < sp->R.chains && sp->R.chains <= DN_ACT_MAX) {
@@ -1771,6 +1772,8 @@ int dense_matvec(Sampler *sp, int nrhs, int n_active, hipEvent_t e0 = nullptr, h
     n_active = act.n;
   }
   dense_launch_shape(sp->dn, n_active);
+  sp->dn.count_passes = timed ? 1 : 0;     // potus_dense_timing: bytes and milliseconds over the same set of passes
+  sp->mv_launches_pending = timed ? (nrhs == 3 ? 2 : 1) : 0;
   // (the bytes the passes stream are counted on the device, DnParams::act_passes: the host's flags may be a few rounds old)
   HIP_TRY(hipEventRecord(e0 ? e0 : sp->mv0, sp->stream));
   dense_symv_launch(sp->stream, sp->dn, act, nrhs);
@@ -1787,7 +1790,7 @@ int dense_sync(Sampler *sp, int *n_active, bool timed_matvec) {
   if (timed_matvec) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, sp->mv0, sp->mv1));
-    sp->mv_ms += ms; sp->mv_calls += 1;
+    sp->mv_ms += ms; sp->mv_calls += sp->mv_launches_pending;
   }
   *n_active = n;
   return 0;
@@ -1817,11 +1820,11 @@ int dense_init_stepsize(Sampler *sp, unsigned iter) {
     if (attempt > 200) return fail(POTUS_ERR_STATE, "dense init_stepsize did not terminate");
     if ((rc = dense_sample_p(sp, iter, RNG_INIT_EPS))) return rc;
     hipLaunchKernelGGL(k_dn_eps_prekick, dn_grid(sp), dim3(256), 0, sp->stream, sp->dn, (const RunParams *)sp->dR);
-    if ((rc = dense_matvec(sp, 2, n_active))) return rc;
+    if ((rc = dense_matvec(sp, 2, n_active, nullptr, nullptr, false))) return rc;
     hipLaunchKernelGGL(k_dn_eps_mid, dim3(cg), dim3(64), 0, sp->stream, sp->dn, (const RunParams *)sp->dR);
     if ((rc = dense_grad(sp))) return rc;
     hipLaunchKernelGGL(k_dn_kick, dn_grid(sp), dim3(256), 0, sp->stream, sp->dn);
-    if ((rc = dense_matvec(sp, 1, n_active))) return rc;
+    if ((rc = dense_matvec(sp, 1, n_active, nullptr, nullptr, false))) return rc;
     hipLaunchKernelGGL(k_dn_eps_step, dim3(cg), dim3(64), 0, sp->stream, sp->dn, (const RunParams *)sp->dR);
     HIP_TRY(hipGetLastError());
     if ((rc = dense_sync(sp, &n_active, false))) return rc;
@@ -1962,7 +1965,7 @@ int dense_import_init(Sampler *sp) {
 // ======================================================================== C ABI
 extern "C" {
 
-const char *potus_version(void) { return "potus_hmc 0.1 (gfx950)"; }
+const char *potus_version(void) { return "potus_hmc 0.4 (gfx950)"; }   // 0.4: potus_opts.metric_storage (round 3), potus_diagnostics* (round 4)
 
 int potus_last_error(char *buf, int len) {
   if (buf && len > 0) { std::snprintf(buf, (size_t)len, "%s", g_err.c_str()); }
@@ -2541,8 +2544,10 @@ int potus_dense_timing(int handle, double *matvec_ms, long long *passes, long lo
   if (!sp || !sp->dense) return fail(POTUS_ERR_STATE, "bad handle or not a dense-metric sampler");
   if (matvec_ms) *matvec_ms = sp->mv_ms;
   if (passes) *passes = sp->mv_calls;
-  if (bytes) {   // (chain, pass) pairs counted by the passes themselves x the bytes a pass loads per chain
+  if (bytes) {   // (chain, pass) pairs counted by the timed passes themselves x the bytes a pass loads per chain
     unsigned long long np_ = 0;
+    DeviceGuard guard;
+    DeviceLocks lock(sp->device);
     HIP_TRY(hipSetDevice(sp->device));
     HIP_TRY(hipMemcpy(&np_, sp->dn.act_passes, 8, hipMemcpyDeviceToHost));
     *bytes = (long long)np_ * sp->dn_pass_bytes[sp->dn.rb == DN_RB ? 0 : 1];
@@ -2572,9 +2577,17 @@ int potus_dense_check(int handle, int chain, int n_probe, double *out) {
   if (!sp || !out) return fail(POTUS_ERR_STATE, "bad handle or null output");
   if (!sp->dense) return fail(POTUS_ERR_STATE, "the handle runs the diagonal metric");
   if (chain < 0 || chain >= sp->R.chains || n_probe < 1) return fail(POTUS_ERR_ARG, "potus_dense_check: bad chain or probe count");
+  if (!sp->inited) return fail(POTUS_ERR_STATE, "potus_dense_check: call potus_init first (the check runs the sampler's kernels on the chain's state block)");
+  DeviceGuard guard;                                   // the caller's device comes back
   DeviceLocks lock(sp->device);
   HIP_TRY(hipSetDevice(sp->device));
+  {
+    int failed = 0;
+    HIP_TRY(hipMemcpy(&failed, sp->dn.fail, 4, hipMemcpyDeviceToHost));
+    if (failed) return fail(POTUS_ERR_STATE, "potus_dense_check: the last window end did not produce a factor (the adapted covariance was not positive definite)");
+  }
   DnParams &P = sp->dn;
+  P.count_passes = 0;                                  // verification passes are not part of potus_dense_timing's set
   const int D = P.D, chains = P.chains;
   std::vector<DnRound> rds(chains);
   for (int c = 0; c < chains; c++) { std::memset(&rds[c], 0, sizeof(DnRound)); rds[c].active = c == chain; }
