@@ -76,6 +76,11 @@ for chains in chain_counts:
                 for mm in (0, KCL - 1):
                     print(f"  previous leaf's totals, member {mm}: first fetch of 16 words {out[mm][56]/leaves:.0f} cycles, needed a re-fetch in {100*out[mm][57]/leaves:.0f} % of the leaves, "
                           f"{out[mm][58]/leaves:.2f} re-fetch rounds per leaf")
+            if KCL > 1:
+                for mm in (0, 1, KCL // 2, KCL - 1):
+                    print(f"  X1 fetch (phase B, wave 0), member {mm}: first fetch {out[mm][56]/leaves:.0f} cycles, had to wait in {100*out[mm][57]/leaves:.0f} % of the leaves, "
+                          f"{out[mm][58]/leaves:.2f} re-fetch rounds per leaf;  X2 prefix fetch (phase F, wave 0): first fetch {out[mm][59]/leaves:.0f} cycles, waited in "
+                          f"{100*out[mm][60]/leaves:.0f} %, {out[mm][61]/leaves:.2f} re-fetch rounds per leaf")
             passes = leaves + 1e-9
             for k, nm in sub.items():
                 print(f"    [{nm:36s}] {p[k]/passes:10.0f}")
