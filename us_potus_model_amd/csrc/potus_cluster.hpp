@@ -893,7 +893,11 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         vo[u] = (mm < K && lane < S) ? 16u * (unsigned)lane : PT_OOB;
         so[u] = xch_eslot(x, x1tag, mm < K ? mm : 0);
       }
+#ifdef POTUS_PROF
+      xld(x, vo, so, t16, x1tag, prof);             // slots 56-58 (the phase-C consumer of the previous leaf's totals does not use them when CL_X3_IN_B)
+#else
       xld(x, vo, so, t16, x1tag);
+#endif
 #pragma unroll
       for (int u = 0; u < 16; u++) carry_m += t16[u];
     }
@@ -1361,7 +1365,11 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         vo[u] = (mm < m && lane < S) ? 16u * (unsigned)(XP_PRE + lane) : PT_OOB;
         so[u] = xch_rslot(x, mm < m ? mm : 0);
       }
+#ifdef POTUS_PROF
+      xld(x, vo, so, t16, 0u, prof + 3);        // slots 59-61: cycles of the first fetch, leaves that had to wait, re-fetch rounds
+#else
       xld(x, vo, so, t16);
+#endif
 #pragma unroll
       for (int u = 0; u < 16; u++) carry_m += t16[u];
     }
