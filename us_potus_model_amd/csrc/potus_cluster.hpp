@@ -33,8 +33,6 @@
 // Days per wave (DW) is a compile-time parameter of the pass: 4 (members of at most 32 days, e.g. 2016 with
 // K = 16) keeps the per-day register arrays small enough not to spill; 8 covers up to 64 days per member.
 #define CL_MAXDAYS 64                    // LDS sizing: days per member at DW = 8
-#define CL_LPP 4                         // lanes cooperating on one poll's 51-term dot
-#define CL_PPR (PT_THREADS / CL_LPP)     // polls per round of the poll phase
 #define CL_MAXK 32
 #define CL_DW4_MAXAVG 26                 // days per member on average up to which the 4-days-per-wave build of the pass is used
 #define CL_AUX_SC1 16                    // cache-policy bit of the buffer intrinsics: sc1 (agent scope)
@@ -56,6 +54,12 @@
 #endif
 #ifndef CL_X1_IN_A
 #define CL_X1_IN_A 0                     // 1: the suffix totals sent ahead by the previous leaf are fetched in phase A (see there; measured slower)
+#endif
+#ifndef CL_LPP
+#define CL_LPP 1                         // lanes sharing one poll's 51-term dot in phase C (1, 2 or 4)
+#endif
+#ifndef CL_MERGE_CHAIN
+#define CL_MERGE_CHAIN 1                 // the merges of levels 2 .. m of a leaf in one sweep, rho carried in registers (cl_vop_merge_chain)
 #endif
 #ifndef CL_VERDICT_IN_D
 #define CL_VERDICT_IN_D 0                // 1: the previous leaf's totals are fetched in phase C (idle wave) and its verdicts taken in phase D, on the last wave,
@@ -1024,18 +1028,24 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
 #endif
       WPROF_PTB(30);
     }
-    const bool no_polls_here = w == PT_NW - 2 && pend.n >= 0 && np <= 64 * w;   // the verdict wave, when it has no polls: skip the (idle) trip
-    for (int i0 = 0; i0 < (no_polls_here ? 0 : np); i0 += PT_THREADS) {        // one trip unless a member has more than 512 polls
-      const int il = i0 + tid;
-      const bool ok = il < np;
+    // CL_LPP lanes share a poll: each takes a contiguous part of the 51-term dot (the parts are added across the lanes on the DPP
+    // path, every lane of the group ends up with the same sum and runs the binomial term redundantly); the group's first lane owns
+    // the poll's noise element, its log-density term and its residual.  With two lanes per poll the members of the reference's
+    // posteriors (45-148 polls) spread their polls over three to five waves instead of one to three.
+    constexpr int LPP = CL_LPP, PPW = 64 / LPP, PPT = PT_THREADS / LPP;
+    const int sub = tid & (LPP - 1);
+    const bool no_polls_here = w == PT_NW - 2 && pend.n >= 0 && np <= PPW * w;   // the verdict wave, when it has no polls: skip the (idle) trip
+    for (int i0 = 0; i0 < (no_polls_here ? 0 : np); i0 += PPT) {               // one trip unless a member has more than 512 / CL_LPP polls
+      const int il = i0 + tid / LPP;
+      const bool ok = il < np, lead = ok && sub == 0;
       const int ic = ok ? il : np;                       // slot np holds zeros: N = y = 0
-      const unsigned vq = ok ? 8u * (unsigned)(e_noise + il) : PT_OOB;
+      const unsigned vq = lead ? 8u * (unsigned)(e_noise + il) : PT_OOB;
       typename Pol::QT qt;
       typename Pol::GT gt;
       pol.q_load(vq, qt);
       pol.g_load(vq, gt);
       double gval = 0.0, zn = 0.0;
-      if (i0 + 64 * w < np) {                            // waves without polls skip the arithmetic (wave-uniform); no global
+      if (i0 + PPW * w < np) {                           // waves without polls skip the arithmetic (wave-uniform); no global
         const unsigned long long meta = pm[ic];          // memory operation inside the branch
         const int s = (int)(meta & 0xffu), tl = (int)((meta >> 8) & 0xffu), ip = (int)((meta >> 16) & 0xffffu);
         const int im = (int)((meta >> 32) & 0xffu), ipop = (int)((meta >> 40) & 0xffu);
@@ -1044,37 +1054,55 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         const int t = d0 + tl;
         ldp L0 = Lw + s * SP, C0 = C + tl;
         double a0 = 0.0, a1 = 0.0;
-        int k0 = 0;
-        for (; k0 + 16 <= S; k0 += 16) {                 // 51-term dot, sixteen terms in flight
-          double l[16], c[16];
+        if constexpr (LPP == 1) {
+          int k0 = 0;
+          for (; k0 + 16 <= S; k0 += 16) {               // 51-term dot, sixteen terms in flight
+            double l[16], c[16];
 #pragma unroll
-          for (int j = 0; j < 16; j++) { l[j] = L0[k0 + j]; c[j] = C0[(k0 + j) * NDP]; }
-          ISSUE_FENCE();
+            for (int j = 0; j < 16; j++) { l[j] = L0[k0 + j]; c[j] = C0[(k0 + j) * NDP]; }
+            ISSUE_FENCE();
 #pragma unroll
-          for (int j = 0; j < 16; j += 2) { a0 += l[j] * c[j]; a1 += l[j + 1] * c[j + 1]; }
-        }
-        if (k0 < S) {                                    // remainder: clamped reads, masked products
-          double l[16], c[16];
+            for (int j = 0; j < 16; j += 2) { a0 += l[j] * c[j]; a1 += l[j + 1] * c[j + 1]; }
+          }
+          if (k0 < S) {                                  // remainder: clamped reads, masked products
+            double l[16], c[16];
 #pragma unroll
-          for (int j = 0; j < 16; j++) { const int kk = min(k0 + j, S - 1); l[j] = L0[kk]; c[j] = C0[kk * NDP]; }
-          ISSUE_FENCE();
+            for (int j = 0; j < 16; j++) { const int kk = min(k0 + j, S - 1); l[j] = L0[kk]; c[j] = C0[kk * NDP]; }
+            ISSUE_FENCE();
 #pragma unroll
-          for (int j = 0; j < 16; j += 2) {
-            a0 += (k0 + j < S ? l[j] : 0.0) * c[j];
-            a1 += (k0 + j + 1 < S ? l[j + 1] : 0.0) * c[j + 1];
+            for (int j = 0; j < 16; j += 2) {
+              a0 += (k0 + j < S ? l[j] : 0.0) * c[j];
+              a1 += (k0 + j + 1 < S ? l[j + 1] : 0.0) * c[j + 1];
+            }
+          }
+        } else {
+          const int TL = (S + LPP - 1) / LPP, kb = sub * TL;   // this lane's terms: k = kb .. kb + TL - 1 (those below S)
+          for (int j0 = 0; j0 < TL; j0 += 13) {          // thirteen terms in flight (51 states: two batches with two lanes per poll, one with four)
+            double l[13], c[13];
+#pragma unroll
+            for (int j = 0; j < 13; j++) { const int kk = min(kb + j0 + j, S - 1); l[j] = L0[kk]; c[j] = C0[kk * NDP]; }
+            ISSUE_FENCE();
+#pragma unroll
+            for (int j = 0; j < 13; j++) {
+              const double lj = (j0 + j < TL && kb + j0 + j < S) ? l[j] : 0.0;
+              if (j & 1) a1 += lj * c[j]; else a0 += lj * c[j];
+            }
           }
         }
-        const double dot = a0 + a1;
+        double dot = a0 + a1;
+        if constexpr (LPP >= 2) dot += dpp_fetch<0xB1, 0xf>(0.0, dot);    // quad_perm [1, 0, 3, 2]: the neighbour's part
+        if constexpr (LPP == 4) dot += dpp_fetch<0x4E, 0xf>(0.0, dot);    // quad_perm [2, 3, 0, 1]: the other pair's sum
         const double sg = s == S ? sigma_nn : sigma_ns;
         zn = pol.q_fin(qt);
-        double eta = s_bT[s] + sg * zn + sigma_c * s_mid[ip] + dot;   // s_bT: prior (+ the later members' part of the walk, CL_VC)
+        double eta = s_bT[s] + sg * zn + sigma_c * s_mid[ip] + dot;   // s_bT: mu_b_prior (national: its weighted average)
         if (full) eta += sigma_m * s_mid[om + im] + sigma_pop * s_mid[opop + ipop] + un * s_e[t];
         // binomial_logit with one exp, one log1p, one division:  e = exp(-|eta|), l = log1p(e)
         const double ex = exp(-fabs(eta)), l1 = log1p(ex), pr = (eta >= 0.0 ? 1.0 : ex) / (1.0 + ex);
         const double r = y - N * pr;
-        lp += y * (fmin(eta, 0.0) - l1) + (N - y) * (fmin(-eta, 0.0) - l1) - 0.5 * zn * zn; // stan:126-127,130-131 (zn = 0 on idle lanes)
-        r_lds[ok ? il : np + 1] = r;                     // slot np stays 0 (padding of the task lists), np+1 is a dump
-        ru_lds[ok ? il : np + 1] = r * un;               // feeds the day sums of the AR(1) adjoint
+        const double term = y * (fmin(eta, 0.0) - l1) + (N - y) * (fmin(-eta, 0.0) - l1) - 0.5 * zn * zn;   // stan:126-127,130-131 (zn = 0 on idle lanes)
+        lp += (LPP == 1 || sub == 0) ? term : 0.0;      // (the other lanes of a poll's group hold no noise element: their eta, r are not used)
+        r_lds[lead ? il : np + 1] = r;                   // slot np stays 0 (padding of the task lists), np+1 is a dump
+        ru_lds[lead ? il : np + 1] = r * un;             // feeds the day sums of the AR(1) adjoint
         gval = sg * r - zn;
       }
       pol.g_fin(vq, gval, zn, gt);
@@ -1624,6 +1652,83 @@ __device__ __forceinline__ void cl_vop_merge_partial(ClChain &c, unsigned a_beg,
   // the sweep of the next level reads the vector `out` with a different thread-to-element map only through
   // the same element index i -> same thread: no barrier needed between consecutive sweeps
 }
+// The merges of levels 2 .. m that a leaf closes, in ONE sweep over the member's elements: level j joins the pending subtree of
+// level j - 1 (first / last momentum and rho in the pool, ts->pend_*) with the subtree that ends at this leaf, whose rho is the
+// result of level j - 1 -- kept in registers from level to level (the pair's rho of level 1 comes out of the epilogue, slot
+// SCR0 + 1).  Level by level this used to be: load seven vectors, store rho, load it again for the next level -- a store
+// acknowledgement plus a load round trip (~4 k cycles) per level.  Here the operands of up to CL_MG levels are requested together
+// and only the last rho (the new pending subtree's, slot RHOLEV + m) is stored.  Same arithmetic per element and level; the six
+// dot products of a level stay per-wave partial sums in LDS (part[WP(2 + 6 (j - 1) + k, wave)]) for the leaf's single all-reduce.
+#define CL_MG 3                          // levels whose operands are in flight together
+#define CL_MU 2                          // elements per thread and trip
+__device__ __forceinline__ void cl_vop_merge_chain(ClChain &c, ltp ts, int m, int leaf, ldp part) {
+  const unsigned sM = c.soff(V_MINV), s_be = c.soff(V_POOLP + leaf);
+  const int lane = c.tid & 63, w = c.tid >> 6;
+  unsigned s_br = c.soff(V_SCR0 + 1);
+  for (int j0 = 2; j0 <= m; j0 += CL_MG) {
+    const int ng = min(CL_MG, m - j0 + 1);
+    unsigned s_ab[CL_MG], s_ae[CL_MG], s_ar[CL_MG], s_bb[CL_MG];
+#pragma unroll
+    for (int g = 0; g < CL_MG; g++) {
+      const int j = min(j0 + g, m);
+      s_ab[g] = c.soff(V_POOLP + uni_i(ts->pend_beg[j - 1])); s_ae[g] = c.soff(V_POOLP + uni_i(ts->pend_end[j - 1]));
+      s_ar[g] = c.soff(V_RHOLEV + j - 1); s_bb[g] = c.soff(V_POOLP + uni_i(ts->pend_beg[j - 2]));
+    }
+    const int jl = j0 + ng - 1;                                            // last level of the group
+    const unsigned s_out = jl == m ? c.soff(V_RHOLEV + m) : c.soff(V_SCR0 + (jl & 1));
+    double v[CL_MG][6];
+#pragma unroll
+    for (int g = 0; g < CL_MG; g++)
+#pragma unroll
+      for (int k = 0; k < 6; k++) v[g][k] = 0.0;
+    for (int base = cl_first(c); base < c.e1; base += CL_MU * PT_THREADS) {
+      unsigned o[CL_MU];
+      double mi[CL_MU], be[CL_MU], br[CL_MU], ab[CL_MG][CL_MU], ae[CL_MG][CL_MU], ar[CL_MG][CL_MU], bb[CL_MG][CL_MU];
+#pragma unroll
+      for (int u = 0; u < CL_MU; u++) {
+        const int i = base + u * PT_THREADS;
+        o[u] = i < c.e1 ? 8u * i : PT_OOB;                                  // masked elements read zeros and add nothing
+        mi[u] = bld(c.st, o[u], sM); be[u] = bld(c.st, o[u], s_be); br[u] = bld(c.st, o[u], s_br);
+      }
+#pragma unroll
+      for (int g = 0; g < CL_MG; g++)
+        if (g < ng) {                                                        // wave-uniform
+#pragma unroll
+          for (int u = 0; u < CL_MU; u++) { ab[g][u] = bld(c.st, o[u], s_ab[g]); ae[g][u] = bld(c.st, o[u], s_ae[g]); ar[g][u] = bld(c.st, o[u], s_ar[g]); bb[g][u] = bld(c.st, o[u], s_bb[g]); }
+        }
+#pragma unroll
+      for (int g = 0; g < CL_MG; g++)
+        if (g < ng) {
+#pragma unroll
+          for (int u = 0; u < CL_MU; u++) {
+            const double rs = ar[g][u] + br[u];
+            const double sab = mi[u] * ab[g][u], sbe = mi[u] * be[u];
+            v[g][0] += sab * rs;                 // p#_beg . rho_subtree
+            v[g][1] += sbe * rs;                 // p#_end . rho_subtree
+            const double e1 = ar[g][u] + bb[g][u];  // rho_init + p_final_beg
+            v[g][2] += sab * e1;
+            v[g][3] += mi[u] * bb[g][u] * e1;
+            const double e2 = br[u] + ae[g][u];  // rho_final + p_init_end
+            v[g][4] += mi[u] * ae[g][u] * e2;
+            v[g][5] += sbe * e2;
+            br[u] = rs;                          // the merged subtree is the right-hand one of the next level
+          }
+        }
+#pragma unroll
+      for (int u = 0; u < CL_MU; u++) bst(c.st, o[u], s_out, br[u]);
+    }
+#pragma unroll
+    for (int g = 0; g < CL_MG; g++)
+      if (g < ng) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const double t = dpp_scan_sum(v[g][k]);
+          if (lane == 63) part[WP(2 + 6 * (j0 + g - 1) + k, w)] = t;
+        }
+      }
+    s_br = s_out;
+  }
+}
 // PH[e] = p + he*g ; position buffer dst = q + e*minv*PH[e] ; PF[e] = p.  Ends with a cluster barrier:
 // the next pass of every member reads the new position of the small vectors.
 __device__ __forceinline__ void cl_vop_prekick(ClChain &c, unsigned sq, unsigned sp, unsigned sg, unsigned s_ph, unsigned s_dst, unsigned s_pf,
@@ -1948,6 +2053,9 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, co
         if (TWIN && lane == 63) wpart[WP(nv0, w)] = (w == 0 && ts->tw_ext) ? 1.0 : 0.0;
       }
       if (m > 1 || top) { drain_vmem(); __syncthreads(); }   // the leaf's momentum is read back with another thread map
+#if CL_MERGE_CHAIN
+      if (m >= 2) cl_vop_merge_chain(c, ts, m, leaf, wpart);
+#else
       for (int j = 2; j <= m; j++) {
         const int ib = uni_i(ts->pend_beg[j - 1]), ie = uni_i(ts->pend_end[j - 1]), cb = uni_i(ts->pend_beg[j - 2]);
         const unsigned a_rho = c.soff(V_RHOLEV + j - 1);
@@ -1956,6 +2064,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, co
         cl_vop_merge_partial(c, c.soff(V_POOLP + ib), c.soff(V_POOLP + ie), a_rho, c.soff(V_POOLP + cb), c.soff(V_POOLP + leaf), b_rho, out,
                              wpart, 2 + 6 * (j - 1));
       }
+#endif
       if (top) {
         // the checks at the end of transition(): old trajectory (init side) against the new subtree
         const int nb = depth >= 1 ? uni_i(ts->pend_beg[depth - 1]) : leaf;
