@@ -55,6 +55,9 @@
 #ifndef CL_X1_IN_A
 #define CL_X1_IN_A 0                     // 1: the suffix totals sent ahead by the previous leaf are fetched in phase A (see there; measured slower)
 #endif
+#ifndef CL_LDS_BARRIERS
+#define CL_LDS_BARRIERS 0                // 1: the barriers of the pass behind which only LDS is shared wait for LDS only (see PASS_BARRIER); measured neutral (17.37 against 17.43 us), off
+#endif
 #ifndef CL_LPP
 #define CL_LPP 1                         // lanes sharing one poll's 51-term dot in phase C (1, 2 or 4)
 #endif
@@ -689,6 +692,16 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
 // tells it.
 __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// __syncthreads() waits for EVERY outstanding memory operation of the wave before the barrier (s_waitcnt vmcnt(0) lgkmcnt(0)): behind the
+// poll phase that is the acknowledgement of the noise elements' epilogue stores, in phase F that of the write-through exchange
+// words and of the slot epilogue -- 1.5-2 k cycles each, for barriers behind which the waves share nothing but LDS (every global
+// element is read by the thread that wrote it, or after the drain in front of the U-turn sweeps / of the leaf's report,
+// cl_wide_publish).  Those barriers wait for LDS only; stores and loads stay in flight across them.
+#if CL_LDS_BARRIERS
+#define PASS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define PASS_BARRIER() __syncthreads()
+#endif
 // ---------------------------------------------------------------- one pass of the member's share
 // Returns the chain's lp in every thread of every member; pol.extra[] are summed alongside.
 // cl_pass_partial returns THIS THREAD's share of lp (and leaves the thread's share of pol.extra[] in
@@ -930,7 +943,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   }
   WPROF_ACC(0);
 #if !CL_VC
-  __syncthreads();
+  PASS_BARRIER();
   PROF_MARK(1);
   TSTAMP(2);
   {
@@ -1108,7 +1121,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       pol.g_fin(vq, gval, zn, gt);
     }
   }
-  __syncthreads();
+  PASS_BARRIER();
   PROF_MARK(3);
   TSTAMP(4);
   // The verdicts ended the trajectory: every member leaves here together.  What this pass has stored so far (the
@@ -1468,7 +1481,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     voz[j] = (lane < S && j < wnd) ? 8u * (unsigned)(e0 + lane + S * (wd0 + j)) : PT_OOB;
     pol.g_load(voz[j], gz[j]);
   }
-  __syncthreads();
+  PASS_BARRIER();
   PROF_SUB(53);
   {
     const double carry = lane < S ? X[PT_NW * SE + lane] : 0.0;   // pre[] is already the prefix within the member
@@ -1482,7 +1495,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     PROF_SUB(54);
     if (pubnext) {                                  // wave-uniform; LDS and a barrier only, the store stays outside
       if (lane < S) Y[w * SE + lane] = nrun;
-      __syncthreads();
+      PASS_BARRIER();
     }
     PROF_SUB(55);
   }
