@@ -244,8 +244,8 @@ def load_workloads(cfg, chains_per_gpu, twin_posteriors="", storage=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20, help="launch chunks of --chunk transitions: K // 2 warm-up, the rest sampling")
-    ap.add_argument("--warmup", type=int, default=2, help="untimed chunks on a throw-away sampler")
+    ap.add_argument("--steps", type=int, default=None, help="launch chunks of --chunk transitions: K // 2 warm-up, the rest sampling (default 20; --config 4: 5)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed chunks on a throw-away sampler (default 2; --config 4: 0)")
     ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs[] index: 1 (default), 0, 2, 3, 4")
     ap.add_argument("--chains-per-gpu", type=int, default=0, help="per posterior (0 = the configuration's: 8, 8, 4, 4)")
     ap.add_argument("--cus-per-chain", type=int, default=0, help="workgroups per chain (0 = the library's choice: 16, 10-14, 8, 4 or 1 by what fits)")
@@ -254,7 +254,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="transitions per step (0 = the configuration's: 100; 1 for --config 4)")
     ap.add_argument("--warm-steps", type=int, default=-1, help="how many of the --steps are warm-up (-1 = half of them)")
     ap.add_argument("--metric-storage", default="f64", choices=["f64", "f32"], help="--config 4: storage of the dense inverse metric")
-    ap.add_argument("--max-depth", type=int, default=10)
+    ap.add_argument("--max-depth", type=int, default=None, help="default 10 (CmdStan's); --config 4: 7, stated in the line")
     ap.add_argument("--gather", default="full", choices=["full", "T"], help="what the all-gather pools: lp__ + all of mu_b (SURVEY 8e) or lp__ + mu_b[:, T] only")
     ap.add_argument("--seed", type=int, default=1843)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -280,6 +280,19 @@ def main():
     twin = 0 if dev_backend == "gloo" else args.twin        # (the ranks of the development mode share one GPU's compute units)
 
     cfg = args.config
+    # --config 4 without further flags is a preset the driver can run in a few minutes: 16 chains of the stress shape on the GPU, dense
+    # metric, 20 warm-up iterations (init buffer 3, one window of 15 draws whose end -- covariance, 16 Cholesky factorisations of 13.85 GB
+    # matrices, init_stepsize -- falls into step 4 of 5) + 5 sampling iterations, trees cut at depth 7 (127 leapfrogs; CmdStan's 10
+    # would make the early warm-up iterations ten times longer), chunks of 5 transitions
+    preset4 = cfg == 4 and args.steps is None and args.chunk == 0
+    if args.steps is None:
+        args.steps = 5 if cfg == 4 else 20
+    if args.warmup is None:
+        args.warmup = 0 if cfg == 4 else 2
+    if args.max_depth is None:
+        args.max_depth = 7 if cfg == 4 else 10
+    if preset4:
+        args.chunk, args.warm_steps = 5, 4
     if cfg == 0:
         if world != 1:
             raise SystemExit("--config 0 (the reference's own sampler calls, GPU and CPU port side by side) runs on one GPU")
@@ -460,7 +473,7 @@ def main():
                      "poll data of the reference (fixtures built from its CSVs, tests/golden/data_*.npz)") + "; random inits",
             "config": {"workload": f"{names[2 if (cfg == 1 and world > 1) else cfg]}, adaptive NUTS {'dense_e' if dense else 'diag_e'}, {C_tot} chains per MI355X, "
                                    f"{nw} warmup + {ns} sampling, seed {args.seed}; a step = one launch chunk of {chunk} transitions",
-                       "step": f"{chunk} NUTS transitions of every chain", "iter_warmup": nw, "iter_sampling": ns,
+                       "step": f"{chunk} NUTS transitions of every chain", "iter_warmup": nw, "iter_sampling": ns, "max_depth": args.max_depth,
                        "baseline_config_index": 2 if (cfg == 1 and world > 1) else cfg,
                        "chains_per_gpu": C_tot, "total_chains": C_tot * world, "posteriors": per_post,
                        "all_gather_bytes_per_rank": gathered_bytes,
@@ -529,6 +542,19 @@ def main():
                                      "note": "short warm-up run of 256 chains on the same posterior; kernel time of the launches"}
             except Exception as e:                     # never let the side measurement spoil the bench line
                 line["saturated"] = {"error": str(e)[:200]}
+        if not args.no_cpu_baseline and world == 1 and cfg == 4:
+            # the CPU port under a dense metric: what it can afford of this shape -- a few leapfrogs of ONE chain, the D x D product
+            # spread over the box's cores (oracle_time_leapfrogs_dense); every chain would take the same, one after the other
+            from oracle_lib import OracleModel
+            _, data, variant, C, _ = work[0]
+            om = OracleModel(data, variant)
+            nlf = 6
+            secs, nthreads, mbytes = om.time_leapfrogs_dense(nlf)
+            line["cpu_baseline"] = {"value": nlf / secs, "unit": "leapfrogs/s", "cores": nthreads, "kind": "port",
+                                    "sample": f"{nlf} leapfrogs of one chain of the same posterior (D = {hs[0].D}) under a dense {mbytes / 1e9:.2f} GB inverse metric, the rows of the "
+                                              f"matrix-vector product over {nthreads} OpenMP threads (oracle/potus_oracle.c: dense_e_metric::dtau_dp + the scan/sparse gradient): {secs:.1f} s",
+                                    "seconds": secs, "matrix_GBps": nlf * mbytes / secs / 1e9}
+            line["speedup_vs_cpu_port"] = line["value"] / line["cpu_baseline"]["value"]
         if not args.no_cpu_baseline and world == 1 and cfg in (1, 2):   # the CPU port is timed beside the single-GPU run only
             _, data, variant, C, _ = work[0]
             short = (150, 100)

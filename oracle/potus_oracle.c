@@ -13,6 +13,9 @@
 #include "potus_oracle.h"
 
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1216,6 +1219,48 @@ int oracle_transitions_from(const oracle_model *m, const oracle_opts *o, int cha
   }
   ps_free(&sp.z); free(sp.minv); free(sp.tmpv);
   return 0;
+}
+
+/* bench.py's cpu_baseline for the dense metric (BASELINE configs[4]): n leapfrogs of one chain under a dense D x D inverse metric
+ * (the unit matrix plus a small symmetric perturbation, so that nothing about it can be skipped), the matrix-vector product with its
+ * rows over the OpenMP threads of the box.  Returns the seconds of the n leapfrogs; *threads = OpenMP threads used, *matrix_bytes = 8 D^2. */
+double oracle_time_leapfrogs_dense(const oracle_model *m, int n, double eps, uint64_t seed, int *threads, long long *matrix_bytes) {
+  const int D = m->D;
+  oracle_opts o; oracle_default_opts(&o); o.seed = seed; o.dense_metric = 1;
+  sampler sp; memset(&sp, 0, sizeof(sp));
+  sp.m = m; sp.o = &o; sp.D = D; sp.chain = 1; sp.iter = 0; sp.dense = 1;
+  sp.lpg = oracle_log_prob_grad_fast;
+  sp.minv = vec(D); sp.tmpv = vec(D);
+  sp.Minv = (double *)xmalloc(sizeof(double) * (size_t)D * D);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < D; i++) {
+    double *row = sp.Minv + (size_t)i * D;
+    for (int j = 0; j < D; j++) row[j] = i == j ? 1.0 : 1e-9 / (1.0 + (double)(i > j ? i - j : j - i));
+  }
+  for (int i = 0; i < D; i++) sp.minv[i] = 1.0;
+  sp.z = ps_alloc(D);
+  for (int i = 0; i < D; i++) sp.z.q[i] = 0.1 * (2.0 * oracle_rng_uniform(seed, 1, 0, RNG_INITS, 0, (uint32_t)i) - 1.0);
+  for (int j = 0; 2 * j < D; j++) {
+    double a, b; oracle_rng_normal_pair(seed, 1, 0, RNG_MOMENTUM, 0, (uint32_t)j, &a, &b);
+    sp.z.p[2 * j] = a; if (2 * j + 1 < D) sp.z.p[2 * j + 1] = b;
+  }
+  update_potential_gradient(&sp, &sp.z);
+  struct timespec a, b; clock_gettime(CLOCK_MONOTONIC, &a);
+  for (int i = 0; i < n; i++) evolve(&sp, &sp.z, eps);
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  volatile double sink = sp.z.V; (void)sink;
+  int nt = 1;
+#ifdef _OPENMP
+#pragma omp parallel
+  {
+#pragma omp single
+    nt = omp_get_num_threads();
+  }
+#endif
+  if (threads) *threads = nt;
+  if (matrix_bytes) *matrix_bytes = (long long)sizeof(double) * D * D;
+  ps_free(&sp.z); free(sp.minv); free(sp.tmpv); free(sp.Minv);
+  return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
 }
 
 /* base_hmc::init_stepsize from a given state (tests of the device samplers' window ends): the heuristic as adapt_diag_e_nuts /

@@ -93,6 +93,10 @@ int oracle_sample_chain_timed(const oracle_model *m, const oracle_opts *o, int c
 int oracle_transitions_from(const oracle_model *m, const oracle_opts *o, int chain_id, int iter0, int n, const double *qs,
                             const double *eps, const double *Minv, const double *Lc, double *rows);
 
+/* the same under a dense D x D inverse metric (BASELINE configs[4]); the product's rows run on the OpenMP threads of the box:
+ * *threads = how many, *matrix_bytes = 8 D^2 */
+double oracle_time_leapfrogs_dense(const oracle_model *m, int n, double eps, uint64_t seed, int *threads, long long *matrix_bytes);
+
 /* base_hmc::init_stepsize at point q from step size eps0 under the given metric (Minv / Lc as for oracle_transitions_from), with the
  * momentum draws of RNG iteration iter: what the adaptive samplers run after every metric update.  Returns the step size. */
 double oracle_init_stepsize_from(const oracle_model *m, const oracle_opts *o, int chain_id, uint32_t iter, const double *q, double eps0,

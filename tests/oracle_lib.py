@@ -53,6 +53,8 @@ def lib():
         L.oracle_transitions_from.argtypes = [C.c_void_p, C.POINTER(OracleOpts), C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp]
         L.oracle_init_stepsize_from.restype = C.c_double
         L.oracle_init_stepsize_from.argtypes = [C.c_void_p, C.POINTER(OracleOpts), C.c_int, C.c_uint32, dp, C.c_double, dp, dp]
+        L.oracle_time_leapfrogs_dense.restype = C.c_double
+        L.oracle_time_leapfrogs_dense.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
         L.oracle_philox.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.oracle_rng_uniform.restype = C.c_double
         L.oracle_rng_uniform.argtypes = [C.c_uint64] + [C.c_uint32] * 5
@@ -166,6 +168,12 @@ class OracleModel:
         minv = np.ascontiguousarray(minv, dtype=np.float64)
         cp = _dp(np.ascontiguousarray(chol, dtype=np.float64)) if chol is not None else None
         return self.L.oracle_init_stepsize_from(self.h, C.byref(opts), chain_id, int(iteration) & 0xFFFFFFFF, _dp(q), float(eps0), _dp(minv), cp)
+
+    def time_leapfrogs_dense(self, n, eps=0.01, seed=1):
+        """(seconds, OpenMP threads, bytes of the matrix) of n leapfrogs of one chain under a dense D x D inverse metric."""
+        nt, nb = C.c_int(0), C.c_longlong(0)
+        secs = self.L.oracle_time_leapfrogs_dense(self.h, int(n), float(eps), int(seed), C.byref(nt), C.byref(nb))
+        return secs, nt.value, nb.value
 
     def time_leapfrogs(self, n, eps=0.01, fast=False, seed=1):
         return self.L.oracle_time_leapfrogs(self.h, n, eps, int(fast), seed)

@@ -55,6 +55,10 @@
 #ifndef CL_X1_IN_A
 #define CL_X1_IN_A 0                     // 1: the suffix totals sent ahead by the previous leaf are fetched in phase A (see there; measured slower)
 #endif
+#ifndef CL_FAST_BINOMIAL
+#define CL_FAST_BINOMIAL 0               // 1: the binomial term's exp / log1p / division by d_exp_neg / d_log1p_recip (potus_model.hpp) instead of the library's: same
+                                         //    accuracy, a third of the instructions -- and no faster (14.04 against 14.08 us, 17.9 against 17.5 with one cluster): off
+#endif
 #ifndef CL_LDS_BARRIERS
 #define CL_LDS_BARRIERS 0                // 1: the barriers of the pass behind which only LDS is shared wait for LDS only (see PASS_BARRIER); measured neutral (17.37 against 17.43 us), off
 #endif
@@ -1110,7 +1114,16 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         double eta = s_bT[s] + sg * zn + sigma_c * s_mid[ip] + dot;   // s_bT: mu_b_prior (national: its weighted average)
         if (full) eta += sigma_m * s_mid[om + im] + sigma_pop * s_mid[opop + ipop] + un * s_e[t];
         // binomial_logit with one exp, one log1p, one division:  e = exp(-|eta|), l = log1p(e)
+#if CL_FAST_BINOMIAL
+        const double ex = d_exp_neg(fabs(eta));         // (potus_model.hpp: the same three quantities, written for latency)
+        double l1, inv1;
+        d_log1p_recip(ex, l1, inv1);
+        const double num = eta >= 0.0 ? 1.0 : ex;
+        double pr = num * inv1;
+        pr = __builtin_fma(__builtin_fma(-(1.0 + ex), pr, num), inv1, pr);   // residual-corrected division
+#else
         const double ex = exp(-fabs(eta)), l1 = log1p(ex), pr = (eta >= 0.0 ? 1.0 : ex) / (1.0 + ex);
+#endif
         const double r = y - N * pr;
         const double term = y * (fmin(eta, 0.0) - l1) + (N - y) * (fmin(-eta, 0.0) - l1) - 0.5 * zn * zn;   // stan:126-127,130-131 (zn = 0 on idle lanes)
         lp += (LPP == 1 || sub == 0) ? term : 0.0;      // (the other lanes of a poll's group hold no noise element: their eta, r are not used)

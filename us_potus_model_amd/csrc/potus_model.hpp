@@ -142,6 +142,52 @@ enum { SC_MUE = 0, SC_RHO, SC_SRHO, SC_XMUE, SC_XRHO, SC_LPRHO, SC_DSRHO, SC_N }
 #define PROF_SUB(k) do { } while (0)
 #endif
 
+// exp(-a) for a >= 0, and log1p(e) together with 1 / (1 + e) for 0 <= e <= 1: what binomial_logit needs per poll (stan:130-131), written
+// for LATENCY.  The library versions are ~200 instructions of which most depend on the one before (Horner polynomials, frexp / ldexp,
+// div_scale / div_fixup, special cases that cannot occur here); with one poll per lane and one or two waves per SIMD that chain is
+// long; whether the poll phase of the cluster pass waits for it was the question (it does not: profiles/r04_cl_fold.txt).  Here: argument
+// reduction by rounding, polynomials in Estrin form (independent halves), one reciprocal seed + two Newton steps shared by the
+// division of the logistic and the one inside the logarithm.  Accuracy (CPU prototype against glibc over 2 x 10^7 arguments,
+// scripts/micro/fast_binomial_check.c): exp within 1.0, log1p within 2.0 units of 2^-52 relative -- the library's class.
+__device__ __forceinline__ double d_recip_nr(double d) {   // 1 / d for a normal d of moderate size: v_rcp_f64 + two Newton steps (as the compiler's own division)
+  double y = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, y, 1.0); y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-d, y, 1.0); y = __builtin_fma(y, e, y);
+  return y;
+}
+__device__ __forceinline__ double d_exp_neg(double a) {
+  const double x = -fmin(a, 745.2);                                    // (below exp(-745.2) the double is zero anyway)
+  const double n = __builtin_rint(x * 1.4426950408889634074);
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);         // ln 2 in two pieces
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);                // |r| <= ln 2 / 2
+  const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+  // exp(r) = 1 + r + r^2 q(r), q = sum_{k = 2}^{13} r^(k - 2) / k!  (the next term is below 2^-57)
+  const double q01 = __builtin_fma(1.0 / 6, r, 1.0 / 2), q23 = __builtin_fma(1.0 / 120, r, 1.0 / 24), q45 = __builtin_fma(1.0 / 5040, r, 1.0 / 720);
+  const double q67 = __builtin_fma(1.0 / 362880, r, 1.0 / 40320), q89 = __builtin_fma(1.0 / 39916800, r, 1.0 / 3628800);
+  const double qab = __builtin_fma(1.0 / 6227020800.0, r, 1.0 / 479001600);
+  const double q03 = __builtin_fma(q23, r2, q01), q47 = __builtin_fma(q67, r2, q45), q8b = __builtin_fma(qab, r2, q89);
+  const double q = __builtin_fma(q8b, r8, __builtin_fma(q47, r4, q03));
+  return ldexp(1.0 + __builtin_fma(r2, q, r), (int)n);
+}
+__device__ __forceinline__ void d_log1p_recip(double e, double &l1, double &inv) {   // l1 = log1p(e), inv = 1 / (1 + e);  0 <= e <= 1
+  const double u = 1.0 + e, c = e - (u - 1.0);                         // c: what the sum lost
+  const double yu = d_recip_nr(u);
+  inv = yu;
+  const bool k = u > 1.4142135623730951;                               // log u = k ln 2 + log u',  u' = u / 2^k in (0.707, 1.414]
+  const double up = k ? 0.5 * u : u;
+  const double f = up - 1.0, d = 2.0 + f;
+  const double yd = d_recip_nr(d);
+  double s = f * yd;
+  s = __builtin_fma(__builtin_fma(-d, s, f), yd, s);                   // s = f / (2 + f), residual corrected
+  const double z = s * s, z2 = z * z, z4 = z2 * z2;
+  // log u' = 2 atanh(s) = 2 s + s z Q(z),  Q = sum_{i >= 1} 2 z^(i - 1) / (2 i + 1), twelve terms (z <= 0.0295)
+  const double t01 = __builtin_fma(2.0 / 5, z, 2.0 / 3), t23 = __builtin_fma(2.0 / 9, z, 2.0 / 7), t45 = __builtin_fma(2.0 / 13, z, 2.0 / 11);
+  const double t67 = __builtin_fma(2.0 / 17, z, 2.0 / 15), t89 = __builtin_fma(2.0 / 21, z, 2.0 / 19), tab = __builtin_fma(2.0 / 25, z, 2.0 / 23);
+  const double t03 = __builtin_fma(t23, z2, t01), t47 = __builtin_fma(t67, z2, t45), t8b = __builtin_fma(tab, z2, t89);
+  const double Q = __builtin_fma(t8b, z4 * z4, __builtin_fma(t47, z4, t03));
+  const double lo = __builtin_fma(s * z, Q, c * yu) + (k ? 1.90821492927058770002e-10 : 0.0);
+  l1 = (k ? 6.93147180369123816490e-01 : 0.0) + (2.0 * s + lo);
+}
 __device__ __forceinline__ double d_log_inv_logit(double x) { return x > 0 ? -log1p(exp(-x)) : x - log1p(exp(x)); }
 __device__ __forceinline__ double d_inv_logit(double x) {
   if (x >= 0) return 1.0 / (1.0 + exp(-x));
