@@ -451,8 +451,9 @@ def main():
         tr = measured_traffic(kernel, sides)
         traffic = tr[1]["hbm_bytes_per_leapfrog"] * sum(lf_local) / (kernel_ms * 1e-3) / 1e9 if tr else None
         traffic_note = (f"NOT measured in this run: {tr[1]['hbm_bytes_per_leapfrog']:.0f} HBM bytes per leapfrog from the committed "
-                        f"rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE, profiles/{tr[0]}; WRITE_SIZE "
-                        f"calibrated at 1.000 counted bytes per stored byte, profiles/r03_write_size_calibration.txt) x this run's leapfrogs / launch time" if tr else "no PMC pass committed for this kernel")
+                        f"rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE, profiles/{tr[0]}; FETCH_SIZE calibrated at 0.500 counted "
+                        f"bytes per streamed byte for the sampler's 8- and 16-byte plain and sc1 loads, profiles/r04_fetch_size_calibration.txt; WRITE_SIZE "
+                        f"at 1.000, profiles/r03_write_size_calibration.txt) x this run's leapfrogs / launch time" if tr else "no PMC pass committed for this kernel")
         if dense:   # the matrix pass: HBM reads measured / bytes loaded by construction, from the committed counter pass of the dense sampler
             for f in sorted((ROOT / "profiles").glob("*dense_pmc_fetch.json")):
                 try:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """WRITE_SIZE per kernel of scripts/micro/write_calib.hip against the bytes each kernel stored:
     rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/wcal -o r -- scripts/micro/write_calib > gpurun_out/wcal/bytes.txt
-    python scripts/micro/write_calib.py gpurun_out/wcal > profiles/r03_write_size_calibration.txt"""
+    python scripts/micro/pmc_calib.py gpurun_out/wcal WRITE_SIZE"""
 import sqlite3
 import sys
 from pathlib import Path

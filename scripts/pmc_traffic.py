@@ -50,5 +50,5 @@ print(json.dumps({
     "launch_ms_fetch_pass": f["ms"], "launch_ms_write_pass": w["ms"],
     "leapfrogs_fetch_pass": f["leapfrogs"], "leapfrogs_write_pass": w["leapfrogs"],
     "fetch_bytes_per_leapfrog": fb, "write_bytes_per_leapfrog": wb, "hbm_bytes_per_leapfrog": fb + wb,
-    "note": "FETCH_SIZE doubled per the guide (gfx950 tallies 128-byte requests at 64 bytes); WRITE_SIZE taken as KiB (calibrated at 1.000 counted bytes per stored byte: profiles/r03_write_size_calibration.txt); "
+    "note": "FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 bytes; calibrated for the sampler's load forms at 0.500 counted bytes per streamed byte: profiles/r04_fetch_size_calibration.txt); WRITE_SIZE taken as KiB (1.000 counted bytes per stored byte: profiles/r03_write_size_calibration.txt); "
             "leapfrogs of the untimed warm-up launch estimated from launch time"}, indent=1))
