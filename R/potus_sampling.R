@@ -157,6 +157,17 @@ potus_summary <- function(fit, ev) {
        state_raw = r$state)
 }
 
+# Rank-normalised split R-hat and bulk ESS (Vehtari et al. 2021) of the columns `pars` names, over every chain of the fit, computed on
+# the device (the reference never inspects a diagnostic, final_2016.R:543-556; rstan::monitor would need the draws in R).
+# Returns data.frame(column, rhat, ess_bulk); columns are 0-based positions in the CmdStan row, as in potus_extract.
+potus_diagnostics <- function(fit, col_begin, col_end) {
+  n <- col_end - col_begin
+  r <- .C("potus_R_diagnostics", as.integer(fit$handles), length(fit$handles), as.integer(c(col_begin, col_end)), rhat = double(n), ess = double(n),
+          status = integer(1))
+  .potus_check(r$status)
+  data.frame(column = seq(col_begin, col_end - 1L), rhat = r$rhat, ess_bulk = r$ess)
+}
+
 # Backtest scores of final_2016.R:925-945: EV-weighted Brier, unweighted Brier, states called correctly on `day`
 # (1-based; 0 = the last day).  won: 1 where the Democrat carried the state, in state order.
 potus_backtest_scores <- function(fit, summary, ev, won, day = 0L) {

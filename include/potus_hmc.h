@@ -300,6 +300,7 @@ void potus_R_write_array(int *handle, int *col_begin, int *col_end, double *out,
 void potus_R_write_stan_csv(int *handle, char **dir, char **basename, int *status);
 void potus_R_saved_count(int *handle, int *n_saved, int *status);
 void potus_R_posterior_summary(int *handles, int *n_handles, double *ev, double *state_out, double *natl_out, double *ev_out, int *status);
+void potus_R_diagnostics(int *handles, int *n_handles, int *cols /*[2]: col_begin, col_end*/, double *rhat_out, double *ess_bulk_out, int *status);
 void potus_R_backtest_scores(double *state_out, int *dims /*[3]: T, S, day*/, double *ev, int *won, double *out /*[3]*/, int *status);
 void potus_R_last_error(char **buf, int *len);
 void potus_R_destroy(int *handle, int *status);

@@ -120,6 +120,13 @@ class RShim:
         self.check(st)
         return dict(state_raw=st_, state=st_.reshape(S, T, 4).transpose(1, 0, 2), national=na.reshape(T, 4), electoral_votes=eo.reshape(T, 5))
 
+    def diagnostics(self, fit, begin, end):
+        rh, es, st = np.zeros(end - begin), np.zeros(end - begin), C.c_int(-1)
+        self.call("potus_R_diagnostics", _ints(fit["handles"])[1], C.byref(C.c_int(len(fit["handles"]))), _ints([begin, end])[1], rh.ctypes.data_as(DP),
+                  es.ctypes.data_as(DP), C.byref(st))
+        self.check(st)
+        return rh, es
+
     def scores(self, fit, summ, ev, won, day=0):
         out, st = np.zeros(3), C.c_int(-1)
         self.call("potus_R_backtest_scores", summ["state_raw"].ctypes.data_as(DP), _ints([fit["data"]["T"], fit["data"]["S"], day])[1],
@@ -144,7 +151,7 @@ class RShim:
 @pytest.mark.parametrize("name", ["small_full", "small_nomode"])
 def test_r_entry_points_replay_the_shim(cases, name, tmp_path):
     """potus_R_create -> _init -> _run_many (chunks of `refresh`) -> _num_columns / _saved_count -> _write_array ->
-    _posterior_summary -> _backtest_scores -> _write_stan_csv -> _destroy, with `gpus = c(0, 0)` (two handles),
+    _posterior_summary -> _diagnostics -> _backtest_scores -> _write_stan_csv -> _destroy, with `gpus = c(0, 0)` (two handles),
     a seed beyond 32 bits and cus_per_chain = 8: the same bytes as the struct ABI, and potus_R_run on its own."""
     data, variant = cases[name]
     seed = 2 ** 40 + 1843
@@ -163,6 +170,10 @@ def test_r_entry_points_replay_the_shim(cases, name, tmp_path):
     sm, sm_ref = r.summary(fit, ev), ref.summary(ev)
     for k in ("state", "national", "electoral_votes"):
         assert np.array_equal(sm[k], sm_ref[k]), k
+    from us_potus_model_amd import device_diagnostics
+    rh, es = r.diagnostics(fit, a, a + 30)
+    rh_ref, es_ref = device_diagnostics(ref._hs, a, a + 30)
+    assert np.array_equal(rh, rh_ref) and np.array_equal(es, es_ref) and np.isfinite(es).all()
     won = (np.arange(S) % 2).astype(int)
     sc = r.scores(fit, sm, ev, won)
     p = sm["state"][-1, :, 3]

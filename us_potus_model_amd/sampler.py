@@ -96,7 +96,7 @@ EXPORTS = [
     "potus_last_run_timing", "potus_posterior_summary", "potus_posterior_summary_many", "potus_backtest_scores",
     "potus_diagnostics", "potus_diagnostics_device",
     "potus_R_create", "potus_R_init", "potus_R_run", "potus_R_run_many", "potus_R_num_columns", "potus_R_saved_count",
-    "potus_R_write_array", "potus_R_write_stan_csv", "potus_R_posterior_summary", "potus_R_backtest_scores", "potus_R_last_error", "potus_R_destroy",
+    "potus_R_write_array", "potus_R_write_stan_csv", "potus_R_posterior_summary", "potus_R_diagnostics", "potus_R_backtest_scores", "potus_R_last_error", "potus_R_destroy",
 ]
 
 
