@@ -47,8 +47,7 @@ for chains in chain_counts:
             print(f"  chain 0: leaves {leaves:.0f} merges {merges:.0f}; cycles per leaf by phase (clock64 ticks):")
             for k, nm in NAMES.items():
                 print(f"    {nm:16s} {p[k]/max(leaves,1):10.0f}  ({100*p[k]/tot:4.1f}%)")
-            sub = {18: "C: wave0 after dots (per trip sum)", 25: "C: wave0 at barrier", 19: "D: wave0 after prefetch issue", 20: "D: wave0 after gathers",
-                   21: "D: wave0 at barrier", 24: "E: wave0 at barrier", 22: "F: wave0 after dZ", 23: "F: wave0 at barrier", 26: "B: wave0 at barrier"}
+            sub = {56: "C: thread 0 after the 51-term dot", 57: "C: ... its noise element arrived", 58: "C: ... binomial term done", 59: "C: ... epilogue of the element issued"}
             if KCL > 1:
                 print("  per member (cycles per leaf):  " + " ".join(f"{nm[:9]:>9s}" for nm in NAMES.values()))
                 for mm in range(KCL):
@@ -61,7 +60,7 @@ for chains in chain_counts:
                 print("  timeline of leaf 3000 (us since the first member entered the pass), members as columns:")
                 for k, nm in enumerate(names):
                     print(f"    {nm:22s}" + " ".join(f"{(st[mm, k] - t0) / 100.0:6.2f}" for mm in range(KCL)))
-                for ph, nm in ((0, "B per wave"),):
+                for ph, nm in ((0, {"1": "B", "3": "C", "4": "D", "5": "E", "6": "E2", "7": "F to its first barrier"}[os.environ.get("POTUS_PROF_WAVES", "1")] + " per wave"),):
                     for mm in (0, KCL - 4, KCL - 1):
                         print(f"  {nm} (cycles per leaf, member {mm}): ", [int(out[mm][32 + 8 * ph + w] / max(leaves, 1)) for w in range(8)])
             if KCL > 1:
@@ -72,16 +71,17 @@ for chains in chain_counts:
                 for mm in (0, KCL // 2, KCL - 1):
                     print(f"  phase F, thread 0 of member {mm} (cycles per leaf since its X2 wait ended): own slots done {out[mm][52]/leaves:.0f}, barrier {out[mm][53]/leaves:.0f}, "
                           f"day block stored {out[mm][54]/leaves:.0f}, totals of the next position summed {out[mm][55]/leaves:.0f}")
-            if KCL > 1:
+            PK = os.environ.get("POTUS_PROF_KIND", "")          # which optional counters the build carries in slots 56-61: "fetch" or "c"
+            if KCL > 1 and PK == "fetch":
                 for mm in (0, KCL - 1):
                     print(f"  previous leaf's totals, member {mm}: first fetch of 16 words {out[mm][56]/leaves:.0f} cycles, needed a re-fetch in {100*out[mm][57]/leaves:.0f} % of the leaves, "
                           f"{out[mm][58]/leaves:.2f} re-fetch rounds per leaf")
-            if KCL > 1:
+            if KCL > 1 and PK == "fetch":
                 for mm in (0, 1, KCL // 2, KCL - 1):
                     print(f"  X1 fetch (phase B, wave 0), member {mm}: first fetch {out[mm][56]/leaves:.0f} cycles, had to wait in {100*out[mm][57]/leaves:.0f} % of the leaves, "
                           f"{out[mm][58]/leaves:.2f} re-fetch rounds per leaf;  X2 prefix fetch (phase F, wave 0): first fetch {out[mm][59]/leaves:.0f} cycles, waited in "
                           f"{100*out[mm][60]/leaves:.0f} %, {out[mm][61]/leaves:.2f} re-fetch rounds per leaf")
             passes = leaves + 1e-9
-            for k, nm in sub.items():
-                print(f"    [{nm:36s}] {p[k]/passes:10.0f}")
+            for mm in ((0, KCL // 2, KCL - 1) if KCL > 1 and PK == "c" else ()):
+                print(f"  phase C, thread 0 of member {mm} (cycles per leaf since the phase began): " + ", ".join(f"{nm[3:]} {out[mm][k]/passes:.0f}" for k, nm in sub.items()))
     h.close()

@@ -62,6 +62,20 @@
 #ifndef CL_LDS_BARRIERS
 #define CL_LDS_BARRIERS 0                // 1: the barriers of the pass behind which only LDS is shared wait for LDS only (see PASS_BARRIER); measured neutral (17.37 against 17.43 us), off
 #endif
+#ifndef CL_XLD_COUNT
+#define CL_XLD_COUNT 0                   // 1: exchange fetches issue only the loads they need (0: always all sixteen, idle ones out of range)
+#endif
+#ifndef CL_WIDE_BY_ROWS
+#define CL_WIDE_BY_ROWS 0                // 1: the leaf's totals are fetched four values x sixteen members per load and summed on the DPP path (0: one load per member)
+#endif
+#ifndef CL_SEG_SHIFT
+#define CL_SEG_SHIFT 64                  // the level-2 segment sums of phase E start at this thread (0: at thread 0)
+#endif
+#ifndef CL_TANGENTS_IN_B
+#define CL_TANGENTS_IN_B 2               // where the AR(1) tangent recurrences and the scalars of rho's prior run: 0: on one wave of phase C; 1: in phase B on idle waves;
+                                         // 2: phase C, the scalars on a second wave.  Measured (profiles/r04_cl_inkernel_cycles.txt): 0: 17.41 / 13.87 us per leapfrog with
+                                         // one / two clusters per chain, 1: 17.21 / 14.34, 2: 16.69 / 13.42 (with CL_SEG_SHIFT = 64 each)
+#endif
 #ifndef CL_LPP
 #define CL_LPP 1                         // lanes sharing one poll's 51-term dot in phase C (1, 2 or 4)
 #endif
@@ -281,11 +295,13 @@ __device__ __forceinline__ void xst(const Xch &x, unsigned voff, double v) {
 // fetch NB words of the exchange just published (per-lane byte offsets vo, PT_OOB = idle lane -> 0;
 // uniform slot offsets so); spins until every tag of the wave matches
 template <int NB>
-__device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], const unsigned (&so)[NB], double (&out)[NB], unsigned tag = 0, ldp xprof = nullptr) {
+__device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], const unsigned (&so)[NB], double (&out)[NB], unsigned tag = 0, ldp xprof = nullptr, int n = NB) {
+  // n (wave-uniform): only the first n loads are issued -- a load instruction costs the compute unit's address unit ~70 cycles even when
+  // every lane is out of range (scripts/micro/xfetch.hip), and the fetches of a member's waves queue behind each other there
   Xch x = x_in;
   if (tag) x.epoch = tag;                          // an exchange other than the latest one
   x.epoch = __builtin_amdgcn_readfirstlane(x.epoch); x.launch = __builtin_amdgcn_readfirstlane(x.launch);
-#ifdef POTUS_PROF
+#ifdef POTUS_PROF_FETCH
   const long long xt0_ = clock64();
 #else
   (void)xprof;
@@ -296,11 +312,17 @@ __device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], c
   asm volatile(CL_LD_INV ::: "memory");
 #endif
 #pragma unroll
-  for (int u = 0; u < NB; u++) w[u] = __builtin_amdgcn_raw_buffer_load_b128(x.xb, vo[u], __builtin_amdgcn_readfirstlane(so[u]), CL_AUX_LD);
+  for (int u = 0; u < NB; u++) {
+    if (CL_XLD_COUNT == 0 || u < n) w[u] = __builtin_amdgcn_raw_buffer_load_b128(x.xb, vo[u], __builtin_amdgcn_readfirstlane(so[u]), CL_AUX_LD);
+    else w[u] = u32x4{0u, 0u, 0u, 0u};
+  }
   bool all = true;
 #pragma unroll
-  for (int u = 0; u < NB; u++) { done[u] = __all(vo[u] == PT_OOB || (w[u][2] == x.epoch && w[u][3] == XCH_SEAL(x.launch, w[u][0], w[u][1]))); all = all && done[u]; }
-#ifdef POTUS_PROF
+  for (int u = 0; u < NB; u++) {
+    done[u] = (CL_XLD_COUNT != 0 && u >= n) || __all(vo[u] == PT_OOB || (w[u][2] == x.epoch && w[u][3] == XCH_SEAL(x.launch, w[u][0], w[u][1])));
+    all = all && done[u];
+  }
+#ifdef POTUS_PROF_FETCH
   if (xprof && (threadIdx.x & 63) == 0) { xprof[56] += (double)(clock64() - xt0_); xprof[57] += all ? 0.0 : 1.0; }
 #endif
   // Words that were not there yet are fetched again (words already in hand are not re-read, so a spinning wave
@@ -310,7 +332,7 @@ __device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], c
   for (unsigned spins = 0; !all; spins++) {
     // a member is missing (or another wave of the cluster has already given up): leave instead of hanging the GPU
     if (spins > CL_SPIN_LIMIT || ((spins & 1023u) == 1023u && xch_watchdog_raised(x))) xch_give_up(x);
-#ifdef POTUS_PROF
+#ifdef POTUS_PROF_FETCH
     if (xprof && (threadIdx.x & 63) == 0) xprof[58] += 1.0;
 #endif
     __builtin_amdgcn_s_sleep(CL_SPIN_SLEEP);
@@ -425,8 +447,86 @@ __device__ __forceinline__ unsigned cl_wide_publish(ldp part, int nv, Xch &x, ld
   PROF_MARK(23);
   return x.epoch;
 }
+// One tangent recurrence of the AR(1) bias over all T days, c[t] = rho c[t-1] + in[t], c[0] = 0, with
+//   WHICH = 0: in = 1 (d e / d mu_e_bias),  1: in = d[t-1] = e[t-1] - mu_e (d e / d rho through the recursion),  2: in = z[t] (through sigma_rho):
+// four consecutive days per lane and round of 256, affine scan across lanes on the DPP path; the member keeps its own days (read in phases E2, F).
+// Round 4: the three run on three waves that idle in phase B (until then one wave of phase C did all three plus the logarithms of the prior
+// of rho, 5.4 k cycles, and set the length of that phase: profiles/r04_cl_inkernel_cycles.txt).
+template <int WHICH>
+__device__ __forceinline__ void cl_ar1_tangent(double rho, double mue, ldp ze, ldp s_e, ldp s_c, int T, int d0, int nd) {
+  const int lane = threadIdx.x & 63;
+  constexpr int PER = 4;
+  double c_in = 0.0;
+  for (int base = 0; base < T; base += 64 * PER) {   // one round unless T > 256
+    const int ta = base + lane * PER;
+    double in_[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+      const int t = ta + u;
+      in_[u] = WHICH == 0 ? 1.0 : WHICH == 1 ? s_e[min(max(t - 1, 0), T - 1)] - mue : ze[min(t, T - 1)];
+    }
+    ISSUE_FENCE();
+    double A2 = 1.0, Bc[1] = {0.0};
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+      const int t = ta + u;
+      const bool in = t < T, first = t == 0;
+      const double An = first ? 0.0 : rho * A2, B1 = first ? 0.0 : rho * Bc[0] + in_[u];
+      A2 = in ? An : A2; Bc[0] = in ? B1 : Bc[0];
+    }
+    dpp_scan_affine(A2, Bc);
+    double c = dpp_prev_lane(A2, 1.0) * c_in + dpp_prev_lane(Bc[0], 0.0);
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+      const int t = ta + u;
+      const bool first = t == 0, in = t < T;
+      const double n = first ? 0.0 : rho * c + in_[u];
+      c = in ? n : c;
+      if (in && t >= d0 && t < d0 + nd) s_c[t - d0] = c;   // only the member's own days are read
+    }
+    c_in = dpp_readlane_d(c, 63);
+  }
+}
+
 __device__ __forceinline__ void cl_wide_consume(const Xch &x, unsigned tag, int nv, ldp out, ldp xprof = nullptr) {   // one wave
   const int lane = threadIdx.x & 63;
+#if CL_WIDE_BY_ROWS
+  // A load covers four values of sixteen members (lane = 16 * value + member): a leaf that closes m levels needs
+  // ceil((9 + 6 m) / 4) loads instead of sixteen.  The members are summed along the rows of sixteen lanes on the DPP path,
+  // in a fixed tree, so every member of the cluster ends up with the same bits.
+  const int mm = lane & 15, r = lane >> 4;
+  for (int v0 = 0; v0 < nv; v0 += 64) {
+    const int ni = min(16, (nv - v0 + 3) >> 2);
+    double tot[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) tot[u] = 0.0;
+    for (int mm0 = 0; mm0 < x.K; mm0 += 16) {
+      double t16[16];
+      unsigned vo[16], so[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int v = v0 + 4 * u + r;
+        vo[u] = (mm0 + mm < x.K && v < nv) ? (unsigned)(mm0 + mm) * (unsigned)x.XW * 16u + 16u * (unsigned)v : PT_OOB;
+        so[u] = xch_eslot(x, tag, 0);
+      }
+      xld(x, vo, so, t16, tag, xprof, ni);
+#pragma unroll
+      for (int u = 0; u < 16; u++) tot[u] += t16[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      if (u < ni) {                                  // wave-uniform
+        double t = tot[u];
+        t += dpp_fetch<DPP_ROW_SHR(1), 0xf>(0.0, t);
+        t += dpp_fetch<DPP_ROW_SHR(2), 0xf>(0.0, t);
+        t += dpp_fetch<DPP_ROW_SHR(4), 0xf>(0.0, t);
+        t += dpp_fetch<DPP_ROW_SHR(8), 0xf>(0.0, t);
+        const int v = v0 + 4 * u + r;
+        if (mm == 15 && v < nv) out[v] = t;
+      }
+    }
+  }
+#else
   for (int l0 = 0; l0 < nv; l0 += 64) {
     const int l = l0 + lane;
     double tot = 0.0;
@@ -435,12 +535,13 @@ __device__ __forceinline__ void cl_wide_consume(const Xch &x, unsigned tag, int 
       unsigned vo[16], so[16];
 #pragma unroll
       for (int u = 0; u < 16; u++) { const int mm = mm0 + u; vo[u] = (mm < x.K && l < nv) ? 16u * (unsigned)l : PT_OOB; so[u] = xch_eslot(x, tag, mm < x.K ? mm : 0); }
-      xld(x, vo, so, t16, tag, xprof);
+      xld(x, vo, so, t16, tag, xprof, min(16, x.K - mm0));
 #pragma unroll
       for (int u = 0; u < 16; u++) tot += t16[u];
     }
     if (l < nv) out[l] = tot;
   }
+#endif
 }
 
 // What thread 0 needs to take the verdicts of a leaf once its totals are in (base_nuts::build_tree's bookkeeping):
@@ -619,7 +720,8 @@ __device__ __forceinline__ ClStatic cl_load_static(CCp CL, cip part) {
     const int nseg = part[CP_NSEG];
     // with the adjoint on the matrix cores the level-2 sums share a barrier interval with it: the segments go to the upper
     // waves first (waves 0-3 run the MFMA chains)
-    const int sg = CL->l_G ? ((tid + PT_THREADS / 2) & (PT_THREADS - 1)) : tid;
+    // (walk build: wave 0 turns the chunk totals into prefixes in that interval, so it gets segments last)
+    const int sg = CL->l_G ? ((tid + PT_THREADS / 2) & (PT_THREADS - 1)) : ((tid + PT_THREADS - CL_SEG_SHIFT) & (PT_THREADS - 1));
     const bool ok = sg < nseg;
     c.sg_a = ok ? sch[part[CP_O_SEGPTR] + sg] : 0;
     c.sg_b = ok ? sch[part[CP_O_SEGPTR] + sg + 1] : 0;
@@ -868,8 +970,26 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         d_in = dpp_readlane_d(d, 63);
       }
       if (lane == 0) { s_scal[SC_MUE] = mue; s_scal[SC_RHO] = rho; s_scal[SC_SRHO] = srho; s_scal[SC_XMUE] = xm; s_scal[SC_XRHO] = xr; }
+#if CL_TANGENTS_IN_B == 1
+      cl_ar1_tangent<1>(rho, mue, ze, s_e, s_c2, T, d0, nd);   // needs e[t-1]: this wave's own LDS stores, in order
+#endif
     }
   }
+#if CL_TANGENTS_IN_B == 1
+  // The tangents that do not need e[] and the scalars of rho's prior, on waves that have nothing else to do in this phase (each
+  // recomputes rho from the raw parameter: same operations, same bits).
+  if (full && w >= 3 && w <= 5) {
+    const double rho = d_inv_logit(s_mid[M->o_rho - o_c]);
+    ldp ze = s_mid + (M->o_ze - o_c);
+    if (w == 3) cl_ar1_tangent<0>(rho, 0.0, ze, s_e, s_c1, T, d0, nd);
+    else if (w == 4) cl_ar1_tangent<2>(rho, 0.0, ze, s_e, s_c3, T, d0, nd);
+    else if (lane == 0) {
+      // what the owner of rho_e_bias needs in phase F: Jacobian + prior of rho (stan:63,124), d sigma_rho / d rho
+      s_scal[SC_LPRHO] = log(rho) + log1p(-rho) - 0.5 * ((rho - 0.7) / 0.1) * ((rho - 0.7) / 0.1);
+      s_scal[SC_DSRHO] = M->sigma_e * (-rho / sqrt(1.0 - rho * rho));
+    }
+  }
+#endif
 #if CL_X3_IN_B
   // The previous leaf's totals (exchange pend.tag, sent before this pass began) are fetched here by a wave that has nothing else
   // to do in this phase: an L2 round trip under load costs about 2 k cycles, which the verdict wave of phase C used to pay on
@@ -914,10 +1034,10 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         vo[u] = (mm < K && lane < S) ? 16u * (unsigned)lane : PT_OOB;
         so[u] = xch_eslot(x, x1tag, mm < K ? mm : 0);
       }
-#ifdef POTUS_PROF
-      xld(x, vo, so, t16, x1tag, prof);             // slots 56-58 (the phase-C consumer of the previous leaf's totals does not use them when CL_X3_IN_B)
+#ifdef POTUS_PROF_FETCH
+      xld(x, vo, so, t16, x1tag, prof, min(16, K - mm0));   // slots 56-58 (the phase-C consumer of the previous leaf's totals does not use them when CL_X3_IN_B)
 #else
-      xld(x, vo, so, t16, x1tag);
+      xld(x, vo, so, t16, x1tag, nullptr, min(16, K - mm0));
 #endif
 #pragma unroll
       for (int u = 0; u < 16; u++) carry_m += t16[u];
@@ -945,7 +1065,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
 #endif
     WPROF_PT(28);
   }
-  WPROF_ACC(0);
+  if (POTUS_PROF_WAVES == 1) WPROF_ACC(0);
 #if !CL_VC
   PASS_BARRIER();
   PROF_MARK(1);
@@ -981,12 +1101,16 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // division of the binomial term are ~250 double-precision instructions per wave: polls are dealt to the
   // waves in blocks of 64 so that a member with n polls pays for ceil(n/64) wave passes, spread over the SIMDs
   {
+    WPROF_CT0();
     const int om = M->o_m - o_c, opop = M->o_pop - o_c;
     const double sigma_c = M->sigma_c, sigma_m = M->sigma_m, sigma_pop = M->sigma_pop, sigma_ns = M->sigma_ns, sigma_nn = M->sigma_nn;
     const unsigned long long AS_L *pm = (const unsigned long long AS_L *)(lds + LAY(l_pm));
     const unsigned long long AS_L *pyn = (const unsigned long long AS_L *)(lds + LAY(l_py));
     ldp pun = lds + LAY(l_pun);
-    if (full && w == PT_NW - 1) {
+    // (the split of variant 2 is taken by the fixed build only: in the dynamic builds, which serve the no-mode posteriors among others, its mere presence
+    //  cost 4 % -- bench.py --config 3: 698 k leapfrogs/s without, 667 k with)
+    constexpr int TNG = CL_TANGENTS_IN_B == 2 ? (FX ? 2 : 0) : CL_TANGENTS_IN_B;
+    if (TNG != 1 && full && w == PT_NW - 1) {
       // the three tangent recurrences of the AR(1) bias (needed in phase E2 only) run here, on the wave that
       // has no polls unless the member has more than 448 of them, instead of lengthening phase B
       const double rho = s_scal[SC_RHO], mue = s_scal[SC_MUE], sigma_e = M->sigma_e;
@@ -1021,11 +1145,18 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         }
         c1_in = dpp_readlane_d(c1, 63); c2_in = dpp_readlane_d(c2, 63); c3_in = dpp_readlane_d(c3, 63);
       }
-      if (lane == 0) {
+      if (TNG == 0 && lane == 0) {
         // what the owner of rho_e_bias needs in phase F: Jacobian + prior of rho (stan:63,124), d sigma_rho / d rho
         s_scal[SC_LPRHO] = log(rho) + log1p(-rho) - 0.5 * ((rho - 0.7) / 0.1) * ((rho - 0.7) / 0.1);
         s_scal[SC_DSRHO] = sigma_e * (-rho / sqrt(1.0 - rho * rho));
       }
+    }
+    if (TNG == 2 && full && w == PT_NW - 3 && lane == 0) {
+      // ... on a wave of their own (idle unless the member has more than 320 polls): two logarithms, a square root and a division on
+      // one lane are 3.3 k cycles, as long as the three recurrences together (profiles/r04_cl_inkernel_cycles.txt)
+      const double rho = s_scal[SC_RHO];
+      s_scal[SC_LPRHO] = log(rho) + log1p(-rho) - 0.5 * ((rho - 0.7) / 0.1) * ((rho - 0.7) / 0.1);
+      s_scal[SC_DSRHO] = M->sigma_e * (-rho / sqrt(1.0 - rho * rho));
     }
     if (w == PT_NW - 2 && pend.n >= 0) {
       // The previous leaf's totals and verdicts, on a wave that has no polls unless the member has more than 384 of
@@ -1110,7 +1241,12 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         if constexpr (LPP >= 2) dot += dpp_fetch<0xB1, 0xf>(0.0, dot);    // quad_perm [1, 0, 3, 2]: the neighbour's part
         if constexpr (LPP == 4) dot += dpp_fetch<0x4E, 0xf>(0.0, dot);    // quad_perm [2, 3, 0, 1]: the other pair's sum
         const double sg = s == S ? sigma_nn : sigma_ns;
+        WPROF_CSTAMP(0);
         zn = pol.q_fin(qt);
+#if (POTUS_PROF_CMASK & 2)
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the element and its momentum have arrived
+#endif
+        WPROF_CSTAMP(1);
         double eta = s_bT[s] + sg * zn + sigma_c * s_mid[ip] + dot;   // s_bT: mu_b_prior (national: its weighted average)
         if (full) eta += sigma_m * s_mid[om + im] + sigma_pop * s_mid[opop + ipop] + un * s_e[t];
         // binomial_logit with one exp, one log1p, one division:  e = exp(-|eta|), l = log1p(e)
@@ -1125,6 +1261,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         const double ex = exp(-fabs(eta)), l1 = log1p(ex), pr = (eta >= 0.0 ? 1.0 : ex) / (1.0 + ex);
 #endif
         const double r = y - N * pr;
+        WPROF_CSTAMP(2);
         const double term = y * (fmin(eta, 0.0) - l1) + (N - y) * (fmin(-eta, 0.0) - l1) - 0.5 * zn * zn;   // stan:126-127,130-131 (zn = 0 on idle lanes)
         lp += (LPP == 1 || sub == 0) ? term : 0.0;      // (the other lanes of a poll's group hold no noise element: their eta, r are not used)
         r_lds[lead ? il : np + 1] = r;                   // slot np stays 0 (padding of the task lists), np+1 is a dump
@@ -1132,8 +1269,11 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         gval = sg * r - zn;
       }
       pol.g_fin(vq, gval, zn, gt);
+      WPROF_CSTAMP(3);
     }
+    WPROF_CFLUSH();
   }
+  WAVE_ARRIVE(3);
   PASS_BARRIER();
   PROF_MARK(3);
   TSTAMP(4);
@@ -1221,6 +1361,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       if (ok) Y[sub] = sum;
     }
   }
+  WAVE_ARRIVE(4);
   __syncthreads();
   PROF_MARK(4);
   TSTAMP(5);
@@ -1318,6 +1459,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     if (sg_kind == 0) s_P[sg_index] = sum;          // pollster / mode / population partial (slot index)
     else if (sg_kind == 2) s_ge[sg_index] = sum;    // sum of unadjusted * residual over a local day
   }
+  WAVE_ARRIVE(5);
   __syncthreads();
   PROF_MARK(5);
   TSTAMP(6);
@@ -1368,6 +1510,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // slots add up the words XP_PRE + k instead of partial transposed mat-vecs, which rounds 1-3 computed here on six waves.
   xst(x, (w == 0 && lane < S) ? 16u * (unsigned)(XP_PRE + lane) : (w == 1 && full && lane < 5) ? 16u * (unsigned)(XP_AR + lane) : PT_OOB, pay);
 #if CL_E2_BARRIER == 1
+  WAVE_ARRIVE(6);
   __syncthreads();
 #elif CL_E2_BARRIER == 2
   drain_vmem();
@@ -1419,10 +1562,10 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         vo[u] = (mm < m && lane < S) ? 16u * (unsigned)(XP_PRE + lane) : PT_OOB;
         so[u] = xch_rslot(x, mm < m ? mm : 0);
       }
-#ifdef POTUS_PROF
-      xld(x, vo, so, t16, 0u, prof + 3);        // slots 59-61: cycles of the first fetch, leaves that had to wait, re-fetch rounds
+#ifdef POTUS_PROF_FETCH
+      xld(x, vo, so, t16, 0u, prof + 3, min(16, m - mm0));   // slots 59-61: cycles of the first fetch, leaves that had to wait, re-fetch rounds
 #else
-      xld(x, vo, so, t16);
+      xld(x, vo, so, t16, 0u, nullptr, min(16, m - mm0));
 #endif
 #pragma unroll
       for (int u = 0; u < 16; u++) carry_m += t16[u];
@@ -1494,6 +1637,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     voz[j] = (lane < S && j < wnd) ? 8u * (unsigned)(e0 + lane + S * (wd0 + j)) : PT_OOB;
     pol.g_load(voz[j], gz[j]);
   }
+  WAVE_ARRIVE(7);
   PASS_BARRIER();
   PROF_SUB(53);
   {

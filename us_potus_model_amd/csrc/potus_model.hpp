@@ -112,6 +112,9 @@ enum { SC_MUE = 0, SC_RHO, SC_SRHO, SC_XMUE, SC_XRHO, SC_LPRHO, SC_DSRHO, SC_N }
 #define PT_NRED 8  // reduction slots
 #define PT_NPROF 64
 
+#ifndef POTUS_PROF_WAVES
+#define POTUS_PROF_WAVES 1                  // the phase whose per-wave arrival times (cycles since the phase began) a profile build records in slots 32-39:
+#endif                                      // 1 = B (WPROF_ACC), 3 = C, 4 = D, 5 = E, 6 = E2, 7 = F up to its first barrier
 #ifdef POTUS_PROF
 #define PROF_MARK(k) do { if (threadIdx.x == 0) { const long long t_ = clock64(); prof[k] += (double)(t_ - (long long)prof[PT_NPROF - 1]); prof[PT_NPROF - 1] = (double)t_; } } while (0)
 #define PROF_START() do { if (threadIdx.x == 0) prof[PT_NPROF - 1] = (double)clock64(); } while (0)
@@ -119,9 +122,17 @@ enum { SC_MUE = 0, SC_RHO, SC_SRHO, SC_XMUE, SC_XRHO, SC_LPRHO, SC_DSRHO, SC_N }
 // per-wave timers: slot 32 + 8*ph + wave accumulates the time a wave spends between WPROF_T0 and WPROF_ACC(ph)
 #define WPROF_T0() const long long wt0_ = clock64()
 #define WPROF_ACC(ph) do { if ((threadIdx.x & 63) == 0) prof[32 + 8 * (ph) + (threadIdx.x >> 6)] += (double)(clock64() - wt0_); } while (0)
+#define WAVE_ARRIVE(ph) do { if (POTUS_PROF_WAVES == (ph) && (threadIdx.x & 63) == 0) prof[32 + (threadIdx.x >> 6)] += (double)(clock64() - (long long)prof[PT_NPROF - 1]); } while (0)
 // timeline stamps (device-wide 100 MHz clock) of one chosen leaf: slot 40 + k
 #define TSTAMP(k) do { if (threadIdx.x == 0 && prof[16] == 3000.0) prof[40 + (k)] = (double)wall_clock64(); } while (0)
 #define WPROF_PT(k) do { if (threadIdx.x == 0) prof[k] += (double)(clock64() - wt0_); } while (0)   // thread 0: time since WPROF_T0
+#ifndef POTUS_PROF_CMASK
+#define POTUS_PROF_CMASK 0                  // -DPOTUS_PROF -DPOTUS_PROF_CMASK=15: four stamps of thread 0 inside the poll phase of the cluster pass (slots 56-59,
+#endif                                      // shared with -DPOTUS_PROF_FETCH: one or the other).  The stamps stay in scalar registers until the phase is over:
+                                            // an LDS update under `if (threadIdx.x == 0)` inside the poll arithmetic made the allocator spill 150 vector registers.
+#define WPROF_CT0() const long long wct0_ = clock64(); long long wct_[4] = {wct0_, wct0_, wct0_, wct0_}
+#define WPROF_CSTAMP(i) do { if constexpr ((POTUS_PROF_CMASK >> (i)) & 1) wct_[i] = clock64(); } while (0)
+#define WPROF_CFLUSH() do { if (POTUS_PROF_CMASK != 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 4; i_++) prof[56 + i_] += (double)(wct_[i_] - wct0_); } } while (0)
 #define WPROF_T0B() const long long wt0b_ = clock64()
 #define WPROF_PTB(k) do { if ((threadIdx.x & 63) == 0) prof[k] += (double)(clock64() - wt0b_); } while (0)
 #define WPROF_ACCB(ph) do { if ((threadIdx.x & 63) == 0) prof[32 + 8 * (ph) + (threadIdx.x >> 6)] += (double)(clock64() - wt0b_); } while (0)
@@ -130,6 +141,9 @@ enum { SC_MUE = 0, SC_RHO, SC_SRHO, SC_XMUE, SC_XRHO, SC_LPRHO, SC_DSRHO, SC_N }
 #else
 #define TSTAMP(k) do { } while (0)
 #define WPROF_PT(k) do { } while (0)
+#define WPROF_CT0() do { } while (0)
+#define WPROF_CSTAMP(i) do { } while (0)
+#define WPROF_CFLUSH() do { } while (0)
 #define WPROF_T0B() do { } while (0)
 #define WPROF_PTB(k) do { } while (0)
 #define WPROF_ACCB(ph) do { } while (0)
@@ -137,6 +151,7 @@ enum { SC_MUE = 0, SC_RHO, SC_SRHO, SC_XMUE, SC_XRHO, SC_LPRHO, SC_DSRHO, SC_N }
 #define WPROF_ACCC(ph) do { } while (0)
 #define WPROF_T0() do { } while (0)
 #define WPROF_ACC(ph) do { } while (0)
+#define WAVE_ARRIVE(ph) do { } while (0)
 #define PROF_MARK(k) do { } while (0)
 #define PROF_START() do { } while (0)
 #define PROF_SUB(k) do { } while (0)
