@@ -62,6 +62,9 @@
 #ifndef CL_LDS_BARRIERS
 #define CL_LDS_BARRIERS 0                // 1: the barriers of the pass behind which only LDS is shared wait for LDS only (see PASS_BARRIER); measured neutral (17.37 against 17.43 us), off
 #endif
+#ifndef CL_X3_DELAY
+#define CL_X3_DELAY 0                    // s_sleep argument (units of 64 cycles) before the fetch of the previous leaf's totals in phase B
+#endif
 #ifndef CL_XLD_COUNT
 #define CL_XLD_COUNT 0                   // 1: exchange fetches issue only the loads they need (0: always all sixteen, idle ones out of range)
 #endif
@@ -995,7 +998,12 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // to do in this phase: an L2 round trip under load costs about 2 k cycles, which the verdict wave of phase C used to pay on
   // the critical path of that phase.  (Round 3 tried this while waves 2-7 still carried the 51 x 51 mat-vecs of mu_b_T and
   // the polling bias here and lost; those products are gone, see the carry step below.)
-  if (w == 2 && pend.n >= 0) cl_wide_consume(x, pend.tag, pend.nv, wout);
+  if (w == 2 && pend.n >= 0) {
+    // (this wave's sixteen loads would enter the compute unit's address queue ahead of wave 0's fetch of X1, which the phase ends with:
+    //  it starts a little later instead -- the totals are not needed before the verdicts of phase C)
+    if (CL_X3_DELAY) __builtin_amdgcn_s_sleep(CL_X3_DELAY);
+    cl_wide_consume(x, pend.tag, pend.nv, wout);
+  }
 #endif
   // mu_b[:, t] = prior + L_T z_T + L_W C[:, t] and polling_bias = L_B z_b (stan:77,85-86) enter a poll's predictor only as
   // prior[s] + L_W[s, :] . (aT z_T + aB z_b + C[:, t]): the three factors are one matrix times three scalars (stan:42-55).  So
