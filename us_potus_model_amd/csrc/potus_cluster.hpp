@@ -62,6 +62,12 @@
 #ifndef CL_LDS_BARRIERS
 #define CL_LDS_BARRIERS 0                // 1: the barriers of the pass behind which only LDS is shared wait for LDS only (see PASS_BARRIER); measured neutral (17.37 against 17.43 us), off
 #endif
+#ifndef CL_PRE_EARLY
+#define CL_PRE_EARLY 0                   // 1: a member's adjoint prefix totals (words XP_PRE of X2) are published in phase E, as soon as wave 0 has them, instead of
+#endif                                   //    in phase E2 behind the level-2 sums: the hop to the members that own later days overlaps phases E and E2 (walk build)
+#ifndef CL_F_LATE
+#define CL_F_LATE 0                      // 1: in phase F the AR(1) composites and the slot partials are looked at once before the barrier that hands the prefix carry
+#endif                                   //    around; if they are not there yet they are fetched AFTER the day-block epilogue, so that only the prefix gates that barrier
 #ifndef CL_X3_DELAY
 #define CL_X3_DELAY 0                    // s_sleep argument (units of 64 cycles) before the fetch of the previous leaf's totals in phase B
 #endif
@@ -297,8 +303,9 @@ __device__ __forceinline__ void xst(const Xch &x, unsigned voff, double v) {
 }
 // fetch NB words of the exchange just published (per-lane byte offsets vo, PT_OOB = idle lane -> 0;
 // uniform slot offsets so); spins until every tag of the wave matches
-template <int NB>
-__device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], const unsigned (&so)[NB], double (&out)[NB], unsigned tag = 0, ldp xprof = nullptr, int n = NB) {
+template <int NB, bool TRY = false>
+__device__ __forceinline__ bool xld(const Xch &x_in, const unsigned (&vo)[NB], const unsigned (&so)[NB], double (&out)[NB], unsigned tag = 0, ldp xprof = nullptr, int n = NB) {
+  // TRY: one round only; returns whether every word was there (out is meaningful only then)
   // n (wave-uniform): only the first n loads are issued -- a load instruction costs the compute unit's address unit ~70 cycles even when
   // every lane is out of range (scripts/micro/xfetch.hip), and the fetches of a member's waves queue behind each other there
   Xch x = x_in;
@@ -328,6 +335,11 @@ __device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], c
 #ifdef POTUS_PROF_FETCH
   if (xprof && (threadIdx.x & 63) == 0) { xprof[56] += (double)(clock64() - xt0_); xprof[57] += all ? 0.0 : 1.0; }
 #endif
+  if constexpr (TRY) {
+#pragma unroll
+    for (int u = 0; u < NB; u++) out[u] = __hiloint2double((int)w[u][1], (int)w[u][0]);
+    return all;
+  }
   // Words that were not there yet are fetched again (words already in hand are not re-read, so a spinning wave
   // does not flood the memory pipeline).  The re-fetch must stay an agent-scope (sc1) load: the `volatile` flavour of
   // the builtin becomes a system-scope load that costs ~2 us per round here.  What keeps the compiler from hoisting
@@ -360,6 +372,7 @@ __device__ __forceinline__ void xld(const Xch &x_in, const unsigned (&vo)[NB], c
   }
 #pragma unroll
   for (int u = 0; u < NB; u++) out[u] = __hiloint2double((int)w[u][1], (int)w[u][0]);   // idle lanes loaded zeros
+  return true;
 }
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // NOTE on position vectors (QC and the proposal-pool slots): their small-vector part is written with sc1
@@ -1403,6 +1416,9 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
 #pragma unroll
       for (int c = 0; c < PT_NW; c++) { X[c * SE + lx] = chunk_total; chunk_total += ct[c]; }
     }
+#if CL_PRE_EARLY
+    xst(x, (w == 0 && lane < S) ? 16u * (unsigned)(XP_PRE + lane) : PT_OOB, chunk_total);   // (no branch around the store; the other waves' lanes are out of range)
+#endif
   } else {
     (void)tlast; (void)ch; (void)cv;
     // Adjoint on the matrix cores, step 2: gC[k][t] = sum_s Lw_ext[s][k] G[s][t] as 16 x 16 x 4 fp64 MFMA tiles
@@ -1516,7 +1532,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // over ALL the polls = the sum over the members of the prefix totals published here (the polls of the last day included: they
   // take their real row of the factor in the gather, and the prefix of that day is not used, stan:86).  So the owners of those
   // slots add up the words XP_PRE + k instead of partial transposed mat-vecs, which rounds 1-3 computed here on six waves.
-  xst(x, (w == 0 && lane < S) ? 16u * (unsigned)(XP_PRE + lane) : (w == 1 && full && lane < 5) ? 16u * (unsigned)(XP_AR + lane) : PT_OOB, pay);
+  xst(x, (w == 0 && lane < S && (MF || !CL_PRE_EARLY)) ? 16u * (unsigned)(XP_PRE + lane) : (w == 1 && full && lane < 5) ? 16u * (unsigned)(XP_AR + lane) : PT_OOB, pay);
 #if CL_E2_BARRIER == 1
   WAVE_ARRIVE(6);
   __syncthreads();
@@ -1582,6 +1598,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     PROF_MARK(7);
     TSTAMP(8);
   }
+#if !CL_F_LATE
   double own_g = 0.0, own_q = 0.0;                 // gradient / position of the element this thread owns besides the S x T block
   if (w == 1) {
     if (full) {
@@ -1637,6 +1654,35 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     const int jrep = arl ? NR + d0 + (nd - 1 - lane) : rslot;
     xst(x, (pubnext && (arl || repl)) ? 16u * (unsigned)(XQ0 + jrep) : PT_OOB, qn_own);
   }
+#else
+  // CL_F_LATE: one look at the AR(1) composites / slot partials before the barrier; what is missing is fetched after the day-block epilogue
+  double own_g = 0.0, own_q = 0.0;
+  const bool w_ar = w == 1 && full, w_slot = w >= 2 && __any(repl || is_s3);
+  const unsigned vA = lane < K ? (unsigned)lane * (unsigned)x.XW * 16u + 16u * (unsigned)XP_AR : PT_OOB;
+  const unsigned v1 = is_mue ? 16u * (unsigned)XP_S : is_rho ? 16u * (unsigned)(XP_S + 1) : is_s3 ? 16u * (unsigned)(XP_S + 2)
+                      : !repl ? PT_OOB : rslot < 2 * S ? 16u * (unsigned)(XP_PRE + (rslot < S ? rslot : rslot - S))   // L_W_ext' g, see phase E2
+                      : 16u * (unsigned)(XP_P + rslot);
+  const Xch x2 = x;                                // the exchange the words belong to (x.epoch moves on below when the next X1 goes out)
+  double late_mA = 0.0, late_mB = 0.0, late_sum = 0.0;
+  bool have = true;                                // wave-uniform
+  if (w_ar) {
+    double mAB[2];
+    const unsigned vo[2] = {vA, lane < K ? vA + 16u : PT_OOB}, so[2] = {xch_rslot(x2, 0), xch_rslot(x2, 0)};
+    have = xld<2, true>(x2, vo, so, mAB);
+    late_mA = mAB[0]; late_mB = mAB[1];
+  } else if (w_slot) {
+    for (int mm0 = 0; mm0 < K; mm0 += 16) {
+      double t16[16];
+      unsigned vo[16], so[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) { const int mm = mm0 + u; vo[u] = mm < K ? v1 : PT_OOB; so[u] = xch_rslot(x2, mm < K ? mm : 0); }
+      const bool ok = xld<16, true>(x2, vo, so, t16);
+      have = have && ok;
+#pragma unroll
+      for (int u = 0; u < 16; u++) late_sum += t16[u];
+    }
+  }
+#endif
   PROF_SUB(52);
   typename Pol::GT gz[CL_DW];
   unsigned voz[CL_DW];
@@ -1664,6 +1710,57 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     }
     PROF_SUB(55);
   }
+#if CL_F_LATE
+  if (w_ar) {
+    if (!have) {
+      double mAB[2];
+      const unsigned vo[2] = {vA, lane < K ? vA + 16u : PT_OOB}, so[2] = {xch_rslot(x2, 0), xch_rslot(x2, 0)};
+      xld(x2, vo, so, mAB);
+      late_mA = mAB[0]; late_mB = mAB[1];
+    }
+    const double mA = late_mA, mB = late_mB;
+    double a_in = 0.0;
+    for (int mm = K - 1; mm > m; mm--) a_in = readlane_d(mB, mm) + readlane_d(mA, mm) * a_in;
+    const double a = arB + arA * a_in;
+    const int t = d0 + (arl ? nd - 1 - lane : 0);
+    const double z = s_mid[M->o_ze - o_c + (arl ? t : 0)];
+    const double gv = a * (t >= 1 ? s_scal[SC_SRHO] : M->sigma_e) - z;
+    lp -= arl ? 0.5 * z * z : 0.0;               // stan:125
+    own_g = gv; own_q = z;
+  } else if (w_slot) {
+    if (!have) {
+      late_sum = 0.0;
+      for (int mm0 = 0; mm0 < K; mm0 += 16) {
+        double t16[16];
+        unsigned vo[16], so[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int mm = mm0 + u; vo[u] = mm < K ? v1 : PT_OOB; so[u] = xch_rslot(x2, mm < K ? mm : 0); }
+        xld(x2, vo, so, t16);
+#pragma unroll
+        for (int u = 0; u < 16; u++) late_sum += t16[u];
+      }
+    }
+    const double sum = late_sum;
+    const double s3 = readlane_d(sum, 63);           // third tangent sum (meaningful in the wave that owns rho_e_bias)
+    const double qv = s_rep[rslot];
+    double gv = scale_r * sum - qv;
+    double dl = -0.5 * qv * qv;                    // stan:117,120-122,128
+    if (is_mue || is_rho) {
+      const double rho = s_scal[SC_RHO];
+      const double g_mue = 0.02 * (1.0 - rho) * sum - qv;                       // sum = S1
+      const double g_rho = ((sum + s3 * s_scal[SC_DSRHO]) - (rho - 0.7) / 0.01) * rho * (1.0 - rho) + (1.0 - 2.0 * rho);   // S2, S3
+      gv = is_mue ? g_mue : g_rho;
+      dl = is_mue ? -3.912023005428146 - 0.5 * qv * qv : s_scal[SC_LPRHO];     // log(0.02) + prior (stan:62,123) : stan:63,124
+    }
+    lp += repl ? dl : 0.0;
+    own_g = gv; own_q = qv;
+  }
+  {
+    const double qn_own = pol.gs_fin(vo_x, own_g, own_q, gx);   // outside the branches (vo_x is out of range for non-owners)
+    const int jrep = arl ? NR + d0 + (nd - 1 - lane) : rslot;
+    xst(x, (pubnext && (arl || repl)) ? 16u * (unsigned)(XQ0 + jrep) : PT_OOB, qn_own);
+  }
+#endif
   {
     double tot = 0.0;
 #pragma unroll
