@@ -62,6 +62,11 @@
 #ifndef CL_LDS_BARRIERS
 #define CL_LDS_BARRIERS 0                // 1: the barriers of the pass behind which only LDS is shared wait for LDS only (see PASS_BARRIER); measured neutral (17.37 against 17.43 us), off
 #endif
+#ifndef CL_G_EXCHANGE
+#define CL_G_EXCHANGE 0                  // 1 (fixed build only): the members exchange the per-state sums of their polls' residuals g_m (52 words, right after the poll
+#endif                                   //    phase) instead of the adjoint prefix totals pre_m = L_W' g_m (after gather and pick-up); the prefix and the total over the
+                                         //    members go through L_W' locally, on waves that idle in phases E / E2: phase F starts without an exchange
+#define CL_NSTBCAP 4                     // per-state poll lists of a member: batches of sixteen per (pseudo-)state the fixed layout holds
 #ifndef CL_PRE_EARLY
 #define CL_PRE_EARLY 0                   // 1: a member's adjoint prefix totals (words XP_PRE of X2) are published in phase E, as soon as wave 0 has them, instead of
 #endif                                   //    in phase E2 behind the level-2 sums: the hop to the members that own later days overlaps phases E and E2 (walk build)
@@ -112,7 +117,7 @@
 
 // fields of one member's part descriptor (ints)
 enum { CP_D0 = 0, CP_ND, CP_P0, CP_NP, CP_E0, CP_NE, CP_R0, CP_NR, CP_NSUB, CP_NSEG, CP_WB,
-       CP_O_WD, CP_O_MASK, CP_O_SUB, CP_O_SEGPTR, CP_O_SEGKIND, CP_O_SEGIDX, CP_O_WT, CP_E_SH, CP_NCELL, CP_O_CELL, CP_N = 24 };
+       CP_O_WD, CP_O_MASK, CP_O_SUB, CP_O_SEGPTR, CP_O_SEGKIND, CP_O_SEGIDX, CP_O_WT, CP_E_SH, CP_NCELL, CP_O_CELL, CP_NSTB, CP_O_STL, CP_N = 24 };
 #define CL_CELLS_PER_THREAD 2            // (state, day) cells of a member's polls per thread in the adjoint scatter (<= 1024 cells)
 #define CL_G_PAD 16                      // spare doubles behind G: the dump slot of idle scatter threads
 // payload layout of exchange X2 (doubles); X1 and the scalar all-reduces use the first words
@@ -131,7 +136,7 @@ struct ClModel {
   const double *rep_scale;  // [NR] scale of owned slot r (sigma_c ... ; 1 for zT, zb)
   const int *perm;          // [D] internal index -> Stan index
   int GS, GROWS;            // adjoint on the matrix cores (cl_adjoint_mfma): G[pseudo-state][local day], row stride, rows (l_G = 0: gather walk)
-  int l_C, l_G, l_Lw, l_prior, l_pm, l_py, l_pun, l_sub, l_tab, l_ru, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_e, l_c1, l_c2, l_c3, l_ge, l_P, l_scal, l_red, l_st, l_prof;
+  int l_C, l_G, l_Lw, l_prior, l_pm, l_py, l_pun, l_sub, l_tab, l_ru, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_e, l_c1, l_c2, l_c3, l_ge, l_P, l_scal, l_red, l_st, l_prof, l_stl, l_gx;
   int lds_doubles;
 };
 typedef const ClModel AS_C *CCp;
@@ -140,11 +145,11 @@ typedef const ClModel AS_C *CCp;
 // A member's LDS layout (offsets in doubles) as ONE function of the capacities, used by the host for the dynamic builds
 // (build_cluster: the posterior's own sizes) and at compile time for the fixed build below -- the two cannot drift apart.
 struct ClLay {
-  int l_C, l_G, l_Lw, l_prior, l_pm, l_py, l_pun, l_sub, l_tab, l_ru, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_e, l_c1, l_c2, l_c3, l_ge, l_P, l_scal, l_red, l_st, l_prof;
+  int l_C, l_G, l_Lw, l_prior, l_pm, l_py, l_pun, l_sub, l_tab, l_ru, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_e, l_c1, l_c2, l_c3, l_ge, l_P, l_scal, l_red, l_st, l_prof, l_stl, l_gx;
   int total;
 };
 constexpr int cl_ev(int n) { return (n + 1) & ~1; }   // LDS blocks start on 16-byte boundaries
-constexpr ClLay cl_layout(int S, int SE, int SP, int NDP, int npcap, int nsubcap, int nrepcap, int nrcap, int tcap, int g_doubles) {
+constexpr ClLay cl_layout(int S, int SE, int SP, int NDP, int npcap, int nsubcap, int nrepcap, int nrcap, int tcap, int g_doubles, int nstbcap = 0) {
   ClLay L{};
   int o = 0;
   L.l_C = o; o += cl_ev(S * NDP);                         // C[state][local day]: suffix sums, then the adjoint's running sums
@@ -174,6 +179,9 @@ constexpr ClLay cl_layout(int S, int SE, int SP, int NDP, int npcap, int nsubcap
   L.l_red = o; o += cl_ev((PT_NW + 1) * PT_NRED);
   L.l_st = o; o += cl_ev((npcap + 8 + 7) / 8);
   L.l_prof = o; o += cl_ev(PT_NPROF);
+  // CL_G_EXCHANGE: per-state poll lists (a batch = 64 lanes x 16 entries of 16 bits) | G prefix [64], G total [64], partial products [4][2][64]
+  L.l_stl = nstbcap ? o : 0; o += cl_ev(nstbcap * 256);
+  L.l_gx = nstbcap ? o : 0; o += cl_ev(nstbcap ? 640 : 0);
   L.total = o;
   return L;
 }
@@ -191,10 +199,10 @@ struct ClFixed {
   static constexpr int XW = 832;                     // exchange words per member: max(XP_P + NRCAP, XQ0 + NREPCAP) = max(72 + 512, 64 + 768)
   // and the full model (poll_model_2020.stan: mode / population effects, AR(1) bias); the no_mode_adjustment variant takes the dynamic build
   static constexpr int GS = 48, GROWS = 52;
-  static constexpr ClLay L = cl_layout(S, SE, SP, NDP, NPCAP, NSUBCAP, NREPCAP, NRCAP, TCAP, 0);
+  static constexpr ClLay L = cl_layout(S, SE, SP, NDP, NPCAP, NSUBCAP, NREPCAP, NRCAP, TCAP, 0, CL_G_EXCHANGE ? CL_NSTBCAP : 0);
 #define CLF(f) static constexpr int f = L.f
   CLF(l_C); CLF(l_G); CLF(l_Lw); CLF(l_prior); CLF(l_pm); CLF(l_py); CLF(l_pun); CLF(l_sub); CLF(l_tab); CLF(l_ru); CLF(l_wide); CLF(l_wout); CLF(l_X); CLF(l_Y);
-  CLF(l_r); CLF(l_rep); CLF(l_bT); CLF(l_e); CLF(l_c1); CLF(l_c2); CLF(l_c3); CLF(l_ge); CLF(l_P); CLF(l_scal); CLF(l_red); CLF(l_st); CLF(l_prof);
+  CLF(l_r); CLF(l_rep); CLF(l_bT); CLF(l_e); CLF(l_c1); CLF(l_c2); CLF(l_c3); CLF(l_ge); CLF(l_P); CLF(l_scal); CLF(l_red); CLF(l_st); CLF(l_prof); CLF(l_stl); CLF(l_gx);
 #undef CLF
   static constexpr int lds_doubles = L.total;
 };
@@ -799,6 +807,11 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
     const int n16 = part[CP_NSUB] * PT_SUBLEN;
     for (int i = threadIdx.x; i < n16; i += PT_THREADS) sb[i] = (unsigned short)src_sub[i];
   }
+  if (CL->l_stl) {   // CL_G_EXCHANGE: the member's polls by (pseudo-)state
+    unsigned AS_L *dst = (unsigned AS_L *)(lds + CL->l_stl);
+    gcip src_stl = as_g(CL->sched) + part[CP_O_STL];
+    for (int i = threadIdx.x; i < part[CP_NSTB] * 512; i += PT_THREADS) dst[i] = (unsigned)src_stl[i];
+  }
   // G: zero once; the scatter of every pass rewrites the same cells (the poll structure is static), everything else stays zero
   if (CL->l_G) for (int i = threadIdx.x; i < CL->GROWS * CL->GS + CL_G_PAD; i += PT_THREADS) (lds + CL->l_G)[i] = 0.0;
   const ClStatic c = cl_load_static(CL, part);
@@ -843,6 +856,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // adjoint as a walk over the polls, 12 = four days per wave with the adjoint product on the matrix cores (MF)
   constexpr int CL_DW = ClTag<CL_TAG>::DW;
   constexpr bool MF = ClTag<CL_TAG>::MF, FX = ClTag<CL_TAG>::FX;
+  constexpr bool GX = CL_G_EXCHANGE && FX && !MF;   // see CL_G_EXCHANGE
 #define LAY(f) (FX ? (int)ClFixed::f : CL->f)
   Pol pol = pol_io;
   int tid = threadIdx.x;
@@ -1314,6 +1328,28 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // the previous leaf's verdicts (its totals were collected in phase C): the last wave has no chunk of the gather below
   if (w == PT_NW - 1 && pend.n >= 0) cl_leaf_logic(ts, pend, wout);
 #endif
+  if constexpr (GX) {
+    // g[s] = sum of the residuals of the member's polls of (pseudo-)state s: lane s of the last wave walks the state's list (host: build_cluster),
+    // sixteen entries per batch, and publishes it as word XP_PRE + s of X2 -- a whole gather, pick-up and payload phase before anybody needs it
+    double g = 0.0;
+    if (w == PT_NW - 1) {
+      const u32x4 AS_L *stl = (const u32x4 AS_L *)(lds + LAY(l_stl));
+      const int nstb = part[CP_NSTB];
+      for (int b = 0; b < nstb; b++) {
+        const u32x4 ia = stl[(b * 64 + lane) * 2], ib = stl[(b * 64 + lane) * 2 + 1];
+        double rr[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          rr[2 * j] = r_lds[(int)(ia[j] & 0xffffu)]; rr[2 * j + 1] = r_lds[(int)(ia[j] >> 16)];
+          rr[8 + 2 * j] = r_lds[(int)(ib[j] & 0xffffu)]; rr[9 + 2 * j] = r_lds[(int)(ib[j] >> 16)];
+        }
+        ISSUE_FENCE();
+#pragma unroll
+        for (int j = 0; j < 16; j++) g += rr[j];
+      }
+    }
+    xst(x, (w == PT_NW - 1 && lane < SE) ? 16u * (unsigned)(XP_PRE + lane) : PT_OOB, g);   // (no branch around the store)
+  }
   if constexpr (!MF) {
     const unsigned AS_L *tab = (const unsigned AS_L *)(lds + LAY(l_tab));
     const int lk = lane < S ? lane : 0;
@@ -1395,6 +1431,24 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // ---------------- phase E: the owners of the days pick up the running sums; level-2 segment sums
   // (the chunk totals X[chunk][state] are turned into exclusive prefixes in place by wave 0, which keeps their sum for
   // its X2 word; after the barrier every wave looks its days' chunks up instead of carrying the eight prefixes around)
+  if constexpr (GX) {
+    if (w == PT_NW - 1) {
+      // the rows g_mm of all members (published a phase ago: nothing waits): prefix over the members that own earlier days, and total
+      ldp gxl = lds + LAY(l_gx);
+      double gp = 0.0, gt = 0.0;
+      const unsigned tagx = x.epoch + 1u;          // X2 is still being assembled on this member
+      for (int mm0 = 0; mm0 < K; mm0 += 16) {
+        double t16[16];
+        unsigned vo[16], so[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int mm = mm0 + u; vo[u] = (mm < K && lane < SE) ? 16u * (unsigned)(XP_PRE + lane) : PT_OOB; so[u] = xch_eslot(x, tagx, mm < K ? mm : 0); }
+        xld(x, vo, so, t16, tagx);
+#pragma unroll
+        for (int u = 0; u < 16; u++) { gt += t16[u]; gp += mm0 + u < m ? t16[u] : 0.0; }
+      }
+      gxl[lane] = gp; gxl[64 + lane] = gt;           // (lanes beyond the pseudo-state loaded zeros)
+    }
+  }
   int tlast[CL_DW], ch[CL_DW];
   double cv[CL_DW];
   double chunk_total = 0.0;
@@ -1417,7 +1471,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       for (int c = 0; c < PT_NW; c++) { X[c * SE + lx] = chunk_total; chunk_total += ct[c]; }
     }
 #if CL_PRE_EARLY
-    xst(x, (w == 0 && lane < S) ? 16u * (unsigned)(XP_PRE + lane) : PT_OOB, chunk_total);   // (no branch around the store; the other waves' lanes are out of range)
+    if constexpr (!GX) xst(x, (w == 0 && lane < S) ? 16u * (unsigned)(XP_PRE + lane) : PT_OOB, chunk_total);   // (no branch around the store; the other waves' lanes are out of range)
 #endif
   } else {
     (void)tlast; (void)ch; (void)cv;
@@ -1489,6 +1543,27 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   TSTAMP(6);
 
   // ---------------- phase E2: payload of X2
+  if constexpr (GX) {
+    // L_W_ext' applied to the prefix and to the total of g: waves 4-7 take a quarter of the (pseudo-)states each, lane k the column;
+    // the four partial sums are added (in wave order) by whoever needs the result, behind the first barrier of phase F
+    if (w >= PT_NW - 4) {
+      ldp gxl = lds + LAY(l_gx);
+      const int q = w - (PT_NW - 4), per = (SE + 3) >> 2, s0 = q * per, lk = lane < S ? lane : 0;
+      double a0 = 0.0, a1 = 0.0;
+      for (int j0 = 0; j0 < per; j0 += 13) {
+        double l[13], gpv[13], gtv[13];
+#pragma unroll
+        for (int j = 0; j < 13; j++) {
+          const int ss = (j0 + j < per && s0 + j0 + j < SE) ? s0 + j0 + j : SE;   // row SE of the staged factor is zero, and so are gxl[SE ..]
+          l[j] = Lw[ss * SP + lk]; gpv[j] = gxl[min(ss, 63)]; gtv[j] = gxl[64 + min(ss, 63)];
+        }
+        ISSUE_FENCE();
+#pragma unroll
+        for (int j = 0; j < 13; j++) { a0 += l[j] * gpv[j]; a1 += l[j] * gtv[j]; }
+      }
+      gxl[128 + (2 * q) * 64 + lane] = lane < S ? a0 : 0.0; gxl[128 + (2 * q + 1) * 64 + lane] = lane < S ? a1 : 0.0;
+    }
+  }
   double arA = 1.0, arB = 0.0;                      // wave 1 keeps its per-day adjoint composites for phase F
   double pay = 0.0;                                 // the word this lane publishes (wave 0: prefix total, wave 1: AR words)
   double pre[CL_DW];
@@ -1532,7 +1607,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // over ALL the polls = the sum over the members of the prefix totals published here (the polls of the last day included: they
   // take their real row of the factor in the gather, and the prefix of that day is not used, stan:86).  So the owners of those
   // slots add up the words XP_PRE + k instead of partial transposed mat-vecs, which rounds 1-3 computed here on six waves.
-  xst(x, (w == 0 && lane < S && (MF || !CL_PRE_EARLY)) ? 16u * (unsigned)(XP_PRE + lane) : (w == 1 && full && lane < 5) ? 16u * (unsigned)(XP_AR + lane) : PT_OOB, pay);
+  xst(x, (w == 0 && lane < S && !GX && (MF || !CL_PRE_EARLY)) ? 16u * (unsigned)(XP_PRE + lane) : (w == 1 && full && lane < 5) ? 16u * (unsigned)(XP_AR + lane) : PT_OOB, pay);
 #if CL_E2_BARRIER == 1
   WAVE_ARRIVE(6);
   __syncthreads();
@@ -1575,7 +1650,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // ---------------- phase F: finish the gradients of everything this member owns
   // wave 0 fetches the prefix totals of the members that own earlier days (for the whole workgroup),
   // wave 1 finishes raw_e_bias, the owners of small-vector slots finish theirs; then the S x T block
-  if (w == 0) {
+  if (w == 0 && !GX) {
     double carry_m = 0.0;
     for (int mm0 = 0, bt = 0; mm0 < m && (!(FX && CL_FX_BATCH) || bt < 1); mm0 += 16, bt++) {
       double t16[16];
@@ -1598,8 +1673,10 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     PROF_MARK(7);
     TSTAMP(8);
   }
-#if !CL_F_LATE
+  if constexpr (GX) { PROF_MARK(7); TSTAMP(8); }
   double own_g = 0.0, own_q = 0.0;                 // gradient / position of the element this thread owns besides the S x T block
+  constexpr bool LATE = CL_F_LATE || GX;           // see CL_F_LATE
+  if constexpr (!LATE) {
   if (w == 1) {
     if (full) {
       // carry of the adjoint from the members that own later days, then raw_e_bias of the member's days
@@ -1654,17 +1731,19 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     const int jrep = arl ? NR + d0 + (nd - 1 - lane) : rslot;
     xst(x, (pubnext && (arl || repl)) ? 16u * (unsigned)(XQ0 + jrep) : PT_OOB, qn_own);
   }
-#else
+  }
   // CL_F_LATE: one look at the AR(1) composites / slot partials before the barrier; what is missing is fetched after the day-block epilogue
-  double own_g = 0.0, own_q = 0.0;
+  // (CL_G_EXCHANGE: no look -- the words were published a moment ago -- and always after the epilogue)
   const bool w_ar = w == 1 && full, w_slot = w >= 2 && __any(repl || is_s3);
   const unsigned vA = lane < K ? (unsigned)lane * (unsigned)x.XW * 16u + 16u * (unsigned)XP_AR : PT_OOB;
+  const bool slot_local = GX && repl && rslot < 2 * S;   // raw_mu_b_T / raw_polling_bias: L_W_ext' (total of g), formed on this member (phase E2)
   const unsigned v1 = is_mue ? 16u * (unsigned)XP_S : is_rho ? 16u * (unsigned)(XP_S + 1) : is_s3 ? 16u * (unsigned)(XP_S + 2)
-                      : !repl ? PT_OOB : rslot < 2 * S ? 16u * (unsigned)(XP_PRE + (rslot < S ? rslot : rslot - S))   // L_W_ext' g, see phase E2
+                      : (!repl || slot_local) ? PT_OOB : rslot < 2 * S ? 16u * (unsigned)(XP_PRE + (rslot < S ? rslot : rslot - S))   // L_W_ext' g, see phase E2
                       : 16u * (unsigned)(XP_P + rslot);
   const Xch x2 = x;                                // the exchange the words belong to (x.epoch moves on below when the next X1 goes out)
   double late_mA = 0.0, late_mB = 0.0, late_sum = 0.0;
-  bool have = true;                                // wave-uniform
+  bool have = !LATE || !GX;                        // wave-uniform
+  if constexpr (LATE && !GX) {
   if (w_ar) {
     double mAB[2];
     const unsigned vo[2] = {vA, lane < K ? vA + 16u : PT_OOB}, so[2] = {xch_rslot(x2, 0), xch_rslot(x2, 0)};
@@ -1682,7 +1761,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       for (int u = 0; u < 16; u++) late_sum += t16[u];
     }
   }
-#endif
+  }
   PROF_SUB(52);
   typename Pol::GT gz[CL_DW];
   unsigned voz[CL_DW];
@@ -1695,7 +1774,11 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   PASS_BARRIER();
   PROF_SUB(53);
   {
-    const double carry = lane < S ? X[PT_NW * SE + lane] : 0.0;   // pre[] is already the prefix within the member
+    double carry = lane < S ? X[PT_NW * SE + lane] : 0.0;   // pre[] is already the prefix within the member
+    if constexpr (GX) {
+      ldp gxl = lds + LAY(l_gx);
+      carry = ((gxl[128 + 0 * 64 + lane] + gxl[128 + 2 * 64 + lane]) + gxl[128 + 4 * 64 + lane]) + gxl[128 + 6 * 64 + lane];   // L_W_ext' (prefix of g): zero beyond the states
+    }
     double nrun = 0.0;                              // suffix total of the next position over the wave's days
 #pragma unroll
     for (int j = 0; j < CL_DW; j++) {
@@ -1710,7 +1793,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     }
     PROF_SUB(55);
   }
-#if CL_F_LATE
+  if constexpr (LATE) {
   if (w_ar) {
     if (!have) {
       double mAB[2];
@@ -1740,7 +1823,14 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         for (int u = 0; u < 16; u++) late_sum += t16[u];
       }
     }
-    const double sum = late_sum;
+    double sum = late_sum;
+    if constexpr (GX) {
+      if (slot_local) {                              // (lanes of a wave, not the wave: plain selects, no memory operation)
+        ldp gxl = lds + LAY(l_gx);
+        const int k = rslot < S ? rslot : rslot - S;
+        sum = ((gxl[128 + 1 * 64 + k] + gxl[128 + 3 * 64 + k]) + gxl[128 + 5 * 64 + k]) + gxl[128 + 7 * 64 + k];
+      }
+    }
     const double s3 = readlane_d(sum, 63);           // third tangent sum (meaningful in the wave that owns rho_e_bias)
     const double qv = s_rep[rslot];
     double gv = scale_r * sum - qv;
@@ -1760,7 +1850,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     const int jrep = arl ? NR + d0 + (nd - 1 - lane) : rslot;
     xst(x, (pubnext && (arl || repl)) ? 16u * (unsigned)(XQ0 + jrep) : PT_OOB, qn_own);
   }
-#endif
+  }
   {
     double tot = 0.0;
 #pragma unroll
