@@ -139,6 +139,25 @@ def test_cholesky_factors(cases):
         assert np.sqrt(w @ (L @ L.T) @ w) == pytest.approx(sc, rel=1e-10)
 
 
+@pytest.mark.parametrize("name", ["2016", "2012", "2008", "small_full"])
+def test_the_three_factors_are_one_matrix_times_three_scalars(cases, name):
+    """stan:42-55 derives the three covariances from state_covariance_0 and three scales, so cholesky_ss_cov_mu_b_T = aT * cholesky_ss_cov_mu_b_walk and
+    cholesky_ss_cov_poll_bias = aB * cholesky_ss_cov_mu_b_walk with aT = mu_b_T_scale / random_walk_scale, aB = polling_bias_scale / random_walk_scale.
+    The cluster pass of the device path relies on it ("One matrix, three scalars": no 51 x 51 product besides the walk's); the oracle keeps Stan's
+    three factorisations, so this pins the identity on the factors the parity tests compare against."""
+    data, variant = cases[name]
+    LB, LT, LW = OracleModel(data, variant).cholesky()
+    aT, aB = data["mu_b_T_scale"] / data["random_walk_scale"], data["polling_bias_scale"] / data["random_walk_scale"]
+    scale = np.abs(LW).max()
+    assert np.abs(LT - aT * LW).max() <= 4e-15 * aT * scale
+    assert np.abs(LB - aB * LW).max() <= 4e-15 * aB * scale
+    # ... and what the device does with it: L_T z_T + L_B z_b + L_W c = L_W (aT z_T + aB z_b + c), to rounding
+    rng = np.random.default_rng(7)
+    zT, zb, c = rng.standard_normal((3, LW.shape[0]))
+    lhs, rhs = LT @ zT + LB @ zb + LW @ c, LW @ (aT * zT + aB * zb + c)
+    assert np.abs(lhs - rhs).max() <= 1e-14 * np.abs(lhs).max()
+
+
 def test_sampler_small_posterior(cases):
     """Adaptive NUTS on the small case: sane adaptation, R-hat ~ 1, literal == fast trajectories."""
     from us_potus_model_amd import diagnostics as dg
