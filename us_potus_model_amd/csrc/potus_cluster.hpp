@@ -62,6 +62,11 @@
 #ifndef CL_LDS_BARRIERS
 #define CL_LDS_BARRIERS 0                // 1: the barriers of the pass behind which only LDS is shared wait for LDS only (see PASS_BARRIER); measured neutral (17.37 against 17.43 us), off
 #endif
+#ifndef CL_DOT_PIPE
+#define CL_DOT_PIPE 0                    // 1 (fixed build, one lane per poll): the 51-term dot of the poll phase in batches of eight terms, the next batch's LDS reads issued
+#endif                                   //    before the current batch's products (same products, same order of additions).  Prepared at the end of round 4 from the per-wave
+                                         //    profile (the dot is 1.96 k of the poll wave's 4.1 k cycles, each batch of 32 reads waited for in full).  Measured: 16.80 / 13.76 us per leapfrog against
+                                         //    16.68 / 13.52 -- slower (same draws bit for bit): the verdict wave (3.9 k) ends the phase either way.  Off
 #ifndef CL_G_EXCHANGE
 #define CL_G_EXCHANGE 0                  // 1 (fixed build only): the members exchange the per-state sums of their polls' residuals g_m (52 words, right after the poll
 #endif                                   //    phase) instead of the adjoint prefix totals pre_m = L_W' g_m (after gather and pick-up); the prefix and the total over the
@@ -1237,7 +1242,27 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         const int t = d0 + tl;
         ldp L0 = Lw + s * SP, C0 = C + tl;
         double a0 = 0.0, a1 = 0.0;
-        if constexpr (LPP == 1) {
+        if constexpr (LPP == 1 && FX && CL_DOT_PIPE) {
+          constexpr int NBT = 8, NBATCH = (ClFixed::S + NBT - 1) / NBT;
+          double l[2][NBT], c[2][NBT];
+#pragma unroll
+          for (int j = 0; j < NBT; j++) { l[0][j] = L0[j]; c[0][j] = C0[j * NDP]; }
+#pragma unroll
+          for (int b = 0; b < NBATCH; b++) {
+            const int cur = b & 1, nxt = cur ^ 1, kn = (b + 1) * NBT;
+            if (b + 1 < NBATCH) {
+#pragma unroll
+              for (int j = 0; j < NBT; j++) { const int kk = kn + j < ClFixed::S ? kn + j : ClFixed::S - 1; l[nxt][j] = L0[kk]; c[nxt][j] = C0[kk * NDP]; }
+            }
+            ISSUE_FENCE();
+#pragma unroll
+            for (int j = 0; j < NBT; j += 2) {             // (sixteen-term batches of the other path: a0 takes the even terms, a1 the odd ones, in ascending order -- as here)
+              const int k = b * NBT + j;
+              a0 += (k < ClFixed::S ? l[cur][j] : 0.0) * c[cur][j];
+              a1 += (k + 1 < ClFixed::S ? l[cur][j + 1] : 0.0) * c[cur][j + 1];
+            }
+          }
+        } else if constexpr (LPP == 1) {
           int k0 = 0;
           for (; k0 + 16 <= S; k0 += 16) {               // 51-term dot, sixteen terms in flight
             double l[16], c[16];
