@@ -387,8 +387,16 @@ def main():
         td0 = time.perf_counter()
         if ns >= 8 and full.is_cuda:
             from us_potus_model_amd import device_diagnostics_of_block
-            rh, es = device_diagnostics_of_block(full.contiguous())
-            dev_diag.append({"rhat": rh, "ess_bulk": es, "seconds": time.perf_counter() - td0, "columns": int(full.shape[2]), "S": S})
+            ncols_all = int(full.shape[2])
+            if world == 1:
+                rh, es = device_diagnostics_of_block(full.contiguous())
+            else:
+                # every rank holds the pooled chains; each sorts its 1/world share of the columns (per-GPU work stays what it is at
+                # N = 1: world x the draws, 1/world of the columns) and the per-column results are gathered
+                ca, cb = parallel.column_block(ncols_all, rank, world)
+                rh_l, es_l = device_diagnostics_of_block(full[:, :, ca:cb].contiguous()) if cb > ca else (np.zeros(0), np.zeros(0))
+                rh, es = parallel.all_gather_columns(rh_l, ncols_all, coll_dev), parallel.all_gather_columns(es_l, ncols_all, coll_dev)
+            dev_diag.append({"rhat": rh, "ess_bulk": es, "seconds": time.perf_counter() - td0, "columns": ncols_all, "S": S})
         else:
             dev_diag.append(None)
         sel = torch.cat([full[:, :, :1], full[:, :, 1 + ncol - S:]], dim=2)   # lp__ and mu_b[:, T]

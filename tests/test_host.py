@@ -151,6 +151,14 @@ w8, ev = np.array([0.1, 0.2, 0.3, 0.4]), np.array([100.0, 150.0, 200.0, 88.0])
 a = posterior_summary(got.reshape(-1, 3, 4), w8, ev)
 b = posterior_summary(allps.reshape(-1, 3, 4), w8, ev)
 assert all(np.array_equal(a[k], b[k]) for k in a)
+# convergence diagnostics of the pooled block: the columns are dealt to the ranks, the per-column results gathered (bench.py, N > 1)
+ncol = 11
+ca, cb = parallel.column_block(ncol, rank, world)
+assert (ca, cb) == ((0, 6) if rank == 0 else (6, 11))
+res = parallel.all_gather_columns(np.arange(ca, cb, dtype=np.float64) * 1.5, ncol, None)
+assert np.array_equal(res, np.arange(ncol) * 1.5)
+one = parallel.all_gather_columns(np.full(1, 7.0) if rank == 0 else np.zeros(0), 1, None)        # (a rank without columns still takes part)
+assert one.shape == (1,) and one[0] == 7.0
 assert parallel.max_over_ranks(float(rank)) == world - 1
 assert parallel.sum_over_ranks(1.0) == world
 parallel.barrier()

@@ -89,6 +89,41 @@ def all_gather_chains(local, device=None):
     return out.permute(1, 0, 2, 3).reshape(x.shape[0], world * x.shape[1], x.shape[2])
 
 
+def column_block(n_columns: int, rank: int, world: int):
+    """The columns whose convergence diagnostics rank `rank` computes: a contiguous 1/world share [a, b) of the pooled block's columns.
+    Every rank holds the pooled chains after the all-gather; sorting every column on every rank would make the per-GPU work grow with
+    the number of GPUs (world x the draws per column), so the columns are dealt out and only the results travel (all_gather_columns)."""
+    off, n = chain_block(n_columns, rank, world)
+    return off, off + n
+
+
+def all_gather_columns(local, n_columns: int, device=None):
+    """Per-column results (1-D float64 numpy array of this rank's column_block) from every rank -> [n_columns] on every rank."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return np.asarray(local, dtype=np.float64)
+    world = dist.get_world_size()
+    w_max = -(-n_columns // world)
+    buf = torch.zeros(w_max, dtype=torch.float64, device=device)
+    loc = np.asarray(local, dtype=np.float64)
+    if loc.size:
+        buf[: loc.size] = torch.as_tensor(loc, dtype=torch.float64, device=device)
+    if device is None:
+        out = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(out, buf)
+        rows = [o.numpy() for o in out]
+    else:
+        out = torch.empty((world, w_max), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(out, buf)
+        rows = list(out.cpu().numpy())
+    parts = []
+    for r in range(world):
+        a, b = column_block(n_columns, r, world)
+        parts.append(rows[r][: b - a])
+    return np.concatenate(parts)
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_initialized():
