@@ -197,7 +197,12 @@ def test_bench_bookkeeping_on_the_committed_profiles():
     one, two = bench.measured_traffic("k_cl_run", 1), bench.measured_traffic("k_cl_run", 2)
     assert one and two and one[0] != two[0] and "two clusters" in two[1]["command"] and "two clusters" not in one[1]["command"]
     assert 0.5 < one[1]["hbm_bytes_per_leapfrog"] / 844784 < 0.8 and 0.9 < two[1]["hbm_bytes_per_leapfrog"] / 844784 < 1.3
-    line = json.loads([ln for ln in (ROOT / "profiles" / "r03_bench_line.json").read_text().splitlines() if ln.startswith("{")][0])
+    for committed in ("r03_bench_line.json", "r04b_bench_line.json"):
+        _check_committed_bench_line(json.loads([ln for ln in (ROOT / "profiles" / committed).read_text().splitlines() if ln.startswith("{")][0]),
+                                    device_diagnostics=committed.startswith("r04"))
+
+
+def _check_committed_bench_line(line, device_diagnostics):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
         assert k in line, k
@@ -212,6 +217,9 @@ def test_bench_bookkeeping_on_the_committed_profiles():
     assert sc["ess_per_sec_measured"] > 0 and sc["gpu"]["ess_per_sec_measured"] > sc["ess_per_sec_measured"] and cb["ess_per_sec_measured"] == sc["ess_per_sec_measured"]
     assert abs(line["speedup_vs_cpu_port"] - line["value"] / cb["value"]) < 1e-9 and line["speedup_vs_cpu_leapfrog_loop"] < line["speedup_vs_cpu_port"]
     assert line["config"]["all_gather_bytes_per_rank"] == 1000 * 8 * (1 + 51 * 254) * 8            # lp__ + all of mu_b
+    if device_diagnostics:                                                                          # round 4: R-hat / ESS of every gathered column on the device
+        dd = line["config"]["posteriors"]["2016"]["device_diagnostics"]
+        assert dd["columns"] == 1 + 51 * 254 and dd["ess_bulk_min_all_columns"] > 100 and dd["rhat_max_all_columns"] < 1.05
 
 
 def test_layout_plan_for_every_chain_count():
