@@ -62,6 +62,15 @@
 #ifndef CL_LDS_BARRIERS
 #define CL_LDS_BARRIERS 0                // 1: the barriers of the pass behind which only LDS is shared wait for LDS only (see PASS_BARRIER); measured neutral (17.37 against 17.43 us), off
 #endif
+#ifndef CL_SKIP_OOB
+#define CL_SKIP_OOB 0                    // 1: memory instructions whose lanes are ALL out of range are not issued (wave-uniform branches around them) instead of being
+#endif                                   //    sent with idle offsets.  An instruction costs the compute unit's address unit ~70 cycles whatever its lanes do
+                                         //    (scripts/micro/xfetch.hip; sixteen idle loads: 1.1 k cycles), and a leaf carries ~120 of them: the X1 words of seven waves in
+                                         //    front of the X1 / X3 fetches of phase B, the idle waves' element epilogue in phase C, idle slot stores and small-slot
+                                         //    operands in front of the prefix fetch of phase F, the pair-check operands of leaves that are not the second of a pair.
+                                         //    (The idle-offset form dates from round 1, when updates of the exchange counter under branches made its scalar offsets
+                                         //    "divergent"; the counter is not touched inside these branches.)  Prepared at the end of round 4 WITHOUT a GPU: compiles,
+                                         //    ISA checked for waits at the joins (none), NOT run -- measure and run the parity suite before switching it on
 #ifndef CL_DOT_PIPE
 #define CL_DOT_PIPE 0                    // 1 (fixed build, one lane per poll): the 51-term dot of the poll phase in batches of eight terms, the next batch's LDS reads issued
 #endif                                   //    before the current batch's products (same products, same order of additions).  Prepared at the end of round 4 from the per-wave
@@ -455,6 +464,7 @@ __device__ __forceinline__ unsigned cl_wide_publish(ldp part, int nv, Xch &x, ld
   PROF_MARK(22);
   {
     const bool ok = w == 0 && lane < nv;
+    if (!CL_SKIP_OOB || w == 0) {
     double p8[PT_NW];
 #pragma unroll
     for (int i = 0; i < PT_NW; i++) p8[i] = part[WP(ok ? lane : 0, i)];
@@ -463,8 +473,9 @@ __device__ __forceinline__ unsigned cl_wide_publish(ldp part, int nv, Xch &x, ld
 #pragma unroll
     for (int i = 0; i < PT_NW; i++) s += p8[i];
     xst(x, ok ? 16u * (unsigned)lane : PT_OOB, s);
+    }
   }
-  if (nv > 64) {                                   // trees deeper than 10 doublings only
+  if (nv > 64 && (!CL_SKIP_OOB || w == 0)) {                                   // trees deeper than 10 doublings only
     const int l = 64 + lane;
     const bool ok = w == 0 && l < nv;
     double s = 0.0;
@@ -694,7 +705,8 @@ struct ClLeapPolicy {
   __device__ __forceinline__ double q_fin(QT &t) { return t.q; }
   __device__ __forceinline__ void g_load(unsigned vo, GT &t) {
     t.p = bld(r, vo, sPH); t.m = bld(r, vo, sM);
-    t.pp = bld(r, fuse1 ? vo : PT_OOB, sPrev);
+    if (!CL_SKIP_OOB || fuse1) t.pp = bld(r, fuse1 ? vo : PT_OOB, sPrev);
+    else t.pp = 0.0;                               // (what an idle load returns)
   }
   template <bool SHARED>
   __device__ __forceinline__ double fin(unsigned vo, double v, double q, const GT &t) {   // returns the next position
@@ -706,7 +718,7 @@ struct ClLeapPolicy {
     if (SHARED) bst_s(r, vo, sQn, qn);
     else bst(r, vo, sQn, qn);
     const double rs = t.pp + pf;
-    bst(r, fuse1 ? vo : PT_OOB, sOut1, rs);
+    if (!CL_SKIP_OOB || fuse1) bst(r, fuse1 ? vo : PT_OOB, sOut1, rs);
     extra[0] += t.m * pf * pf;                    // masked-off elements loaded m = 0
     extra[1] += t.m * t.pp * rs;
     extra[2] += t.m * pf * rs;
@@ -959,7 +971,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     double tot = 0.0;
 #pragma unroll
     for (int w2 = 0; w2 < PT_NW; w2++) tot += Y[w2 * SE + (lane < S ? lane : S)];
-    xst(x, (w == 0 && lane < S && x.x1e == 0) ? 16u * (unsigned)lane : PT_OOB, tot);   // no branch around the store
+    if (!CL_SKIP_OOB || (w == 0 && x.x1e == 0)) xst(x, (w == 0 && lane < S && x.x1e == 0) ? 16u * (unsigned)lane : PT_OOB, tot);   // (CL_SKIP_OOB: wave-uniform)
   }
   x.epoch += x.x1e == 0 ? 1u : 0u;                // X1 is on its way (or was sent by the previous pass)
   const unsigned x1tag = x.x1e ? x.x1e : x.epoch;
@@ -1222,7 +1234,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     // posteriors (45-148 polls) spread their polls over three to five waves instead of one to three.
     constexpr int LPP = CL_LPP, PPW = 64 / LPP, PPT = PT_THREADS / LPP;
     const int sub = tid & (LPP - 1);
-    const bool no_polls_here = w == PT_NW - 2 && pend.n >= 0 && np <= PPW * w;   // the verdict wave, when it has no polls: skip the (idle) trip
+    const bool no_polls_here = (CL_SKIP_OOB || (w == PT_NW - 2 && pend.n >= 0)) && np <= PPW * w;   // the verdict wave (CL_SKIP_OOB: any wave), when it has no polls: skip the (idle) trip
     for (int i0 = 0; i0 < (no_polls_here ? 0 : np); i0 += PPT) {               // one trip unless a member has more than 512 / CL_LPP polls
       const int il = i0 + tid / LPP;
       const bool ok = il < np, lead = ok && sub == 0;
@@ -1632,7 +1644,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // over ALL the polls = the sum over the members of the prefix totals published here (the polls of the last day included: they
   // take their real row of the factor in the gather, and the prefix of that day is not used, stan:86).  So the owners of those
   // slots add up the words XP_PRE + k instead of partial transposed mat-vecs, which rounds 1-3 computed here on six waves.
-  xst(x, (w == 0 && lane < S && !GX && (MF || !CL_PRE_EARLY)) ? 16u * (unsigned)(XP_PRE + lane) : (w == 1 && full && lane < 5) ? 16u * (unsigned)(XP_AR + lane) : PT_OOB, pay);
+  if (!CL_SKIP_OOB || w <= 1) xst(x, (w == 0 && lane < S && !GX && (MF || !CL_PRE_EARLY)) ? 16u * (unsigned)(XP_PRE + lane) : (w == 1 && full && lane < 5) ? 16u * (unsigned)(XP_AR + lane) : PT_OOB, pay);
 #if CL_E2_BARRIER == 1
   WAVE_ARRIVE(6);
   __syncthreads();
@@ -1650,6 +1662,8 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     for (int h = 0; h < 2; h++) {
       const int rr = tid + h * PT_THREADS;
       const bool ok = rr >= 2 * S && rr < NR;
+      const int rr0 = 64 * w + h * PT_THREADS;       // the wave's first slot of this round
+      if (CL_SKIP_OOB && (rr0 + 63 < 2 * S || rr0 >= NR)) continue;   // wave-uniform: none of its lanes has a slot
       const double vp = s_P[ok ? rr : 2 * S];
       xst(x, ok ? 16u * (unsigned)(XP_P + rr) : PT_OOB, vp);
     }
@@ -1667,8 +1681,9 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   const bool repl = (jr >= 0 && jr < nro) || is_mue || is_rho;
   const int rslot = is_mue ? NR - 2 : is_rho ? NR - 1 : (repl ? r0 + jr : 0);
   const unsigned vo_x = arl ? 8u * (unsigned)(e_ze + nd - 1 - lane) : repl ? 8u * (unsigned)(e_rep + rslot - r0) : PT_OOB;
-  typename Pol::GT gx;
-  pol.g_load(vo_x, gx);
+  typename Pol::GT gx{};
+  const bool own_any = !CL_SKIP_OOB || __any(arl || repl);   // wave-uniform: some lane of the wave owns an element besides the S x T block
+  if (own_any) pol.g_load(vo_x, gx);
   const double scale_r = cst.scale_r;
   x.epoch++;
 
@@ -1750,11 +1765,11 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     lp += repl ? dl : 0.0;
     own_g = gv; own_q = qv;
   }
-  {
+  if (own_any) {
     const double qn_own = pol.gs_fin(vo_x, own_g, own_q, gx);   // outside the branches (vo_x is out of range for non-owners)
     // ... and sent ahead to the members that evaluate the next position (word XQ0 + index of the small parameter)
     const int jrep = arl ? NR + d0 + (nd - 1 - lane) : rslot;
-    xst(x, (pubnext && (arl || repl)) ? 16u * (unsigned)(XQ0 + jrep) : PT_OOB, qn_own);
+    if (!CL_SKIP_OOB || pubnext) xst(x, (pubnext && (arl || repl)) ? 16u * (unsigned)(XQ0 + jrep) : PT_OOB, qn_own);
   }
   }
   // CL_F_LATE: one look at the AR(1) composites / slot partials before the barrier; what is missing is fetched after the day-block epilogue
@@ -1870,17 +1885,17 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     lp += repl ? dl : 0.0;
     own_g = gv; own_q = qv;
   }
-  {
+  if (own_any) {
     const double qn_own = pol.gs_fin(vo_x, own_g, own_q, gx);   // outside the branches (vo_x is out of range for non-owners)
     const int jrep = arl ? NR + d0 + (nd - 1 - lane) : rslot;
-    xst(x, (pubnext && (arl || repl)) ? 16u * (unsigned)(XQ0 + jrep) : PT_OOB, qn_own);
+    if (!CL_SKIP_OOB || pubnext) xst(x, (pubnext && (arl || repl)) ? 16u * (unsigned)(XQ0 + jrep) : PT_OOB, qn_own);
   }
   }
   {
     double tot = 0.0;
 #pragma unroll
     for (int w2 = 0; w2 < PT_NW; w2++) tot += Y[w2 * SE + (lane < S ? lane : S)];
-    xst(x, (pubnext && w == 0 && lane < S) ? 16u * (unsigned)lane : PT_OOB, tot);
+    if (!CL_SKIP_OOB || (pubnext && w == 0)) xst(x, (pubnext && w == 0 && lane < S) ? 16u * (unsigned)lane : PT_OOB, tot);
     x.epoch += pubnext ? 1u : 0u;
     x.x1e = pubnext ? x.epoch : 0u;
   }
