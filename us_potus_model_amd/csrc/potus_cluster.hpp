@@ -69,8 +69,8 @@
                                          //    front of the X1 / X3 fetches of phase B, the idle waves' element epilogue in phase C, idle slot stores and small-slot
                                          //    operands in front of the prefix fetch of phase F, the pair-check operands of leaves that are not the second of a pair.
                                          //    (The idle-offset form dates from round 1, when updates of the exchange counter under branches made its scalar offsets
-                                         //    "divergent"; the counter is not touched inside these branches.)  Prepared at the end of round 4 WITHOUT a GPU: compiles,
-                                         //    ISA checked for waits at the joins (none), NOT run -- measure and run the parity suite before switching it on
+                                         //    "divergent"; the counter is not touched inside these branches.)  Measured at the very end of round 4: 13.59 against 13.49 us
+                                         //    per leapfrog with two clusters per chain, same draws, lp / gradient parity green -- neutral to slightly slower.  Off
 #ifndef CL_DOT_PIPE
 #define CL_DOT_PIPE 0                    // 1 (fixed build, one lane per poll): the 51-term dot of the poll phase in batches of eight terms, the next batch's LDS reads issued
 #endif                                   //    before the current batch's products (same products, same order of additions).  Prepared at the end of round 4 from the per-wave
