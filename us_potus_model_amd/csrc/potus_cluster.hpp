@@ -36,94 +36,8 @@
 #define CL_MAXK 32
 #define CL_DW4_MAXAVG 26                 // days per member on average up to which the 4-days-per-wave build of the pass is used
 #define CL_AUX_SC1 16                    // cache-policy bit of the buffer intrinsics: sc1 (agent scope)
-#ifndef CL_AUX_LD
-#define CL_AUX_LD CL_AUX_SC1             // policy of the exchange reader's loads
-#endif
-// experiments on the fixed build (all measured slower together: r03_cl_fixed_layout_build.txt); 0 = off
-#ifndef CL_FX_FULL
-#define CL_FX_FULL 1                     // the fixed build serves the full model only: `full` is a constant there (-4.6 % / -1.3 %)
-#endif
-#ifndef CL_FX_K16
-#define CL_FX_K16 0
-#endif
-#ifndef CL_FX_XW
-#define CL_FX_XW 0
-#endif
-#ifndef CL_FX_BATCH
-#define CL_FX_BATCH 0
-#endif
-#ifndef CL_X1_IN_A
-#define CL_X1_IN_A 0                     // 1: the suffix totals sent ahead by the previous leaf are fetched in phase A (see there; measured slower)
-#endif
-#ifndef CL_FAST_BINOMIAL
-#define CL_FAST_BINOMIAL 0               // 1: the binomial term's exp / log1p / division by d_exp_neg / d_log1p_recip (potus_model.hpp) instead of the library's: same
-                                         //    accuracy, a third of the instructions -- and no faster (14.04 against 14.08 us, 17.9 against 17.5 with one cluster): off
-#endif
-#ifndef CL_LDS_BARRIERS
-#define CL_LDS_BARRIERS 0                // 1: the barriers of the pass behind which only LDS is shared wait for LDS only (see PASS_BARRIER); measured neutral (17.37 against 17.43 us), off
-#endif
-#ifndef CL_SKIP_OOB
-#define CL_SKIP_OOB 0                    // 1: memory instructions whose lanes are ALL out of range are not issued (wave-uniform branches around them) instead of being
-#endif                                   //    sent with idle offsets.  An instruction costs the compute unit's address unit ~70 cycles whatever its lanes do
-                                         //    (scripts/micro/xfetch.hip; sixteen idle loads: 1.1 k cycles), and a leaf carries ~120 of them: the X1 words of seven waves in
-                                         //    front of the X1 / X3 fetches of phase B, the idle waves' element epilogue in phase C, idle slot stores and small-slot
-                                         //    operands in front of the prefix fetch of phase F, the pair-check operands of leaves that are not the second of a pair.
-                                         //    (The idle-offset form dates from round 1, when updates of the exchange counter under branches made its scalar offsets
-                                         //    "divergent"; the counter is not touched inside these branches.)  Measured at the very end of round 4: 13.59 against 13.49 us
-                                         //    per leapfrog with two clusters per chain, same draws, lp / gradient parity green -- neutral to slightly slower.  Off
-#ifndef CL_DOT_PIPE
-#define CL_DOT_PIPE 0                    // 1 (fixed build, one lane per poll): the 51-term dot of the poll phase in batches of eight terms, the next batch's LDS reads issued
-#endif                                   //    before the current batch's products (same products, same order of additions).  Prepared at the end of round 4 from the per-wave
-                                         //    profile (the dot is 1.96 k of the poll wave's 4.1 k cycles, each batch of 32 reads waited for in full).  Measured: 16.80 / 13.76 us per leapfrog against
-                                         //    16.68 / 13.52 -- slower (same draws bit for bit): the verdict wave (3.9 k) ends the phase either way.  Off
-#ifndef CL_G_EXCHANGE
-#define CL_G_EXCHANGE 0                  // 1 (fixed build only): the members exchange the per-state sums of their polls' residuals g_m (52 words, right after the poll
-#endif                                   //    phase) instead of the adjoint prefix totals pre_m = L_W' g_m (after gather and pick-up); the prefix and the total over the
-                                         //    members go through L_W' locally, on waves that idle in phases E / E2: phase F starts without an exchange
-#define CL_NSTBCAP 4                     // per-state poll lists of a member: batches of sixteen per (pseudo-)state the fixed layout holds
-#ifndef CL_PRE_EARLY
-#define CL_PRE_EARLY 0                   // 1: a member's adjoint prefix totals (words XP_PRE of X2) are published in phase E, as soon as wave 0 has them, instead of
-#endif                                   //    in phase E2 behind the level-2 sums: the hop to the members that own later days overlaps phases E and E2 (walk build)
-#ifndef CL_F_LATE
-#define CL_F_LATE 0                      // 1: in phase F the AR(1) composites and the slot partials are looked at once before the barrier that hands the prefix carry
-#endif                                   //    around; if they are not there yet they are fetched AFTER the day-block epilogue, so that only the prefix gates that barrier
-#ifndef CL_X3_DELAY
-#define CL_X3_DELAY 0                    // s_sleep argument (units of 64 cycles) before the fetch of the previous leaf's totals in phase B
-#endif
-#ifndef CL_XLD_COUNT
-#define CL_XLD_COUNT 0                   // 1: exchange fetches issue only the loads they need (0: always all sixteen, idle ones out of range)
-#endif
-#ifndef CL_WIDE_BY_ROWS
-#define CL_WIDE_BY_ROWS 0                // 1: the leaf's totals are fetched four values x sixteen members per load and summed on the DPP path (0: one load per member)
-#endif
-#ifndef CL_SEG_SHIFT
-#define CL_SEG_SHIFT 64                  // the level-2 segment sums of phase E start at this thread (0: at thread 0)
-#endif
-#ifndef CL_TANGENTS_IN_B
-#define CL_TANGENTS_IN_B 2               // where the AR(1) tangent recurrences and the scalars of rho's prior run: 0: on one wave of phase C; 1: in phase B on idle waves;
-                                         // 2: phase C, the scalars on a second wave.  Measured (profiles/r04_cl_inkernel_cycles.txt): 0: 17.41 / 13.87 us per leapfrog with
-                                         // one / two clusters per chain, 1: 17.21 / 14.34, 2: 16.69 / 13.42 (with CL_SEG_SHIFT = 64 each)
-#endif
-#ifndef CL_LPP
-#define CL_LPP 1                         // lanes sharing one poll's 51-term dot in phase C (1, 2 or 4)
-#endif
-#ifndef CL_MERGE_CHAIN
-#define CL_MERGE_CHAIN 1                 // the merges of levels 2 .. m of a leaf in one sweep, rho carried in registers (cl_vop_merge_chain)
-#endif
-#ifndef CL_VERDICT_IN_D
-#define CL_VERDICT_IN_D 0                // 1: the previous leaf's totals are fetched in phase C (idle wave) and its verdicts taken in phase D, on the last wave,
-                                         //    which then has no chunk of the adjoint gather (CL_NCHUNK = PT_NW - 1): neither phase B nor phase C carries them
-#endif
-#define CL_NCHUNK (CL_VERDICT_IN_D ? PT_NW - 1 : PT_NW)   // chunks the member's polls are cut into for the adjoint gather (host: build_cluster)
-#ifndef CL_X3_IN_B
-#define CL_X3_IN_B (CL_VERDICT_IN_D ? 0 : 1)                     // 1: the previous leaf's totals are collected in phase B by a wave that is done early there (see phase C)
-#endif
-#ifndef CL_E2_BARRIER
-#define CL_E2_BARRIER 0
-#endif
-#ifndef CL_VC
-#define CL_VC 0                          // 1: no separate carry step between phases B and C (the later members' suffix totals enter through vc[s], see phase B); measured slower: the fetch wave also carries the 52 x 51 product (profiles/r04_cl_fold.txt)
-#endif
+#define CL_NCHUNK PT_NW                  // chunks the member's polls are cut into for the adjoint gather (host: build_cluster)
+#define CL_SEG_SHIFT 64                  // the level-2 segment sums of phase E start at this thread: wave 0 turns the chunk totals into prefixes there
 #define CL_SPIN_LIMIT 8000000u
 #ifndef CL_SPIN_SLEEP
 #define CL_SPIN_SLEEP 1                  // s_sleep argument between two looks at an exchange word that has not arrived
@@ -131,7 +45,7 @@
 
 // fields of one member's part descriptor (ints)
 enum { CP_D0 = 0, CP_ND, CP_P0, CP_NP, CP_E0, CP_NE, CP_R0, CP_NR, CP_NSUB, CP_NSEG, CP_WB,
-       CP_O_WD, CP_O_MASK, CP_O_SUB, CP_O_SEGPTR, CP_O_SEGKIND, CP_O_SEGIDX, CP_O_WT, CP_E_SH, CP_NCELL, CP_O_CELL, CP_NSTB, CP_O_STL, CP_N = 24 };
+       CP_O_WD, CP_O_MASK, CP_O_SUB, CP_O_SEGPTR, CP_O_SEGKIND, CP_O_SEGIDX, CP_O_WT, CP_E_SH, CP_NCELL, CP_O_CELL, CP_N = 24 };
 #define CL_CELLS_PER_THREAD 2            // (state, day) cells of a member's polls per thread in the adjoint scatter (<= 1024 cells)
 #define CL_G_PAD 16                      // spare doubles behind G: the dump slot of idle scatter threads
 // payload layout of exchange X2 (doubles); X1 and the scalar all-reduces use the first words
@@ -150,7 +64,7 @@ struct ClModel {
   const double *rep_scale;  // [NR] scale of owned slot r (sigma_c ... ; 1 for zT, zb)
   const int *perm;          // [D] internal index -> Stan index
   int GS, GROWS;            // adjoint on the matrix cores (cl_adjoint_mfma): G[pseudo-state][local day], row stride, rows (l_G = 0: gather walk)
-  int l_C, l_G, l_Lw, l_prior, l_pm, l_py, l_pun, l_sub, l_tab, l_ru, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_e, l_c1, l_c2, l_c3, l_ge, l_P, l_scal, l_red, l_st, l_prof, l_stl, l_gx;
+  int l_C, l_G, l_Lw, l_prior, l_pm, l_py, l_pun, l_sub, l_tab, l_ru, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_e, l_c1, l_c2, l_c3, l_ge, l_P, l_scal, l_red, l_st, l_prof;
   int lds_doubles;
 };
 typedef const ClModel AS_C *CCp;
@@ -159,11 +73,11 @@ typedef const ClModel AS_C *CCp;
 // A member's LDS layout (offsets in doubles) as ONE function of the capacities, used by the host for the dynamic builds
 // (build_cluster: the posterior's own sizes) and at compile time for the fixed build below -- the two cannot drift apart.
 struct ClLay {
-  int l_C, l_G, l_Lw, l_prior, l_pm, l_py, l_pun, l_sub, l_tab, l_ru, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_e, l_c1, l_c2, l_c3, l_ge, l_P, l_scal, l_red, l_st, l_prof, l_stl, l_gx;
+  int l_C, l_G, l_Lw, l_prior, l_pm, l_py, l_pun, l_sub, l_tab, l_ru, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_e, l_c1, l_c2, l_c3, l_ge, l_P, l_scal, l_red, l_st, l_prof;
   int total;
 };
 constexpr int cl_ev(int n) { return (n + 1) & ~1; }   // LDS blocks start on 16-byte boundaries
-constexpr ClLay cl_layout(int S, int SE, int SP, int NDP, int npcap, int nsubcap, int nrepcap, int nrcap, int tcap, int g_doubles, int nstbcap = 0) {
+constexpr ClLay cl_layout(int S, int SE, int SP, int NDP, int npcap, int nsubcap, int nrepcap, int nrcap, int tcap, int g_doubles) {
   ClLay L{};
   int o = 0;
   L.l_C = o; o += cl_ev(S * NDP);                         // C[state][local day]: suffix sums, then the adjoint's running sums
@@ -193,9 +107,6 @@ constexpr ClLay cl_layout(int S, int SE, int SP, int NDP, int npcap, int nsubcap
   L.l_red = o; o += cl_ev((PT_NW + 1) * PT_NRED);
   L.l_st = o; o += cl_ev((npcap + 8 + 7) / 8);
   L.l_prof = o; o += cl_ev(PT_NPROF);
-  // CL_G_EXCHANGE: per-state poll lists (a batch = 64 lanes x 16 entries of 16 bits) | G prefix [64], G total [64], partial products [4][2][64]
-  L.l_stl = nstbcap ? o : 0; o += cl_ev(nstbcap * 256);
-  L.l_gx = nstbcap ? o : 0; o += cl_ev(nstbcap ? 640 : 0);
   L.total = o;
   return L;
 }
@@ -213,10 +124,10 @@ struct ClFixed {
   static constexpr int XW = 832;                     // exchange words per member: max(XP_P + NRCAP, XQ0 + NREPCAP) = max(72 + 512, 64 + 768)
   // and the full model (poll_model_2020.stan: mode / population effects, AR(1) bias); the no_mode_adjustment variant takes the dynamic build
   static constexpr int GS = 48, GROWS = 52;
-  static constexpr ClLay L = cl_layout(S, SE, SP, NDP, NPCAP, NSUBCAP, NREPCAP, NRCAP, TCAP, 0, CL_G_EXCHANGE ? CL_NSTBCAP : 0);
+  static constexpr ClLay L = cl_layout(S, SE, SP, NDP, NPCAP, NSUBCAP, NREPCAP, NRCAP, TCAP, 0);
 #define CLF(f) static constexpr int f = L.f
   CLF(l_C); CLF(l_G); CLF(l_Lw); CLF(l_prior); CLF(l_pm); CLF(l_py); CLF(l_pun); CLF(l_sub); CLF(l_tab); CLF(l_ru); CLF(l_wide); CLF(l_wout); CLF(l_X); CLF(l_Y);
-  CLF(l_r); CLF(l_rep); CLF(l_bT); CLF(l_e); CLF(l_c1); CLF(l_c2); CLF(l_c3); CLF(l_ge); CLF(l_P); CLF(l_scal); CLF(l_red); CLF(l_st); CLF(l_prof); CLF(l_stl); CLF(l_gx);
+  CLF(l_r); CLF(l_rep); CLF(l_bT); CLF(l_e); CLF(l_c1); CLF(l_c2); CLF(l_c3); CLF(l_ge); CLF(l_P); CLF(l_scal); CLF(l_red); CLF(l_st); CLF(l_prof);
 #undef CLF
   static constexpr int lds_doubles = L.total;
 };
@@ -284,14 +195,6 @@ __shared__ int cl_dead;
 // statement that names the data registers so that nothing can be scheduled onto them before it;
 // scripts/check_store_hazard.py scans every build for the shape (tests/test_code_object.py).
 #define STORE128_PAD(w) asm volatile("s_nop 1" :: "v"(w) : "memory")
-#ifndef CL_SEAL
-#define CL_SEAL 0
-#endif
-#if CL_SEAL
-#define XCH_SEAL(launch, lo, hi) ((launch) ^ (lo) ^ (((hi) << 7) | ((hi) >> 25)))   // experiment: the fourth dword also vouches for the value's two dwords
-#else
-#define XCH_SEAL(launch, lo, hi) (launch)
-#endif
 struct Xch {
   rsrc_t xb;               // the chain's exchange buffer [4][K][XW] words of 16 bytes (+ the watchdog word)
   unsigned epoch;          // exchanges published so far in this launch (identical in every member)
@@ -317,7 +220,7 @@ __device__ __forceinline__ void xch_give_up(const Xch &x) {
 // publish one word of the exchange being assembled (voff = 16 * word, or PT_OOB for idle lanes)
 __device__ __forceinline__ void xst(const Xch &x, unsigned voff, double v) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-  const u32x4 w = {(unsigned)u, (unsigned)(u >> 32), x.epoch + 1u, XCH_SEAL(x.launch, (unsigned)u, (unsigned)(u >> 32))};
+  const u32x4 w = {(unsigned)u, (unsigned)(u >> 32), x.epoch + 1u, x.launch};
   // (soffset through readfirstlane: the exchange counter ends up in a vector register wherever it was updated under a
   // branch whose condition came out of LDS, and a "divergent" scalar offset costs a waterfall loop around every access)
   __builtin_amdgcn_raw_buffer_store_b128(w, x.xb, voff, __builtin_amdgcn_readfirstlane(xch_wslot(x, x.m)), CL_AUX_SC1);
@@ -325,11 +228,8 @@ __device__ __forceinline__ void xst(const Xch &x, unsigned voff, double v) {
 }
 // fetch NB words of the exchange just published (per-lane byte offsets vo, PT_OOB = idle lane -> 0;
 // uniform slot offsets so); spins until every tag of the wave matches
-template <int NB, bool TRY = false>
-__device__ __forceinline__ bool xld(const Xch &x_in, const unsigned (&vo)[NB], const unsigned (&so)[NB], double (&out)[NB], unsigned tag = 0, ldp xprof = nullptr, int n = NB) {
-  // TRY: one round only; returns whether every word was there (out is meaningful only then)
-  // n (wave-uniform): only the first n loads are issued -- a load instruction costs the compute unit's address unit ~70 cycles even when
-  // every lane is out of range (scripts/micro/xfetch.hip), and the fetches of a member's waves queue behind each other there
+template <int NB>
+__device__ __forceinline__ bool xld(const Xch &x_in, const unsigned (&vo)[NB], const unsigned (&so)[NB], double (&out)[NB], unsigned tag = 0, ldp xprof = nullptr) {
   Xch x = x_in;
   if (tag) x.epoch = tag;                          // an exchange other than the latest one
   x.epoch = __builtin_amdgcn_readfirstlane(x.epoch); x.launch = __builtin_amdgcn_readfirstlane(x.launch);
@@ -340,28 +240,17 @@ __device__ __forceinline__ bool xld(const Xch &x_in, const unsigned (&vo)[NB], c
 #endif
   u32x4 w[NB];
   bool done[NB];                                   // wave-uniform
-#ifdef CL_LD_INV
-  asm volatile(CL_LD_INV ::: "memory");
-#endif
 #pragma unroll
-  for (int u = 0; u < NB; u++) {
-    if (CL_XLD_COUNT == 0 || u < n) w[u] = __builtin_amdgcn_raw_buffer_load_b128(x.xb, vo[u], __builtin_amdgcn_readfirstlane(so[u]), CL_AUX_LD);
-    else w[u] = u32x4{0u, 0u, 0u, 0u};
-  }
+  for (int u = 0; u < NB; u++) w[u] = __builtin_amdgcn_raw_buffer_load_b128(x.xb, vo[u], __builtin_amdgcn_readfirstlane(so[u]), CL_AUX_SC1);
   bool all = true;
 #pragma unroll
   for (int u = 0; u < NB; u++) {
-    done[u] = (CL_XLD_COUNT != 0 && u >= n) || __all(vo[u] == PT_OOB || (w[u][2] == x.epoch && w[u][3] == XCH_SEAL(x.launch, w[u][0], w[u][1])));
+    done[u] = __all(vo[u] == PT_OOB || (w[u][2] == x.epoch && w[u][3] == x.launch));
     all = all && done[u];
   }
 #ifdef POTUS_PROF_FETCH
   if (xprof && (threadIdx.x & 63) == 0) { xprof[56] += (double)(clock64() - xt0_); xprof[57] += all ? 0.0 : 1.0; }
 #endif
-  if constexpr (TRY) {
-#pragma unroll
-    for (int u = 0; u < NB; u++) out[u] = __hiloint2double((int)w[u][1], (int)w[u][0]);
-    return all;
-  }
   // Words that were not there yet are fetched again (words already in hand are not re-read, so a spinning wave
   // does not flood the memory pipeline).  The re-fetch must stay an agent-scope (sc1) load: the `volatile` flavour of
   // the builtin becomes a system-scope load that costs ~2 us per round here.  What keeps the compiler from hoisting
@@ -373,22 +262,18 @@ __device__ __forceinline__ bool xld(const Xch &x_in, const unsigned (&vo)[NB], c
     if (xprof && (threadIdx.x & 63) == 0) xprof[58] += 1.0;
 #endif
     __builtin_amdgcn_s_sleep(CL_SPIN_SLEEP);
-#ifdef CL_LD_INV
-    asm volatile(CL_LD_INV ::: "memory");
-#else
     asm volatile("" ::: "memory");
-#endif
 #pragma unroll
     for (int u = 0; u < NB; u++)
       if (!done[u]) {
         unsigned v = vo[u];
         asm volatile("" : "+v"(v));
-        w[u] = __builtin_amdgcn_raw_buffer_load_b128(x.xb, v, __builtin_amdgcn_readfirstlane(so[u]), CL_AUX_LD);
+        w[u] = __builtin_amdgcn_raw_buffer_load_b128(x.xb, v, __builtin_amdgcn_readfirstlane(so[u]), CL_AUX_SC1);
       }
     all = true;
 #pragma unroll
     for (int u = 0; u < NB; u++) {
-      if (!done[u]) done[u] = __all(vo[u] == PT_OOB || (w[u][2] == x.epoch && w[u][3] == XCH_SEAL(x.launch, w[u][0], w[u][1])));
+      if (!done[u]) done[u] = __all(vo[u] == PT_OOB || (w[u][2] == x.epoch && w[u][3] == x.launch));
       all = all && done[u];
     }
   }
@@ -464,7 +349,6 @@ __device__ __forceinline__ unsigned cl_wide_publish(ldp part, int nv, Xch &x, ld
   PROF_MARK(22);
   {
     const bool ok = w == 0 && lane < nv;
-    if (!CL_SKIP_OOB || w == 0) {
     double p8[PT_NW];
 #pragma unroll
     for (int i = 0; i < PT_NW; i++) p8[i] = part[WP(ok ? lane : 0, i)];
@@ -473,9 +357,8 @@ __device__ __forceinline__ unsigned cl_wide_publish(ldp part, int nv, Xch &x, ld
 #pragma unroll
     for (int i = 0; i < PT_NW; i++) s += p8[i];
     xst(x, ok ? 16u * (unsigned)lane : PT_OOB, s);
-    }
   }
-  if (nv > 64 && (!CL_SKIP_OOB || w == 0)) {                                   // trees deeper than 10 doublings only
+  if (nv > 64) {                                   // trees deeper than 10 doublings only
     const int l = 64 + lane;
     const bool ok = w == 0 && l < nv;
     double s = 0.0;
@@ -487,86 +370,8 @@ __device__ __forceinline__ unsigned cl_wide_publish(ldp part, int nv, Xch &x, ld
   PROF_MARK(23);
   return x.epoch;
 }
-// One tangent recurrence of the AR(1) bias over all T days, c[t] = rho c[t-1] + in[t], c[0] = 0, with
-//   WHICH = 0: in = 1 (d e / d mu_e_bias),  1: in = d[t-1] = e[t-1] - mu_e (d e / d rho through the recursion),  2: in = z[t] (through sigma_rho):
-// four consecutive days per lane and round of 256, affine scan across lanes on the DPP path; the member keeps its own days (read in phases E2, F).
-// Round 4: the three run on three waves that idle in phase B (until then one wave of phase C did all three plus the logarithms of the prior
-// of rho, 5.4 k cycles, and set the length of that phase: profiles/r04_cl_inkernel_cycles.txt).
-template <int WHICH>
-__device__ __forceinline__ void cl_ar1_tangent(double rho, double mue, ldp ze, ldp s_e, ldp s_c, int T, int d0, int nd) {
-  const int lane = threadIdx.x & 63;
-  constexpr int PER = 4;
-  double c_in = 0.0;
-  for (int base = 0; base < T; base += 64 * PER) {   // one round unless T > 256
-    const int ta = base + lane * PER;
-    double in_[PER];
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-      const int t = ta + u;
-      in_[u] = WHICH == 0 ? 1.0 : WHICH == 1 ? s_e[min(max(t - 1, 0), T - 1)] - mue : ze[min(t, T - 1)];
-    }
-    ISSUE_FENCE();
-    double A2 = 1.0, Bc[1] = {0.0};
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-      const int t = ta + u;
-      const bool in = t < T, first = t == 0;
-      const double An = first ? 0.0 : rho * A2, B1 = first ? 0.0 : rho * Bc[0] + in_[u];
-      A2 = in ? An : A2; Bc[0] = in ? B1 : Bc[0];
-    }
-    dpp_scan_affine(A2, Bc);
-    double c = dpp_prev_lane(A2, 1.0) * c_in + dpp_prev_lane(Bc[0], 0.0);
-#pragma unroll
-    for (int u = 0; u < PER; u++) {
-      const int t = ta + u;
-      const bool first = t == 0, in = t < T;
-      const double n = first ? 0.0 : rho * c + in_[u];
-      c = in ? n : c;
-      if (in && t >= d0 && t < d0 + nd) s_c[t - d0] = c;   // only the member's own days are read
-    }
-    c_in = dpp_readlane_d(c, 63);
-  }
-}
-
 __device__ __forceinline__ void cl_wide_consume(const Xch &x, unsigned tag, int nv, ldp out, ldp xprof = nullptr) {   // one wave
   const int lane = threadIdx.x & 63;
-#if CL_WIDE_BY_ROWS
-  // A load covers four values of sixteen members (lane = 16 * value + member): a leaf that closes m levels needs
-  // ceil((9 + 6 m) / 4) loads instead of sixteen.  The members are summed along the rows of sixteen lanes on the DPP path,
-  // in a fixed tree, so every member of the cluster ends up with the same bits.
-  const int mm = lane & 15, r = lane >> 4;
-  for (int v0 = 0; v0 < nv; v0 += 64) {
-    const int ni = min(16, (nv - v0 + 3) >> 2);
-    double tot[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) tot[u] = 0.0;
-    for (int mm0 = 0; mm0 < x.K; mm0 += 16) {
-      double t16[16];
-      unsigned vo[16], so[16];
-#pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const int v = v0 + 4 * u + r;
-        vo[u] = (mm0 + mm < x.K && v < nv) ? (unsigned)(mm0 + mm) * (unsigned)x.XW * 16u + 16u * (unsigned)v : PT_OOB;
-        so[u] = xch_eslot(x, tag, 0);
-      }
-      xld(x, vo, so, t16, tag, xprof, ni);
-#pragma unroll
-      for (int u = 0; u < 16; u++) tot[u] += t16[u];
-    }
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-      if (u < ni) {                                  // wave-uniform
-        double t = tot[u];
-        t += dpp_fetch<DPP_ROW_SHR(1), 0xf>(0.0, t);
-        t += dpp_fetch<DPP_ROW_SHR(2), 0xf>(0.0, t);
-        t += dpp_fetch<DPP_ROW_SHR(4), 0xf>(0.0, t);
-        t += dpp_fetch<DPP_ROW_SHR(8), 0xf>(0.0, t);
-        const int v = v0 + 4 * u + r;
-        if (mm == 15 && v < nv) out[v] = t;
-      }
-    }
-  }
-#else
   for (int l0 = 0; l0 < nv; l0 += 64) {
     const int l = l0 + lane;
     double tot = 0.0;
@@ -575,13 +380,12 @@ __device__ __forceinline__ void cl_wide_consume(const Xch &x, unsigned tag, int 
       unsigned vo[16], so[16];
 #pragma unroll
       for (int u = 0; u < 16; u++) { const int mm = mm0 + u; vo[u] = (mm < x.K && l < nv) ? 16u * (unsigned)l : PT_OOB; so[u] = xch_eslot(x, tag, mm < x.K ? mm : 0); }
-      xld(x, vo, so, t16, tag, xprof, min(16, x.K - mm0));
+      xld(x, vo, so, t16, tag, xprof);
 #pragma unroll
       for (int u = 0; u < 16; u++) tot += t16[u];
     }
     if (l < nv) out[l] = tot;
   }
-#endif
 }
 
 // What thread 0 needs to take the verdicts of a leaf once its totals are in (base_nuts::build_tree's bookkeeping):
@@ -705,8 +509,7 @@ struct ClLeapPolicy {
   __device__ __forceinline__ double q_fin(QT &t) { return t.q; }
   __device__ __forceinline__ void g_load(unsigned vo, GT &t) {
     t.p = bld(r, vo, sPH); t.m = bld(r, vo, sM);
-    if (!CL_SKIP_OOB || fuse1) t.pp = bld(r, fuse1 ? vo : PT_OOB, sPrev);
-    else t.pp = 0.0;                               // (what an idle load returns)
+    t.pp = bld(r, fuse1 ? vo : PT_OOB, sPrev);
   }
   template <bool SHARED>
   __device__ __forceinline__ double fin(unsigned vo, double v, double q, const GT &t) {   // returns the next position
@@ -718,7 +521,7 @@ struct ClLeapPolicy {
     if (SHARED) bst_s(r, vo, sQn, qn);
     else bst(r, vo, sQn, qn);
     const double rs = t.pp + pf;
-    if (!CL_SKIP_OOB || fuse1) bst(r, fuse1 ? vo : PT_OOB, sOut1, rs);
+    bst(r, fuse1 ? vo : PT_OOB, sOut1, rs);
     extra[0] += t.m * pf * pf;                    // masked-off elements loaded m = 0
     extra[1] += t.m * t.pp * rs;
     extra[2] += t.m * pf * rs;
@@ -824,11 +627,6 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
     const int n16 = part[CP_NSUB] * PT_SUBLEN;
     for (int i = threadIdx.x; i < n16; i += PT_THREADS) sb[i] = (unsigned short)src_sub[i];
   }
-  if (CL->l_stl) {   // CL_G_EXCHANGE: the member's polls by (pseudo-)state
-    unsigned AS_L *dst = (unsigned AS_L *)(lds + CL->l_stl);
-    gcip src_stl = as_g(CL->sched) + part[CP_O_STL];
-    for (int i = threadIdx.x; i < part[CP_NSTB] * 512; i += PT_THREADS) dst[i] = (unsigned)src_stl[i];
-  }
   // G: zero once; the scatter of every pass rewrites the same cells (the poll structure is static), everything else stays zero
   if (CL->l_G) for (int i = threadIdx.x; i < CL->GROWS * CL->GS + CL_G_PAD; i += PT_THREADS) (lds + CL->l_G)[i] = 0.0;
   const ClStatic c = cl_load_static(CL, part);
@@ -844,16 +642,6 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
 // tells it.
 __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// __syncthreads() waits for EVERY outstanding memory operation of the wave before the barrier (s_waitcnt vmcnt(0) lgkmcnt(0)): behind the
-// poll phase that is the acknowledgement of the noise elements' epilogue stores, in phase F that of the write-through exchange
-// words and of the slot epilogue -- 1.5-2 k cycles each, for barriers behind which the waves share nothing but LDS (every global
-// element is read by the thread that wrote it, or after the drain in front of the U-turn sweeps / of the leaf's report,
-// cl_wide_publish).  Those barriers wait for LDS only; stores and loads stay in flight across them.
-#if CL_LDS_BARRIERS
-#define PASS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#else
-#define PASS_BARRIER() __syncthreads()
-#endif
 // ---------------------------------------------------------------- one pass of the member's share
 // Returns the chain's lp in every thread of every member; pol.extra[] are summed alongside.
 // cl_pass_partial returns THIS THREAD's share of lp (and leaves the thread's share of pol.extra[] in
@@ -873,7 +661,6 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // adjoint as a walk over the polls, 12 = four days per wave with the adjoint product on the matrix cores (MF)
   constexpr int CL_DW = ClTag<CL_TAG>::DW;
   constexpr bool MF = ClTag<CL_TAG>::MF, FX = ClTag<CL_TAG>::FX;
-  constexpr bool GX = CL_G_EXCHANGE && FX && !MF;   // see CL_G_EXCHANGE
 #define LAY(f) (FX ? (int)ClFixed::f : CL->f)
   Pol pol = pol_io;
   int tid = threadIdx.x;
@@ -883,11 +670,11 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   cip part = launder_s(part_in);
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if constexpr (FX) { lds = (ldp)lds_dyn; if (CL_FX_XW) x.XW = ClFixed::XW; if (CL_FX_K16) x.K = 16; }   // the LDS base is a link-time constant; the exchange stride a compile-time one (the host uses the same number)
-  const int S = FX ? (int)ClFixed::S : M->S, T = M->T, SE = FX ? (int)ClFixed::SE : M->SE, SP = FX ? (int)ClFixed::SP : M->SP, full = (FX && CL_FX_FULL) ? 1 : M->full, o_c = M->o_c;
+  if constexpr (FX) lds = (ldp)lds_dyn;   // the LDS base is a link-time constant
+  const int S = FX ? (int)ClFixed::S : M->S, T = M->T, SE = FX ? (int)ClFixed::SE : M->SE, SP = FX ? (int)ClFixed::SP : M->SP, full = FX ? 1 : M->full, o_c = M->o_c;
   const int NDP = FX ? (int)ClFixed::NDP : CL->NDP, NR = CL->NR, NREP = CL->NREP;
   const int d0 = part[CP_D0], nd = part[CP_ND], np = part[CP_NP], e0 = part[CP_E0], r0 = part[CP_R0], nr = part[CP_NR];
-  const int K = (FX && CL_FX_K16) ? 16 : x.K, m = x.m;
+  const int K = x.K, m = x.m;
   const int wd0 = __builtin_amdgcn_readfirstlane(cst.wd0), wnd = __builtin_amdgcn_readfirstlane(cst.wnd);
   ldp C = lds + LAY(l_C), Lw = lds + LAY(l_Lw), X = lds + LAY(l_X), Y = lds + LAY(l_Y), r_lds = lds + LAY(l_r), ru_lds = lds + LAY(l_ru);
   ldp s_rep = lds + LAY(l_rep);
@@ -922,29 +709,6 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       const int tl = wd0 + j;
       pol.q_load((lane < S && j < wnd) ? 8u * (unsigned)(e0 + lane + S * tl) : PT_OOB, qt[j]);
     }
-#if CL_X1_IN_A
-    // The suffix totals of the members that own later days travel with the same exchange as the small vectors above (sent ahead
-    // by the previous leaf): wave 0 fetches them here, next to the loads of phase A, instead of on its own in phase B, where the
-    // round trip was the longest thing of the phase (4.2 k cycles on wave 0 against 2.2-2.6 k on the others).  Measured: 21.1
-    // against 19.5 us per leaf, 16.5 against 15.8 with two clusters (profiles/r03_cl_fixed_layout_build.txt) -- off.
-    if (w == 0 && ahead) {
-      double carry_a = 0.0;
-      for (int mm0 = m + 1; mm0 < K; mm0 += 16) {
-        double t16[16];
-        unsigned vo[16], so[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) {
-          const int mm = mm0 + u;
-          vo[u] = (mm < K && lane < S) ? 16u * (unsigned)lane : PT_OOB;
-          so[u] = xch_eslot(x, x.x1e, mm < K ? mm : 0);
-        }
-        xld(x, vo, so, t16, x.x1e);
-#pragma unroll
-        for (int u = 0; u < 16; u++) carry_a += t16[u];
-      }
-      if (lane < S) Y[PT_NW * SE + lane] = carry_a;
-    }
-#endif
     for (int i = tid; i < NR + 8; i += PT_THREADS) s_P[i] = 0.0;   // accumulators that this member's polls may not cover
     if (tid >= 64 && tid < 64 + CL_MAXDAYS) s_ge[tid - 64] = 0.0;
 #pragma unroll
@@ -971,11 +735,10 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     double tot = 0.0;
 #pragma unroll
     for (int w2 = 0; w2 < PT_NW; w2++) tot += Y[w2 * SE + (lane < S ? lane : S)];
-    if (!CL_SKIP_OOB || (w == 0 && x.x1e == 0)) xst(x, (w == 0 && lane < S && x.x1e == 0) ? 16u * (unsigned)lane : PT_OOB, tot);   // (CL_SKIP_OOB: wave-uniform)
+    xst(x, (w == 0 && lane < S && x.x1e == 0) ? 16u * (unsigned)lane : PT_OOB, tot);
   }
   x.epoch += x.x1e == 0 ? 1u : 0u;                // X1 is on its way (or was sent by the previous pass)
   const unsigned x1tag = x.x1e ? x.x1e : x.epoch;
-  const bool x1_early = CL_X1_IN_A && x.x1e != 0; // (then wave 0 took the totals in phase A)
   x.x1e = 0;
   if (w == 1) {
     if (full) {
@@ -1017,67 +780,26 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         d_in = dpp_readlane_d(d, 63);
       }
       if (lane == 0) { s_scal[SC_MUE] = mue; s_scal[SC_RHO] = rho; s_scal[SC_SRHO] = srho; s_scal[SC_XMUE] = xm; s_scal[SC_XRHO] = xr; }
-#if CL_TANGENTS_IN_B == 1
-      cl_ar1_tangent<1>(rho, mue, ze, s_e, s_c2, T, d0, nd);   // needs e[t-1]: this wave's own LDS stores, in order
-#endif
     }
   }
-#if CL_TANGENTS_IN_B == 1
-  // The tangents that do not need e[] and the scalars of rho's prior, on waves that have nothing else to do in this phase (each
-  // recomputes rho from the raw parameter: same operations, same bits).
-  if (full && w >= 3 && w <= 5) {
-    const double rho = d_inv_logit(s_mid[M->o_rho - o_c]);
-    ldp ze = s_mid + (M->o_ze - o_c);
-    if (w == 3) cl_ar1_tangent<0>(rho, 0.0, ze, s_e, s_c1, T, d0, nd);
-    else if (w == 4) cl_ar1_tangent<2>(rho, 0.0, ze, s_e, s_c3, T, d0, nd);
-    else if (lane == 0) {
-      // what the owner of rho_e_bias needs in phase F: Jacobian + prior of rho (stan:63,124), d sigma_rho / d rho
-      s_scal[SC_LPRHO] = log(rho) + log1p(-rho) - 0.5 * ((rho - 0.7) / 0.1) * ((rho - 0.7) / 0.1);
-      s_scal[SC_DSRHO] = M->sigma_e * (-rho / sqrt(1.0 - rho * rho));
-    }
-  }
-#endif
-#if CL_X3_IN_B
   // The previous leaf's totals (exchange pend.tag, sent before this pass began) are fetched here by a wave that has nothing else
   // to do in this phase: an L2 round trip under load costs about 2 k cycles, which the verdict wave of phase C used to pay on
   // the critical path of that phase.  (Round 3 tried this while waves 2-7 still carried the 51 x 51 mat-vecs of mu_b_T and
   // the polling bias here and lost; those products are gone, see the carry step below.)
   if (w == 2 && pend.n >= 0) {
-    // (this wave's sixteen loads would enter the compute unit's address queue ahead of wave 0's fetch of X1, which the phase ends with:
-    //  it starts a little later instead -- the totals are not needed before the verdicts of phase C)
-    if (CL_X3_DELAY) __builtin_amdgcn_s_sleep(CL_X3_DELAY);
     cl_wide_consume(x, pend.tag, pend.nv, wout);
   }
-#endif
   // mu_b[:, t] = prior + L_T z_T + L_W C[:, t] and polling_bias = L_B z_b (stan:77,85-86) enter a poll's predictor only as
   // prior[s] + L_W[s, :] . (aT z_T + aB z_b + C[:, t]): the three factors are one matrix times three scalars (stan:42-55).  So
   // u = aT z_T + aB z_b is folded into the suffix sums and no 51 x 51 product is left in the forward pass (rounds 1-3 computed
   // L_T z_T and L_B z_b here on six waves out of packed triangles in LDS, bound by LDS bandwidth).
   const double aT = M->aT, aB = M->aB;
-#if CL_VC
-  // C[k][t] of the member's days WITHOUT the carry of the members that own later days: local suffix + later waves + u.  The
-  // carry enters the predictors through vc[s] = L_W_ext[s, :] . carry (wave 0, below), so nothing here waits for the exchange.
-  if (lane < S) {
-    double cy[PT_NW];
-#pragma unroll
-    for (int w2 = 0; w2 < PT_NW; w2++) cy[w2] = Y[w2 * SE + lane];
-    const double zt = s_zT[lane], zb = s_zb[lane];
-    ISSUE_FENCE();
-    double carry = aT * zt + aB * zb;
-#pragma unroll
-    for (int w2 = 0; w2 < PT_NW; w2++) carry += w2 > w ? cy[w2] : 0.0;
-#pragma unroll
-    for (int j = 0; j < CL_DW; j++) {
-      if (j < wnd) C[lane * NDP + wd0 + j] = cs[j] + carry;
-    }
-  }
-#endif
   // suffix totals of the members that own later days: fetched once per workgroup (wave 0, which has
   // nothing else to do here) and handed to the other waves through LDS
-  if (w == 0 && !x1_early) {
+  if (w == 0) {
     WPROF_PT(27);
     double carry_m = 0.0;
-    for (int mm0 = m + 1, bt = 0; mm0 < K && (!(FX && CL_FX_BATCH) || bt < 1); mm0 += 16, bt++) {   // (FX: at most sixteen members, one batch)
+    for (int mm0 = m + 1; mm0 < K; mm0 += 16) {
       double t16[16];
       unsigned vo[16], so[16];
 #pragma unroll
@@ -1087,39 +809,18 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         so[u] = xch_eslot(x, x1tag, mm < K ? mm : 0);
       }
 #ifdef POTUS_PROF_FETCH
-      xld(x, vo, so, t16, x1tag, prof, min(16, K - mm0));   // slots 56-58 (the phase-C consumer of the previous leaf's totals does not use them when CL_X3_IN_B)
+      xld(x, vo, so, t16, x1tag, prof);   // slots 56-58
 #else
-      xld(x, vo, so, t16, x1tag, nullptr, min(16, K - mm0));
+      xld(x, vo, so, t16, x1tag, nullptr);
 #endif
 #pragma unroll
       for (int u = 0; u < 16; u++) carry_m += t16[u];
     }
-#if CL_VC
-    // vc[s] = L_W_ext[s, :] . carry for every (pseudo-)state: lane s, the carry's elements handed around with v_readlane
-    {
-      const int ls = lane < SE ? lane : SE;            // row SE of the staged factor is zero
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-      for (int k0 = 0; k0 < S; k0 += 17) {             // S = 51: three batches of seventeen terms
-        double l[17];
-#pragma unroll
-        for (int j = 0; j < 17; j++) l[j] = Lw[ls * SP + min(k0 + j, S - 1)];
-        ISSUE_FENCE();
-#pragma unroll
-        for (int j = 0; j < 17; j++) {
-          const double c = k0 + j < S ? readlane_d(carry_m, min(k0 + j, 63)) : 0.0;
-          if (j % 3 == 0) a0 += l[j] * c; else if (j % 3 == 1) a1 += l[j] * c; else a2 += l[j] * c;
-        }
-      }
-      if (lane < SE) s_bT[lane] = (lds + LAY(l_prior))[lane] + ((a0 + a1) + a2);
-    }
-#else
     if (lane < S) Y[PT_NW * SE + lane] = carry_m;
-#endif
     WPROF_PT(28);
   }
   if (POTUS_PROF_WAVES == 1) WPROF_ACC(0);
-#if !CL_VC
-  PASS_BARRIER();
+  __syncthreads();
   PROF_MARK(1);
   TSTAMP(2);
   {
@@ -1140,10 +841,6 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     }
   }
   if (tid < SE) s_bT[tid] = (lds + LAY(l_prior))[tid];
-#else
-  PROF_MARK(1);
-  TSTAMP(2);
-#endif
   if (tid == 0) { r_lds[np] = 0.0; ru_lds[np] = 0.0; }
   __syncthreads();
   PROF_MARK(2);
@@ -1159,10 +856,11 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     const unsigned long long AS_L *pm = (const unsigned long long AS_L *)(lds + LAY(l_pm));
     const unsigned long long AS_L *pyn = (const unsigned long long AS_L *)(lds + LAY(l_py));
     ldp pun = lds + LAY(l_pun);
-    // (the split of variant 2 is taken by the fixed build only: in the dynamic builds, which serve the no-mode posteriors among others, its mere presence
-    //  cost 4 % -- bench.py --config 3: 698 k leapfrogs/s without, 667 k with)
-    constexpr int TNG = CL_TANGENTS_IN_B == 2 ? (FX ? 2 : 0) : CL_TANGENTS_IN_B;
-    if (TNG != 1 && full && w == PT_NW - 1) {
+    // The scalars of rho's prior have a wave of their own in the fixed build only (profiles/r04_cl_inkernel_cycles.txt: one wave doing both set the
+    // length of the phase): in the dynamic builds, which serve the no-mode posteriors among others, the mere presence of that branch cost 4 %
+    // (bench.py --config 3: 698 k leapfrogs/s without, 667 k with)
+    constexpr bool SPLIT_SCALARS = FX;
+    if (full && w == PT_NW - 1) {
       // the three tangent recurrences of the AR(1) bias (needed in phase E2 only) run here, on the wave that
       // has no polls unless the member has more than 448 of them, instead of lengthening phase B
       const double rho = s_scal[SC_RHO], mue = s_scal[SC_MUE], sigma_e = M->sigma_e;
@@ -1197,13 +895,13 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         }
         c1_in = dpp_readlane_d(c1, 63); c2_in = dpp_readlane_d(c2, 63); c3_in = dpp_readlane_d(c3, 63);
       }
-      if (TNG == 0 && lane == 0) {
+      if (!SPLIT_SCALARS && lane == 0) {
         // what the owner of rho_e_bias needs in phase F: Jacobian + prior of rho (stan:63,124), d sigma_rho / d rho
         s_scal[SC_LPRHO] = log(rho) + log1p(-rho) - 0.5 * ((rho - 0.7) / 0.1) * ((rho - 0.7) / 0.1);
         s_scal[SC_DSRHO] = sigma_e * (-rho / sqrt(1.0 - rho * rho));
       }
     }
-    if (TNG == 2 && full && w == PT_NW - 3 && lane == 0) {
+    if (SPLIT_SCALARS && full && w == PT_NW - 3 && lane == 0) {
       // ... on a wave of their own (idle unless the member has more than 320 polls): two logarithms, a square root and a division on
       // one lane are 3.3 k cycles, as long as the three recurrences together (profiles/r04_cl_inkernel_cycles.txt)
       const double rho = s_scal[SC_RHO];
@@ -1211,33 +909,17 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       s_scal[SC_DSRHO] = M->sigma_e * (-rho / sqrt(1.0 - rho * rho));
     }
     if (w == PT_NW - 2 && pend.n >= 0) {
-      // The previous leaf's totals and verdicts, on a wave that has no polls unless the member has more than 384 of
-      // them: the totals were sent a whole phase B ago, so nothing waits here, and the U-turn / accept logic runs
-      // beside the poll arithmetic of the other waves.
+      // The previous leaf's verdicts, on a wave that has no polls unless the member has more than 384 of them (its totals
+      // were collected in phase B): the U-turn / accept logic runs beside the poll arithmetic of the other waves.
       WPROF_T0B();
-#if !CL_X3_IN_B
-#ifdef POTUS_PROF
-      cl_wide_consume(x, pend.tag, pend.nv, wout, prof);
-#else
-      cl_wide_consume(x, pend.tag, pend.nv, wout);
-#endif
-#endif
       WPROF_PTB(29);
-#if !CL_VERDICT_IN_D
       cl_leaf_logic(ts, pend, wout);
-#endif
       WPROF_PTB(30);
     }
-    // CL_LPP lanes share a poll: each takes a contiguous part of the 51-term dot (the parts are added across the lanes on the DPP
-    // path, every lane of the group ends up with the same sum and runs the binomial term redundantly); the group's first lane owns
-    // the poll's noise element, its log-density term and its residual.  With two lanes per poll the members of the reference's
-    // posteriors (45-148 polls) spread their polls over three to five waves instead of one to three.
-    constexpr int LPP = CL_LPP, PPW = 64 / LPP, PPT = PT_THREADS / LPP;
-    const int sub = tid & (LPP - 1);
-    const bool no_polls_here = (CL_SKIP_OOB || (w == PT_NW - 2 && pend.n >= 0)) && np <= PPW * w;   // the verdict wave (CL_SKIP_OOB: any wave), when it has no polls: skip the (idle) trip
-    for (int i0 = 0; i0 < (no_polls_here ? 0 : np); i0 += PPT) {               // one trip unless a member has more than 512 / CL_LPP polls
-      const int il = i0 + tid / LPP;
-      const bool ok = il < np, lead = ok && sub == 0;
+    const bool no_polls_here = w == PT_NW - 2 && pend.n >= 0 && np <= 64 * w;   // the verdict wave, when it has no polls: skip the (idle) trip
+    for (int i0 = 0; i0 < (no_polls_here ? 0 : np); i0 += PT_THREADS) {        // one trip unless a member has more than 512 polls
+      const int il = i0 + tid;
+      const bool ok = il < np, lead = ok;
       const int ic = ok ? il : np;                       // slot np holds zeros: N = y = 0
       const unsigned vq = lead ? 8u * (unsigned)(e_noise + il) : PT_OOB;
       typename Pol::QT qt;
@@ -1245,7 +927,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       pol.q_load(vq, qt);
       pol.g_load(vq, gt);
       double gval = 0.0, zn = 0.0;
-      if (i0 + PPW * w < np) {                           // waves without polls skip the arithmetic (wave-uniform); no global
+      if (i0 + 64 * w < np) {                           // waves without polls skip the arithmetic (wave-uniform); no global
         const unsigned long long meta = pm[ic];          // memory operation inside the branch
         const int s = (int)(meta & 0xffu), tl = (int)((meta >> 8) & 0xffu), ip = (int)((meta >> 16) & 0xffffu);
         const int im = (int)((meta >> 32) & 0xffu), ipop = (int)((meta >> 40) & 0xffu);
@@ -1254,27 +936,6 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         const int t = d0 + tl;
         ldp L0 = Lw + s * SP, C0 = C + tl;
         double a0 = 0.0, a1 = 0.0;
-        if constexpr (LPP == 1 && FX && CL_DOT_PIPE) {
-          constexpr int NBT = 8, NBATCH = (ClFixed::S + NBT - 1) / NBT;
-          double l[2][NBT], c[2][NBT];
-#pragma unroll
-          for (int j = 0; j < NBT; j++) { l[0][j] = L0[j]; c[0][j] = C0[j * NDP]; }
-#pragma unroll
-          for (int b = 0; b < NBATCH; b++) {
-            const int cur = b & 1, nxt = cur ^ 1, kn = (b + 1) * NBT;
-            if (b + 1 < NBATCH) {
-#pragma unroll
-              for (int j = 0; j < NBT; j++) { const int kk = kn + j < ClFixed::S ? kn + j : ClFixed::S - 1; l[nxt][j] = L0[kk]; c[nxt][j] = C0[kk * NDP]; }
-            }
-            ISSUE_FENCE();
-#pragma unroll
-            for (int j = 0; j < NBT; j += 2) {             // (sixteen-term batches of the other path: a0 takes the even terms, a1 the odd ones, in ascending order -- as here)
-              const int k = b * NBT + j;
-              a0 += (k < ClFixed::S ? l[cur][j] : 0.0) * c[cur][j];
-              a1 += (k + 1 < ClFixed::S ? l[cur][j + 1] : 0.0) * c[cur][j + 1];
-            }
-          }
-        } else if constexpr (LPP == 1) {
           int k0 = 0;
           for (; k0 + 16 <= S; k0 += 16) {               // 51-term dot, sixteen terms in flight
             double l[16], c[16];
@@ -1295,23 +956,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
               a1 += (k0 + j + 1 < S ? l[j + 1] : 0.0) * c[j + 1];
             }
           }
-        } else {
-          const int TL = (S + LPP - 1) / LPP, kb = sub * TL;   // this lane's terms: k = kb .. kb + TL - 1 (those below S)
-          for (int j0 = 0; j0 < TL; j0 += 13) {          // thirteen terms in flight (51 states: two batches with two lanes per poll, one with four)
-            double l[13], c[13];
-#pragma unroll
-            for (int j = 0; j < 13; j++) { const int kk = min(kb + j0 + j, S - 1); l[j] = L0[kk]; c[j] = C0[kk * NDP]; }
-            ISSUE_FENCE();
-#pragma unroll
-            for (int j = 0; j < 13; j++) {
-              const double lj = (j0 + j < TL && kb + j0 + j < S) ? l[j] : 0.0;
-              if (j & 1) a1 += lj * c[j]; else a0 += lj * c[j];
-            }
-          }
-        }
-        double dot = a0 + a1;
-        if constexpr (LPP >= 2) dot += dpp_fetch<0xB1, 0xf>(0.0, dot);    // quad_perm [1, 0, 3, 2]: the neighbour's part
-        if constexpr (LPP == 4) dot += dpp_fetch<0x4E, 0xf>(0.0, dot);    // quad_perm [2, 3, 0, 1]: the other pair's sum
+        const double dot = a0 + a1;
         const double sg = s == S ? sigma_nn : sigma_ns;
         WPROF_CSTAMP(0);
         zn = pol.q_fin(qt);
@@ -1322,20 +967,11 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         double eta = s_bT[s] + sg * zn + sigma_c * s_mid[ip] + dot;   // s_bT: mu_b_prior (national: its weighted average)
         if (full) eta += sigma_m * s_mid[om + im] + sigma_pop * s_mid[opop + ipop] + un * s_e[t];
         // binomial_logit with one exp, one log1p, one division:  e = exp(-|eta|), l = log1p(e)
-#if CL_FAST_BINOMIAL
-        const double ex = d_exp_neg(fabs(eta));         // (potus_model.hpp: the same three quantities, written for latency)
-        double l1, inv1;
-        d_log1p_recip(ex, l1, inv1);
-        const double num = eta >= 0.0 ? 1.0 : ex;
-        double pr = num * inv1;
-        pr = __builtin_fma(__builtin_fma(-(1.0 + ex), pr, num), inv1, pr);   // residual-corrected division
-#else
         const double ex = exp(-fabs(eta)), l1 = log1p(ex), pr = (eta >= 0.0 ? 1.0 : ex) / (1.0 + ex);
-#endif
         const double r = y - N * pr;
         WPROF_CSTAMP(2);
         const double term = y * (fmin(eta, 0.0) - l1) + (N - y) * (fmin(-eta, 0.0) - l1) - 0.5 * zn * zn;   // stan:126-127,130-131 (zn = 0 on idle lanes)
-        lp += (LPP == 1 || sub == 0) ? term : 0.0;      // (the other lanes of a poll's group hold no noise element: their eta, r are not used)
+        lp += term;
         r_lds[lead ? il : np + 1] = r;                   // slot np stays 0 (padding of the task lists), np+1 is a dump
         ru_lds[lead ? il : np + 1] = r * un;             // feeds the day sums of the AR(1) adjoint
         gval = sg * r - zn;
@@ -1346,14 +982,12 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     WPROF_CFLUSH();
   }
   WAVE_ARRIVE(3);
-  PASS_BARRIER();
+  __syncthreads();
   PROF_MARK(3);
   TSTAMP(4);
   // The verdicts ended the trajectory: every member leaves here together.  What this pass has stored so far (the
   // epilogue of the poll-noise elements) went to slots nobody reads once the trajectory is over.
-#if !CL_VERDICT_IN_D
   if (pend.n >= 0 && uni_i(ts->abort)) { aborted = true; return 0.0; }
-#endif
 
   // ---------------- phase D: adjoint of the walk, gC[:,t] = sum_i r_i Lw_ext[s_i,:] summed over days <= t.
   // The member's polls (day order) are cut into PT_NW equal chunks, one per wave, whatever the days: a wave
@@ -1361,32 +995,6 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // readlane; lanes < S keep the running sum over the chunk, lane 63 the day's sum of unadjusted * residual
   // (the adjoint input of e_bias[t]).  At the last poll of a day the running values go to LDS; the owners
   // of the days pick them up in phase E.  Level-1 segment sums follow.
-#if CL_VERDICT_IN_D
-  // the previous leaf's verdicts (its totals were collected in phase C): the last wave has no chunk of the gather below
-  if (w == PT_NW - 1 && pend.n >= 0) cl_leaf_logic(ts, pend, wout);
-#endif
-  if constexpr (GX) {
-    // g[s] = sum of the residuals of the member's polls of (pseudo-)state s: lane s of the last wave walks the state's list (host: build_cluster),
-    // sixteen entries per batch, and publishes it as word XP_PRE + s of X2 -- a whole gather, pick-up and payload phase before anybody needs it
-    double g = 0.0;
-    if (w == PT_NW - 1) {
-      const u32x4 AS_L *stl = (const u32x4 AS_L *)(lds + LAY(l_stl));
-      const int nstb = part[CP_NSTB];
-      for (int b = 0; b < nstb; b++) {
-        const u32x4 ia = stl[(b * 64 + lane) * 2], ib = stl[(b * 64 + lane) * 2 + 1];
-        double rr[16];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          rr[2 * j] = r_lds[(int)(ia[j] & 0xffffu)]; rr[2 * j + 1] = r_lds[(int)(ia[j] >> 16)];
-          rr[8 + 2 * j] = r_lds[(int)(ib[j] & 0xffffu)]; rr[9 + 2 * j] = r_lds[(int)(ib[j] >> 16)];
-        }
-        ISSUE_FENCE();
-#pragma unroll
-        for (int j = 0; j < 16; j++) g += rr[j];
-      }
-    }
-    xst(x, (w == PT_NW - 1 && lane < SE) ? 16u * (unsigned)(XP_PRE + lane) : PT_OOB, g);   // (no branch around the store)
-  }
   if constexpr (!MF) {
     const unsigned AS_L *tab = (const unsigned AS_L *)(lds + LAY(l_tab));
     const int lk = lane < S ? lane : 0;
@@ -1459,33 +1067,10 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   __syncthreads();
   PROF_MARK(4);
   TSTAMP(5);
-#if CL_VERDICT_IN_D
-  // The verdicts ended the trajectory: every member leaves here together (what this pass has stored so far -- the epilogue of the
-  // poll-noise elements -- went to slots nobody reads once the trajectory is over).
-  if (pend.n >= 0 && uni_i(ts->abort)) { aborted = true; return 0.0; }
-#endif
 
   // ---------------- phase E: the owners of the days pick up the running sums; level-2 segment sums
   // (the chunk totals X[chunk][state] are turned into exclusive prefixes in place by wave 0, which keeps their sum for
   // its X2 word; after the barrier every wave looks its days' chunks up instead of carrying the eight prefixes around)
-  if constexpr (GX) {
-    if (w == PT_NW - 1) {
-      // the rows g_mm of all members (published a phase ago: nothing waits): prefix over the members that own earlier days, and total
-      ldp gxl = lds + LAY(l_gx);
-      double gp = 0.0, gt = 0.0;
-      const unsigned tagx = x.epoch + 1u;          // X2 is still being assembled on this member
-      for (int mm0 = 0; mm0 < K; mm0 += 16) {
-        double t16[16];
-        unsigned vo[16], so[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) { const int mm = mm0 + u; vo[u] = (mm < K && lane < SE) ? 16u * (unsigned)(XP_PRE + lane) : PT_OOB; so[u] = xch_eslot(x, tagx, mm < K ? mm : 0); }
-        xld(x, vo, so, t16, tagx);
-#pragma unroll
-        for (int u = 0; u < 16; u++) { gt += t16[u]; gp += mm0 + u < m ? t16[u] : 0.0; }
-      }
-      gxl[lane] = gp; gxl[64 + lane] = gt;           // (lanes beyond the pseudo-state loaded zeros)
-    }
-  }
   int tlast[CL_DW], ch[CL_DW];
   double cv[CL_DW];
   double chunk_total = 0.0;
@@ -1507,9 +1092,6 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
 #pragma unroll
       for (int c = 0; c < PT_NW; c++) { X[c * SE + lx] = chunk_total; chunk_total += ct[c]; }
     }
-#if CL_PRE_EARLY
-    if constexpr (!GX) xst(x, (w == 0 && lane < S) ? 16u * (unsigned)(XP_PRE + lane) : PT_OOB, chunk_total);   // (no branch around the store; the other waves' lanes are out of range)
-#endif
   } else {
     (void)tlast; (void)ch; (void)cv;
     // Adjoint on the matrix cores, step 2: gC[k][t] = sum_s Lw_ext[s][k] G[s][t] as 16 x 16 x 4 fp64 MFMA tiles
@@ -1580,27 +1162,6 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   TSTAMP(6);
 
   // ---------------- phase E2: payload of X2
-  if constexpr (GX) {
-    // L_W_ext' applied to the prefix and to the total of g: waves 4-7 take a quarter of the (pseudo-)states each, lane k the column;
-    // the four partial sums are added (in wave order) by whoever needs the result, behind the first barrier of phase F
-    if (w >= PT_NW - 4) {
-      ldp gxl = lds + LAY(l_gx);
-      const int q = w - (PT_NW - 4), per = (SE + 3) >> 2, s0 = q * per, lk = lane < S ? lane : 0;
-      double a0 = 0.0, a1 = 0.0;
-      for (int j0 = 0; j0 < per; j0 += 13) {
-        double l[13], gpv[13], gtv[13];
-#pragma unroll
-        for (int j = 0; j < 13; j++) {
-          const int ss = (j0 + j < per && s0 + j0 + j < SE) ? s0 + j0 + j : SE;   // row SE of the staged factor is zero, and so are gxl[SE ..]
-          l[j] = Lw[ss * SP + lk]; gpv[j] = gxl[min(ss, 63)]; gtv[j] = gxl[64 + min(ss, 63)];
-        }
-        ISSUE_FENCE();
-#pragma unroll
-        for (int j = 0; j < 13; j++) { a0 += l[j] * gpv[j]; a1 += l[j] * gtv[j]; }
-      }
-      gxl[128 + (2 * q) * 64 + lane] = lane < S ? a0 : 0.0; gxl[128 + (2 * q + 1) * 64 + lane] = lane < S ? a1 : 0.0;
-    }
-  }
   double arA = 1.0, arB = 0.0;                      // wave 1 keeps its per-day adjoint composites for phase F
   double pay = 0.0;                                 // the word this lane publishes (wave 0: prefix total, wave 1: AR words)
   double pre[CL_DW];
@@ -1644,15 +1205,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // over ALL the polls = the sum over the members of the prefix totals published here (the polls of the last day included: they
   // take their real row of the factor in the gather, and the prefix of that day is not used, stan:86).  So the owners of those
   // slots add up the words XP_PRE + k instead of partial transposed mat-vecs, which rounds 1-3 computed here on six waves.
-  if (!CL_SKIP_OOB || w <= 1) xst(x, (w == 0 && lane < S && !GX && (MF || !CL_PRE_EARLY)) ? 16u * (unsigned)(XP_PRE + lane) : (w == 1 && full && lane < 5) ? 16u * (unsigned)(XP_AR + lane) : PT_OOB, pay);
-#if CL_E2_BARRIER == 1
-  WAVE_ARRIVE(6);
-  __syncthreads();
-#elif CL_E2_BARRIER == 2
-  drain_vmem();
-#elif CL_E2_BARRIER == 3
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
+  xst(x, (w == 0 && lane < S) ? 16u * (unsigned)(XP_PRE + lane) : (w == 1 && full && lane < 5) ? 16u * (unsigned)(XP_AR + lane) : PT_OOB, pay);
   PROF_MARK(6);
   TSTAMP(7);
   {
@@ -1662,8 +1215,6 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     for (int h = 0; h < 2; h++) {
       const int rr = tid + h * PT_THREADS;
       const bool ok = rr >= 2 * S && rr < NR;
-      const int rr0 = 64 * w + h * PT_THREADS;       // the wave's first slot of this round
-      if (CL_SKIP_OOB && (rr0 + 63 < 2 * S || rr0 >= NR)) continue;   // wave-uniform: none of its lanes has a slot
       const double vp = s_P[ok ? rr : 2 * S];
       xst(x, ok ? 16u * (unsigned)(XP_P + rr) : PT_OOB, vp);
     }
@@ -1682,17 +1233,16 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   const int rslot = is_mue ? NR - 2 : is_rho ? NR - 1 : (repl ? r0 + jr : 0);
   const unsigned vo_x = arl ? 8u * (unsigned)(e_ze + nd - 1 - lane) : repl ? 8u * (unsigned)(e_rep + rslot - r0) : PT_OOB;
   typename Pol::GT gx{};
-  const bool own_any = !CL_SKIP_OOB || __any(arl || repl);   // wave-uniform: some lane of the wave owns an element besides the S x T block
-  if (own_any) pol.g_load(vo_x, gx);
+  pol.g_load(vo_x, gx);
   const double scale_r = cst.scale_r;
   x.epoch++;
 
   // ---------------- phase F: finish the gradients of everything this member owns
   // wave 0 fetches the prefix totals of the members that own earlier days (for the whole workgroup),
   // wave 1 finishes raw_e_bias, the owners of small-vector slots finish theirs; then the S x T block
-  if (w == 0 && !GX) {
+  if (w == 0) {
     double carry_m = 0.0;
-    for (int mm0 = 0, bt = 0; mm0 < m && (!(FX && CL_FX_BATCH) || bt < 1); mm0 += 16, bt++) {
+    for (int mm0 = 0; mm0 < m; mm0 += 16) {
       double t16[16];
       unsigned vo[16], so[16];
 #pragma unroll
@@ -1702,9 +1252,9 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         so[u] = xch_rslot(x, mm < m ? mm : 0);
       }
 #ifdef POTUS_PROF_FETCH
-      xld(x, vo, so, t16, 0u, prof + 3, min(16, m - mm0));   // slots 59-61: cycles of the first fetch, leaves that had to wait, re-fetch rounds
+      xld(x, vo, so, t16, 0u, prof + 3);   // slots 59-61: cycles of the first fetch, leaves that had to wait, re-fetch rounds
 #else
-      xld(x, vo, so, t16, 0u, nullptr, min(16, m - mm0));
+      xld(x, vo, so, t16, 0u, nullptr);
 #endif
 #pragma unroll
       for (int u = 0; u < 16; u++) carry_m += t16[u];
@@ -1713,10 +1263,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     PROF_MARK(7);
     TSTAMP(8);
   }
-  if constexpr (GX) { PROF_MARK(7); TSTAMP(8); }
   double own_g = 0.0, own_q = 0.0;                 // gradient / position of the element this thread owns besides the S x T block
-  constexpr bool LATE = CL_F_LATE || GX;           // see CL_F_LATE
-  if constexpr (!LATE) {
   if (w == 1) {
     if (full) {
       // carry of the adjoint from the members that own later days, then raw_e_bias of the member's days
@@ -1742,7 +1289,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     const unsigned v1 = is_mue ? 16u * (unsigned)XP_S : is_rho ? 16u * (unsigned)(XP_S + 1) : is_s3 ? 16u * (unsigned)(XP_S + 2)
                         : !repl ? PT_OOB : rslot < 2 * S ? 16u * (unsigned)(XP_PRE + (rslot < S ? rslot : rslot - S))   // L_W_ext' g, see phase E2
                         : 16u * (unsigned)(XP_P + rslot);
-    for (int mm0 = 0, bt = 0; mm0 < K && (!(FX && CL_FX_BATCH) || bt < 1); mm0 += 16, bt++) {
+    for (int mm0 = 0; mm0 < K; mm0 += 16) {
       double t16[16];
       unsigned vo[16], so[16];
 #pragma unroll
@@ -1765,42 +1312,11 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     lp += repl ? dl : 0.0;
     own_g = gv; own_q = qv;
   }
-  if (own_any) {
+  {
     const double qn_own = pol.gs_fin(vo_x, own_g, own_q, gx);   // outside the branches (vo_x is out of range for non-owners)
     // ... and sent ahead to the members that evaluate the next position (word XQ0 + index of the small parameter)
     const int jrep = arl ? NR + d0 + (nd - 1 - lane) : rslot;
-    if (!CL_SKIP_OOB || pubnext) xst(x, (pubnext && (arl || repl)) ? 16u * (unsigned)(XQ0 + jrep) : PT_OOB, qn_own);
-  }
-  }
-  // CL_F_LATE: one look at the AR(1) composites / slot partials before the barrier; what is missing is fetched after the day-block epilogue
-  // (CL_G_EXCHANGE: no look -- the words were published a moment ago -- and always after the epilogue)
-  const bool w_ar = w == 1 && full, w_slot = w >= 2 && __any(repl || is_s3);
-  const unsigned vA = lane < K ? (unsigned)lane * (unsigned)x.XW * 16u + 16u * (unsigned)XP_AR : PT_OOB;
-  const bool slot_local = GX && repl && rslot < 2 * S;   // raw_mu_b_T / raw_polling_bias: L_W_ext' (total of g), formed on this member (phase E2)
-  const unsigned v1 = is_mue ? 16u * (unsigned)XP_S : is_rho ? 16u * (unsigned)(XP_S + 1) : is_s3 ? 16u * (unsigned)(XP_S + 2)
-                      : (!repl || slot_local) ? PT_OOB : rslot < 2 * S ? 16u * (unsigned)(XP_PRE + (rslot < S ? rslot : rslot - S))   // L_W_ext' g, see phase E2
-                      : 16u * (unsigned)(XP_P + rslot);
-  const Xch x2 = x;                                // the exchange the words belong to (x.epoch moves on below when the next X1 goes out)
-  double late_mA = 0.0, late_mB = 0.0, late_sum = 0.0;
-  bool have = !LATE || !GX;                        // wave-uniform
-  if constexpr (LATE && !GX) {
-  if (w_ar) {
-    double mAB[2];
-    const unsigned vo[2] = {vA, lane < K ? vA + 16u : PT_OOB}, so[2] = {xch_rslot(x2, 0), xch_rslot(x2, 0)};
-    have = xld<2, true>(x2, vo, so, mAB);
-    late_mA = mAB[0]; late_mB = mAB[1];
-  } else if (w_slot) {
-    for (int mm0 = 0; mm0 < K; mm0 += 16) {
-      double t16[16];
-      unsigned vo[16], so[16];
-#pragma unroll
-      for (int u = 0; u < 16; u++) { const int mm = mm0 + u; vo[u] = mm < K ? v1 : PT_OOB; so[u] = xch_rslot(x2, mm < K ? mm : 0); }
-      const bool ok = xld<16, true>(x2, vo, so, t16);
-      have = have && ok;
-#pragma unroll
-      for (int u = 0; u < 16; u++) late_sum += t16[u];
-    }
-  }
+    xst(x, (pubnext && (arl || repl)) ? 16u * (unsigned)(XQ0 + jrep) : PT_OOB, qn_own);
   }
   PROF_SUB(52);
   typename Pol::GT gz[CL_DW];
@@ -1811,14 +1327,10 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     pol.g_load(voz[j], gz[j]);
   }
   WAVE_ARRIVE(7);
-  PASS_BARRIER();
+  __syncthreads();
   PROF_SUB(53);
   {
-    double carry = lane < S ? X[PT_NW * SE + lane] : 0.0;   // pre[] is already the prefix within the member
-    if constexpr (GX) {
-      ldp gxl = lds + LAY(l_gx);
-      carry = ((gxl[128 + 0 * 64 + lane] + gxl[128 + 2 * 64 + lane]) + gxl[128 + 4 * 64 + lane]) + gxl[128 + 6 * 64 + lane];   // L_W_ext' (prefix of g): zero beyond the states
-    }
+    const double carry = lane < S ? X[PT_NW * SE + lane] : 0.0;   // pre[] is already the prefix within the member
     double nrun = 0.0;                              // suffix total of the next position over the wave's days
 #pragma unroll
     for (int j = 0; j < CL_DW; j++) {
@@ -1829,73 +1341,15 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     PROF_SUB(54);
     if (pubnext) {                                  // wave-uniform; LDS and a barrier only, the store stays outside
       if (lane < S) Y[w * SE + lane] = nrun;
-      PASS_BARRIER();
+      __syncthreads();
     }
     PROF_SUB(55);
-  }
-  if constexpr (LATE) {
-  if (w_ar) {
-    if (!have) {
-      double mAB[2];
-      const unsigned vo[2] = {vA, lane < K ? vA + 16u : PT_OOB}, so[2] = {xch_rslot(x2, 0), xch_rslot(x2, 0)};
-      xld(x2, vo, so, mAB);
-      late_mA = mAB[0]; late_mB = mAB[1];
-    }
-    const double mA = late_mA, mB = late_mB;
-    double a_in = 0.0;
-    for (int mm = K - 1; mm > m; mm--) a_in = readlane_d(mB, mm) + readlane_d(mA, mm) * a_in;
-    const double a = arB + arA * a_in;
-    const int t = d0 + (arl ? nd - 1 - lane : 0);
-    const double z = s_mid[M->o_ze - o_c + (arl ? t : 0)];
-    const double gv = a * (t >= 1 ? s_scal[SC_SRHO] : M->sigma_e) - z;
-    lp -= arl ? 0.5 * z * z : 0.0;               // stan:125
-    own_g = gv; own_q = z;
-  } else if (w_slot) {
-    if (!have) {
-      late_sum = 0.0;
-      for (int mm0 = 0; mm0 < K; mm0 += 16) {
-        double t16[16];
-        unsigned vo[16], so[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) { const int mm = mm0 + u; vo[u] = mm < K ? v1 : PT_OOB; so[u] = xch_rslot(x2, mm < K ? mm : 0); }
-        xld(x2, vo, so, t16);
-#pragma unroll
-        for (int u = 0; u < 16; u++) late_sum += t16[u];
-      }
-    }
-    double sum = late_sum;
-    if constexpr (GX) {
-      if (slot_local) {                              // (lanes of a wave, not the wave: plain selects, no memory operation)
-        ldp gxl = lds + LAY(l_gx);
-        const int k = rslot < S ? rslot : rslot - S;
-        sum = ((gxl[128 + 1 * 64 + k] + gxl[128 + 3 * 64 + k]) + gxl[128 + 5 * 64 + k]) + gxl[128 + 7 * 64 + k];
-      }
-    }
-    const double s3 = readlane_d(sum, 63);           // third tangent sum (meaningful in the wave that owns rho_e_bias)
-    const double qv = s_rep[rslot];
-    double gv = scale_r * sum - qv;
-    double dl = -0.5 * qv * qv;                    // stan:117,120-122,128
-    if (is_mue || is_rho) {
-      const double rho = s_scal[SC_RHO];
-      const double g_mue = 0.02 * (1.0 - rho) * sum - qv;                       // sum = S1
-      const double g_rho = ((sum + s3 * s_scal[SC_DSRHO]) - (rho - 0.7) / 0.01) * rho * (1.0 - rho) + (1.0 - 2.0 * rho);   // S2, S3
-      gv = is_mue ? g_mue : g_rho;
-      dl = is_mue ? -3.912023005428146 - 0.5 * qv * qv : s_scal[SC_LPRHO];     // log(0.02) + prior (stan:62,123) : stan:63,124
-    }
-    lp += repl ? dl : 0.0;
-    own_g = gv; own_q = qv;
-  }
-  if (own_any) {
-    const double qn_own = pol.gs_fin(vo_x, own_g, own_q, gx);   // outside the branches (vo_x is out of range for non-owners)
-    const int jrep = arl ? NR + d0 + (nd - 1 - lane) : rslot;
-    if (!CL_SKIP_OOB || pubnext) xst(x, (pubnext && (arl || repl)) ? 16u * (unsigned)(XQ0 + jrep) : PT_OOB, qn_own);
-  }
   }
   {
     double tot = 0.0;
 #pragma unroll
     for (int w2 = 0; w2 < PT_NW; w2++) tot += Y[w2 * SE + (lane < S ? lane : S)];
-    if (!CL_SKIP_OOB || (pubnext && w == 0)) xst(x, (pubnext && w == 0 && lane < S) ? 16u * (unsigned)lane : PT_OOB, tot);
+    xst(x, (pubnext && w == 0 && lane < S) ? 16u * (unsigned)lane : PT_OOB, tot);
     x.epoch += pubnext ? 1u : 0u;
     x.x1e = pubnext ? x.epoch : 0u;
   }
@@ -1985,39 +1439,7 @@ __device__ __forceinline__ double cl_vop_momentum(ClChain &c, unsigned sP, uint3
   cl_allreduce(v, c.red(), c.x, c.tid, CPROFPTR(c));
   return v[0];
 }
-__device__ __forceinline__ bool cl_vop_merge(ClChain &c, unsigned a_beg, unsigned a_end, unsigned a_rho, unsigned b_beg, unsigned b_end,
-                                             unsigned b_rho, unsigned out) {
-  const unsigned sM = c.soff(V_MINV);
-  double v[6] = {0, 0, 0, 0, 0, 0};
-  for (int base = cl_first(c); base < c.e1; base += CL_UNR * PT_THREADS) {
-    double mi[CL_UNR], ab[CL_UNR], ae[CL_UNR], ar[CL_UNR], bb[CL_UNR], be[CL_UNR], br[CL_UNR];
-#pragma unroll
-    for (int k = 0; k < CL_UNR; k++) {
-      const int i = base + k * PT_THREADS;
-      const unsigned o = i < c.e1 ? 8u * i : PT_OOB;   // masked elements read zeros and add nothing
-      mi[k] = bld(c.st, o, sM); ab[k] = bld(c.st, o, a_beg); ae[k] = bld(c.st, o, a_end); ar[k] = bld(c.st, o, a_rho);
-      bb[k] = bld(c.st, o, b_beg); be[k] = bld(c.st, o, b_end); br[k] = bld(c.st, o, b_rho);
-    }
-#pragma unroll
-    for (int k = 0; k < CL_UNR; k++) {
-      const int i = base + k * PT_THREADS;
-      const double rs = ar[k] + br[k];
-      bst(c.st, i < c.e1 ? 8u * i : PT_OOB, out, rs);
-      const double sab = mi[k] * ab[k], sbe = mi[k] * be[k];
-      v[0] += sab * rs;                 // p#_beg . rho_subtree
-      v[1] += sbe * rs;                 // p#_end . rho_subtree
-      const double e1 = ar[k] + bb[k];  // rho_init + p_final_beg
-      v[2] += sab * e1;
-      v[3] += mi[k] * bb[k] * e1;
-      const double e2 = br[k] + ae[k];  // rho_final + p_init_end
-      v[4] += mi[k] * ae[k] * e2;
-      v[5] += sbe * e2;
-    }
-  }
-  cl_allreduce(v, c.red(), c.x, c.tid, CPROFPTR(c));
-  return v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0 && v[4] > 0 && v[5] > 0;
-}
-// Same sweep, but the six dot products stay per-wave partial sums in LDS (part[WP(v0 + k, wave)]);
+// One U-turn check (base_nuts::build_tree / transition): the six dot products stay per-wave partial sums in LDS (part[WP(v0 + k, wave)]);
 // the leaf's single all-reduce adds them over the cluster.
 __device__ __forceinline__ void cl_vop_merge_partial(ClChain &c, unsigned a_beg, unsigned a_end, unsigned a_rho, unsigned b_beg, unsigned b_end,
                                                      unsigned b_rho, unsigned out, ldp part, int v0) {
@@ -2458,18 +1880,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, co
         if (TWIN && lane == 63) wpart[WP(nv0, w)] = (w == 0 && ts->tw_ext) ? 1.0 : 0.0;
       }
       if (m > 1 || top) { drain_vmem(); __syncthreads(); }   // the leaf's momentum is read back with another thread map
-#if CL_MERGE_CHAIN
       if (m >= 2) cl_vop_merge_chain(c, ts, m, leaf, wpart);
-#else
-      for (int j = 2; j <= m; j++) {
-        const int ib = uni_i(ts->pend_beg[j - 1]), ie = uni_i(ts->pend_end[j - 1]), cb = uni_i(ts->pend_beg[j - 2]);
-        const unsigned a_rho = c.soff(V_RHOLEV + j - 1);
-        const unsigned b_rho = c.soff(V_SCR0 + ((j - 1) & 1));
-        const unsigned out = j == m ? c.soff(V_RHOLEV + j) : c.soff(V_SCR0 + (j & 1));
-        cl_vop_merge_partial(c, c.soff(V_POOLP + ib), c.soff(V_POOLP + ie), a_rho, c.soff(V_POOLP + cb), c.soff(V_POOLP + leaf), b_rho, out,
-                             wpart, 2 + 6 * (j - 1));
-      }
-#endif
       if (top) {
         // the checks at the end of transition(): old trajectory (init side) against the new subtree
         const int nb = depth >= 1 ? uni_i(ts->pend_beg[depth - 1]) : leaf;

@@ -1355,7 +1355,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   if (mfma) sp->cl_dw = 12;
   std::vector<int> part((size_t)K * CP_N, 0), sched, perm;   // perm: internal index -> Stan index, -1 for padding
   std::vector<double> wts;
-  int e = 0, npmax = 0, nsubmax = 0, nstbmax = 0;
+  int e = 0, npmax = 0, nsubmax = 0;
   for (int m = 0; m < K; m++) {
     int *pt_ = &part[(size_t)m * CP_N];
     const int d0 = cut[m], nd = cut[m + 1] - cut[m], p0 = dp[d0], np = dp[d0 + nd] - p0;
@@ -1498,22 +1498,6 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
     pt_[CP_O_MASK] = appi(tab); pt_[CP_O_SUB] = appi(sub16); pt_[CP_O_SEGPTR] = appi(seg_ptr);
     pt_[CP_O_SEGKIND] = appi(seg_kind); pt_[CP_O_SEGIDX] = appi(seg_index);
     pt_[CP_O_CELL] = appi(cellw);
-    {
-      // CL_G_EXCHANGE: the member's polls by (pseudo-)state, sixteen local indices per batch and state, 16-bit entries (two per int),
-      // [batch][64 lanes][8 ints]; unused entries point at the zero slot np
-      std::vector<std::vector<int>> bys(64);
-      for (int il = 0; il < np; il++) bys[sp->h_ps[p0 + il] & 63].push_back(il);
-      int nstb = 0;
-      for (const auto &l : bys) nstb = std::max(nstb, ((int)l.size() + 15) / 16);
-      std::vector<int> stl((size_t)nstb * 512, np | (np << 16));
-      for (int s_ = 0; s_ < 64; s_++)
-        for (size_t j = 0; j < bys[s_].size(); j++) {
-          int &wd = stl[((j / 16) * 64 + s_) * 8 + (j % 16) / 2];
-          wd = (j & 1) ? ((wd & 0xffff) | (bys[s_][j] << 16)) : ((wd & ~0xffff) | bys[s_][j]);
-        }
-      pt_[CP_NSTB] = nstb; pt_[CP_O_STL] = appi(stl);
-      nstbmax = std::max(nstbmax, nstb);
-    }
     while (wts.size() % 2) wts.push_back(0.0);
     pt_[CP_O_WT] = (int)wts.size();
     wts.insert(wts.end(), sub_wt.begin(), sub_wt.end());
@@ -1551,9 +1535,8 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   // level-1 tasks, the walk for the adjoint.  The layout is then the same function of ClFixed's capacities -- the numbers the
   // kernel uses as immediates.
   {
-    const bool fits = DW == 4 && !mfma && full && (CL_FX_K16 ? K == 16 : K <= ClFixed::KMAX) && std::max(XP_P + C.NR, XQ0 + C.NREP) <= ClFixed::XW && S == ClFixed::S && M.SE == ClFixed::SE && M.SP == ClFixed::SP && ndmax <= ClFixed::NDP - 1 && npmax <= ClFixed::NPCAP &&
-                      nsubmax <= ClFixed::NSUBCAP && C.NREP <= ClFixed::NREPCAP && C.NR <= ClFixed::NRCAP && T <= ClFixed::TCAP && (int)SC_N <= 8 &&
-                      (!CL_G_EXCHANGE || (nstbmax <= CL_NSTBCAP && npmax < 65535));
+    const bool fits = DW == 4 && !mfma && full && K <= ClFixed::KMAX && std::max(XP_P + C.NR, XQ0 + C.NREP) <= ClFixed::XW && S == ClFixed::S && M.SE == ClFixed::SE && M.SP == ClFixed::SP && ndmax <= ClFixed::NDP - 1 && npmax <= ClFixed::NPCAP &&
+                      nsubmax <= ClFixed::NSUBCAP && C.NREP <= ClFixed::NREPCAP && C.NR <= ClFixed::NRCAP && T <= ClFixed::TCAP && (int)SC_N <= 8;
     if (fits && !(getenv("POTUS_CL_DYNAMIC") && atoi(getenv("POTUS_CL_DYNAMIC")))) {
       C.NDP = ClFixed::NDP; C.XW = ClFixed::XW;
       lay = ClFixed::L;
@@ -1563,7 +1546,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   C.l_C = lay.l_C; C.l_G = lay.l_G; C.l_Lw = lay.l_Lw; C.l_prior = lay.l_prior; C.l_pm = lay.l_pm; C.l_py = lay.l_py; C.l_pun = lay.l_pun;
   C.l_sub = lay.l_sub; C.l_tab = lay.l_tab; C.l_ru = lay.l_ru; C.l_wide = lay.l_wide; C.l_wout = lay.l_wout; C.l_X = lay.l_X; C.l_Y = lay.l_Y;
   C.l_r = lay.l_r; C.l_rep = lay.l_rep; C.l_bT = lay.l_bT; C.l_e = lay.l_e; C.l_c1 = lay.l_c1; C.l_c2 = lay.l_c2; C.l_c3 = lay.l_c3; C.l_ge = lay.l_ge;
-  C.l_P = lay.l_P; C.l_scal = lay.l_scal; C.l_red = lay.l_red; C.l_st = lay.l_st; C.l_prof = lay.l_prof; C.l_stl = lay.l_stl; C.l_gx = lay.l_gx; C.lds_doubles = lay.total;
+  C.l_P = lay.l_P; C.l_scal = lay.l_scal; C.l_red = lay.l_red; C.l_st = lay.l_st; C.l_prof = lay.l_prof; C.lds_doubles = lay.total;
   const int o = lay.total;
   sp->cl_lds_bytes = (size_t)o * 8 + sizeof(TS) + 16;
   if (sp->cl_lds_bytes > 160 * 1024 - 64) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode needs %zu bytes of LDS per workgroup", sp->cl_lds_bytes);
