@@ -107,6 +107,26 @@ def test_dense_sampler_follows_the_oracle_and_adapts_its_metric(cases, cus):
     h.close()
 
 
+@pytest.mark.parametrize("cus", [1, 8])
+@pytest.mark.parametrize("nw,windows", [(280, [(75, 99), (100, 229)]), (200, [(75, 99), (100, 149)])])
+def test_dense_adaptation_replayed_through_every_window_end(cases, nw, windows, cus):
+    """The dense sampler's adaptation lives on the HOST (potus_hmc.hip: the window counters of dense_transition_end, a mirror of
+    windowed_adaptation), so its schedule needs its own replay: 280 warm-up iterations = 75 | 25, then the second
+    window stretched to 130 | 50; 200 = 75 | 25, 50 (doubled) | 50.  Every step size from the device's own accept_stat__ column, the
+    D x D metric the device holds after EVERY update against covar_adaptation's regularised covariance of the very draws of that
+    window, init_stepsize under that matrix, and two transitions on either side of every window end replayed by the oracle."""
+    from adaptation_replay import adaptation_replayed_from_the_device_rows, rows_around, run_through_the_windows, window_schedule
+    data, variant = cases["small_full"]
+    assert window_schedule(nw, 75, 50, 25) == windows
+    h = Handle(data, variant, chains=2, num_warmup=nw, num_samples=2, save_warmup=1, seed=1843, metric=_abi.METRIC_DENSE, cus_per_chain=cus)
+    h.init()
+    held = run_through_the_windows(h, nw + 2)
+    assert sorted(held) == [e for _, e in windows]
+    for c in (0, 1):
+        assert adaptation_replayed_from_the_device_rows(data, variant, h, c, 1843, [(1, 2)] + rows_around([e for _, e in windows], 2) + [(nw, 2)], held) == len(windows)
+    h.close()
+
+
 def test_dense_sampler_is_reproducible_and_chunk_invariant(cases):
     data, variant = cases["small_nomode"]
     kw = dict(chains=3, num_warmup=40, num_samples=10, seed=7, metric=_abi.METRIC_DENSE)

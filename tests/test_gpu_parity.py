@@ -9,6 +9,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+from adaptation_replay import adaptation_replayed_from_the_device_rows as _adaptation_replayed_from_the_device_rows, rows_around, run_through_the_windows, window_schedule
 from conftest import GOLD
 from oracle_lib import OracleModel
 from us_potus_model_amd import Handle, PotusModel, _abi, diagnostics as dg, sampler
@@ -202,86 +203,6 @@ def test_nuts_follows_the_oracle_chain(cases, name, iters, cus):
     h.close()
 
 
-def _adaptation_replayed_from_the_device_rows(data, variant, h, chain, seed, replay_rows):
-    """Stan 2.24 adapt_diag_e_nuts restated from the device chain's OWN saved warm-up rows, one transition at a time, so that nothing
-    can drift (the technique of test_gpu_dense._post_window_rows_against_the_oracle, for the diagonal samplers):
-      * the step size of every transition = exp(x) of stepsize_adaptation::learn_stepsize fed with the accept_stat__ of the rows
-        before it (restarted after a metric update with mu = log(10 eps));
-      * at the end of a window the inverse metric = var_adaptation's regularised variance of the very draws saved for that window,
-        and the step size that follows = base_hmc::init_stepsize run by the ORACLE from the device's draw, that metric and the
-        step size learn_stepsize had just proposed (same Philox momenta);
-      * the step size kept after the warm-up = exp(x_bar);
-      * the transitions named in replay_rows are the oracle's transitions from the device's previous draw, step size and metric:
-        same tree depth, leapfrog count and divergence flag, values to 1e-6.
-    Covers warm-ups whose windows all lie inside the saved rows (save_warmup = 1)."""
-    o_ = h.opts
-    nw = o_.num_warmup
-    d = h.draws()[chain]
-    eps_final, minv_final = h.adaptation()
-    eps_final, minv_final = eps_final[chain], np.asarray(minv_final[chain])
-    D = h.D
-    m = OracleModel(data, variant)
-    o = m.default_opts(num_warmup=nw, num_samples=o_.num_samples, seed=seed, fast_grad=1, max_depth=o_.max_depth)
-    chain_id = o_.chain_id_offset + chain + 1
-    ib, tb, bw = o_.init_buffer, o_.term_buffer, o_.window          # windowed_adaptation's constructor
-    if nw >= 20 and ib + bw + tb > nw:
-        ib, tb = int(0.15 * nw), int(0.1 * nw)
-        bw = nw - (ib + tb)
-    win_size, win_next = bw, ib + bw - 1
-    delta, gamma, kappa, t0 = o_.delta, o_.gamma, o_.kappa, o_.t0
-    # the very first search: from the initial point (U(-2,2), Philox index = Stan index, first attempt) with the unit metric
-    q_init = np.array([o_.init_radius * (2.0 * m.L.oracle_rng_uniform(seed, chain_id, 0xFFFFFFFF, 5, 0, i) - 1.0) for i in range(D)])
-    minv = np.ones(D)
-    eps0 = m.init_stepsize_from(chain_id, o, 0xFFFFFFFF, q_init, o_.stepsize, minv)
-    assert d[0, 2] == eps0, (d[0, 2], eps0)
-    mu, s_bar, x_bar, cnt = np.log(10.0 * o_.stepsize), 0.0, 0.0, 0.0   # (services: set_mu(log(10 * stepsize)) precedes the first search)
-    wf = []                                                          # draws of the current window
-    metric_at = {}                                                   # first row that ran under the metric
-    next_eps = eps0
-    for it in range(nw):
-        assert abs(d[it, 2] / next_eps - 1.0) < 1e-12, (it, d[it, 2], next_eps)
-        metric_at[it] = minv
-        cnt += 1.0                                                   # learn_stepsize
-        a = min(1.0, d[it, 1])
-        eta = 1.0 / (cnt + t0)
-        s_bar = (1.0 - eta) * s_bar + eta * (delta - a)
-        x = mu - s_bar * np.sqrt(cnt) / gamma
-        x_eta = cnt ** (-kappa)
-        x_bar = (1.0 - x_eta) * x_bar + x_eta * x
-        next_eps = np.exp(x)
-        if nw >= 20:                                                 # learn_variance
-            if ib <= it < nw - tb:
-                wf.append(d[it, 7:])
-            if it == win_next:
-                n = float(len(wf))
-                want = (n / (n + 5.0)) * np.var(np.array(wf), axis=0, ddof=1) + 1e-3 * (5.0 / (n + 5.0))
-                wf = []
-                last = nw - tb - 1                                   # compute_next_window
-                if win_next != last:
-                    win_size *= 2
-                    win_next = it + win_size
-                    if win_next != last and win_next + 2 * win_size >= nw - tb:
-                        win_next = last
-                later_update = win_next > it and win_next < nw
-                if not later_update:                                 # the last metric update: the device still holds it
-                    assert np.allclose(minv_final, want, rtol=1e-9, atol=0), np.abs(minv_final / want - 1).max()
-                    minv = minv_final
-                else:
-                    minv = want
-                next_eps = m.init_stepsize_from(chain_id, o, it, d[it, 7:], next_eps, minv)
-                mu, s_bar, x_bar, cnt = np.log(10.0 * next_eps), 0.0, 0.0, 0.0
-    assert abs(eps_final / np.exp(x_bar) - 1.0) < 1e-12, (eps_final, np.exp(x_bar))   # complete_adaptation
-    for it in range(nw, len(d)):                                     # sampling: the adapted step size and metric
-        assert d[it, 2] == eps_final
-        metric_at[it] = minv_final
-    for first, count in replay_rows:
-        for it in range(first, first + count):
-            ref = m.transitions_from(chain_id, o, it, d[it - 1, 7:], d[it, 2], metric_at[it])[0]
-            assert np.array_equal(d[it, 3:6], ref[3:6]), (it, d[it, :7], ref[:7])                  # treedepth__, n_leapfrog__, divergent__
-            assert np.allclose(d[it, [0, 1, 6]], ref[[0, 1, 6]], rtol=1e-6, atol=1e-8), (it, d[it, :7], ref[:7])
-            assert np.allclose(d[it, 7:], ref[7:], rtol=1e-6, atol=1e-7), (it, np.abs(d[it, 7:] - ref[7:]).max())
-
-
 @pytest.mark.parametrize("cus,twin", [(1, 0), (1, 1), (16, 0), (16, 1)])
 def test_adaptation_matches_oracle_through_a_metric_update(cases, cus, twin):
     """150 warm-up iterations of the small model: init buffer, one window (draws 75 .. 99), metric update + init_stepsize, term
@@ -317,6 +238,45 @@ def test_diag_transitions_after_the_window_match_the_oracle_at_2016_size(cases, 
     h.run(nw + 2)
     assert np.isfinite(h.draws()).all()
     _adaptation_replayed_from_the_device_rows(data, variant, h, 1, 1843, [(33, 3), (36, 3), (40, 2)])
+    h.close()
+
+
+@pytest.mark.parametrize("cus,twin", [(1, 0), (1, 1), (16, 0), (16, 1)])
+@pytest.mark.parametrize("nw,windows", [(500, [(75, 99), (100, 149), (150, 249), (250, 449)]), (400, [(75, 99), (100, 149), (150, 349)])])
+def test_adaptation_replayed_through_every_window_end(cases, nw, windows, cus, twin):
+    """The schedules the reference runs.  500 warm-up iterations are final_2016.R:6-11,533-541's: 75 | 25, 50, 100, 200 | 50
+    -- four metric updates through the DOUBLING branch of windowed_adaptation::compute_next_window; 400 give 75 | 25, 50, 200 | 50 -- the
+    third window STRETCHED to the start of the terminal buffer.  Small model, every form of the diagonal sampler, both chains: every
+    step size of the warm-up from the device's own accept_stat__ column, the metric the device holds after EVERY update against the
+    regularised variance of the very draws of that window, init_stepsize at every window end, and three transitions on either side
+    of every window end (plus the first and last of the warm-up) replayed by the oracle from the device's own rows."""
+    data, variant = cases["small_full"]
+    assert window_schedule(nw, 75, 50, 25) == windows
+    h = Handle(data, variant, chains=2, num_warmup=nw, num_samples=3, save_warmup=1, seed=11, cus_per_chain=cus, twin=twin)
+    h.init()
+    held = run_through_the_windows(h, nw + 3)
+    assert sorted(held) == [e for _, e in windows]
+    for c in (0, 1):
+        n = _adaptation_replayed_from_the_device_rows(data, variant, h, c, 11, [(1, 3)] + rows_around([e for _, e in windows]) + [(nw - 2, 5)], held)
+        assert n == len(windows)
+    h.close()
+
+
+@pytest.mark.parametrize("name,cus,twin", [("2016", 16, 1), ("2008", 16, 0), ("2012", 1, 1)])
+def test_two_window_ends_at_2016_size(cases, name, cus, twin):
+    """The headline kernels through two metric updates at full size: init_buffer = window = term_buffer = 10 of 60 warm-up iterations
+    -> windows of 10 (rows 10 .. 19) and, stretched, 30 (rows 20 .. 49).  Both chains; k_cl_run<16, true> on 2016, the dynamic
+    cluster build on 2008 (no-mode variant), two workgroups per chain on 2012."""
+    data, variant = cases[name]
+    nw = 60
+    assert window_schedule(nw, 10, 10, 10) == [(10, 19), (20, 49)]
+    h = Handle(data, variant, chains=2, num_warmup=nw, num_samples=2, save_warmup=1, seed=1843, cus_per_chain=cus, twin=twin,
+               init_buffer=10, term_buffer=10, window=10)
+    h.init()
+    held = run_through_the_windows(h, nw + 2)
+    assert sorted(held) == [19, 49] and np.isfinite(h.draws()).all()
+    for c in (0, 1):
+        assert _adaptation_replayed_from_the_device_rows(data, variant, h, c, 1843, [(18, 2), (20, 2), (48, 2), (50, 2), (60, 2)], held) == 2
     h.close()
 
 

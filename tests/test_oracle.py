@@ -287,3 +287,27 @@ def test_transitions_from_replays_a_chain(cases):
         assert np.array_equal(rows[:, 3:6], d[40:46, 3:6])
         np.testing.assert_allclose(rows[:, [0, 1, 6]], d[40:46][:, [0, 1, 6]], rtol=1e-9)
         np.testing.assert_allclose(rows[:, 7:], d[40:46, 7:], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("nw,windows,dense", [(500, [(75, 99), (100, 149), (150, 249), (250, 449)], 0), (400, [(75, 99), (100, 149), (150, 349)], 0),
+                                              (280, [(75, 99), (100, 229)], 0), (30, [(4, 26)], 0),
+                                              (280, [(75, 99), (100, 229)], 1), (30, [(4, 26)], 1)])   # (the oracle's dense_e chain costs 25 s per 280 iterations)
+def test_the_replay_harness_accepts_the_oracles_own_chain(cases, nw, windows, dense):
+    """tests/adaptation_replay.py is what holds the device samplers to Stan's adaptation window by window (GPU suite).  Here the harness
+    itself is checked on a chain that must satisfy it: the oracle's own (its window schedule, oracle/potus_oracle.c:1006-1065, against the
+    Python restatement of windowed_adaptation::compute_next_window -- doubling, the stretched last window, the constructor's rescaling for
+    short warm-ups), diagonal and dense."""
+    from types import SimpleNamespace
+    from adaptation_replay import adaptation_replayed_from_the_device_rows, rows_around, window_schedule
+    data, variant = cases["small_full"]
+    assert window_schedule(nw, 75, 50, 25) == windows
+    m = OracleModel(data, variant)
+    o = m.default_opts(num_warmup=nw, num_samples=3, seed=11, save_warmup=1, dense_metric=dense, fast_grad=1)
+    d, adapt, _, metric = m.sample_chain_metric(1, o)
+    opts = SimpleNamespace(num_warmup=nw, num_samples=3, max_depth=o.max_depth, init_buffer=75, term_buffer=50, window=25, chain_id_offset=0, chains=1,
+                           delta=o.delta, gamma=o.gamma, kappa=o.kappa, t0=o.t0, stepsize=o.stepsize, init_radius=o.init_radius,
+                           metric=_abi.METRIC_DENSE if dense else _abi.METRIC_DIAG)
+    fake = SimpleNamespace(opts=opts, D=m.D, draws=lambda: d[None], adaptation=lambda: (np.array([adapt[0]]), adapt[None, 1:]),
+                           dense_metric=lambda c: metric)
+    n = adaptation_replayed_from_the_device_rows(data, variant, fake, 0, 11, [(1, 2)] + rows_around([e for _, e in windows], 2) + [(nw, 3)])
+    assert n == len(windows)
