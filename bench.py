@@ -14,6 +14,12 @@ objects, allocator).
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|3|4]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset) starts its own N ranks -- it re-executes itself
+under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1 with a free port, one rank per GPU over the "nccl"
+backend (= RCCL), rank 0 prints the ONE JSON line and the parent returns the ranks' exit status.  Fewer than N visible GPUs is an error
+(exit status 2), never an n_gpus = 1 line.  HSA_ENABLE_IPC_MODE_LEGACY=0 is set (if unset) before the first HIP call: the host driver of
+these boxes only supports dmabuf IPC and RCCL's intra-node transport fails without it.
+
 --config 1/2  2016 backtest, C = 8 chains per GPU (configs[1]; with N GPUs configs[2]: 8 N chains, one RCCL all-gather
               of the draws-of-interest for pooled R-hat / ESS, device buffers end to end)
 --config 0    the reference's own sampler calls as scripted (6 chains x (500 + 500), seed 1843: final_2016.R, final_2012.R, final_2008.R;
@@ -71,6 +77,91 @@ def measured_traffic(kernel, sides=1):
         if d.get("kernel") == kernel and (kernel != "k_cl_run" or ("two clusters" in d.get("command", "")) == (sides == 2)):
             best = (f.name, d)
     return best
+
+
+# ------------------------------------------------------------------------------------------------ N ranks
+def visible_gpus():
+    """HIP devices this process would see, counted in a child process so that the parent never initialises the runtime before its ranks do."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count() if torch.cuda.is_available() else 0)"],
+                             capture_output=True, text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N ranks of this very command under torch.distributed.run (see the module docstring)."""
+    import socket
+    import subprocess
+    have = visible_gpus()
+    if os.environ.get("POTUS_DIST_BACKEND") != "gloo" and have < n:
+        print(f"bench.py: --gpus {n} but {have} HIP device(s) visible on this box: refusing to run (no line is printed for a run that did not happen)", file=sys.stderr)
+        return 2
+    if have < 1:
+        print("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------ the other configurations, beside the default line
+def side_measurements(seed, budget_s=150.0):
+    """BASELINE's other single-GPU configurations under the same clock as the default line: each is this very script with
+    --config X in a child process (GPU only: no CPU baseline, no saturated point, no side measurements of its own), after the timed region and
+    after the default run's handles are gone; the child's JSON line is kept in a compact form.  A failure or a timeout costs its own entry only."""
+    import subprocess
+    out, t_all = {}, time.perf_counter()
+    for key, cfg, extra, tmo in (("configs[0]", 0, [], 120), ("configs[3]", 3, [], 120), ("configs[4]_preset", 4, [], 240)):
+        left = budget_s - (time.perf_counter() - t_all)
+        if left < 20:
+            out[key] = {"skipped": "time budget of the side measurements spent"}
+            continue
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--config", str(cfg), "--seed", str(seed), "--no-cpu-baseline", "--no-saturated", "--no-side"] + extra,
+                               capture_output=True, text=True, timeout=min(tmo, left), env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or len(lines) != 1:
+                out[key] = {"error": (r.stderr or r.stdout)[-300:], "rc": r.returncode}
+                continue
+            d = json.loads(lines[0])
+            e = {"baseline_config_index": cfg, "command": f"bench.py --config {cfg}", "value": d["value"], "unit": d["unit"], "metric": d["metric"], "steps": d["steps"],
+                 "ms_per_step": d["ms_per_step"], "workload": d["config"]["workload"], "wall_seconds_with_process_start": time.perf_counter() - t0}
+            for k in ("seconds", "leapfrogs", "ess_bulk_min", "ess_per_sec", "rhat_max", "us_per_leapfrog_per_chain"):
+                if k in d:
+                    e[k] = d[k]
+            if "roofline" in d:
+                e["roofline"] = {k: d["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms_total", "leapfrogs_in_launches",
+                                                                "matrix_passes", "avg_pass_ms", "matrix_bytes_streamed", "metric_storage") if k in d["roofline"]}
+            if "runs" in d:     # configs[0]: the reference's scripted calls, one by one
+                e["runs"] = [{"call": r_["call"], "posterior": r_["posterior"], "variant": r_["variant"], "chains": r_["chains"], "iter_warmup": r_["iter_warmup"],
+                              "iter_sampling": r_["iter_sampling"], **{k: r_["gpu"][k] for k in ("seconds", "leapfrogs", "leapfrogs_per_sec", "ess_bulk_min", "ess_per_sec",
+                                                                                               "divergent_transitions", "cus_per_chain", "clusters_per_chain")}} for r_ in d["runs"]]
+            if "dense" in d:
+                e["dense"] = {k: d["dense"][k] for k in ("window_ends", "window_end_seconds", "cholesky_seconds", "cholesky_tflops", "adapted_phase") if k in d["dense"]}
+                e["max_depth"] = d["config"].get("max_depth")
+            if "posteriors" in d["config"]:
+                e["posteriors"] = {n: {k: v[k] for k in ("chains_per_gpu", "D", "cus_per_chain", "clusters_per_chain", "divergent_transitions", "ess_bulk_min", "rhat_max") if k in v}
+                                   for n, v in d["config"]["posteriors"].items()}
+            out[key] = e
+        except subprocess.TimeoutExpired:
+            out[key] = {"error": f"timed out after {time.perf_counter() - t0:.0f} s"}
+        except Exception as ex:                        # never let a side measurement spoil the bench line
+            out[key] = {"error": str(ex)[:200]}
+    out["note"] = ("GPU-only runs of `bench.py --config X` in child processes after the default line's timed region: same box, same clock; "
+                   "configs[0] = the reference's scripted sampler calls (final_2016.R:533-541 and its 2012 / 2008 siblings), configs[3] = the three backtests "
+                   "concurrently on this one GPU (4 chains each), configs[4]_preset = the dense-metric stress shape in its driver-runnable preset")
+    out["seconds"] = time.perf_counter() - t_all
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -137,10 +228,11 @@ def cpu_baseline(data, variant, chains, seed, nw, ns, short, budget=12.0, loop_b
     cols = np.stack([r[2] for r in sres])                                    # [chain, draw, 1 + 2 S]
     s_ess = ess_min(cols)
     s_secs, s_samp = float((st[:, 0] + st[:, 1]).max()), float(st[:, 1].max())   # the chains run side by side: the slowest sets the time
-    out = dict(value=rate, unit="leapfrogs/s", cores=procs, kind="port", leapfrogs_per_sec_per_core=rate / procs,
+    out = dict(value=rate, unit="leapfrogs/s", cores=procs, host_cores_total=os.cpu_count(), kind="port", leapfrogs_per_sec_per_core=rate / procs,
                sample=f"the first {int(timing[:, 4].min())}-{int(timing[:, 4].max())} iterations of the same run ({procs} chains, ids 1..{procs}, seed {seed}, "
                       f"{nw} warm-up + {ns} sampling configured) on {procs} host processes, cut after {budget:.0f} s each: "
                       f"{int(timing[:, 2:4].sum())} leapfrogs; scan/sparse gradient, pooled-buffer tree (the fastest form of the port)",
+               cores_note=f"one process per chain, as the reference runs its chains (final_2016.R:536): {procs} of the box's {os.cpu_count()} host cores are used",
                seconds=wall, **loop,
                leapfrog_loop_note="plain leapfrog loops (unit metric, eps 0.01, no tree, no U-turn bookkeeping) of the literal stan:86 recursion and of the "
                                   f"scan/sparse gradient, {procs} processes x {loop_budget:.0f} s each: the rate of the arithmetic alone",
@@ -259,7 +351,14 @@ def main():
     ap.add_argument("--seed", type=int, default=1843)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturated", action="store_true", help="skip the 256-chain reference point")
+    ap.add_argument("--no-side", action="store_true", help="skip the side measurements of configs[0], configs[3] and the configs[4] preset (default line only)")
     args = ap.parse_args()
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the first HIP call (module docstring)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     import torch
     from us_potus_model_amd import Handle, diagnostics as dg, parallel, run_many
@@ -268,12 +367,14 @@ def main():
     # the N > 1 flow on a one-GPU box (the measured configuration is one rank per GPU over RCCL)
     dev_backend = os.environ.get("POTUS_DIST_BACKEND")
     rank, world, local = parallel.init_process_group(dev_backend)
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     if dev_backend == "gloo":
         local = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {args.gpus}: {torch.cuda.device_count()} HIP device(s) visible, one rank per GPU needs {world}")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     coll_dev = None if dev_backend == "gloo" else dev       # collectives on CPU tensors in the development mode
@@ -387,16 +488,20 @@ def main():
         td0 = time.perf_counter()
         if ns >= 8 and full.is_cuda:
             from us_potus_model_amd import device_diagnostics_of_block
-            ncols_all = int(full.shape[2])
+            # + predicted_score[T, :] = inv_logit(mu_b[:, T]) as S columns of their own (stan:137): a monotone map keeps the ranks, hence
+            # the bulk ESS, but not the FOLDED split R-hat (|x - median| is not invariant under it), and the metric's column set names them
+            blk = torch.cat([full, torch.sigmoid(full[:, :, 1 + ncol - S:])], dim=2)
+            ncols_all = int(blk.shape[2])
             if world == 1:
-                rh, es = device_diagnostics_of_block(full.contiguous())
+                rh, es = device_diagnostics_of_block(blk.contiguous())
             else:
                 # every rank holds the pooled chains; each sorts its 1/world share of the columns (per-GPU work stays what it is at
                 # N = 1: world x the draws, 1/world of the columns) and the per-column results are gathered
                 ca, cb = parallel.column_block(ncols_all, rank, world)
-                rh_l, es_l = device_diagnostics_of_block(full[:, :, ca:cb].contiguous()) if cb > ca else (np.zeros(0), np.zeros(0))
+                rh_l, es_l = device_diagnostics_of_block(blk[:, :, ca:cb].contiguous()) if cb > ca else (np.zeros(0), np.zeros(0))
                 rh, es = parallel.all_gather_columns(rh_l, ncols_all, coll_dev), parallel.all_gather_columns(es_l, ncols_all, coll_dev)
             dev_diag.append({"rhat": rh, "ess_bulk": es, "seconds": time.perf_counter() - td0, "columns": ncols_all, "S": S})
+            del blk
         else:
             dev_diag.append(None)
         sel = torch.cat([full[:, :, :1], full[:, :, 1 + ncol - S:]], dim=2)   # lp__ and mu_b[:, T]
@@ -428,17 +533,16 @@ def main():
                                 "leaves_run_per_counted": (rb + rf) / max(cnt, 1),
                                 "note": "each side integrates the doublings of its end, those of speculative subtrees that are dropped included"}
             if dd is not None:
-                # The metric's ESS: min bulk-ESS over lp__, mu_b[:, T], predicted_score[T, :].  predicted_score is a monotone
-                # map of mu_b column for column, so its ranks -- and rank-normalised ESS / R-hat -- are mu_b's: the set is lp__ and the
-                # last S gathered columns (--gather full: the last day of the S x T block; --gather T: all of them).
+                # The metric's ESS: min bulk-ESS (and max R-hat) over lp__, mu_b[:, T], predicted_score[T, :]: column 0 and the
+                # last 2 S columns of the block the diagnostics ran on (mu_b's last day, then its inverse logit).
                 Sd = dd["S"]
-                sel = np.r_[0, np.arange(dd["columns"] - Sd, dd["columns"])]
+                sel = np.r_[0, np.arange(dd["columns"] - 2 * Sd, dd["columns"])]
                 info["ess_bulk_min"] = float(np.nanmin(dd["ess_bulk"][sel]))
                 info["rhat_max"] = float(np.nanmax(dd["rhat"][sel]))
                 info["pooled_draws"] = int(ns * C * world)
                 info["device_diagnostics"] = {"columns": dd["columns"], "seconds": dd["seconds"], "ess_bulk_min_all_columns": float(np.nanmin(dd["ess_bulk"])),
                                               "ess_bulk_median_all_columns": float(np.nanmedian(dd["ess_bulk"])), "rhat_max_all_columns": float(np.nanmax(dd["rhat"])),
-                                              "note": "potus_diagnostics_device over every gathered column (lp__ + mu_b), pooled chains of all ranks, inside the timed region"}
+                                              "note": "potus_diagnostics_device over every gathered column (lp__ + mu_b) + predicted_score[T, :], pooled chains of all ranks, inside the timed region"}
                 ess_all.append(info["ess_bulk_min"]); rhat_all.append(info["rhat_max"])
             elif pl is not None and ns >= 8:                                     # development mode (collectives on CPU tensors): the numpy restatement
                 x = np.transpose(pl.cpu().numpy(), (1, 0, 2))                    # [chain, draw, 1 + S]
@@ -592,6 +696,11 @@ def main():
             line["speedup_vs_cpu_leapfrog_loop"] = line["value"] / cb["leapfrog_loop_scan_sparse_value"]
             line["speedup_note"] = ("speedup_vs_cpu_port: against the port's NUTS in its fastest form (scan/sparse gradient, pooled tree) on the box's "
                                     f"{cb['cores']} cores; speedup_vs_cpu_leapfrog_loop: against its bare leapfrog loop, which no CPU sampler can exceed")
+        if world == 1 and cfg == 1 and not args.no_side:
+            for h in hs:
+                h.close()
+            torch.cuda.empty_cache()
+            line["side"] = side_measurements(args.seed)
         print(json.dumps(line), flush=True)
     for h in hs:
         h.close()

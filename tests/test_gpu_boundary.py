@@ -362,6 +362,31 @@ def test_bench_two_ranks_end_to_end_gloo_development_mode(tmp_path):
     assert d["config"]["posteriors"]["2016"]["pooled_draws"] == 8 * 20 and d["leapfrogs"] > 0 and d["roofline"]["frac"] > 0
 
 
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` WITHOUT a launcher around it -- the command the driver issues for its scaling runs -- starts two ranks
+    by itself (re-execution under torch.distributed.run on 127.0.0.1 with a free port) and prints ONE line with n_gpus = 2, 16 chains,
+    configs[2] (until round 4 the bare command ran one rank and printed an n_gpus = 1 line).  On a one-GPU box: the
+    development mode (both ranks on GPU 0, gloo collectives, clusters of 8 so that the two processes' workgroups fit the chip together);
+    with two GPUs: one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT, gpu_count
+    two = gpu_count() >= 2
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "POTUS_DIST_BACKEND")}
+    if not two:
+        env["POTUS_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--chunk", "10", "--no-cpu-baseline", "--no-saturated"] + \
+          ([] if two else ["--cus-per-chain", "8"])
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(ROOT))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["total_chains"] == 16 and d["config"]["baseline_config_index"] == 2 and "configs[2]" in d["config"]["workload"]
+    assert d["config"]["posteriors"]["2016"]["pooled_draws"] == 16 * 10 and d["leapfrogs"] > 0
+
+
 def test_rccl_collectives_on_device_buffers_one_rank():
     """The collectives bench.py issues at N > 1 -- all_gather_into_tensor of the [draws, chains, columns] block, MAX / SUM
     all-reduces of a double, barrier -- on the "nccl" backend (= RCCL) with device tensors.  One GPU here, so a group of
@@ -484,4 +509,4 @@ def test_bench_two_ranks_over_rccl_on_two_gpus():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["total_chains"] == 16 and d["config"]["baseline_config_index"] == 2 and "configs[2]" in d["config"]["workload"]
     post = d["config"]["posteriors"]["2016"]
-    assert post["pooled_draws"] == 16 * 20 and post["device_diagnostics"]["columns"] == 12955 and d["leapfrogs"] > 0
+    assert post["pooled_draws"] == 16 * 20 and post["device_diagnostics"]["columns"] == 12955 + 51 and d["leapfrogs"] > 0

@@ -251,3 +251,20 @@ def test_layout_plan_for_every_chain_count():
         sampler.plan_layout(40, 600, one_workgroup_ok=False)                       # 40 chains x 8 compute units do not fit
     with pytest.raises(sampler.PotusError):
         sampler.plan_layout(2, 600, cus_per_chain=1, one_workgroup_ok=False)
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`python bench.py --gpus N` with fewer than N visible GPUs exits non-zero and prints NO JSON line (here: no GPU at all; on a GPU box:
+    fewer than 64) -- it must never fall back to an n_gpus = 1 line, which a scaling run would record as an N-GPU number."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "POTUS_DIST_BACKEND")}
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "64", "--steps", "2", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=600, cwd=str(ROOT))
+    assert out.returncode != 0 and "refusing to run" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    # a launcher that started a different number of ranks than --gpus says is an error too, even a single rank
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2"], capture_output=True, text=True, timeout=600, cwd=str(ROOT),
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

@@ -27,6 +27,10 @@ def chain_block(total_chains: int, rank: int, world: int):
 
 
 def init_process_group(backend: str | None = None):
+    """Join the job's process group (no-op for a single process).  HSA_ENABLE_IPC_MODE_LEGACY=0 is set if unset: the host driver of the
+    MI355X boxes only supports dmabuf IPC, and RCCL's intra-node transport (hipIpcGetMemHandle) fails without it.  ROCr reads the variable
+    when the runtime initialises, so call this -- or set the variable -- before the process's first HIP call (bench.py does both)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     rank, world, local = env_rank_world()
