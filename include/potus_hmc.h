@@ -248,7 +248,9 @@ int potus_backtest_scores(const double *state_out, int T, int S, int day, const 
 /* Cross-chain diagnostics on the device: rank-normalised split R-hat and bulk ESS (Vehtari et al. 2021; the definitions bench.py's
  * ESS/s uses) of the columns [col_begin, col_end) of the output row, over the pooled chains of several handles of ONE posterior
  * (equal numbers of saved draws).  The reference has no counterpart (final_2016.R:543-556 never looks at a diagnostic); the
- * all-gather of BASELINE.json's north_star exists "to pool draws for R-hat / ESS".  rhat_out, ess_bulk_out: [col_end - col_begin]. */
+ * all-gather of BASELINE.json's north_star exists "to pool draws for R-hat / ESS".  rhat_out, ess_bulk_out: [col_end - col_begin].
+ * Warm-up rows saved with save_warmup = 1 are left out, as rstan::monitor / extract() leave them out; at most 512 chains pooled; a
+ * column that holds a NaN or an infinite draw gets NaN for both, a constant column NaN as in `posterior`. */
 int potus_diagnostics(const int *handles, int n_handles, int col_begin, int col_end, double *rhat_out, double *ess_bulk_out);
 /* The same for a block that already sits in DEVICE memory of GPU `device`: block[draw][chain][column] -- the layout
  * potus_write_array_device produces and an RCCL all-gather of it keeps.  rhat_out, ess_bulk_out: host arrays [n_cols]. */

@@ -21,6 +21,10 @@ int potus_debug_state(int handle, int which, double *out, unsigned char *scal);
 /* -DPOTUS_PROF builds: the in-kernel cycle counters, [chains x members (x 2)][64] doubles (scripts/gpu_probe.py).  Returns 1 when
  * the build carries them, 0 otherwise. */
 int potus_debug_profile(int handle, double *out);
+/* Which build of the cluster pass the handle runs: 4 / 8 = days per wave with every size read from the model descriptor, 12 = 4 days per
+ * wave with the adjoint product on the fp64 matrix cores, 16 / 17 = the fixed-layout builds of poll_model_2020.stan / its
+ * no_mode_adjustment variant; 0 = one workgroup per chain; -1 = bad handle (tests: which posterior gets which kernel). */
+int potus_debug_build_tag(int handle);
 /* Dense metric, without a sampler: y = M^-1 x for `chains` matrices (D x D, row-major, upper triangle read) and nrhs <= 3 vectors
  * each by the sampler's matrix pass (k_dn_symv + k_dn_symv_finish), repeated `reps` times; dot_host: x_0 . y_0 per chain; ms: time
  * of the passes; pass_bytes: bytes of matrix one pass loads (tests/test_gpu_dense.py, scripts/micro/dense_probe.py). */

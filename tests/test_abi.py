@@ -137,3 +137,14 @@ def test_device_code_has_no_waterfall_loops(tmp_path):
     bad = [asm[i].strip() for i in range(len(asm) - 1) if mem.search(asm[i]) and "s_xor_b64 exec, exec" in asm[i + 1]]
     assert not bad, bad[:5]
     shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+def test_the_library_was_built_from_these_sources():
+    """libpotus_hmc.so is git-ignored and travels prebuilt to the GPU box: the digest __graft_entry__.build() leaves beside it must be that of the
+    sources in the tree (a source edited after -- or during -- the last build would otherwise ship a library that is not the code under review)."""
+    import __graft_entry__ as g
+    src = g.PKG / "csrc"
+    deps = [src / "potus_hmc.hip", *sorted(src.glob("*.hpp")), *sorted((g.ROOT / "include").glob("*.h"))]
+    stamp = g.PKG / "libpotus_hmc.so.src"
+    assert stamp.exists(), "run `python __graft_entry__.py` (build())"
+    assert stamp.read_text().strip() == g._digest(deps), "libpotus_hmc.so is older than its sources: run `python __graft_entry__.py`"

@@ -467,6 +467,38 @@ def test_device_diagnostics_match_the_numpy_restatement(draws, chains, ncols):
 
 
 @pytest.mark.gpu
+def test_device_diagnostics_of_non_finite_columns_and_saved_warmup_rows(cases):
+    """a column holding a NaN or an infinite draw gets NaN for both diagnostics (numpy propagates it; the padding key of the
+    bitonic sort is a NaN pattern); with save_warmup = 1 the warm-up rows are left out, as rstan::monitor / extract() leave them out;
+    more pooled chains than the kernel's tables hold are refused before anything is allocated."""
+    from us_potus_model_amd import device_diagnostics
+    rng = np.random.default_rng(3)
+    blk = rng.standard_normal((200, 4, 4))
+    blk[17, 2, 1] = np.nan
+    blk[5, 0, 2] = np.inf
+    blk[199, 3, 3] = -np.inf
+    L = sampler.load_library()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    p, free = _device_block(blk)
+    rhat, ess = np.zeros(4), np.zeros(4)
+    assert L.potus_diagnostics_device(0, p, 200, 4, 4, dp(rhat), dp(ess)) == 0
+    r_ref, e_ref = _numpy_diagnostics(blk[:, :, :1])
+    assert np.allclose(rhat[0], r_ref[0], rtol=1e-10) and np.allclose(ess[0], e_ref[0], rtol=1e-10)
+    assert np.isnan(rhat[1:]).all() and np.isnan(ess[1:]).all()
+    assert L.potus_diagnostics_device(0, p, 2, 600, 1, dp(rhat), dp(ess)) != 0            # 600 chains pooled: refused up front
+    free()
+    data, variant = cases["small_full"]
+    h = Handle(data, variant, chains=3, num_warmup=40, num_samples=30, seed=5, save_warmup=1)
+    h.init(); h.run(70)
+    a = h.layout["mu_b"][0]
+    for cb, ce in ((0, 1), (a, a + 12)):
+        rhat, ess = device_diagnostics([h], cb, ce)
+        r_ref, e_ref = _numpy_diagnostics(h.write_array(cb, ce, 70)[40:])                 # the 30 sampling rows only
+        assert np.allclose(rhat, r_ref, rtol=1e-10, equal_nan=True) and np.allclose(ess, e_ref, rtol=1e-10, equal_nan=True)
+    h.close()
+
+
+@pytest.mark.gpu
 def test_device_diagnostics_over_the_chains_of_several_handles(cases):
     """potus_diagnostics pools the chains of the listed handles (chain ids 1-3 and 4-5 of one posterior): lp__ and a block of mu_b
     columns against diagnostics.py on the same rows fetched with potus_write_array."""

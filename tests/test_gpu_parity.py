@@ -183,6 +183,51 @@ def test_log_prob_grad_is_deterministic_and_batched(cases, cus):
     h.close()
 
 
+@pytest.mark.parametrize("name,tag", [("2016", 16), ("2012", 17), ("2008", 17), ("small_full", 4)])
+def test_fixed_layout_builds_serve_both_variants_and_agree_with_the_dynamic_one(cases, name, tag, monkeypatch):
+    """The reference's posteriors on clusters of 16 take the fixed-layout builds of the pass: tag 16 for poll_model_2020.stan (2016), tag 17
+    for poll_model_2020_no_mode_adjustment.stan (final_2012.R:558, final_2008.R:562; round 5 -- until then they ran the dynamic build).
+    Same arithmetic in the same order as the dynamic build (POTUS_CL_DYNAMIC=1): log density, gradient and the first transitions bit for bit."""
+    data, variant = cases[name]
+    K = 16 if tag >= 16 else 4
+    kw = dict(chains=2, num_warmup=20, num_samples=0, save_warmup=1, seed=1843, cus_per_chain=K)
+    q = np.random.default_rng(2).uniform(-2, 2, (3, Handle(data, variant, chains=1, cus_per_chain=1).D))
+    out = []
+    for dyn in ("0", "1"):
+        monkeypatch.setenv("POTUS_CL_DYNAMIC", dyn)
+        h = Handle(data, variant, **kw)
+        assert h.L.potus_debug_build_tag(h.h) == (tag if dyn == "0" else 4)
+        lp, g = h.log_prob_grad(q)
+        h.init(); h.run(4)
+        out.append((lp, g, h.draws()[:, :4].copy()))
+        h.close()
+    m = OracleModel(data, variant)
+    for i in range(3):
+        lpo, go = m.log_prob_grad(q[i])
+        assert abs(out[0][0][i] - lpo) <= 1e-11 * abs(lpo) and np.abs(out[0][1][i] - go).max() <= 1e-10 * np.abs(go).max()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("cus", [1, 4, 16])
+def test_negative_scales_are_their_absolute_values(cases, cus):
+    """Stan bounds none of the three scales and only uses their squares (stan:50-52), so a negative scale gives the same posterior.  The
+    cluster pass folds L_T = aT L_W, L_B = aB L_W with aT, aB = ratios of the scales (signed until round 5, which flipped the
+    prior deviation of mu_b_T / polling_bias on clusters only): log density and gradient against the oracle, and against the positive
+    scales bit for bit."""
+    data, variant = cases["2016" if cus == 16 else "small_full"]
+    neg = dict(data, mu_b_T_scale=-data["mu_b_T_scale"], polling_bias_scale=-data["polling_bias_scale"])
+    q = np.random.default_rng(5).uniform(-2, 2, (2, Handle(data, variant, chains=1, cus_per_chain=cus).D))
+    hp, hn = Handle(data, variant, chains=1, cus_per_chain=cus), Handle(neg, variant, chains=1, cus_per_chain=cus)
+    (lp_p, g_p), (lp_n, g_n) = hp.log_prob_grad(q), hn.log_prob_grad(q)
+    assert np.array_equal(lp_p, lp_n) and np.array_equal(g_p, g_n)
+    m = OracleModel(neg, variant)
+    for i in range(2):
+        lpo, go = m.log_prob_grad(q[i])
+        assert abs(lp_n[i] - lpo) <= 1e-11 * abs(lpo) and np.abs(g_n[i] - go).max() <= 1e-10 * np.abs(go).max()
+    hp.close(); hn.close()
+
+
 @pytest.mark.parametrize("cus", CUS)
 @pytest.mark.parametrize("name,iters", [("small_full", 8), ("small_nomode", 8), ("2016", 3), ("2012", 3), ("2008", 3)])
 def test_nuts_follows_the_oracle_chain(cases, name, iters, cus):

@@ -132,9 +132,10 @@ struct ClFixed {
   static constexpr int lds_doubles = L.total;
 };
 template <int TAG> struct ClTag {
-  static constexpr int DW = (TAG == 12 || TAG == 16) ? 4 : TAG;      // days per wave
+  static constexpr int DW = (TAG == 12 || TAG == 16 || TAG == 17) ? 4 : TAG;   // days per wave
   static constexpr bool MF = TAG == 12;                               // adjoint product on the matrix cores
-  static constexpr bool FX = TAG == 16;                               // LDS layout and state count fixed at compile time
+  static constexpr bool FX = TAG == 16 || TAG == 17;                  // LDS layout and state count fixed at compile time ...
+  static constexpr int FULL = TAG == 16 ? 1 : 0;                      // ... and the model variant: 16 = poll_model_2020.stan, 17 = poll_model_2020_no_mode_adjustment.stan
 };
 typedef const int AS_C *cip;
 
@@ -671,7 +672,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   if constexpr (FX) lds = (ldp)lds_dyn;   // the LDS base is a link-time constant
-  const int S = FX ? (int)ClFixed::S : M->S, T = M->T, SE = FX ? (int)ClFixed::SE : M->SE, SP = FX ? (int)ClFixed::SP : M->SP, full = FX ? 1 : M->full, o_c = M->o_c;
+  const int S = FX ? (int)ClFixed::S : M->S, T = M->T, SE = FX ? (int)ClFixed::SE : M->SE, SP = FX ? (int)ClFixed::SP : M->SP, full = FX ? ClTag<CL_TAG>::FULL : M->full, o_c = M->o_c;
   const int NDP = FX ? (int)ClFixed::NDP : CL->NDP, NR = CL->NR, NREP = CL->NREP;
   const int d0 = part[CP_D0], nd = part[CP_ND], np = part[CP_NP], e0 = part[CP_E0], r0 = part[CP_R0], nr = part[CP_NR];
   const int K = x.K, m = x.m;
@@ -859,7 +860,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
     // The scalars of rho's prior have a wave of their own in the fixed build only (profiles/r04_cl_inkernel_cycles.txt: one wave doing both set the
     // length of the phase): in the dynamic builds, which serve the no-mode posteriors among others, the mere presence of that branch cost 4 %
     // (bench.py --config 3: 698 k leapfrogs/s without, 667 k with)
-    constexpr bool SPLIT_SCALARS = FX;
+    constexpr bool SPLIT_SCALARS = FX && ClTag<CL_TAG>::FULL;
     if (full && w == PT_NW - 1) {
       // the three tangent recurrences of the AR(1) bias (needed in phase E2 only) run here, on the wave that
       // has no polls unless the member has more than 448 of them, instead of lengthening phase B

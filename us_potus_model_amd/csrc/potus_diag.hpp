@@ -21,9 +21,10 @@
 #include "potus_dpp.hpp"
 #include "potus_summary.hpp"
 
-#define DG_RUN 8192           // (key, split index) pairs sorted in LDS at a time: 96 KB
+#define DG_RUN 8192           // (key, split index) pairs sorted in LDS at a time: 96 KB of dynamic LDS -- beyond the 64 KB of other parts: gfx950 (160 KB per
+                              // workgroup) only, like the rest of this library; the host's hipFuncSetAttribute call fails with a message elsewhere
 #define DG_THREADS 512
-#define DG_MAXCH 256          // split chains (2 x pooled chains)
+#define DG_MAXCH 1024         // split chains (2 x pooled chains): up to 512 pooled chains -- two full GPUs of one-workgroup chains, or the 64 / 96 / 128 of BASELINE configs[2..4]
 #define DG_LAGS 64            // autocorrelations formed per round of Geyer's sequence
 
 // block [nd][C][NC] (row = one draw of one chain) -> cols [NC][Ctot][nd], the block's chains at offset coff (several handles pooled)
@@ -146,6 +147,13 @@ __global__ __launch_bounds__(DG_THREADS) void k_dg_column(DgParams P) {
     const double *x = P.cols + (size_t)col * C * n;
     if (h < 2) { if (tid == 0) { P.rhat[col] = NAN; P.ess[col] = NAN; } continue; }
     auto val = [&](long long j) { return dg_split_value(x, n, C, h, j); };
+    {
+      // a NaN or infinite draw makes median, folded values and ranks meaningless (and a NaN with an all-ones payload has the key of the
+      // sort's padding): the column's diagnostics are NaN, as numpy's propagate it
+      int bad = 0;
+      for (long long j = tid; j < N; j += DG_THREADS) bad |= !isfinite(val(j));
+      if (__syncthreads_or(bad)) { if (tid == 0) { P.rhat[col] = NAN; P.ess[col] = NAN; } continue; }
+    }
     // ---- bulk: ranks of the split draws
     dg_sort_runs(val, N, xk, xi, rkey, ridx);
     if (tid == 0) {                                    // the median of the split draws (numpy: mean of the two middle ones)

@@ -1254,7 +1254,8 @@ int build_model(Sampler *sp, const potus_data *d) {
     px.push_back(nat); px.push_back(0.0);
     M.m_priorx = app(px);
   }
-  M.aT = d->mu_b_T_scale / d->random_walk_scale; M.aB = d->polling_bias_scale / d->random_walk_scale;
+  // (stan:50-52 uses square(scale): the sign of a scale does not reach the factors, chol(c^2 A) = |c| chol(A))
+  M.aT = std::fabs(d->mu_b_T_scale / d->random_walk_scale); M.aB = std::fabs(d->polling_bias_scale / d->random_walk_scale);
   M.Npad = (Np + 15) & ~15;
   std::vector<int> pi((size_t)6 * M.Npad, 0);
   std::vector<double> pdv((size_t)4 * M.Npad, 0.0);
@@ -1531,16 +1532,16 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   C.NDP = ndmax | 1;   // odd row stride of the member's C[state][local day] block
   C.GS = GS; C.GROWS = GROWS;
   ClLay lay = cl_layout(S, M.SE, M.SP, C.NDP, npmax, nsubmax, C.NREP, C.NR, T, mfma ? GROWS * GS + CL_G_PAD : 0);
-  // The build with the layout fixed at compile time (tag 16, ClFixed): 51 states, members of at most 32 days / 256 polls / 384
-  // level-1 tasks, the walk for the adjoint.  The layout is then the same function of ClFixed's capacities -- the numbers the
+  // The builds with the layout fixed at compile time (tags 16 and 17 = full model / no_mode_adjustment variant, ClFixed): 51 states, members of
+  // at most 32 days / 256 polls / 384 level-1 tasks, the walk for the adjoint.  The layout is then the same function of ClFixed's capacities -- the numbers the
   // kernel uses as immediates.
   {
-    const bool fits = DW == 4 && !mfma && full && K <= ClFixed::KMAX && std::max(XP_P + C.NR, XQ0 + C.NREP) <= ClFixed::XW && S == ClFixed::S && M.SE == ClFixed::SE && M.SP == ClFixed::SP && ndmax <= ClFixed::NDP - 1 && npmax <= ClFixed::NPCAP &&
+    const bool fits = DW == 4 && !mfma && K <= ClFixed::KMAX && std::max(XP_P + C.NR, XQ0 + C.NREP) <= ClFixed::XW && S == ClFixed::S && M.SE == ClFixed::SE && M.SP == ClFixed::SP && ndmax <= ClFixed::NDP - 1 && npmax <= ClFixed::NPCAP &&
                       nsubmax <= ClFixed::NSUBCAP && C.NREP <= ClFixed::NREPCAP && C.NR <= ClFixed::NRCAP && T <= ClFixed::TCAP && (int)SC_N <= 8;
     if (fits && !(getenv("POTUS_CL_DYNAMIC") && atoi(getenv("POTUS_CL_DYNAMIC")))) {
       C.NDP = ClFixed::NDP; C.XW = ClFixed::XW;
       lay = ClFixed::L;
-      sp->cl_dw = 16;
+      sp->cl_dw = full ? 16 : 17;       // the variant is a constant of the build as well (ClTag::FULL)
     }
   }
   C.l_C = lay.l_C; C.l_G = lay.l_G; C.l_Lw = lay.l_Lw; C.l_prior = lay.l_prior; C.l_pm = lay.l_pm; C.l_py = lay.l_py; C.l_pun = lay.l_pun;
@@ -1563,6 +1564,8 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   for (const void *f : {reinterpret_cast<const void *>(k_cl_logprob_grad<4>), reinterpret_cast<const void *>(k_cl_logprob_grad<8>), reinterpret_cast<const void *>(k_cl_logprob_grad<12>),
                         reinterpret_cast<const void *>(k_cl_logprob_grad<16>), reinterpret_cast<const void *>(k_cl_init<16>),
                         reinterpret_cast<const void *>(k_cl_run<16, false>), reinterpret_cast<const void *>(k_cl_run<16, true>),
+                        reinterpret_cast<const void *>(k_cl_logprob_grad<17>), reinterpret_cast<const void *>(k_cl_init<17>),
+                        reinterpret_cast<const void *>(k_cl_run<17, false>), reinterpret_cast<const void *>(k_cl_run<17, true>),
                         reinterpret_cast<const void *>(k_cl_init<4>), reinterpret_cast<const void *>(k_cl_init<8>), reinterpret_cast<const void *>(k_cl_init<12>),
                         reinterpret_cast<const void *>(k_cl_run<4, false>), reinterpret_cast<const void *>(k_cl_run<8, false>), reinterpret_cast<const void *>(k_cl_run<12, false>),
                         reinterpret_cast<const void *>(k_cl_run<4, true>), reinterpret_cast<const void *>(k_cl_run<8, true>), reinterpret_cast<const void *>(k_cl_run<12, true>)})
@@ -1574,7 +1577,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
 // The builds of the cluster pass (template tag of potus_cluster.hpp): 4 = four days per wave, 8 = eight days per wave, 12 = four
 // days per wave with the adjoint product on the fp64 matrix cores (poll-dense posteriors), 16 = four days per wave, 51 states, LDS
 // layout fixed at compile time (ClFixed: the reference's posteriors on clusters of 16).
-#define CL_DISPATCH(tag, CALL) do { if ((tag) == 16) { CALL(16); } else if ((tag) == 4) { CALL(4); } else if ((tag) == 12) { CALL(12); } else { CALL(8); } } while (0)
+#define CL_DISPATCH(tag, CALL) do { if ((tag) == 16) { CALL(16); } else if ((tag) == 17) { CALL(17); } else if ((tag) == 4) { CALL(4); } else if ((tag) == 12) { CALL(12); } else { CALL(8); } } while (0)
 
 // replica 0 of every chain's scalars
 int read_scalars(Sampler *sp, std::vector<ChainScalars> &sc) {
@@ -1718,7 +1721,7 @@ int dense_alloc(Sampler *sp) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(1)));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(2)));
   if (sp->K == 1) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_grad1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
-  else for (const void *f : {reinterpret_cast<const void *>(k_dn_gradK<4>), reinterpret_cast<const void *>(k_dn_gradK<8>), reinterpret_cast<const void *>(k_dn_gradK<12>), reinterpret_cast<const void *>(k_dn_gradK<16>)})
+  else for (const void *f : {reinterpret_cast<const void *>(k_dn_gradK<4>), reinterpret_cast<const void *>(k_dn_gradK<8>), reinterpret_cast<const void *>(k_dn_gradK<12>), reinterpret_cast<const void *>(k_dn_gradK<16>), reinterpret_cast<const void *>(k_dn_gradK<17>)})
     HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
   hipLaunchKernelGGL(k_dn_identity, dim3((D + 255) / 256, chains), dim3(256), 0, sp->stream, P);
   HIP_TRY(hipGetLastError());
@@ -2136,7 +2139,7 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
       if (rc) return bail(rc);
       // the members of a cluster wait for each other: the whole grid has to be resident at once
       int per_cu = 0;
-      const void *kfn = sp->cl_dw == 16 ? reinterpret_cast<const void *>(k_cl_run<16, false>) : sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4, false>)
+      const void *kfn = sp->cl_dw == 16 ? reinterpret_cast<const void *>(k_cl_run<16, false>) : sp->cl_dw == 17 ? reinterpret_cast<const void *>(k_cl_run<17, false>) : sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4, false>)
                         : sp->cl_dw == 12 ? reinterpret_cast<const void *>(k_cl_run<12, false>) : reinterpret_cast<const void *>(k_cl_run<8, false>);
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, PT_THREADS, sp->cl_lds_bytes) != hipSuccess || per_cu < 1)
         return bail(fail(POTUS_ERR_DEVICE, "cluster kernel cannot be resident on this device (occupancy query: %d workgroups per compute unit with %zu bytes of LDS)",
@@ -2148,7 +2151,7 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
       int sides_plan = 1;
       if ((rc = potus_plan_sides(o->chains, K, ncu, 1, o->cus_per_chain, o->twin, o->metric, &sides_plan))) return bail(rc);
       const bool twin_fits = sides_plan == 2;      // asked for or chosen, and the compute units are there
-      const void *kft = sp->cl_dw == 16 ? reinterpret_cast<const void *>(k_cl_run<16, true>) : sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4, true>)
+      const void *kft = sp->cl_dw == 16 ? reinterpret_cast<const void *>(k_cl_run<16, true>) : sp->cl_dw == 17 ? reinterpret_cast<const void *>(k_cl_run<17, true>) : sp->cl_dw == 4 ? reinterpret_cast<const void *>(k_cl_run<4, true>)
                         : sp->cl_dw == 12 ? reinterpret_cast<const void *>(k_cl_run<12, true>) : reinterpret_cast<const void *>(k_cl_run<8, true>);
       int per_cu_t = 0;
       if (twin_fits && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, kft, PT_THREADS, sp->cl_lds_bytes) == hipSuccess && per_cu_t >= 1)
@@ -2816,7 +2819,10 @@ int diagnostics_of_columns(hipStream_t stream, const double *cols, long long n, 
   double *zbuf = nullptr, *dout = nullptr;
   unsigned long long *rkey = nullptr;
   unsigned *ridx = nullptr;
-  const int grid = std::min(NC, 1024);
+  // a workgroup's scratch: two rank-normalised copies of the column, and the sorted runs when they do not fit LDS; the grid is
+  // capped so that the scratch of a call stays within 768 MB whatever the number of pooled draws (a workgroup loops over columns)
+  const long long per_wg = std::max<long long>(N, 1) * (16 + (N > DG_RUN ? 12 : 0));
+  const int grid = (int)std::max<long long>(1, std::min<long long>(std::min(NC, 1024), (768ll << 20) / per_wg));
   HIP_TRY(tmp.alloc(&zbuf, (size_t)grid * 2 * (size_t)std::max<long long>(N, 1) * 8));
   if (N > DG_RUN) { HIP_TRY(tmp.alloc(&rkey, (size_t)grid * (size_t)N * 8)); HIP_TRY(tmp.alloc(&ridx, (size_t)grid * (size_t)N * 4)); }
   HIP_TRY(tmp.alloc(&dout, (size_t)NC * 2 * 8));
@@ -2836,6 +2842,7 @@ int diagnostics_of_columns(hipStream_t stream, const double *cols, long long n, 
 
 int potus_diagnostics_device(int device, const void *block, long long n_draws, int n_chains, int n_cols, double *rhat_out, double *ess_bulk_out) {
   if (!block || !rhat_out || !ess_bulk_out || n_draws < 1 || n_chains < 1 || n_cols < 1) return fail(POTUS_ERR_ARG, "potus_diagnostics_device: bad argument");
+  if (2 * n_chains > DG_MAXCH) return fail(POTUS_ERR_UNSUPPORTED, "potus_diagnostics_device: %d chains pooled (at most %d)", n_chains, DG_MAXCH / 2);   // before anything is allocated
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(POTUS_ERR_DEVICE, "potus_diagnostics_device: no HIP device %d", device);
   DeviceGuard guard;
@@ -2875,12 +2882,18 @@ int potus_diagnostics(const int *handles, int n_handles, int col_begin, int col_
     if (n_saved >= 0 && ns != n_saved) return fail(POTUS_ERR_STATE, "potus_diagnostics: handle %d has saved %d draws per chain, handle %d has %d", handles[i], ns, handles[0], n_saved);
     n_saved = ns; Ctot += sp->R.chains;
   }
-  if (n_saved < 4) return fail(POTUS_ERR_STATE, "R-hat / ESS need at least four saved draws per chain");
+  if (2 * Ctot > DG_MAXCH) return fail(POTUS_ERR_UNSUPPORTED, "potus_diagnostics: %d chains pooled (at most %d)", Ctot, DG_MAXCH / 2);
+  // warm-up rows (save_warmup = 1) are not draws from the posterior: rstan::monitor and extract() drop them, and so does this
+  const int n_warm_rows = s0->opts.save_warmup ? std::min(n_saved, s0->R.num_warmup) : 0;
+  for (Sampler *sp : sps)
+    if ((sp->opts.save_warmup ? std::min(n_saved, sp->R.num_warmup) : 0) != n_warm_rows) return fail(POTUS_ERR_ARG, "potus_diagnostics: the handles saved different numbers of warm-up rows");
+  const int n_post = n_saved - n_warm_rows;
+  if (n_post < 4) return fail(POTUS_ERR_STATE, "R-hat / ESS need at least four saved post-warm-up draws per chain (%d saved, %d of them warm-up)", n_saved, n_warm_rows);
   const int NC = col_end - col_begin;
   HIP_TRY(hipSetDevice(s0->device));
   DevBufs tmp;
   double *cols = nullptr;
-  HIP_TRY(tmp.alloc(&cols, (size_t)n_saved * Ctot * NC * 8));
+  HIP_TRY(tmp.alloc(&cols, (size_t)n_post * Ctot * NC * 8));
   int coff = 0;
   for (size_t i = 0; i < sps.size(); i++) {
     Sampler *sp = sps[i];
@@ -2903,12 +2916,13 @@ int potus_diagnostics(const int *handles, int n_handles, int col_begin, int col_
       HIP_TRY(hipMemcpyPeer(blk, s0->device, fb, sp->device, (size_t)n_saved * C * NC * 8));
       HIP_TRY(hipSetDevice(s0->device));
     }
-    hipLaunchKernelGGL(k_dg_transpose, dim3((NC + 63) / 64, (unsigned)((n_saved + 63) / 64), C), dim3(256), 0, s0->stream, (const double *)blk, cols, (long long)n_saved, C, NC, Ctot, coff);
+    hipLaunchKernelGGL(k_dg_transpose, dim3((NC + 63) / 64, (unsigned)((n_post + 63) / 64), C), dim3(256), 0, s0->stream, (const double *)(blk + (size_t)n_warm_rows * C * NC), cols,
+                       (long long)n_post, C, NC, Ctot, coff);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s0->stream));
     coff += C;
   }
-  return diagnostics_of_columns(s0->stream, cols, n_saved, Ctot, NC, rhat_out, ess_bulk_out);
+  return diagnostics_of_columns(s0->stream, cols, n_post, Ctot, NC, rhat_out, ess_bulk_out);
 }
 
 // The backtest scores of final_2016.R:925-945 (final_2012.R:918-931, final_2008.R:922-935) from the state summaries:
@@ -3062,6 +3076,12 @@ int potus_debug_profile(int handle, double *out) {
   (void)hipSetDevice(sp->device);
   if (hipMemcpy(out, sp->R.prof, sizeof(double) * PT_NPROF * sp->R.chains * sp->K * sp->sides(), hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return PT_NPROF;
+}
+
+// Which build of the cluster pass a handle runs (template tag of potus_cluster.hpp: 4, 8, 12, 16, 17), 0 for one workgroup per chain.
+int potus_debug_build_tag(int handle) {
+  Sampler *sp = get(handle);
+  return sp ? (sp->K > 1 ? sp->cl_dw : 0) : -1;
 }
 
 // Development entry points (not in include/potus_hmc.h) that run single pieces of the dense-metric path on caller data,
