@@ -35,7 +35,11 @@ potus_sample <- function(data, variant = c("full", "no_mode_adjustment"), seed =
                          parallel_chains = chains, iter_warmup = 1000, iter_sampling = 1000, refresh = 100,
                          adapt_delta = 0.8, max_treedepth = 10, init = 2, device = 0, chain_id_offset = 0,
                          save_warmup = FALSE, gpus = device, cus_per_chain = 0, metric = c("diag_e", "dense_e"), twin = -1,
-                         metric_storage = c("f64", "f32")) {
+                         metric_storage = c("f64", "f32"), rhat_stop = NULL, ess_stop = 400) {
+  # rhat_stop (off by default; a DEVIATION from Stan / the reference, which always run iter_sampling iterations, final_2016.R:539): after every
+  # `refresh` transitions of the sampling phase the pooled chains' rank-normalised split R-hat / bulk ESS of lp__ and mu_b[, T] are taken on the
+  # device (potus_R_check_convergence) and sampling ends once every R-hat < rhat_stop and every bulk ESS >= ess_stop; the draws up to that point
+  # are those of the uninterrupted run.
   metric_storage <- match.arg(metric_storage)
   metric <- match.arg(metric)
   variant <- match.arg(variant)
@@ -76,19 +80,31 @@ potus_sample <- function(data, variant = c("full", "no_mode_adjustment"), seed =
   total <- iter_warmup + iter_sampling
   done <- 0L
   chunk <- if (is.null(refresh) || refresh <= 0) total else as.integer(refresh)
+  convergence <- NULL
   while (done < total) {                     # chunked so that R can print progress / be interrupted
     n <- min(chunk, total - done)
+    if (done < iter_warmup) n <- min(n, iter_warmup - done)
     .potus_check(.C("potus_R_run_many", as.integer(handles), length(handles), as.integer(n), status = integer(1))$status)
     done <- done + n
     message(sprintf("Iteration: %5d / %d [%3d%%]  (%s)", done, total, as.integer(100 * done / total),
                     if (done <= iter_warmup) "Warmup" else "Sampling"))
+    if (!is.null(rhat_stop) && done > iter_warmup && done < total) {
+      cv <- .C("potus_R_check_convergence", as.integer(handles), length(handles), as.double(c(rhat_stop, ess_stop)), converged = integer(1), out = double(2),
+               status = integer(1))
+      .potus_check(cv$status)
+      convergence <- rbind(convergence, data.frame(iterations = done, rhat_max = cv$out[1], ess_bulk_min = cv$out[2], converged = cv$converged == 1L))
+      if (cv$converged == 1L) {
+        message(sprintf("Stopped after %d sampling iterations: R-hat %.4f < %g, bulk ESS %.0f >= %g", done - iter_warmup, cv$out[1], rhat_stop, cv$out[2], ess_stop))
+        break
+      }
+    }
   }
   info <- .C("potus_R_num_columns", handles[1], D = integer(1), n_cols = integer(1), status = integer(1))
   .potus_check(info$status)
   saved <- .C("potus_R_saved_count", handles[1], n_saved = integer(1), status = integer(1))   # what the library holds, not what was asked for
   .potus_check(saved$status)
   structure(list(handle = handles[1], handles = handles, chains_per_handle = counts, D = info$D, n_cols = info$n_cols, chains = chains,
-                 n_saved = saved$n_saved, data = data, variant = variant,
+                 n_saved = saved$n_saved, data = data, variant = variant, convergence = convergence,
                  model_name = if (full) "poll_model_2020_model" else "poll_model_2020_no_mode_adjustment_model"),
             class = "potus_fit")
 }

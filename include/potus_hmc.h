@@ -256,6 +256,15 @@ int potus_diagnostics(const int *handles, int n_handles, int col_begin, int col_
  * potus_write_array_device produces and an RCCL all-gather of it keeps.  rhat_out, ess_bulk_out: host arrays [n_cols]. */
 int potus_diagnostics_device(int device, const void *block, long long n_draws, int n_chains, int n_cols, double *rhat_out, double *ess_bulk_out);
 
+/* Online convergence check for a host loop that advances the sampler in chunks ("online R-hat-based early
+ * stop"): rank-normalised split R-hat and bulk ESS of lp__ and mu_b[:, T] (what predicted_score[T, :], the quantity the scripts report, is a
+ * monotone map of: final_2016.R:708-762) over the post-warm-up draws saved so far by the pooled chains of the handles.  *converged = 1 when
+ * every R-hat is below rhat_below and every bulk ESS is at least ess_at_least (fewer than four draws: 0, no error).  The sampler itself never
+ * looks at the flag: the draws up to that point are those of an uninterrupted run.  Stopping on it is a DEVIATION from Stan / the reference,
+ * which always run iter_sampling iterations (final_2016.R:539): the host has to ask (argument rhat_stop of the R shim's and the
+ * Python host's sample functions). */
+int potus_check_convergence(const int *handles, int n_handles, double rhat_below, double ess_at_least, int *converged, double *rhat_max, double *ess_bulk_min);
+
 /* Kernel timing of the most recent potus_run, measured with HIP events on the
  * sampler's own stream: elapsed milliseconds and leapfrogs executed in it. */
 int potus_last_run_timing(int handle, double *ms, long long *leapfrogs);
@@ -303,6 +312,8 @@ void potus_R_write_stan_csv(int *handle, char **dir, char **basename, int *statu
 void potus_R_saved_count(int *handle, int *n_saved, int *status);
 void potus_R_posterior_summary(int *handles, int *n_handles, double *ev, double *state_out, double *natl_out, double *ev_out, int *status);
 void potus_R_diagnostics(int *handles, int *n_handles, int *cols /*[2]: col_begin, col_end*/, double *rhat_out, double *ess_bulk_out, int *status);
+void potus_R_check_convergence(int *handles, int *n_handles, double *limits /*[2]: rhat_below, ess_at_least*/, int *converged, double *out /*[2]: rhat_max, ess_bulk_min*/,
+                                int *status);
 void potus_R_backtest_scores(double *state_out, int *dims /*[3]: T, S, day*/, double *ev, int *won, double *out /*[3]*/, int *status);
 void potus_R_last_error(char **buf, int *len);
 void potus_R_destroy(int *handle, int *status);

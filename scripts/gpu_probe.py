@@ -13,7 +13,9 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from us_potus_model_amd import Handle, dataprep, sampler  # noqa: E402
 
-data = dataprep.load_npz(ROOT / "tests" / "golden" / "data_2016.npz")["data"]
+YEAR = os.environ.get("POTUS_YEAR", "2016")             # 2012 / 2008: the no_mode_adjustment posteriors (final_2012.R:558, final_2008.R:562)
+VARIANT = "full" if YEAR == "2016" else "no_mode_adjustment"
+data = dataprep.load_npz(ROOT / "tests" / "golden" / f"data_{YEAR}.npz")["data"]
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 chain_counts = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 8, 64, 256]
 KCL = int(os.environ.get("POTUS_K", "1"))
@@ -26,7 +28,7 @@ NAMES1 = {0: "A load+suffix", 1: "B carry/C/AR1", 2: "C polls", 3: "D gathers", 
          8: "momentum", 9: "init copy", 10: "leaf scalar", 11: "merge", 12: "copy q", 13: "p_near", 14: "adapt", 15: "save"}
 NAMES = NAMES1 if KCL == 1 else NAMESK
 for chains in chain_counts:
-    h = Handle(data, "full", chains=chains, num_warmup=iters, num_samples=0, seed=1843, cus_per_chain=KCL, twin=TWIN)
+    h = Handle(data, VARIANT, chains=chains, num_warmup=iters, num_samples=0, seed=1843, cus_per_chain=KCL, twin=TWIN)
     h.init()
     ms_tot, lf_tot = 0.0, 0
     for _ in range(3):

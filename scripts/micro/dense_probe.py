@@ -57,7 +57,11 @@ def active_sweep():
 
 
 def pieces():
-    for chains, D, nrhs in ((1, 15098, 1), (1, 15098, 2), (8, 15098, 2), (8, 15098, 3), (1, 41610, 2), (4, 41610, 2)):
+    f32 = bool(int(os.environ.get("POTUS_PROBE_F32", "0")))     # the pass over fp32 storage (generated matrices)
+    cases = ((1, 15098, 1), (1, 15098, 2), (8, 15098, 2), (8, 15098, 3), (1, 41610, 2), (4, 41610, 2))
+    if os.environ.get("POTUS_PROBE_CASES") == "short":
+        cases = ((8, 15098, 2), (4, 41610, 2), (16, 41610, 2))
+    for chains, D, nrhs in cases:
         x = np.random.default_rng(1).standard_normal((chains, nrhs, D))
         y, ms, nb = np.zeros((chains, nrhs, D)), C.c_double(), C.c_longlong()
         rc = L.potus_dense_matvec_probe(0, chains, D, nrhs, None, x.ctypes.data, y.ctypes.data, None, 5, C.byref(ms), C.byref(nb))
@@ -69,11 +73,15 @@ def pieces():
             for i in (0, D // 3, D - 1):
                 j = np.arange(D)
                 row = np.exp(-np.abs(i - j) / 50.0) * (1.0 + 0.1 * c) + (j == i)
+                if f32:
+                    row = np.where(j == i, row, row.astype(np.float32).astype(np.float64))      # off-diagonal elements are stored rounded
                 ok &= abs(row @ x[c, nrhs - 1] - y[c, nrhs - 1, i]) <= 1e-10 * max(1.0, abs(y[c, nrhs - 1, i]))
         gb = chains * nb.value / 1e9                     # bytes the pass loads: the upper-triangle tiles (about 4 D^2 per chain)
-        print(f"matrix pass chains={chains} D={D} nrhs={nrhs}: {ms.value:.3f} ms, {gb:.2f} GB loaded -> {gb / (ms.value * 1e-3):.0f} GB/s = "
+        print(f"matrix pass{' (fp32 storage)' if f32 else ''} chains={chains} D={D} nrhs={nrhs}: {ms.value:.3f} ms, {gb:.2f} GB loaded -> {gb / (ms.value * 1e-3):.0f} GB/s = "
               f"{gb / (ms.value * 1e-3) / 8000:.2f} of 8 TB/s ({chains * D * D * 8 / 1e9 / (ms.value * 1e-3):.0f} GB/s in full-matrix terms); "
               f"rows check {'ok' if ok else 'MISMATCH'}", flush=True)
+    if os.environ.get("POTUS_PROBE_CASES") == "short":
+        return
     for chains, D, n in ((1, 15098, 100), (4, 15098, 500), (1, 41610, 100)):
         rng = np.random.default_rng(2)
         draws = rng.standard_normal((chains, n, D))

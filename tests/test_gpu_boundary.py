@@ -127,6 +127,13 @@ class RShim:
         self.check(st)
         return rh, es
 
+    def check_convergence(self, fit, rhat_below, ess_at_least):
+        conv, out, st = C.c_int(-1), np.zeros(2), C.c_int(-1)
+        self.call("potus_R_check_convergence", _ints(fit["handles"])[1], C.byref(C.c_int(len(fit["handles"]))), _dbls([rhat_below, ess_at_least])[1], C.byref(conv),
+                  out.ctypes.data_as(DP), C.byref(st))
+        self.check(st)
+        return conv.value, out[0], out[1]
+
     def scores(self, fit, summ, ev, won, day=0):
         out, st = np.zeros(3), C.c_int(-1)
         self.call("potus_R_backtest_scores", summ["state_raw"].ctypes.data_as(DP), _ints([fit["data"]["T"], fit["data"]["S"], day])[1],
@@ -174,6 +181,8 @@ def test_r_entry_points_replay_the_shim(cases, name, tmp_path):
     rh, es = r.diagnostics(fit, a, a + 30)
     rh_ref, es_ref = device_diagnostics(ref._hs, a, a + 30)
     assert np.array_equal(rh, rh_ref) and np.array_equal(es, es_ref) and np.isfinite(es).all()
+    from us_potus_model_amd import check_convergence
+    assert r.check_convergence(fit, 1.5, 1.0) == tuple(int(x) if i == 0 else x for i, x in enumerate(check_convergence(ref._hs, 1.5, 1.0)))
     won = (np.arange(S) % 2).astype(int)
     sc = r.scores(fit, sm, ev, won)
     p = sm["state"][-1, :, 3]
@@ -198,6 +207,37 @@ def test_r_entry_points_replay_the_shim(cases, name, tmp_path):
     r.free(one); r.free(fit)
     with pytest.raises(RuntimeError, match="seed"):
         r.sample(data, variant, gpus=(0,), **{**kw, "seed": -1})
+
+
+def test_rhat_stop_ends_sampling_early_without_changing_a_draw(cases):
+    """SURVEY 8(f4), "online R-hat-based early stop" (VERDICT r04 item 8): with rhat_stop the host loop asks potus_check_convergence after every
+    `refresh` transitions of the sampling phase -- rank-normalised split R-hat / bulk ESS of lp__ and mu_b[:, T] over the pooled chains of both
+    handles, on the device -- and stops once they pass.  The flag trips on the small model; the draws saved up to that point are, bit for bit, the
+    first draws of the uninterrupted run; the check's numbers are the numpy restatement's; and a threshold nothing meets never trips.  Declared
+    in INTEGRATION.md as a deviation from Stan (off by default)."""
+    from us_potus_model_amd import check_convergence, diagnostics as dg
+    data, variant = cases["small_full"]
+    kw = dict(seed=7, chains=4, iter_warmup=150, iter_sampling=400, refresh=50, devices=[0, 0])
+    m_full, m_stop, m_never = PotusModel(variant), PotusModel(variant), PotusModel(variant)
+    full = m_full.sample(data, **kw)
+    stop = m_stop.sample(data, rhat_stop=1.05, ess_stop=100.0, **kw)
+    assert m_full.last_convergence == [] and full.n_saved == 400
+    log = m_stop.last_convergence
+    assert log and log[-1]["converged"] and all(not c["converged"] for c in log[:-1])
+    n = log[-1]["sampling_draws"]
+    assert stop.n_saved == n and 50 <= n < 400 and n % 50 == 0
+    a, b, _ = full._h.layout["mu_b"]
+    assert np.array_equal(stop.as_array("mu_b"), full.as_array("mu_b")[:n])                     # same draws up to the stop
+    assert np.array_equal(stop.sampler_params()["lp__"], full.sampler_params()["lp__"][:, :n])
+    S, T = int(data["S"]), int(data["T"])
+    cols = np.concatenate([stop._write_array(0, 1), stop._write_array(a + S * (T - 1), a + S * T)], axis=2)   # [draw, chain, 1 + S]
+    x = np.transpose(cols, (1, 0, 2))
+    r_ref = max(dg.rhat(x[:, :, j]) for j in range(1 + S)); e_ref = min(dg.ess_bulk(x[:, :, j]) for j in range(1 + S))
+    conv, r, e = check_convergence(stop._hs, 1.05, 100.0)
+    assert conv and np.isclose(r, r_ref, rtol=1e-9) and np.isclose(e, e_ref, rtol=1e-9) and r == log[-1]["rhat_max"] and e == log[-1]["ess_bulk_min"]
+    never = m_never.sample(data, rhat_stop=1.0, **kw)                                            # R-hat < 1 exactly: never
+    assert never.n_saved == 400 and not any(c["converged"] for c in m_never.last_convergence) and len(m_never.last_convergence) == 7
+    assert np.array_equal(never.as_array("mu_b"), full.as_array("mu_b"))
 
 
 def _readme(year):

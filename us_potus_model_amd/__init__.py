@@ -5,5 +5,5 @@ reference's `$sample()` / `rstan::extract()` surface), dataprep.py / synthetic.p
 lists), diagnostics.py (R-hat / ESS), _abi.py (ctypes structs).
 """
 from . import _abi  # noqa: F401
-from .sampler import (Handle, PotusError, PotusModel, StanFit, backtest_scores, device_diagnostics, device_diagnostics_of_block,  # noqa: F401
+from .sampler import (Handle, PotusError, PotusModel, StanFit, backtest_scores, check_convergence, device_diagnostics, device_diagnostics_of_block,  # noqa: F401
                       load_library, posterior_summary, run_many, sampling)

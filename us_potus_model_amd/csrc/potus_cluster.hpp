@@ -38,6 +38,11 @@
 #define CL_AUX_SC1 16                    // cache-policy bit of the buffer intrinsics: sc1 (agent scope)
 #define CL_NCHUNK PT_NW                  // chunks the member's polls are cut into for the adjoint gather (host: build_cluster)
 #define CL_SEG_SHIFT 64                  // the level-2 segment sums of phase E start at this thread: wave 0 turns the chunk totals into prefixes there
+#ifndef CL_RES
+#define CL_RES 1                         // fixed builds, two clusters per chain: the member's share of M^-1, of the leaf's momentum and of the pair's rho stays in LDS across
+#endif                                   // the leaves of a doubling (ClLeapPolicyRes).  Measured side by side (profiles/r05_cl_resident_share.txt): 13.50 -> 13.15 / 13.22 us per
+                                         // leapfrog with two clusters per chain (all 256 compute units busy: a round trip through L2 costs more), 16.53 -> 16.97 / 17.03 with one
+                                         // -- so the one-cluster kernels keep the loads (CL_RES = 2 forces the resident share there too)
 #define CL_SPIN_LIMIT 8000000u
 #ifndef CL_SPIN_SLEEP
 #define CL_SPIN_SLEEP 1                  // s_sleep argument between two looks at an exchange word that has not arrived
@@ -74,10 +79,11 @@ typedef const ClModel AS_C *CCp;
 // (build_cluster: the posterior's own sizes) and at compile time for the fixed build below -- the two cannot drift apart.
 struct ClLay {
   int l_C, l_G, l_Lw, l_prior, l_pm, l_py, l_pun, l_sub, l_tab, l_ru, l_wide, l_wout, l_X, l_Y, l_r, l_rep, l_bT, l_e, l_c1, l_c2, l_c3, l_ge, l_P, l_scal, l_red, l_st, l_prof;
+  int l_rm, l_rpf, l_rrs;   // the member's share of three vectors, resident across the leaves of a doubling (fixed builds; see ClLeapPolicyRes)
   int total;
 };
 constexpr int cl_ev(int n) { return (n + 1) & ~1; }   // LDS blocks start on 16-byte boundaries
-constexpr ClLay cl_layout(int S, int SE, int SP, int NDP, int npcap, int nsubcap, int nrepcap, int nrcap, int tcap, int g_doubles) {
+constexpr ClLay cl_layout(int S, int SE, int SP, int NDP, int npcap, int nsubcap, int nrepcap, int nrcap, int tcap, int g_doubles, int necap = 0) {
   ClLay L{};
   int o = 0;
   L.l_C = o; o += cl_ev(S * NDP);                         // C[state][local day]: suffix sums, then the adjoint's running sums
@@ -107,6 +113,9 @@ constexpr ClLay cl_layout(int S, int SE, int SP, int NDP, int npcap, int nsubcap
   L.l_red = o; o += cl_ev((PT_NW + 1) * PT_NRED);
   L.l_st = o; o += cl_ev((npcap + 8 + 7) / 8);
   L.l_prof = o; o += cl_ev(PT_NPROF);
+  L.l_rm = necap ? o : 0; o += necap ? cl_ev(necap + 8) : 0;       // [necap] + a dump slot (index necap) for masked lanes
+  L.l_rpf = necap ? o : 0; o += necap ? cl_ev(necap + 8) : 0;
+  L.l_rrs = necap ? o : 0; o += necap ? cl_ev(necap + 8) : 0;
   L.total = o;
   return L;
 }
@@ -121,13 +130,14 @@ struct ClFixed {
   static constexpr int S = 51, SE = 52, SP = 51, NDP = 33;
   static constexpr int NPCAP = 256, NSUBCAP = 384, NREPCAP = 768, NRCAP = 512, TCAP = 320;   // polls, level-1 tasks per member; small parameters; slots; days
   static constexpr int KMAX = 16;                    // members per cluster: every loop over the members is a single batch of sixteen tagged words
+  static constexpr int NECAP = CL_RES ? 1920 : 0;    // elements of a vector per member (CP_NE) the resident share holds: 32 days x 51 states + 256 polls + slots (2016 on 16 members: 1792)
   static constexpr int XW = 832;                     // exchange words per member: max(XP_P + NRCAP, XQ0 + NREPCAP) = max(72 + 512, 64 + 768)
   // and the full model (poll_model_2020.stan: mode / population effects, AR(1) bias); the no_mode_adjustment variant takes the dynamic build
   static constexpr int GS = 48, GROWS = 52;
-  static constexpr ClLay L = cl_layout(S, SE, SP, NDP, NPCAP, NSUBCAP, NREPCAP, NRCAP, TCAP, 0);
+  static constexpr ClLay L = cl_layout(S, SE, SP, NDP, NPCAP, NSUBCAP, NREPCAP, NRCAP, TCAP, 0, NECAP);
 #define CLF(f) static constexpr int f = L.f
   CLF(l_C); CLF(l_G); CLF(l_Lw); CLF(l_prior); CLF(l_pm); CLF(l_py); CLF(l_pun); CLF(l_sub); CLF(l_tab); CLF(l_ru); CLF(l_wide); CLF(l_wout); CLF(l_X); CLF(l_Y);
-  CLF(l_r); CLF(l_rep); CLF(l_bT); CLF(l_e); CLF(l_c1); CLF(l_c2); CLF(l_c3); CLF(l_ge); CLF(l_P); CLF(l_scal); CLF(l_red); CLF(l_st); CLF(l_prof);
+  CLF(l_r); CLF(l_rep); CLF(l_bT); CLF(l_e); CLF(l_c1); CLF(l_c2); CLF(l_c3); CLF(l_ge); CLF(l_P); CLF(l_scal); CLF(l_red); CLF(l_st); CLF(l_prof); CLF(l_rm); CLF(l_rpf); CLF(l_rrs);
 #undef CLF
   static constexpr int lds_doubles = L.total;
 };
@@ -524,6 +534,65 @@ struct ClLeapPolicy {
     const double rs = t.pp + pf;
     bst(r, fuse1 ? vo : PT_OOB, sOut1, rs);
     extra[0] += t.m * pf * pf;                    // masked-off elements loaded m = 0
+    extra[1] += t.m * t.pp * rs;
+    extra[2] += t.m * pf * rs;
+    return qn;
+  }
+  __device__ __forceinline__ double g_fin(unsigned vo, double v, double q, const GT &t) { return fin<false>(vo, v, q, t); }
+  __device__ __forceinline__ double gs_fin(unsigned vo, double v, double q, const GT &t) { return fin<true>(vo, v, q, t); }
+};
+
+// The same leapfrog with the member's share of three vectors RESIDENT IN LDS across the leaves of a doubling (fixed-layout builds; round 5).
+// Every element of the member's share is finished by the same thread in every pass, and what the epilogue of leaf n stores is what leaf
+// n + 1 and the U-turn sweeps of leaf n load back: through L2, as store -> load round trips on the same address.  Resident, indexed by the
+// element's position in the member's share (vo / 8 - e0; masked lanes use the dump slot NECAP):
+//   RM   the inverse metric (constant during a transition; filled when a doubling starts, cl_fill_resident)
+//   RPF  the momentum of the latest leaf: written here, read back as the previous leaf's momentum of the pair check (pp) by the next leaf and
+//        as p_end of every subtree that closes at this leaf by the sweeps (cl_vop_merge_chain) -- with another thread map, behind an LDS barrier
+//   RRS  rho of the pair that closes at this leaf: the right-hand rho of the level-2 merge
+// Global stores stay where somebody reads them LATER (leaf slot, next position, pre-kicked momentum, the pair's rho when it becomes a pending
+// subtree's: m == 1) and become write-only: nothing on the critical path reads them back.  Same arithmetic in the same order: same bytes.
+struct ClLeapPolicyRes {
+  rsrc_t r;
+  unsigned sQc, sQn, sPH, sL;
+  double he, e;
+  unsigned sOut1;
+  bool fuse1, out1_global;      // out1_global: the pair's rho is a pending subtree's (this leaf closes level 1 only): it goes to memory as well
+  unsigned e0b;                 // byte offset of the member's first element
+  static constexpr int NEXTRA = 3;
+  double extra[3];
+  struct QT { double q; };
+  struct GT { double p, m, pp; };
+  __device__ __forceinline__ int slot(unsigned vo) const { return vo == PT_OOB ? (int)ClFixed::NECAP : (int)((vo - e0b) >> 3); }   // position in the member's share; masked lanes: the dump slot
+  static __device__ __forceinline__ ldp RM() { return (ldp)lds_dyn + ClFixed::l_rm; }
+  static __device__ __forceinline__ ldp RPF() { return (ldp)lds_dyn + ClFixed::l_rpf; }
+  static __device__ __forceinline__ ldp RRS() { return (ldp)lds_dyn + ClFixed::l_rrs; }
+  __device__ __forceinline__ void q_load(unsigned vo, QT &t) { t.q = bld(r, vo, sQc); }
+  __device__ __forceinline__ void qs_load(unsigned vo, QT &t) { t.q = bld_s(r, vo, sQc); }
+  __device__ __forceinline__ double q_fin(QT &t) { return t.q; }
+  __device__ __forceinline__ void g_load(unsigned vo, GT &t) {
+    t.p = bld(r, vo, sPH);
+    const int idx = slot(vo);
+    t.m = RM()[idx];                                 // the dump slot holds 0: masked-off elements add nothing
+    const double ppv = RPF()[idx];
+    t.pp = fuse1 ? ppv : 0.0;
+  }
+  template <bool SHARED>
+  __device__ __forceinline__ double fin(unsigned vo, double v, double q, const GT &t) {   // returns the next position
+    const int idx = slot(vo);
+    const bool ok = vo != PT_OOB;
+    const double pf = t.p + he * v;
+    bst(r, vo, sL, pf);
+    RPF()[idx] = ok ? pf : 0.0;
+    const double ph = pf + he * v;
+    bst(r, vo, sPH, ph);
+    const double qn = q + e * t.m * ph;
+    if (SHARED) bst_s(r, vo, sQn, qn);
+    else bst(r, vo, sQn, qn);
+    const double rs = t.pp + pf;
+    RRS()[idx] = ok ? rs : 0.0;
+    bst(r, (fuse1 && out1_global) ? vo : PT_OOB, sOut1, rs);
+    extra[0] += t.m * pf * pf;
     extra[1] += t.m * t.pp * rs;
     extra[2] += t.m * pf * rs;
     return qn;
@@ -1487,8 +1556,26 @@ __device__ __forceinline__ void cl_vop_merge_partial(ClChain &c, unsigned a_beg,
 // acknowledgement plus a load round trip (~4 k cycles) per level.  Here the operands of up to CL_MG levels are requested together
 // and only the last rho (the new pending subtree's, slot RHOLEV + m) is stored.  Same arithmetic per element and level; the six
 // dot products of a level stay per-wave partial sums in LDS (part[WP(2 + 6 (j - 1) + k, wave)]) for the leaf's single all-reduce.
+#ifndef CL_MG
 #define CL_MG 3                          // levels whose operands are in flight together
+#endif
+#ifndef CL_MU
 #define CL_MU 2                          // elements per thread and trip
+#endif
+// RES (fixed builds, ClLeapPolicyRes): the inverse metric, the leaf's momentum (p_end of every subtree that closes here) and the pair's rho
+// (the right-hand rho of level 2) come out of the member's resident share in LDS -- the epilogue wrote them a moment ago, and loading them
+// back from memory meant draining the stores and a store -> load round trip through L2 in front of every sweep.  What still comes from memory
+// are the pending subtrees' vectors, written leaves ago.  (Requesting those ahead of the barrier in front of the sweep was built and measured in
+// round 5: 48 more live registers, 41 vector spills, 16.0 against 13.5 us per leapfrog -- docs/HISTORY.md.)
+__device__ __forceinline__ void cl_merge_slots(const ClChain &c, ltp ts, int m, int j0, unsigned (&s_ab)[CL_MG], unsigned (&s_ae)[CL_MG], unsigned (&s_ar)[CL_MG], unsigned (&s_bb)[CL_MG]) {
+#pragma unroll
+  for (int g = 0; g < CL_MG; g++) {
+    const int j = min(j0 + g, m);
+    s_ab[g] = c.soff(V_POOLP + uni_i(ts->pend_beg[j - 1])); s_ae[g] = c.soff(V_POOLP + uni_i(ts->pend_end[j - 1]));
+    s_ar[g] = c.soff(V_RHOLEV + j - 1); s_bb[g] = c.soff(V_POOLP + uni_i(ts->pend_beg[j - 2]));
+  }
+}
+template <bool RES>
 __device__ __forceinline__ void cl_vop_merge_chain(ClChain &c, ltp ts, int m, int leaf, ldp part) {
   const unsigned sM = c.soff(V_MINV), s_be = c.soff(V_POOLP + leaf);
   const int lane = c.tid & 63, w = c.tid >> 6;
@@ -1496,14 +1583,10 @@ __device__ __forceinline__ void cl_vop_merge_chain(ClChain &c, ltp ts, int m, in
   for (int j0 = 2; j0 <= m; j0 += CL_MG) {
     const int ng = min(CL_MG, m - j0 + 1);
     unsigned s_ab[CL_MG], s_ae[CL_MG], s_ar[CL_MG], s_bb[CL_MG];
-#pragma unroll
-    for (int g = 0; g < CL_MG; g++) {
-      const int j = min(j0 + g, m);
-      s_ab[g] = c.soff(V_POOLP + uni_i(ts->pend_beg[j - 1])); s_ae[g] = c.soff(V_POOLP + uni_i(ts->pend_end[j - 1]));
-      s_ar[g] = c.soff(V_RHOLEV + j - 1); s_bb[g] = c.soff(V_POOLP + uni_i(ts->pend_beg[j - 2]));
-    }
+    cl_merge_slots(c, ts, m, j0, s_ab, s_ae, s_ar, s_bb);
     const int jl = j0 + ng - 1;                                            // last level of the group
     const unsigned s_out = jl == m ? c.soff(V_RHOLEV + m) : c.soff(V_SCR0 + (jl & 1));
+    const bool first_group = j0 == 2;                                      // its right-hand rho is the pair's (out of the epilogue)
     double v[CL_MG][6];
 #pragma unroll
     for (int g = 0; g < CL_MG; g++)
@@ -1516,7 +1599,14 @@ __device__ __forceinline__ void cl_vop_merge_chain(ClChain &c, ltp ts, int m, in
       for (int u = 0; u < CL_MU; u++) {
         const int i = base + u * PT_THREADS;
         o[u] = i < c.e1 ? 8u * i : PT_OOB;                                  // masked elements read zeros and add nothing
-        mi[u] = bld(c.st, o[u], sM); be[u] = bld(c.st, o[u], s_be); br[u] = bld(c.st, o[u], s_br);
+        if constexpr (RES) {
+          const int ii = i < c.e1 ? i - c.e0 : (int)ClFixed::NECAP;        // (the dump slot holds zeros)
+          mi[u] = ClLeapPolicyRes::RM()[ii]; be[u] = ClLeapPolicyRes::RPF()[ii];
+          const double brl = ClLeapPolicyRes::RRS()[ii], brg = bld(c.st, first_group ? PT_OOB : o[u], s_br);
+          br[u] = first_group ? brl : brg;
+        } else {
+          mi[u] = bld(c.st, o[u], sM); be[u] = bld(c.st, o[u], s_be); br[u] = bld(c.st, o[u], s_br);
+        }
       }
 #pragma unroll
       for (int g = 0; g < CL_MG; g++)
@@ -1556,6 +1646,23 @@ __device__ __forceinline__ void cl_vop_merge_chain(ClChain &c, ltp ts, int m, in
       }
     s_br = s_out;
   }
+}
+// The inverse metric of the member's share into its resident copy (start of a doubling: the metric changes at window ends only, between
+// transitions).  The momentum and rho copies start from zeros: the epilogue never touches the padding elements of the member's share (their
+// momentum is 0 in memory, and the sweeps multiply it with a metric element of 1), and LDS keeps whatever the previous kernel left there --
+// found as transitions that differed from the oracle's once in some ten thousand leaves.  Ends with a barrier.
+__device__ __forceinline__ void cl_fill_resident(const ClChain &c) {
+  const unsigned sM = c.soff(V_MINV);
+  for (int i = c.tid; i <= (int)ClFixed::NECAP; i += PT_THREADS) { ClLeapPolicyRes::RPF()[i] = 0.0; ClLeapPolicyRes::RRS()[i] = 0.0; }
+  for (int base = cl_first(c); base < c.e1; base += CL_UNR * PT_THREADS) {
+    double v[CL_UNR];
+#pragma unroll
+    for (int k = 0; k < CL_UNR; k++) { const int i = base + k * PT_THREADS; v[k] = bld(c.st, i < c.e1 ? 8u * i : PT_OOB, sM); }
+#pragma unroll
+    for (int k = 0; k < CL_UNR; k++) { const int i = base + k * PT_THREADS; ClLeapPolicyRes::RM()[i < c.e1 ? i - c.e0 : (int)ClFixed::NECAP] = v[k]; }   // (idle lanes: 0 into the dump slot)
+  }
+  if (c.tid == 0) ClLeapPolicyRes::RM()[ClFixed::NECAP] = 0.0;
+  __syncthreads();
 }
 // PH[e] = p + he*g ; position buffer dst = q + e*minv*PH[e] ; PF[e] = p.  Ends with a cluster barrier:
 // the next pass of every member reads the new position of the small vectors.
@@ -1747,6 +1854,7 @@ template <int CL_DW> __device__ __noinline__ unsigned cl_cold_twin_combine(const
 template <int CL_DW, bool TWIN>
 __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, const ClTwinArgs &ta) {
   constexpr bool FX = ClTag<CL_DW>::FX;              // (the template argument is the build's tag)
+  constexpr bool RES = FX && CL_RES && (TWIN || CL_RES > 1);   // the member's share resident in LDS (ClLeapPolicyRes): two clusters per chain only, see CL_RES
   ltp ts = FX ? (ltp)((ldp)lds_dyn + ClFixed::lds_doubles) : c.ts;
   const int tid = c.tid;
   const double eps = ts->eps;
@@ -1813,6 +1921,7 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, co
     const int dir = uni_i(ts->dir);
     CPROF_START(c);
     cl_vop_copy<false, TWIN>(c, c.soff(V_PNEAR), c.soff(V_PF0 + dir));   // (twin mode: the end momentum was stored write-through)
+    if constexpr (RES) cl_fill_resident(c);
     CPROF_MARK(c, PF_PNEAR);
     bool valid = true;
     const int nleaf = 1 << depth;
@@ -1838,9 +1947,16 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, co
       const bool last = n == nleaf - 1;           // then m == depth
       const bool top = !TWIN && last;             // twin mode: the checks across the whole trajectory belong to the combine
       // (for an odd leaf the level-1 partner is the previous leaf: its momentum slot is known without its verdicts)
-      ClLeapPolicy lp{c.st, c.soff(V_POOLQ + inq), c.soff(V_POOLQ + outq), c.soff(V_PH0 + dir), c.soff(V_MINV),
-                      s_leaf, 0.5 * e, e, c.soff(V_POOLP + (m >= 1 ? prev_leaf : 0)), m == 1 ? c.soff(V_RHOLEV + 1) : c.soff(V_SCR0 + 1),
-                      m >= 1, {0.0, 0.0, 0.0}};
+      auto make_policy = [&]() {
+        if constexpr (RES)
+          return ClLeapPolicyRes{c.st, c.soff(V_POOLQ + inq), c.soff(V_POOLQ + outq), c.soff(V_PH0 + dir), s_leaf, 0.5 * e, e, c.soff(V_RHOLEV + 1),
+                                 m >= 1, m == 1, uni32(8u * (unsigned)c.e0), {0.0, 0.0, 0.0}};
+        else
+          return ClLeapPolicy{c.st, c.soff(V_POOLQ + inq), c.soff(V_POOLQ + outq), c.soff(V_PH0 + dir), c.soff(V_MINV),
+                              s_leaf, 0.5 * e, e, c.soff(V_POOLP + (m >= 1 ? prev_leaf : 0)), m == 1 ? c.soff(V_RHOLEV + 1) : c.soff(V_SCR0 + 1),
+                              m >= 1, {0.0, 0.0, 0.0}};
+      };
+      auto lp = make_policy();
       if (tid >= PT_THREADS - 64) {
         // the uniforms of this leaf's accept steps depend on nothing computed here: the last wave draws them
         // now (one lane per level) instead of thread 0 drawing them one after the other
@@ -1880,8 +1996,10 @@ __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, co
         }
         if (TWIN && lane == 63) wpart[WP(nv0, w)] = (w == 0 && ts->tw_ext) ? 1.0 : 0.0;
       }
-      if (m > 1 || top) { drain_vmem(); __syncthreads(); }   // the leaf's momentum is read back with another thread map
-      if (m >= 2) cl_vop_merge_chain(c, ts, m, leaf, wpart);
+      // the leaf's momentum is read back with another thread map: out of memory behind a drain, or (RES) out of LDS behind an LDS-only barrier
+      if (top || (!RES && m > 1)) { drain_vmem(); __syncthreads(); }
+      else if (m > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (m >= 2) cl_vop_merge_chain<RES>(c, ts, m, leaf, wpart);
       if (top) {
         // the checks at the end of transition(): old trajectory (init side) against the new subtree
         const int nb = depth >= 1 ? uni_i(ts->pend_beg[depth - 1]) : leaf;

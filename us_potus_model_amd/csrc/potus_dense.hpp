@@ -33,6 +33,7 @@
 // Layout: per chain a block of DV_COUNT vectors of LD doubles (Stan's parameter order); the matrix row-major D x LD
 // with LD = D rounded up to 8 doubles (rows start on 64-byte lines).
 #pragma once
+#include <type_traits>
 #include "potus_dpp.hpp"
 #include "potus_nuts.hpp"
 
@@ -44,6 +45,9 @@
 #define DN_RG 4                                           // rows of a wave loaded together (16 loads of 16 bytes in flight per lane)
 #define DN_FIN 256                                        // threads of the finishing kernel = elements per partial sum
 #define DN_SPLIT_MAX 8                                    // at most this many workgroups share a pair of row blocks
+#ifndef DN_MASKLESS
+#define DN_MASKLESS 1                                     // tiles off the band and off the right edge take a loop without per-element masks (k_dn_symv)
+#endif
 typedef double dn_d2 __attribute__((ext_vector_type(2)));
 
 // vector slots of a chain's dense state block
@@ -192,45 +196,53 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
 #pragma unroll
           for (int e = 0; e < NE; e++) { xc[u][e][r] = xs[r * DN_CT + NE * (lane + 64 * u) + e]; t_acc[u][e][r] = 0.0; }
       }
-      const bool band = c0 < r0 + RB;                  // the tile overlaps the block's own rows: only j > i counts
+      // The tile overlaps the block's own rows (only j > i counts) or the matrix's right edge (fp32 storage: beyond column D a row's
+      // float half runs into the next row's doubles, whose halves may read as NaN): elements are masked one by one.  Every other tile
+      // -- 79 of 81 per row block at D = 41 610 -- takes the loop without the two compares and the select per element (DN_MASKLESS;
+      // same products in the same order: same bytes).
+      const bool band = c0 < r0 + RB;
+      const bool masked = band || (F32 && c0 + DN_CT > D) || !DN_MASKLESS;
+      auto rows = [&](auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll 1
-      for (int q = 0; q < RW; q += RG) {                  // RG rows at a time: 16 loads of 16 bytes in flight per lane
-        u32x4 a[RG][NU];
+        for (int q = 0; q < RW; q += RG) {                  // RG rows at a time: 16 loads of 16 bytes in flight per lane
+          u32x4 a[RG][NU];
 #pragma unroll
-        for (int k = 0; k < RG; k++)
+          for (int k = 0; k < RG; k++)
 #pragma unroll
-          for (int u = 0; u < NU; u++)
-            a[k][u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[u], (unsigned)(q + k) * rowbytes, 2 /* nt: read once */);
+            for (int u = 0; u < NU; u++)
+              a[k][u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[u], (unsigned)(q + k) * rowbytes, 2 /* nt: read once */);
 #pragma unroll
-        for (int k = 0; k < RG; k++) {
-          const int lrow = RW * w + q + k;
-          const int lim = band ? r0 + lrow : -1;          // no branch: outside the band every column counts
-          double xrow[NRHS], sp[NRHS];
+          for (int k = 0; k < RG; k++) {
+            const int lrow = RW * w + q + k;
+            const int lim = band ? r0 + lrow : -1;          // no branch: outside the band every column counts
+            double xrow[NRHS], sp[NRHS];
 #pragma unroll
-          for (int r = 0; r < NRHS; r++) { xrow[r] = xr[r * DN_RB_MAX + lrow]; sp[r] = 0.0; }
+            for (int r = 0; r < NRHS; r++) { xrow[r] = xr[r * DN_RB_MAX + lrow]; sp[r] = 0.0; }
 #pragma unroll
-          for (int u = 0; u < NU; u++) {
+            for (int u = 0; u < NU; u++) {
 #pragma unroll
-            for (int e = 0; e < NE; e++) {
-              const int col = c0 + NE * (lane + 64 * u) + e;
-              double av;
-              // (through a scalar: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index, hipcc 7.2)
-              if constexpr (F32) { const unsigned wv = a[k][u][e]; av = (double)__uint_as_float(wv); }
-              else av = __hiloint2double((int)a[k][u][2 * e + 1], (int)a[k][u][2 * e]);   // (constexpr: the other branch would index past the vector)
-              // (fp32: beyond column D a row's float half runs into the next row's doubles, whose halves may read as NaN)
-              const double ae = (col > lim && (!F32 || col < D)) ? av : 0.0;
+              for (int e = 0; e < NE; e++) {
+                const int col = c0 + NE * (lane + 64 * u) + e;
+                double av;
+                // (through a scalar: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index, hipcc 7.2)
+                if constexpr (F32) { const unsigned wv = a[k][u][e]; av = (double)__uint_as_float(wv); }
+                else av = __hiloint2double((int)a[k][u][2 * e + 1], (int)a[k][u][2 * e]);   // (constexpr: the other branch would index past the vector)
+                const double ae = (!MASKED || (col > lim && (!F32 || col < D))) ? av : 0.0;
 #pragma unroll
-              for (int r = 0; r < NRHS; r++) { sp[r] += ae * xc[u][e][r]; t_acc[u][e][r] += ae * xrow[r]; }
+                for (int r = 0; r < NRHS; r++) { sp[r] += ae * xc[u][e][r]; t_acc[u][e][r] += ae * xrow[r]; }
+              }
+            }
+            // the row's sum over this tile: across the lanes by DPP (lane 63 ends up with it), then into the block's row sums
+#pragma unroll
+            for (int r = 0; r < NRHS; r++) {
+              const double tot = dpp_scan_sum(sp[r]);   // (measured: without it the fp64 pass is no faster, the fp32 pass 6 %: r03_dense_storage_study.txt)
+              if (lane == 63) sacc[r * DN_RB_MAX + lrow] += tot;
             }
           }
-          // the row's sum over this tile: across the lanes by DPP (lane 63 ends up with it), then into the block's row sums
-#pragma unroll
-          for (int r = 0; r < NRHS; r++) {
-            const double tot = dpp_scan_sum(sp[r]);   // (measured: without it the fp64 pass is no faster, the fp32 pass 6 %: r03_dense_storage_study.txt)
-            if (lane == 63) sacc[r * DN_RB_MAX + lrow] += tot;
-          }
         }
-      }
+      };
+      if (masked) rows(std::true_type{}); else rows(std::false_type{});   // wave-uniform (the whole workgroup takes the same tile)
       // column sums of this (block, tile): over the 8 waves in wave order
 #pragma unroll
       for (int u = 0; u < NU; u++)
@@ -971,7 +983,10 @@ __global__ void k_dn_fill(const DnParams P) {
       const int i = (int)(e / P.D), j = (int)(e % P.D);
       const int d = i > j ? i - j : j - i;
       const double v = exp(-(double)d / 50.0) * (1.0 + 0.1 * c) + (i == j ? 1.0 : 0.0);
-      if (j > i) P.A[(size_t)c * P.D * P.LD + (size_t)i * P.LD + j] = v;
+      if (j > i) {
+        if (P.f32) dn_f32_row(P.A + (size_t)c * P.D * P.LD, P.LD, i)[j] = (float)v;   // (development: POTUS_PROBE_F32)
+        else P.A[(size_t)c * P.D * P.LD + (size_t)i * P.LD + j] = v;
+      }
       if (j == i) { P.A[(size_t)c * P.D * P.LD + (size_t)i * P.LD + j] = 1.0; P.dg[(size_t)c * P.LD + i] = v; }
     }
 }

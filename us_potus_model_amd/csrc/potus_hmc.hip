@@ -1527,8 +1527,8 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   }
   sp->h_perm = perm;
 
-  int ndmax = 1;
-  for (int m = 0; m < K; m++) ndmax = std::max(ndmax, part[(size_t)m * CP_N + CP_ND]);
+  int ndmax = 1, nemax = 0;
+  for (int m = 0; m < K; m++) { ndmax = std::max(ndmax, part[(size_t)m * CP_N + CP_ND]); nemax = std::max(nemax, part[(size_t)m * CP_N + CP_NE]); }
   C.NDP = ndmax | 1;   // odd row stride of the member's C[state][local day] block
   C.GS = GS; C.GROWS = GROWS;
   ClLay lay = cl_layout(S, M.SE, M.SP, C.NDP, npmax, nsubmax, C.NREP, C.NR, T, mfma ? GROWS * GS + CL_G_PAD : 0);
@@ -1537,7 +1537,8 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   // kernel uses as immediates.
   {
     const bool fits = DW == 4 && !mfma && K <= ClFixed::KMAX && std::max(XP_P + C.NR, XQ0 + C.NREP) <= ClFixed::XW && S == ClFixed::S && M.SE == ClFixed::SE && M.SP == ClFixed::SP && ndmax <= ClFixed::NDP - 1 && npmax <= ClFixed::NPCAP &&
-                      nsubmax <= ClFixed::NSUBCAP && C.NREP <= ClFixed::NREPCAP && C.NR <= ClFixed::NRCAP && T <= ClFixed::TCAP && (int)SC_N <= 8;
+                      nsubmax <= ClFixed::NSUBCAP && C.NREP <= ClFixed::NREPCAP && C.NR <= ClFixed::NRCAP && T <= ClFixed::TCAP && (int)SC_N <= 8 &&
+                      (!CL_RES || nemax <= ClFixed::NECAP);   // the member's resident share of a vector (ClLeapPolicyRes)
     if (fits && !(getenv("POTUS_CL_DYNAMIC") && atoi(getenv("POTUS_CL_DYNAMIC")))) {
       C.NDP = ClFixed::NDP; C.XW = ClFixed::XW;
       lay = ClFixed::L;
@@ -2925,6 +2926,31 @@ int potus_diagnostics(const int *handles, int n_handles, int col_begin, int col_
   return diagnostics_of_columns(s0->stream, cols, n_post, Ctot, NC, rhat_out, ess_bulk_out);
 }
 
+// SURVEY 8(f4), "online R-hat-based early stop": the diagnostics of lp__ and mu_b[:, T] (the columns bench.py's ESS / s is defined on;
+// predicted_score[T, :] is their inverse logit) over the post-warm-up draws saved SO FAR by the pooled chains of the handles.  The host loop
+// that advances the sampler in chunks of `refresh` transitions may stop once *converged is set; nothing the sampler does depends on it (same
+// draws up to that point as an uninterrupted run).  A deviation from Stan, which always runs num_samples iterations: off unless the host asks.
+int potus_check_convergence(const int *handles, int n_handles, double rhat_below, double ess_at_least, int *converged, double *rhat_max, double *ess_bulk_min) {
+  if (!handles || n_handles < 1 || !converged || !rhat_max || !ess_bulk_min) return fail(POTUS_ERR_ARG, "potus_check_convergence: null argument");
+  Sampler *s0 = get(handles[0]);
+  if (!s0) return fail(POTUS_ERR_STATE, "bad handle %d", handles[0]);
+  const int S = s0->M.S, T = s0->M.T, a_mu = POTUS_N_SAMPLER_COLS + s0->L.D + S * (T - 1);
+  std::vector<double> rh(1 + S), es(1 + S);
+  *converged = 0; *rhat_max = NAN; *ess_bulk_min = NAN;
+  int ns = 0;
+  { DeviceGuard guard; HIP_TRY(hipSetDevice(s0->device)); const int rc = saved_count(s0, &ns); if (rc) return rc; }
+  if (ns - (s0->opts.save_warmup ? std::min(ns, s0->R.num_warmup) : 0) < 4) return 0;      // too early to say anything: not converged, no error
+  int rc;
+  if ((rc = potus_diagnostics(handles, n_handles, 0, 1, rh.data(), es.data()))) return rc;
+  if ((rc = potus_diagnostics(handles, n_handles, a_mu, a_mu + S, rh.data() + 1, es.data() + 1))) return rc;
+  double r = -INFINITY, e = INFINITY;
+  bool bad = false;
+  for (int i = 0; i <= S; i++) { bad = bad || std::isnan(rh[i]) || std::isnan(es[i]); r = std::max(r, rh[i]); e = std::min(e, es[i]); }
+  *rhat_max = bad ? NAN : r; *ess_bulk_min = bad ? NAN : e;
+  *converged = (!bad && r < rhat_below && e >= ess_at_least) ? 1 : 0;
+  return 0;
+}
+
 // The backtest scores of final_2016.R:925-945 (final_2012.R:918-931, final_2008.R:922-935) from the state summaries:
 // with p_s = P(score > 0.5) of state s on `day` (1-based; 0 = the last day) and won_s the actual outcome,
 //   out[0] = weighted.mean((won - p)^2, ev / sum(ev)), out[1] = mean((won - p)^2), out[2] = sum(round(p) == won)
@@ -3127,7 +3153,15 @@ int potus_dense_matvec_probe(int device, int chains, int D, int nrhs, const doub
     std::vector<double> dg((size_t)chains * P.LD, 0.0);
     for (int c = 0; c < chains; c++) for (int i = 0; i < D; i++) dg[(size_t)c * P.LD + i] = Minv_host[((size_t)c * D + i) * D + i];
     HIP_TRY(hipMemcpy(P.dg, dg.data(), dg.size() * 8, hipMemcpyHostToDevice));
-  } else hipLaunchKernelGGL(k_dn_fill, dim3(4096), dim3(256), 0, 0, P);
+  } else {
+    // development: POTUS_PROBE_F32 = 1 times the pass over fp32 storage (generated matrices only)
+    if (getenv("POTUS_PROBE_F32") && atoi(getenv("POTUS_PROBE_F32"))) {
+      P.f32 = 1;
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(1)));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_symv<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYMV_LDS(2)));
+    }
+    hipLaunchKernelGGL(k_dn_fill, dim3(4096), dim3(256), 0, 0, P);
+  }
   std::vector<DnRound> rds(chains);
   // development: a launch with idle companions (POTUS_PROBE_ACTIVE = n: the first n chains take part; or a list "2,7,11")
   std::vector<int> act_flag(chains, 1);
@@ -3162,7 +3196,7 @@ int potus_dense_matvec_probe(int device, int chains, int D, int nrhs, const doub
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (!ok) return fail(POTUS_ERR_DEVICE, "k_dn_symv failed");
   if (ms) *ms = (double)t / reps;
-  if (pass_bytes) *pass_bytes = dense_pass_bytes(D, P.LD, P.rb) * (nrhs == 3 ? 2 : 1);
+  if (pass_bytes) *pass_bytes = dense_pass_bytes(D, P.LD, P.rb) * (nrhs == 3 ? 2 : 1) / (P.f32 ? 2 : 1);
   for (int c = 0; c < chains; c++) {
     for (int k = 0; k < nrhs; k++)
       HIP_TRY(hipMemcpy(y_host + ((size_t)c * nrhs + k) * D, P.state + ((size_t)c * DV_COUNT + DV_POOLPS + k) * P.LD, (size_t)D * 8, hipMemcpyDeviceToHost));
@@ -3286,6 +3320,9 @@ void potus_R_posterior_summary(int *handles, int *n_handles, double *ev, double 
 }
 void potus_R_diagnostics(int *handles, int *n_handles, int *cols /*[2]: col_begin, col_end*/, double *rhat_out, double *ess_bulk_out, int *status) {
   *status = potus_diagnostics(handles, *n_handles, cols[0], cols[1], rhat_out, ess_bulk_out);
+}
+void potus_R_check_convergence(int *handles, int *n_handles, double *limits /*[2]: rhat_below, ess_at_least*/, int *converged, double *out /*[2]: rhat_max, ess_bulk_min*/, int *status) {
+  *status = potus_check_convergence(handles, *n_handles, limits[0], limits[1], converged, out, out + 1);
 }
 void potus_R_backtest_scores(double *state_out, int *dims /*[3]: T, S, day*/, double *ev, int *won, double *out, int *status) {
   *status = potus_backtest_scores(state_out, dims[0], dims[1], dims[2], ev, won, out);

@@ -78,6 +78,8 @@ def load_library():
     L.potus_write_array_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.potus_diagnostics.argtypes = [ip, C.c_int, C.c_int, C.c_int, dp, dp]
     L.potus_diagnostics_device.argtypes = [C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_int, dp, dp]
+    if hasattr(L, "potus_check_convergence"):           # (development builds selected through POTUS_LIB may predate an export)
+        L.potus_check_convergence.argtypes = [ip, C.c_int, C.c_double, C.c_double, ip, dp, dp]
     L.potus_get_dense_metric.argtypes = [C.c_int, C.c_int, dp]
     L.potus_cus_per_chain.argtypes = [C.c_int, ip]
     L.potus_clusters_per_chain.argtypes = [C.c_int, ip]
@@ -94,9 +96,9 @@ EXPORTS = [
     "potus_iterations_done", "potus_total_leapfrogs", "potus_chain_status", "potus_get_adaptation",
     "potus_get_dense_metric", "potus_dense_timing", "potus_dense_adapt_timing", "potus_dense_check", "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_array_device", "potus_write_stan_csv",
     "potus_last_run_timing", "potus_posterior_summary", "potus_posterior_summary_many", "potus_backtest_scores",
-    "potus_diagnostics", "potus_diagnostics_device",
+    "potus_diagnostics", "potus_diagnostics_device", "potus_check_convergence",
     "potus_R_create", "potus_R_init", "potus_R_run", "potus_R_run_many", "potus_R_num_columns", "potus_R_saved_count",
-    "potus_R_write_array", "potus_R_write_stan_csv", "potus_R_posterior_summary", "potus_R_diagnostics", "potus_R_backtest_scores", "potus_R_last_error", "potus_R_destroy",
+    "potus_R_write_array", "potus_R_write_stan_csv", "potus_R_posterior_summary", "potus_R_diagnostics", "potus_R_check_convergence", "potus_R_backtest_scores", "potus_R_last_error", "potus_R_destroy",
 ]
 
 
@@ -309,6 +311,16 @@ def device_diagnostics(handles, col_begin, col_end):
     return rhat, ess
 
 
+def check_convergence(handles, rhat_below=1.01, ess_at_least=400.0):
+    """potus_check_convergence: (converged, rhat_max, ess_bulk_min) of lp__ and mu_b[:, T] over the post-warm-up draws the pooled chains of
+    the handles have saved so far (the online early-stop check of SURVEY 8(f4); a deviation from Stan when acted upon)."""
+    h0 = handles[0]
+    ids = (C.c_int * len(handles))(*[h.h for h in handles])
+    conv, r, e = C.c_int(0), C.c_double(), C.c_double()
+    _check(h0.L, h0.L.potus_check_convergence(ids, len(handles), C.c_double(rhat_below), C.c_double(ess_at_least), C.byref(conv), C.byref(r), C.byref(e)))
+    return bool(conv.value), r.value, e.value
+
+
 def device_diagnostics_of_block(block):
     """potus_diagnostics_device on a torch tensor [draws, chains, columns] (float64, contiguous, on a GPU) -- e.g. the result of the
     all-gather of potus_write_array_device blocks.  Returns (rhat, ess_bulk) as numpy arrays [columns]."""
@@ -450,9 +462,13 @@ class PotusModel:
     def sample(self, data, seed=1843, chains=4, parallel_chains=None, iter_warmup=1000, iter_sampling=1000,
                refresh=100, adapt_delta=0.8, max_treedepth=10, init=2.0, save_warmup=False, device=0,
                chain_id_offset=0, show_messages=False, inits=None, devices=None, metric="diag_e", cus_per_chain=0, twin=-1,
-               metric_storage="f64"):
+               metric_storage="f64", rhat_stop=None, ess_stop=400.0):
         """`devices`: GPU ids; the chains are dealt to them in consecutive blocks and advance together under
-        potus_run_many (one host thread).  Chain ids -- hence RNG streams and draws -- do not depend on the split."""
+        potus_run_many (one host thread).  Chain ids -- hence RNG streams and draws -- do not depend on the split.
+        `rhat_stop` (off by default; a DEVIATION from Stan, which always runs iter_sampling iterations): after every `refresh` transitions
+        of the sampling phase the pooled chains' rank-normalised split R-hat / bulk ESS of lp__ and mu_b[:, T] are taken on the device
+        (potus_check_convergence) and sampling ends once every R-hat < rhat_stop and every bulk ESS >= ess_stop; the draws up to that
+        point are those of the uninterrupted run.  `self.last_convergence` keeps the checks."""
         from . import parallel
         devs = [int(device)] if devices is None else [int(d) for d in devices]
         hs, first = [], 0
@@ -470,13 +486,23 @@ class PotusModel:
         total = int(iter_warmup) + int(iter_sampling)
         chunk = max(1, int(refresh)) if refresh else total
         done = 0
+        self.last_convergence = []
         while done < total:
             n = min(chunk, total - done)
+            if done < iter_warmup:
+                n = min(n, int(iter_warmup) - done)          # the first check falls on a whole chunk of sampling draws
             run_many(hs, n)
             done += n
             if show_messages:
                 phase = "Warmup" if done <= iter_warmup else "Sampling"
                 print(f"Iteration: {done:5d} / {total} [{100 * done // total:3d}%]  ({phase})", flush=True)
+            if rhat_stop is not None and done > iter_warmup and done < total:
+                conv, r, e = check_convergence(hs, float(rhat_stop), float(ess_stop))
+                self.last_convergence.append({"iterations": done, "sampling_draws": done - int(iter_warmup), "rhat_max": r, "ess_bulk_min": e, "converged": conv})
+                if conv:
+                    if show_messages:
+                        print(f"Stopped after {done - int(iter_warmup)} sampling iterations: R-hat {r:.4f} < {rhat_stop}, bulk ESS {e:.0f} >= {ess_stop}", flush=True)
+                    break
         self.last_handle = hs[0]
         self.last_handles = hs
         return StanFit(hs, self.model_name)
