@@ -347,6 +347,8 @@ def main():
     ap.add_argument("--warm-steps", type=int, default=-1, help="how many of the --steps are warm-up (-1 = half of them)")
     ap.add_argument("--metric-storage", default="f64", choices=["f64", "f32"], help="--config 4: storage of the dense inverse metric")
     ap.add_argument("--max-depth", type=int, default=None, help="default 10 (CmdStan's); --config 4: 7, stated in the line")
+    ap.add_argument("--adapt-windows", default="", help="init_buffer,window,term_buffer of the warm-up (default: CmdStan's 75,25,50, rescaled by windowed_adaptation for short warm-ups); "
+                                                        "e.g. 6,8,6 puts two window ends into a 40-iteration warm-up of --config 4")
     ap.add_argument("--gather", default="full", choices=["full", "T"], help="what the all-gather pools: lp__ + all of mu_b (SURVEY 8e) or lp__ + mu_b[:, T] only")
     ap.add_argument("--seed", type=int, default=1843)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -416,6 +418,9 @@ def main():
     def make(seed, num_warmup, num_samples):
         hs = []
         for i, (name, data, variant, C, extra) in enumerate(work):
+            if args.adapt_windows:
+                ib_, bw_, tb_ = (int(x) for x in args.adapt_windows.split(","))
+                extra = {**extra, "init_buffer": ib_, "window": bw_, "term_buffer": tb_}
             while True:
                 try:
                     hs.append(Handle(data, variant, chains=C, chain_id_offset=rank * C, num_warmup=num_warmup, num_samples=num_samples,
@@ -587,6 +592,7 @@ def main():
             "config": {"workload": f"{names[2 if (cfg == 1 and world > 1) else cfg]}, adaptive NUTS {'dense_e' if dense else 'diag_e'}, {C_tot} chains per MI355X, "
                                    f"{nw} warmup + {ns} sampling, seed {args.seed}; a step = one launch chunk of {chunk} transitions",
                        "step": f"{chunk} NUTS transitions of every chain", "iter_warmup": nw, "iter_sampling": ns, "max_depth": args.max_depth,
+                       **({"adapt_windows_init_window_term": args.adapt_windows} if args.adapt_windows else {}),
                        "baseline_config_index": 2 if (cfg == 1 and world > 1) else cfg,
                        "chains_per_gpu": C_tot, "total_chains": C_tot * world, "posteriors": per_post,
                        "all_gather_bytes_per_rank": gathered_bytes,

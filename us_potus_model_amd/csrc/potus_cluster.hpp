@@ -35,6 +35,8 @@
 #define CL_MAXDAYS 64                    // LDS sizing: days per member at DW = 8
 #define CL_MAXK 32
 #define CL_DW4_MAXAVG 26                 // days per member on average up to which the 4-days-per-wave build of the pass is used
+#define CL_DW4_MAXDAYS 28                // ... and the days a member takes at most there (its waves could hold 32: 13.62 us per leapfrog against 13.49 with 28, 14.5 with 24;
+                                         //     profiles/r05_cl_partition.txt)
 #define CL_AUX_SC1 16                    // cache-policy bit of the buffer intrinsics: sc1 (agent scope)
 #define CL_NCHUNK PT_NW                  // chunks the member's polls are cut into for the adjoint gather (host: build_cluster)
 #define CL_SEG_SHIFT 64                  // the level-2 segment sums of phase E start at this thread: wave 0 turns the chunk totals into prefixes there
@@ -1556,12 +1558,8 @@ __device__ __forceinline__ void cl_vop_merge_partial(ClChain &c, unsigned a_beg,
 // acknowledgement plus a load round trip (~4 k cycles) per level.  Here the operands of up to CL_MG levels are requested together
 // and only the last rho (the new pending subtree's, slot RHOLEV + m) is stored.  Same arithmetic per element and level; the six
 // dot products of a level stay per-wave partial sums in LDS (part[WP(2 + 6 (j - 1) + k, wave)]) for the leaf's single all-reduce.
-#ifndef CL_MG
 #define CL_MG 3                          // levels whose operands are in flight together
-#endif
-#ifndef CL_MU
-#define CL_MU 2                          // elements per thread and trip
-#endif
+#define CL_MU 2                          // elements per thread and trip (4 x 2 levels, one trip for every member: 13.78 against 13.63 us, round 5)
 // RES (fixed builds, ClLeapPolicyRes): the inverse metric, the leaf's momentum (p_end of every subtree that closes here) and the pair's rho
 // (the right-hand rho of level 2) come out of the member's resident share in LDS -- the epilogue wrote them a moment ago, and loading them
 // back from memory meant draining the stores and a store -> load round trip through L2 in front of every sweep.  What still comes from memory
