@@ -35,8 +35,6 @@
 #define CL_MAXDAYS 64                    // LDS sizing: days per member at DW = 8
 #define CL_MAXK 32
 #define CL_DW4_MAXAVG 26                 // days per member on average up to which the 4-days-per-wave build of the pass is used
-#define CL_DW4_MAXDAYS 28                // ... and the days a member takes at most there (its waves could hold 32: 13.62 us per leapfrog against 13.49 with 28, 14.5 with 24;
-                                         //     profiles/r05_cl_partition.txt)
 #define CL_AUX_SC1 16                    // cache-policy bit of the buffer intrinsics: sc1 (agent scope)
 #define CL_NCHUNK PT_NW                  // chunks the member's polls are cut into for the adjoint gather (host: build_cluster)
 #define CL_SEG_SHIFT 64                  // the level-2 segment sums of phase E start at this thread: wave 0 turns the chunk totals into prefixes there

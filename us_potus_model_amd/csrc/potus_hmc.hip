@@ -1314,8 +1314,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   const int dw4_max = getenv("POTUS_CL_DW4_MAXAVG") ? atoi(getenv("POTUS_CL_DW4_MAXAVG")) : CL_DW4_MAXAVG;   // development: sweeps
   const int DW = (T + K - 1) / K <= dw4_max ? 4 : 8;
   // (development: POTUS_CL_MAXDAYS caps the days of a member below what its waves hold -- partition sweeps, profiles/r05_cl_partition.txt)
-  const int maxdays_default = DW == 4 ? std::max(CL_DW4_MAXDAYS, (T + K - 1) / K) : PT_NW * DW;
-  const int maxdays = getenv("POTUS_CL_MAXDAYS") ? std::max(1, std::min(PT_NW * DW, atoi(getenv("POTUS_CL_MAXDAYS")))) : maxdays_default;
+  const int maxdays = getenv("POTUS_CL_MAXDAYS") ? std::max(1, std::min(PT_NW * DW, atoi(getenv("POTUS_CL_MAXDAYS")))) : PT_NW * DW;
   sp->cl_dw = DW;   // (12 once the adjoint goes to the matrix cores, below)
   C.XW = (std::max(XP_P + C.NR, XQ0 + C.NREP) + 7) & ~7;
   if (P > 65535 || M.M > 255 || M.Pop > 255) return fail(POTUS_ERR_UNSUPPORTED, "cluster mode packs pollster/mode/population indices in 16/8/8 bits");
