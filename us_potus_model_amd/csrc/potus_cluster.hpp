@@ -856,6 +856,8 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // to do in this phase: an L2 round trip under load costs about 2 k cycles, which the verdict wave of phase C used to pay on
   // the critical path of that phase.  (Round 3 tried this while waves 2-7 still carried the 51 x 51 mat-vecs of mu_b_T and
   // the polling bias here and lost; those products are gone, see the carry step below.)
+  // (Round 5 built the obvious merger -- the totals in the lanes the X1 fetch leaves idle, one round of sixteen loads for both, three leaves in four -- and
+  //  measured it 9 % slower, 14.55 against 13.29 us per leapfrog: the totals arrive late, and wave 0 then holds the suffix carry back with them; docs/HISTORY.md.)
   if (w == 2 && pend.n >= 0) {
     cl_wide_consume(x, pend.tag, pend.nv, wout);
   }
