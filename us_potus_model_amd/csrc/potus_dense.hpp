@@ -45,6 +45,7 @@
 #define DN_RG 4                                           // rows of a wave loaded together (16 loads of 16 bytes in flight per lane)
 #define DN_FIN 256                                        // threads of the finishing kernel = elements per partial sum
 #define DN_SPLIT_MAX 8                                    // at most this many workgroups share a pair of row blocks
+#define DN_F32_PIPE_ROWS 2                                // fp32 storage: row groups software-pipelined, two buffers of this many rows (k_dn_symv)
 #ifndef DN_MASKLESS
 #define DN_MASKLESS 1                                     // tiles off the band and off the right edge take a loop without per-element masks (k_dn_symv)
 #endif
@@ -142,6 +143,8 @@ __device__ __forceinline__ double *dn_vec(const DnParams &P, int chain, int slot
 template <int NRHS, bool F32 = false>
 __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const DnActive act, int job0) {
   constexpr int NU = F32 ? 2 : 4, NE = F32 ? 4 : 2, RG = F32 ? 2 * DN_RG : DN_RG;   // 16-byte loads per lane and row, elements per load, rows in flight
+  constexpr bool PIPE = F32;                         // fp32 storage: row groups software-pipelined (see the tile loop)
+  constexpr int GR = PIPE ? DN_F32_PIPE_ROWS : RG;   // rows per group
   extern __shared__ __attribute__((aligned(16))) double dn_lds[];
   const int chain = act.n ? act.idx[blockIdx.y] : (int)blockIdx.y;
   const DnRound &rd = P.rd[chain];
@@ -204,16 +207,18 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
       const bool masked = band || (F32 && c0 + DN_CT > D) || !DN_MASKLESS;
       auto rows = [&](auto masked_c) {
         constexpr bool MASKED = decltype(masked_c)::value;
-#pragma unroll 1
-        for (int q = 0; q < RW; q += RG) {                  // RG rows at a time: 16 loads of 16 bytes in flight per lane
-          u32x4 a[RG][NU];
+        // one group of GR rows: the loads ...
+        auto request = [&](auto &buf, int q) {
 #pragma unroll
-          for (int k = 0; k < RG; k++)
+          for (int k = 0; k < GR; k++)
 #pragma unroll
-            for (int u = 0; u < NU; u++)
-              a[k][u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[u], (unsigned)(q + k) * rowbytes, 2 /* nt: read once */);
+            for (int u = 0; u < NU; u++)    // (rows beyond the wave's lie outside its resource: nothing is read, zeros come back)
+              buf[k][u] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[u], (unsigned)(q + k) * rowbytes, 2 /* nt: read once */);
+        };
+        // ... and their products
+        auto consume = [&](const auto &buf, int q) {
 #pragma unroll
-          for (int k = 0; k < RG; k++) {
+          for (int k = 0; k < GR; k++) {
             const int lrow = RW * w + q + k;
             const int lim = band ? r0 + lrow : -1;          // no branch: outside the band every column counts
             double xrow[NRHS], sp[NRHS];
@@ -226,8 +231,8 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
                 const int col = c0 + NE * (lane + 64 * u) + e;
                 double av;
                 // (through a scalar: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index, hipcc 7.2)
-                if constexpr (F32) { const unsigned wv = a[k][u][e]; av = (double)__uint_as_float(wv); }
-                else av = __hiloint2double((int)a[k][u][2 * e + 1], (int)a[k][u][2 * e]);   // (constexpr: the other branch would index past the vector)
+                if constexpr (F32) { const unsigned wv = buf[k][u][e]; av = (double)__uint_as_float(wv); }
+                else av = __hiloint2double((int)buf[k][u][2 * e + 1], (int)buf[k][u][2 * e]);   // (constexpr: the other branch would index past the vector)
                 const double ae = (!MASKED || (col > lim && (!F32 || col < D))) ? av : 0.0;
 #pragma unroll
                 for (int r = 0; r < NRHS; r++) { sp[r] += ae * xc[u][e][r]; t_acc[u][e][r] += ae * xrow[r]; }
@@ -239,6 +244,29 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
               const double tot = dpp_scan_sum(sp[r]);   // (measured: without it the fp64 pass is no faster, the fp32 pass 6 %: r03_dense_storage_study.txt)
               if (lane == 63) sacc[r * DN_RB_MAX + lrow] += tot;
             }
+          }
+        };
+        if constexpr (PIPE) {
+          // fp32 storage: twice the arithmetic per byte (SQ_ACTIVE_INST_VALU 24.5 % of the wave cycles against 13.4 %, two waves per SIMD: the
+          // vector pipe is half busy) while a wave that multiplies has nothing in flight.  Two buffers of GR = DN_F32_PIPE_ROWS rows: the next group's loads
+          // are requested before the current group's products (same rows in the same order: same bytes).  Measured (profiles/r05_dense_maskless.txt):
+          // two rows per buffer 0.62-0.63 -> 0.64-0.65 of the peak at 16 x 41 610 with 201 VGPRs instead of 256 + 4 spills; four rows per buffer spill
+          // 55 registers into the loop and fall to 0.51.
+          u32x4 a0[GR][NU], a1[GR][NU];
+          request(a0, 0);
+#pragma unroll 1
+          for (int q = 0; q < RW; q += 2 * GR) {
+            request(a1, q + GR);
+            consume(a0, q);
+            request(a0, q + 2 * GR);
+            consume(a1, q + GR);
+          }
+        } else {
+#pragma unroll 1
+          for (int q = 0; q < RW; q += GR) {                // GR = RG rows at a time: 16 loads of 16 bytes in flight per lane
+            u32x4 a[GR][NU];
+            request(a, q);
+            consume(a, q);
           }
         }
       };

@@ -64,6 +64,10 @@ __device__ __forceinline__ double dg_split_value(const double *x, long long n, i
   return x[(size_t)c * n + (cp < C ? i : n - h + i)] + 0.0;
 }
 
+// normcdfinv out of line: inlined into the two ranking loops its table of coefficients is hoisted out of them and held in registers across the
+// whole column loop (217 spilled vector registers in round 4's build)
+__device__ __noinline__ double dg_normal_score(double p) { return normcdfinv(p); }
+
 // A draw's rank among the pooled split draws, ties in the order of the split array (numpy: argsort(argsort(x, stable), stable)) = 1 + the
 // number of (key, split index) pairs that are lexicographically smaller.  The pairs are bitonic-sorted in LDS in runs of DG_RUN;
 // one run stays there, several go to global memory; the count is a binary search per run.  No scan over tied draws: a sampler
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_dg_column(DgParams P) {
     for (long long j = tid; j < N; j += DG_THREADS) {
       const double v = val(j);
       const long long r = dg_rank(v, j, N, xk, xi, rkey, ridx);
-      z[j] = normcdfinv(((double)r - 0.375) / ((double)N + 0.25));
+      z[j] = dg_normal_score(((double)r - 0.375) / ((double)N + 0.25));
     }
     __syncthreads();
     const double med = sc[0];
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_dg_column(DgParams P) {
     for (long long j = tid; j < N; j += DG_THREADS) {
       const double v = fval(j);
       const long long r = dg_rank(v, j, N, xk, xi, rkey, ridx);
-      zf[j] = normcdfinv(((double)r - 0.375) / ((double)N + 0.25));
+      zf[j] = dg_normal_score(((double)r - 0.375) / ((double)N + 0.25));
     }
     __threadfence_block();
     __syncthreads();
