@@ -196,10 +196,12 @@ def test_bench_bookkeeping_on_the_committed_profiles():
     assert bench.algorithmic_bytes_per_leapfrog(data, "full", True) == 844784 + 4 * D * D
     one, two = bench.measured_traffic("k_cl_run", 1), bench.measured_traffic("k_cl_run", 2)
     assert one and two and one[0] != two[0] and "two clusters" in two[1]["command"] and "two clusters" not in one[1]["command"]
-    assert 0.5 < one[1]["hbm_bytes_per_leapfrog"] / 844784 < 0.8 and 0.9 < two[1]["hbm_bytes_per_leapfrog"] / 844784 < 1.3
-    for committed in ("r03_bench_line.json", "r04b_bench_line.json"):
+    # (two clusters per chain: 1.04 x / 1.007 x the algorithmic bytes in rounds 3 / 4, 0.785 x since round 5 keeps a member's share of three vectors in LDS)
+    assert 0.5 < one[1]["hbm_bytes_per_leapfrog"] / 844784 < 0.8 and 0.6 < two[1]["hbm_bytes_per_leapfrog"] / 844784 < 1.3
+    assert two[0] == "r05_cl_twin_pmc_traffic.json"                     # the latest committed pass is the one the bench line quotes
+    for committed in ("r03_bench_line.json", "r04b_bench_line.json", "r05_bench_line.json"):
         _check_committed_bench_line(json.loads([ln for ln in (ROOT / "profiles" / committed).read_text().splitlines() if ln.startswith("{")][0]),
-                                    device_diagnostics=committed.startswith("r04"))
+                                    device_diagnostics=int(committed[1:3]) if int(committed[1:3]) >= 4 else 0)
 
 
 def _check_committed_bench_line(line, device_diagnostics):
@@ -219,7 +221,15 @@ def _check_committed_bench_line(line, device_diagnostics):
     assert line["config"]["all_gather_bytes_per_rank"] == 1000 * 8 * (1 + 51 * 254) * 8            # lp__ + all of mu_b
     if device_diagnostics:                                                                          # round 4: R-hat / ESS of every gathered column on the device
         dd = line["config"]["posteriors"]["2016"]["device_diagnostics"]
-        assert dd["columns"] == 1 + 51 * 254 and dd["ess_bulk_min_all_columns"] > 100 and dd["rhat_max_all_columns"] < 1.05
+        extra = 51 if device_diagnostics >= 5 else 0                                                # round 5: + predicted_score[T, :] as columns of their own
+        assert dd["columns"] == 1 + 51 * 254 + extra and dd["ess_bulk_min_all_columns"] > 100 and dd["rhat_max_all_columns"] < 1.05
+    if device_diagnostics >= 5:
+        # round 5: the other single-GPU configurations as side measurements under the same clock, the host's core count beside the cores used
+        side = line["side"]
+        assert {r["posterior"] for r in side["configs[0]"]["runs"]} == {"2016", "2012", "2008"} and side["configs[0]"]["baseline_config_index"] == 0
+        assert side["configs[3]"]["baseline_config_index"] == 3 and side["configs[3]"]["value"] > 0 and side["configs[3]"]["roofline"]["kernel"] == "k_cl_run"
+        assert side["configs[4]_preset"]["roofline"]["kernel"] == "k_dn_symv" and 0.5 < side["configs[4]_preset"]["roofline"]["frac"] < 0.9
+        assert cb["host_cores_total"] >= cb["cores"]
 
 
 def test_layout_plan_for_every_chain_count():
