@@ -251,7 +251,8 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
           // vector pipe is half busy) while a wave that multiplies has nothing in flight.  Two buffers of GR = DN_F32_PIPE_ROWS rows: the next group's loads
           // are requested before the current group's products (same rows in the same order: same bytes).  Measured (profiles/r05_dense_maskless.txt):
           // two rows per buffer 0.62-0.63 -> 0.64-0.65 of the peak at 16 x 41 610 with 201 VGPRs instead of 256 + 4 spills; four rows per buffer spill
-          // 55 registers into the loop and fall to 0.51.
+          // 55 registers into the loop and fall to 0.51.  (Two workgroups per compute unit instead -- 128 VGPRs, amdgpu_waves_per_eu(4) -- spill
+          // 21-118 registers: 0.53-0.63 with one row per buffer, 0.15 with two.)
           u32x4 a0[GR][NU], a1[GR][NU];
           request(a0, 0);
 #pragma unroll 1
