@@ -40,7 +40,10 @@
 #define DN_THREADS 512
 #define DN_NB 64                                          // block size of the factorisation / triangular solve
 #define DN_RB 128                                         // rows per block of the symmetric product: the unit of its column sums
-#define DN_RB_MAX 256                                     // a workgroup takes DnParams::rb = 128 or 256 rows at a time (16 or 32 per wave)
+#define DN_RB_BIG 256                                     // a workgroup takes DnParams::rb = 128, 256 or 512 rows at a time (16, 32 or 64 per wave), by the size of
+#define DN_RB_MAX 512                                     // the matrix (potus_hmc.hip: dense_launch_shape).  Round 5: 512 from D = 16 384 on -- the per-tile costs of a
+                                                          // block (x staged, three barriers, the column sums through LDS) are paid once per 512 rows instead of 256:
+                                                          // 16 x 41 610: fp64 0.72 -> 0.74-0.75 of the peak, fp32 storage 0.64 -> 0.67 (profiles/r05_dense_maskless.txt)
 #define DN_CT 512                                         // columns per tile of it (8 per lane)
 #define DN_RG 4                                           // rows of a wave loaded together (16 loads of 16 bytes in flight per lane)
 #define DN_FIN 256                                        // threads of the finishing kernel = elements per partial sum
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
           // vector pipe is half busy) while a wave that multiplies has nothing in flight.  Two buffers of GR = DN_F32_PIPE_ROWS rows: the next group's loads
           // are requested before the current group's products (same rows in the same order: same bytes).  Measured (profiles/r05_dense_maskless.txt):
           // two rows per buffer 0.62-0.63 -> 0.64-0.65 of the peak at 16 x 41 610 with 201 VGPRs instead of 256 + 4 spills; four rows per buffer spill
-          // 55 registers into the loop and fall to 0.51.  (Two workgroups per compute unit instead -- 128 VGPRs, amdgpu_waves_per_eu(4) -- spill
+          // 55 registers into the loop and fall to 0.51; three buffers of two rows measure the same as two (0.64-0.65).  (Two workgroups per compute unit instead -- 128 VGPRs, amdgpu_waves_per_eu(4) -- spill
           // 21-118 registers: 0.53-0.63 with one row per buffer, 0.15 with two.)
           u32x4 a0[GR][NU], a1[GR][NU];
           request(a0, 0);

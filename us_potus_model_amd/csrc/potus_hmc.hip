@@ -1042,7 +1042,7 @@ struct Sampler {
   hipEvent_t rv0[DN_AHEAD] = {}, rv1[DN_AHEAD] = {}, rdone[DN_AHEAD] = {};   // per queued round: around its matrix pass, after its flag copy
   double mv_ms = 0;                        // time spent in the matrix passes (k_dn_symv + finish, events), their number and the bytes they loaded
   int mv_launches_pending = 0;             // matrix passes between the event pair of the last timed dense_matvec (the first pass of a transition: two)
-  long long mv_calls = 0, mv_bytes = 0, dn_rounds = 0, dn_pass_bytes[2] = {0, 0};   // bytes per pass at DN_RB / DN_RB_MAX rows per workgroup
+  long long mv_calls = 0, mv_bytes = 0, dn_rounds = 0, dn_pass_bytes[2] = {0, 0};   // bytes per pass at DN_RB rows per workgroup / at the handle's DnParams::rb
   double we_cov_ms = 0, we_chol_ms = 0, we_eps_ms = 0;   // window ends: covariance, factorisation, init_stepsize (host clock around synchronised sections)
   int we_count = 0;
 };
@@ -1663,7 +1663,7 @@ void dense_cholesky_launch(hipStream_t st, const DnParams &P, int chains) {
 // busy when the active chains are few; the results do not depend on it).
 void dense_launch_shape(DnParams &P, int active) {
   active = std::max(active, 1);
-  P.rb = P.D >= 32 * DN_RB_MAX ? DN_RB_MAX : DN_RB;      // by the size of the matrix alone: a chain's numbers must not depend on its companions
+  P.rb = P.D >= 32 * DN_RB_MAX ? DN_RB_MAX : P.D >= 32 * DN_RB_BIG ? DN_RB_BIG : DN_RB;   // by the size of the matrix alone: a chain's numbers must not depend on its companions
   P.ntile = (P.D + DN_CT - 1) / DN_CT;
   const int pairs = ((P.D + P.rb - 1) / P.rb + 1) / 2;
   // One 78 KB-LDS workgroup per compute unit at a time: the launch runs in waves of 256 workgroups.  Few, large workgroups are
@@ -1729,7 +1729,7 @@ int dense_alloc(Sampler *sp) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(sp->stream));
   sp->dn_win_counter = 0; sp->dn_win_size = sp->R.window; sp->dn_win_next = sp->R.init_buffer + sp->R.window - 1; sp->dn_wf_n = 0;
-  sp->dn_pass_bytes[0] = dense_pass_bytes(D, P.LD, DN_RB) / (P.f32 ? 2 : 1); sp->dn_pass_bytes[1] = dense_pass_bytes(D, P.LD, DN_RB_MAX) / (P.f32 ? 2 : 1);
+  sp->dn_pass_bytes[0] = dense_pass_bytes(D, P.LD, DN_RB) / (P.f32 ? 2 : 1); sp->dn_pass_bytes[1] = dense_pass_bytes(D, P.LD, P.rb) / (P.f32 ? 2 : 1);   // ([1]: at the handle's own block size)
   return 0;
 }
 
