@@ -278,3 +278,40 @@ def test_bench_refuses_more_gpus_than_the_box_has():
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
     assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_side_measurements_keep_the_line_alive(monkeypatch):
+    """bench.py's side measurements (configs[0], configs[3], the configs[4] preset as child processes behind the default line) only ever run on the
+    driver's GPU box; here their bookkeeping with the children faked: a good child's line is kept in compact form, a child that fails, prints
+    garbage or times out costs its own entry only, and a spent time budget skips the rest -- the default line is printed whatever happens."""
+    import importlib.util
+    import json
+    import subprocess
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod2", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    good = json.loads([ln for ln in (ROOT / "profiles" / "r05_bench_config4.json").read_text().splitlines() if ln.startswith("{")][0])
+    calls = []
+
+    def fake_run(cmd, **kw):
+        cfg = cmd[cmd.index("--config") + 1]
+        calls.append(cfg)
+        assert "--no-side" in cmd and "--no-cpu-baseline" in cmd and "WORLD_SIZE" not in kw["env"]
+        if cfg == "0":
+            return subprocess.CompletedProcess(cmd, 1, stdout="", stderr="boom")
+        if cfg == "3":
+            raise subprocess.TimeoutExpired(cmd, kw["timeout"])
+        return subprocess.CompletedProcess(cmd, 0, stdout="noise\n" + json.dumps(good) + "\n", stderr="")
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    out = bench.side_measurements(1843)
+    assert calls == ["0", "3", "4"]
+    assert out["configs[0]"]["rc"] == 1 and "boom" in out["configs[0]"]["error"] and "timed out" in out["configs[3]"]["error"]
+    e = out["configs[4]_preset"]
+    assert e["baseline_config_index"] == 4 and e["value"] == good["value"] and e["roofline"]["kernel"] == "k_dn_symv" and e["max_depth"] == 7
+    assert abs(e["roofline"]["frac"] - good["roofline"]["frac"]) < 1e-15 and "per_step" not in e["dense"] and e["dense"]["window_ends"] == 1
+    calls.clear()
+    out = bench.side_measurements(1843, budget_s=10.0)                    # nothing fits a budget of ten seconds
+    assert calls == [] and all("skipped" in out[k] for k in ("configs[0]", "configs[3]", "configs[4]_preset"))
