@@ -38,11 +38,6 @@
 #define CL_AUX_SC1 16                    // cache-policy bit of the buffer intrinsics: sc1 (agent scope)
 #define CL_NCHUNK PT_NW                  // chunks the member's polls are cut into for the adjoint gather (host: build_cluster)
 #define CL_SEG_SHIFT 64                  // the level-2 segment sums of phase E start at this thread: wave 0 turns the chunk totals into prefixes there
-#ifndef CL_RES
-#define CL_RES 1                         // fixed builds, two clusters per chain: the member's share of M^-1, of the leaf's momentum and of the pair's rho stays in LDS across
-#endif                                   // the leaves of a doubling (ClLeapPolicyRes).  Measured side by side (profiles/r05_cl_resident_share.txt): 13.50 -> 13.15 / 13.22 us per
-                                         // leapfrog with two clusters per chain (all 256 compute units busy: a round trip through L2 costs more), 16.53 -> 16.97 / 17.03 with one
-                                         // -- so the one-cluster kernels keep the loads (CL_RES = 2 forces the resident share there too)
 #define CL_SPIN_LIMIT 8000000u
 #ifndef CL_SPIN_SLEEP
 #define CL_SPIN_SLEEP 1                  // s_sleep argument between two looks at an exchange word that has not arrived
@@ -130,7 +125,7 @@ struct ClFixed {
   static constexpr int S = 51, SE = 52, SP = 51, NDP = 33;
   static constexpr int NPCAP = 256, NSUBCAP = 384, NREPCAP = 768, NRCAP = 512, TCAP = 320;   // polls, level-1 tasks per member; small parameters; slots; days
   static constexpr int KMAX = 16;                    // members per cluster: every loop over the members is a single batch of sixteen tagged words
-  static constexpr int NECAP = CL_RES ? 1920 : 0;    // elements of a vector per member (CP_NE) the resident share holds: 32 days x 51 states + 256 polls + slots (2016 on 16 members: 1792)
+  static constexpr int NECAP = 1920;                 // elements of a vector per member (CP_NE) the resident share holds: 32 days x 51 states + 256 polls + slots (2016 on 16 members: 1792)
   static constexpr int XW = 832;                     // exchange words per member: max(XP_P + NRCAP, XQ0 + NREPCAP) = max(72 + 512, 64 + 768)
   // and the full model (poll_model_2020.stan: mode / population effects, AR(1) bias); the no_mode_adjustment variant takes the dynamic build
   static constexpr int GS = 48, GROWS = 52;
@@ -1852,7 +1847,9 @@ template <int CL_DW> __device__ __noinline__ unsigned cl_cold_twin_combine(const
 template <int CL_DW, bool TWIN>
 __device__ __forceinline__ void cl_transition_tree(ClChain &c, uint32_t iter, const ClTwinArgs &ta) {
   constexpr bool FX = ClTag<CL_DW>::FX;              // (the template argument is the build's tag)
-  constexpr bool RES = FX && CL_RES && (TWIN || CL_RES > 1);   // the member's share resident in LDS (ClLeapPolicyRes): two clusters per chain only, see CL_RES
+  // The member's share resident in LDS (ClLeapPolicyRes) with two clusters per chain only: measured side by side (profiles/r05_cl_resident_share.txt)
+  // 13.50 -> 13.15 / 13.22 us per leapfrog there (all 256 compute units busy: a round trip through L2 costs more), 16.53 -> 16.97 / 17.03 with one cluster.
+  constexpr bool RES = FX && TWIN;
   ltp ts = FX ? (ltp)((ldp)lds_dyn + ClFixed::lds_doubles) : c.ts;
   const int tid = c.tid;
   const double eps = ts->eps;

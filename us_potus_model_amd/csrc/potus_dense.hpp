@@ -49,9 +49,6 @@
 #define DN_FIN 256                                        // threads of the finishing kernel = elements per partial sum
 #define DN_SPLIT_MAX 8                                    // at most this many workgroups share a pair of row blocks
 #define DN_F32_PIPE_ROWS 2                                // fp32 storage: row groups software-pipelined, two buffers of this many rows (k_dn_symv)
-#ifndef DN_MASKLESS
-#define DN_MASKLESS 1                                     // tiles off the band and off the right edge take a loop without per-element masks (k_dn_symv)
-#endif
 typedef double dn_d2 __attribute__((ext_vector_type(2)));
 
 // vector slots of a chain's dense state block
@@ -204,10 +201,10 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
       }
       // The tile overlaps the block's own rows (only j > i counts) or the matrix's right edge (fp32 storage: beyond column D a row's
       // float half runs into the next row's doubles, whose halves may read as NaN): elements are masked one by one.  Every other tile
-      // -- 79 of 81 per row block at D = 41 610 -- takes the loop without the two compares and the select per element (DN_MASKLESS;
+      // -- 79 of 81 per row block at D = 41 610 -- takes the loop without the two compares and the select per element (
       // same products in the same order: same bytes).
       const bool band = c0 < r0 + RB;
-      const bool masked = band || (F32 && c0 + DN_CT > D) || !DN_MASKLESS;
+      const bool masked = band || (F32 && c0 + DN_CT > D);
       auto rows = [&](auto masked_c) {
         constexpr bool MASKED = decltype(masked_c)::value;
         // one group of GR rows: the loads ...

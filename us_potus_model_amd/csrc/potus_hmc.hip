@@ -1539,7 +1539,7 @@ int build_cluster(Sampler *sp, const potus_data *d, int K) {
   {
     const bool fits = DW == 4 && !mfma && K <= ClFixed::KMAX && std::max(XP_P + C.NR, XQ0 + C.NREP) <= ClFixed::XW && S == ClFixed::S && M.SE == ClFixed::SE && M.SP == ClFixed::SP && ndmax <= ClFixed::NDP - 1 && npmax <= ClFixed::NPCAP &&
                       nsubmax <= ClFixed::NSUBCAP && C.NREP <= ClFixed::NREPCAP && C.NR <= ClFixed::NRCAP && T <= ClFixed::TCAP && (int)SC_N <= 8 &&
-                      (!CL_RES || nemax <= ClFixed::NECAP);   // the member's resident share of a vector (ClLeapPolicyRes)
+                      nemax <= ClFixed::NECAP;                // the member's resident share of a vector (ClLeapPolicyRes)
     if (fits && !(getenv("POTUS_CL_DYNAMIC") && atoi(getenv("POTUS_CL_DYNAMIC")))) {
       C.NDP = ClFixed::NDP; C.XW = ClFixed::XW;
       lay = ClFixed::L;
