@@ -114,26 +114,46 @@ def launch_ranks(n):
 
 
 # ------------------------------------------------------------------------------------------------ the other configurations, beside the default line
-def side_measurements(seed, budget_s=150.0):
+def seed_summary(entry):
+    """What `side.seeds` keeps of one configs[1] run: rate, time, ESS / s and how deep each chain's trees go in the sampling phase."""
+    post = next(iter(entry["config"]["posteriors"].values()))
+    return {"seed": entry["seed"], "leapfrogs_per_sec": entry["value"], "seconds": entry["seconds"], "leapfrogs": entry["leapfrogs"],
+            "ess_per_sec": entry.get("ess_per_sec"), "ess_bulk_min": entry.get("ess_bulk_min"), "rhat_max": entry.get("rhat_max"),
+            "treedepth_max_per_chain": post.get("treedepth_max_per_chain"), "stepsize_per_chain": post.get("stepsize_per_chain")}
+
+
+def side_measurements(seed, budget_s=200.0, headline=None):
     """BASELINE's other single-GPU configurations under the same clock as the default line: each is this very script with
     --config X in a child process (GPU only: no CPU baseline, no saturated point, no side measurements of its own), after the timed region and
-    after the default run's handles are gone; the child's JSON line is kept in a compact form.  A failure or a timeout costs its own entry only."""
+    after the default run's handles are gone; the child's JSON line is kept in a compact form.  A failure or a timeout costs its own entry only.
+    Round 6: `seeds` -- the headline configuration itself (configs[1]) run again under seeds + 1 and + 2, with the default
+    line's own run (`headline`, its seed_summary) beside them and min / median / max over the three: a launch lasts as long as its slowest chain,
+    and whether a chain of this posterior ends its warm-up in trees of eight or nine doublings is a property of (kernel, seed, summation order)."""
     import subprocess
     out, t_all = {}, time.perf_counter()
-    for key, cfg, extra, tmo in (("configs[0]", 0, [], 120), ("configs[3]", 3, [], 120), ("configs[4]_preset", 4, [], 240)):
+    plan = [("configs[0]", 0, [], 120), ("configs[3]", 3, [], 120)]
+    plan += [(f"seed_{seed + k}", 1, ["--seed", str(seed + k), "--warmup", "1"], 90) for k in (1, 2)]
+    plan += [("configs[4]_preset", 4, [], 240)]
+    seed_runs = [headline] if headline else []
+    for key, cfg, extra, tmo in plan:
         left = budget_s - (time.perf_counter() - t_all)
         if left < 20:
             out[key] = {"skipped": "time budget of the side measurements spent"}
             continue
         t0 = time.perf_counter()
         try:
-            r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--config", str(cfg), "--seed", str(seed), "--no-cpu-baseline", "--no-saturated", "--no-side"] + extra,
+            r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--config", str(cfg)] + ([] if "--seed" in extra else ["--seed", str(seed)]) +
+                               ["--no-cpu-baseline", "--no-saturated", "--no-side"] + extra,
                                capture_output=True, text=True, timeout=min(tmo, left), env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or len(lines) != 1:
                 out[key] = {"error": (r.stderr or r.stdout)[-300:], "rc": r.returncode}
                 continue
             d = json.loads(lines[0])
+            if key.startswith("seed_"):
+                d["seed"] = int(extra[extra.index("--seed") + 1])
+                seed_runs.append(seed_summary(d))
+                continue
             e = {"baseline_config_index": cfg, "command": f"bench.py --config {cfg}", "value": d["value"], "unit": d["unit"], "metric": d["metric"], "steps": d["steps"],
                  "ms_per_step": d["ms_per_step"], "workload": d["config"]["workload"], "wall_seconds_with_process_start": time.perf_counter() - t0}
             for k in ("seconds", "leapfrogs", "ess_bulk_min", "ess_per_sec", "rhat_max", "us_per_leapfrog_per_chain"):
@@ -157,6 +177,18 @@ def side_measurements(seed, budget_s=150.0):
             out[key] = {"error": f"timed out after {time.perf_counter() - t0:.0f} s"}
         except Exception as ex:                        # never let a side measurement spoil the bench line
             out[key] = {"error": str(ex)[:200]}
+    if seed_runs:
+        def mmm(k):
+            v = sorted(r[k] for r in seed_runs if r.get(k) is not None)
+            return {"min": v[0], "median": v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]), "max": v[-1]} if v else None
+        deepest = [max(r["treedepth_max_per_chain"]) for r in seed_runs if r.get("treedepth_max_per_chain")]
+        out["seeds"] = {"runs": seed_runs, "leapfrogs_per_sec": mmm("leapfrogs_per_sec"), "seconds": mmm("seconds"), "ess_per_sec": mmm("ess_per_sec"),
+                        "deepest_tree_by_seed": deepest,
+                        "note": "configs[1] (8 chains x (1000 + 1000), the default line's command) under the default seed and the next two; the first run is the "
+                                "default line itself.  A launch lasts as long as its slowest chain: a chain that adapts into trees one doubling deeper "
+                                "than the others sets the time of every sampling launch"}
+    # the default line's figures first, so that a reader of `side` sees the spread before anything else
+    out = {**({"seeds": out.pop("seeds")} if "seeds" in out else {}), **out}
     out["note"] = ("GPU-only runs of `bench.py --config X` in child processes after the default line's timed region: same box, same clock; "
                    "configs[0] = the reference's scripted sampler calls (final_2016.R:533-541 and its 2012 / 2008 siblings), configs[3] = the three backtests "
                    "concurrently on this one GPU (4 chains each), configs[4]_preset = the dense-metric stress shape in its driver-runnable preset")
@@ -229,6 +261,9 @@ def cpu_baseline(data, variant, chains, seed, nw, ns, short, budget=12.0, loop_b
     s_ess = ess_min(cols)
     s_secs, s_samp = float((st[:, 0] + st[:, 1]).max()), float(st[:, 1].max())   # the chains run side by side: the slowest sets the time
     out = dict(value=rate, unit="leapfrogs/s", cores=procs, host_cores_total=os.cpu_count(), kind="port", leapfrogs_per_sec_per_core=rate / procs,
+               value_is=f"the rate of the FIRST {int(timing[:, 4].min())}-{int(timing[:, 4].max())} iterations (early warm-up: the longest trees) of the configured "
+                        f"{nw} + {ns}, {budget:.0f} s per chain -- a bounded sample, not a complete run; the like-for-like pair, both sides run to the end, is short_config",
+               iterations_sampled=[int(timing[:, 4].min()), int(timing[:, 4].max())], iterations_configured=nw + ns,
                sample=f"the first {int(timing[:, 4].min())}-{int(timing[:, 4].max())} iterations of the same run ({procs} chains, ids 1..{procs}, seed {seed}, "
                       f"{nw} warm-up + {ns} sampling configured) on {procs} host processes, cut after {budget:.0f} s each: "
                       f"{int(timing[:, 2:4].sum())} leapfrogs; scan/sparse gradient, pooled-buffer tree (the fastest form of the port)",
@@ -238,10 +273,9 @@ def cpu_baseline(data, variant, chains, seed, nw, ns, short, budget=12.0, loop_b
                                   f"scan/sparse gradient, {procs} processes x {loop_budget:.0f} s each: the rate of the arithmetic alone",
                short_config=dict(iter_warmup=snw, iter_sampling=sns, chains=procs, seed=seed, leapfrogs=int(st[:, 2:4].sum()), seconds=s_secs,
                                  sampling_seconds=s_samp, leapfrogs_per_sec=float(st[:, 2:4].sum()) / s_secs, ess_bulk_min=s_ess,
-                                 ess_per_sec_measured=s_ess / s_samp, wall_seconds=short_wall,
+                                 ess_per_sec=s_ess / s_samp, wall_seconds=short_wall,
                                  note="a complete run of the port, measured: min bulk-ESS over lp__, mu_b[:, T], predicted_score[T, :] of its own "
-                                      "draws / the sampling time of its slowest chain"),
-               ess_per_sec_measured=s_ess / s_samp)
+                                      "draws / the sampling time of its slowest chain"))
     full = ROOT / "tests" / "golden" / "posterior_2016.npz"
     if full.exists() and int(data["T"]) == 254:
         g = np.load(full)
@@ -495,18 +529,26 @@ def main():
             from us_potus_model_amd import device_diagnostics_of_block
             # + predicted_score[T, :] = inv_logit(mu_b[:, T]) as S columns of their own (stan:137): a monotone map keeps the ranks, hence
             # the bulk ESS, but not the FOLDED split R-hat (|x - median| is not invariant under it), and the metric's column set names them
-            blk = torch.cat([full, torch.sigmoid(full[:, :, 1 + ncol - S:])], dim=2)
-            ncols_all = int(blk.shape[2])
+            # (two calls -- the gathered block as it is, then the S sigmoid columns -- instead of one concatenated copy of the whole block: ADVICE r05)
+            sig = torch.sigmoid(full[:, :, 1 + ncol - S:]).contiguous()
+            nf = int(full.shape[2])
+            ncols_all = nf + S
+
+            def diag_cols(ca, cb):
+                parts = ([full[:, :, ca:min(cb, nf)]] if ca < nf else []) + ([sig[:, :, max(ca, nf) - nf:cb - nf]] if cb > nf else [])
+                res = [device_diagnostics_of_block(p_.contiguous()) for p_ in parts if p_.shape[2] > 0]
+                return (np.concatenate([r_[0] for r_ in res]), np.concatenate([r_[1] for r_ in res])) if res else (np.zeros(0), np.zeros(0))
+
             if world == 1:
-                rh, es = device_diagnostics_of_block(blk.contiguous())
+                rh, es = diag_cols(0, ncols_all)
             else:
                 # every rank holds the pooled chains; each sorts its 1/world share of the columns (per-GPU work stays what it is at
                 # N = 1: world x the draws, 1/world of the columns) and the per-column results are gathered
                 ca, cb = parallel.column_block(ncols_all, rank, world)
-                rh_l, es_l = device_diagnostics_of_block(blk[:, :, ca:cb].contiguous()) if cb > ca else (np.zeros(0), np.zeros(0))
+                rh_l, es_l = diag_cols(ca, cb)
                 rh, es = parallel.all_gather_columns(rh_l, ncols_all, coll_dev), parallel.all_gather_columns(es_l, ncols_all, coll_dev)
             dev_diag.append({"rhat": rh, "ess_bulk": es, "seconds": time.perf_counter() - td0, "columns": ncols_all, "S": S})
-            del blk
+            del sig
         else:
             dev_diag.append(None)
         sel = torch.cat([full[:, :, :1], full[:, :, 1 + ncol - S:]], dim=2)   # lp__ and mu_b[:, T]
@@ -532,6 +574,11 @@ def main():
                     "polls": int(data["N_state_polls"]) + int(data["N_national_polls"]), "cus_per_chain": h.cus_per_chain,
                     "clusters_per_chain": h.clusters_per_chain,
                     "divergent_transitions": int(sum(dv)), "chain_status": st}
+            if ns > 0 and cfg != 4:
+                sp = h.write_array(2, 4, ns)                                     # stepsize__, treedepth__ of the saved (sampling) draws: [draw, chain, 2]
+                info["treedepth_max_per_chain"] = [int(v) for v in sp[:, :, 1].max(axis=0)]
+                info["treedepth_mean_per_chain"] = [round(float(v), 3) for v in sp[:, :, 1].mean(axis=0)]
+                info["stepsize_per_chain"] = [float(v) for v in sp[-1, :, 0]]
             if h.clusters_per_chain == 2:
                 cnt, rb, rf = h.twin_stats()
                 info["twin"] = {"leapfrogs_counted": cnt, "leaves_run_backward_side": rb, "leaves_run_forward_side": rf,
@@ -673,7 +720,7 @@ def main():
                                     "sample": f"{nlf} leapfrogs of one chain of the same posterior (D = {hs[0].D}) under a dense {mbytes / 1e9:.2f} GB inverse metric, the rows of the "
                                               f"matrix-vector product over {nthreads} OpenMP threads (oracle/potus_oracle.c: dense_e_metric::dtau_dp + the scan/sparse gradient): {secs:.1f} s",
                                     "seconds": secs, "matrix_GBps": nlf * mbytes / secs / 1e9}
-            line["speedup_vs_cpu_port"] = line["value"] / line["cpu_baseline"]["value"]
+            line["value_over_cpu_sample"] = line["value"] / line["cpu_baseline"]["value"]
         if not args.no_cpu_baseline and world == 1 and cfg in (1, 2):   # the CPU port is timed beside the single-GPU run only
             _, data, variant, C, _ = work[0]
             short = (150, 100)
@@ -693,20 +740,28 @@ def main():
             hg.close()
             cb = cpu_baseline(data, variant, C, args.seed, nw, ns, short)
             cb["short_config"]["gpu"] = dict(leapfrogs=g_lf, seconds=tg2 - tg0, sampling_seconds=tg2 - tg1, leapfrogs_per_sec=g_lf / (tg2 - tg0),
-                                             ess_bulk_min=g_ess, ess_per_sec_measured=g_ess / (tg2 - tg1))
-            cb["short_config"]["gpu_over_cpu"] = dict(leapfrogs_per_sec=(g_lf / (tg2 - tg0)) / cb["short_config"]["leapfrogs_per_sec"],
-                                                      ess_per_sec=(g_ess / (tg2 - tg1)) / cb["short_config"]["ess_per_sec_measured"],
-                                                      wall=cb["short_config"]["seconds"] / (tg2 - tg0))
-            line["cpu_baseline"] = cb
-            line["speedup_vs_cpu_port"] = line["value"] / cb["value"]
-            line["speedup_vs_cpu_leapfrog_loop"] = line["value"] / cb["leapfrog_loop_scan_sparse_value"]
-            line["speedup_note"] = ("speedup_vs_cpu_port: against the port's NUTS in its fastest form (scan/sparse gradient, pooled tree) on the box's "
-                                    f"{cb['cores']} cores; speedup_vs_cpu_leapfrog_loop: against its bare leapfrog loop, which no CPU sampler can exceed")
+                                             ess_bulk_min=g_ess, ess_per_sec=g_ess / (tg2 - tg1))
+            like = dict(leapfrogs_per_sec=(g_lf / (tg2 - tg0)) / cb["short_config"]["leapfrogs_per_sec"],
+                        ess_per_sec=(g_ess / (tg2 - tg1)) / cb["short_config"]["ess_per_sec"],
+                        wall=cb["short_config"]["seconds"] / (tg2 - tg0),
+                        of=f"the complete short configuration {C} chains x ({short[0]} + {short[1]}), seed {args.seed}, run to the end on both sides")
+            cb["short_config"]["gpu_over_cpu"] = like
+            # the like-for-like ratios first; the ratio against the bounded sample (`value`) after them, named for what it is
+            line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
+                                    "like_for_like_gpu_over_cpu": like, **{k: v for k, v in cb.items() if k not in ("value", "unit", "cores", "kind", "sample")}}
+            line["gpu_over_cpu_like_for_like"] = like
+            line["value_over_cpu_sample"] = line["value"] / cb["value"]
+            line["value_over_cpu_leapfrog_loop"] = line["value"] / cb["leapfrog_loop_scan_sparse_value"]
+            line["gpu_over_cpu_note"] = ("gpu_over_cpu_like_for_like: the same complete short configuration on both sides (leapfrogs / s, ESS / s of its own draws, wall time); "
+                                         f"value_over_cpu_sample: this line's whole-run rate over the rate of the port's first {cb['iterations_sampled'][0]}-{cb['iterations_sampled'][1]} "
+                                         f"iterations of the same run on {cb['cores']} host cores (a bounded sample of early warm-up, not the same iterations); "
+                                         "value_over_cpu_leapfrog_loop: over the port's bare leapfrog loop, which no CPU sampler can exceed.  None of them says anything "
+                                         "about kernel quality: roofline.frac does")
         if world == 1 and cfg == 1 and not args.no_side:
             for h in hs:
                 h.close()
             torch.cuda.empty_cache()
-            line["side"] = side_measurements(args.seed)
+            line["side"] = side_measurements(args.seed, headline=seed_summary({**line, "seed": args.seed}))
         print(json.dumps(line), flush=True)
     for h in hs:
         h.close()

@@ -9,6 +9,8 @@ transcription in tests/stan_transcription.py before anything is written.
   python scripts/make_golden.py data        # tests/golden/data_{2016,2012,2008}.npz   (needs /root/reference)
   python scripts/make_golden.py logprob     # tests/golden/logprob_*.npz
   python scripts/make_golden.py posterior [2016 2012 2008]   # tests/golden/posterior_<year>.npz (minutes each, 8 processes)
+  python scripts/make_golden.py posterior --call scripted    # tests/golden/posterior_2016_scripted.npz: the reference's own sampler call,
+                                                             #   6 chains x (500 + 500), final_2016.R:6-11,533-541
 """
 import multiprocessing as mp
 import sys
@@ -87,8 +89,9 @@ def _chain(args):
     return chain, draws, adapt, nl, time.time() - t
 
 
-def make_posterior(name="2016", chains=8, nw=1000, ns=1000):
-    """BASELINE configs[1] on the CPU oracle (8 chains x 1000/1000, seed 1843) for one of the three backtests."""
+def make_posterior(name="2016", chains=8, nw=1000, ns=1000, suffix=""):
+    """BASELINE configs[1] on the CPU oracle (8 chains x 1000/1000, seed 1843) for one of the three backtests; with
+    chains=6, nw=ns=500, suffix="_scripted" the call final_2016.R:6-11,533-541 scripts (BASELINE configs[0])."""
     from oracle_lib import OracleModel
     data, variant = cases()[name]
     with mp.Pool(min(chains, mp.cpu_count())) as pool:
@@ -122,7 +125,7 @@ def make_posterior(name="2016", chains=8, nw=1000, ns=1000):
     nat = ps_T @ w                                                         # [chain, draw]
     out["national__mean"] = nat.mean(); out["national__q025"] = np.quantile(nat, 0.025)
     out["national__q975"] = np.quantile(nat, 0.975); out["national__p_win"] = (nat > 0.5).mean()
-    np.savez_compressed(GOLD / f"posterior_{name}.npz", **out)
+    np.savez_compressed(GOLD / f"posterior_{name}{suffix}.npz", **out)
     print("leapfrogs", [r[3] for r in res], "seconds", [round(r[4], 1) for r in res])
     print("national", out["national__mean"], out["national__q025"], out["national__q975"], out["national__p_win"])
     print("rhat max", out["mu_b_T__rhat"].max(), "min bulk ess", out["mu_b_T__ess_bulk"].min(), out["lp__ess_bulk"])
@@ -136,5 +139,9 @@ if __name__ == "__main__":
     if what in ("logprob", "all"):
         make_logprob()
     if what in ("posterior", "all"):
-        for name in (sys.argv[2:] or ["2016", "2012", "2008"]):
-            make_posterior(name)
+        args = sys.argv[2:]
+        if args[:2] == ["--call", "scripted"]:
+            make_posterior("2016", chains=6, nw=500, ns=500, suffix="_scripted")
+        else:
+            for name in (args or ["2016", "2012", "2008"]):
+                make_posterior(name)

@@ -91,3 +91,36 @@ def rmse_ex_dc(states, mean_by_state, rows):
     act = {r["state"]: float(r["actual"]) for r in rows if r["state"] != "--"}
     d = [mean_by_state[i] - act[s] for i, s in enumerate(states) if s != "DC"]
     return float(np.sqrt(np.mean(np.square(d))))
+
+
+def election_day_draws(h, n_saved):
+    """mu_b[:, T] and predicted_score[T, :] of a handle's saved draws as [chains, draws, S] each (columns of the CmdStan output row, potus_write_array):
+    mu_b is S x T column-major (stan:73), predicted_score T x S column-major (stan:135)."""
+    import numpy as np
+    S, T = int(h.data["S"]), int(h.data["T"])
+    a_mu = h.layout["mu_b"][0]
+    mu = h.write_array(a_mu + S * (T - 1), a_mu + S * T, n_saved).transpose(1, 0, 2)
+    a_ps = h.layout["predicted_score"][0]
+    ps = h.write_array(a_ps + (T - 1), a_ps + (T - 1) + T * (S - 1) + 1, n_saved)[:, :, ::T].transpose(1, 0, 2)
+    return np.ascontiguousarray(mu), np.ascontiguousarray(ps)
+
+
+def assert_posterior_within_mcse(mu_b_T, ps_T, golden, nsig=5.0, rhat_max=1.05):
+    """Statistical parity with a committed run of the CPU oracle (tests/golden/posterior_*.npz, scripts/make_golden.py posterior): the pooled means of
+    mu_b[:, T] and predicted_score[T, :] within `nsig` combined Monte-Carlo standard errors, the 2.5 % / 97.5 % quantiles within 6 MCSE + 0.004
+    (the bar of test_posterior_2016_against_golden_and_readme since round 1).  Arrays are [chains, draws, S].  Returns the worst z-score."""
+    import numpy as np
+    from us_potus_model_amd import diagnostics as dg
+    worst = 0.0
+    for name, x in (("mu_b_T", mu_b_T), ("predicted_score_T", ps_T)):
+        sm = dg.summarise(x)
+        se = np.hypot(sm["mcse"], golden[f"{name}__mcse"])
+        z = np.abs(sm["mean"] - golden[f"{name}__mean"]) / se
+        assert z.max() < nsig, (name, float(z.max()))
+        assert sm["rhat"].max() < rhat_max, (name, float(sm["rhat"].max()))
+        pooled = x.reshape(-1, x.shape[-1])
+        for q, key in ((0.025, "q025"), (0.975, "q975")):
+            d = np.abs(np.quantile(pooled, q, axis=0) - golden[f"{name}__{key}"]).max()
+            assert d < 6 * se.max() + 0.004, (name, key, float(d))
+        worst = max(worst, float(z.max()))
+    return worst

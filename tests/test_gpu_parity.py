@@ -310,8 +310,8 @@ def test_adaptation_replayed_through_every_window_end(cases, nw, windows, cus, t
 @pytest.mark.parametrize("name,cus,twin", [("2016", 16, 1), ("2008", 16, 0), ("2012", 1, 1)])
 def test_two_window_ends_at_2016_size(cases, name, cus, twin):
     """The headline kernels through two metric updates at full size: init_buffer = window = term_buffer = 10 of 60 warm-up iterations
-    -> windows of 10 (rows 10 .. 19) and, stretched, 30 (rows 20 .. 49).  Both chains; k_cl_run<16, true> on 2016, the dynamic
-    cluster build on 2008 (no-mode variant), two workgroups per chain on 2012."""
+    -> windows of 10 (rows 10 .. 19) and, stretched, 30 (rows 20 .. 49).  Both chains; k_cl_run<16, true> on 2016,
+    k_cl_run<17, false> on 2008 (the fixed build of the no-mode variant, round 5), two workgroups per chain on 2012."""
     data, variant = cases[name]
     nw = 60
     assert window_schedule(nw, 10, 10, 10) == [(10, 19), (20, 49)]
@@ -631,19 +631,29 @@ def test_posterior_2016_against_golden_and_readme(data_2016):
     S, T = 51, 254
     mu_b_T = fit.extract("mu_b")[:, :, T - 1].reshape(8, 1000, S)
     ps_T = fit.extract("predicted_score")[:, T - 1, :].reshape(8, 1000, S)
-    for name, x in (("mu_b_T", mu_b_T), ("predicted_score_T", ps_T)):
-        sm = dg.summarise(x)
-        se = np.hypot(sm["mcse"], g[f"{name}__mcse"])
-        z = np.abs(sm["mean"] - g[f"{name}__mean"]) / se
-        assert z.max() < 5.0, (name, z.max())
-        assert sm["rhat"].max() < 1.05
-        pooled = x.reshape(-1, S)
-        assert np.abs(np.quantile(pooled, 0.025, axis=0) - g[f"{name}__q025"]).max() < 6 * se.max() + 0.004
-        assert np.abs(np.quantile(pooled, 0.975, axis=0) - g[f"{name}__q975"]).max() < 6 * se.max() + 0.004
+    from conftest import assert_posterior_within_mcse
+    assert_posterior_within_mcse(mu_b_T, ps_T, g)
     nat = ps_T @ np.asarray(data_2016["state_weights"])
     assert abs(nat.mean() - 0.512) < 0.01 and abs(np.quantile(nat, 0.025) - 0.485) < 0.012 and abs(np.quantile(nat, 0.975) - 0.540) < 0.012
     sp = fit.sampler_params()
     assert sp["divergent__"].mean() < 0.01 and 0.6 < sp["accept_stat__"].mean() < 0.97
+
+
+def test_the_references_scripted_call_against_the_oracles_run_of_it(data_2016):
+    """BASELINE configs[0] as the reference scripts it -- final_2016.R:6-11 (n_chains 6, n_warmup 500, n_sampling 500) and :533-541 (seed 1843,
+    refresh 50): the same call on the device against the CPU oracle's run of that very call (tests/golden/posterior_2016_scripted.npz,
+    `scripts/make_golden.py posterior --call scripted`): means of mu_b[:, T] and predicted_score[T, :] within 5 combined MCSE, interval ends
+    within 6 MCSE + 0.004.  (`bench.py --config 0` times this call; until round 6 nothing compared its draws with anything but their own R-hat.)"""
+    from conftest import assert_posterior_within_mcse
+    g = np.load(GOLD / "posterior_2016_scripted.npz")
+    assert list(g["config"]) == [6, 500, 500, 1843]
+    fit = PotusModel("full").sample(data_2016, seed=1843, chains=6, iter_warmup=500, iter_sampling=500, refresh=50)
+    S, T = 51, 254
+    mu_b_T = fit.extract("mu_b")[:, :, T - 1].reshape(6, 500, S)
+    ps_T = fit.extract("predicted_score")[:, T - 1, :].reshape(6, 500, S)
+    z = assert_posterior_within_mcse(mu_b_T, ps_T, g, rhat_max=1.08)
+    sp = fit.sampler_params()
+    assert sp["divergent__"].mean() < 0.01 and 0.6 < sp["accept_stat__"].mean() < 0.97, z
 
 
 @pytest.mark.parametrize("name", ["small_full", "2016"])

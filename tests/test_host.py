@@ -216,8 +216,18 @@ def _check_committed_bench_line(line, device_diagnostics):
     assert cb["kind"] == "port" and cb["cores"] >= 1 and line["rhat_max"] < 1.01
     # the CPU side is measured, not derived: a complete short configuration run to the end on both sides
     sc = cb["short_config"]
-    assert sc["ess_per_sec_measured"] > 0 and sc["gpu"]["ess_per_sec_measured"] > sc["ess_per_sec_measured"] and cb["ess_per_sec_measured"] == sc["ess_per_sec_measured"]
-    assert abs(line["speedup_vs_cpu_port"] - line["value"] / cb["value"]) < 1e-9 and line["speedup_vs_cpu_leapfrog_loop"] < line["speedup_vs_cpu_port"]
+    if device_diagnostics >= 6:
+        # round 6: the ESS / s of the short configuration lives under short_config only, the like-for-like ratios come first and
+        # the ratio against the bounded sample is named for what it is
+        assert "ess_per_sec_measured" not in cb and "speedup_vs_cpu_port" not in line
+        assert sc["ess_per_sec"] > 0 and sc["gpu"]["ess_per_sec"] > sc["ess_per_sec"] and cb["like_for_like_gpu_over_cpu"] == sc["gpu_over_cpu"] == line["gpu_over_cpu_like_for_like"]
+        assert list(cb)[:6] == ["value", "unit", "cores", "kind", "sample", "like_for_like_gpu_over_cpu"]
+        assert cb["iterations_sampled"][1] < cb["iterations_configured"] == 2000 and "bounded sample" in cb["value_is"]
+        assert abs(line["value_over_cpu_sample"] - line["value"] / cb["value"]) < 1e-9 and line["value_over_cpu_leapfrog_loop"] < line["value_over_cpu_sample"]
+        assert abs(sc["gpu_over_cpu"]["ess_per_sec"] - sc["gpu"]["ess_per_sec"] / sc["ess_per_sec"]) < 1e-9
+    else:
+        assert sc["ess_per_sec_measured"] > 0 and sc["gpu"]["ess_per_sec_measured"] > sc["ess_per_sec_measured"] and cb["ess_per_sec_measured"] == sc["ess_per_sec_measured"]
+        assert abs(line["speedup_vs_cpu_port"] - line["value"] / cb["value"]) < 1e-9 and line["speedup_vs_cpu_leapfrog_loop"] < line["speedup_vs_cpu_port"]
     assert line["config"]["all_gather_bytes_per_rank"] == 1000 * 8 * (1 + 51 * 254) * 8            # lp__ + all of mu_b
     if device_diagnostics:                                                                          # round 4: R-hat / ESS of every gathered column on the device
         dd = line["config"]["posteriors"]["2016"]["device_diagnostics"]
@@ -230,6 +240,17 @@ def _check_committed_bench_line(line, device_diagnostics):
         assert side["configs[3]"]["baseline_config_index"] == 3 and side["configs[3]"]["value"] > 0 and side["configs[3]"]["roofline"]["kernel"] == "k_cl_run"
         assert side["configs[4]_preset"]["roofline"]["kernel"] == "k_dn_symv" and 0.5 < side["configs[4]_preset"]["roofline"]["frac"] < 0.9
         assert cb["host_cores_total"] >= cb["cores"]
+    if device_diagnostics >= 6:
+        # round 6: where the headline's seed sits -- the same command under the next two seeds, the default line's own run first
+        sd = line["side"]["seeds"]
+        assert list(line["side"])[0] == "seeds" and [r["seed"] for r in sd["runs"]] == [1843, 1844, 1845]
+        assert sd["runs"][0]["leapfrogs_per_sec"] == line["value"] and sd["runs"][0]["seconds"] == line["seconds"]
+        for k in ("leapfrogs_per_sec", "seconds", "ess_per_sec"):
+            v = sorted(r[k] for r in sd["runs"])
+            assert sd[k] == {"min": v[0], "median": v[1], "max": v[2]}
+        assert all(len(r["treedepth_max_per_chain"]) == 8 and 7 <= max(r["treedepth_max_per_chain"]) <= 10 for r in sd["runs"])
+        assert sd["deepest_tree_by_seed"] == [max(r["treedepth_max_per_chain"]) for r in sd["runs"]]
+        assert line["config"]["posteriors"]["2016"]["treedepth_max_per_chain"] == sd["runs"][0]["treedepth_max_per_chain"]
 
 
 def test_layout_plan_for_every_chain_count():
@@ -292,12 +313,22 @@ def test_side_measurements_keep_the_line_alive(monkeypatch):
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     good = json.loads([ln for ln in (ROOT / "profiles" / "r05_bench_config4.json").read_text().splitlines() if ln.startswith("{")][0])
+    head = json.loads([ln for ln in (ROOT / "profiles" / "r05_bench_line.json").read_text().splitlines() if ln.startswith("{")][0])
+    head["config"]["posteriors"]["2016"]["treedepth_max_per_chain"] = [8] * 8
     calls = []
 
     def fake_run(cmd, **kw):
         cfg = cmd[cmd.index("--config") + 1]
         calls.append(cfg)
-        assert "--no-side" in cmd and "--no-cpu-baseline" in cmd and "WORLD_SIZE" not in kw["env"]
+        assert "--no-side" in cmd and "--no-cpu-baseline" in cmd and "WORLD_SIZE" not in kw["env"] and cmd.count("--seed") == 1
+        if cfg == "1":                                   # the headline configuration under another seed: a slower re-roll for the first, garbage for the second
+            sd = int(cmd[cmd.index("--seed") + 1])
+            if sd == 1845:
+                return subprocess.CompletedProcess(cmd, 0, stdout="{not json\n", stderr="")
+            slow = json.loads(json.dumps(head))
+            slow["value"], slow["seconds"] = head["value"] * 0.8, head["seconds"] / 0.8
+            slow["config"]["posteriors"]["2016"]["treedepth_max_per_chain"] = [8] * 7 + [9]
+            return subprocess.CompletedProcess(cmd, 0, stdout=json.dumps(slow) + "\n", stderr="")
         if cfg == "0":
             return subprocess.CompletedProcess(cmd, 1, stdout="", stderr="boom")
         if cfg == "3":
@@ -306,12 +337,16 @@ def test_side_measurements_keep_the_line_alive(monkeypatch):
 
     monkeypatch.setattr(subprocess, "run", fake_run)
     monkeypatch.setenv("WORLD_SIZE", "1")
-    out = bench.side_measurements(1843)
-    assert calls == ["0", "3", "4"]
+    out = bench.side_measurements(1843, headline=bench.seed_summary({**head, "seed": 1843}))
+    assert calls == ["0", "3", "1", "1", "4"] and list(out)[0] == "seeds"
+    sd = out["seeds"]                                    # the default line's own run first; the child that printed garbage costs its own entry only
+    assert [r["seed"] for r in sd["runs"]] == [1843, 1844] and "error" in out["seed_1845"] and sd["deepest_tree_by_seed"] == [8, 9]
+    assert sd["leapfrogs_per_sec"]["max"] == head["value"] and abs(sd["leapfrogs_per_sec"]["min"] - 0.8 * head["value"]) < 1e-9
+    assert abs(sd["seconds"]["median"] - 0.5 * (head["seconds"] + head["seconds"] / 0.8)) < 1e-9
     assert out["configs[0]"]["rc"] == 1 and "boom" in out["configs[0]"]["error"] and "timed out" in out["configs[3]"]["error"]
     e = out["configs[4]_preset"]
     assert e["baseline_config_index"] == 4 and e["value"] == good["value"] and e["roofline"]["kernel"] == "k_dn_symv" and e["max_depth"] == 7
     assert abs(e["roofline"]["frac"] - good["roofline"]["frac"]) < 1e-15 and "per_step" not in e["dense"] and e["dense"]["window_ends"] == 1
     calls.clear()
     out = bench.side_measurements(1843, budget_s=10.0)                    # nothing fits a budget of ten seconds
-    assert calls == [] and all("skipped" in out[k] for k in ("configs[0]", "configs[3]", "configs[4]_preset"))
+    assert calls == [] and all("skipped" in out[k] for k in ("configs[0]", "configs[3]", "seed_1844", "seed_1845", "configs[4]_preset")) and "seeds" not in out

@@ -127,7 +127,7 @@ struct ClFixed {
   static constexpr int KMAX = 16;                    // members per cluster: every loop over the members is a single batch of sixteen tagged words
   static constexpr int NECAP = 1920;                 // elements of a vector per member (CP_NE) the resident share holds: 32 days x 51 states + 256 polls + slots (2016 on 16 members: 1792)
   static constexpr int XW = 832;                     // exchange words per member: max(XP_P + NRCAP, XQ0 + NREPCAP) = max(72 + 512, 64 + 768)
-  // and the full model (poll_model_2020.stan: mode / population effects, AR(1) bias); the no_mode_adjustment variant takes the dynamic build
+  // (the model variant is the tag's: 16 = poll_model_2020.stan with mode / population effects and the AR(1) bias, 17 = the no_mode_adjustment variant)
   static constexpr int GS = 48, GROWS = 52;
   static constexpr ClLay L = cl_layout(S, SE, SP, NDP, NPCAP, NSUBCAP, NREPCAP, NRCAP, TCAP, 0, NECAP);
 #define CLF(f) static constexpr int f = L.f

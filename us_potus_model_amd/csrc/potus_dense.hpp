@@ -259,7 +259,8 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
           for (int q = 0; q < RW; q += 2 * GR) {
             request(a1, q + GR);
             consume(a0, q);
-            request(a0, q + 2 * GR);
+            if (q + 2 * GR < RW) request(a0, q + 2 * GR);   // wave-uniform; the last trip has no next group (its rows would lie past the wave's: a
+                                                            // buffer's scalar offset is not part of the bounds check -- ADVICE r05)
             consume(a1, q + GR);
           }
         } else {

@@ -1666,7 +1666,7 @@ void dense_launch_shape(DnParams &P, int active) {
   P.rb = P.D >= 32 * DN_RB_MAX ? DN_RB_MAX : P.D >= 32 * DN_RB_BIG ? DN_RB_BIG : DN_RB;   // by the size of the matrix alone: a chain's numbers must not depend on its companions
   P.ntile = (P.D + DN_CT - 1) / DN_CT;
   const int pairs = ((P.D + P.rb - 1) / P.rb + 1) / 2;
-  // One 78 KB-LDS workgroup per compute unit at a time: the launch runs in waves of 256 workgroups.  Few, large workgroups are
+  // One workgroup per compute unit at a time (DN_SYMV_LDS(2) = 90 KB of LDS with DN_RB_MAX = 512): the launch runs in waves of 256 workgroups.  Few, large workgroups are
   // best (measured: profiles/r02_dense_active_sweep.txt), so: the smallest split whose last wave is at least 90 % full.
   const int base = active * pairs;
   P.split = 1;

@@ -311,10 +311,18 @@ def device_diagnostics(handles, col_begin, col_end):
     return rhat, ess
 
 
+def _need_check_convergence(L):
+    """A development build selected through POTUS_LIB may predate the export: say so up front, with the library's name, instead of an
+    AttributeError in the middle of a run whose warm-up has already been paid for."""
+    if not hasattr(L, "potus_check_convergence"):
+        raise PotusError(f"{lib_path()} does not export potus_check_convergence (an older development build?): rhat_stop / check_convergence need it")
+
+
 def check_convergence(handles, rhat_below=1.01, ess_at_least=400.0):
     """potus_check_convergence: (converged, rhat_max, ess_bulk_min) of lp__ and mu_b[:, T] over the post-warm-up draws the pooled chains of
     the handles have saved so far (the online early-stop check of SURVEY 8(f4); a deviation from Stan when acted upon)."""
     h0 = handles[0]
+    _need_check_convergence(h0.L)
     ids = (C.c_int * len(handles))(*[h.h for h in handles])
     conv, r, e = C.c_int(0), C.c_double(), C.c_double()
     _check(h0.L, h0.L.potus_check_convergence(ids, len(handles), C.c_double(rhat_below), C.c_double(ess_at_least), C.byref(conv), C.byref(r), C.byref(e)))
@@ -470,6 +478,8 @@ class PotusModel:
         (potus_check_convergence) and sampling ends once every R-hat < rhat_stop and every bulk ESS >= ess_stop; the draws up to that
         point are those of the uninterrupted run.  `self.last_convergence` keeps the checks."""
         from . import parallel
+        if rhat_stop is not None:
+            _need_check_convergence(load_library())
         devs = [int(device)] if devices is None else [int(d) for d in devices]
         hs, first = [], 0
         for r, dev in enumerate(devs):
