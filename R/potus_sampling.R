@@ -35,7 +35,9 @@ potus_sample <- function(data, variant = c("full", "no_mode_adjustment"), seed =
                          parallel_chains = chains, iter_warmup = 1000, iter_sampling = 1000, refresh = 100,
                          adapt_delta = 0.8, max_treedepth = 10, init = 2, device = 0, chain_id_offset = 0,
                          save_warmup = FALSE, gpus = device, cus_per_chain = 0, metric = c("diag_e", "dense_e"), twin = -1,
-                         metric_storage = c("f64", "f32"), rhat_stop = NULL, ess_stop = 400) {
+                         metric_storage = c("f64", "f32"), rhat_stop = NULL, ess_stop = 400, pooled_metric = FALSE) {
+  # pooled_metric (off by default; metric = "dense_e" only; a DEVIATION from Stan / CmdStan, whose chains are separate processes): ONE inverse metric
+  # per GPU, adapted at every window end from the draws of all chains on it (potus_opts.pooled_metric, include/potus_hmc.h).
   # rhat_stop (off by default; a DEVIATION from Stan / the reference, which always run iter_sampling iterations, final_2016.R:539): after every
   # `refresh` transitions of the sampling phase the pooled chains' rank-normalised split R-hat / bulk ESS of lp__ and mu_b[, T] are taken on the
   # device (potus_R_check_convergence) and sampling ends once every R-hat < rhat_stop and every bulk ESS >= ess_stop; the draws up to that point
@@ -70,7 +72,7 @@ potus_sample <- function(data, variant = c("full", "no_mode_adjustment"), seed =
               as.double(data$state_covariance_0),           # column-major, as R stores it
               as.integer(c(per[g], chain_id_offset + first[g], iter_warmup, iter_sampling, max_treedepth, gpus[g],
                            as.integer(save_warmup), cus_per_chain, if (metric == "dense_e") 1L else 0L, twin,
-                           if (metric_storage == "f32") 1L else 0L)),
+                           if (metric_storage == "f32") 1L else 0L, if (isTRUE(pooled_metric)) 1L else 0L)),
               as.double(c(adapt_delta, 0.05, 0.75, 10, 1, init, seed)),   # the seed as a double: exact to 2^53
               handle = integer(1), status = integer(1))
     .potus_check(res$status)

@@ -133,7 +133,7 @@ def side_measurements(seed, budget_s=200.0, headline=None):
     out, t_all = {}, time.perf_counter()
     plan = [("configs[0]", 0, [], 120), ("configs[3]", 3, [], 120)]
     plan += [(f"seed_{seed + k}", 1, ["--seed", str(seed + k), "--warmup", "1"], 90) for k in (1, 2)]
-    plan += [("configs[4]_preset", 4, [], 240)]
+    plan += [("configs[4]_preset", 4, [], 240), ("configs[4]_pooled", 4, ["--pooled-metric"], 150)]
     seed_runs = [headline] if headline else []
     for key, cfg, extra, tmo in plan:
         left = budget_s - (time.perf_counter() - t_all)
@@ -161,7 +161,7 @@ def side_measurements(seed, budget_s=200.0, headline=None):
                     e[k] = d[k]
             if "roofline" in d:
                 e["roofline"] = {k: d["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms_total", "leapfrogs_in_launches",
-                                                                "matrix_passes", "avg_pass_ms", "matrix_bytes_streamed", "metric_storage") if k in d["roofline"]}
+                                                                "matrix_passes", "avg_pass_ms", "matrix_bytes_streamed", "metric_storage", "pooled_metric", "mfma") if k in d["roofline"]}
             if "runs" in d:     # configs[0]: the reference's scripted calls, one by one
                 e["runs"] = [{"call": r_["call"], "posterior": r_["posterior"], "variant": r_["variant"], "chains": r_["chains"], "iter_warmup": r_["iter_warmup"],
                               "iter_sampling": r_["iter_sampling"], **{k: r_["gpu"][k] for k in ("seconds", "leapfrogs", "leapfrogs_per_sec", "ess_bulk_min", "ess_per_sec",
@@ -191,7 +191,8 @@ def side_measurements(seed, budget_s=200.0, headline=None):
     out = {**({"seeds": out.pop("seeds")} if "seeds" in out else {}), **out}
     out["note"] = ("GPU-only runs of `bench.py --config X` in child processes after the default line's timed region: same box, same clock; "
                    "configs[0] = the reference's scripted sampler calls (final_2016.R:533-541 and its 2012 / 2008 siblings), configs[3] = the three backtests "
-                   "concurrently on this one GPU (4 chains each), configs[4]_preset = the dense-metric stress shape in its driver-runnable preset")
+                   "concurrently on this one GPU (4 chains each), configs[4]_preset = the dense-metric stress shape in its driver-runnable preset, "
+                   "configs[4]_pooled = the same preset with potus_opts.pooled_metric (one inverse metric per GPU: a declared deviation from Stan)")
     out["seconds"] = time.perf_counter() - t_all
     return out
 
@@ -349,7 +350,7 @@ def reference_sampler_calls(local, seed, cus_per_chain, twin, max_depth, cpu=Tru
 
 
 # ------------------------------------------------------------------------------------------------ workloads
-def load_workloads(cfg, chains_per_gpu, twin_posteriors="", storage=0):
+def load_workloads(cfg, chains_per_gpu, twin_posteriors="", storage=0, pooled=0):
     """[(name, data, variant, chains per GPU, options)] of the posteriors one GPU runs."""
     from us_potus_model_amd import dataprep, synthetic
     gold = ROOT / "tests" / "golden"
@@ -363,7 +364,7 @@ def load_workloads(cfg, chains_per_gpu, twin_posteriors="", storage=0):
                 for y, v in (("2008", "no_mode_adjustment"), ("2012", "no_mode_adjustment"), ("2016", "full"))]
     if cfg == 4:
         from us_potus_model_amd import _abi
-        return [("stress", synthetic.stress(), "full", chains_per_gpu or 16, {"metric": _abi.METRIC_DENSE, "metric_storage": storage})]
+        return [("stress", synthetic.stress(), "full", chains_per_gpu or 16, {"metric": _abi.METRIC_DENSE, "metric_storage": storage, "pooled_metric": pooled})]
     raise SystemExit(f"unknown --config {cfg}")
 
 
@@ -380,6 +381,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="transitions per step (0 = the configuration's: 100; 1 for --config 4)")
     ap.add_argument("--warm-steps", type=int, default=-1, help="how many of the --steps are warm-up (-1 = half of them)")
     ap.add_argument("--metric-storage", default="f64", choices=["f64", "f32"], help="--config 4: storage of the dense inverse metric")
+    ap.add_argument("--pooled-metric", action="store_true", help="--config 4: ONE dense inverse metric per GPU, adapted from the window draws of all its chains "
+                                                                 "(potus_opts.pooled_metric; a declared deviation from Stan)")
     ap.add_argument("--max-depth", type=int, default=None, help="default 10 (CmdStan's); --config 4: 7, stated in the line")
     ap.add_argument("--adapt-windows", default="", help="init_buffer,window,term_buffer of the warm-up (default: CmdStan's 75,25,50, rescaled by windowed_adaptation for short warm-ups); "
                                                         "e.g. 6,8,6 puts two window ends into a 40-iteration warm-up of --config 4")
@@ -445,7 +448,10 @@ def main():
         parallel.barrier()
         return
     chunk = args.chunk or (1 if cfg == 4 else 100)
-    work = load_workloads(cfg, args.chains_per_gpu, "" if dev_backend == "gloo" else args.twin_posteriors, 1 if args.metric_storage == "f32" else 0)
+    if args.pooled_metric and (cfg != 4 or args.metric_storage != "f64"):
+        raise SystemExit("--pooled-metric applies to --config 4 with fp64 storage")
+    work = load_workloads(cfg, args.chains_per_gpu, "" if dev_backend == "gloo" else args.twin_posteriors, 1 if args.metric_storage == "f32" else 0,
+                          1 if args.pooled_metric else 0)
     warm_steps = args.steps // 2 if args.warm_steps < 0 else min(args.warm_steps, args.steps)
     nw, ns = warm_steps * chunk, (args.steps - warm_steps) * chunk
 
@@ -618,7 +624,17 @@ def main():
                         f"rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE, profiles/{tr[0]}; FETCH_SIZE calibrated at 0.500 counted "
                         f"bytes per streamed byte for the sampler's 8- and 16-byte plain and sc1 loads, profiles/r04_fetch_size_calibration.txt; WRITE_SIZE "
                         f"at 1.000, profiles/r03_write_size_calibration.txt) x this run's leapfrogs / launch time" if tr else "no PMC pass committed for this kernel")
-        if dense:   # the matrix pass: HBM reads measured / bytes loaded by construction, from the committed counter pass of the dense sampler
+        if dense and args.pooled_metric:
+            traffic, traffic_note = None, "no counter pass committed for k_dn_pool_mm"
+            for f in sorted((ROOT / "profiles").glob("*dense_pooled_pmc_fetch.json")):
+                try:
+                    ratio = json.loads(f.read_text())["ratio"]
+                except (OSError, ValueError, KeyError):
+                    continue
+                traffic = achieved * ratio
+                traffic_note = (f"NOT measured in this run: HBM reads of k_dn_pool_mm = {ratio:.3f} x the bytes of the matrix (rocprofv3 --pmc FETCH_SIZE pass of the pooled "
+                                f"sampler, doubled per the guide; profiles/{f.name}) x this run's rate")
+        elif dense:   # the matrix pass: HBM reads measured / bytes loaded by construction, from the committed counter pass of the dense sampler
             for f in sorted((ROOT / "profiles").glob("*dense_pmc_fetch.json")):
                 try:
                     ratio = json.loads(f.read_text())["ratio_with_finish"]
@@ -629,7 +645,8 @@ def main():
                                 f"construction (rocprofv3 --pmc FETCH_SIZE pass of the dense sampler, doubled per the guide; profiles/{f.name}) x this run's rate")
         C_tot = sum(w[3] for w in work)
         names = {1: "configs[1]: 2016 backtest", 2: "configs[2]: 2016 backtest, chains sharded over the GPUs",
-                 3: "configs[3]: 2008 + 2012 + 2016 backtests concurrently", 4: "configs[4]: synthetic stress posterior, dense metric"}
+                 3: "configs[3]: 2008 + 2012 + 2016 backtests concurrently",
+                 4: "configs[4]: synthetic stress posterior, dense metric" + (" POOLED over the GPU's chains (a declared deviation from Stan)" if args.pooled_metric else "")}
         line = {
             "metric": "leapfrog_steps_per_sec", "value": leapfrogs / elapsed, "unit": "leapfrogs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -662,10 +679,21 @@ def main():
                          **({"matrix_passes": dense_t[1], "matrix_pass_ms_total": dense_t[0], "matrix_bytes_streamed": dense_t[2],
                              "avg_pass_ms": dense_t[0] / max(dense_t[1], 1), "leaf_rounds": dense_t[3],
                              "metric_storage": args.metric_storage} if dense else {}),
+                         **({"pooled_metric": True, "kernel": "k_dn_pool_mm",
+                             # the pooled pass is a D x D times D x R product: its second bound is the fp64 matrix peak (MI355X_MICROARCH.md: 78.6 TFLOP/s dense)
+                             "mfma": {"bound": "mfma", "achieved": 2.0 * hs[0].D ** 2 * 2.0 * sum(lf_local) / max(dense_t[0] * 1e-3, 1e-9) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                                      "frac": 2.0 * hs[0].D ** 2 * 2.0 * sum(lf_local) / max(dense_t[0] * 1e-3, 1e-9) / 1e12 / 78.6,
+                                      "note": "2 D^2 flops per right-hand side, two right-hand sides per counted leapfrog (the first pass of a transition carries three: not counted), "
+                                              "over the time of the passes; the pass streams the FULL symmetric matrix (8 D^2 bytes) once per round for all chains"}}
+                            if dense and args.pooled_metric else {}),
                          "note": (f"latency-bound at {C_tot} chains ({C_tot * K * sides} of 256 CUs busy): the state of a chain stays in L2, a leapfrog "
                                   "is a chain of dependent phases and exchanges between the CUs of a cluster; see DESIGN.md") if not dense else
-                                 "dense metric: every leapfrog streams the upper triangle of the chain's D x D inverse metric (4 D^2 bytes; the "
-                                 "survey's 8 D^2 assumed the full matrix); achieved = bytes loaded by the matrix passes / their time"},
+                                 ("pooled dense metric (potus_opts.pooled_metric, a declared deviation from Stan): every leaf ROUND streams the handle's one full "
+                                  "symmetric D x D inverse metric (8 D^2 bytes) once for all chains and multiplies it with their right-hand sides on the fp64 matrix "
+                                  "cores; achieved = bytes loaded by the passes / their time; roofline.mfma is the same passes against the matrix peak"
+                                  if args.pooled_metric else
+                                  "dense metric: every leapfrog streams the upper triangle of the chain's D x D inverse metric (4 D^2 bytes; the "
+                                  "survey's 8 D^2 assumed the full matrix); achieved = bytes loaded by the matrix passes / their time")},
         }
         if dense:
             at = hs[0].dense_adapt_timing()
@@ -673,7 +701,8 @@ def main():
             line["dense"] = {
                 "window_ends": at["window_ends"], "window_end_seconds": (at["cov_ms"] + at["chol_ms"] + at["init_stepsize_ms"]) * 1e-3,
                 "covariance_seconds": at["cov_ms"] * 1e-3, "cholesky_seconds": at["chol_ms"] * 1e-3, "init_stepsize_seconds": at["init_stepsize_ms"] * 1e-3,
-                "cholesky_tflops": (work[0][3] * hs[0].D ** 3 / 3.0 * at["window_ends"]) / max(at["chol_ms"] * 1e-3, 1e-9) / 1e12,
+                "cholesky_tflops": ((1 if args.pooled_metric else work[0][3]) * hs[0].D ** 3 / 3.0 * at["window_ends"]) / max(at["chol_ms"] * 1e-3, 1e-9) / 1e12,
+                "matrices_factored_per_window_end": 1 if args.pooled_metric else work[0][3],
                 "adapted_phase": ({"steps": len(adapted), "leapfrogs": sum(p["leapfrogs"] for p in adapted), "seconds": sum(p["seconds"] for p in adapted),
                                    "leapfrogs_per_sec": sum(p["leapfrogs"] for p in adapted) / max(sum(p["seconds"] for p in adapted), 1e-9),
                                    "matrix_pass_TBps": sum(p["matrix_bytes"] for p in adapted) / max(sum(p["matrix_pass_ms"] for p in adapted), 1e-9) / 1e9,

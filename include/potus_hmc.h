@@ -90,7 +90,7 @@ typedef struct potus_data {
 /* Sampler options: the argument surface of cmdstanr's $sample() as used at
  * final_2016.R:533-541 plus the CmdStan 2.24 defaults it implies.
  * ALWAYS start from potus_default_opts(): fields are appended over time (metric_storage came with library version 0.4 in what used
- * to be tail padding), and a struct filled field by field by a caller built against an older header leaves them undefined;
+ * to be tail padding, pooled_metric with 0.5), and a struct filled field by field by a caller built against an older header leaves them undefined;
  * potus_version() names the version the header must match. */
 typedef struct potus_opts {
   int32_t chains;          /* chains run by THIS handle                                  */
@@ -132,6 +132,14 @@ typedef struct potus_opts {
                               leapfrog multiplies with it (fp64 accumulation), so the sampler stays exact while the matrix pass
                               of every leapfrog streams 2 D^2 bytes instead of 4 D^2.  A declared deviation from Stan, which
                               keeps the covariance in fp64; same memory per chain. */
+  int32_t pooled_metric;   /* dense metric only, 0 (Stan's: every chain adapts its own covariance) or 1: at every window end the draws of ALL
+                              chains of the handle form ONE regularised covariance -- covar_adaptation::learn_covariance applied to the
+                              pooled sample of chains x n draws -- and ONE Cholesky factor (library version 0.5).  A leaf round then streams
+                              one D x D matrix once for every chain (M^-1 times a D x (chains x right-hand sides) block on the fp64 matrix
+                              cores) instead of one triangle per chain, and the handle keeps two matrices instead of one per chain.  A
+                              declared deviation from Stan / CmdStan, whose chains are separate processes and cannot pool (SURVEY.md
+                              section 7.3-5, section 8 f4); the sampler stays exact for the metric it uses.  fp64 storage only. */
+  int32_t reserved_;       /* (keeps the struct a multiple of 8 bytes; set by potus_default_opts) */
 } potus_opts;
 #define POTUS_METRIC_DIAG 0
 #define POTUS_METRIC_DENSE 1
@@ -298,8 +306,8 @@ void potus_R_create(int *dims /*[8]: N_nat,N_state,T,S,P,M,Pop,variant*/,
                     sigma_noise_nat,sigma_noise_state,sigma_e_bias,random_walk_scale,
                     mu_b_T_scale,polling_bias_scale*/,
                     double *state_covariance_0,
-                    int *iopts /*[11]: chains,chain_id_offset,num_warmup,num_samples,max_depth,
-                    device,save_warmup,cus_per_chain,metric,twin,metric_storage*/,
+                    int *iopts /*[12]: chains,chain_id_offset,num_warmup,num_samples,max_depth,
+                    device,save_warmup,cus_per_chain,metric,twin,metric_storage,pooled_metric*/,
                     double *dopts /*[7]: delta,gamma,kappa,t0,stepsize,init_radius,seed (an integer < 2^53:
                     R's own integers have 32 bits)*/,
                     int *handle, int *status);

@@ -35,6 +35,14 @@ int potus_dense_matvec_probe(int device, int chains, int D, int nrhs, const doub
  * solve. */
 int potus_dense_factor_probe(int device, int chains, int D, int n, const double *draws_host, const double *u_host, double *Minv_host, double *L_host,
                              double *p_host, double *ms);
+/* The same two probes for the POOLED dense metric (potus_opts.pooled_metric, csrc/potus_dense_pool.hpp): ONE D x D matrix (full symmetric storage)
+ * for all chains -- Minv_host [D][D] (NULL: generated on the device) -- every right-hand side of every chain in one pass on the fp64 matrix cores
+ * (k_dn_pool_mm + k_dn_pool_finish), pass_bytes = the whole matrix; and the pooled window end: ONE regularised covariance of chains x n draws ->
+ * Minv_host [D][D], ONE factor L_host [D][D], p = L^-T u for every chain's u [chains][D]. */
+int potus_dense_pool_matvec_probe(int device, int chains, int D, int nrhs, const double *Minv_host, const double *x_host, double *y_host, double *dot_host, int reps,
+                                  double *ms, long long *pass_bytes);
+int potus_dense_pool_factor_probe(int device, int chains, int D, int n, const double *draws_host, const double *u_host, double *Minv_host, double *L_host,
+                                  double *p_host, double *ms);
 
 #ifdef __cplusplus
 }

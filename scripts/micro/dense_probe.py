@@ -4,6 +4,8 @@
   python scripts/micro/dense_probe.py sampler C N [cus]  2016 posterior, C chains, N warm-up iterations, dense metric
   python scripts/micro/dense_probe.py stress C N         the same on the configs[4] shape (D = 41 610)
   python scripts/micro/dense_probe.py active             matrix pass with 1..16 of 16 resident chains active, by tile split
+  python scripts/micro/dense_probe.py pooled [D]         the POOLED pass (potus_opts.pooled_metric: one full matrix, all right-hand sides on the matrix cores)
+                                                         for 1 .. 64 chains x 2 right-hand sides, by row split
 
 Matrices of `pieces` are generated on the device; a matrix pass loads the upper-triangle tiles, about 4 D^2 bytes per chain.
 """
@@ -34,6 +36,30 @@ def err():
 
 ACTIVE_CASES = ("1", "2", "3", "4", "6", "8", "12", "16")      # "n": the first n chains of the handle take part; "a,b,c": those chains
 SPLIT_CASES = (0, 1, 2, 3, 4, 6, 8)
+
+
+def pooled_sweep(D=41610):
+    """k_dn_pool_mm + k_dn_pool_finish on a generated matrix: ms per pass, TB/s of the 8 D^2 bytes it streams, TFLOP/s of its 2 D^2 R flops."""
+    L.potus_dense_pool_matvec_probe.argtypes = L.potus_dense_matvec_probe.argtypes
+    nrhs = 2
+    LD = (D + 7) // 8 * 8
+    for chains in (1, 4, 8, 16, 24, 32, 64):
+        x = np.random.default_rng(1).standard_normal((chains, nrhs, D))
+        y, ms, nb = np.zeros((chains, nrhs, D)), C.c_double(), C.c_longlong()
+        line = []
+        for s in (0, 1, 2, 3, 4, 6, 8):
+            if s:
+                os.environ["POTUS_POOL_SPLIT"] = str(s)
+            else:
+                os.environ.pop("POTUS_POOL_SPLIT", None)
+            rc = L.potus_dense_pool_matvec_probe(0, chains, D, nrhs, None, x.ctypes.data, y.ctypes.data, None, 5, C.byref(ms), C.byref(nb))
+            if rc:
+                line.append(f"{s}: error {err()}")
+                continue
+            tbs, tf = nb.value / 1e12 / (ms.value * 1e-3), 2.0 * D * D * chains * nrhs / 1e12 / (ms.value * 1e-3)
+            line.append(f"{'auto' if not s else s}: {ms.value:.3f} ms {tbs:.2f} TB/s {tf:.1f} TF")
+        print(f"pooled pass D={D} chains={chains:2d} x {nrhs} rhs ({nb.value / 1e9:.2f} GB per call) by row split  " + " | ".join(line), flush=True)
+    os.environ.pop("POTUS_POOL_SPLIT", None)
 
 
 def active_sweep():
@@ -122,6 +148,8 @@ if __name__ == "__main__":
         if len(sys.argv) > 3:
             SPLIT_CASES = tuple(int(v) for v in sys.argv[3].split(","))
         active_sweep()
+    elif what == "pooled":
+        pooled_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 41610)
     else:
         chains, iters = int(sys.argv[2]), int(sys.argv[3])
         cus = int(sys.argv[4]) if len(sys.argv) > 4 else 0

@@ -16,6 +16,10 @@ previous row.
   * the transitions named in replay_rows are the oracle's transitions from the device's previous draw, step size and metric:
     same tree depth, leapfrog count and divergence flag, values to 1e-6.
 
+With potus_opts.pooled_metric (a declared deviation from Stan: one dense metric for all chains of a handle) the estimate at a window end is
+covar_adaptation's formula applied to the window draws of ALL chains of the handle, chain after chain -- N = chains x n draws, N/(N+5) cov +
+1e-3 5/(N+5) I; everything else is per chain as before.
+
 Covers warm-ups whose rows are all saved (save_warmup = 1).  Reference schedule: scripts/model/final_2016.R:6-11,533-541 runs 500
 warm-up iterations = 75 | 25, 50, 100, 200 | 50."""
 import numpy as np
@@ -67,7 +71,9 @@ def adaptation_replayed_from_the_device_rows(data, variant, h, chain, seed, repl
     o_ = h.opts
     nw = o_.num_warmup
     dense = o_.metric == _abi.METRIC_DENSE
-    d = h.draws()[chain]
+    d_all = h.draws()
+    d = d_all[chain]
+    pooled = bool(getattr(o_, "pooled_metric", 0))                   # potus_opts.pooled_metric: ONE estimate from the window draws of ALL chains of the handle
     eps_final, minv_final = h.adaptation()
     eps_final = eps_final[chain]
     minv_final = h.dense_metric(chain) if dense else np.asarray(minv_final[chain])
@@ -108,7 +114,7 @@ def adaptation_replayed_from_the_device_rows(data, variant, h, chain, seed, repl
         next_eps = np.exp(x)
         if it in ends:
             start, idx = ends[it]
-            want = estimate(d[start:it + 1, 7:])
+            want = estimate(np.concatenate([dc[start:it + 1, 7:] for dc in d_all]) if pooled else d[start:it + 1, 7:])
             scale = np.abs(want).max()
             if held is not None and it in held:                      # what the device held right after this update
                 got = np.asarray(held[it][1][chain])

@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     # potus_data: 7 int32 + pad, 13 + 4 pointers, 6 doubles, pointer, 3 doubles, int32 (+pad)
     assert C.sizeof(_abi.PotusData) == 32 + 17 * 8 + 6 * 8 + 8 + 3 * 8 + 8
-    assert C.sizeof(_abi.PotusOpts) == 8 * 4 + 6 * 8 + 8 + 6 * 4             # ... device, save_warmup, cus_per_chain, metric, twin, metric_storage
+    assert C.sizeof(_abi.PotusOpts) == 8 * 4 + 6 * 8 + 8 + 8 * 4             # ... device, save_warmup, cus_per_chain, metric, twin, metric_storage, pooled_metric, reserved_
 
 
 @pytest.mark.parametrize("name,D,ncols", [("2016", 15098, 43360), ("small_full", 292, 753), ("small_nomode", 260, 690)])

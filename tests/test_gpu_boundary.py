@@ -53,7 +53,7 @@ class RShim:
             raise RuntimeError(f"libpotus_hmc error {status.value}: {buf.value.decode().strip()}")
 
     def sample(self, data, variant, seed, chains, iter_warmup, iter_sampling, refresh, gpus=(0,), cus_per_chain=0, metric="diag_e", twin=-1,
-               metric_storage="f64", chain_id_offset=0, save_warmup=False, adapt_delta=0.8, max_treedepth=10, init=2.0):
+               metric_storage="f64", chain_id_offset=0, save_warmup=False, adapt_delta=0.8, max_treedepth=10, init=2.0, pooled_metric=False):
         full = variant == "full"
         Ns, Nn = int(data["N_state_polls"]), int(data["N_national_polls"])
         iv = lambda k, n: _ints(data[k] if data.get(k) is not None else np.zeros(max(n, 1)))
@@ -75,7 +75,7 @@ class RShim:
                     dv("unadjusted_national", Nn), dv("unadjusted_state", Ns), _dbls(data["mu_b_prior"]), _dbls(data["state_weights"]),
                     scalars, cov,
                     _ints([per[g], chain_id_offset + first[g], iter_warmup, iter_sampling, max_treedepth, dev, int(save_warmup), cus_per_chain,
-                           1 if metric == "dense_e" else 0, twin, 1 if metric_storage == "f32" else 0]),
+                           1 if metric == "dense_e" else 0, twin, 1 if metric_storage == "f32" else 0, 1 if pooled_metric else 0]),
                     _dbls([adapt_delta, 0.05, 0.75, 10, 1, init, seed])]
             h, st = C.c_int(-1), C.c_int(-1)
             self.call("potus_R_create", *[a[1] for a in args], C.byref(h), C.byref(st))

@@ -17,6 +17,8 @@ def _lib():
     L = sampler.load_library()
     L.potus_dense_matvec_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, DP, C.POINTER(C.c_longlong)]
     L.potus_dense_factor_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, DP]
+    L.potus_dense_pool_matvec_probe.argtypes = L.potus_dense_matvec_probe.argtypes
+    L.potus_dense_pool_factor_probe.argtypes = L.potus_dense_factor_probe.argtypes
     return L
 
 
@@ -322,3 +324,152 @@ def test_dense_fp32_storage_samples_the_same_posterior(cases):
         worst = max(worst, abs(a.mean() - b.mean()) / se)
     assert worst < 5.0, worst
     assert abs(runs[_abi.STORAGE_F64][:, :, 1].mean() - runs[_abi.STORAGE_F32][:, :, 1].mean()) < 0.05
+
+
+# ---------------------------------------------------------------- potus_opts.pooled_metric (csrc/potus_dense_pool.hpp; round 6)
+@pytest.mark.parametrize("chains,D,nrhs", [(3, 1000, 1), (2, 2049, 2), (16, 700, 2), (17, 333, 3), (1, 71, 2), (5, 257, 3), (2, 16500, 3), (4, 4097, 2)])
+def test_pooled_product_against_numpy(chains, D, nrhs, monkeypatch):
+    """Y = M^-1 X for ONE full symmetric matrix and the right-hand sides of every chain in one pass on the fp64 matrix cores (k_dn_pool_mm +
+    k_dn_pool_finish): one to three operand tiles of sixteen right-hand sides, more than 48 of them (several launches), column panels and row
+    splits with ragged ends, odd D (padded rows), D below one panel; the fused x_0 . M^-1 x_0 per chain; reproducible bit for bit; and a chain's
+    numbers do not depend on which other chains take part in the launch."""
+    L = _lib()
+    rng = np.random.default_rng(4)
+    B = rng.standard_normal((D, 8))
+    M = B @ B.T / 8 + np.eye(D)
+    x = rng.standard_normal((chains, nrhs, D))
+    out = []
+    for _ in range(2):
+        y, dot, ms, nb = np.zeros((chains, nrhs, D)), np.zeros(chains), C.c_double(), C.c_longlong()
+        assert L.potus_dense_pool_matvec_probe(0, chains, D, nrhs, M.ctypes.data, x.ctypes.data, y.ctypes.data, dot.ctypes.data, 2, C.byref(ms), C.byref(nb)) == 0
+        assert nb.value == 8 * D * ((D + 7) // 8 * 8) * -(-chains * nrhs // 48)        # the whole matrix once per launch of up to 48 right-hand sides
+        out.append((y, dot))
+    ref = np.einsum("ij,crj->cri", M, x)
+    assert np.abs(out[0][0] - ref).max() <= 1e-12 * np.abs(ref).max() * np.sqrt(D)
+    assert np.allclose(out[0][1], np.einsum("ci,ci->c", x[:, 0], ref[:, 0]), rtol=1e-11)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    if chains >= 3:                                                          # idle companions (compacted list of active chains): same bytes for those that run
+        monkeypatch.setenv("POTUS_PROBE_ACTIVE", f"0,{chains - 1}")
+        y2, dot2, ms, nb = np.zeros((chains, nrhs, D)), np.zeros(chains), C.c_double(), C.c_longlong()
+        assert L.potus_dense_pool_matvec_probe(0, chains, D, nrhs, M.ctypes.data, x.ctypes.data, y2.ctypes.data, dot2.ctypes.data, 1, C.byref(ms), C.byref(nb)) == 0
+        for c in (0, chains - 1):
+            assert np.array_equal(y2[c], out[0][0][c]) and dot2[c] == out[0][1][c]
+
+
+@pytest.mark.parametrize("chains,D,n", [(4, 300, 10), (2, 1000, 25), (3, 2051, 40)])
+def test_pooled_window_end_against_numpy(chains, D, n):
+    """The pooled window end on caller data: ONE M^-1 = N/(N+5) cov + 1e-3 5/(N+5) I over the N = chains x n draws of all chains
+    (covar_adaptation::learn_covariance applied to the pooled sample), stored as the full symmetric matrix; ONE blocked Cholesky factor in
+    its own buffer; every chain's momentum draw p = L^-T u out of that one factor."""
+    import scipy.linalg as sl
+    L = _lib()
+    rng = np.random.default_rng(11)
+    draws = rng.standard_normal((chains, n, D)) * rng.uniform(0.2, 3.0, (1, 1, D)) + rng.standard_normal((chains, 1, D))
+    u = rng.standard_normal((chains, D))
+    Mi, Lc, p, ms = np.zeros((D, D)), np.zeros((D, D)), np.zeros((chains, D)), (C.c_double * 3)()
+    assert L.potus_dense_pool_factor_probe(0, chains, D, n, draws.ctypes.data, u.ctypes.data, Mi.ctypes.data, Lc.ctypes.data, p.ctypes.data, ms) == 0
+    N = chains * n
+    ref = (N / (N + 5.0)) * np.cov(draws.reshape(N, D).T) + 1e-3 * (5.0 / (N + 5.0)) * np.eye(D)
+    assert np.allclose(Mi, ref, rtol=1e-10, atol=1e-12 * np.abs(ref).max()) and np.array_equal(Mi, Mi.T)
+    Lg = np.tril(Lc)
+    assert np.allclose(Lg @ Lg.T, Mi, rtol=1e-10, atol=1e-12 * np.abs(ref).max())
+    for c in range(chains):
+        pref = sl.solve_triangular(Lg.T, u[c], lower=False)
+        assert np.allclose(p[c], pref, rtol=1e-8, atol=1e-9 * np.abs(pref).max())
+
+
+@pytest.mark.parametrize("cus", [1, 8])
+def test_pooled_sampler_replayed_through_every_window_end(cases, cus):
+    """potus_opts.pooled_metric on the small model, 3 chains, 200 warm-up iterations = 75 | 25, 50 (doubled) | 50: up to the first window end
+    the chains are the per-chain sampler's (unit metric: same bytes as pooled_metric = 0); after EVERY window end all chains hold the SAME
+    matrix = the regularised covariance of the window draws of all three (tests/adaptation_replay.py, pooled estimate), every chain's step
+    size is init_stepsize's under that matrix, and two transitions on either side of every window end are the oracle's from the device's
+    own state, that matrix and its factor.  The matrix pass streams ONE matrix per round."""
+    from adaptation_replay import adaptation_replayed_from_the_device_rows, rows_around, run_through_the_windows, window_schedule
+    data, variant = cases["small_full"]
+    nw, windows = 200, [(75, 99), (100, 149)]
+    assert window_schedule(nw, 75, 50, 25) == windows
+    kw = dict(chains=3, num_warmup=nw, num_samples=2, save_warmup=1, seed=1843, metric=_abi.METRIC_DENSE, cus_per_chain=cus)
+    h = Handle(data, variant, pooled_metric=1, **kw)
+    h.init()
+    held = run_through_the_windows(h, nw + 2)
+    assert sorted(held) == [e for _, e in windows]
+    for e in held:
+        for c in (1, 2):
+            assert np.array_equal(held[e][1][c], held[e][1][0])                 # one matrix for everybody
+    for c in range(3):
+        assert adaptation_replayed_from_the_device_rows(data, variant, h, c, 1843, [(1, 2)] + rows_around([e for _, e in windows], 2) + [(nw, 2)], held) == len(windows)
+    d = h.draws()
+    ms, passes, nbytes, rounds = h.dense_timing()
+    assert passes > 0 and nbytes == passes * 8 * h.D * ((h.D + 7) // 8 * 8)      # bytes = passes x ONE full matrix, whatever the number of chains
+    res, solve = h.dense_check(2, 2)
+    assert res < 1e-12 and solve < 1e-9, (res, solve)                            # L L' x = M^-1 x by the pooled pass; L' p = u
+    h.close()
+    g = Handle(data, variant, pooled_metric=0, **kw)
+    g.init(); g.run(75 + 25)
+    assert np.array_equal(g.draws()[:, :100], d[:, :100])                       # rows 0 .. 99: before anybody's first metric update
+    g.close()
+
+
+def test_pooled_sampler_is_reproducible_and_chunk_invariant(cases):
+    data, variant = cases["small_nomode"]
+    kw = dict(chains=3, num_warmup=40, num_samples=10, seed=7, metric=_abi.METRIC_DENSE, pooled_metric=1)
+    a = Handle(data, variant, **kw); a.init(); a.run(50); da = a.draws(); a.close()
+    b = Handle(data, variant, **kw); b.init(); b.run(33); b.run(3); b.run(14); db = b.draws(); b.close()
+    assert np.array_equal(da, db) and np.isfinite(da).all()
+    a = Handle(data, variant, **kw); a.init(); a.run(20); a.init(); a.run(50); dc = a.draws(); a.close()   # a second potus_init: back to the unit metric
+    assert np.array_equal(da, dc)
+
+
+def test_pooled_posterior_parity_small(cases):
+    """Statistical parity of the pooled-metric sampler with the oracle's (per-chain) dense_e sampler: pooled means of every unconstrained
+    coordinate within 5 combined MCSE; accept rate around delta."""
+    from us_potus_model_amd import synthetic
+    variant = "full"
+    data = synthetic.make(S=4, T=12, N_state=30, N_national=8, P=3, seed=3, variant=variant)
+    nw = ns = 400
+    h = Handle(data, variant, chains=4, num_warmup=nw, num_samples=ns, seed=1843, metric=_abi.METRIC_DENSE, pooled_metric=1)
+    h.init(); h.run(nw + ns)
+    d = h.draws()
+    x = d[:, :, 7:]
+    st, _ = h.chain_status()
+    assert st == [0, 0, 0, 0] and d[:, :, 5].mean() < 0.02 and 0.6 < d[:, :, 1].mean() < 0.97
+    m = OracleModel(data, variant)
+    o = m.default_opts(num_warmup=nw, num_samples=ns, seed=4242, fast_grad=1, dense_metric=1)
+    y = np.stack([m.sample_chain(c, o)[0][:, 7:] for c in (1, 2, 3, 4)])
+    worst = 0.0
+    for j in range(h.D):
+        a, b = x[:, :, j], y[:, :, j]
+        se = np.hypot(a.std() / np.sqrt(dg.ess_mean(a)), b.std() / np.sqrt(dg.ess_mean(b)))
+        worst = max(worst, abs(a.mean() - b.mean()) / se)
+        assert dg.rhat(a) < 1.08
+    assert worst < 5.0, worst
+    h.close()
+
+
+def test_pooled_transitions_after_the_window_match_the_oracle_at_2016_size(cases):
+    """D = 15 098 with ONE 1.8 GB inverse metric for 4 chains (30 warm-up iterations: one window of 4 x 23 pooled draws, update after iteration 26;
+    236-block Cholesky in the factor's own buffer).  The matrix every chain reports is the pooled estimate; the three transitions that follow are the
+    oracle's from the device's own state under that matrix and its factor -- momenta from the one factor, p# = M^-1 p out of the pooled pass
+    (k_dn_pool_mm): same tree depth, leapfrog count and divergence flag, values to 1e-6, for the first and the last chain.  (A posterior-level
+    comparison at this size would say nothing: a dense metric adapted on a few hundred draws in 15 098 dimensions leaves every tree at its depth
+    limit -- DESIGN 4c; the small-model test above carries the statistical parity.)"""
+    data, variant = cases["2016"]
+    nw, md, chains = 30, 6, 4
+    h = Handle(data, variant, chains=chains, num_warmup=nw, num_samples=0, save_warmup=1, seed=1843, metric=_abi.METRIC_DENSE, max_depth=md, pooled_metric=1)
+    h.init(); h.run(nw)
+    d = h.draws()
+    assert np.isfinite(d).all()
+    w = np.concatenate([d[c][4:27, 7:] for c in range(chains)])
+    N = len(w)
+    want = (N / (N + 5.0)) * np.cov(w.T) + 1e-3 * (5.0 / (N + 5.0)) * np.eye(h.D)
+    Mi = h.dense_metric(chains - 1)
+    assert np.allclose(Mi, want, rtol=1e-9, atol=1e-12 * np.abs(want).max()) and np.array_equal(Mi, Mi.T)
+    assert np.array_equal(h.dense_metric(0), Mi)
+    res, solve = h.dense_check(chains - 1, 2)
+    assert res < 1e-12 and solve < 1e-9, (res, solve)
+    for c in (0, chains - 1):
+        _post_window_rows_against_the_oracle(data, variant, h, d, c, 27, 3, md, Mi, c + 1)
+    ms, passes, nbytes, rounds = h.dense_timing()
+    print(f"2016, pooled dense metric, {chains} chains: {passes} matrix passes of {nbytes / max(passes, 1) / 1e9:.2f} GB in {ms:.0f} ms = {nbytes / ms / 1e9:.2f} TB/s; {rounds} leaf rounds")
+    h.close()

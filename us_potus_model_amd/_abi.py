@@ -52,6 +52,7 @@ class PotusOpts(C.Structure):
         ("stepsize", C.c_double), ("init_radius", C.c_double),
         ("seed", C.c_uint64), ("device", C.c_int32), ("save_warmup", C.c_int32),
         ("cus_per_chain", C.c_int32), ("metric", C.c_int32), ("twin", C.c_int32), ("metric_storage", C.c_int32),
+        ("pooled_metric", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

@@ -105,7 +105,17 @@ struct DnParams {
   int f32, pad1;                     // potus_opts.metric_storage = f32: M^-1 is kept rounded to fp32 (see dn_f32_row)
   unsigned long long *act_passes;    // [1] (chain, matrix pass) pairs that really ran: the bytes the passes streamed, whatever the host believed
   int count_passes;                  // this launch belongs to the timed set (transitions); init_stepsize / verification passes are neither timed nor counted
+  // potus_opts.pooled_metric (potus_dense_pool.hpp): ONE inverse metric for all chains of the handle -- A is then a single FULL symmetric D x LD matrix,
+  // dg one vector, the Cholesky factor lives in a buffer of its own
+  int pooled;
+  double *Lf;                        // [D][LD] pooled: the factor (lower triangle incl. diagonal)
+  double *ypool;                     // [pool_split][DNP_RMAX][LD] pooled: the product's partial sums per row split
+  int pool_split, pool_rows;         // row splits of the pooled product (fixed per handle: the order of summation must not depend on who is active), rows per split
 };
+// where a chain's matrix, factor and diagonal live (pooled: everybody's are the handle's one)
+__device__ __host__ __forceinline__ double *dn_mat(const DnParams &P, int chain) { return P.pooled ? P.A : P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD; }
+__device__ __host__ __forceinline__ double *dn_fac(const DnParams &P, int chain) { return P.pooled ? P.Lf : P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD; }
+__device__ __host__ __forceinline__ double *dn_diag(const DnParams &P, int chain) { return P.pooled ? P.dg : P.dg + (size_t)chain * (size_t)P.LD; }
 
 // fp32 storage of M^-1 (potus_opts.metric_storage): the matrix pass streams half the bytes.  The rounded matrix IS the metric:
 // the lower triangle of the chain's buffer starts from the rounded values (as doubles) and becomes their Cholesky factor in
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(DN_THREADS) void k_dn_symv(const DnParams P, const 
   double *xr = xs + NRHS * DN_CT;                        // [NRHS][RB]  x over the block's rows
   double *sacc = xr + NRHS * DN_RB_MAX;                  // [NRHS][RB]  row sums of the block, accumulated over the tiles
   double *tacc = sacc + NRHS * DN_RB_MAX;                // [8 waves][NRHS][DN_CT]
-  const double *A = P.A + (size_t)chain * (size_t)D * (size_t)LD;
+  const double *A = dn_mat(P, chain);
   const double *x[NRHS];
 #pragma unroll
   for (int r = 0; r < NRHS; r++) x[r] = dn_vec(P, chain, rd.job[job0 + r].x);
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(DN_FIN) void k_dn_symv_finish(const DnParams P, con
   const int LD = P.LD;
   const double *tp = P.tpart + ((size_t)chain * P.nblk * 3 + job0) * (size_t)LD;
   const double *sr = P.srow + ((size_t)chain * 3 + job0) * (size_t)P.ntile * (size_t)LD;
-  const double *dg = P.dg + (size_t)chain * LD;
+  const double *dg = dn_diag(P, chain);
   if (i < P.D) {
     const int nb = i / P.rb + 1, t_first = ((i / P.rb) * P.rb) / DN_CT;
 #pragma unroll
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(64) void k_dn_trsv_diag(const DnParams P, int b) {
   const int chain = blockIdx.x;
   if (!P.rd[chain].active) return;
   const int lane = threadIdx.x, r0 = b * DN_NB, nb = min(DN_NB, P.D - r0);
-  const double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  const double *L = dn_fac(P, chain);
   for (int i = 0; i < nb; i++) Lb[i][lane] = lane <= i ? L[(size_t)(r0 + i) * P.LD + r0 + lane] : 0.0;
   __syncthreads();
   double *p = dn_vec(P, chain, DV_P0);
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(256) void k_dn_trsv_update(const DnParams P, int b)
   const int chain = blockIdx.y;
   if (!P.rd[chain].active) return;
   const int r0 = b * DN_NB, nb = min(DN_NB, P.D - r0);
-  const double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  const double *L = dn_fac(P, chain);
   double *p = dn_vec(P, chain, DV_P0);
   if (threadIdx.x < DN_NB) pb[threadIdx.x] = (int)threadIdx.x < nb ? p[r0 + threadIdx.x] : 0.0;
   __syncthreads();
@@ -835,7 +845,7 @@ __global__ __launch_bounds__(256) void k_dn_cov(const DnParams P, int n) {
 __global__ __launch_bounds__(256) void k_dn_potrf(const DnParams P, int kb) {
   __shared__ double a[DN_NB][DN_NB + 1];
   const int chain = blockIdx.x, tid = threadIdx.x, r0 = kb * DN_NB, nb = min(DN_NB, P.D - r0);
-  double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  double *L = dn_fac(P, chain);
   for (int e = tid; e < DN_NB * DN_NB; e += 256) { const int i = e >> 6, j = e & 63; a[i][j] = (i < nb && j <= i) ? L[(size_t)(r0 + i) * P.LD + r0 + j] : 0.0; }
   __syncthreads();
   for (int j = 0; j < nb; j++) {
@@ -861,7 +871,7 @@ __global__ __launch_bounds__(256) void k_dn_trsm(const DnParams P, int kb) {
   const int chain = blockIdx.y, tid = threadIdx.x, c0 = kb * DN_NB, nb = min(DN_NB, P.D - c0);
   const int r0 = (kb + 1) * DN_NB + blockIdx.x * DN_NB;
   if (r0 >= P.D) return;
-  double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  double *L = dn_fac(P, chain);
   for (int e = tid; e < DN_NB * DN_NB; e += 256) {
     const int i = e >> 6, j = e & 63;
     lk[i][j] = (i < nb && j <= i) ? L[(size_t)(c0 + i) * P.LD + c0 + j] : 0.0;
@@ -887,7 +897,7 @@ __global__ __launch_bounds__(256) void k_dn_syrk(const DnParams P, int kb, int j
   const int I = kb + 1 + blockIdx.x, J = kb + 1 + blockIdx.y, chain = blockIdx.z;
   if (J > I || J > jmax) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 15, kk = lane >> 4, c0 = kb * DN_NB;
-  double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  double *L = dn_fac(P, chain);
   for (int e = tid; e < DN_NB * DN_NB; e += 256) {
     const int i = e >> 6, t = e & 63;
     a[i][t] = I * DN_NB + i < P.D ? L[(size_t)(I * DN_NB + i) * P.LD + c0 + t] : 0.0;
@@ -916,7 +926,7 @@ __global__ __launch_bounds__(256) void k_dn_syrk(const DnParams P, int kb, int j
 // y = L' x and z = L y out of the lower triangle, written for clarity, not speed: with M^-1 x from the sampler's own matrix pass
 // they tell whether L L' is the metric the leapfrog uses, at sizes no host can factor in a test's time.
 __global__ __launch_bounds__(256) void k_dn_chk_ltx(const DnParams P, int chain, int xslot, int yslot) {
-  const double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD, *x = dn_vec(P, chain, xslot);
+  const double *L = dn_fac(P, chain), *x = dn_vec(P, chain, xslot);
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= P.D) return;
   double s = 0.0;
@@ -925,7 +935,7 @@ __global__ __launch_bounds__(256) void k_dn_chk_ltx(const DnParams P, int chain,
 }
 __global__ __launch_bounds__(256) void k_dn_chk_lx(const DnParams P, int chain, int yslot, int zslot) {
   __shared__ double red[256];
-  const double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD, *y = dn_vec(P, chain, yslot);
+  const double *L = dn_fac(P, chain), *y = dn_vec(P, chain, yslot);
   const int i = blockIdx.x;
   double s = 0.0;
   for (int j = threadIdx.x; j <= i; j += 256) s += L[(size_t)i * P.LD + j] * y[j];
@@ -951,7 +961,7 @@ __global__ __launch_bounds__(256, 2) void k_dn_syrk_wide(const DnParams P, int p
   if (J0 > I0 || I0 >= P.D) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, n = lane & 15, wr = w >> 1, wc = w & 1;
   const int c0 = pb * DN_NB, K = min(nk * DN_NB, P.D - c0);
-  double *L = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD;
+  double *L = dn_fac(P, chain);
   dn_d4 acc[4][4];
 #pragma unroll
   for (int ti = 0; ti < 4; ti++)
@@ -1001,8 +1011,8 @@ __global__ __launch_bounds__(256, 2) void k_dn_syrk_wide(const DnParams P, int p
 // unit metric: M^-1 = L = I (the matrix buffer is zero apart from the diagonal)
 __global__ void k_dn_identity(const DnParams P) {
   const int chain = blockIdx.y;
-  double *A = P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD, *dg = P.dg + (size_t)chain * P.LD;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.D; i += gridDim.x * blockDim.x) { A[(size_t)i * P.LD + i] = 1.0; dg[i] = 1.0; }
+  double *A = dn_mat(P, chain), *dg = dn_diag(P, chain), *Lf = dn_fac(P, chain);   // (pooled: launched for one "chain")
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.D; i += gridDim.x * blockDim.x) { A[(size_t)i * P.LD + i] = 1.0; Lf[(size_t)i * P.LD + i] = 1.0; dg[i] = 1.0; }
 }
 // fills the upper triangle and the diagonal vector with a symmetric positive definite test matrix on the device (rates
 // at sizes that would take seconds to upload): a_ij = exp(-|i-j|/50) * (1 + 0.1 c) + (i == j ? 1 : 0)
@@ -1020,3 +1030,5 @@ __global__ void k_dn_fill(const DnParams P) {
       if (j == i) { P.A[(size_t)c * P.D * P.LD + (size_t)i * P.LD + j] = 1.0; P.dg[(size_t)c * P.LD + i] = v; }
     }
 }
+
+#include "potus_dense_pool.hpp"

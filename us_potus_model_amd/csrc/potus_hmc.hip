@@ -1040,6 +1040,7 @@ struct Sampler {
   hipEvent_t mv0 = nullptr, mv1 = nullptr;
   static constexpr int DN_AHEAD = 4;       // leaf rounds the host keeps queued beyond the one whose activity flags it has seen
   hipEvent_t rv0[DN_AHEAD] = {}, rv1[DN_AHEAD] = {}, rdone[DN_AHEAD] = {};   // per queued round: around its matrix pass, after its flag copy
+  int rv_launches[DN_AHEAD] = {1, 1, 1, 1};   // ... and the launches of that pass (pooled metric: one per DNP_RMAX right-hand sides)
   double mv_ms = 0;                        // time spent in the matrix passes (k_dn_symv + finish, events), their number and the bytes they loaded
   int mv_launches_pending = 0;             // matrix passes between the event pair of the last timed dense_matvec (the first pass of a transition: two)
   long long mv_calls = 0, mv_bytes = 0, dn_rounds = 0, dn_pass_bytes[2] = {0, 0};   // bytes per pass at DN_RB rows per workgroup / at the handle's DnParams::rb
@@ -1694,14 +1695,27 @@ int dense_alloc(Sampler *sp) {
   P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_FIN / 4 - 1) / (DN_FIN / 4); P.nblk = (D + DN_RB - 1) / DN_RB; P.sc_stride = sp->K; P.identity = 1;
   P.win_cap = dense_window_capacity(sp->R.num_warmup, sp->R.init_buffer, sp->R.term_buffer, sp->R.window);
   P.f32 = sp->opts.metric_storage == POTUS_STORAGE_F32 ? 1 : 0;
+  P.pooled = sp->opts.pooled_metric ? 1 : 0;
   dense_launch_shape(P, chains);
-  const size_t mat = (size_t)chains * D * P.LD * 8, vec = (size_t)chains * DV_COUNT * P.LD * 8, win = (size_t)chains * P.win_cap * P.LD * 8;
+  // pooled metric: ONE full symmetric matrix + ONE factor for the handle, and the partial products of the row splits.  The number of splits is a
+  // function of D alone (the order in which a product is summed must not depend on who else is active): the largest one (up to DNP_SPLIT_MAX) that keeps the launch
+  // within two workgroups of 256 columns per compute unit -- all resident at once, no tail --, in whole batches of DNP_KB rows.
+  P.pool_split = 1; P.pool_rows = D;
+  if (P.pooled) {
+    const int panels = (D + DNP_COLS - 1) / DNP_COLS;
+    int s = std::max(1, std::min(DNP_SPLIT_MAX, (2 * 256) / panels));   // at most two workgroups per compute unit, all resident at once (measured: profiles/r06_dense_pooled.txt)
+    if (const char *e = getenv("POTUS_POOL_SPLIT")) s = std::max(1, std::min(DNP_SPLIT_MAX, atoi(e)));   // development: sweeps
+    P.pool_rows = (((D + s - 1) / s + DNP_KB - 1) / DNP_KB) * DNP_KB;
+    P.pool_split = (D + P.pool_rows - 1) / P.pool_rows;
+  }
+  const int mchains = P.pooled ? 1 : chains;
+  const size_t mat = (size_t)mchains * D * P.LD * 8 * (P.pooled ? 2 : 1) + (P.pooled ? (size_t)P.pool_split * DNP_RMAX * P.LD * 8 : 0), vec = (size_t)chains * DV_COUNT * P.LD * 8, win = (size_t)chains * P.win_cap * P.LD * 8;
   const size_t tp = (size_t)chains * (P.nblk + P.ntile) * 3 * P.LD * 8;   // column sums per row block + row sums per column tile
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   if (mat + vec + win + tp + (64u << 20) > free_b)
     return fail(POTUS_ERR_UNSUPPORTED, "dense metric: %d chains x (D^2 + %d window draws + %d vectors + %d partial vectors) x 8 bytes = %.1f GB, %.1f GB free on GPU %d "
-                                       "(D = %d: %.2f GB per matrix)", chains, P.win_cap, DV_COUNT, 3 * P.nblk, (mat + vec + win + tp) / 1e9, free_b / 1e9, sp->device, D, (double)D * P.LD * 8 / 1e9);
+                                       "(D = %d: %.2f GB per matrix; potus_opts.pooled_metric keeps one matrix and one factor for all chains of the handle)", chains, P.win_cap, DV_COUNT, 3 * P.nblk, (mat + vec + win + tp) / 1e9, free_b / 1e9, sp->device, D, (double)D * P.LD * 8 / 1e9);
   auto get = [&](void **q, size_t bytes) {
     if (hipMalloc(q, std::max<size_t>(bytes, 8)) != hipSuccess) return fail(POTUS_ERR_DEVICE, "hipMalloc(%zu) for the dense metric failed", bytes);
     sp->allocs.push_back(*q);
@@ -1709,7 +1723,8 @@ int dense_alloc(Sampler *sp) {
     return hipMemsetAsync(*q, 0, std::max<size_t>(bytes, 8), sp->stream) == hipSuccess ? 0 : fail(POTUS_ERR_DEVICE, "hipMemset failed");
   };
   int rc;
-  if ((rc = get((void **)&P.state, vec)) || (rc = get((void **)&P.A, mat)) || (rc = get((void **)&P.dg, (size_t)chains * P.LD * 8)) || (rc = get((void **)&P.win, win)) ||
+  if ((rc = get((void **)&P.state, vec)) || (rc = get((void **)&P.A, (size_t)mchains * D * P.LD * 8)) || (rc = get((void **)&P.dg, (size_t)mchains * P.LD * 8)) || (rc = get((void **)&P.win, win)) ||
+      (P.pooled && ((rc = get((void **)&P.Lf, (size_t)D * P.LD * 8)) || (rc = get((void **)&P.ypool, (size_t)P.pool_split * DNP_RMAX * P.LD * 8)))) ||
       (rc = get((void **)&P.tpart, (size_t)chains * P.nblk * 3 * P.LD * 8)) || (rc = get((void **)&P.srow, (size_t)chains * 3 * P.ntile * P.LD * 8)) ||
       (rc = get((void **)&P.partial, (size_t)chains * P.npart * 8)) || (rc = get((void **)&P.lpbuf, (size_t)chains * 8)) ||
       (rc = get((void **)&P.ts, (size_t)chains * sizeof(TS))) || (rc = get((void **)&P.rd, (size_t)chains * sizeof(DnRound))) ||
@@ -1725,17 +1740,38 @@ int dense_alloc(Sampler *sp) {
   if (sp->K == 1) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_grad1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
   else for (const void *f : {reinterpret_cast<const void *>(k_dn_gradK<4>), reinterpret_cast<const void *>(k_dn_gradK<8>), reinterpret_cast<const void *>(k_dn_gradK<12>), reinterpret_cast<const void *>(k_dn_gradK<16>), reinterpret_cast<const void *>(k_dn_gradK<17>)})
     HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
-  hipLaunchKernelGGL(k_dn_identity, dim3((D + 255) / 256, chains), dim3(256), 0, sp->stream, P);
+  for (const void *f : {reinterpret_cast<const void *>(k_dn_pool_mm<1>), reinterpret_cast<const void *>(k_dn_pool_mm<2>), reinterpret_cast<const void *>(k_dn_pool_mm<3>)})
+    HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DNP_LDS(3)));
+  hipLaunchKernelGGL(k_dn_identity, dim3((D + 255) / 256, mchains), dim3(256), 0, sp->stream, P);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(sp->stream));
   sp->dn_win_counter = 0; sp->dn_win_size = sp->R.window; sp->dn_win_next = sp->R.init_buffer + sp->R.window - 1; sp->dn_wf_n = 0;
   sp->dn_pass_bytes[0] = dense_pass_bytes(D, P.LD, DN_RB) / (P.f32 ? 2 : 1); sp->dn_pass_bytes[1] = dense_pass_bytes(D, P.LD, P.rb) / (P.f32 ? 2 : 1);   // ([1]: at the handle's own block size)
+  if (P.pooled) sp->dn_pass_bytes[0] = sp->dn_pass_bytes[1] = (long long)D * P.LD * 8;   // the whole symmetric matrix, once per pass whatever the number of chains
   return 0;
 }
 
 // M^-1 times the round's right-hand sides for the active chains: one pass over the upper triangles (two launches when
 // there are three right-hand sides) and the finishing kernel
 void dense_symv_launch(hipStream_t st, const DnParams &P, const DnActive &act, int nrhs) {
+  if (P.pooled) {
+    // one pass over the handle's ONE matrix for every right-hand side of every chain that takes part (potus_dense_pool.hpp); more than
+    // DNP_RMAX of them (over sixteen chains with three each) go in several launches, whole chains at a time
+    const int nact = act.n ? act.n : P.chains, per = DNP_RMAX / nrhs;
+    for (int c0 = 0; c0 < nact; c0 += per) {
+      DnPoolRhs R;
+      const int nc = std::min(per, nact - c0);
+      R.n = nc * nrhs; R.nrhs = nrhs; R.job0 = 0;
+      for (int r = 0; r < DNP_RMAX; r++) R.chain[r] = (unsigned char)(r < R.n ? (act.n ? act.idx[c0 + r / nrhs] : c0 + r / nrhs) : 0);
+      const dim3 grid((unsigned)((P.D + DNP_COLS - 1) / DNP_COLS), (unsigned)P.pool_split);
+      const int nt = (R.n + 15) / 16;
+      if (nt == 1) hipLaunchKernelGGL(k_dn_pool_mm<1>, grid, dim3(DNP_THREADS), DNP_LDS(1), st, P, R, P.pool_rows);
+      else if (nt == 2) hipLaunchKernelGGL(k_dn_pool_mm<2>, grid, dim3(DNP_THREADS), DNP_LDS(2), st, P, R, P.pool_rows);
+      else hipLaunchKernelGGL(k_dn_pool_mm<3>, grid, dim3(DNP_THREADS), DNP_LDS(3), st, P, R, P.pool_rows);
+      hipLaunchKernelGGL(k_dn_pool_finish, dim3((unsigned)P.npart, (unsigned)R.n), dim3(64), 0, st, P, R, P.pool_split);
+    }
+    return;
+  }
   const int nblk = (P.D + P.rb - 1) / P.rb;
   const unsigned ny = (unsigned)(act.n ? act.n : P.chains);
   const dim3 grid((unsigned)(((nblk + 1) / 2) * P.split), ny), fin((unsigned)P.npart, ny);
@@ -1778,7 +1814,8 @@ int dense_matvec(Sampler *sp, int nrhs, int n_active, hipEvent_t e0 = nullptr, h
   }
   dense_launch_shape(sp->dn, n_active);
   sp->dn.count_passes = timed ? 1 : 0;     // potus_dense_timing: bytes and milliseconds over the same set of passes
-  sp->mv_launches_pending = timed ? (nrhs == 3 ? 2 : 1) : 0;
+  // (launches of the matrix pass: two for three right-hand sides per chain; pooled: one per DNP_RMAX right-hand sides)
+  sp->mv_launches_pending = !timed ? 0 : sp->dn.pooled ? (n_active * nrhs + (DNP_RMAX / nrhs) * nrhs - 1) / ((DNP_RMAX / nrhs) * nrhs) : (nrhs == 3 ? 2 : 1);
   // (the bytes the passes stream are counted on the device, DnParams::act_passes: the host's flags may be a few rounds old)
   HIP_TRY(hipEventRecord(e0 ? e0 : sp->mv0, sp->stream));
   dense_symv_launch(sp->stream, sp->dn, act, nrhs);
@@ -1844,12 +1881,17 @@ int dense_window_end(Sampler *sp, int n, unsigned iter) {
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   HIP_TRY(hipStreamSynchronize(sp->stream));
   const double t0 = now();
-  hipLaunchKernelGGL(k_dn_center, dn_grid(sp), dim3(256), 0, sp->stream, P, n);
-  hipLaunchKernelGGL(k_dn_cov, dim3(nb, nb, chains), dim3(256), 0, sp->stream, P, n);
+  if (P.pooled) {   // ONE covariance out of the draws of every chain, ONE factor (potus_dense_pool.hpp)
+    hipLaunchKernelGGL(k_dn_pool_center, dim3((unsigned)std::min((D + 255) / 256, 64)), dim3(256), 0, sp->stream, P, n);
+    hipLaunchKernelGGL(k_dn_pool_cov, dim3(nb, nb), dim3(256), 0, sp->stream, P, n);
+  } else {
+    hipLaunchKernelGGL(k_dn_center, dn_grid(sp), dim3(256), 0, sp->stream, P, n);
+    hipLaunchKernelGGL(k_dn_cov, dim3(nb, nb, chains), dim3(256), 0, sp->stream, P, n);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(sp->stream));
   const double t1 = now();
-  dense_cholesky_launch(sp->stream, P, chains);   // in place on the lower triangle; the upper one keeps M^-1
+  dense_cholesky_launch(sp->stream, P, P.pooled ? 1 : chains);   // in place on the lower triangle; the upper one keeps M^-1 (pooled: in the factor's own buffer)
   HIP_TRY(hipGetLastError());
   int failed = 0;
   HIP_TRY(hipMemcpyAsync(&failed, P.fail, 4, hipMemcpyDeviceToHost, sp->stream));
@@ -1896,7 +1938,7 @@ int dense_run(Sampler *sp, int n_iter) {
         HIP_TRY(hipEventSynchronize(sp->rdone[k]));
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, sp->rv0[k], sp->rv1[k]));
-        sp->mv_ms += ms; sp->mv_calls += 1;
+        sp->mv_ms += ms; sp->mv_calls += sp->rv_launches[k];
         int n = 0;
         for (int c = 0; c < sp->R.chains; c++) n += sp->h_active[c] != 0;
         n_active = n;
@@ -1908,6 +1950,7 @@ int dense_run(Sampler *sp, int n_iter) {
         if ((rc = dense_grad(sp))) return rc;
         hipLaunchKernelGGL(k_dn_kick, dn_grid(sp), dim3(256), 0, sp->stream, P);
         if ((rc = dense_matvec(sp, 2, n_active, sp->rv0[k], sp->rv1[k]))) return rc;
+        sp->rv_launches[k] = sp->mv_launches_pending;
         hipLaunchKernelGGL(k_dn_step, dim3(chains), dim3(DN_THREADS), 0, sp->stream, P, (const RunParams *)sp->dR, (unsigned)it, (int)DN_MODE_LEAF);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(sp->h_active, sp->dn.active, (size_t)sp->R.chains * sizeof(int), hipMemcpyDeviceToHost, sp->stream));
@@ -1951,9 +1994,10 @@ int dense_import_init(Sampler *sp) {
     // a second potus_init: back to the unit metric and the start of the window schedule (the upper triangle is what the matrix
     // pass reads, so the whole matrix goes, not only the flag)
     DnParams &P = sp->dn;
-    HIP_TRY(hipMemsetAsync(P.A, 0, (size_t)P.chains * P.D * P.LD * 8, sp->stream));
+    HIP_TRY(hipMemsetAsync(P.A, 0, (size_t)(P.pooled ? 1 : P.chains) * P.D * P.LD * 8, sp->stream));
+    if (P.pooled) HIP_TRY(hipMemsetAsync(P.Lf, 0, (size_t)P.D * P.LD * 8, sp->stream));
     HIP_TRY(hipMemsetAsync(P.fail, 0, 4, sp->stream));
-    hipLaunchKernelGGL(k_dn_identity, dim3((P.D + 255) / 256, P.chains), dim3(256), 0, sp->stream, P);
+    hipLaunchKernelGGL(k_dn_identity, dim3((P.D + 255) / 256, P.pooled ? 1 : P.chains), dim3(256), 0, sp->stream, P);
     HIP_TRY(hipGetLastError());
     P.identity = 1;
   }
@@ -1970,7 +2014,7 @@ int dense_import_init(Sampler *sp) {
 // ======================================================================== C ABI
 extern "C" {
 
-const char *potus_version(void) { return "potus_hmc 0.4 (gfx950)"; }   // 0.4: potus_opts.metric_storage (round 3), potus_diagnostics* (round 4)
+const char *potus_version(void) { return "potus_hmc 0.5 (gfx950)"; }   // 0.5: potus_opts.pooled_metric (round 6);   // 0.4: potus_opts.metric_storage (round 3), potus_diagnostics* (round 4)
 
 int potus_last_error(char *buf, int len) {
   if (buf && len > 0) { std::snprintf(buf, (size_t)len, "%s", g_err.c_str()); }
@@ -1982,7 +2026,7 @@ void potus_default_opts(potus_opts *o) {
   o->chains = 4; o->chain_id_offset = 0; o->num_warmup = 1000; o->num_samples = 1000; o->max_depth = 10;
   o->init_buffer = 75; o->term_buffer = 50; o->window = 25;
   o->delta = 0.8; o->gamma = 0.05; o->kappa = 0.75; o->t0 = 10; o->stepsize = 1.0; o->init_radius = 2.0;
-  o->seed = 1843; o->device = 0; o->save_warmup = 0; o->cus_per_chain = 0; o->metric = POTUS_METRIC_DIAG; o->twin = -1; o->metric_storage = POTUS_STORAGE_F64;
+  o->seed = 1843; o->device = 0; o->save_warmup = 0; o->cus_per_chain = 0; o->metric = POTUS_METRIC_DIAG; o->twin = -1; o->pooled_metric = 0; o->reserved_ = 0; o->metric_storage = POTUS_STORAGE_F64;
 }
 
 int potus_num_params(const potus_data *d, int *D) {
@@ -2088,6 +2132,9 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   if (o->metric != POTUS_METRIC_DIAG && o->metric != POTUS_METRIC_DENSE) return fail(POTUS_ERR_ARG, "metric must be POTUS_METRIC_DIAG or POTUS_METRIC_DENSE");
   if (o->twin < -1 || o->twin > 1) return fail(POTUS_ERR_ARG, "twin must be -1 (library's choice), 0 or 1");
   if (o->metric_storage != POTUS_STORAGE_F64 && o->metric_storage != POTUS_STORAGE_F32) return fail(POTUS_ERR_ARG, "metric_storage must be POTUS_STORAGE_F64 or POTUS_STORAGE_F32");
+  if (o->pooled_metric != 0 && o->pooled_metric != 1) return fail(POTUS_ERR_ARG, "pooled_metric must be 0 or 1");
+  if (o->pooled_metric && o->metric != POTUS_METRIC_DENSE) return fail(POTUS_ERR_ARG, "pooled_metric applies to the dense metric (metric = POTUS_METRIC_DENSE)");
+  if (o->pooled_metric && o->metric_storage != POTUS_STORAGE_F64) return fail(POTUS_ERR_ARG, "pooled_metric keeps its one matrix in fp64 (metric_storage = f64)");
   if (o->metric_storage == POTUS_STORAGE_F32 && o->metric != POTUS_METRIC_DENSE) return fail(POTUS_ERR_ARG, "metric_storage = f32 applies to the dense metric only");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(POTUS_ERR_DEVICE, "no HIP device: libpotus_hmc needs an MI355X (gfx950)");
@@ -2498,7 +2545,7 @@ int potus_get_adaptation(int handle, double *stepsize, double *inv_metric) {
   for (int c = 0; c < sp->R.chains; c++) {
     if (stepsize) stepsize[c] = sc[c].nom_eps;
     if (inv_metric && sp->dense) {   // the diagonal of the dense inverse metric
-      HIP_TRY(hipMemcpy(inv_metric + (size_t)c * sp->L.D, sp->dn.dg + (size_t)c * sp->dn.LD, (size_t)sp->L.D * 8, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(inv_metric + (size_t)c * sp->L.D, dn_diag(sp->dn, c), (size_t)sp->L.D * 8, hipMemcpyDeviceToHost));   // (pooled: the one diagonal for every chain)
     } else if (inv_metric) {
       double *dst = inv_metric + (size_t)c * sp->L.D;
       if (sp->K == 1) HIP_TRY(hipMemcpy(dst, sp->R.state + ((size_t)c * V_COUNT + V_MINV) * sp->R.Dpad, (size_t)sp->L.D * 8, hipMemcpyDeviceToHost));
@@ -2532,9 +2579,9 @@ int potus_get_dense_metric(int handle, int chain, double *inv_metric) {
       }
     }
   } else
-  HIP_TRY(hipMemcpy2D(inv_metric, D * 8, sp->dn.A + (size_t)chain * D * sp->dn.LD, (size_t)sp->dn.LD * 8, D * 8, D, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy2D(inv_metric, D * 8, dn_mat(sp->dn, chain), (size_t)sp->dn.LD * 8, D * 8, D, hipMemcpyDeviceToHost));   // (pooled: every chain's is the handle's one)
   std::vector<double> dg(D);
-  HIP_TRY(hipMemcpy(dg.data(), sp->dn.dg + (size_t)chain * sp->dn.LD, D * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(dg.data(), dn_diag(sp->dn, chain), D * 8, hipMemcpyDeviceToHost));
   for (size_t i = 0; i < D; i++) {
     inv_metric[i * D + i] = dg[i];
     for (size_t j = 0; j < i; j++) inv_metric[i * D + j] = inv_metric[j * D + i];
@@ -3013,7 +3060,8 @@ int potus_write_stan_csv(int handle, const char *dir, const char *basename) {
     fprintf(f, "# id = %d\n# data\n#   file = (in-memory)\n# init = %g\n# random\n#   seed = %llu\n# output\n#   file = %s\n#   diagnostic_file =  (Default)\n#   refresh = 100 (Default)\n",
             sp->R.chain_id_offset + c + 1, o.init_radius, (unsigned long long)o.seed, path.c_str());
     // (not CmdStan's: what the library resolved cus_per_chain = 0 / twin = -1 to -- draws are reproducible bit for bit for a given pair)
-    fprintf(f, "# potus_hmc\n#   cus_per_chain = %d\n#   clusters_per_chain = %d\n#   metric_storage = %s\n", sp->K, sp->sides(), sp->dense && sp->dn.f32 ? "f32" : "f64");
+    fprintf(f, "# potus_hmc\n#   cus_per_chain = %d\n#   clusters_per_chain = %d\n#   metric_storage = %s\n#   pooled_metric = %d\n", sp->K, sp->sides(), sp->dense && sp->dn.f32 ? "f32" : "f64",
+            sp->dense && sp->dn.pooled ? 1 : 0);
     char name[96];
     for (int k = 0; k < ncols; k++) { potus_column_name(&dd, k, name, sizeof name); fprintf(f, k ? ",%s" : "%s", name); }
     fprintf(f, "\n");
@@ -3117,11 +3165,24 @@ namespace {
 struct DenseProbe {   // a DnParams with every chain active, owned buffers
   DnParams P{};
   DevBufs bufs;
-  int init(int device, int chains, int D, int win_cap) {
+  int init(int device, int chains, int D, int win_cap, bool pooled = false) {
     HIP_TRY(hipSetDevice(device));
     P.chains = chains; P.D = D; P.LD = (D + 7) & ~7; P.npart = (D + DN_FIN / 4 - 1) / (DN_FIN / 4); P.nblk = (D + DN_RB - 1) / DN_RB; P.sc_stride = 1; P.win_cap = win_cap; P.identity = 0;
-    const size_t mat = (size_t)chains * D * P.LD * 8;
+    P.pooled = pooled ? 1 : 0;
+    const size_t mat = (size_t)(pooled ? 1 : chains) * D * P.LD * 8;
     HIP_TRY(bufs.alloc(&P.state, (size_t)chains * DV_COUNT * P.LD * 8)); HIP_TRY(bufs.alloc(&P.A, mat)); HIP_TRY(bufs.alloc(&P.dg, (size_t)chains * P.LD * 8));
+    P.pool_split = 1; P.pool_rows = D;
+    if (pooled) {   // (as dense_alloc)
+      const int panels = (D + DNP_COLS - 1) / DNP_COLS;
+      int s = std::max(1, std::min(DNP_SPLIT_MAX, (2 * 256) / panels));   // at most two workgroups per compute unit, all resident at once (measured: profiles/r06_dense_pooled.txt)
+      if (const char *e = getenv("POTUS_POOL_SPLIT")) s = std::max(1, std::min(DNP_SPLIT_MAX, atoi(e)));
+      P.pool_rows = (((D + s - 1) / s + DNP_KB - 1) / DNP_KB) * DNP_KB;
+      P.pool_split = (D + P.pool_rows - 1) / P.pool_rows;
+      HIP_TRY(bufs.alloc(&P.Lf, mat)); HIP_TRY(hipMemset(P.Lf, 0, mat));
+      HIP_TRY(bufs.alloc(&P.ypool, (size_t)P.pool_split * DNP_RMAX * P.LD * 8));
+      for (const void *f : {reinterpret_cast<const void *>(k_dn_pool_mm<1>), reinterpret_cast<const void *>(k_dn_pool_mm<2>), reinterpret_cast<const void *>(k_dn_pool_mm<3>)})
+        HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DNP_LDS(3)));
+    }
     dense_launch_shape(P, chains);
     HIP_TRY(bufs.alloc(&P.tpart, (size_t)chains * P.nblk * 3 * P.LD * 8)); HIP_TRY(bufs.alloc(&P.srow, (size_t)chains * 3 * P.ntile * P.LD * 8));
     HIP_TRY(bufs.alloc(&P.win, (size_t)chains * std::max(win_cap, 1) * P.LD * 8)); HIP_TRY(bufs.alloc(&P.partial, (size_t)chains * P.npart * 8));
@@ -3142,14 +3203,17 @@ struct DenseProbe {   // a DnParams with every chain active, owned buffers
 // at sizes whose matrices would take seconds to upload.  Runs the product `reps` times; x_host / y_host are
 // [chains][nrhs][D]; dot_host [chains] receives x_0 . M^-1 x_0; *ms the average time of a pass (HIP events); *pass_bytes
 // the bytes of matrix one pass loads per chain.
-int potus_dense_matvec_probe(int device, int chains, int D, int nrhs, const double *Minv_host, const double *x_host, double *y_host, double *dot_host, int reps,
-                             double *ms, long long *pass_bytes) {
+static int dense_matvec_probe_impl(bool pooled, int device, int chains, int D, int nrhs, const double *Minv_host, const double *x_host, double *y_host, double *dot_host, int reps,
+                                   double *ms, long long *pass_bytes) {
   if (chains < 1 || D < 1 || nrhs < 1 || nrhs > 3 || !x_host || !y_host || reps < 1) return fail(POTUS_ERR_ARG, "potus_dense_matvec_probe: bad arguments");
   DenseProbe pr;
-  int rc = pr.init(device, chains, D, 1);
+  int rc = pr.init(device, chains, D, 1, pooled);
   if (rc) return rc;
   DnParams &P = pr.P;
-  if (Minv_host) {
+  if (pooled) {   // ONE full symmetric matrix for every chain (generated: chain 0's of k_dn_fill, mirrored)
+    if (Minv_host) HIP_TRY(hipMemcpy2D(P.A, (size_t)P.LD * 8, Minv_host, (size_t)D * 8, (size_t)D * 8, (size_t)D, hipMemcpyHostToDevice));
+    else hipLaunchKernelGGL(k_dn_pool_fill, dim3(4096), dim3(256), 0, 0, P);
+  } else if (Minv_host) {
     HIP_TRY(hipMemcpy2D(P.A, (size_t)P.LD * 8, Minv_host, (size_t)D * 8, (size_t)D * 8, (size_t)chains * D, hipMemcpyHostToDevice));   // the lower half is ignored
     std::vector<double> dg((size_t)chains * P.LD, 0.0);
     for (int c = 0; c < chains; c++) for (int i = 0; i < D; i++) dg[(size_t)c * P.LD + i] = Minv_host[((size_t)c * D + i) * D + i];
@@ -3197,7 +3261,8 @@ int potus_dense_matvec_probe(int device, int chains, int D, int nrhs, const doub
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (!ok) return fail(POTUS_ERR_DEVICE, "k_dn_symv failed");
   if (ms) *ms = (double)t / reps;
-  if (pass_bytes) *pass_bytes = dense_pass_bytes(D, P.LD, P.rb) * (nrhs == 3 ? 2 : 1) / (P.f32 ? 2 : 1);
+  if (pass_bytes) *pass_bytes = pooled ? (long long)D * P.LD * 8 * ((n_act * nrhs + DNP_RMAX - 1) / DNP_RMAX)
+                                       : dense_pass_bytes(D, P.LD, P.rb) * (nrhs == 3 ? 2 : 1) / (P.f32 ? 2 : 1);
   for (int c = 0; c < chains; c++) {
     for (int k = 0; k < nrhs; k++)
       HIP_TRY(hipMemcpy(y_host + ((size_t)c * nrhs + k) * D, P.state + ((size_t)c * DV_COUNT + DV_POOLPS + k) * P.LD, (size_t)D * 8, hipMemcpyDeviceToHost));
@@ -3211,15 +3276,26 @@ int potus_dense_matvec_probe(int device, int chains, int D, int nrhs, const doub
   return 0;
 }
 
+int potus_dense_matvec_probe(int device, int chains, int D, int nrhs, const double *Minv_host, const double *x_host, double *y_host, double *dot_host, int reps,
+                             double *ms, long long *pass_bytes) {
+  return dense_matvec_probe_impl(false, device, chains, D, nrhs, Minv_host, x_host, y_host, dot_host, reps, ms, pass_bytes);
+}
+// the same for the POOLED metric (potus_opts.pooled_metric): ONE D x D matrix Minv_host for all chains (NULL: generated), every right-hand side of every
+// chain in one pass (k_dn_pool_mm); *pass_bytes = the whole matrix per pass
+int potus_dense_pool_matvec_probe(int device, int chains, int D, int nrhs, const double *Minv_host, const double *x_host, double *y_host, double *dot_host, int reps,
+                                  double *ms, long long *pass_bytes) {
+  return dense_matvec_probe_impl(true, device, chains, D, nrhs, Minv_host, x_host, y_host, dot_host, reps, ms, pass_bytes);
+}
+
 // covar_adaptation on caller data: draws [chains][n][D] -> M^-1 (covariance of the window, regularised), its lower
 // Cholesky factor (in place, in the lower triangle of the same matrix), and p = L^-T u for u [chains][D] (the momentum
 // draw's triangular solve).  Outputs [chains][D][D] (M^-1 rebuilt from the upper triangle and the diagonal vector; L the
 // lower triangle, zeros above) / [chains][D]; ms[3] = covariance, factorisation, solve (milliseconds).
-int potus_dense_factor_probe(int device, int chains, int D, int n, const double *draws_host, const double *u_host, double *Minv_host, double *L_host,
-                             double *p_host, double *ms) {
+static int dense_factor_probe_impl(bool pooled, int device, int chains, int D, int n, const double *draws_host, const double *u_host, double *Minv_host, double *L_host,
+                                   double *p_host, double *ms) {
   if (chains < 1 || D < 1 || n < 2 || !draws_host) return fail(POTUS_ERR_ARG, "potus_dense_factor_probe: bad arguments");
   DenseProbe pr;
-  int rc = pr.init(device, chains, D, n);
+  int rc = pr.init(device, chains, D, n, pooled);
   if (rc) return rc;
   DnParams &P = pr.P;
   HIP_TRY(hipMemcpy2D(P.win, (size_t)P.LD * 8, draws_host, (size_t)D * 8, (size_t)D * 8, (size_t)chains * n, hipMemcpyHostToDevice));
@@ -3231,10 +3307,15 @@ int potus_dense_factor_probe(int device, int chains, int D, int n, const double 
   const int nb = (D + DN_NB - 1) / DN_NB;
   const dim3 eg((unsigned)std::min((D + 255) / 256, 64), (unsigned)chains);
   (void)hipEventRecord(ev[0], 0);
-  hipLaunchKernelGGL(k_dn_center, eg, dim3(256), 0, 0, P, n);
-  hipLaunchKernelGGL(k_dn_cov, dim3(nb, nb, chains), dim3(256), 0, 0, P, n);
+  if (pooled) {
+    hipLaunchKernelGGL(k_dn_pool_center, dim3(eg.x), dim3(256), 0, 0, P, n);
+    hipLaunchKernelGGL(k_dn_pool_cov, dim3(nb, nb), dim3(256), 0, 0, P, n);
+  } else {
+    hipLaunchKernelGGL(k_dn_center, eg, dim3(256), 0, 0, P, n);
+    hipLaunchKernelGGL(k_dn_cov, dim3(nb, nb, chains), dim3(256), 0, 0, P, n);
+  }
   (void)hipEventRecord(ev[1], 0);
-  dense_cholesky_launch(0, P, chains);
+  dense_cholesky_launch(0, P, pooled ? 1 : chains);
   (void)hipEventRecord(ev[2], 0);
   if (u_host && p_host) {
     for (int c = 0; c < chains; c++) HIP_TRY(hipMemcpy(P.state + ((size_t)c * DV_COUNT + DV_P0) * P.LD, u_host + (size_t)c * D, (size_t)D * 8, hipMemcpyHostToDevice));
@@ -3252,20 +3333,32 @@ int potus_dense_factor_probe(int device, int chains, int D, int n, const double 
   HIP_TRY(hipMemcpy(&failed, P.fail, 4, hipMemcpyDeviceToHost));
   if (failed) return fail(POTUS_ERR_STATE, "covariance not positive definite");
   if (Minv_host || L_host) {
-    std::vector<double> buf((size_t)D * D), dg(D);
-    for (int c = 0; c < chains; c++) {
-      HIP_TRY(hipMemcpy2D(buf.data(), (size_t)D * 8, P.A + (size_t)c * D * P.LD, (size_t)P.LD * 8, (size_t)D * 8, (size_t)D, hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemcpy(dg.data(), P.dg + (size_t)c * P.LD, (size_t)D * 8, hipMemcpyDeviceToHost));
+    std::vector<double> buf((size_t)D * D), dg(D), lbuf;
+    for (int c = 0; c < (pooled ? 1 : chains); c++) {   // (pooled: ONE matrix and ONE factor come back)
+      HIP_TRY(hipMemcpy2D(buf.data(), (size_t)D * 8, dn_mat(P, c), (size_t)P.LD * 8, (size_t)D * 8, (size_t)D, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(dg.data(), dn_diag(P, c), (size_t)D * 8, hipMemcpyDeviceToHost));
+      if (pooled) { lbuf.resize((size_t)D * D); HIP_TRY(hipMemcpy2D(lbuf.data(), (size_t)D * 8, P.Lf, (size_t)P.LD * 8, (size_t)D * 8, (size_t)D, hipMemcpyDeviceToHost)); }
+      const std::vector<double> &lb = pooled ? lbuf : buf;
       for (size_t i = 0; i < (size_t)D; i++)
         for (size_t j = 0; j < (size_t)D; j++) {
-          if (Minv_host) Minv_host[((size_t)c * D + i) * D + j] = i == j ? dg[i] : (i < j ? buf[i * D + j] : buf[j * D + i]);
-          if (L_host) L_host[((size_t)c * D + i) * D + j] = j <= i ? buf[i * D + j] : 0.0;
+          if (Minv_host) Minv_host[((size_t)c * D + i) * D + j] = pooled ? buf[i * D + j] : (i == j ? dg[i] : (i < j ? buf[i * D + j] : buf[j * D + i]));
+          if (L_host) L_host[((size_t)c * D + i) * D + j] = j <= i ? lb[i * D + j] : 0.0;
         }
     }
   }
   if (u_host && p_host)
     for (int c = 0; c < chains; c++) HIP_TRY(hipMemcpy(p_host + (size_t)c * D, P.state + ((size_t)c * DV_COUNT + DV_P0) * P.LD, (size_t)D * 8, hipMemcpyDeviceToHost));
   return 0;
+}
+int potus_dense_factor_probe(int device, int chains, int D, int n, const double *draws_host, const double *u_host, double *Minv_host, double *L_host,
+                             double *p_host, double *ms) {
+  return dense_factor_probe_impl(false, device, chains, D, n, draws_host, u_host, Minv_host, L_host, p_host, ms);
+}
+// the POOLED window end: ONE regularised covariance of all chains x n draws -> Minv_host [D][D] (as the device holds it: the full symmetric matrix),
+// ONE factor L_host [D][D], and p = L^-T u for every chain's u
+int potus_dense_pool_factor_probe(int device, int chains, int D, int n, const double *draws_host, const double *u_host, double *Minv_host, double *L_host,
+                                  double *p_host, double *ms) {
+  return dense_factor_probe_impl(true, device, chains, D, n, draws_host, u_host, Minv_host, L_host, p_host, ms);
 }
 
 // Development aid: the whole state block [chains][V_COUNT][Dpad] (internal element order) and every replica of the
@@ -3300,7 +3393,7 @@ void potus_R_create(int *dims, int *state, int *day_state, int *day_national, in
   d.polling_bias_scale = scalars[8]; d.state_covariance_0 = state_covariance_0;
   potus_opts o; potus_default_opts(&o);
   o.chains = iopts[0]; o.chain_id_offset = iopts[1]; o.num_warmup = iopts[2]; o.num_samples = iopts[3]; o.max_depth = iopts[4];
-  o.device = iopts[5]; o.save_warmup = iopts[6]; o.cus_per_chain = iopts[7]; o.metric = iopts[8]; o.twin = iopts[9]; o.metric_storage = iopts[10];
+  o.device = iopts[5]; o.save_warmup = iopts[6]; o.cus_per_chain = iopts[7]; o.metric = iopts[8]; o.twin = iopts[9]; o.metric_storage = iopts[10]; o.pooled_metric = iopts[11];
   o.delta = dopts[0]; o.gamma = dopts[1]; o.kappa = dopts[2]; o.t0 = dopts[3]; o.stepsize = dopts[4]; o.init_radius = dopts[5];
   if (!(dopts[6] >= 0) || dopts[6] > 9007199254740992.0 || dopts[6] != std::floor(dopts[6])) { *status = fail(POTUS_ERR_ARG, "seed must be a non-negative integer below 2^53"); return; }
   o.seed = (uint64_t)dopts[6];   // R integers are 32 bits wide: the seed travels as a double (exact to 2^53)

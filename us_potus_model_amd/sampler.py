@@ -470,13 +470,15 @@ class PotusModel:
     def sample(self, data, seed=1843, chains=4, parallel_chains=None, iter_warmup=1000, iter_sampling=1000,
                refresh=100, adapt_delta=0.8, max_treedepth=10, init=2.0, save_warmup=False, device=0,
                chain_id_offset=0, show_messages=False, inits=None, devices=None, metric="diag_e", cus_per_chain=0, twin=-1,
-               metric_storage="f64", rhat_stop=None, ess_stop=400.0):
+               metric_storage="f64", rhat_stop=None, ess_stop=400.0, pooled_metric=False):
         """`devices`: GPU ids; the chains are dealt to them in consecutive blocks and advance together under
         potus_run_many (one host thread).  Chain ids -- hence RNG streams and draws -- do not depend on the split.
         `rhat_stop` (off by default; a DEVIATION from Stan, which always runs iter_sampling iterations): after every `refresh` transitions
         of the sampling phase the pooled chains' rank-normalised split R-hat / bulk ESS of lp__ and mu_b[:, T] are taken on the device
         (potus_check_convergence) and sampling ends once every R-hat < rhat_stop and every bulk ESS >= ess_stop; the draws up to that
-        point are those of the uninterrupted run.  `self.last_convergence` keeps the checks."""
+        point are those of the uninterrupted run.  `self.last_convergence` keeps the checks.
+        `pooled_metric` (off by default; metric = "dense_e"; a DEVIATION from Stan): one inverse metric per GPU, adapted at every window end from
+        the draws of all chains on it (potus_opts.pooled_metric)."""
         from . import parallel
         if rhat_stop is not None:
             _need_check_convergence(load_library())
@@ -490,7 +492,7 @@ class PotusModel:
                        num_warmup=int(iter_warmup), num_samples=int(iter_sampling), max_depth=int(max_treedepth),
                        delta=float(adapt_delta), init_radius=float(init), seed=int(seed), device=dev,
                        save_warmup=int(bool(save_warmup)), metric=_abi.METRICS[metric], cus_per_chain=int(cus_per_chain), twin=int(twin),
-                       metric_storage={"f64": _abi.STORAGE_F64, "f32": _abi.STORAGE_F32}[metric_storage])
+                       metric_storage={"f64": _abi.STORAGE_F64, "f32": _abi.STORAGE_F32}[metric_storage], pooled_metric=int(bool(pooled_metric)))
             h.init(None if inits is None else np.asarray(inits)[off:off + n_loc])
             hs.append(h)
         total = int(iter_warmup) + int(iter_sampling)
