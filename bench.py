@@ -450,8 +450,9 @@ def main():
     chunk = args.chunk or (1 if cfg == 4 else 100)
     if args.pooled_metric and (cfg != 4 or args.metric_storage != "f64"):
         raise SystemExit("--pooled-metric applies to --config 4 with fp64 storage")
-    work = load_workloads(cfg, args.chains_per_gpu, "" if dev_backend == "gloo" else args.twin_posteriors, 1 if args.metric_storage == "f32" else 0,
-                          1 if args.pooled_metric else 0)
+    # (N > 1: every window end pooled over the ranks as well -- pooled_metric = 2, sampler.run_pooled: two small all-reduces and one of D x D doubles per window end)
+    pooled_mode = 0 if not args.pooled_metric else (2 if world > 1 else 1)
+    work = load_workloads(cfg, args.chains_per_gpu, "" if dev_backend == "gloo" else args.twin_posteriors, 1 if args.metric_storage == "f32" else 0, pooled_mode)
     warm_steps = args.steps // 2 if args.warm_steps < 0 else min(args.warm_steps, args.steps)
     nw, ns = warm_steps * chunk, (args.steps - warm_steps) * chunk
 
@@ -493,7 +494,11 @@ def main():
     for step in range(args.steps):
         ts0, lf0 = time.perf_counter(), sum(h.total_leapfrogs() for h in hs)
         dt0 = hs[0].dense_timing() if cfg == 4 else None
-        run_many(hs, chunk)
+        if pooled_mode == 2:
+            from us_potus_model_amd import sampler as _sampler
+            _sampler.run_pooled(hs, chunk, coll_dev)
+        else:
+            run_many(hs, chunk)
         kernel_ms += max(h.last_run_timing()[0] for h in hs)        # the handles of a step run concurrently
         if cfg == 4:
             dt1, at = hs[0].dense_timing(), hs[0].dense_adapt_timing()

@@ -132,7 +132,8 @@ typedef struct potus_opts {
                               leapfrog multiplies with it (fp64 accumulation), so the sampler stays exact while the matrix pass
                               of every leapfrog streams 2 D^2 bytes instead of 4 D^2.  A declared deviation from Stan, which
                               keeps the covariance in fp64; same memory per chain. */
-  int32_t pooled_metric;   /* dense metric only, 0 (Stan's: every chain adapts its own covariance) or 1: at every window end the draws of ALL
+  int32_t pooled_metric;   /* dense metric only, 0 (Stan's: every chain adapts its own covariance), 1 or 2 (as 1, but every window end is finished by
+                              the host, which may pool over several handles and GPUs first: potus_dense_pool_window).  1: at every window end the draws of ALL
                               chains of the handle form ONE regularised covariance -- covar_adaptation::learn_covariance applied to the
                               pooled sample of chains x n draws -- and ONE Cholesky factor (library version 0.5).  A leaf round then streams
                               one D x D matrix once for every chain (M^-1 times a D x (chains x right-hand sides) block on the fp64 matrix
@@ -285,6 +286,16 @@ int potus_dense_timing(int handle, double *matvec_ms, long long *passes, long lo
  * cost since potus_create: milliseconds in the covariance, in the blocked Cholesky factorisation and in the step-size search,
  * and the number of window ends. */
 int potus_dense_adapt_timing(int handle, double *cov_ms, double *chol_ms, double *init_stepsize_ms, int *window_ends);
+/* potus_opts.pooled_metric = 2: the pooled window end in two halves, so that the HOST can pool further -- over the handles of a process, and through an
+ * all-reduce (RCCL) over the GPUs of a node (us_potus_model_amd/parallel.py: pool_window_moments, sampler.run_pooled).
+ * potus_run / potus_run_many stop after the transition that ends a window (potus_iterations_done says where; a further potus_run before the finish is
+ * POTUS_ERR_STATE).  potus_dense_pool_window: *pending = 1 then; *count = the draws behind the handle's moments (chains x window length); *mean_dev and
+ * *m2_dev = DEVICE pointers to the handle's mean [D] and M2 = sum of the centred outer products [D rows of *ld doubles, both triangles].  The host
+ * replaces M2 by the pooled one (Chan's update: M2 += count (mean - pooled mean)(mean - pooled mean)', then the sum over all handles and ranks) and
+ * calls potus_dense_pool_finish with the pooled count N: M^-1 = N/(N+5) M2/(N-1) + 1e-3 5/(N+5) I, its Cholesky factor, base_hmc::init_stepsize.
+ * With one handle and nothing done in between, finish(count) is exactly pooled_metric = 1. */
+int potus_dense_pool_window(int handle, int *pending, double *count, void **mean_dev, void **m2_dev, long long *ld);
+int potus_dense_pool_finish(int handle, double n_total);
 /* Dense metric only, verification hook (as potus_log_prob_grad is for the gradient): is the factor L the momentum draw solves
  * with the Cholesky factor of the inverse metric the leapfrog multiplies with?  For n_probe standard-normal vectors x,
  * M^-1 x by the sampler's own matrix pass against L (L' x) by plain kernels over the factor, and the momentum draw's blocked

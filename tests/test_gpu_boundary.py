@@ -453,6 +453,14 @@ def test_rccl_collectives_on_device_buffers_one_rank():
         "y = parallel.all_gather_chains(x, dev)\n"
         "assert y.shape == (5, 8, 52) and y.device.type == 'cuda' and torch.equal(y, x)\n"
         "assert parallel.max_over_ranks(3.5, dev) == 3.5 and parallel.sum_over_ranks(2.25, dev) == 2.25\n"
+        # round 6: the all-reduces of the pooled dense metric (parallel.pool_window_moments: count, count x mean, and M2 slice by slice) on device buffers
+        "g = torch.Generator(device='cpu').manual_seed(3)\n"
+        "w = torch.randn(40, 37, dtype=torch.float64, generator=g).to(dev)\n"
+        "mean = w.mean(dim=0); m2 = torch.zeros(37, 40, dtype=torch.float64, device=dev); m2[:, :37] = (w - mean).T @ (w - mean); ref = m2.clone()\n"
+        "n, gm = parallel.pool_window_moments(40.0, mean, m2, dev)\n"
+        "assert n == 40.0 and torch.equal(gm, mean) and torch.equal(m2, ref) and m2.is_cuda\n"
+        "parallel.pool_window_m2(m2, dev, slice_bytes=640)\n"
+        "assert torch.equal(m2, ref)\n"
         "parallel.barrier(); torch.cuda.synchronize(); dist.destroy_process_group(); print('rccl ok')\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(ROOT),
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))

@@ -473,3 +473,54 @@ def test_pooled_transitions_after_the_window_match_the_oracle_at_2016_size(cases
     ms, passes, nbytes, rounds = h.dense_timing()
     print(f"2016, pooled dense metric, {chains} chains: {passes} matrix passes of {nbytes / max(passes, 1) / 1e9:.2f} GB in {ms:.0f} ms = {nbytes / ms / 1e9:.2f} TB/s; {rounds} leaf rounds")
     h.close()
+
+
+def test_pooled_over_two_handles_equals_one_handle_with_all_chains(cases):
+    """pooled_metric = 2 (the window end in two halves, potus_dense_pool_window / _finish): four chains of one posterior as TWO handles of two -- the second on
+    `second_device()` where the box has one (peer copies), else on the same GPU -- driven by sampler.run_pooled, which adds the handles' moments (Chan's
+    update, what parallel.pool_window_moments does across ranks) before every window end is finished.  Against ONE handle that pools the four chains itself
+    (pooled_metric = 1): the same matrix on both handles after every window end, equal to the one handle's to rounding (another order of summation), draws
+    before the first window end identical, and the rows after it the oracle's transitions from the device's own state under the device's own matrix.
+    With one handle and nothing in between, the two halves ARE pooled_metric = 1: same bytes."""
+    from conftest import second_device
+    from adaptation_replay import window_schedule
+    data, variant = cases["small_full"]
+    nw = 60                                                     # 15 % / 10 %: init buffer 9, one window of 45 draws (rows 9 .. 53), terminal buffer 6
+    (start, end), = window_schedule(nw, 75, 50, 25)
+    kw = dict(num_warmup=nw, num_samples=4, save_warmup=1, seed=1843, metric=_abi.METRIC_DENSE)
+    one = Handle(data, variant, chains=4, pooled_metric=1, **kw)
+    one.init(); one.run(nw + 4)
+    d1, M1 = one.draws(), one.dense_metric(0)
+    one.close()
+    hs = [Handle(data, variant, chains=2, chain_id_offset=0, pooled_metric=2, **kw),
+          Handle(data, variant, chains=2, chain_id_offset=2, pooled_metric=2, device=second_device(), **kw)]
+    for h in hs:
+        h.init()
+    sampler.run_pooled(hs, 20)                                  # (stops and resumes: chunks that do not end at the window end)
+    sampler.run_pooled(hs, nw + 4 - 20)
+    d2 = np.concatenate([h.draws() for h in hs])
+    Ma, Mb = hs[0].dense_metric(1), hs[1].dense_metric(0)
+    assert np.array_equal(Ma, Mb) and np.array_equal(Ma, Ma.T)
+    assert np.allclose(Ma, M1, rtol=1e-10, atol=1e-13 * np.abs(M1).max()), np.abs(Ma - M1).max()
+    assert np.array_equal(d2[:, :end + 1], d1[:, :end + 1])     # up to and including the window's last row: the unit metric
+    w = np.concatenate([d2[c][start:end + 1, 7:] for c in range(4)])
+    N = len(w)
+    want = (N / (N + 5.0)) * np.cov(w.T) + 1e-3 * (5.0 / (N + 5.0)) * np.eye(hs[0].D)
+    assert np.allclose(Ma, want, rtol=1e-9, atol=1e-12 * np.abs(want).max())
+    for hi, h in enumerate(hs):
+        res, solve = h.dense_check(0, 2)
+        assert res < 1e-12 and solve < 1e-9, (res, solve)
+        for c in range(2):
+            _post_window_rows_against_the_oracle(data, variant, h, h.draws(), c, end + 1, 3, 10, Ma, 2 * hi + c + 1)
+    with pytest.raises(sampler.PotusError):
+        hs[0].pool_finish(10.0)                                 # nothing pending
+    for h in hs:
+        h.close()
+    solo = Handle(data, variant, chains=4, pooled_metric=2, **kw)
+    solo.init()
+    sampler.run_pooled([solo], nw + 4)
+    assert np.array_equal(solo.draws(), d1) and np.array_equal(solo.dense_metric(3), M1)
+    with pytest.raises(sampler.PotusError):                     # a pending window end blocks the next run
+        t = Handle(data, variant, chains=2, pooled_metric=2, **kw)
+        t.init(); t.run(nw); t.run(1)
+    solo.close()

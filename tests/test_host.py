@@ -161,6 +161,25 @@ one = parallel.all_gather_columns(np.full(1, 7.0) if rank == 0 else np.zeros(0),
 assert one.shape == (1,) and one[0] == 7.0
 assert parallel.max_over_ranks(float(rank)) == world - 1
 assert parallel.sum_over_ranks(1.0) == world
+# the pooled dense metric across ranks (potus_opts.pooled_metric = 2; SURVEY 8e: the path's one all-reduce): every rank holds count, mean and
+# M2 = sum of centred outer products of ITS chains' window draws -- different counts per rank --; after parallel.pool_window_moments every rank
+# holds the count, the mean and the M2 of ALL draws, hence covar_adaptation's estimate of the pooled sample
+Dp, LDp = 37, 40
+rngp = np.random.default_rng(5)
+alld = [rngp.standard_normal((11 + 6 * r, Dp)) * rngp.uniform(0.3, 2.0, Dp) + r for r in range(world)]   # the same on every rank
+mine_d = alld[rank]
+mean_l = torch.as_tensor(mine_d.mean(axis=0))
+m2_l = torch.zeros((Dp, LDp), dtype=torch.float64)
+m2_l[:, :Dp] = torch.as_tensor((mine_d - mine_d.mean(axis=0)).T @ (mine_d - mine_d.mean(axis=0)))
+n_tot, gmean = parallel.pool_window_moments(float(len(mine_d)), mean_l, m2_l, None)
+cat = np.concatenate(alld)
+assert n_tot == len(cat) and np.allclose(gmean.numpy(), cat.mean(axis=0), rtol=1e-13, atol=1e-14)
+want = (cat - cat.mean(axis=0)).T @ (cat - cat.mean(axis=0))
+assert np.allclose(m2_l[:, :Dp].numpy(), want, rtol=1e-12, atol=1e-12 * np.abs(want).max()) and float(m2_l[:, Dp:].abs().max()) == 0.0
+N = n_tot
+est = (N / (N + 5.0)) * m2_l[:, :Dp].numpy() / (N - 1.0) + 1e-3 * (5.0 / (N + 5.0)) * np.eye(Dp)
+assert np.allclose(est, (N / (N + 5.0)) * np.cov(cat.T) + 1e-3 * (5.0 / (N + 5.0)) * np.eye(Dp), rtol=1e-12, atol=1e-14)
+parallel.pool_window_m2(torch.ones((5, 3), dtype=torch.float64), None, slice_bytes=24)      # (sliced: one row per all-reduce)
 parallel.barrier()
 dist.destroy_process_group()
 print("ok", rank)

@@ -110,6 +110,7 @@ struct DnParams {
   int pooled;
   double *Lf;                        // [D][LD] pooled: the factor (lower triangle incl. diagonal)
   double *ypool;                     // [pool_split][DNP_RMAX][LD] pooled: the product's partial sums per row split
+  double *pmean;                     // [LD] pooled: the mean of the handle's window draws (window end, potus_dense_pool.hpp)
   int pool_split, pool_rows;         // row splits of the pooled product (fixed per handle: the order of summation must not depend on who is active), rows per split
 };
 // where a chain's matrix, factor and diagonal live (pooled: everybody's are the handle's one)

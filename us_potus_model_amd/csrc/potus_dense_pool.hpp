@@ -161,8 +161,14 @@ __global__ __launch_bounds__(64) void k_dn_pool_finish(const DnParams P, const D
   if (threadIdx.x == 0 && job == 0) P.partial[(size_t)chain * P.npart + blockIdx.x] = tot;
 }
 
-// Pooled covar_adaptation at a window's end: the mean over the draws of every chain (welford_covar_estimator's recurrence over the chains one after
-// the other), the draws centred in place ...
+// Pooled covar_adaptation at a window's end, in three steps so that a host can pool further -- over the handles of a process and, through an all-reduce, over
+// the GPUs of a node -- between the second and the third (pooled_metric = 2: potus_dense_pool_window / potus_dense_pool_finish):
+//   1. the mean over the draws of every chain of the handle (welford_covar_estimator's recurrence over the chains one after the other) -> P.pmean, the
+//      draws centred in place;
+//   2. M2 = sum over chains and draws of c c' (tiles of 64 x 64 on the matrix cores as k_dn_cov, lower tiles computed and mirrored: exactly symmetric) -> P.A,
+//      unscaled;   [host: M2 += n_loc (mean_loc - mean)(mean_loc - mean)' and the sums over handles / ranks: Chan's pairwise update]
+//   3. M^-1 = N/(N+5) * M2 / (N-1) + 1e-3 * 5/(N+5) * I with N the number of pooled draws (learn_covariance on the pooled sample): both triangles and the
+//      diagonal to the matrix, the lower triangle also to the factor's buffer, where the factorisation starts from it.
 __global__ __launch_bounds__(256) void k_dn_pool_center(const DnParams P, int n) {
   for (int j = blockIdx.x * 256 + threadIdx.x; j < P.D; j += gridDim.x * 256) {
     double m = 0.0, cnt = 0.0;
@@ -174,11 +180,9 @@ __global__ __launch_bounds__(256) void k_dn_pool_center(const DnParams P, int n)
       double *W = P.win + (size_t)c * P.win_cap * (size_t)P.LD;
       for (int k = 0; k < n; k++) W[(size_t)k * P.LD + j] -= m;
     }
+    P.pmean[j] = m;
   }
 }
-// ... and M^-1 = N/(N+5) * (sum over chains and draws of c c') / (N-1) + 1e-3 * 5/(N+5) * I with N = chains * n (learn_covariance on the pooled
-// sample): tiles of 64 x 64 on the matrix cores as k_dn_cov, lower tiles computed and mirrored (exactly symmetric); both triangles and the
-// diagonal go to the matrix, the lower triangle also to the factor's buffer, where the factorisation starts from it.
 __global__ __launch_bounds__(256) void k_dn_pool_cov(const DnParams P, int n) {
   __shared__ double a[DN_NB][DN_NB + 1], b[DN_NB][DN_NB + 1];
   const int I = blockIdx.x, J = blockIdx.y;
@@ -206,22 +210,25 @@ __global__ __launch_bounds__(256) void k_dn_pool_cov(const DnParams P, int n) {
       }
     }
   }
-  const double nn = (double)n * (double)P.chains, f = (nn / (nn + 5.0)) / (nn - 1.0), reg = 1e-3 * (5.0 / (nn + 5.0));
 #pragma unroll
   for (int cb = 0; cb < 4; cb++)
 #pragma unroll
     for (int v = 0; v < 4; v++) {
       const int i = I * DN_NB + 16 * w + kk + 4 * v, j = J * DN_NB + 16 * cb + m;
-      if (i < P.D && j < P.D && (I != J || j <= i)) {
-        const double val = f * acc[cb][v] + (i == j ? reg : 0.0);
-        P.A[(size_t)i * P.LD + j] = val;
-        P.A[(size_t)j * P.LD + i] = val;
-        P.Lf[(size_t)i * P.LD + j] = val;
-        if (i == j) P.dg[i] = val;
-      }
+      if (i < P.D && j < P.D && (I != J || j <= i)) { P.A[(size_t)i * P.LD + j] = acc[cb][v]; P.A[(size_t)j * P.LD + i] = acc[cb][v]; }
     }
 }
-
+__global__ __launch_bounds__(256) void k_dn_pool_scale(const DnParams P, double nn) {
+  const double f = (nn / (nn + 5.0)) / (nn - 1.0), reg = 1e-3 * (5.0 / (nn + 5.0));
+  const int i = blockIdx.y;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j <= i; j += gridDim.x * 256) {
+    const double val = f * P.A[(size_t)i * P.LD + j] + (i == j ? reg : 0.0);
+    P.A[(size_t)i * P.LD + j] = val;
+    P.A[(size_t)j * P.LD + i] = val;
+    P.Lf[(size_t)i * P.LD + j] = val;
+    if (i == j) P.dg[i] = val;
+  }
+}
 // a symmetric positive definite test matrix generated on the device, as k_dn_fill's of chain 0: a_ij = exp(-|i-j|/50) + (i == j ? 1 : 0), FULL storage
 __global__ void k_dn_pool_fill(const DnParams P) {
   const size_t n = (size_t)P.D * P.D;

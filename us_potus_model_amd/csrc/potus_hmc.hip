@@ -1040,6 +1040,8 @@ struct Sampler {
   hipEvent_t mv0 = nullptr, mv1 = nullptr;
   static constexpr int DN_AHEAD = 4;       // leaf rounds the host keeps queued beyond the one whose activity flags it has seen
   hipEvent_t rv0[DN_AHEAD] = {}, rv1[DN_AHEAD] = {}, rdone[DN_AHEAD] = {};   // per queued round: around its matrix pass, after its flag copy
+  bool dn_pending = false;                 // pooled_metric = 2: a window end whose moments wait for the host (potus_dense_pool_window / _finish)
+  int dn_pending_n = 0; unsigned dn_pending_iter = 0; double dn_pending_cov_ms = 0;
   int rv_launches[DN_AHEAD] = {1, 1, 1, 1};   // ... and the launches of that pass (pooled metric: one per DNP_RMAX right-hand sides)
   double mv_ms = 0;                        // time spent in the matrix passes (k_dn_symv + finish, events), their number and the bytes they loaded
   int mv_launches_pending = 0;             // matrix passes between the event pair of the last timed dense_matvec (the first pass of a transition: two)
@@ -1724,7 +1726,8 @@ int dense_alloc(Sampler *sp) {
   };
   int rc;
   if ((rc = get((void **)&P.state, vec)) || (rc = get((void **)&P.A, (size_t)mchains * D * P.LD * 8)) || (rc = get((void **)&P.dg, (size_t)mchains * P.LD * 8)) || (rc = get((void **)&P.win, win)) ||
-      (P.pooled && ((rc = get((void **)&P.Lf, (size_t)D * P.LD * 8)) || (rc = get((void **)&P.ypool, (size_t)P.pool_split * DNP_RMAX * P.LD * 8)))) ||
+      (P.pooled && ((rc = get((void **)&P.Lf, (size_t)D * P.LD * 8)) || (rc = get((void **)&P.ypool, (size_t)P.pool_split * DNP_RMAX * P.LD * 8)) ||
+                    (rc = get((void **)&P.pmean, (size_t)P.LD * 8)))) ||
       (rc = get((void **)&P.tpart, (size_t)chains * P.nblk * 3 * P.LD * 8)) || (rc = get((void **)&P.srow, (size_t)chains * 3 * P.ntile * P.LD * 8)) ||
       (rc = get((void **)&P.partial, (size_t)chains * P.npart * 8)) || (rc = get((void **)&P.lpbuf, (size_t)chains * 8)) ||
       (rc = get((void **)&P.ts, (size_t)chains * sizeof(TS))) || (rc = get((void **)&P.rd, (size_t)chains * sizeof(DnRound))) ||
@@ -1815,7 +1818,8 @@ int dense_matvec(Sampler *sp, int nrhs, int n_active, hipEvent_t e0 = nullptr, h
   dense_launch_shape(sp->dn, n_active);
   sp->dn.count_passes = timed ? 1 : 0;     // potus_dense_timing: bytes and milliseconds over the same set of passes
   // (launches of the matrix pass: two for three right-hand sides per chain; pooled: one per DNP_RMAX right-hand sides)
-  sp->mv_launches_pending = !timed ? 0 : sp->dn.pooled ? (n_active * nrhs + (DNP_RMAX / nrhs) * nrhs - 1) / ((DNP_RMAX / nrhs) * nrhs) : (nrhs == 3 ? 2 : 1);
+  const int nact_launch = act.n ? act.n : sp->R.chains;   // (an empty list means everybody: dense_symv_launch)
+  sp->mv_launches_pending = !timed ? 0 : sp->dn.pooled ? (nact_launch + DNP_RMAX / nrhs - 1) / (DNP_RMAX / nrhs) : (nrhs == 3 ? 2 : 1);
   // (the bytes the passes stream are counted on the device, DnParams::act_passes: the host's flags may be a few rounds old)
   HIP_TRY(hipEventRecord(e0 ? e0 : sp->mv0, sp->stream));
   dense_symv_launch(sp->stream, sp->dn, act, nrhs);
@@ -1873,15 +1877,42 @@ int dense_init_stepsize(Sampler *sp, unsigned iter) {
   }
   return 0;
 }
+// the rest of a window end once M^-1 stands (pooled: once the pooled M2 stands in P.A, n_total draws behind it): factor, new step size
+static double dn_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+int dense_window_finish(Sampler *sp, int n, unsigned iter, double n_total, double cov_ms) {
+  DnParams &P = sp->dn;
+  const int D = sp->L.D, chains = sp->R.chains;
+  if (P.pooled) {
+    const double ts = dn_now();
+    hipLaunchKernelGGL(k_dn_pool_scale, dim3((unsigned)std::min((D + 255) / 256, 64), (unsigned)D), dim3(256), 0, sp->stream, P, n_total);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(sp->stream));
+    cov_ms += dn_now() - ts;
+  }
+  const double tc = dn_now();
+  dense_cholesky_launch(sp->stream, P, P.pooled ? 1 : chains);   // in place on the lower triangle; the upper one keeps M^-1 (pooled: in the factor's own buffer)
+  HIP_TRY(hipGetLastError());
+  int failed = 0;
+  HIP_TRY(hipMemcpyAsync(&failed, P.fail, 4, hipMemcpyDeviceToHost, sp->stream));
+  HIP_TRY(hipStreamSynchronize(sp->stream));
+  if (failed) return fail(POTUS_ERR_STATE, "the adapted covariance of a chain is not positive definite (window of %d draws)", n);
+  const double t2 = dn_now();
+  P.identity = 0;
+  int rc;
+  if ((rc = dense_init_stepsize(sp, iter))) return rc;
+  sp->we_cov_ms += cov_ms; sp->we_chol_ms += t2 - tc; sp->we_eps_ms += dn_now() - t2; sp->we_count += 1;
+  hipLaunchKernelGGL(k_dn_window_done, dim3((chains + 63) / 64), dim3(64), 0, sp->stream, P, (const RunParams *)sp->dR, (int)iter);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 // covar_adaptation at the end of a window of n draws: covariance -> M^-1, Cholesky factor, new step size
 int dense_window_end(Sampler *sp, int n, unsigned iter) {
   DnParams &P = sp->dn;
   const int D = sp->L.D, chains = sp->R.chains, nb = (D + DN_NB - 1) / DN_NB;
   if (n < 2) return fail(POTUS_ERR_STATE, "adaptation window of %d draws", n);
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   HIP_TRY(hipStreamSynchronize(sp->stream));
-  const double t0 = now();
-  if (P.pooled) {   // ONE covariance out of the draws of every chain, ONE factor (potus_dense_pool.hpp)
+  const double t0 = dn_now();
+  if (P.pooled) {   // the handle's mean and M2 over the draws of every chain (potus_dense_pool.hpp)
     hipLaunchKernelGGL(k_dn_pool_center, dim3((unsigned)std::min((D + 255) / 256, 64)), dim3(256), 0, sp->stream, P, n);
     hipLaunchKernelGGL(k_dn_pool_cov, dim3(nb, nb), dim3(256), 0, sp->stream, P, n);
   } else {
@@ -1890,21 +1921,12 @@ int dense_window_end(Sampler *sp, int n, unsigned iter) {
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(sp->stream));
-  const double t1 = now();
-  dense_cholesky_launch(sp->stream, P, P.pooled ? 1 : chains);   // in place on the lower triangle; the upper one keeps M^-1 (pooled: in the factor's own buffer)
-  HIP_TRY(hipGetLastError());
-  int failed = 0;
-  HIP_TRY(hipMemcpyAsync(&failed, P.fail, 4, hipMemcpyDeviceToHost, sp->stream));
-  HIP_TRY(hipStreamSynchronize(sp->stream));
-  if (failed) return fail(POTUS_ERR_STATE, "the adapted covariance of a chain is not positive definite (window of %d draws)", n);
-  const double t2 = now();
-  P.identity = 0;
-  int rc;
-  if ((rc = dense_init_stepsize(sp, iter))) return rc;
-  sp->we_cov_ms += t1 - t0; sp->we_chol_ms += t2 - t1; sp->we_eps_ms += now() - t2; sp->we_count += 1;
-  hipLaunchKernelGGL(k_dn_window_done, dim3((chains + 63) / 64), dim3(64), 0, sp->stream, P, (const RunParams *)sp->dR, (int)iter);
-  HIP_TRY(hipGetLastError());
-  return 0;
+  const double t1 = dn_now();
+  if (sp->opts.pooled_metric == 2) {   // the host pools further (other handles, other ranks) and calls potus_dense_pool_finish
+    sp->dn_pending = true; sp->dn_pending_n = n; sp->dn_pending_iter = iter; sp->dn_pending_cov_ms = t1 - t0;
+    return 0;
+  }
+  return dense_window_finish(sp, n, iter, (double)chains * (double)n, t1 - t0);
 }
 // n_iter transitions of every chain of the handle
 int dense_run(Sampler *sp, int n_iter) {
@@ -1913,9 +1935,10 @@ int dense_run(Sampler *sp, int n_iter) {
   const int nw = sp->R.num_warmup, ib = sp->R.init_buffer, tb = sp->R.term_buffer;
   std::vector<ChainScalars> sc;
   int rc;
+  if (sp->dn_pending) return fail(POTUS_ERR_STATE, "a pooled window end is pending (pooled_metric = 2): potus_dense_pool_finish comes before the next potus_run");
   if ((rc = read_scalars(sp, sc))) return rc;
   int it = sc[0].iter;
-  for (int k = 0; k < n_iter && it < total; k++, it++) {
+  for (int k = 0; k < n_iter && it < total && !sp->dn_pending; k++, it++) {
     int n_active = 0;
     hipLaunchKernelGGL(k_dn_arm, dim3(cg), dim3(64), 0, sp->stream, P, (const RunParams *)sp->dR, total);
     if ((rc = dense_sample_p(sp, (unsigned)it, RNG_MOMENTUM))) return rc;
@@ -2001,6 +2024,7 @@ int dense_import_init(Sampler *sp) {
     HIP_TRY(hipGetLastError());
     P.identity = 1;
   }
+  sp->dn_pending = false;
   sp->dn_win_counter = 0; sp->dn_win_size = sp->R.window; sp->dn_win_next = sp->R.init_buffer + sp->R.window - 1; sp->dn_wf_n = 0;
   hipLaunchKernelGGL(k_dn_import_q, dim3(64, sp->R.chains), dim3(256), 0, sp->stream, (const RunParams *)sp->dR, sp->dn,
                      sp->K > 1 ? sp->CL.perm : (const int *)nullptr, sp->K > 1 ? sp->CL.Dint : 0);
@@ -2132,7 +2156,7 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   if (o->metric != POTUS_METRIC_DIAG && o->metric != POTUS_METRIC_DENSE) return fail(POTUS_ERR_ARG, "metric must be POTUS_METRIC_DIAG or POTUS_METRIC_DENSE");
   if (o->twin < -1 || o->twin > 1) return fail(POTUS_ERR_ARG, "twin must be -1 (library's choice), 0 or 1");
   if (o->metric_storage != POTUS_STORAGE_F64 && o->metric_storage != POTUS_STORAGE_F32) return fail(POTUS_ERR_ARG, "metric_storage must be POTUS_STORAGE_F64 or POTUS_STORAGE_F32");
-  if (o->pooled_metric != 0 && o->pooled_metric != 1) return fail(POTUS_ERR_ARG, "pooled_metric must be 0 or 1");
+  if (o->pooled_metric < 0 || o->pooled_metric > 2) return fail(POTUS_ERR_ARG, "pooled_metric must be 0, 1 or 2");
   if (o->pooled_metric && o->metric != POTUS_METRIC_DENSE) return fail(POTUS_ERR_ARG, "pooled_metric applies to the dense metric (metric = POTUS_METRIC_DENSE)");
   if (o->pooled_metric && o->metric_storage != POTUS_STORAGE_F64) return fail(POTUS_ERR_ARG, "pooled_metric keeps its one matrix in fp64 (metric_storage = f64)");
   if (o->metric_storage == POTUS_STORAGE_F32 && o->metric != POTUS_METRIC_DENSE) return fail(POTUS_ERR_ARG, "metric_storage = f32 applies to the dense metric only");
@@ -2618,6 +2642,38 @@ int potus_dense_adapt_timing(int handle, double *cov_ms, double *chol_ms, double
   if (init_stepsize_ms) *init_stepsize_ms = sp->we_eps_ms;
   if (window_ends) *window_ends = sp->we_count;
   return 0;
+}
+
+// pooled_metric = 2: the window end in two halves, so that the host can pool over handles and ranks in between.  potus_run stops after the transition that ends
+// a window (potus_iterations_done says where); *pending = 1 then, *count = the draws behind the handle's moments (chains x window length), *mean_dev /
+// *m2_dev = DEVICE pointers to the handle's mean [D] and M2 = sum of centred outer products [D rows of *ld doubles, both triangles] -- the host replaces M2 by the
+// pooled one (Chan's update: M2 += count (mean - pooled mean)(mean - pooled mean)', then the sum over everybody; us_potus_model_amd/parallel.py) and calls
+// potus_dense_pool_finish with the pooled count: M^-1 = N/(N+5) M2/(N-1) + 1e-3 5/(N+5) I, its factor, init_stepsize.  With one handle and nothing in between,
+// finish(count) is exactly pooled_metric = 1.
+int potus_dense_pool_window(int handle, int *pending, double *count, void **mean_dev, void **m2_dev, long long *ld) {
+  Sampler *sp = get(handle);
+  if (!sp || !pending) return fail(POTUS_ERR_STATE, "bad handle or null output");
+  if (!sp->dense || !sp->dn.pooled) return fail(POTUS_ERR_STATE, "potus_dense_pool_window: the handle does not run a pooled dense metric");
+  *pending = sp->dn_pending ? 1 : 0;
+  if (count) *count = sp->dn_pending ? (double)sp->R.chains * (double)sp->dn_pending_n : 0.0;
+  if (mean_dev) *mean_dev = sp->dn.pmean;
+  if (m2_dev) *m2_dev = sp->dn.A;
+  if (ld) *ld = sp->dn.LD;
+  return 0;
+}
+int potus_dense_pool_finish(int handle, double n_total) {
+  Sampler *sp = get(handle);
+  if (!sp) return fail(POTUS_ERR_STATE, "bad handle");
+  if (!sp->dense || !sp->dn.pooled || !sp->dn_pending) return fail(POTUS_ERR_STATE, "potus_dense_pool_finish: no pooled window end is pending on this handle");
+  if (!(n_total >= (double)sp->R.chains * (double)sp->dn_pending_n)) return fail(POTUS_ERR_ARG, "potus_dense_pool_finish: the pooled count cannot be below the handle's own %d x %d draws", sp->R.chains, sp->dn_pending_n);
+  DeviceGuard guard;
+  DeviceLocks lock(sp->device);
+  HIP_TRY(hipSetDevice(sp->device));
+  sp->dn_pending = false;
+  const int rc = dense_window_finish(sp, sp->dn_pending_n, sp->dn_pending_iter, n_total, sp->dn_pending_cov_ms);   // (the time between the halves is the host's)
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(sp->stream));
+  return check_chains(sp);
 }
 
 // Dense metric, verification hook (like potus_log_prob_grad): is the factor in the lower triangle the factor of the metric the
@@ -3179,7 +3235,7 @@ struct DenseProbe {   // a DnParams with every chain active, owned buffers
       P.pool_rows = (((D + s - 1) / s + DNP_KB - 1) / DNP_KB) * DNP_KB;
       P.pool_split = (D + P.pool_rows - 1) / P.pool_rows;
       HIP_TRY(bufs.alloc(&P.Lf, mat)); HIP_TRY(hipMemset(P.Lf, 0, mat));
-      HIP_TRY(bufs.alloc(&P.ypool, (size_t)P.pool_split * DNP_RMAX * P.LD * 8));
+      HIP_TRY(bufs.alloc(&P.ypool, (size_t)P.pool_split * DNP_RMAX * P.LD * 8)); HIP_TRY(bufs.alloc(&P.pmean, (size_t)P.LD * 8));
       for (const void *f : {reinterpret_cast<const void *>(k_dn_pool_mm<1>), reinterpret_cast<const void *>(k_dn_pool_mm<2>), reinterpret_cast<const void *>(k_dn_pool_mm<3>)})
         HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DNP_LDS(3)));
     }
@@ -3310,6 +3366,7 @@ static int dense_factor_probe_impl(bool pooled, int device, int chains, int D, i
   if (pooled) {
     hipLaunchKernelGGL(k_dn_pool_center, dim3(eg.x), dim3(256), 0, 0, P, n);
     hipLaunchKernelGGL(k_dn_pool_cov, dim3(nb, nb), dim3(256), 0, 0, P, n);
+    hipLaunchKernelGGL(k_dn_pool_scale, dim3(eg.x, (unsigned)D), dim3(256), 0, 0, P, (double)chains * (double)n);
   } else {
     hipLaunchKernelGGL(k_dn_center, eg, dim3(256), 0, 0, P, n);
     hipLaunchKernelGGL(k_dn_cov, dim3(nb, nb, chains), dim3(256), 0, 0, P, n);

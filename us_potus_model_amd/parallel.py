@@ -152,3 +152,51 @@ def sum_over_ranks(x: float, device=None) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+# ------------------------------------------------------------------------------------------------ pooled dense metric across ranks
+# potus_opts.pooled_metric = 2: at a window end every rank holds (count, mean, M2 = sum of centred outer products) of ITS chains' window draws.  The pooled
+# covariance of all chains of the job follows Chan et al.'s pairwise update,
+#     N = sum_r n_r,   mean = sum_r n_r mean_r / N,   M2 = sum_r [ M2_r + n_r (mean_r - mean)(mean_r - mean)' ],
+# i.e. two small all-reduces and ONE all-reduce of D x D doubles (13.9 GB at the configs[4] shape: RCCL over xGMI, in slices so that no rank needs a second
+# copy) -- the only all-reduce of the whole path, and a declared deviation from Stan, whose chains never talk (SURVEY 8e "Anything else?").
+# sampler.run_pooled drives it; the gloo world-size-2 test (tests/test_host.py) holds the algebra to numpy.
+def pool_window_mean(count: float, count_times_mean, device=None):
+    """(N, pooled mean) from this rank's draw count and count x mean (a 1-D float64 torch tensor); device=None: the collectives run on CPU tensors (gloo)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return float(count), count_times_mean / float(count)
+    n = torch.tensor([float(count)], dtype=torch.float64, device=device)
+    s = count_times_mean.to(device) if device is not None else count_times_mean.cpu()
+    s = s.contiguous().clone()
+    dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    return float(n.item()), (s / n.item()).to(count_times_mean.device)
+
+
+def pool_window_m2(m2, device=None, slice_bytes=1 << 30):
+    """In place: m2 (this rank's M2, already shifted to the pooled mean; a 2-D float64 torch tensor) becomes the sum over the ranks, slice by slice."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return m2
+    rows = max(1, slice_bytes // max(1, m2.shape[1] * 8))
+    for r0 in range(0, m2.shape[0], rows):
+        blk = m2[r0:r0 + rows]
+        if device is None and blk.is_cuda:                 # development mode: the collective on CPU tensors
+            t = blk.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            blk.copy_(t)
+        else:
+            dist.all_reduce(blk, op=dist.ReduceOp.SUM)     # (a row slice of a contiguous matrix is contiguous)
+    return m2
+
+
+def pool_window_moments(count: float, mean, m2, device=None):
+    """The whole update on tensors the caller owns (what sampler.run_pooled does on the library's buffers): returns (N, pooled mean); m2 is updated in place to
+    the pooled M2.  mean [D], m2 [D, >= D] (columns beyond D are padding)."""
+    n_tot, gmean = pool_window_mean(count, float(count) * mean, device)
+    d = mean - gmean
+    m2[:, :mean.numel()].addr_(d, d, alpha=float(count))
+    pool_window_m2(m2, device)
+    return n_tot, gmean

@@ -81,6 +81,10 @@ def load_library():
     if hasattr(L, "potus_check_convergence"):           # (development builds selected through POTUS_LIB may predate an export)
         L.potus_check_convergence.argtypes = [ip, C.c_int, C.c_double, C.c_double, ip, dp, dp]
     L.potus_get_dense_metric.argtypes = [C.c_int, C.c_int, dp]
+    if hasattr(L, "potus_dense_pool_window"):
+        L.potus_dense_pool_window.argtypes = [C.c_int, ip, dp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]
+        L.potus_dense_pool_finish.argtypes = [C.c_int, C.c_double]
+    L.potus_iterations_done.argtypes = [C.c_int, ip]
     L.potus_cus_per_chain.argtypes = [C.c_int, ip]
     L.potus_clusters_per_chain.argtypes = [C.c_int, ip]
     L.potus_plan_cus_per_chain.argtypes = [C.c_int] * 7 + [ip, ip]
@@ -94,7 +98,7 @@ EXPORTS = [
     "potus_version", "potus_last_error", "potus_default_opts", "potus_num_params", "potus_num_columns",
     "potus_column_name", "potus_create", "potus_destroy", "potus_cus_per_chain", "potus_clusters_per_chain", "potus_plan_cus_per_chain", "potus_plan_sides", "potus_twin_stats", "potus_log_prob_grad", "potus_init", "potus_run", "potus_run_many",
     "potus_iterations_done", "potus_total_leapfrogs", "potus_chain_status", "potus_get_adaptation",
-    "potus_get_dense_metric", "potus_dense_timing", "potus_dense_adapt_timing", "potus_dense_check", "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_array_device", "potus_write_stan_csv",
+    "potus_get_dense_metric", "potus_dense_timing", "potus_dense_adapt_timing", "potus_dense_pool_window", "potus_dense_pool_finish", "potus_dense_check", "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_array_device", "potus_write_stan_csv",
     "potus_last_run_timing", "potus_posterior_summary", "potus_posterior_summary_many", "potus_backtest_scores",
     "potus_diagnostics", "potus_diagnostics_device", "potus_check_convergence",
     "potus_R_create", "potus_R_init", "potus_R_run", "potus_R_run_many", "potus_R_num_columns", "potus_R_saved_count",
@@ -256,6 +260,31 @@ class Handle:
         _check(L, L.potus_dense_adapt_timing(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
         return dict(cov_ms=a.value, chol_ms=b.value, init_stepsize_ms=c.value, window_ends=n.value)
 
+    def iterations_done(self):
+        n = C.c_int()
+        _check(self.L, self.L.potus_iterations_done(self.h, C.byref(n)))
+        return n.value
+
+    def pool_window(self):
+        """pooled_metric = 2: (pending, count, mean, m2) of a window end that waits for the host -- mean [D] and m2 [D, LD] are torch tensors ON the handle's
+        GPU that alias the library's buffers (zero copy; m2[:, :D] is the matrix of centred outer products, both triangles)."""
+        pend, cnt, pm, p2, ld = C.c_int(), C.c_double(), C.c_void_p(), C.c_void_p(), C.c_longlong()
+        _check(self.L, self.L.potus_dense_pool_window(self.h, C.byref(pend), C.byref(cnt), C.byref(pm), C.byref(p2), C.byref(ld)))
+        if not pend.value:
+            return False, 0.0, None, None
+        import torch
+
+        class _Dev:                                        # __cuda_array_interface__: torch wraps the device pointer without copying
+            def __init__(s_, ptr, shape):
+                s_.__cuda_array_interface__ = {"shape": shape, "typestr": "<f8", "data": (ptr, False), "version": 2}
+        dev = f"cuda:{self.opts.device}"
+        mean = torch.as_tensor(_Dev(pm.value, (self.D,)), device=dev)
+        m2 = torch.as_tensor(_Dev(p2.value, (self.D, ld.value)), device=dev)
+        return True, cnt.value, mean, m2
+
+    def pool_finish(self, n_total):
+        _check(self.L, self.L.potus_dense_pool_finish(self.h, C.c_double(float(n_total))))
+
     def dense_check(self, chain=0, n_probe=2):
         """metric = dense_e: (max ||L L' x - M^-1 x|| / ||M^-1 x|| over n_probe random x, ||L' p - u|| / ||u|| of the momentum solve)."""
         L = self.L
@@ -298,6 +327,44 @@ def posterior_summary(handles, ev):
     ids = (C.c_int * len(handles))(*[h.h for h in handles])
     _check(h0.L, h0.L.potus_posterior_summary_many(ids, len(handles), _dp(ev), _dp(st), _dp(na), _dp(eo)))
     return dict(state=np.ascontiguousarray(st.transpose(1, 0, 2)), national=na, electoral_votes=eo)
+
+
+def run_pooled(handles, n_iter, coll_device=None):
+    """potus_run_many for dense samplers with pooled_metric = 2 (one posterior, its chains spread over several handles / GPUs / ranks): every window end is
+    pooled over ALL of them before it is finished -- the handles of this process by adding their moments on the first handle's GPU, the ranks of an initialised
+    torch.distributed group by all-reduces (RCCL over xGMI when coll_device is a GPU; parallel.pool_window_moments) -- so that every GPU ends up with the
+    same inverse metric, estimated from the window draws of every chain of the job.  A declared deviation from Stan (potus_opts.pooled_metric)."""
+    import torch
+    from . import parallel
+    left = int(n_iter)
+    while left > 0:
+        it0 = handles[0].iterations_done()
+        run_many(handles, left)
+        done = handles[0].iterations_done() - it0
+        left -= done
+        wins = [h.pool_window() for h in handles]
+        if not any(w[0] for w in wins):
+            if done == 0:
+                break                                      # the sampler has run all its iterations
+            continue
+        if not all(w[0] for w in wins):
+            raise PotusError("run_pooled: the handles do not share a warm-up schedule (a window end is pending on some of them only)")
+        dev0 = wins[0][2].device
+        cnt = float(sum(w[1] for w in wins))
+        msum = sum((w[1] * w[2]).to(dev0) for w in wins)                       # sum of count x mean over this process's handles
+        n_tot, gmean = parallel.pool_window_mean(cnt, msum, coll_device)       # ... and over the ranks
+        for _, c, mean, m2 in wins:                                           # Chan: M2 += count (mean - pooled mean)(mean - pooled mean)'
+            d = mean - gmean.to(mean.device)
+            m2[:, :mean.numel()].addr_(d, d, alpha=c)
+        total = wins[0][3]
+        for w in wins[1:]:
+            total += w[3].to(dev0)
+        parallel.pool_window_m2(total, coll_device)                            # in place: the sum over the ranks
+        for w in wins[1:]:
+            w[3].copy_(total)
+        torch.cuda.synchronize()
+        for h in handles:
+            h.pool_finish(n_tot)
 
 
 def device_diagnostics(handles, col_begin, col_end):
