@@ -32,6 +32,11 @@ Each chain runs on a cluster of K workgroups (potus_cluster.hpp); --cus-per-chai
 kernel.  N > 1: one process per GPU; rank r owns chains [r C, (r + 1) C) (RNG streams keyed by global chain id), no
 communication while sampling.  Weak scaling: C chains per GPU whatever N is.
 
+--single-process  (with --gpus N, configs[1] / [2]) the path the reference-side binding takes -- R is one process: potus_sample(gpus = 0:7) --: ONE process,
+              N handles on N devices advancing together under potus_run_many, R-hat / ESS of the pooled chains through potus_diagnostics (the other GPUs'
+              blocks come over with peer copies); no torch.distributed, no RCCL.  The line says "launcher": "single_process".  Under the launcher
+              (N > 1) rank 0 adds this run as side.single_process once the ranks have released their GPUs, so that a scaling run times both paths.
+
 Rank 0 prints ONE JSON line.  `value` = leapfrogs of all chains on all GPUs / max-over-ranks wall time of
 (init + K chunks [+ all-gather]), inputs already resident in HBM.
 """
@@ -195,6 +200,107 @@ def side_measurements(seed, budget_s=200.0, headline=None):
                    "configs[4]_pooled = the same preset with potus_opts.pooled_metric (one inverse metric per GPU: a declared deviation from Stan)")
     out["seconds"] = time.perf_counter() - t_all
     return out
+
+
+# ------------------------------------------------------------------------------------------------ the R-facing multi-GPU path
+def single_process_side(args, n):
+    """`bench.py --gpus n --single-process` as a child process of rank 0 (the other ranks wait at a barrier with their samplers closed): compact form of its line."""
+    import subprocess
+    t0 = time.perf_counter()
+    try:
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", str(n), "--single-process", "--seed", str(args.seed), "--steps", str(args.steps), "--warmup", "1"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420,
+                           env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")})
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or len(lines) != 1:
+            return {"error": (r.stderr or r.stdout)[-300:], "rc": r.returncode}
+        d = json.loads(lines[0])
+        return {"launcher": d["launcher"], "command": f"bench.py --gpus {n} --single-process", "value": d["value"], "unit": d["unit"], "n_gpus": d["n_gpus"], "seconds": d["seconds"],
+                "leapfrogs": d["leapfrogs"], "ess_bulk_min": d["ess_bulk_min"], "ess_per_sec": d["ess_per_sec"], "rhat_max": d["rhat_max"],
+                "diagnostics_seconds": d["diagnostics_seconds"], "wall_seconds_with_process_start": time.perf_counter() - t0,
+                "note": "ONE process, one handle per GPU under potus_run_many, pooled R-hat / ESS through potus_diagnostics (peer copies): what the R shim's "
+                        "potus_sample(gpus = ...) does; same chains, same draws as the multi-process line above"}
+    except subprocess.TimeoutExpired:
+        return {"error": f"timed out after {time.perf_counter() - t0:.0f} s"}
+    except Exception as ex:                                # never let a side measurement spoil the line
+        return {"error": str(ex)[:200]}
+
+
+
+def single_process_line(args):
+    """`bench.py --gpus N --single-process`: what potus_sample(gpus = 0:(N-1)) does from R's one process (R/potus_sampling.R; final_2016.R:536 is the
+    reference's only parallelism, `parallel_chains`) -- N handles of 8 chains on N devices under potus_run_many, chain ids by block as in the multi-process run
+    (same draws), the pooled chains' R-hat / bulk ESS of lp__, mu_b[:, T] and predicted_score[T, :] through potus_diagnostics on the first handle's GPU.
+    POTUS_BENCH_DEVICES="0,0" (development / tests on a one-GPU box) names the device of every handle."""
+    from us_potus_model_amd import Handle, device_diagnostics, run_many
+    n = args.gpus
+    devs = [int(x) for x in os.environ["POTUS_BENCH_DEVICES"].split(",")] if os.environ.get("POTUS_BENCH_DEVICES") else list(range(n))
+    if len(devs) != n:
+        raise SystemExit(f"--single-process: POTUS_BENCH_DEVICES names {len(devs)} devices, --gpus {n}")
+    if not os.environ.get("POTUS_BENCH_DEVICES") and visible_gpus() < n:
+        raise SystemExit(f"--gpus {n} --single-process: {visible_gpus()} HIP device(s) visible")
+    name, data, variant, C, _ = load_workloads(1, args.chains_per_gpu)[0]
+    steps = 20 if args.steps is None else args.steps
+    warmup = 2 if args.warmup is None else args.warmup
+    chunk = args.chunk or 100
+    warm_steps = steps // 2 if args.warm_steps < 0 else min(args.warm_steps, steps)
+    nw, ns = warm_steps * chunk, (steps - warm_steps) * chunk
+    md = 10 if args.max_depth is None else args.max_depth
+
+    def make(seed, num_warmup, num_samples):
+        return [Handle(data, variant, chains=C, chain_id_offset=r * C, num_warmup=num_warmup, num_samples=num_samples, seed=seed, device=d,
+                       cus_per_chain=args.cus_per_chain, max_depth=md, twin=args.twin) for r, d in enumerate(devs)]
+
+    if warmup > 0:
+        hw = make(args.seed + 1, warmup * chunk, 0)
+        for h in hw:
+            h.init()
+        for _ in range(warmup):
+            run_many(hw, chunk)
+        for h in hw:
+            h.close()
+    hs = make(args.seed, nw, ns)
+    t0 = time.perf_counter()
+    for h in hs:
+        h.init()
+    kernel_ms, t_warm_end = 0.0, None
+    for step in range(steps):
+        run_many(hs, chunk)
+        kernel_ms += max(h.last_run_timing()[0] for h in hs)
+        if step + 1 == warm_steps:
+            t_warm_end = time.perf_counter()
+    ess, rhat, diag_s = None, None, 0.0
+    if ns >= 8:
+        S, T = int(data["S"]), int(data["T"])
+        a_mu, a_ps = hs[0].layout["mu_b"][0], hs[0].layout["predicted_score"][0]
+        td0 = time.perf_counter()
+        parts = [device_diagnostics(hs, 0, 1), device_diagnostics(hs, a_mu + S * (T - 1), a_mu + S * T)]
+        rp, ep = device_diagnostics(hs, a_ps + (T - 1), a_ps + (T - 1) + T * (S - 1) + 1)             # predicted_score[T, s]: every T-th column
+        parts.append((rp[::T], ep[::T]))
+        diag_s = time.perf_counter() - td0
+        rhat, ess = float(np.nanmax(np.concatenate([p_[0] for p_ in parts]))), float(np.nanmin(np.concatenate([p_[1] for p_ in parts])))
+    t1 = time.perf_counter()
+    elapsed, samp = t1 - t0, t1 - (t_warm_end or t0)
+    lf = [h.total_leapfrogs() for h in hs]
+    bpl = algorithmic_bytes_per_leapfrog(data, variant)
+    K, sides = hs[0].cus_per_chain, hs[0].clusters_per_chain
+    achieved = bpl * sum(lf) / n / (kernel_ms * 1e-3) / 1e9        # per GPU: the devices run side by side
+    line = {"metric": "leapfrog_steps_per_sec", "value": sum(lf) / elapsed, "unit": "leapfrogs/s", "n_gpus": n, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "poll data of the reference (fixtures built from its CSVs, tests/golden/data_*.npz); random inits", "launcher": "single_process",
+            "config": {"workload": f"configs[{1 if n == 1 else 2}]: 2016 backtest, adaptive NUTS diag_e, {C} chains per MI355X x {n}, {nw} warmup + {ns} sampling, seed {args.seed}; "
+                                   f"ONE process, {n} handles under potus_run_many (the R-facing path: potus_sample(gpus = ...)); a step = one launch chunk of {chunk} transitions",
+                       "baseline_config_index": 1 if n == 1 else 2, "chains_per_gpu": C, "total_chains": C * n, "devices": devs, "iter_warmup": nw, "iter_sampling": ns,
+                       "parallelism": f"one host process, {n} handles of {C} chains, one per device; pooled R-hat / ESS through potus_diagnostics (peer copies), no RCCL",
+                       "cus_per_chain": K, "clusters_per_chain": sides},
+            "leapfrogs": int(sum(lf)), "seconds": elapsed, "sampling_seconds": samp, "ess_bulk_min": ess, "ess_per_sec": (ess / samp) if ess else None, "rhat_max": rhat,
+            "diagnostics_seconds": diag_s,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_cl_run" if K > 1 else "k_run", "algorithmic_bytes_per_leapfrog": bpl, "leapfrogs_in_launches": int(sum(lf)), "launch_ms_total": kernel_ms,
+                         "note": "per GPU: leapfrogs of all handles / n_gpus x the algorithmic bytes / the launches' time (the handles of a step run side by side)"}}
+    for h in hs:
+        h.close()
+    return line
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -390,12 +496,18 @@ def main():
     ap.add_argument("--seed", type=int, default=1843)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturated", action="store_true", help="skip the 256-chain reference point")
+    ap.add_argument("--single-process", action="store_true", help="ONE process, --gpus N handles on N devices under potus_run_many: the R-facing multi-GPU path")
     ap.add_argument("--no-side", action="store_true", help="skip the side measurements of configs[0], configs[3] and the configs[4] preset (default line only)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the first HIP call (module docstring)
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
+    if args.single_process:
+        if args.config not in (1, 2):
+            raise SystemExit("--single-process runs configs[1] / configs[2]")
+        print(json.dumps(single_process_line(args)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
 
@@ -796,7 +908,20 @@ def main():
                 h.close()
             torch.cuda.empty_cache()
             line["side"] = side_measurements(args.seed, headline=seed_summary({**line, "seed": args.seed}))
+        if world > 1 and cfg in (1, 2) and not args.no_side and dev_backend != "gloo":
+            for h in hs:
+                h.close()
+            hs = []
+            torch.cuda.empty_cache()
+            parallel.barrier()                                   # every rank has released its sampler: the GPUs are free
+            line["side"] = {"single_process": single_process_side(args, world)}
         print(json.dumps(line), flush=True)
+    elif world > 1 and cfg in (1, 2) and not args.no_side and dev_backend != "gloo":
+        for h in hs:
+            h.close()
+        hs = []
+        torch.cuda.empty_cache()
+        parallel.barrier()
     for h in hs:
         h.close()
     parallel.barrier()

@@ -410,6 +410,33 @@ def test_bench_two_ranks_end_to_end_gloo_development_mode(tmp_path):
     assert d["config"]["posteriors"]["2016"]["pooled_draws"] == 8 * 20 and d["leapfrogs"] > 0 and d["roofline"]["frac"] > 0
 
 
+def test_bench_single_process_gives_the_pooled_diagnostics_of_the_two_rank_run(tmp_path):
+    """`bench.py --gpus 2 --single-process`: the path the reference-side binding takes -- R is ONE process, potus_sample(gpus = 0:1),
+    final_2016.R:536 -- two handles of four chains under potus_run_many, the second on `second_device()` where the box has one (else both on GPU 0), pooled
+    R-hat / bulk ESS through potus_diagnostics over the two handles.  One line with "launcher": "single_process"; the same chains (global chain ids), hence
+    the same leapfrog count and, to 1e-9, the same pooled R-hat / ESS as the two-rank run of the same command (development mode: both ranks on GPU 0, gloo)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT, second_device
+    common = ["--gpus", "2", "--steps", "4", "--warmup", "0", "--chunk", "10", "--chains-per-gpu", "4", "--no-cpu-baseline", "--no-saturated"]
+    env = dict(os.environ, POTUS_BENCH_DEVICES=f"0,{second_device()}")
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--single-process"] + common, capture_output=True, text=True, env=env, timeout=300, cwd=str(ROOT))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    sp = json.loads(lines[0])
+    assert sp["launcher"] == "single_process" and sp["n_gpus"] == 2 and sp["config"]["total_chains"] == 8 and sp["config"]["devices"] == [0, second_device()]
+    assert sp["roofline"]["frac"] > 0 and abs(sp["value"] - sp["leapfrogs"] / sp["seconds"]) < 1e-6 * sp["value"]
+    env = dict(os.environ, POTUS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29543", str(ROOT / "bench.py")] + common
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=str(ROOT))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    mp_ = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert mp_["leapfrogs"] == sp["leapfrogs"] and "launcher" not in mp_
+    assert abs(mp_["rhat_max"] - sp["rhat_max"]) <= 1e-9 * sp["rhat_max"] and abs(mp_["ess_bulk_min"] - sp["ess_bulk_min"]) <= 1e-9 * sp["ess_bulk_min"], (mp_["rhat_max"], sp["rhat_max"])
+
+
 def test_bench_starts_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2 ...` WITHOUT a launcher around it -- the command the driver issues for its scaling runs -- starts two ranks
     by itself (re-execution under torch.distributed.run on 127.0.0.1 with a free port) and prints ONE line with n_gpus = 2, 16 chains,
@@ -458,9 +485,9 @@ def test_rccl_collectives_on_device_buffers_one_rank():
         "w = torch.randn(40, 37, dtype=torch.float64, generator=g).to(dev)\n"
         "mean = w.mean(dim=0); m2 = torch.zeros(37, 40, dtype=torch.float64, device=dev); m2[:, :37] = (w - mean).T @ (w - mean); ref = m2.clone()\n"
         "n, gm = parallel.pool_window_moments(40.0, mean, m2, dev)\n"
-        "assert n == 40.0 and torch.equal(gm, mean) and torch.equal(m2, ref) and m2.is_cuda\n"
-        "parallel.pool_window_m2(m2, dev, slice_bytes=640)\n"
-        "assert torch.equal(m2, ref)\n"
+        "assert n == 40.0 and torch.allclose(gm, mean, rtol=1e-15, atol=1e-16) and torch.allclose(m2, ref, rtol=1e-14, atol=1e-14) and m2.is_cuda\n"
+        "ref2 = m2.clone(); parallel.pool_window_m2(m2, dev, slice_bytes=640)\n"
+        "assert torch.equal(m2, ref2)\n"
         "parallel.barrier(); torch.cuda.synchronize(); dist.destroy_process_group(); print('rccl ok')\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(ROOT),
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
