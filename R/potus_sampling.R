@@ -1,4 +1,6 @@
-# potus_sampling.R -- R host shim over libpotus_hmc.so (plain .C(), no Rcpp, no Rinternals.h).
+# potus_sampling.R -- R host shim over libpotus_hmc.so: plain .C() everywhere (no Rcpp, no Rinternals.h needed), and -- where R/src/potus_call.c has been
+# built (R CMD SHLIB) and loaded -- .Call() for the calls that return draws: the result is then allocated once and filled in place (long vectors welcome),
+# where .C() copies every argument in and out and the shim permutes the block once more.
 #
 # Drop-in for the sampler call of the reference scripts:
 #
@@ -20,7 +22,12 @@
 # replayed argument for argument (int* / double* / char** only, outputs through the same buffers) by
 # tests/test_gpu_boundary.py::test_r_entry_points_replay_the_shim with ctypes.
 
-potus_load <- function(path) dyn.load(path)
+# path: libpotus_hmc.so; call_path: R/src/potus_call.so (optional: without it every call goes through .C())
+potus_load <- function(path, call_path = NULL) {
+  dyn.load(path, local = FALSE)                  # (global: potus_call.so resolves the C ABI against it)
+  if (!is.null(call_path)) dyn.load(call_path)
+  invisible(is.loaded("potus_call_extract"))
+}
 
 .potus_check <- function(status) {
   if (status != 0L) {
@@ -143,6 +150,10 @@ potus_extract <- function(fit, name) {
   b <- .potus_layout(fit)[[name]]
   if (is.null(b)) stop("unknown parameter ", name)
   n <- b$end - b$begin
+  if (is.loaded("potus_call_extract")) {          # .Call(): ONE allocation, filled in place in R's own order [draws, columns] (R/src/potus_call.c)
+    a <- .Call("potus_call_extract", as.integer(fit$handles), as.integer(b$begin), as.integer(b$end))
+    return(if (length(b$dims)) { dim(a) <- c(nrow(a), b$dims); a } else as.vector(a))
+  }
   parts <- lapply(seq_along(fit$handles), function(g) {
     ch <- fit$chains_per_handle[g]
     res <- .C("potus_R_write_array", fit$handles[g], as.integer(b$begin), as.integer(b$end),
@@ -180,6 +191,10 @@ potus_summary <- function(fit, ev) {
 # Returns data.frame(column, rhat, ess_bulk); columns are 0-based positions in the CmdStan row, as in potus_extract.
 potus_diagnostics <- function(fit, col_begin, col_end) {
   n <- col_end - col_begin
+  if (is.loaded("potus_call_diagnostics")) {
+    m <- .Call("potus_call_diagnostics", as.integer(fit$handles), as.integer(col_begin), as.integer(col_end))
+    return(data.frame(column = seq(col_begin, col_end - 1L), rhat = m[, 1], ess_bulk = m[, 2]))
+  }
   r <- .C("potus_R_diagnostics", as.integer(fit$handles), length(fit$handles), as.integer(c(col_begin, col_end)), rhat = double(n), ess = double(n),
           status = integer(1))
   .potus_check(r$status)

@@ -232,6 +232,12 @@ int potus_write_array(int handle, int col_begin, int col_end, double *out);
 /* The same rows written into DEVICE memory of the handle's GPU (e.g. the data_ptr() of a torch tensor that an RCCL
  * all-gather then sends: the draws-of-interest never visit the host). */
 int potus_write_array_device(int handle, int col_begin, int col_end, void *out_device);
+/* rstan::extract(out, pars)[[1]] (final_2016.R:556, :708) as R stores it, filled in place in ONE pass: `out` = a column-major matrix
+ * [rows, col_end - col_begin] whose row chain_global * n_saved + iteration holds a draw -- chains merged chain after chain, the handles' chains in the order
+ * listed.  out = NULL: only *rows_out (the draws the handles hold) is set, to size the result; otherwise rows must equal it.  This is what the .Call()
+ * wrapper R/src/potus_call.c hands an allocMatrix'ed result to (long vectors welcome); the .C() path returns [iteration][chain][column] rows that the R shim
+ * must permute -- two more copies of the block. */
+int potus_extract_matrix(const int *handles, int n_handles, int col_begin, int col_end, double *out, long long rows, long long *rows_out);
 
 /* One CmdStan-format CSV per chain (<dir>/<basename>-<chain>.csv) readable by
  * rstan::read_stan_csv (final_2016.R:543). */

@@ -148,3 +148,28 @@ def test_the_library_was_built_from_these_sources():
     stamp = g.PKG / "libpotus_hmc.so.src"
     assert stamp.exists(), "run `python __graft_entry__.py` (build())"
     assert stamp.read_text().strip() == g._digest(deps), "libpotus_hmc.so is older than its sources: run `python __graft_entry__.py`"
+
+
+def test_dot_call_wrappers_compile_and_fail_like_r_errors(tmp_path):
+    """R/src/potus_call.c -- the .Call() entry points the R shim prefers when they are loaded (north_star: "thin C-ABI .Call()/dyn.load FFI") -- compiles
+    warning-free against the stub R API of tests/r_stub/ (R is not in the image), exports the four entry points R/potus_sampling.R names, and turns a
+    library error into an R error carrying the library's message, with the PROTECT stack balanced (without a GPU every call ends that way:
+    tests/test_gpu_boundary.py drives the wrappers for real)."""
+    import ctypes as C
+    from conftest import build_call_wrapper, call_wrapper_int
+    W = build_call_wrapper(tmp_path)
+    shim = open(ROOT / "R" / "potus_sampling.R").read()
+    for name in ("potus_call_extract", "potus_call_diagnostics", "potus_call_sampler_params", "potus_call_version"):
+        assert hasattr(W, name)
+    assert '.Call("potus_call_extract"' in shim and '.Call("potus_call_diagnostics"' in shim and 'is.loaded("potus_call_extract")' in shim
+    v = W.stub_call0(C.cast(W.potus_call_version, C.c_void_p))
+    assert W.stub_string(v).decode().startswith("potus_hmc 0.5") and W.stub_last_error() == b""
+    h = call_wrapper_int(W, [12345])                                   # no such handle
+    for fn in (W.potus_call_extract, W.potus_call_diagnostics):
+        r = W.stub_call3(C.cast(fn, C.c_void_p), h, call_wrapper_int(W, [0]), call_wrapper_int(W, [7]))
+        assert b"libpotus_hmc error" in W.stub_last_error() and b"handle" in W.stub_last_error(), W.stub_last_error()
+        assert W.XLENGTH(r) == 0 and W.stub_protect_depth() == 0       # R_NilValue came back through the error handler; nothing left protected
+    W.stub_call1(C.cast(W.potus_call_sampler_params, C.c_void_p), call_wrapper_int(W, [12345]))
+    assert b"libpotus_hmc error" in W.stub_last_error() and W.stub_protect_depth() == 0
+    W.stub_release_all()
+    assert W.stub_live_bytes() == 0

@@ -410,6 +410,42 @@ def test_bench_two_ranks_end_to_end_gloo_development_mode(tmp_path):
     assert d["config"]["posteriors"]["2016"]["pooled_draws"] == 8 * 20 and d["leapfrogs"] > 0 and d["roofline"]["frac"] > 0
 
 
+def test_dot_call_wrappers_fill_r_matrices_in_place(cases, tmp_path):
+    """R/src/potus_call.c driven through the stub R API (tests/r_stub/: R is not in the image): potus_call_extract allocates ONE [draws, columns] matrix
+    and potus_extract_matrix fills it in R's column-major order, chains merged chain after chain over TWO handles (the second on `second_device()`) --
+    equal, element for element, to what the .C() path + the shim's aperm / rbind produce (StanFit.extract restates that); the sampler columns and the
+    device diagnostics likewise.  This is rstan::extract(out, pars = "predicted_score")[[1]] of final_2016.R:708 without its two extra copies."""
+    from conftest import build_call_wrapper, call_wrapper_int, second_device
+    W = build_call_wrapper(tmp_path)
+    data, variant = cases["small_full"]
+    kw = dict(num_warmup=20, num_samples=12, seed=1843)
+    hs = [Handle(data, variant, chains=3, chain_id_offset=0, **kw), Handle(data, variant, chains=2, chain_id_offset=3, device=second_device(), **kw)]
+    for h in hs:
+        h.init(); h.run(32)
+    ids = call_wrapper_int(W, [h.h for h in hs])
+    lay = hs[0].layout
+    for name in ("predicted_score", "mu_b", "raw_mu_c"):
+        a, b_, dims = lay[name]
+        r = W.stub_call3(C.cast(W.potus_call_extract, C.c_void_p), ids, call_wrapper_int(W, [a]), call_wrapper_int(W, [b_]))
+        assert W.stub_last_error() == b"" and W.XLENGTH(r) == 5 * 12 * (b_ - a) and W.stub_protect_depth() == 0
+        got = np.ctypeslib.as_array(W.REAL(r), shape=(b_ - a, 5 * 12)).T            # column-major [draws, columns]
+        want = np.concatenate([h.write_array(a, b_, 12).transpose(1, 0, 2).reshape(-1, b_ - a) for h in hs])   # chain-major merge, handle after handle
+        assert np.array_equal(got, want), name
+    r = W.stub_call1(C.cast(W.potus_call_sampler_params, C.c_void_p), ids)
+    sp = np.ctypeslib.as_array(W.REAL(r), shape=(7, 60)).T
+    assert np.array_equal(sp, np.concatenate([h.draws()[:, :, :7].reshape(-1, 7) for h in hs]))
+    a, b_, _ = lay["mu_b"]
+    r = W.stub_call3(C.cast(W.potus_call_diagnostics, C.c_void_p), ids, call_wrapper_int(W, [a]), call_wrapper_int(W, [b_]))
+    dgm = np.ctypeslib.as_array(W.REAL(r), shape=(2, b_ - a))
+    rh, es = sampler.device_diagnostics(hs, a, b_)
+    assert np.array_equal(dgm[0], rh, equal_nan=True) and np.array_equal(dgm[1], es, equal_nan=True)
+    bad = W.stub_call3(C.cast(W.potus_call_extract, C.c_void_p), ids, call_wrapper_int(W, [5]), call_wrapper_int(W, [5]))   # an empty range is an R error
+    assert b"bad column range" in W.stub_last_error() and W.XLENGTH(bad) == 0 and W.stub_protect_depth() == 0
+    W.stub_release_all()
+    for h in hs:
+        h.close()
+
+
 def test_bench_single_process_gives_the_pooled_diagnostics_of_the_two_rank_run(tmp_path):
     """`bench.py --gpus 2 --single-process`: the path the reference-side binding takes -- R is ONE process, potus_sample(gpus = 0:1),
     final_2016.R:536 -- two handles of four chains under potus_run_many, the second on `second_device()` where the box has one (else both on GPU 0), pooled

@@ -2805,6 +2805,77 @@ int potus_write_array(int handle, int col_begin, int col_end, double *out) {
   return write_array_range(sp, n_saved, col_begin, col_end, out);
 }
 
+// rstan::extract(out, pars)[[1]] as R stores it, in ONE pass and in place: `out` is a column-major matrix [rows, col_end - col_begin] whose row
+// chain_global * n_saved + iteration holds a draw -- chains merged chain after chain, the handles' chains in the order listed (R/potus_sampling.R deals
+// consecutive chain ids to consecutive handles).  *rows_out = the rows the listed handles hold (call with out = NULL to size the result); rows must equal it.
+// What R's .Call() wrapper (R/src/potus_call.c) fills an allocVector'ed result with: no second copy in R, long vectors welcome (the .C() path hands R
+// [iteration][chain][column] rows, which the shim then permutes -- two more copies of 0.83 GB for predicted_score of 8 x 1000 draws, final_2016.R:708).
+__global__ __launch_bounds__(256) void k_rows_to_r_matrix(const double *in, double *out, int n_saved, int chains, int ncol) {
+  // in [iteration][chain][column] -> out [column][chain][iteration]; tiles of 32 x 32 through LDS
+  __shared__ double tile[32][33];
+  const long long nrow = (long long)n_saved * chains;
+  const long long r0 = (long long)blockIdx.x * 32;
+  const int c0 = (int)blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const long long r = r0 + k;
+    tile[k][tx] = (r < nrow && c0 + tx < ncol) ? in[r * ncol + c0 + tx] : 0.0;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const long long r = r0 + tx;                                   // source row = iteration * chains + chain
+    if (r < nrow && c0 + k < ncol) {
+      const long long it = r / chains, ch = r % chains;
+      out[(long long)(c0 + k) * nrow + ch * n_saved + it] = tile[tx][k];
+    }
+  }
+}
+int potus_extract_matrix(const int *handles, int n_handles, int col_begin, int col_end, double *out, long long rows, long long *rows_out) {
+  if (!handles || n_handles < 1) return fail(POTUS_ERR_ARG, "potus_extract_matrix: null handle list");
+  std::vector<Sampler *> sps;
+  std::vector<int> saved(n_handles, 0), devs;
+  long long total = 0;
+  for (int i = 0; i < n_handles; i++) {
+    Sampler *sp = get(handles[i]);
+    if (!sp) return fail(POTUS_ERR_STATE, "potus_extract_matrix: bad handle %d", handles[i]);
+    for (int j = 0; j < i; j++) if (handles[j] == handles[i]) return fail(POTUS_ERR_ARG, "potus_extract_matrix: handle %d listed twice", handles[i]);
+    if (i > 0 && sp->L.ncols != sps[0]->L.ncols) return fail(POTUS_ERR_ARG, "potus_extract_matrix: the handles hold different posteriors");
+    sps.push_back(sp); devs.push_back(sp->device);
+  }
+  if (col_begin < 0 || col_end > sps[0]->L.ncols || col_begin >= col_end) return fail(POTUS_ERR_ARG, "bad column range [%d,%d) of %d", col_begin, col_end, sps[0]->L.ncols);
+  DeviceGuard guard;
+  DeviceLocks lock(devs);
+  for (int i = 0; i < n_handles; i++) {
+    HIP_TRY(hipSetDevice(sps[i]->device));
+    const int rc = saved_count(sps[i], &saved[i]);
+    if (rc) return rc;
+    if (i > 0 && saved[i] != saved[0]) return fail(POTUS_ERR_STATE, "potus_extract_matrix: the handles have saved different numbers of draws (%d, %d)", saved[0], saved[i]);
+    total += (long long)saved[i] * sps[i]->R.chains;
+  }
+  if (rows_out) *rows_out = total;
+  if (!out) return 0;
+  if (rows != total) return fail(POTUS_ERR_ARG, "potus_extract_matrix: the result has %lld rows, the handles hold %lld draws", rows, total);
+  const int nsel = col_end - col_begin;
+  long long off = 0;
+  for (int i = 0; i < n_handles; i++) {
+    Sampler *sp = sps[i];
+    const long long nrow = (long long)saved[i] * sp->R.chains;
+    if (nrow == 0) continue;
+    HIP_TRY(hipSetDevice(sp->device));
+    DevBufs tmp;
+    double *rowsd = nullptr, *colsd = nullptr;
+    HIP_TRY(tmp.alloc(&rowsd, (size_t)nrow * nsel * 8)); HIP_TRY(tmp.alloc(&colsd, (size_t)nrow * nsel * 8));
+    const int rc = write_array_range(sp, saved[i], col_begin, col_end, rowsd, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_rows_to_r_matrix, dim3((unsigned)((nrow + 31) / 32), (unsigned)((nsel + 31) / 32)), dim3(256), 0, sp->stream, rowsd, colsd, saved[i], sp->R.chains, nsel);
+    HIP_TRY(hipGetLastError());
+    // column k of this handle's block -> rows [off, off + nrow) of column k of the result
+    HIP_TRY(hipMemcpy2DAsync(out + off, (size_t)total * 8, colsd, (size_t)nrow * 8, (size_t)nrow * 8, (size_t)nsel, hipMemcpyDeviceToHost, sp->stream));
+    HIP_TRY(hipStreamSynchronize(sp->stream));
+    off += nrow;
+  }
+  return 0;
+}
+
 // The same rows written straight into a DEVICE buffer of the sampler's GPU (e.g. a torch tensor's data_ptr()): what
 // the RCCL all-gather of the draws-of-interest sends, without a trip through host memory.
 int potus_write_array_device(int handle, int col_begin, int col_end, void *out_device) {

@@ -98,7 +98,7 @@ EXPORTS = [
     "potus_version", "potus_last_error", "potus_default_opts", "potus_num_params", "potus_num_columns",
     "potus_column_name", "potus_create", "potus_destroy", "potus_cus_per_chain", "potus_clusters_per_chain", "potus_plan_cus_per_chain", "potus_plan_sides", "potus_twin_stats", "potus_log_prob_grad", "potus_init", "potus_run", "potus_run_many",
     "potus_iterations_done", "potus_total_leapfrogs", "potus_chain_status", "potus_get_adaptation",
-    "potus_get_dense_metric", "potus_dense_timing", "potus_dense_adapt_timing", "potus_dense_pool_window", "potus_dense_pool_finish", "potus_dense_check", "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_array_device", "potus_write_stan_csv",
+    "potus_get_dense_metric", "potus_dense_timing", "potus_dense_adapt_timing", "potus_dense_pool_window", "potus_dense_pool_finish", "potus_dense_check", "potus_get_draws", "potus_draws_device_ptr", "potus_write_array", "potus_write_array_device", "potus_extract_matrix", "potus_write_stan_csv",
     "potus_last_run_timing", "potus_posterior_summary", "potus_posterior_summary_many", "potus_backtest_scores",
     "potus_diagnostics", "potus_diagnostics_device", "potus_check_convergence",
     "potus_R_create", "potus_R_init", "potus_R_run", "potus_R_run_many", "potus_R_num_columns", "potus_R_saved_count",
