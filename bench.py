@@ -102,7 +102,8 @@ def launch_ranks(n):
     import subprocess
     have = visible_gpus()
     if os.environ.get("POTUS_DIST_BACKEND") != "gloo" and have < n:
-        print(f"bench.py: --gpus {n} but {have} HIP device(s) visible on this box: refusing to run (no line is printed for a run that did not happen)", file=sys.stderr)
+        print(f"bench.py: --gpus {n} but {have} HIP device(s) visible on this box: refusing to run (no line is printed for a run that "
+                f"did not happen)", file=sys.stderr)
         return 2
     if have < 1:
         print("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)", file=sys.stderr)
@@ -113,7 +114,8 @@ def launch_ranks(n):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port),
            str(Path(__file__).resolve())] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
 
@@ -147,9 +149,11 @@ def side_measurements(seed, budget_s=200.0, headline=None):
             continue
         t0 = time.perf_counter()
         try:
-            r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--config", str(cfg)] + ([] if "--seed" in extra else ["--seed", str(seed)]) +
+            r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--config",
+                    str(cfg)] + ([] if "--seed" in extra else ["--seed", str(seed)]) +
                                ["--no-cpu-baseline", "--no-saturated", "--no-side"] + extra,
-                               capture_output=True, text=True, timeout=min(tmo, left), env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+                               capture_output=True, text=True, timeout=min(tmo, left), env={k: v for k,
+                                       v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or len(lines) != 1:
                 out[key] = {"error": (r.stderr or r.stdout)[-300:], "rc": r.returncode}
@@ -159,23 +163,32 @@ def side_measurements(seed, budget_s=200.0, headline=None):
                 d["seed"] = int(extra[extra.index("--seed") + 1])
                 seed_runs.append(seed_summary(d))
                 continue
-            e = {"baseline_config_index": cfg, "command": f"bench.py --config {cfg}", "value": d["value"], "unit": d["unit"], "metric": d["metric"], "steps": d["steps"],
-                 "ms_per_step": d["ms_per_step"], "workload": d["config"]["workload"], "wall_seconds_with_process_start": time.perf_counter() - t0}
+            e = {"baseline_config_index": cfg, "command": f"bench.py --config {cfg}", "value": d["value"], "unit": d["unit"],
+                    "metric": d["metric"], "steps": d["steps"],
+                 "ms_per_step": d["ms_per_step"], "workload": d["config"]["workload"],
+                         "wall_seconds_with_process_start": time.perf_counter() - t0}
             for k in ("seconds", "leapfrogs", "ess_bulk_min", "ess_per_sec", "rhat_max", "us_per_leapfrog_per_chain"):
                 if k in d:
                     e[k] = d[k]
             if "roofline" in d:
-                e["roofline"] = {k: d["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms_total", "leapfrogs_in_launches",
-                                                                "matrix_passes", "avg_pass_ms", "matrix_bytes_streamed", "metric_storage", "pooled_metric", "mfma") if k in d["roofline"]}
+                e["roofline"] = {k: d["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
+                        "launch_ms_total", "leapfrogs_in_launches",
+                                                                "matrix_passes", "avg_pass_ms", "matrix_bytes_streamed", "metric_storage",
+                                                                        "pooled_metric", "mfma") if k in d["roofline"]}
             if "runs" in d:     # configs[0]: the reference's scripted calls, one by one
-                e["runs"] = [{"call": r_["call"], "posterior": r_["posterior"], "variant": r_["variant"], "chains": r_["chains"], "iter_warmup": r_["iter_warmup"],
-                              "iter_sampling": r_["iter_sampling"], **{k: r_["gpu"][k] for k in ("seconds", "leapfrogs", "leapfrogs_per_sec", "ess_bulk_min", "ess_per_sec",
-                                                                                               "divergent_transitions", "cus_per_chain", "clusters_per_chain")}} for r_ in d["runs"]]
+                e["runs"] = [{"call": r_["call"], "posterior": r_["posterior"], "variant": r_["variant"], "chains": r_["chains"],
+                        "iter_warmup": r_["iter_warmup"],
+                              "iter_sampling": r_["iter_sampling"], **{k: r_["gpu"][k] for k in ("seconds", "leapfrogs",
+                                      "leapfrogs_per_sec", "ess_bulk_min", "ess_per_sec",
+                                                                                               "divergent_transitions", "cus_per_chain",
+                                                                                                       "clusters_per_chain")}} for r_ in d["runs"]]
             if "dense" in d:
-                e["dense"] = {k: d["dense"][k] for k in ("window_ends", "window_end_seconds", "cholesky_seconds", "cholesky_tflops", "adapted_phase") if k in d["dense"]}
+                e["dense"] = {k: d["dense"][k] for k in ("window_ends", "window_end_seconds", "cholesky_seconds", "cholesky_tflops",
+                        "adapted_phase") if k in d["dense"]}
                 e["max_depth"] = d["config"].get("max_depth")
             if "posteriors" in d["config"]:
-                e["posteriors"] = {n: {k: v[k] for k in ("chains_per_gpu", "D", "cus_per_chain", "clusters_per_chain", "divergent_transitions", "ess_bulk_min", "rhat_max") if k in v}
+                e["posteriors"] = {n: {k: v[k] for k in ("chains_per_gpu", "D", "cus_per_chain", "clusters_per_chain",
+                        "divergent_transitions", "ess_bulk_min", "rhat_max") if k in v}
                                    for n, v in d["config"]["posteriors"].items()}
             out[key] = e
         except subprocess.TimeoutExpired:
@@ -185,19 +198,26 @@ def side_measurements(seed, budget_s=200.0, headline=None):
     if seed_runs:
         def mmm(k):
             v = sorted(r[k] for r in seed_runs if r.get(k) is not None)
-            return {"min": v[0], "median": v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]), "max": v[-1]} if v else None
+            return {"min": v[0], "median": v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]),
+                    "max": v[-1]} if v else None
         deepest = [max(r["treedepth_max_per_chain"]) for r in seed_runs if r.get("treedepth_max_per_chain")]
-        out["seeds"] = {"runs": seed_runs, "leapfrogs_per_sec": mmm("leapfrogs_per_sec"), "seconds": mmm("seconds"), "ess_per_sec": mmm("ess_per_sec"),
+        out["seeds"] = {"runs": seed_runs, "leapfrogs_per_sec": mmm("leapfrogs_per_sec"), "seconds": mmm("seconds"),
+                "ess_per_sec": mmm("ess_per_sec"),
                         "deepest_tree_by_seed": deepest,
-                        "note": "configs[1] (8 chains x (1000 + 1000), the default line's command) under the default seed and the next two; the first run is the "
-                                "default line itself.  A launch lasts as long as its slowest chain: a chain that adapts into trees one doubling deeper "
+                        "note": "configs[1] (8 chains x (1000 + 1000), the default line's command) under the default seed and the next "
+                                "two; the first run is the "
+                                "default line itself.  A launch lasts as long as its slowest chain: a chain that adapts into "
+                                        "trees one doubling deeper "
                                 "than the others sets the time of every sampling launch"}
     # the default line's figures first, so that a reader of `side` sees the spread before anything else
     out = {**({"seeds": out.pop("seeds")} if "seeds" in out else {}), **out}
     out["note"] = ("GPU-only runs of `bench.py --config X` in child processes after the default line's timed region: same box, same clock; "
-                   "configs[0] = the reference's scripted sampler calls (final_2016.R:533-541 and its 2012 / 2008 siblings), configs[3] = the three backtests "
-                   "concurrently on this one GPU (4 chains each), configs[4]_preset = the dense-metric stress shape in its driver-runnable preset, "
-                   "configs[4]_pooled = the same preset with potus_opts.pooled_metric (one inverse metric per GPU: a declared deviation from Stan)")
+                   "configs[0] = the reference's scripted sampler calls (final_2016.R:533-541 and its 2012 / 2008 siblings), "
+                           "configs[3] = the three backtests "
+                   "concurrently on this one GPU (4 chains each), configs[4]_preset = the dense-metric stress shape in its "
+                           "driver-runnable preset, "
+                   "configs[4]_pooled = the same preset with potus_opts.pooled_metric (one inverse metric per GPU: a declared "
+                           "deviation from Stan)")
     out["seconds"] = time.perf_counter() - t_all
     return out
 
@@ -208,17 +228,21 @@ def single_process_side(args, n):
     import subprocess
     t0 = time.perf_counter()
     try:
-        cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", str(n), "--single-process", "--seed", str(args.seed), "--steps", str(args.steps), "--warmup", "1"]
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", str(n), "--single-process", "--seed", str(args.seed), "--steps",
+                str(args.steps), "--warmup", "1"]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=420,
-                           env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")})
+                           env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR",
+                                   "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")})
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or len(lines) != 1:
             return {"error": (r.stderr or r.stdout)[-300:], "rc": r.returncode}
         d = json.loads(lines[0])
-        return {"launcher": d["launcher"], "command": f"bench.py --gpus {n} --single-process", "value": d["value"], "unit": d["unit"], "n_gpus": d["n_gpus"], "seconds": d["seconds"],
+        return {"launcher": d["launcher"], "command": f"bench.py --gpus {n} --single-process", "value": d["value"], "unit": d["unit"],
+                "n_gpus": d["n_gpus"], "seconds": d["seconds"],
                 "leapfrogs": d["leapfrogs"], "ess_bulk_min": d["ess_bulk_min"], "ess_per_sec": d["ess_per_sec"], "rhat_max": d["rhat_max"],
                 "diagnostics_seconds": d["diagnostics_seconds"], "wall_seconds_with_process_start": time.perf_counter() - t0,
-                "note": "ONE process, one handle per GPU under potus_run_many, pooled R-hat / ESS through potus_diagnostics (peer copies): what the R shim's "
+                "note": "ONE process, one handle per GPU under potus_run_many, pooled R-hat / ESS through potus_diagnostics (peer "
+                        "copies): what the R shim's "
                         "potus_sample(gpus = ...) does; same chains, same draws as the multi-process line above"}
     except subprocess.TimeoutExpired:
         return {"error": f"timed out after {time.perf_counter() - t0:.0f} s"}
@@ -275,7 +299,8 @@ def single_process_line(args):
         a_mu, a_ps = hs[0].layout["mu_b"][0], hs[0].layout["predicted_score"][0]
         td0 = time.perf_counter()
         parts = [device_diagnostics(hs, 0, 1), device_diagnostics(hs, a_mu + S * (T - 1), a_mu + S * T)]
-        rp, ep = device_diagnostics(hs, a_ps + (T - 1), a_ps + (T - 1) + T * (S - 1) + 1)             # predicted_score[T, s]: every T-th column
+        rp, ep = device_diagnostics(hs, a_ps + (T - 1),
+                a_ps + (T - 1) + T * (S - 1) + 1)             # predicted_score[T, s]: every T-th column
         parts.append((rp[::T], ep[::T]))
         diag_s = time.perf_counter() - td0
         rhat, ess = float(np.nanmax(np.concatenate([p_[0] for p_ in parts]))), float(np.nanmin(np.concatenate([p_[1] for p_ in parts])))
@@ -285,19 +310,29 @@ def single_process_line(args):
     bpl = algorithmic_bytes_per_leapfrog(data, variant)
     K, sides = hs[0].cus_per_chain, hs[0].clusters_per_chain
     achieved = bpl * sum(lf) / n / (kernel_ms * 1e-3) / 1e9        # per GPU: the devices run side by side
-    line = {"metric": "leapfrog_steps_per_sec", "value": sum(lf) / elapsed, "unit": "leapfrogs/s", "n_gpus": n, "steps": steps, "warmup": warmup,
+    line = {"metric": "leapfrog_steps_per_sec", "value": sum(lf) / elapsed, "unit": "leapfrogs/s", "n_gpus": n, "steps": steps,
+            "warmup": warmup,
             "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "poll data of the reference (fixtures built from its CSVs, tests/golden/data_*.npz); random inits", "launcher": "single_process",
-            "config": {"workload": f"configs[{1 if n == 1 else 2}]: 2016 backtest, adaptive NUTS diag_e, {C} chains per MI355X x {n}, {nw} warmup + {ns} sampling, seed {args.seed}; "
-                                   f"ONE process, {n} handles under potus_run_many (the R-facing path: potus_sample(gpus = ...)); a step = one launch chunk of {chunk} transitions",
-                       "baseline_config_index": 1 if n == 1 else 2, "chains_per_gpu": C, "total_chains": C * n, "devices": devs, "iter_warmup": nw, "iter_sampling": ns,
-                       "parallelism": f"one host process, {n} handles of {C} chains, one per device; pooled R-hat / ESS through potus_diagnostics (peer copies), no RCCL",
+            "data": "poll data of the reference (fixtures built from its CSVs, tests/golden/data_*.npz); random inits",
+                    "launcher": "single_process",
+            "config": {"workload": f"configs[{1 if n == 1 else 2}]: 2016 backtest, adaptive NUTS diag_e, {C} chains per MI355X x {n}, "
+                                   f"{nw} warmup + {ns} sampling, seed {args.seed}; "
+                                   f"ONE process, {n} handles under potus_run_many (the R-facing path: potus_sample(gpus = "
+                                           f"...)); a step = one launch chunk of {chunk} transitions",
+                       "baseline_config_index": 1 if n == 1 else 2, "chains_per_gpu": C, "total_chains": C * n, "devices": devs,
+                               "iter_warmup": nw, "iter_sampling": ns,
+                       "parallelism": f"one host process, {n} handles of {C} chains, one per device; pooled R-hat / ESS through "
+                                      f"potus_diagnostics (peer copies), no RCCL",
                        "cus_per_chain": K, "clusters_per_chain": sides},
-            "leapfrogs": int(sum(lf)), "seconds": elapsed, "sampling_seconds": samp, "ess_bulk_min": ess, "ess_per_sec": (ess / samp) if ess else None, "rhat_max": rhat,
+            "leapfrogs": int(sum(lf)), "seconds": elapsed, "sampling_seconds": samp, "ess_bulk_min": ess,
+                    "ess_per_sec": (ess / samp) if ess else None, "rhat_max": rhat,
             "diagnostics_seconds": diag_s,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_cl_run" if K > 1 else "k_run", "algorithmic_bytes_per_leapfrog": bpl, "leapfrogs_in_launches": int(sum(lf)), "launch_ms_total": kernel_ms,
-                         "note": "per GPU: leapfrogs of all handles / n_gpus x the algorithmic bytes / the launches' time (the handles of a step run side by side)"}}
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None,
+                         "kernel": "k_cl_run" if K > 1 else "k_run", "algorithmic_bytes_per_leapfrog": bpl,
+                                 "leapfrogs_in_launches": int(sum(lf)), "launch_ms_total": kernel_ms,
+                         "note": "per GPU: leapfrogs of all handles / n_gpus x the algorithmic bytes / the launches' time (the handles "
+                                 "of a step run side by side)"}}
     for h in hs:
         h.close()
     return line
@@ -367,30 +402,41 @@ def cpu_baseline(data, variant, chains, seed, nw, ns, short, budget=12.0, loop_b
     cols = np.stack([r[2] for r in sres])                                    # [chain, draw, 1 + 2 S]
     s_ess = ess_min(cols)
     s_secs, s_samp = float((st[:, 0] + st[:, 1]).max()), float(st[:, 1].max())   # the chains run side by side: the slowest sets the time
-    out = dict(value=rate, unit="leapfrogs/s", cores=procs, host_cores_total=os.cpu_count(), kind="port", leapfrogs_per_sec_per_core=rate / procs,
-               value_is=f"the rate of the FIRST {int(timing[:, 4].min())}-{int(timing[:, 4].max())} iterations (early warm-up: the longest trees) of the configured "
-                        f"{nw} + {ns}, {budget:.0f} s per chain -- a bounded sample, not a complete run; the like-for-like pair, both sides run to the end, is short_config",
+    out = dict(value=rate, unit="leapfrogs/s", cores=procs, host_cores_total=os.cpu_count(), kind="port",
+            leapfrogs_per_sec_per_core=rate / procs,
+               value_is=f"the rate of the FIRST {int(timing[:, 4].min())}-{int(timing[:, 4].max())} iterations (early warm-up: the "
+                        f"longest trees) of the configured "
+                        f"{nw} + {ns}, {budget:.0f} s per chain -- a bounded sample, not a complete run; the like-for-like pair, "
+                                f"both sides run to the end, is short_config",
                iterations_sampled=[int(timing[:, 4].min()), int(timing[:, 4].max())], iterations_configured=nw + ns,
-               sample=f"the first {int(timing[:, 4].min())}-{int(timing[:, 4].max())} iterations of the same run ({procs} chains, ids 1..{procs}, seed {seed}, "
+               sample=f"the first {int(timing[:, 4].min())}-{int(timing[:, 4].max())} iterations of the same run ({procs} chains, ids "
+                       f"1..{procs}, seed {seed}, "
                       f"{nw} warm-up + {ns} sampling configured) on {procs} host processes, cut after {budget:.0f} s each: "
                       f"{int(timing[:, 2:4].sum())} leapfrogs; scan/sparse gradient, pooled-buffer tree (the fastest form of the port)",
-               cores_note=f"one process per chain, as the reference runs its chains (final_2016.R:536): {procs} of the box's {os.cpu_count()} host cores are used",
+               cores_note=f"one process per chain, as the reference runs its chains (final_2016.R:536): {procs} of the box's "
+                          f"{os.cpu_count()} host cores are used",
                seconds=wall, **loop,
-               leapfrog_loop_note="plain leapfrog loops (unit metric, eps 0.01, no tree, no U-turn bookkeeping) of the literal stan:86 recursion and of the "
+               leapfrog_loop_note="plain leapfrog loops (unit metric, eps 0.01, no tree, no U-turn bookkeeping) of the literal stan:86 "
+                                  "recursion and of the "
                                   f"scan/sparse gradient, {procs} processes x {loop_budget:.0f} s each: the rate of the arithmetic alone",
-               short_config=dict(iter_warmup=snw, iter_sampling=sns, chains=procs, seed=seed, leapfrogs=int(st[:, 2:4].sum()), seconds=s_secs,
+               short_config=dict(iter_warmup=snw, iter_sampling=sns, chains=procs, seed=seed, leapfrogs=int(st[:, 2:4].sum()),
+                       seconds=s_secs,
                                  sampling_seconds=s_samp, leapfrogs_per_sec=float(st[:, 2:4].sum()) / s_secs, ess_bulk_min=s_ess,
                                  ess_per_sec=s_ess / s_samp, wall_seconds=short_wall,
-                                 note="a complete run of the port, measured: min bulk-ESS over lp__, mu_b[:, T], predicted_score[T, :] of its own "
+                                 note="a complete run of the port, measured: min bulk-ESS over lp__, mu_b[:, T], predicted_score[T, "
+                                         ":] of its own "
                                       "draws / the sampling time of its slowest chain"))
     full = ROOT / "tests" / "golden" / "posterior_2016.npz"
     if full.exists() and int(data["T"]) == 254:
         g = np.load(full)
         lf, sec = float(g["leapfrogs"].sum()), float(g["seconds"].max())
         ess = float(min(g["lp__ess_bulk"].min(), g["mu_b_T__ess_bulk"].min(), g["predicted_score_T__ess_bulk"].min()))
-        out["full_run_in_build_container"] = dict(leapfrogs_per_sec=lf / sec, ess_bulk_min=ess, ess_per_sec_total_time=ess / sec, seconds=sec,
-                                                  note="the whole 8 x (1000 + 1000) run of the oracle (scan/sparse gradient, recursive tree) behind "
-                                                       "tests/golden/posterior_2016.npz, 8 processes on the build container's 8 vCPUs -- not this box")
+        out["full_run_in_build_container"] = dict(leapfrogs_per_sec=lf / sec, ess_bulk_min=ess, ess_per_sec_total_time=ess / sec,
+                seconds=sec,
+                                                  note="the whole 8 x (1000 + 1000) run of the oracle (scan/sparse gradient, "
+                                                          "recursive tree) behind "
+                                                       "tests/golden/posterior_2016.npz, 8 processes on the build container's 8 "
+                                                               "vCPUs -- not this box")
     return out
 
 
@@ -404,16 +450,20 @@ def reference_sampler_calls(local, seed, cus_per_chain, twin, max_depth, cpu=Tru
     import torch
     from us_potus_model_amd import Handle, dataprep
     gold = ROOT / "tests" / "golden"
-    calls = [("final_2016.R:533-541 as scripted", "2016", "full", 6, 500, 500), ("BASELINE configs[0]: 4 chains x 500 iterations (rstan: 250 + 250)", "2016", "full", 4, 250, 250),
-             ("final_2012.R:558-569 as scripted", "2012", "no_mode_adjustment", 6, 500, 500), ("final_2008.R:562-573 as scripted", "2008", "no_mode_adjustment", 6, 500, 500)]
+    calls = [("final_2016.R:533-541 as scripted", "2016", "full", 6, 500, 500),
+            ("BASELINE configs[0]: 4 chains x 500 iterations (rstan: 250 + 250)", "2016", "full", 4, 250, 250),
+             ("final_2012.R:558-569 as scripted", "2012", "no_mode_adjustment", 6, 500, 500), ("final_2008.R:562-573 as scripted", "2008",
+                     "no_mode_adjustment", 6, 500, 500)]
     out = []
     for label, year, variant, chains, nw, ns in calls:
         data = dataprep.load_npz(gold / f"data_{year}.npz")["data"]
         S, T = int(data["S"]), int(data["T"])
         refresh = max(ns // 10, 1)
-        hw = Handle(data, variant, chains=chains, num_warmup=refresh, num_samples=0, seed=seed + 1, device=local, cus_per_chain=cus_per_chain, twin=twin, max_depth=max_depth)
+        hw = Handle(data, variant, chains=chains, num_warmup=refresh, num_samples=0, seed=seed + 1, device=local,
+                cus_per_chain=cus_per_chain, twin=twin, max_depth=max_depth)
         hw.init(); hw.run(refresh); hw.close()                       # untimed: code objects, clocks
-        h = Handle(data, variant, chains=chains, num_warmup=nw, num_samples=ns, seed=seed, device=local, cus_per_chain=cus_per_chain, twin=twin, max_depth=max_depth)
+        h = Handle(data, variant, chains=chains, num_warmup=nw, num_samples=ns, seed=seed, device=local, cus_per_chain=cus_per_chain,
+                twin=twin, max_depth=max_depth)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         h.init()
@@ -429,8 +479,10 @@ def reference_sampler_calls(local, seed, cus_per_chain, twin, max_depth, cpu=Tru
         cols = np.concatenate([lpc, mu, 1.0 / (1.0 + np.exp(-mu))], axis=2)
         g_ess, g_lf = ess_min(cols), h.total_leapfrogs()
         st, dv = h.chain_status()
-        run = {"call": label, "posterior": year, "variant": variant, "chains": chains, "iter_warmup": nw, "iter_sampling": ns, "seed": seed, "D": h.D,
-               "gpu": {"seconds": t2 - t0, "sampling_seconds": t2 - t1, "leapfrogs": g_lf, "leapfrogs_per_sec": g_lf / (t2 - t0), "ess_bulk_min": g_ess,
+        run = {"call": label, "posterior": year, "variant": variant, "chains": chains, "iter_warmup": nw, "iter_sampling": ns,
+                "seed": seed, "D": h.D,
+               "gpu": {"seconds": t2 - t0, "sampling_seconds": t2 - t1, "leapfrogs": g_lf, "leapfrogs_per_sec": g_lf / (t2 - t0),
+                       "ess_bulk_min": g_ess,
                        "ess_per_sec": g_ess / (t2 - t1), "divergent_transitions": int(sum(dv)), "cus_per_chain": h.cus_per_chain,
                        "clusters_per_chain": h.clusters_per_chain, "mean_predicted_score_T": cols[:, :, 1 + S:].mean(axis=(0, 1)).tolist()}}
         h.close()
@@ -438,17 +490,22 @@ def reference_sampler_calls(local, seed, cus_per_chain, twin, max_depth, cpu=Tru
             procs = max(1, min(chains, os.cpu_count() or 1))
             tc0 = time.perf_counter()
             with mp.get_context("spawn").Pool(procs) as pool:
-                res = sorted(pool.map(_cpu_nuts_worker, [(data, variant, c + 1, nw, ns, seed, 0.0) for c in range(chains)]), key=lambda r: r[0])
+                res = sorted(pool.map(_cpu_nuts_worker, [(data, variant, c + 1, nw, ns, seed, 0.0) for c in range(chains)]),
+                        key=lambda r: r[0])
             wall = time.perf_counter() - tc0
             tm = np.stack([r[1] for r in res])
             ccols = np.stack([r[2] for r in res])
             c_ess = ess_min(ccols)
             c_secs, c_samp = float((tm[:, 0] + tm[:, 1]).max()), float(tm[:, 1].max())
-            run["cpu_port"] = {"seconds": c_secs, "sampling_seconds": c_samp, "wall_seconds_with_process_start": wall, "leapfrogs": int(tm[:, 2:4].sum()),
-                               "leapfrogs_per_sec": float(tm[:, 2:4].sum()) / c_secs, "ess_bulk_min": c_ess, "ess_per_sec": c_ess / c_samp, "cores": procs,
+            run["cpu_port"] = {"seconds": c_secs, "sampling_seconds": c_samp, "wall_seconds_with_process_start": wall,
+                    "leapfrogs": int(tm[:, 2:4].sum()),
+                               "leapfrogs_per_sec": float(tm[:, 2:4].sum()) / c_secs, "ess_bulk_min": c_ess, "ess_per_sec": c_ess / c_samp,
+                                       "cores": procs,
                                "kind": "port", "mean_predicted_score_T": ccols[:, :, 1 + S:].mean(axis=(0, 1)).tolist(),
-                               "note": "oracle/potus_oracle.c, scan/sparse gradient, pooled-buffer tree, one chain per host process: the same run (seed, chain ids) to completion"}
-            run["gpu_over_cpu"] = {"wall": c_secs / (t2 - t0), "leapfrogs_per_sec": run["gpu"]["leapfrogs_per_sec"] / run["cpu_port"]["leapfrogs_per_sec"],
+                               "note": "oracle/potus_oracle.c, scan/sparse gradient, pooled-buffer tree, one chain per host process: the "
+                                       "same run (seed, chain ids) to completion"}
+            run["gpu_over_cpu"] = {"wall": c_secs / (t2 - t0),
+                    "leapfrogs_per_sec": run["gpu"]["leapfrogs_per_sec"] / run["cpu_port"]["leapfrogs_per_sec"],
                                    "ess_per_sec": run["gpu"]["ess_per_sec"] / run["cpu_port"]["ess_per_sec"],
                                    "max_abs_diff_of_mean_predicted_score_T": float(np.abs(np.array(run["gpu"]["mean_predicted_score_T"]) - np.array(run["cpu_port"]["mean_predicted_score_T"])).max())}
         out.append(run)
@@ -470,34 +527,45 @@ def load_workloads(cfg, chains_per_gpu, twin_posteriors="", storage=0, pooled=0)
                 for y, v in (("2008", "no_mode_adjustment"), ("2012", "no_mode_adjustment"), ("2016", "full"))]
     if cfg == 4:
         from us_potus_model_amd import _abi
-        return [("stress", synthetic.stress(), "full", chains_per_gpu or 16, {"metric": _abi.METRIC_DENSE, "metric_storage": storage, "pooled_metric": pooled})]
+        return [("stress", synthetic.stress(), "full", chains_per_gpu or 16, {"metric": _abi.METRIC_DENSE, "metric_storage": storage,
+                "pooled_metric": pooled})]
     raise SystemExit(f"unknown --config {cfg}")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="launch chunks of --chunk transitions: K // 2 warm-up, the rest sampling (default 20; --config 4: 5)")
+    ap.add_argument("--steps", type=int, default=None,
+            help="launch chunks of --chunk transitions: K // 2 warm-up, the rest sampling (default 20; --config 4: 5)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed chunks on a throw-away sampler (default 2; --config 4: 0)")
     ap.add_argument("--config", type=int, default=1, help="BASELINE.json configs[] index: 1 (default), 0, 2, 3, 4")
     ap.add_argument("--chains-per-gpu", type=int, default=0, help="per posterior (0 = the configuration's: 8, 8, 4, 4)")
-    ap.add_argument("--cus-per-chain", type=int, default=0, help="workgroups per chain (0 = the library's choice: 16, 10-14, 8, 4 or 1 by what fits)")
-    ap.add_argument("--twin", type=int, default=-1, help="two clusters per chain, one per end of the trajectory: 1, 0, or -1 = the library's choice")
-    ap.add_argument("--twin-posteriors", default="2016", help="--config 3: the posteriors (comma-separated years) that get two clusters per chain")
+    ap.add_argument("--cus-per-chain", type=int, default=0,
+            help="workgroups per chain (0 = the library's choice: 16, 10-14, 8, 4 or 1 by what fits)")
+    ap.add_argument("--twin", type=int, default=-1,
+            help="two clusters per chain, one per end of the trajectory: 1, 0, or -1 = the library's choice")
+    ap.add_argument("--twin-posteriors", default="2016",
+            help="--config 3: the posteriors (comma-separated years) that get two clusters per chain")
     ap.add_argument("--chunk", type=int, default=0, help="transitions per step (0 = the configuration's: 100; 1 for --config 4)")
     ap.add_argument("--warm-steps", type=int, default=-1, help="how many of the --steps are warm-up (-1 = half of them)")
     ap.add_argument("--metric-storage", default="f64", choices=["f64", "f32"], help="--config 4: storage of the dense inverse metric")
-    ap.add_argument("--pooled-metric", action="store_true", help="--config 4: ONE dense inverse metric per GPU, adapted from the window draws of all its chains "
+    ap.add_argument("--pooled-metric", action="store_true",
+            help="--config 4: ONE dense inverse metric per GPU, adapted from the window draws of all its chains "
                                                                  "(potus_opts.pooled_metric; a declared deviation from Stan)")
     ap.add_argument("--max-depth", type=int, default=None, help="default 10 (CmdStan's); --config 4: 7, stated in the line")
-    ap.add_argument("--adapt-windows", default="", help="init_buffer,window,term_buffer of the warm-up (default: CmdStan's 75,25,50, rescaled by windowed_adaptation for short warm-ups); "
+    ap.add_argument("--adapt-windows", default="",
+            help="init_buffer,window,term_buffer of the warm-up (default: CmdStan's 75,25,50, rescaled by windowed_adaptation for "
+                    "short warm-ups); "
                                                         "e.g. 6,8,6 puts two window ends into a 40-iteration warm-up of --config 4")
-    ap.add_argument("--gather", default="full", choices=["full", "T"], help="what the all-gather pools: lp__ + all of mu_b (SURVEY 8e) or lp__ + mu_b[:, T] only")
+    ap.add_argument("--gather", default="full", choices=["full", "T"],
+            help="what the all-gather pools: lp__ + all of mu_b (SURVEY 8e) or lp__ + mu_b[:, T] only")
     ap.add_argument("--seed", type=int, default=1843)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturated", action="store_true", help="skip the 256-chain reference point")
-    ap.add_argument("--single-process", action="store_true", help="ONE process, --gpus N handles on N devices under potus_run_many: the R-facing multi-GPU path")
-    ap.add_argument("--no-side", action="store_true", help="skip the side measurements of configs[0], configs[3] and the configs[4] preset (default line only)")
+    ap.add_argument("--single-process", action="store_true",
+            help="ONE process, --gpus N handles on N devices under potus_run_many: the R-facing multi-GPU path")
+    ap.add_argument("--no-side", action="store_true",
+            help="skip the side measurements of configs[0], configs[3] and the configs[4] preset (default line only)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the first HIP call (module docstring)
@@ -550,11 +618,15 @@ def main():
             raise SystemExit("--config 0 (the reference's own sampler calls, GPU and CPU port side by side) runs on one GPU")
         runs = reference_sampler_calls(local, args.seed, args.cus_per_chain, args.twin, args.max_depth, cpu=not args.no_cpu_baseline)
         r0 = runs[0]
-        print(json.dumps({"metric": "leapfrog_steps_per_sec", "value": r0["gpu"]["leapfrogs_per_sec"], "unit": "leapfrogs/s", "n_gpus": 1, "steps": 20, "warmup": 1,
-                          "ms_per_step": 1e3 * r0["gpu"]["seconds"] / 20, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        print(json.dumps({"metric": "leapfrog_steps_per_sec", "value": r0["gpu"]["leapfrogs_per_sec"], "unit": "leapfrogs/s", "n_gpus": 1,
+                "steps": 20, "warmup": 1,
+                          "ms_per_step": 1e3 * r0["gpu"]["seconds"] / 20, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                                  "dtype": "f64",
                           "data": "poll data of the reference (fixtures built from its CSVs, tests/golden/data_*.npz); random inits",
-                          "config": {"workload": "configs[0]: the reference's sampler calls as scripted (final_2016.R:533-541: 6 chains x (500 + 500), seed 1843; final_2012.R, "
-                                                 "final_2008.R likewise; BASELINE's 4 x 500), each run to completion on the MI355X and on the CPU port; value = the 2016 call on the GPU; "
+                          "config": {"workload": "configs[0]: the reference's sampler calls as scripted (final_2016.R:533-541: 6 chains "
+                                                 "x (500 + 500), seed 1843; final_2012.R, "
+                                                 "final_2008.R likewise; BASELINE's 4 x 500), each run to completion on the "
+                                                         "MI355X and on the CPU port; value = the 2016 call on the GPU; "
                                                  "a step = `refresh` = 50 transitions"},
                           "runs": runs}), flush=True)
         parallel.barrier()
@@ -564,7 +636,8 @@ def main():
         raise SystemExit("--pooled-metric applies to --config 4 with fp64 storage")
     # (N > 1: every window end pooled over the ranks as well -- pooled_metric = 2, sampler.run_pooled: two small all-reduces and one of D x D doubles per window end)
     pooled_mode = 0 if not args.pooled_metric else (2 if world > 1 else 1)
-    work = load_workloads(cfg, args.chains_per_gpu, "" if dev_backend == "gloo" else args.twin_posteriors, 1 if args.metric_storage == "f32" else 0, pooled_mode)
+    work = load_workloads(cfg, args.chains_per_gpu, "" if dev_backend == "gloo" else args.twin_posteriors,
+            1 if args.metric_storage == "f32" else 0, pooled_mode)
     warm_steps = args.steps // 2 if args.warm_steps < 0 else min(args.warm_steps, args.steps)
     nw, ns = warm_steps * chunk, (args.steps - warm_steps) * chunk
 
@@ -577,7 +650,8 @@ def main():
             while True:
                 try:
                     hs.append(Handle(data, variant, chains=C, chain_id_offset=rank * C, num_warmup=num_warmup, num_samples=num_samples,
-                                     seed=seed, device=local, cus_per_chain=args.cus_per_chain, max_depth=args.max_depth, **{"twin": twin, **extra}))
+                                     seed=seed, device=local, cus_per_chain=args.cus_per_chain, max_depth=args.max_depth, **{"twin": twin,
+                                             **extra}))
                     break
                 except Exception as e:      # the dense metric keeps two D x D matrices per chain: as many chains as the HBM holds
                     if cfg != 4 or args.chains_per_gpu or C <= 1 or "GB free" not in str(e):
@@ -698,7 +772,8 @@ def main():
                     "clusters_per_chain": h.clusters_per_chain,
                     "divergent_transitions": int(sum(dv)), "chain_status": st}
             if ns > 0 and cfg != 4:
-                sp = h.write_array(2, 4, ns)                                     # stepsize__, treedepth__ of the saved (sampling) draws: [draw, chain, 2]
+                sp = h.write_array(2, 4,
+                        ns)                                     # stepsize__, treedepth__ of the saved (sampling) draws: [draw, chain, 2]
                 info["treedepth_max_per_chain"] = [int(v) for v in sp[:, :, 1].max(axis=0)]
                 info["treedepth_mean_per_chain"] = [round(float(v), 3) for v in sp[:, :, 1].mean(axis=0)]
                 info["stepsize_per_chain"] = [float(v) for v in sp[-1, :, 0]]
@@ -706,7 +781,8 @@ def main():
                 cnt, rb, rf = h.twin_stats()
                 info["twin"] = {"leapfrogs_counted": cnt, "leaves_run_backward_side": rb, "leaves_run_forward_side": rf,
                                 "leaves_run_per_counted": (rb + rf) / max(cnt, 1),
-                                "note": "each side integrates the doublings of its end, those of speculative subtrees that are dropped included"}
+                                "note": "each side integrates the doublings of its end, those of speculative subtrees that are dropped "
+                                        "included"}
             if dd is not None:
                 # The metric's ESS: min bulk-ESS (and max R-hat) over lp__, mu_b[:, T], predicted_score[T, :]: column 0 and the
                 # last 2 S columns of the block the diagnostics ran on (mu_b's last day, then its inverse logit).
@@ -715,9 +791,12 @@ def main():
                 info["ess_bulk_min"] = float(np.nanmin(dd["ess_bulk"][sel]))
                 info["rhat_max"] = float(np.nanmax(dd["rhat"][sel]))
                 info["pooled_draws"] = int(ns * C * world)
-                info["device_diagnostics"] = {"columns": dd["columns"], "seconds": dd["seconds"], "ess_bulk_min_all_columns": float(np.nanmin(dd["ess_bulk"])),
-                                              "ess_bulk_median_all_columns": float(np.nanmedian(dd["ess_bulk"])), "rhat_max_all_columns": float(np.nanmax(dd["rhat"])),
-                                              "note": "potus_diagnostics_device over every gathered column (lp__ + mu_b) + predicted_score[T, :], pooled chains of all ranks, inside the timed region"}
+                info["device_diagnostics"] = {"columns": dd["columns"], "seconds": dd["seconds"],
+                        "ess_bulk_min_all_columns": float(np.nanmin(dd["ess_bulk"])),
+                                              "ess_bulk_median_all_columns": float(np.nanmedian(dd["ess_bulk"])),
+                                                      "rhat_max_all_columns": float(np.nanmax(dd["rhat"])),
+                                              "note": "potus_diagnostics_device over every gathered column (lp__ + mu_b) + "
+                                                      "predicted_score[T, :], pooled chains of all ranks, inside the timed region"}
                 ess_all.append(info["ess_bulk_min"]); rhat_all.append(info["rhat_max"])
             elif pl is not None and ns >= 8:                                     # development mode (collectives on CPU tensors): the numpy restatement
                 x = np.transpose(pl.cpu().numpy(), (1, 0, 2))                    # [chain, draw, 1 + S]
@@ -738,8 +817,10 @@ def main():
         tr = measured_traffic(kernel, sides)
         traffic = tr[1]["hbm_bytes_per_leapfrog"] * sum(lf_local) / (kernel_ms * 1e-3) / 1e9 if tr else None
         traffic_note = (f"NOT measured in this run: {tr[1]['hbm_bytes_per_leapfrog']:.0f} HBM bytes per leapfrog from the committed "
-                        f"rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE, profiles/{tr[0]}; FETCH_SIZE calibrated at 0.500 counted "
-                        f"bytes per streamed byte for the sampler's 8- and 16-byte plain and sc1 loads, profiles/r04_fetch_size_calibration.txt; WRITE_SIZE "
+                        f"rocprofv3 --pmc passes of this command (2 x FETCH_SIZE + WRITE_SIZE, profiles/{tr[0]}; FETCH_SIZE "
+                                f"calibrated at 0.500 counted "
+                        f"bytes per streamed byte for the sampler's 8- and 16-byte plain and sc1 loads, "
+                                f"profiles/r04_fetch_size_calibration.txt; WRITE_SIZE "
                         f"at 1.000, profiles/r03_write_size_calibration.txt) x this run's leapfrogs / launch time" if tr else "no PMC pass committed for this kernel")
         if dense and args.pooled_metric:
             traffic, traffic_note = None, "no counter pass committed for k_dn_pool_mm"
@@ -749,7 +830,8 @@ def main():
                 except (OSError, ValueError, KeyError):
                     continue
                 traffic = achieved * ratio
-                traffic_note = (f"NOT measured in this run: HBM reads of k_dn_pool_mm = {ratio:.3f} x the bytes of the matrix (rocprofv3 --pmc FETCH_SIZE pass of the pooled "
+                traffic_note = (f"NOT measured in this run: HBM reads of k_dn_pool_mm = {ratio:.3f} x the bytes of the matrix (rocprofv3 "
+                                f"--pmc FETCH_SIZE pass of the pooled "
                                 f"sampler, doubled per the guide; profiles/{f.name}) x this run's rate")
         elif dense:   # the matrix pass: HBM reads measured / bytes loaded by construction, from the committed counter pass of the dense sampler
             for f in sorted((ROOT / "profiles").glob("*dense_pmc_fetch.json")):
@@ -758,28 +840,34 @@ def main():
                 except (OSError, ValueError, KeyError):
                     continue
                 traffic = achieved * ratio
-                traffic_note = (f"NOT measured in this run: HBM reads of k_dn_symv + k_dn_symv_finish = {ratio:.3f} x the bytes the passes load by "
-                                f"construction (rocprofv3 --pmc FETCH_SIZE pass of the dense sampler, doubled per the guide; profiles/{f.name}) x this run's rate")
+                traffic_note = (f"NOT measured in this run: HBM reads of k_dn_symv + k_dn_symv_finish = {ratio:.3f} x the bytes the "
+                                f"passes load by "
+                                f"construction (rocprofv3 --pmc FETCH_SIZE pass of the dense sampler, doubled per the guide; "
+                                        f"profiles/{f.name}) x this run's rate")
         C_tot = sum(w[3] for w in work)
         names = {1: "configs[1]: 2016 backtest", 2: "configs[2]: 2016 backtest, chains sharded over the GPUs",
                  3: "configs[3]: 2008 + 2012 + 2016 backtests concurrently",
-                 4: "configs[4]: synthetic stress posterior, dense metric" + (" POOLED over the GPU's chains (a declared deviation from Stan)" if args.pooled_metric else "")}
+                 4: "configs[4]: synthetic stress posterior, dense metric" + (" POOLED over the GPU's chains (a declared deviation from "
+                                                                              "Stan)" if args.pooled_metric else "")}
         line = {
             "metric": "leapfrog_steps_per_sec", "value": leapfrogs / elapsed, "unit": "leapfrogs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": ("synthetic polls (us_potus_model_amd.synthetic.stress, seed 20201103)" if cfg == 4 else
                      "poll data of the reference (fixtures built from its CSVs, tests/golden/data_*.npz)") + "; random inits",
-            "config": {"workload": f"{names[2 if (cfg == 1 and world > 1) else cfg]}, adaptive NUTS {'dense_e' if dense else 'diag_e'}, {C_tot} chains per MI355X, "
+            "config": {"workload": f"{names[2 if (cfg == 1 and world > 1) else cfg]}, adaptive NUTS {'dense_e' if dense else 'diag_e'}, "
+                                   f"{C_tot} chains per MI355X, "
                                    f"{nw} warmup + {ns} sampling, seed {args.seed}; a step = one launch chunk of {chunk} transitions",
-                       "step": f"{chunk} NUTS transitions of every chain", "iter_warmup": nw, "iter_sampling": ns, "max_depth": args.max_depth,
+                       "step": f"{chunk} NUTS transitions of every chain", "iter_warmup": nw, "iter_sampling": ns,
+                               "max_depth": args.max_depth,
                        **({"adapt_windows_init_window_term": args.adapt_windows} if args.adapt_windows else {}),
                        "baseline_config_index": 2 if (cfg == 1 and world > 1) else cfg,
                        "chains_per_gpu": C_tot, "total_chains": C_tot * world, "posteriors": per_post,
                        "all_gather_bytes_per_rank": gathered_bytes,
                        "parallelism": (f"chains sharded {C_tot}/GPU x {world}, no data-path collective; one RCCL all-gather of the "
                                        f"draws-of-interest (device buffers); " if world > 1 else f"{C_tot} chains; ") +
-                                      (f"each chain on two clusters of {K} workgroups, one per end of the NUTS trajectory ({C_tot * K * 2} of 256 CUs busy)"
+                                      (f"each chain on two clusters of {K} workgroups, one per end of the NUTS trajectory "
+                                              f"({C_tot * K * 2} of 256 CUs busy)"
                                        if K > 1 and sides == 2 else
                                        f"each chain on a cluster of {K} workgroups ({C_tot * K} of 256 CUs busy)" if K > 1
                                        else "one workgroup per chain")},
@@ -798,18 +886,26 @@ def main():
                              "metric_storage": args.metric_storage} if dense else {}),
                          **({"pooled_metric": True, "kernel": "k_dn_pool_mm",
                              # the pooled pass is a D x D times D x R product: its second bound is the fp64 matrix peak (MI355X_MICROARCH.md: 78.6 TFLOP/s dense)
-                             "mfma": {"bound": "mfma", "achieved": 2.0 * hs[0].D ** 2 * 2.0 * sum(lf_local) / max(dense_t[0] * 1e-3, 1e-9) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                             "mfma": {"bound": "mfma", "achieved": 2.0 * hs[0].D ** 2 * 2.0 * sum(lf_local) / max(dense_t[0] * 1e-3,
+                                     1e-9) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                                       "frac": 2.0 * hs[0].D ** 2 * 2.0 * sum(lf_local) / max(dense_t[0] * 1e-3, 1e-9) / 1e12 / 78.6,
-                                      "note": "2 D^2 flops per right-hand side, two right-hand sides per counted leapfrog (the first pass of a transition carries three: not counted), "
-                                              "over the time of the passes; the pass streams the FULL symmetric matrix (8 D^2 bytes) once per round for all chains"}}
+                                      "note": "2 D^2 flops per right-hand side, two right-hand sides per counted leapfrog (the first "
+                                              "pass of a transition carries three: not counted), "
+                                              "over the time of the passes; the pass streams the FULL symmetric matrix (8 D^2 "
+                                                      "bytes) once per round for all chains"}}
                             if dense and args.pooled_metric else {}),
-                         "note": (f"latency-bound at {C_tot} chains ({C_tot * K * sides} of 256 CUs busy): the state of a chain stays in L2, a leapfrog "
+                         "note": (f"latency-bound at {C_tot} chains ({C_tot * K * sides} of 256 CUs busy): the state of a chain stays in "
+                                  f"L2, a leapfrog "
                                   "is a chain of dependent phases and exchanges between the CUs of a cluster; see DESIGN.md") if not dense else
-                                 ("pooled dense metric (potus_opts.pooled_metric, a declared deviation from Stan): every leaf ROUND streams the handle's one full "
-                                  "symmetric D x D inverse metric (8 D^2 bytes) once for all chains and multiplies it with their right-hand sides on the fp64 matrix "
-                                  "cores; achieved = bytes loaded by the passes / their time; roofline.mfma is the same passes against the matrix peak"
+                                 ("pooled dense metric (potus_opts.pooled_metric, a declared deviation from Stan): every leaf "
+                                         "ROUND streams the handle's one full "
+                                  "symmetric D x D inverse metric (8 D^2 bytes) once for all chains and multiplies it with their "
+                                          "right-hand sides on the fp64 matrix "
+                                  "cores; achieved = bytes loaded by the passes / their time; roofline.mfma is the same passes "
+                                          "against the matrix peak"
                                   if args.pooled_metric else
-                                  "dense metric: every leapfrog streams the upper triangle of the chain's D x D inverse metric (4 D^2 bytes; the "
+                                  "dense metric: every leapfrog streams the upper triangle of the chain's D x D inverse metric "
+                                          "(4 D^2 bytes; the "
                                   "survey's 8 D^2 assumed the full matrix); achieved = bytes loaded by the matrix passes / their time")},
         }
         if dense:
@@ -817,14 +913,18 @@ def main():
             adapted = [p for p in per_step if p["window_ends_so_far"] > 0 and p is not next((q for q in per_step if q["window_ends_so_far"] > 0), None)]
             line["dense"] = {
                 "window_ends": at["window_ends"], "window_end_seconds": (at["cov_ms"] + at["chol_ms"] + at["init_stepsize_ms"]) * 1e-3,
-                "covariance_seconds": at["cov_ms"] * 1e-3, "cholesky_seconds": at["chol_ms"] * 1e-3, "init_stepsize_seconds": at["init_stepsize_ms"] * 1e-3,
+                "covariance_seconds": at["cov_ms"] * 1e-3, "cholesky_seconds": at["chol_ms"] * 1e-3,
+                        "init_stepsize_seconds": at["init_stepsize_ms"] * 1e-3,
                 "cholesky_tflops": ((1 if args.pooled_metric else work[0][3]) * hs[0].D ** 3 / 3.0 * at["window_ends"]) / max(at["chol_ms"] * 1e-3, 1e-9) / 1e12,
                 "matrices_factored_per_window_end": 1 if args.pooled_metric else work[0][3],
-                "adapted_phase": ({"steps": len(adapted), "leapfrogs": sum(p["leapfrogs"] for p in adapted), "seconds": sum(p["seconds"] for p in adapted),
-                                   "leapfrogs_per_sec": sum(p["leapfrogs"] for p in adapted) / max(sum(p["seconds"] for p in adapted), 1e-9),
+                "adapted_phase": ({"steps": len(adapted), "leapfrogs": sum(p["leapfrogs"] for p in adapted),
+                        "seconds": sum(p["seconds"] for p in adapted),
+                                   "leapfrogs_per_sec": sum(p["leapfrogs"] for p in adapted) / max(sum(p["seconds"] for p in adapted),
+                                           1e-9),
                                    "matrix_pass_TBps": sum(p["matrix_bytes"] for p in adapted) / max(sum(p["matrix_pass_ms"] for p in adapted), 1e-9) / 1e9,
                                    "matrix_pass_share_of_wall": sum(p["matrix_pass_ms"] for p in adapted) * 1e-3 / max(sum(p["seconds"] for p in adapted), 1e-9),
-                                   "note": "the steps after the one in which the first window ended: transitions under the adapted dense metric"}
+                                   "note": "the steps after the one in which the first window ended: transitions under the adapted dense "
+                                           "metric"}
                                   if adapted else None),
                 "per_step": per_step}
         if world == 1 and cfg == 1 and not args.no_saturated:
@@ -834,7 +934,8 @@ def main():
                 _, data, variant, _, _ = work[0]
 
                 def short_run(chains, twin_):
-                    hsat = Handle(data, variant, chains=chains, num_warmup=60, num_samples=0, seed=args.seed + 7, device=local, cus_per_chain=1, twin=twin_)
+                    hsat = Handle(data, variant, chains=chains, num_warmup=60, num_samples=0, seed=args.seed + 7, device=local,
+                            cus_per_chain=1, twin=twin_)
                     hsat.init()
                     ms_s, lf_s = 0.0, 0
                     for _ in range(3):
@@ -846,11 +947,14 @@ def main():
 
                 rate = short_run(256, 0)
                 r128 = [short_run(128, t) for t in (0, 1)]
-                line["saturated"] = {"chains": 256, "cus_per_chain": 1, "kernel": "k_run", "iterations": 60, "value": rate, "unit": "leapfrogs/s",
+                line["saturated"] = {"chains": 256, "cus_per_chain": 1, "kernel": "k_run", "iterations": 60, "value": rate,
+                        "unit": "leapfrogs/s",
                                      "roofline_frac": rate * bpl[0] / 1e9 / HBM_PEAK_GBS,
-                                     "chains_128": {"one_workgroup_per_chain": r128[0], "two_workgroups_per_chain": r128[1], "kernel": "k_run / k_run_twin",
+                                     "chains_128": {"one_workgroup_per_chain": r128[0], "two_workgroups_per_chain": r128[1],
+                                             "kernel": "k_run / k_run_twin",
                                                     "roofline_frac": max(r128) * bpl[0] / 1e9 / HBM_PEAK_GBS,
-                                                    "note": "65-128 chains: the library's choice is two workgroups per chain, one per end of the trajectory"},
+                                                    "note": "65-128 chains: the library's choice is two workgroups per chain, one per "
+                                                            "end of the trajectory"},
                                      "note": "short warm-up run of 256 chains on the same posterior; kernel time of the launches"}
             except Exception as e:                     # never let the side measurement spoil the bench line
                 line["saturated"] = {"error": str(e)[:200]}
@@ -863,15 +967,18 @@ def main():
             nlf = 6
             secs, nthreads, mbytes = om.time_leapfrogs_dense(nlf)
             line["cpu_baseline"] = {"value": nlf / secs, "unit": "leapfrogs/s", "cores": nthreads, "kind": "port",
-                                    "sample": f"{nlf} leapfrogs of one chain of the same posterior (D = {hs[0].D}) under a dense {mbytes / 1e9:.2f} GB inverse metric, the rows of the "
-                                              f"matrix-vector product over {nthreads} OpenMP threads (oracle/potus_oracle.c: dense_e_metric::dtau_dp + the scan/sparse gradient): {secs:.1f} s",
+                                    "sample": f"{nlf} leapfrogs of one chain of the same posterior (D = {hs[0].D}) under a dense "
+                                              f"{mbytes / 1e9:.2f} GB inverse metric, the rows of the "
+                                              f"matrix-vector product over {nthreads} OpenMP threads (oracle/potus_oracle.c: "
+                                                      f"dense_e_metric::dtau_dp + the scan/sparse gradient): {secs:.1f} s",
                                     "seconds": secs, "matrix_GBps": nlf * mbytes / secs / 1e9}
             line["value_over_cpu_sample"] = line["value"] / line["cpu_baseline"]["value"]
         if not args.no_cpu_baseline and world == 1 and cfg in (1, 2):   # the CPU port is timed beside the single-GPU run only
             _, data, variant, C, _ = work[0]
             short = (150, 100)
             # the same complete short configuration on the GPU (after the timed region), to put measured ESS / s side by side
-            hg = Handle(data, variant, chains=C, num_warmup=short[0], num_samples=short[1], seed=args.seed, device=local, cus_per_chain=args.cus_per_chain, twin=twin)
+            hg = Handle(data, variant, chains=C, num_warmup=short[0], num_samples=short[1], seed=args.seed, device=local,
+                    cus_per_chain=args.cus_per_chain, twin=twin)
             tg0 = time.perf_counter()
             hg.init(); hg.run(short[0])
             tg1 = time.perf_counter()
@@ -885,23 +992,31 @@ def main():
             g_lf = hg.total_leapfrogs()
             hg.close()
             cb = cpu_baseline(data, variant, C, args.seed, nw, ns, short)
-            cb["short_config"]["gpu"] = dict(leapfrogs=g_lf, seconds=tg2 - tg0, sampling_seconds=tg2 - tg1, leapfrogs_per_sec=g_lf / (tg2 - tg0),
+            cb["short_config"]["gpu"] = dict(leapfrogs=g_lf, seconds=tg2 - tg0, sampling_seconds=tg2 - tg1,
+                    leapfrogs_per_sec=g_lf / (tg2 - tg0),
                                              ess_bulk_min=g_ess, ess_per_sec=g_ess / (tg2 - tg1))
             like = dict(leapfrogs_per_sec=(g_lf / (tg2 - tg0)) / cb["short_config"]["leapfrogs_per_sec"],
                         ess_per_sec=(g_ess / (tg2 - tg1)) / cb["short_config"]["ess_per_sec"],
                         wall=cb["short_config"]["seconds"] / (tg2 - tg0),
-                        of=f"the complete short configuration {C} chains x ({short[0]} + {short[1]}), seed {args.seed}, run to the end on both sides")
+                        of=f"the complete short configuration {C} chains x ({short[0]} + {short[1]}), seed {args.seed}, run to the "
+                                f"end on both sides")
             cb["short_config"]["gpu_over_cpu"] = like
             # the like-for-like ratios first; the ratio against the bounded sample (`value`) after them, named for what it is
-            line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
-                                    "like_for_like_gpu_over_cpu": like, **{k: v for k, v in cb.items() if k not in ("value", "unit", "cores", "kind", "sample")}}
+            line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                    "sample": cb["sample"],
+                                    "like_for_like_gpu_over_cpu": like, **{k: v for k, v in cb.items() if k not in ("value", "unit",
+                                            "cores", "kind", "sample")}}
             line["gpu_over_cpu_like_for_like"] = like
             line["value_over_cpu_sample"] = line["value"] / cb["value"]
             line["value_over_cpu_leapfrog_loop"] = line["value"] / cb["leapfrog_loop_scan_sparse_value"]
-            line["gpu_over_cpu_note"] = ("gpu_over_cpu_like_for_like: the same complete short configuration on both sides (leapfrogs / s, ESS / s of its own draws, wall time); "
-                                         f"value_over_cpu_sample: this line's whole-run rate over the rate of the port's first {cb['iterations_sampled'][0]}-{cb['iterations_sampled'][1]} "
-                                         f"iterations of the same run on {cb['cores']} host cores (a bounded sample of early warm-up, not the same iterations); "
-                                         "value_over_cpu_leapfrog_loop: over the port's bare leapfrog loop, which no CPU sampler can exceed.  None of them says anything "
+            line["gpu_over_cpu_note"] = ("gpu_over_cpu_like_for_like: the same complete short configuration on both sides (leapfrogs / "
+                                         "s, ESS / s of its own draws, wall time); "
+                                         f"value_over_cpu_sample: this line's whole-run rate over the rate of the port's first "
+                                                 f"{cb['iterations_sampled'][0]}-{cb['iterations_sampled'][1]} "
+                                         f"iterations of the same run on {cb['cores']} host cores (a bounded sample of early "
+                                                 f"warm-up, not the same iterations); "
+                                         "value_over_cpu_leapfrog_loop: over the port's bare leapfrog loop, which no CPU sampler "
+                                                 "can exceed.  None of them says anything "
                                          "about kernel quality: roofline.frac does")
         if world == 1 and cfg == 1 and not args.no_side:
             for h in hs:

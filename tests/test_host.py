@@ -217,8 +217,8 @@ def test_bench_bookkeeping_on_the_committed_profiles():
     assert one and two and one[0] != two[0] and "two clusters" in two[1]["command"] and "two clusters" not in one[1]["command"]
     # (two clusters per chain: 1.04 x / 1.007 x the algorithmic bytes in rounds 3 / 4, 0.785 x since round 5 keeps a member's share of three vectors in LDS)
     assert 0.5 < one[1]["hbm_bytes_per_leapfrog"] / 844784 < 0.8 and 0.6 < two[1]["hbm_bytes_per_leapfrog"] / 844784 < 1.3
-    assert two[0] == "r05_cl_twin_pmc_traffic.json"                     # the latest committed pass is the one the bench line quotes
-    for committed in ("r03_bench_line.json", "r04b_bench_line.json", "r05_bench_line.json", "r05b_bench_line.json"):
+    assert two[0] == "r06_cl_twin_pmc_traffic.json"                     # the latest committed pass is the one the bench line quotes
+    for committed in ("r03_bench_line.json", "r04b_bench_line.json", "r05_bench_line.json", "r05b_bench_line.json", "r06_bench_line.json"):
         _check_committed_bench_line(json.loads([ln for ln in (ROOT / "profiles" / committed).read_text().splitlines() if ln.startswith("{")][0]),
                                     device_diagnostics=int(committed[1:3]) if int(committed[1:3]) >= 4 else 0)
 
@@ -259,6 +259,11 @@ def _check_committed_bench_line(line, device_diagnostics):
         assert side["configs[3]"]["baseline_config_index"] == 3 and side["configs[3]"]["value"] > 0 and side["configs[3]"]["roofline"]["kernel"] == "k_cl_run"
         assert side["configs[4]_preset"]["roofline"]["kernel"] == "k_dn_symv" and 0.5 < side["configs[4]_preset"]["roofline"]["frac"] < 0.9
         assert cb["host_cores_total"] >= cb["cores"]
+    if device_diagnostics >= 6:
+        # round 6: the configs[4] preset with the dense metric pooled over the GPU's chains (potus_opts.pooled_metric): the pass against BOTH its bounds
+        pl = line["side"]["configs[4]_pooled"]
+        assert pl["roofline"]["kernel"] == "k_dn_pool_mm" and pl["roofline"]["pooled_metric"] and 0.5 < pl["roofline"]["frac"] < 0.95
+        assert pl["roofline"]["mfma"]["peak"] == 78.6 and 0.2 < pl["roofline"]["mfma"]["frac"] < 0.9 and pl["value"] > 3 * line["side"]["configs[4]_preset"]["value"]
     if device_diagnostics >= 6:
         # round 6: where the headline's seed sits -- the same command under the next two seeds, the default line's own run first
         sd = line["side"]["seeds"]
