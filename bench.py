@@ -229,7 +229,9 @@ def single_process_side(args, n):
     t0 = time.perf_counter()
     try:
         cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", str(n), "--single-process", "--seed", str(args.seed), "--steps",
-                str(args.steps), "--warmup", "1"]
+               str(args.steps), "--warmup", "1", "--chunk", str(args.chunk), "--chains-per-gpu", str(args.chains_per_gpu), "--cus-per-chain",
+               str(args.cus_per_chain), "--twin", str(args.twin), "--warm-steps", str(args.warm_steps)]
+        cmd += ["--max-depth", str(args.max_depth)] if args.max_depth is not None else []
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=420,
                            env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR",
                                    "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")})
@@ -586,6 +588,12 @@ def main():
     # the N > 1 flow on a one-GPU box (the measured configuration is one rank per GPU over RCCL)
     dev_backend = os.environ.get("POTUS_DIST_BACKEND")
     rank, world, local = parallel.init_process_group(dev_backend)
+    # (the single-process side run needs the GPUs to itself: not in the development mode, where the ranks share GPU 0 -- unless a test asks for it)
+    sp_side = dev_backend != "gloo" or bool(os.environ.get("POTUS_BENCH_FORCE_SP_SIDE"))
+    wait_for_rank0 = None
+    if world > 1:                                           # the job's key-value store (TCP, CPU side): how the ranks wait for rank 0's side measurement without a GPU kernel
+        import torch.distributed as dist
+        wait_for_rank0 = dist.distributed_c10d._get_default_store()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -1023,20 +1031,26 @@ def main():
                 h.close()
             torch.cuda.empty_cache()
             line["side"] = side_measurements(args.seed, headline=seed_summary({**line, "seed": args.seed}))
-        if world > 1 and cfg in (1, 2) and not args.no_side and dev_backend != "gloo":
+        if world > 1 and cfg in (1, 2) and not args.no_side and sp_side:
             for h in hs:
                 h.close()
             hs = []
             torch.cuda.empty_cache()
             parallel.barrier()                                   # every rank has released its sampler: the GPUs are free
+            torch.cuda.synchronize()
             line["side"] = {"single_process": single_process_side(args, world)}
+            wait_for_rank0.set("bench_side_done", "1")           # (see below)
         print(json.dumps(line), flush=True)
-    elif world > 1 and cfg in (1, 2) and not args.no_side and dev_backend != "gloo":
+    elif world > 1 and cfg in (1, 2) and not args.no_side and sp_side:
         for h in hs:
             h.close()
         hs = []
         torch.cuda.empty_cache()
         parallel.barrier()
+        torch.cuda.synchronize()
+        # Rank 0's child process now needs every compute unit of every GPU resident for its cluster launches: the other ranks must NOT wait for it inside an
+        # RCCL collective (a barrier is a kernel that spins on the GPU and holds compute units) -- they block on the job's TCP store, on the CPU
+        wait_for_rank0.wait(["bench_side_done"], __import__("datetime").timedelta(seconds=900))
     for h in hs:
         h.close()
     parallel.barrier()

@@ -464,12 +464,17 @@ def test_bench_single_process_gives_the_pooled_diagnostics_of_the_two_rank_run(t
     sp = json.loads(lines[0])
     assert sp["launcher"] == "single_process" and sp["n_gpus"] == 2 and sp["config"]["total_chains"] == 8 and sp["config"]["devices"] == [0, second_device()]
     assert sp["roofline"]["frac"] > 0 and abs(sp["value"] - sp["leapfrogs"] / sp["seconds"]) < 1e-6 * sp["value"]
-    env = dict(os.environ, POTUS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543")
+    # ... and the two-rank run carries the single-process run as side.single_process (rank 0 starts it once both ranks have closed their samplers; the other
+    # rank waits on the job's TCP store, not inside a collective: an RCCL barrier would hold compute units the child's cluster launches need)
+    env = dict(os.environ, POTUS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", POTUS_BENCH_FORCE_SP_SIDE="1", POTUS_BENCH_DEVICES=f"0,{second_device()}")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29543", str(ROOT / "bench.py")] + common
-    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=str(ROOT))
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(ROOT))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     mp_ = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert mp_["leapfrogs"] == sp["leapfrogs"] and "launcher" not in mp_
+    side = mp_["side"]["single_process"]
+    assert side.get("launcher") == "single_process" and side["n_gpus"] == 2 and side["leapfrogs"] == sp["leapfrogs"], side
+    assert abs(side["rhat_max"] - sp["rhat_max"]) <= 1e-9 * sp["rhat_max"]
     assert abs(mp_["rhat_max"] - sp["rhat_max"]) <= 1e-9 * sp["rhat_max"] and abs(mp_["ess_bulk_min"] - sp["ess_bulk_min"]) <= 1e-9 * sp["ess_bulk_min"], (mp_["rhat_max"], sp["rhat_max"])
 
 
