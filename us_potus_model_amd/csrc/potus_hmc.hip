@@ -3033,7 +3033,9 @@ int potus_diagnostics_device(int device, const void *block, long long n_draws, i
   return diagnostics_of_columns(0, cols, n_draws, n_chains, n_cols, rhat_out, ess_bulk_out);
 }
 
-int potus_diagnostics(const int *handles, int n_handles, int col_begin, int col_end, double *rhat_out, double *ess_bulk_out) {
+// (have_locks: the caller already holds the device locks of every handle -- potus_check_convergence takes its two column ranges under ONE set of locks, so that
+//  no run on another host thread can add draws between them)
+static int diagnostics_impl(const int *handles, int n_handles, int col_begin, int col_end, double *rhat_out, double *ess_bulk_out, bool have_locks) {
   if (!handles || n_handles < 1 || !rhat_out || !ess_bulk_out) return fail(POTUS_ERR_ARG, "potus_diagnostics: null argument");
   std::vector<Sampler *> sps;
   std::vector<int> devs;
@@ -3046,7 +3048,7 @@ int potus_diagnostics(const int *handles, int n_handles, int col_begin, int col_
   Sampler *s0 = sps[0];
   if (col_begin < 0 || col_end > s0->L.ncols || col_begin >= col_end) return fail(POTUS_ERR_ARG, "potus_diagnostics: columns [%d, %d) of %d", col_begin, col_end, s0->L.ncols);
   DeviceGuard guard;
-  DeviceLocks lock(devs);
+  DeviceLocks lock(have_locks ? std::vector<int>{} : devs);
   int n_saved = -1, Ctot = 0;
   for (size_t i = 0; i < sps.size(); i++) {
     Sampler *sp = sps[i];
@@ -3105,10 +3107,17 @@ int potus_diagnostics(const int *handles, int n_handles, int col_begin, int col_
 // predicted_score[T, :] is their inverse logit) over the post-warm-up draws saved SO FAR by the pooled chains of the handles.  The host loop
 // that advances the sampler in chunks of `refresh` transitions may stop once *converged is set; nothing the sampler does depends on it (same
 // draws up to that point as an uninterrupted run).  A deviation from Stan, which always runs num_samples iterations: off unless the host asks.
+int potus_diagnostics(const int *handles, int n_handles, int col_begin, int col_end, double *rhat_out, double *ess_bulk_out) {
+  return diagnostics_impl(handles, n_handles, col_begin, col_end, rhat_out, ess_bulk_out, false);
+}
+
 int potus_check_convergence(const int *handles, int n_handles, double rhat_below, double ess_at_least, int *converged, double *rhat_max, double *ess_bulk_min) {
   if (!handles || n_handles < 1 || !converged || !rhat_max || !ess_bulk_min) return fail(POTUS_ERR_ARG, "potus_check_convergence: null argument");
   Sampler *s0 = get(handles[0]);
   if (!s0) return fail(POTUS_ERR_STATE, "bad handle %d", handles[0]);
+  std::vector<int> devs;
+  for (int i = 0; i < n_handles; i++) { Sampler *sp = get(handles[i]); if (!sp) return fail(POTUS_ERR_STATE, "bad handle %d", handles[i]); devs.push_back(sp->device); }
+  DeviceLocks lock(devs);                            // one set of locks for the count and both column ranges
   const int S = s0->M.S, T = s0->M.T, a_mu = POTUS_N_SAMPLER_COLS + s0->L.D + S * (T - 1);
   std::vector<double> rh(1 + S), es(1 + S);
   *converged = 0; *rhat_max = NAN; *ess_bulk_min = NAN;
@@ -3116,8 +3125,8 @@ int potus_check_convergence(const int *handles, int n_handles, double rhat_below
   { DeviceGuard guard; HIP_TRY(hipSetDevice(s0->device)); const int rc = saved_count(s0, &ns); if (rc) return rc; }
   if (ns - (s0->opts.save_warmup ? std::min(ns, s0->R.num_warmup) : 0) < 4) return 0;      // too early to say anything: not converged, no error
   int rc;
-  if ((rc = potus_diagnostics(handles, n_handles, 0, 1, rh.data(), es.data()))) return rc;
-  if ((rc = potus_diagnostics(handles, n_handles, a_mu, a_mu + S, rh.data() + 1, es.data() + 1))) return rc;
+  if ((rc = diagnostics_impl(handles, n_handles, 0, 1, rh.data(), es.data(), true))) return rc;
+  if ((rc = diagnostics_impl(handles, n_handles, a_mu, a_mu + S, rh.data() + 1, es.data() + 1, true))) return rc;
   double r = -INFINITY, e = INFINITY;
   bool bad = false;
   for (int i = 0; i <= S; i++) { bad = bad || std::isnan(rh[i]) || std::isnan(es[i]); r = std::max(r, rh[i]); e = std::min(e, es[i]); }
