@@ -398,7 +398,16 @@ __global__ __launch_bounds__(64) void k_dn_trsv_diag(const DnParams P, int b) {
   if (!P.rd[chain].active) return;
   const int lane = threadIdx.x, r0 = b * DN_NB, nb = min(DN_NB, P.D - r0);
   const double *L = dn_fac(P, chain);
-  for (int i = 0; i < nb; i++) Lb[i][lane] = lane <= i ? L[(size_t)(r0 + i) * P.LD + r0 + lane] : 0.0;
+  // (the block's rows sixteen loads at a time: one row per trip of a loop whose every trip waited for its own load made the 64 x 64 triangle 30 of
+  //  the kernel's 39 us -- 651 blocks per momentum draw at D = 41 610, 9 % of a pooled-metric run: profiles/r06_dense_pooled_rocprof_summary.txt)
+#pragma unroll
+  for (int i0 = 0; i0 < DN_NB; i0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const int i = i0 + u; v[u] = (i < nb && lane <= i) ? L[(size_t)(r0 + i) * P.LD + r0 + lane] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 16; u++) Lb[i0 + u][lane] = v[u];
+  }
   __syncthreads();
   double *p = dn_vec(P, chain, DV_P0);
   double r = lane < nb ? p[r0 + lane] : 0.0;
@@ -421,7 +430,13 @@ __global__ __launch_bounds__(256) void k_dn_trsv_update(const DnParams P, int b)
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= r0) return;
   double s = 0.0;
-  for (int i = 0; i < nb; i++) s += L[(size_t)(r0 + i) * P.LD + c] * pb[i];
+  for (int i0 = 0; i0 < nb; i0 += 16) {             // sixteen loads in flight, the products added in the same order as ever (same bytes)
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) v[u] = i0 + u < nb ? L[(size_t)(r0 + i0 + u) * P.LD + c] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; u++) if (i0 + u < nb) s += v[u] * pb[i0 + u];
+  }
   p[c] -= s;
 }
 
