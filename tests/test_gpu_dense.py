@@ -524,3 +524,22 @@ def test_pooled_over_two_handles_equals_one_handle_with_all_chains(cases):
         t = Handle(data, variant, chains=2, pooled_metric=2, **kw)
         t.init(); t.run(nw); t.run(1)
     solo.close()
+
+
+def test_pooled_sampler_with_more_right_hand_sides_than_one_launch_holds(cases):
+    """Twenty chains on one pooled metric: the first pass of a transition carries 60 right-hand sides (two launches of the product, whole chains at a time), a
+    leaf round 40; reproducible bit for bit and chunk-invariant, every chain reports the one matrix, the factor is its factor, and a chain's draws are those it
+    has in a handle of eight (the product's order of summation does not depend on the companions) as long as the metrics agree -- i.e. up to the first window end."""
+    data, variant = cases["small_nomode"]
+    kw = dict(num_warmup=40, num_samples=6, seed=11, metric=_abi.METRIC_DENSE, pooled_metric=1, save_warmup=1, cus_per_chain=1)   # (one gradient kernel for both chain counts)
+    a = Handle(data, variant, chains=20, **kw); a.init(); a.run(46); da = a.draws()
+    assert np.isfinite(da).all() and np.array_equal(a.dense_metric(19), a.dense_metric(0))
+    res, solve = a.dense_check(19, 2)
+    assert res < 1e-12 and solve < 1e-9, (res, solve)
+    a.close()
+    b = Handle(data, variant, chains=20, **kw); b.init(); b.run(17); b.run(29); db = b.draws(); b.close()
+    assert np.array_equal(da, db)
+    from adaptation_replay import window_schedule
+    first_end = window_schedule(40, 75, 50, 25)[0][1]
+    c = Handle(data, variant, chains=8, chain_id_offset=5, **kw); c.init(); c.run(first_end + 1); dc = c.draws(); c.close()
+    assert np.array_equal(dc[:, :first_end + 1], da[5:13, :first_end + 1])
