@@ -20,7 +20,7 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 chain_counts = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 8, 64, 256]
 KCL = int(os.environ.get("POTUS_K", "1"))
 TWIN = int(os.environ.get("POTUS_TWIN", "0"))          # 1: two clusters per chain (profile rows: side 0's members, then side 1's)
-NAMESK = {0: "A load+suffix", 1: "B matvec/AR + X1", 2: "carry -> C", 3: "C polls", 4: "D gathers/seg1", 5: "E prefix/seg2", 6: "E2 payload parts",
+NAMESK = {0: "A load+suffix", 1: "B matvec/AR + X1", 2: "(carry: in B)", 3: "C polls", 4: "D gathers/seg1", 5: "E prefix/seg2", 6: "E2 payload parts",
           7: "X2 publish+wait", 18: "F finish grads", 19: "X3 allreduce", 10: "leaf scalar", 11: "merge", 12: "copy q", 13: "p_near",
           9: "begin (all transitions)", 15: "end (all transitions)", 20: "ar:shuffle", 21: "ar:drain", 22: "ar:barrier1", 23: "ar:payload st",
           24: "ar:signal+poll", 25: "ar:barrier2", 26: "ar:gather"}

@@ -678,6 +678,13 @@ __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp ld
         v = (unsigned long long)(unsigned)pi[g] | ((unsigned long long)(unsigned)(pi[Npad + g] - d0) << 8) |
             ((unsigned long long)(unsigned)pi[2 * Npad + g] << 16);
         if (full) v |= ((unsigned long long)(unsigned)pi[3 * Npad + g] << 32) | ((unsigned long long)(unsigned)pi[4 * Npad + g] << 40);
+        {   // bits 48..: the wave that owns the poll's day (its suffix carry is row `wave` of the carry table, phase B)
+          gcip scw = as_g(CL->sched) + part[CP_O_WD];
+          const int tl_ = pi[Npad + g] - d0;
+          int wt = 0;
+          for (int w_ = 0; w_ < PT_NW; w_++) { const int a_ = scw[PT_THREADS + w_], n_ = scw[PT_THREADS + PT_NW + w_]; if (tl_ >= a_ && tl_ < a_ + n_) wt = w_; }
+          v |= (unsigned long long)(unsigned)wt << 48;
+        }
         y = pd[g]; N = pd[Npad + g]; un = full ? pd[2 * Npad + g] : 0.0;
       }
       pm[i] = v; pyn[i] = (unsigned long long)(unsigned)(int)y | ((unsigned long long)(unsigned)(int)N << 32); pun[i] = un;
@@ -788,7 +795,13 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
       run += (t < T - 1) ? z : 0.0;               // column T is not part of the walk (stan:86)
       cs[j] = run;
     }
-    if (lane < S) Y[w * SE + lane] = run;
+    if (lane < S) {
+      Y[w * SE + lane] = run;
+      // C[k][t] for now holds the suffix WITHIN the wave; what the later waves, the later members and u add is the same for every day of a wave: the poll phase adds
+      // that one number per state from the carry table (round 6: the pass over the day block that did it, and its barrier, are gone -- same sums, same bytes)
+#pragma unroll
+      for (int j = 0; j < CL_DW; j++) { if (j < wnd) C[lane * NDP + wd0 + j] = cs[j]; }
+    }
   }
   __syncthreads();
   PROF_MARK(0);
@@ -850,7 +863,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
   // The previous leaf's totals (exchange pend.tag, sent before this pass began) are fetched here by a wave that has nothing else
   // to do in this phase: an L2 round trip under load costs about 2 k cycles, which the verdict wave of phase C used to pay on
   // the critical path of that phase.  (Round 3 tried this while waves 2-7 still carried the 51 x 51 mat-vecs of mu_b_T and
-  // the polling bias here and lost; those products are gone, see the carry step below.)
+  // the polling bias here and lost; those products are gone, see the carry table below.)
   // (Round 5 built the obvious merger -- the totals in the lanes the X1 fetch leaves idle, one round of sixteen loads for both, three leaves in four -- and
   //  measured it 9 % slower, 14.55 against 13.29 us per leapfrog: the totals arrive late, and wave 0 then holds the suffix carry back with them; docs/HISTORY.md.)
   if (w == 2 && pend.n >= 0) {
@@ -883,33 +896,30 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
 #pragma unroll
       for (int u = 0; u < 16; u++) carry_m += t16[u];
     }
-    if (lane < S) Y[PT_NW * SE + lane] = carry_m;
+    if (lane < S) {
+      // carry table X[w][k] (rows 0 .. 7 of X are free until phase D): what wave w's days add to their local suffix sums -- u = aT z_T + aB z_b, the later
+      // members' totals and the later waves' -- summed exactly as the day-block pass used to sum it per wave
+      double cy[PT_NW];
+#pragma unroll
+      for (int w2 = 0; w2 < PT_NW; w2++) cy[w2] = Y[w2 * SE + lane];
+      const double zt = s_zT[lane], zb = s_zb[lane];
+      ISSUE_FENCE();
+#pragma unroll
+      for (int w1 = 0; w1 < PT_NW; w1++) {
+        double carry = carry_m + (aT * zt + aB * zb);
+#pragma unroll
+        for (int w2 = 0; w2 < PT_NW; w2++) carry += w2 > w1 ? cy[w2] : 0.0;
+        X[w1 * SE + lane] = carry;
+      }
+    }
     WPROF_PT(28);
   }
+  if (tid >= PT_THREADS - SE) s_bT[tid - (PT_THREADS - SE)] = (lds + LAY(l_prior))[tid - (PT_THREADS - SE)];
+  if (tid == PT_THREADS - 64) { r_lds[np] = 0.0; ru_lds[np] = 0.0; }
   if (POTUS_PROF_WAVES == 1) WPROF_ACC(0);
   __syncthreads();
   PROF_MARK(1);
   TSTAMP(2);
-  {
-    // C[k][t] for the member's days: local suffix + later waves + later members + u
-    if (lane < S) {
-      double cy[PT_NW + 1];
-#pragma unroll
-      for (int w2 = 0; w2 <= PT_NW; w2++) cy[w2] = Y[w2 * SE + lane];
-      const double zt = s_zT[lane], zb = s_zb[lane];
-      ISSUE_FENCE();
-      double carry = cy[PT_NW] + (aT * zt + aB * zb);
-#pragma unroll
-      for (int w2 = 0; w2 < PT_NW; w2++) carry += w2 > w ? cy[w2] : 0.0;
-#pragma unroll
-      for (int j = 0; j < CL_DW; j++) {
-        if (j < wnd) C[lane * NDP + wd0 + j] = cs[j] + carry;
-      }
-    }
-  }
-  if (tid < SE) s_bT[tid] = (lds + LAY(l_prior))[tid];
-  if (tid == 0) { r_lds[np] = 0.0; ru_lds[np] = 0.0; }
-  __syncthreads();
   PROF_MARK(2);
   TSTAMP(3);
 
@@ -1001,13 +1011,16 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         const unsigned long long yn = pyn[ic];
         const double y = (double)(int)(unsigned)yn, N = (double)(int)(unsigned)(yn >> 32), un = pun[ic];
         const int t = d0 + tl;
-        ldp L0 = Lw + s * SP, C0 = C + tl;
+        ldp L0 = Lw + s * SP, C0 = C + tl, CW = X + (int)((meta >> 48) & 0xffu) * SE;   // CW: the carry of the wave that owns day tl
         double a0 = 0.0, a1 = 0.0;
           int k0 = 0;
           for (; k0 + 16 <= S; k0 += 16) {               // 51-term dot, sixteen terms in flight
             double l[16], c[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++) { l[j] = L0[k0 + j]; c[j] = C0[(k0 + j) * NDP]; }
+            for (int j = 0; j < 16; j++) c[j] = C0[(k0 + j) * NDP] + CW[k0 + j];   // (the three arrays in flight at once spill in this loop: +20 %)
+            ISSUE_FENCE();
+#pragma unroll
+            for (int j = 0; j < 16; j++) l[j] = L0[k0 + j];
             ISSUE_FENCE();
 #pragma unroll
             for (int j = 0; j < 16; j += 2) { a0 += l[j] * c[j]; a1 += l[j + 1] * c[j + 1]; }
@@ -1015,7 +1028,7 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
           if (k0 < S) {                                  // remainder: clamped reads, masked products
             double l[16], c[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++) { const int kk = min(k0 + j, S - 1); l[j] = L0[kk]; c[j] = C0[kk * NDP]; }
+            for (int j = 0; j < 16; j++) { const int kk = min(k0 + j, S - 1); l[j] = L0[kk]; c[j] = C0[kk * NDP] + CW[kk]; }
             ISSUE_FENCE();
 #pragma unroll
             for (int j = 0; j < 16; j += 2) {
