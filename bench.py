@@ -32,10 +32,11 @@ Each chain runs on a cluster of K workgroups (potus_cluster.hpp); --cus-per-chai
 kernel.  N > 1: one process per GPU; rank r owns chains [r C, (r + 1) C) (RNG streams keyed by global chain id), no
 communication while sampling.  Weak scaling: C chains per GPU whatever N is.
 
---single-process  (with --gpus N, configs[1] / [2]) the path the reference-side binding takes -- R is one process: potus_sample(gpus = 0:7) --: ONE process,
-              N handles on N devices advancing together under potus_run_many, R-hat / ESS of the pooled chains through potus_diagnostics (the other GPUs'
-              blocks come over with peer copies); no torch.distributed, no RCCL.  The line says "launcher": "single_process".  Under the launcher
-              (N > 1) rank 0 adds this run as side.single_process once the ranks have released their GPUs, so that a scaling run times both paths.
+--single-process  (with --gpus N, configs[1] / [2]) the path the reference-side binding takes -- R is one process: potus_sample(gpus =
+              0:7) --: ONE process, N handles on N devices advancing together under potus_run_many, R-hat / ESS of the pooled chains
+              through potus_diagnostics (the other GPUs' blocks come over with peer copies); no torch.distributed, no RCCL.  The line says
+              "launcher": "single_process".  Under the launcher (N > 1) rank 0 adds this run as side.single_process once the ranks have
+              released their GPUs, so that a scaling run times both paths.
 
 Rank 0 prints ONE JSON line.  `value` = leapfrogs of all chains on all GPUs / max-over-ranks wall time of
 (init + K chunks [+ all-gather]), inputs already resident in HBM.
@@ -86,7 +87,8 @@ def measured_traffic(kernel, sides=1):
 
 # ------------------------------------------------------------------------------------------------ N ranks
 def visible_gpus():
-    """HIP devices this process would see, counted in a child process so that the parent never initialises the runtime before its ranks do."""
+    """HIP devices this process would see, counted in a child process so that the parent never initialises the runtime before its ranks
+    do."""
     import subprocess
     try:
         out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count() if torch.cuda.is_available() else 0)"],
@@ -97,7 +99,8 @@ def visible_gpus():
 
 
 def launch_ranks(n):
-    """`python bench.py --gpus N` without a launcher: N ranks of this very command under torch.distributed.run (see the module docstring)."""
+    """`python bench.py --gpus N` without a launcher: N ranks of this very command under torch.distributed.run (see the module
+    docstring)."""
     import socket
     import subprocess
     have = visible_gpus()
@@ -120,7 +123,8 @@ def launch_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
-# ------------------------------------------------------------------------------------------------ the other configurations, beside the default line
+# ------------------------------------------------------------------------------------------------ the other configurations, beside the
+# default line
 def seed_summary(entry):
     """What `side.seeds` keeps of one configs[1] run: rate, time, ESS / s and how deep each chain's trees go in the sampling phase."""
     post = next(iter(entry["config"]["posteriors"].values()))
@@ -130,12 +134,13 @@ def seed_summary(entry):
 
 
 def side_measurements(seed, budget_s=200.0, headline=None):
-    """BASELINE's other single-GPU configurations under the same clock as the default line: each is this very script with
-    --config X in a child process (GPU only: no CPU baseline, no saturated point, no side measurements of its own), after the timed region and
-    after the default run's handles are gone; the child's JSON line is kept in a compact form.  A failure or a timeout costs its own entry only.
-    Round 6: `seeds` -- the headline configuration itself (configs[1]) run again under seeds + 1 and + 2, with the default
-    line's own run (`headline`, its seed_summary) beside them and min / median / max over the three: a launch lasts as long as its slowest chain,
-    and whether a chain of this posterior ends its warm-up in trees of eight or nine doublings is a property of (kernel, seed, summation order)."""
+    """BASELINE's other single-GPU configurations under the same clock as the default line: each is this very script
+    with --config X in a child process (GPU only: no CPU baseline, no saturated point, no side measurements of its own), after the timed
+    region and after the default run's handles are gone; the child's JSON line is kept in a compact form.  A failure or a timeout costs
+    its own entry only. Round 6: `seeds` -- the headline configuration itself (configs[1]) run again under seeds + 1
+    and + 2, with the default line's own run (`headline`, its seed_summary) beside them and min / median / max over the three: a launch
+    lasts as long as its slowest chain, and whether a chain of this posterior ends its warm-up in trees of eight or nine doublings is a
+    property of (kernel, seed, summation order)."""
     import subprocess
     out, t_all = {}, time.perf_counter()
     plan = [("configs[0]", 0, [], 120), ("configs[3]", 3, [], 120)]
@@ -176,12 +181,11 @@ def side_measurements(seed, budget_s=200.0, headline=None):
                                                                 "matrix_passes", "avg_pass_ms", "matrix_bytes_streamed", "metric_storage",
                                                                         "pooled_metric", "mfma") if k in d["roofline"]}
             if "runs" in d:     # configs[0]: the reference's scripted calls, one by one
+                gpu_keys = ("seconds", "leapfrogs", "leapfrogs_per_sec", "ess_bulk_min", "ess_per_sec", "divergent_transitions", "cus_per_chain",
+                            "clusters_per_chain")
                 e["runs"] = [{"call": r_["call"], "posterior": r_["posterior"], "variant": r_["variant"], "chains": r_["chains"],
-                        "iter_warmup": r_["iter_warmup"],
-                              "iter_sampling": r_["iter_sampling"], **{k: r_["gpu"][k] for k in ("seconds", "leapfrogs",
-                                      "leapfrogs_per_sec", "ess_bulk_min", "ess_per_sec",
-                                                                                               "divergent_transitions", "cus_per_chain",
-                                                                                                       "clusters_per_chain")}} for r_ in d["runs"]]
+                              "iter_warmup": r_["iter_warmup"], "iter_sampling": r_["iter_sampling"], **{k: r_["gpu"][k] for k in gpu_keys}}
+                             for r_ in d["runs"]]
             if "dense" in d:
                 e["dense"] = {k: d["dense"][k] for k in ("window_ends", "window_end_seconds", "cholesky_seconds", "cholesky_tflops",
                         "adapted_phase") if k in d["dense"]}
@@ -224,13 +228,14 @@ def side_measurements(seed, budget_s=200.0, headline=None):
 
 # ------------------------------------------------------------------------------------------------ the R-facing multi-GPU path
 def single_process_side(args, n):
-    """`bench.py --gpus n --single-process` as a child process of rank 0 (the other ranks wait at a barrier with their samplers closed): compact form of its line."""
+    """`bench.py --gpus n --single-process` as a child process of rank 0 (the other ranks wait at a barrier with their samplers closed):
+    compact form of its line."""
     import subprocess
     t0 = time.perf_counter()
     try:
         cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", str(n), "--single-process", "--seed", str(args.seed), "--steps",
-               str(args.steps), "--warmup", "1", "--chunk", str(args.chunk), "--chains-per-gpu", str(args.chains_per_gpu), "--cus-per-chain",
-               str(args.cus_per_chain), "--twin", str(args.twin), "--warm-steps", str(args.warm_steps)]
+               str(args.steps), "--warmup", "1", "--chunk", str(args.chunk), "--chains-per-gpu", str(args.chains_per_gpu),
+               "--cus-per-chain", str(args.cus_per_chain), "--twin", str(args.twin), "--warm-steps", str(args.warm_steps)]
         cmd += ["--max-depth", str(args.max_depth)] if args.max_depth is not None else []
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=420,
                            env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR",
@@ -254,10 +259,11 @@ def single_process_side(args, n):
 
 
 def single_process_line(args):
-    """`bench.py --gpus N --single-process`: what potus_sample(gpus = 0:(N-1)) does from R's one process (R/potus_sampling.R; final_2016.R:536 is the
-    reference's only parallelism, `parallel_chains`) -- N handles of 8 chains on N devices under potus_run_many, chain ids by block as in the multi-process run
-    (same draws), the pooled chains' R-hat / bulk ESS of lp__, mu_b[:, T] and predicted_score[T, :] through potus_diagnostics on the first handle's GPU.
-    POTUS_BENCH_DEVICES="0,0" (development / tests on a one-GPU box) names the device of every handle."""
+    """`bench.py --gpus N --single-process`: what potus_sample(gpus = 0:(N-1)) does from R's one process (R/potus_sampling.R;
+    final_2016.R:536 is the reference's only parallelism, `parallel_chains`) -- N handles of 8 chains on N devices under potus_run_many,
+    chain ids by block as in the multi-process run (same draws), the pooled chains' R-hat / bulk ESS of lp__, mu_b[:, T] and
+    predicted_score[T, :] through potus_diagnostics on the first handle's GPU. POTUS_BENCH_DEVICES="0,0" (development / tests on a one-GPU
+    box) names the device of every handle."""
     from us_potus_model_amd import Handle, device_diagnostics, run_many
     n = args.gpus
     devs = [int(x) for x in os.environ["POTUS_BENCH_DEVICES"].split(",")] if os.environ.get("POTUS_BENCH_DEVICES") else list(range(n))
@@ -506,10 +512,11 @@ def reference_sampler_calls(local, seed, cus_per_chain, twin, max_depth, cpu=Tru
                                "kind": "port", "mean_predicted_score_T": ccols[:, :, 1 + S:].mean(axis=(0, 1)).tolist(),
                                "note": "oracle/potus_oracle.c, scan/sparse gradient, pooled-buffer tree, one chain per host process: the "
                                        "same run (seed, chain ids) to completion"}
+            score_gpu, score_cpu = np.array(run["gpu"]["mean_predicted_score_T"]), np.array(run["cpu_port"]["mean_predicted_score_T"])
             run["gpu_over_cpu"] = {"wall": c_secs / (t2 - t0),
-                    "leapfrogs_per_sec": run["gpu"]["leapfrogs_per_sec"] / run["cpu_port"]["leapfrogs_per_sec"],
+                                   "leapfrogs_per_sec": run["gpu"]["leapfrogs_per_sec"] / run["cpu_port"]["leapfrogs_per_sec"],
                                    "ess_per_sec": run["gpu"]["ess_per_sec"] / run["cpu_port"]["ess_per_sec"],
-                                   "max_abs_diff_of_mean_predicted_score_T": float(np.abs(np.array(run["gpu"]["mean_predicted_score_T"]) - np.array(run["cpu_port"]["mean_predicted_score_T"])).max())}
+                                   "max_abs_diff_of_mean_predicted_score_T": float(np.abs(score_gpu - score_cpu).max())}
         out.append(run)
     return out
 
@@ -588,10 +595,12 @@ def main():
     # the N > 1 flow on a one-GPU box (the measured configuration is one rank per GPU over RCCL)
     dev_backend = os.environ.get("POTUS_DIST_BACKEND")
     rank, world, local = parallel.init_process_group(dev_backend)
-    # (the single-process side run needs the GPUs to itself: not in the development mode, where the ranks share GPU 0 -- unless a test asks for it)
+    # (the single-process side run needs the GPUs to itself: not in the development mode, where the ranks share GPU 0 -- unless a test asks
+    # for it)
     sp_side = dev_backend != "gloo" or bool(os.environ.get("POTUS_BENCH_FORCE_SP_SIDE"))
     wait_for_rank0 = None
-    if world > 1:                                           # the job's key-value store (TCP, CPU side): how the ranks wait for rank 0's side measurement without a GPU kernel
+    # the job's key-value store (TCP, CPU side): how the ranks wait for rank 0's side measurement without a GPU kernel
+    if world > 1:
         import torch.distributed as dist
         wait_for_rank0 = dist.distributed_c10d._get_default_store()
     if world != args.gpus:
@@ -642,7 +651,8 @@ def main():
     chunk = args.chunk or (1 if cfg == 4 else 100)
     if args.pooled_metric and (cfg != 4 or args.metric_storage != "f64"):
         raise SystemExit("--pooled-metric applies to --config 4 with fp64 storage")
-    # (N > 1: every window end pooled over the ranks as well -- pooled_metric = 2, sampler.run_pooled: two small all-reduces and one of D x D doubles per window end)
+    # (N > 1: every window end pooled over the ranks as well -- pooled_metric = 2, sampler.run_pooled: two small all-reduces and one of D x
+    # D doubles per window end)
     pooled_mode = 0 if not args.pooled_metric else (2 if world > 1 else 1)
     work = load_workloads(cfg, args.chains_per_gpu, "" if dev_backend == "gloo" else args.twin_posteriors,
             1 if args.metric_storage == "f32" else 0, pooled_mode)
@@ -734,7 +744,8 @@ def main():
             from us_potus_model_amd import device_diagnostics_of_block
             # + predicted_score[T, :] = inv_logit(mu_b[:, T]) as S columns of their own (stan:137): a monotone map keeps the ranks, hence
             # the bulk ESS, but not the FOLDED split R-hat (|x - median| is not invariant under it), and the metric's column set names them
-            # (two calls -- the gathered block as it is, then the S sigmoid columns -- instead of one concatenated copy of the whole block: ADVICE r05)
+            # (two calls -- the gathered block as it is, then the S sigmoid columns -- instead of one concatenated copy of the whole block:
+            # ADVICE r05)
             sig = torch.sigmoid(full[:, :, 1 + ncol - S:]).contiguous()
             nf = int(full.shape[2])
             ncols_all = nf + S
@@ -806,7 +817,8 @@ def main():
                                               "note": "potus_diagnostics_device over every gathered column (lp__ + mu_b) + "
                                                       "predicted_score[T, :], pooled chains of all ranks, inside the timed region"}
                 ess_all.append(info["ess_bulk_min"]); rhat_all.append(info["rhat_max"])
-            elif pl is not None and ns >= 8:                                     # development mode (collectives on CPU tensors): the numpy restatement
+            # development mode (collectives on CPU tensors): the numpy restatement
+            elif pl is not None and ns >= 8:
                 x = np.transpose(pl.cpu().numpy(), (1, 0, 2))                    # [chain, draw, 1 + S]
                 cols = np.concatenate([x, 1.0 / (1.0 + np.exp(-x[:, :, 1:]))], axis=2)   # + predicted_score[T, :]
                 info["ess_bulk_min"] = float(min(dg.ess_bulk(cols[:, :, j]) for j in range(cols.shape[2])))
@@ -829,7 +841,8 @@ def main():
                                 f"calibrated at 0.500 counted "
                         f"bytes per streamed byte for the sampler's 8- and 16-byte plain and sc1 loads, "
                                 f"profiles/r04_fetch_size_calibration.txt; WRITE_SIZE "
-                        f"at 1.000, profiles/r03_write_size_calibration.txt) x this run's leapfrogs / launch time" if tr else "no PMC pass committed for this kernel")
+                        f"at 1.000, profiles/r03_write_size_calibration.txt) x this run's leapfrogs / launch time" if tr
+                        else "no PMC pass committed for this kernel")
         if dense and args.pooled_metric:
             traffic, traffic_note = None, "no counter pass committed for k_dn_pool_mm"
             for f in sorted((ROOT / "profiles").glob("*dense_pooled_pmc_fetch.json")):
@@ -841,7 +854,8 @@ def main():
                 traffic_note = (f"NOT measured in this run: HBM reads of k_dn_pool_mm = {ratio:.3f} x the bytes of the matrix (rocprofv3 "
                                 f"--pmc FETCH_SIZE pass of the pooled "
                                 f"sampler, doubled per the guide; profiles/{f.name}) x this run's rate")
-        elif dense:   # the matrix pass: HBM reads measured / bytes loaded by construction, from the committed counter pass of the dense sampler
+        # the matrix pass: HBM reads measured / bytes loaded by construction, from the committed counter pass of the dense sampler
+        elif dense:
             for f in sorted((ROOT / "profiles").glob("*dense_pmc_fetch.json")):
                 try:
                     ratio = json.loads(f.read_text())["ratio_with_finish"]
@@ -893,7 +907,8 @@ def main():
                              "avg_pass_ms": dense_t[0] / max(dense_t[1], 1), "leaf_rounds": dense_t[3],
                              "metric_storage": args.metric_storage} if dense else {}),
                          **({"pooled_metric": True, "kernel": "k_dn_pool_mm",
-                             # the pooled pass is a D x D times D x R product: its second bound is the fp64 matrix peak (MI355X_MICROARCH.md: 78.6 TFLOP/s dense)
+                             # the pooled pass is a D x D times D x R product: its second bound is the fp64 matrix peak
+                             # (MI355X_MICROARCH.md: 78.6 TFLOP/s dense)
                              "mfma": {"bound": "mfma", "achieved": 2.0 * hs[0].D ** 2 * 2.0 * sum(lf_local) / max(dense_t[0] * 1e-3,
                                      1e-9) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                                       "frac": 2.0 * hs[0].D ** 2 * 2.0 * sum(lf_local) / max(dense_t[0] * 1e-3, 1e-9) / 1e12 / 78.6,
@@ -904,7 +919,8 @@ def main():
                             if dense and args.pooled_metric else {}),
                          "note": (f"latency-bound at {C_tot} chains ({C_tot * K * sides} of 256 CUs busy): the state of a chain stays in "
                                   f"L2, a leapfrog "
-                                  "is a chain of dependent phases and exchanges between the CUs of a cluster; see DESIGN.md") if not dense else
+                                  "is a chain of dependent phases and exchanges between the CUs of a cluster; see DESIGN.md")
+                                 if not dense else
                                  ("pooled dense metric (potus_opts.pooled_metric, a declared deviation from Stan): every leaf "
                                          "ROUND streams the handle's one full "
                                   "symmetric D x D inverse metric (8 D^2 bytes) once for all chains and multiplies it with their "
@@ -918,19 +934,22 @@ def main():
         }
         if dense:
             at = hs[0].dense_adapt_timing()
-            adapted = [p for p in per_step if p["window_ends_so_far"] > 0 and p is not next((q for q in per_step if q["window_ends_so_far"] > 0), None)]
+            first_adapted = next((q for q in per_step if q["window_ends_so_far"] > 0), None)
+            adapted = [p for p in per_step if p["window_ends_so_far"] > 0 and p is not first_adapted]
+            mv_ms, ad_s = sum(p["matrix_pass_ms"] for p in adapted), sum(p["seconds"] for p in adapted)
             line["dense"] = {
                 "window_ends": at["window_ends"], "window_end_seconds": (at["cov_ms"] + at["chol_ms"] + at["init_stepsize_ms"]) * 1e-3,
                 "covariance_seconds": at["cov_ms"] * 1e-3, "cholesky_seconds": at["chol_ms"] * 1e-3,
                         "init_stepsize_seconds": at["init_stepsize_ms"] * 1e-3,
-                "cholesky_tflops": ((1 if args.pooled_metric else work[0][3]) * hs[0].D ** 3 / 3.0 * at["window_ends"]) / max(at["chol_ms"] * 1e-3, 1e-9) / 1e12,
+                "cholesky_tflops": ((1 if args.pooled_metric else work[0][3]) * hs[0].D ** 3 / 3.0 * at["window_ends"])
+                                   / max(at["chol_ms"] * 1e-3, 1e-9) / 1e12,
                 "matrices_factored_per_window_end": 1 if args.pooled_metric else work[0][3],
                 "adapted_phase": ({"steps": len(adapted), "leapfrogs": sum(p["leapfrogs"] for p in adapted),
                         "seconds": sum(p["seconds"] for p in adapted),
                                    "leapfrogs_per_sec": sum(p["leapfrogs"] for p in adapted) / max(sum(p["seconds"] for p in adapted),
                                            1e-9),
-                                   "matrix_pass_TBps": sum(p["matrix_bytes"] for p in adapted) / max(sum(p["matrix_pass_ms"] for p in adapted), 1e-9) / 1e9,
-                                   "matrix_pass_share_of_wall": sum(p["matrix_pass_ms"] for p in adapted) * 1e-3 / max(sum(p["seconds"] for p in adapted), 1e-9),
+                                   "matrix_pass_TBps": sum(p["matrix_bytes"] for p in adapted) / max(mv_ms, 1e-9) / 1e9,
+                                   "matrix_pass_share_of_wall": mv_ms * 1e-3 / max(ad_s, 1e-9),
                                    "note": "the steps after the one in which the first window ended: transitions under the adapted dense "
                                            "metric"}
                                   if adapted else None),
@@ -1048,8 +1067,10 @@ def main():
         torch.cuda.empty_cache()
         parallel.barrier()
         torch.cuda.synchronize()
-        # Rank 0's child process now needs every compute unit of every GPU resident for its cluster launches: the other ranks must NOT wait for it inside an
-        # RCCL collective (a barrier is a kernel that spins on the GPU and holds compute units) -- they block on the job's TCP store, on the CPU
+        # Rank 0's child process now needs every compute unit of every GPU resident for its cluster launches: the other ranks must NOT wait
+        # for it inside an
+        # RCCL collective (a barrier is a kernel that spins on the GPU and holds compute units) -- they block on the job's TCP store, on the
+        # CPU
         wait_for_rank0.wait(["bench_side_done"], __import__("datetime").timedelta(seconds=900))
     for h in hs:
         h.close()
