@@ -181,8 +181,8 @@ def side_measurements(seed, budget_s=200.0, headline=None):
                                                                 "matrix_passes", "avg_pass_ms", "matrix_bytes_streamed", "metric_storage",
                                                                         "pooled_metric", "mfma") if k in d["roofline"]}
             if "runs" in d:     # configs[0]: the reference's scripted calls, one by one
-                gpu_keys = ("seconds", "leapfrogs", "leapfrogs_per_sec", "ess_bulk_min", "ess_per_sec", "divergent_transitions", "cus_per_chain",
-                            "clusters_per_chain")
+                gpu_keys = ("seconds", "leapfrogs", "leapfrogs_per_sec", "ess_bulk_min", "ess_per_sec", "divergent_transitions",
+                            "cus_per_chain", "clusters_per_chain")
                 e["runs"] = [{"call": r_["call"], "posterior": r_["posterior"], "variant": r_["variant"], "chains": r_["chains"],
                               "iter_warmup": r_["iter_warmup"], "iter_sampling": r_["iter_sampling"], **{k: r_["gpu"][k] for k in gpu_keys}}
                              for r_ in d["runs"]]
