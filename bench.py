@@ -145,7 +145,8 @@ def side_measurements(seed, budget_s=200.0, headline=None):
     out, t_all = {}, time.perf_counter()
     plan = [("configs[0]", 0, [], 120), ("configs[3]", 3, [], 120)]
     plan += [(f"seed_{seed + k}", 1, ["--seed", str(seed + k), "--warmup", "1"], 90) for k in (1, 2)]
-    plan += [("configs[4]_preset", 4, [], 240), ("configs[4]_pooled", 4, ["--pooled-metric"], 150)]
+    plan += [("configs[4]_preset", 4, [], 240), ("configs[4]_pooled", 4, ["--pooled-metric"], 150),
+             ("configs[4]_pooled_f32", 4, ["--pooled-metric", "--metric-storage", "f32"], 150)]
     seed_runs = [headline] if headline else []
     for key, cfg, extra, tmo in plan:
         left = budget_s - (time.perf_counter() - t_all)
@@ -221,7 +222,8 @@ def side_measurements(seed, budget_s=200.0, headline=None):
                    "concurrently on this one GPU (4 chains each), configs[4]_preset = the dense-metric stress shape in its "
                            "driver-runnable preset, "
                    "configs[4]_pooled = the same preset with potus_opts.pooled_metric (one inverse metric per GPU: a declared "
-                           "deviation from Stan)")
+                           "deviation from Stan), configs[4]_pooled_f32 = that one matrix kept rounded to fp32 as well (metric_storage = f32: "
+                           "half the bytes per pass, fp64 arithmetic)")
     out["seconds"] = time.perf_counter() - t_all
     return out
 
@@ -649,8 +651,8 @@ def main():
         parallel.barrier()
         return
     chunk = args.chunk or (1 if cfg == 4 else 100)
-    if args.pooled_metric and (cfg != 4 or args.metric_storage != "f64"):
-        raise SystemExit("--pooled-metric applies to --config 4 with fp64 storage")
+    if args.pooled_metric and cfg != 4:
+        raise SystemExit("--pooled-metric applies to --config 4")
     # (N > 1: every window end pooled over the ranks as well -- pooled_metric = 2, sampler.run_pooled: two small all-reduces and one of D x
     # D doubles per window end)
     pooled_mode = 0 if not args.pooled_metric else (2 if world > 1 else 1)
@@ -915,7 +917,7 @@ def main():
                                       "note": "2 D^2 flops per right-hand side, two right-hand sides per counted leapfrog (the first "
                                               "pass of a transition carries three: not counted), "
                                               "over the time of the passes; the pass streams the FULL symmetric matrix (8 D^2 "
-                                                      "bytes) once per round for all chains"}}
+                                                      "bytes; 4 D^2 with --metric-storage f32) once per round for all chains"}}
                             if dense and args.pooled_metric else {}),
                          "note": (f"latency-bound at {C_tot} chains ({C_tot * K * sides} of 256 CUs busy): the state of a chain stays in "
                                   f"L2, a leapfrog "
@@ -923,7 +925,8 @@ def main():
                                  if not dense else
                                  ("pooled dense metric (potus_opts.pooled_metric, a declared deviation from Stan): every leaf "
                                          "ROUND streams the handle's one full "
-                                  "symmetric D x D inverse metric (8 D^2 bytes) once for all chains and multiplies it with their "
+                                  "symmetric D x D inverse metric (8 D^2 bytes; 4 D^2 when it is kept rounded to fp32) once for "
+                                          "all chains and multiplies it with their "
                                           "right-hand sides on the fp64 matrix "
                                   "cores; achieved = bytes loaded by the passes / their time; roofline.mfma is the same passes "
                                           "against the matrix peak"

@@ -131,7 +131,9 @@ typedef struct potus_opts {
                               rounded to fp32 and THAT matrix is the metric: its Cholesky factor (fp64) draws the momenta, the
                               leapfrog multiplies with it (fp64 accumulation), so the sampler stays exact while the matrix pass
                               of every leapfrog streams 2 D^2 bytes instead of 4 D^2.  A declared deviation from Stan, which
-                              keeps the covariance in fp64; same memory per chain. */
+                              keeps the covariance in fp64; same memory per chain.  With pooled_metric
+                              the handle's ONE matrix is kept in fp32 beside its fp64 factor and the pooled pass streams 4 D^2
+                              bytes per round instead of 8 D^2. */
   int32_t pooled_metric;   /* dense metric only, 0 (Stan's: every chain adapts its own covariance), 1 or 2 (as 1, but every window end is finished by
                               the host, which may pool over several handles and GPUs first: potus_dense_pool_window).  1: at every window end the draws of ALL
                               chains of the handle form ONE regularised covariance -- covar_adaptation::learn_covariance applied to the

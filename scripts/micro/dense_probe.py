@@ -39,7 +39,8 @@ SPLIT_CASES = (0, 1, 2, 3, 4, 6, 8)
 
 
 def pooled_sweep(D=41610):
-    """k_dn_pool_mm + k_dn_pool_finish on a generated matrix: ms per pass, TB/s of the 8 D^2 bytes it streams, TFLOP/s of its 2 D^2 R flops."""
+    """k_dn_pool_mm + k_dn_pool_finish on a generated matrix: ms per pass, TB/s of the 8 D^2 bytes it streams, TFLOP/s of its 2 D^2 R flops.
+    POTUS_PROBE_F32=1: the same with the matrix kept rounded to fp32 (metric_storage = f32: 4 D^2 bytes per pass)."""
     L.potus_dense_pool_matvec_probe.argtypes = L.potus_dense_matvec_probe.argtypes
     nrhs = 2
     LD = (D + 7) // 8 * 8

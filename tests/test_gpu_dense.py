@@ -327,24 +327,28 @@ def test_dense_fp32_storage_samples_the_same_posterior(cases):
 
 
 # ---------------------------------------------------------------- potus_opts.pooled_metric (csrc/potus_dense_pool.hpp; round 6)
-@pytest.mark.parametrize("chains,D,nrhs", [(3, 1000, 1), (2, 2049, 2), (16, 700, 2), (17, 333, 3), (1, 71, 2), (5, 257, 3), (2, 16500, 3), (4, 4097, 2)])
-def test_pooled_product_against_numpy(chains, D, nrhs, monkeypatch):
+@pytest.mark.parametrize("chains,D,nrhs,f32", [(3, 1000, 1, 0), (2, 2049, 2, 0), (16, 700, 2, 0), (17, 333, 3, 0), (1, 71, 2, 0), (5, 257, 3, 0), (2, 16500, 3, 0),
+                                               (4, 4097, 2, 0), (3, 1000, 1, 1), (16, 700, 2, 1), (17, 333, 3, 1), (1, 71, 2, 1), (2, 16500, 3, 1), (4, 4097, 2, 1)])
+def test_pooled_product_against_numpy(chains, D, nrhs, f32, monkeypatch):
     """Y = M^-1 X for ONE full symmetric matrix and the right-hand sides of every chain in one pass on the fp64 matrix cores (k_dn_pool_mm +
     k_dn_pool_finish): one to three operand tiles of sixteen right-hand sides, more than 48 of them (several launches), column panels and row
     splits with ragged ends, odd D (padded rows), D below one panel; the fused x_0 . M^-1 x_0 per chain; reproducible bit for bit; and a chain's
-    numbers do not depend on which other chains take part in the launch."""
+    numbers do not depend on which other chains take part in the launch.  f32: the same with metric_storage = f32 -- the matrix rounded to fp32 IS the
+    matrix (four columns per 16-byte load, panels of 512 columns), the arithmetic stays fp64: the same tolerance against the rounded matrix, half the bytes."""
     L = _lib()
+    monkeypatch.setenv("POTUS_PROBE_F32", str(f32))
     rng = np.random.default_rng(4)
     B = rng.standard_normal((D, 8))
     M = B @ B.T / 8 + np.eye(D)
+    Mref = M.astype(np.float32).astype(np.float64) if f32 else M
     x = rng.standard_normal((chains, nrhs, D))
     out = []
     for _ in range(2):
         y, dot, ms, nb = np.zeros((chains, nrhs, D)), np.zeros(chains), C.c_double(), C.c_longlong()
         assert L.potus_dense_pool_matvec_probe(0, chains, D, nrhs, M.ctypes.data, x.ctypes.data, y.ctypes.data, dot.ctypes.data, 2, C.byref(ms), C.byref(nb)) == 0
-        assert nb.value == 8 * D * ((D + 7) // 8 * 8) * -(-chains * nrhs // 48)        # the whole matrix once per launch of up to 48 right-hand sides
+        assert nb.value == (4 if f32 else 8) * D * ((D + 7) // 8 * 8) * -(-chains * nrhs // 48)   # the whole matrix once per launch of up to 48 right-hand sides
         out.append((y, dot))
-    ref = np.einsum("ij,crj->cri", M, x)
+    ref = np.einsum("ij,crj->cri", Mref, x)
     assert np.abs(out[0][0] - ref).max() <= 1e-12 * np.abs(ref).max() * np.sqrt(D)
     assert np.allclose(out[0][1], np.einsum("ci,ci->c", x[:, 0], ref[:, 0]), rtol=1e-11)
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
@@ -356,13 +360,15 @@ def test_pooled_product_against_numpy(chains, D, nrhs, monkeypatch):
             assert np.array_equal(y2[c], out[0][0][c]) and dot2[c] == out[0][1][c]
 
 
-@pytest.mark.parametrize("chains,D,n", [(4, 300, 10), (2, 1000, 25), (3, 2051, 40)])
-def test_pooled_window_end_against_numpy(chains, D, n):
+@pytest.mark.parametrize("chains,D,n,f32", [(4, 300, 10, 0), (2, 1000, 25, 0), (3, 2051, 40, 0), (4, 300, 10, 1), (3, 2051, 40, 1)])
+def test_pooled_window_end_against_numpy(chains, D, n, f32, monkeypatch):
     """The pooled window end on caller data: ONE M^-1 = N/(N+5) cov + 1e-3 5/(N+5) I over the N = chains x n draws of all chains
     (covar_adaptation::learn_covariance applied to the pooled sample), stored as the full symmetric matrix; ONE blocked Cholesky factor in
-    its own buffer; every chain's momentum draw p = L^-T u out of that one factor."""
+    its own buffer; every chain's momentum draw p = L^-T u out of that one factor.  f32 (metric_storage = f32): the matrix is that estimate rounded to
+    fp32 -- exactly representable, symmetric -- and the factor is the factor OF THE ROUNDED matrix to fp64 accuracy."""
     import scipy.linalg as sl
     L = _lib()
+    monkeypatch.setenv("POTUS_PROBE_F32", str(f32))
     rng = np.random.default_rng(11)
     draws = rng.standard_normal((chains, n, D)) * rng.uniform(0.2, 3.0, (1, 1, D)) + rng.standard_normal((chains, 1, D))
     u = rng.standard_normal((chains, D))
@@ -370,7 +376,10 @@ def test_pooled_window_end_against_numpy(chains, D, n):
     assert L.potus_dense_pool_factor_probe(0, chains, D, n, draws.ctypes.data, u.ctypes.data, Mi.ctypes.data, Lc.ctypes.data, p.ctypes.data, ms) == 0
     N = chains * n
     ref = (N / (N + 5.0)) * np.cov(draws.reshape(N, D).T) + 1e-3 * (5.0 / (N + 5.0)) * np.eye(D)
-    assert np.allclose(Mi, ref, rtol=1e-10, atol=1e-12 * np.abs(ref).max()) and np.array_equal(Mi, Mi.T)
+    if f32:
+        assert np.array_equal(Mi, Mi.astype(np.float32).astype(np.float64)) and np.allclose(Mi, ref, rtol=1e-7, atol=1e-7 * np.abs(ref).max()) and np.array_equal(Mi, Mi.T)
+    else:
+        assert np.allclose(Mi, ref, rtol=1e-10, atol=1e-12 * np.abs(ref).max()) and np.array_equal(Mi, Mi.T)
     Lg = np.tril(Lc)
     assert np.allclose(Lg @ Lg.T, Mi, rtol=1e-10, atol=1e-12 * np.abs(ref).max())
     for c in range(chains):
@@ -411,9 +420,10 @@ def test_pooled_sampler_replayed_through_every_window_end(cases, cus):
     g.close()
 
 
-def test_pooled_sampler_is_reproducible_and_chunk_invariant(cases):
+@pytest.mark.parametrize("storage", [_abi.STORAGE_F64, _abi.STORAGE_F32])
+def test_pooled_sampler_is_reproducible_and_chunk_invariant(cases, storage):
     data, variant = cases["small_nomode"]
-    kw = dict(chains=3, num_warmup=40, num_samples=10, seed=7, metric=_abi.METRIC_DENSE, pooled_metric=1)
+    kw = dict(chains=3, num_warmup=40, num_samples=10, seed=7, metric=_abi.METRIC_DENSE, pooled_metric=1, metric_storage=storage)
     a = Handle(data, variant, **kw); a.init(); a.run(50); da = a.draws(); a.close()
     b = Handle(data, variant, **kw); b.init(); b.run(33); b.run(3); b.run(14); db = b.draws(); b.close()
     assert np.array_equal(da, db) and np.isfinite(da).all()
@@ -447,16 +457,20 @@ def test_pooled_posterior_parity_small(cases):
     h.close()
 
 
-def test_pooled_transitions_after_the_window_match_the_oracle_at_2016_size(cases):
+@pytest.mark.parametrize("storage", [_abi.STORAGE_F64, _abi.STORAGE_F32])
+def test_pooled_transitions_after_the_window_match_the_oracle_at_2016_size(cases, storage):
     """D = 15 098 with ONE 1.8 GB inverse metric for 4 chains (30 warm-up iterations: one window of 4 x 23 pooled draws, update after iteration 26;
     236-block Cholesky in the factor's own buffer).  The matrix every chain reports is the pooled estimate; the three transitions that follow are the
     oracle's from the device's own state under that matrix and its factor -- momenta from the one factor, p# = M^-1 p out of the pooled pass
     (k_dn_pool_mm): same tree depth, leapfrog count and divergence flag, values to 1e-6, for the first and the last chain.  (A posterior-level
     comparison at this size would say nothing: a dense metric adapted on a few hundred draws in 15 098 dimensions leaves every tree at its depth
-    limit -- DESIGN 4c; the small-model test above carries the statistical parity.)"""
+    limit -- DESIGN 4c; the small-model test above carries the statistical parity.)  With metric_storage = f32 the matrix every chain reports is that
+    estimate rounded to fp32, and the oracle's transitions under THAT matrix are the device's: one 0.9 GB matrix streamed per round."""
     data, variant = cases["2016"]
     nw, md, chains = 30, 6, 4
-    h = Handle(data, variant, chains=chains, num_warmup=nw, num_samples=0, save_warmup=1, seed=1843, metric=_abi.METRIC_DENSE, max_depth=md, pooled_metric=1)
+    f32 = storage == _abi.STORAGE_F32
+    h = Handle(data, variant, chains=chains, num_warmup=nw, num_samples=0, save_warmup=1, seed=1843, metric=_abi.METRIC_DENSE, max_depth=md, pooled_metric=1,
+               metric_storage=storage)
     h.init(); h.run(nw)
     d = h.draws()
     assert np.isfinite(d).all()
@@ -464,14 +478,18 @@ def test_pooled_transitions_after_the_window_match_the_oracle_at_2016_size(cases
     N = len(w)
     want = (N / (N + 5.0)) * np.cov(w.T) + 1e-3 * (5.0 / (N + 5.0)) * np.eye(h.D)
     Mi = h.dense_metric(chains - 1)
-    assert np.allclose(Mi, want, rtol=1e-9, atol=1e-12 * np.abs(want).max()) and np.array_equal(Mi, Mi.T)
+    if f32:
+        assert np.array_equal(Mi, Mi.astype(np.float32).astype(np.float64)) and np.allclose(Mi, want, rtol=1e-6, atol=1e-7 * np.abs(want).max()) and np.array_equal(Mi, Mi.T)
+    else:
+        assert np.allclose(Mi, want, rtol=1e-9, atol=1e-12 * np.abs(want).max()) and np.array_equal(Mi, Mi.T)
     assert np.array_equal(h.dense_metric(0), Mi)
     res, solve = h.dense_check(chains - 1, 2)
     assert res < 1e-12 and solve < 1e-9, (res, solve)
     for c in (0, chains - 1):
         _post_window_rows_against_the_oracle(data, variant, h, d, c, 27, 3, md, Mi, c + 1)
     ms, passes, nbytes, rounds = h.dense_timing()
-    print(f"2016, pooled dense metric, {chains} chains: {passes} matrix passes of {nbytes / max(passes, 1) / 1e9:.2f} GB in {ms:.0f} ms = {nbytes / ms / 1e9:.2f} TB/s; {rounds} leaf rounds")
+    assert nbytes == passes * (4 if f32 else 8) * h.D * ((h.D + 7) // 8 * 8)
+    print(f"2016, pooled dense metric{' (fp32 storage)' if f32 else ''}, {chains} chains: {passes} matrix passes of {nbytes / max(passes, 1) / 1e9:.2f} GB in {ms:.0f} ms = {nbytes / ms / 1e9:.2f} TB/s; {rounds} leaf rounds")
     h.close()
 
 

@@ -363,7 +363,8 @@ def test_side_measurements_keep_the_line_alive(monkeypatch):
     monkeypatch.setattr(subprocess, "run", fake_run)
     monkeypatch.setenv("WORLD_SIZE", "1")
     out = bench.side_measurements(1843, headline=bench.seed_summary({**head, "seed": 1843}))
-    assert calls == ["0", "3", "1", "1", "4", "4"] and list(out)[0] == "seeds" and out["configs[4]_pooled"]["value"] == good["value"]
+    assert calls == ["0", "3", "1", "1", "4", "4", "4"] and list(out)[0] == "seeds" and out["configs[4]_pooled"]["value"] == good["value"]
+    assert out["configs[4]_pooled_f32"]["value"] == good["value"]
     sd = out["seeds"]                                    # the default line's own run first; the child that printed garbage costs its own entry only
     assert [r["seed"] for r in sd["runs"]] == [1843, 1844] and "error" in out["seed_1845"] and sd["deepest_tree_by_seed"] == [8, 9]
     assert sd["leapfrogs_per_sec"]["max"] == head["value"] and abs(sd["leapfrogs_per_sec"]["min"] - 0.8 * head["value"]) < 1e-9
@@ -374,4 +375,5 @@ def test_side_measurements_keep_the_line_alive(monkeypatch):
     assert abs(e["roofline"]["frac"] - good["roofline"]["frac"]) < 1e-15 and "per_step" not in e["dense"] and e["dense"]["window_ends"] == 1
     calls.clear()
     out = bench.side_measurements(1843, budget_s=10.0)                    # nothing fits a budget of ten seconds
-    assert calls == [] and all("skipped" in out[k] for k in ("configs[0]", "configs[3]", "seed_1844", "seed_1845", "configs[4]_preset", "configs[4]_pooled")) and "seeds" not in out
+    assert calls == [] and all("skipped" in out[k] for k in ("configs[0]", "configs[3]", "seed_1844", "seed_1845", "configs[4]_preset", "configs[4]_pooled",
+                                                         "configs[4]_pooled_f32")) and "seeds" not in out

@@ -112,6 +112,7 @@ struct DnParams {
   double *ypool;                     // [pool_split][DNP_RMAX][LD] pooled: the product's partial sums per row split
   double *pmean;                     // [LD] pooled: the mean of the handle's window draws (window end, potus_dense_pool.hpp)
   int pool_split, pool_rows;         // row splits of the pooled product (fixed per handle: the order of summation must not depend on who is active), rows per split
+  float *A32;                        // [D][LD] pooled with metric_storage = f32: the matrix the pass streams (A holds the same rounded values as doubles)
 };
 // where a chain's matrix, factor and diagonal live (pooled: everybody's are the handle's one)
 __device__ __host__ __forceinline__ double *dn_mat(const DnParams &P, int chain) { return P.pooled ? P.A : P.A + (size_t)chain * (size_t)P.D * (size_t)P.LD; }
@@ -1028,7 +1029,10 @@ __global__ __launch_bounds__(256, 2) void k_dn_syrk_wide(const DnParams P, int p
 __global__ void k_dn_identity(const DnParams P) {
   const int chain = blockIdx.y;
   double *A = dn_mat(P, chain), *dg = dn_diag(P, chain), *Lf = dn_fac(P, chain);   // (pooled: launched for one "chain")
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.D; i += gridDim.x * blockDim.x) { A[(size_t)i * P.LD + i] = 1.0; Lf[(size_t)i * P.LD + i] = 1.0; dg[i] = 1.0; }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.D; i += gridDim.x * blockDim.x) {
+    A[(size_t)i * P.LD + i] = 1.0; Lf[(size_t)i * P.LD + i] = 1.0; dg[i] = 1.0;
+    if (P.pooled && P.f32) P.A32[(size_t)i * P.LD + i] = 1.0f;
+  }
 }
 // fills the upper triangle and the diagonal vector with a symmetric positive definite test matrix on the device (rates
 // at sizes that would take seconds to upload): a_ij = exp(-|i-j|/50) * (1 + 0.1 c) + (i == j ? 1 : 0)

@@ -33,6 +33,12 @@
 // third of their rate when squeezed into 128 (70 spills: 5.4 against 3.35 ms) -- profiles/r06_dense_pooled.txt
 #define DNP_WAVES_PER_SIMD(NT) ((NT) <= 2 ? 4 : 2)
 #define DNP_LDS(NT) ((size_t)2 * (NT) * 16 * DNP_XS * 8)
+// potus_opts.metric_storage = f32 on top of pooled_metric: the ONE matrix is kept rounded to fp32 as well (DnParams::A32; the rounded matrix IS the metric, its
+// factor is the factor of the rounded values -- the argument of dn_f32_row), the pass streams 4 D^2 bytes.  A 16-byte load then brings FOUR columns: a wave
+// takes 64 columns as four interleaved operand tiles, a workgroup 512; the arithmetic stays fp64 (v_cvt_f64_f32 on the way into the matrix instruction).
+#define DNP_CT(F32) ((F32) ? 4 : 2)                     // operand tiles (= columns per 16-byte load) per wave
+#define DNP_COLS_OF(F32) (128 * DNP_CT(F32))            // columns per workgroup
+#define DNP_WAVES_PER_SIMD_OF(NT, F32) ((F32) ? ((NT) <= 1 ? 4 : 2) : DNP_WAVES_PER_SIMD(NT))
 
 // the right-hand sides of a pooled launch: column r = (chain, job)
 struct DnPoolRhs {
@@ -46,24 +52,25 @@ struct DnPoolRhs {
 // Software pipeline over batches of DNP_KB rows, two register sets and two LDS buffers: while batch b is multiplied, the matrix block and the right-hand sides of
 // batch b + 1 are on their way (128 registers at NT = 2: two workgroups per compute unit, i.e. four waves per SIMD to hide what is left).  First version of the
 // round (one batch of 64 rows in flight, nothing requested ahead): 4.6 TB/s with 32 right-hand sides at D = 41 610, the matrix pipe 47 % busy.
-template <int NT>
-__global__ __launch_bounds__(DNP_THREADS, DNP_WAVES_PER_SIMD(NT)) void k_dn_pool_mm(const DnParams P, const DnPoolRhs R, int rows_per_split) {
+template <int NT, bool F32 = false>
+__global__ __launch_bounds__(DNP_THREADS, DNP_WAVES_PER_SIMD_OF(NT, F32)) void k_dn_pool_mm(const DnParams P, const DnPoolRhs R, int rows_per_split) {
+  constexpr int CT = DNP_CT(F32), EB = F32 ? 4 : 8;                  // operand tiles per wave; bytes per stored element
   extern __shared__ __attribute__((aligned(16))) double dnp_lds[];   // [2][NT * 16][DNP_XS]
   typedef double d4_t __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = P.D, LD = P.LD;
-  const int c0 = (int)blockIdx.x * DNP_COLS + 32 * w;                 // the wave's 32 columns
+  const int c0 = (int)blockIdx.x * DNP_COLS_OF(F32) + 16 * CT * w;    // the wave's 32 (fp32 storage: 64) columns
   const int rbeg = (int)blockIdx.y * rows_per_split, rend = min(D, rbeg + rows_per_split);
   const int mcol = lane & 15, krow = lane >> 4;
   // the lane's two columns (operand tile 0: even, tile 1: odd) as one 16-byte load; columns at or beyond D read nothing
-  const int colA = c0 + 2 * mcol;
-  const unsigned rowbytes = uni32(8u * (unsigned)LD);
+  const int colA = c0 + CT * mcol;
+  const unsigned rowbytes = uni32((unsigned)EB * (unsigned)LD);
   // (the lane's row of a four-row step travels in the vector offset -- a scalar offset must be wave-uniform -- and rows beyond the split's end are
   //  masked lane by lane: the bounds check of a raw buffer does not look at the scalar offset)
-  const unsigned voffA = colA + 1 < LD && colA < D ? 8u * (unsigned)colA + (unsigned)krow * rowbytes : PT_OOB;   // (LD is even and the padding columns hold zeros)
-  d4_t acc[2][NT];
+  const unsigned voffA = colA + CT - 1 < LD && colA < D ? (unsigned)EB * (unsigned)colA + (unsigned)krow * rowbytes : PT_OOB;   // (LD is a multiple of 8 and the padding columns hold zeros)
+  d4_t acc[CT][NT];
 #pragma unroll
-  for (int t = 0; t < 2; t++)
+  for (int t = 0; t < CT; t++)
 #pragma unroll
     for (int n = 0; n < NT; n++) acc[t][n] = d4_t{0.0, 0.0, 0.0, 0.0};
   // staging of the right-hand sides: thread -> (row tid & 31 of the batch, right-hand sides (tid >> 5) + 16 i); their vectors are looked up once
@@ -81,7 +88,8 @@ __global__ __launch_bounds__(DNP_THREADS, DNP_WAVES_PER_SIMD(NT)) void k_dn_pool
   }
   auto request = [&](u32x4 (&a)[DNP_KB / 4], int r0) {    // the batch's rows are one resource (none left: size 0, zeros come back); the step of four rows is the scalar offset
     const int nrows = max(0, min(DNP_KB, rend - r0));
-    const rsrc_t rsA = make_rsrc(uni_ptr(P.A + (size_t)min(r0, D - 1) * LD), uni32((unsigned)nrows * rowbytes));
+    const rsrc_t rsA = F32 ? make_rsrc(uni_ptr(P.A32 + (size_t)min(r0, D - 1) * LD), uni32((unsigned)nrows * rowbytes))
+                           : make_rsrc(uni_ptr(P.A + (size_t)min(r0, D - 1) * LD), uni32((unsigned)nrows * rowbytes));
 #pragma unroll
     for (int k = 0; k < DNP_KB / 4; k++)
       a[k] = __builtin_amdgcn_raw_buffer_load_b128(rsA, 4 * k + krow < nrows ? voffA : PT_OOB, (unsigned)(4 * k) * rowbytes, 2 /* nt: read once per round */);
@@ -97,15 +105,20 @@ __global__ __launch_bounds__(DNP_THREADS, DNP_WAVES_PER_SIMD(NT)) void k_dn_pool
   auto multiply = [&](const u32x4 (&a)[DNP_KB / 4], const double *xs) {
 #pragma unroll
     for (int k = 0; k < DNP_KB / 4; k++) {
-      const double a0 = __hiloint2double((int)a[k][1], (int)a[k][0]), a1 = __hiloint2double((int)a[k][3], (int)a[k][2]);
+      double av[CT];
+      if constexpr (F32) {
+#pragma unroll
+        for (int t = 0; t < CT; t++) av[t] = (double)__uint_as_float((unsigned)a[k][t]);
+      } else {
+        av[0] = __hiloint2double((int)a[k][1], (int)a[k][0]); av[1] = __hiloint2double((int)a[k][3], (int)a[k][2]);
+      }
       double bv[NT];
 #pragma unroll
       for (int n = 0; n < NT; n++) bv[n] = xs[(16 * n + mcol) * DNP_XS + 4 * k + krow];
 #pragma unroll
-      for (int n = 0; n < NT; n++) {
-        acc[0][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv[n], acc[0][n], 0, 0, 0);
-        acc[1][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv[n], acc[1][n], 0, 0, 0);
-      }
+      for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int t = 0; t < CT; t++) acc[t][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[n], acc[t][n], 0, 0, 0);
     }
   };
   double *xs0 = dnp_lds, *xs1 = dnp_lds + (size_t)NT * 16 * DNP_XS;
@@ -127,15 +140,15 @@ __global__ __launch_bounds__(DNP_THREADS, DNP_WAVES_PER_SIMD(NT)) void k_dn_pool
     xstore(xs0, xv);
     __syncthreads();
   }
-  // D[(l >> 4) + 4 v][l & 15]: column c0 + 2 ((l >> 4) + 4 v) + tile, right-hand side 16 n + (l & 15)
+  // D[(l >> 4) + 4 v][l & 15]: column c0 + CT ((l >> 4) + 4 v) + tile, right-hand side 16 n + (l & 15)
   double *yp = P.ypool + (size_t)blockIdx.y * DNP_RMAX * (size_t)LD;
 #pragma unroll
-  for (int t = 0; t < 2; t++)
+  for (int t = 0; t < CT; t++)
 #pragma unroll
     for (int n = 0; n < NT; n++)
 #pragma unroll
       for (int v = 0; v < 4; v++) {
-        const int col = c0 + 2 * (krow + 4 * v) + t, r = 16 * n + mcol;
+        const int col = c0 + CT * (krow + 4 * v) + t, r = 16 * n + mcol;
         if (col < D && r < R.n) yp[(size_t)r * LD + col] = acc[t][n][v];
       }
 }
@@ -222,11 +235,24 @@ __global__ __launch_bounds__(256) void k_dn_pool_scale(const DnParams P, double 
   const double f = (nn / (nn + 5.0)) / (nn - 1.0), reg = 1e-3 * (5.0 / (nn + 5.0));
   const int i = blockIdx.y;
   for (int j = blockIdx.x * 256 + threadIdx.x; j <= i; j += gridDim.x * 256) {
-    const double val = f * P.A[(size_t)i * P.LD + j] + (i == j ? reg : 0.0);
+    double val = f * P.A[(size_t)i * P.LD + j] + (i == j ? reg : 0.0);
+    if (P.f32) {                                   // the rounded matrix is the metric: the factor is ITS factor
+      val = (double)(float)val;
+      P.A32[(size_t)i * P.LD + j] = (float)val; P.A32[(size_t)j * P.LD + i] = (float)val;
+    }
     P.A[(size_t)i * P.LD + j] = val;
     P.A[(size_t)j * P.LD + i] = val;
     P.Lf[(size_t)i * P.LD + j] = val;
     if (i == j) P.dg[i] = val;
+  }
+}
+// metric_storage = f32 for a matrix that arrived in fp64 (development: the probes' uploads): A rounded in place, the floats beside it
+__global__ void k_dn_pool_round32(const DnParams P) {
+  const size_t n = (size_t)P.D * P.LD;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float v = (float)P.A[e];
+    P.A32[e] = v; P.A[e] = (double)v;
+    if (e / P.LD == e % P.LD) P.dg[e / P.LD] = (double)v;
   }
 }
 // a symmetric positive definite test matrix generated on the device, as k_dn_fill's of chain 0: a_ij = exp(-|i-j|/50) + (i == j ? 1 : 0), FULL storage
@@ -236,7 +262,8 @@ __global__ void k_dn_pool_fill(const DnParams P) {
     const int i = (int)(e / P.D), j = (int)(e % P.D);
     const int d = i > j ? i - j : j - i;
     const double v = exp(-(double)d / 50.0) + (i == j ? 1.0 : 0.0);
-    P.A[(size_t)i * P.LD + j] = v;
-    if (i == j) P.dg[i] = v;
+    P.A[(size_t)i * P.LD + j] = P.f32 ? (double)(float)v : v;
+    if (P.f32) P.A32[(size_t)i * P.LD + j] = (float)v;
+    if (i == j) P.dg[i] = P.f32 ? (double)(float)v : v;
   }
 }

@@ -1704,14 +1704,14 @@ int dense_alloc(Sampler *sp) {
   // within two workgroups of 256 columns per compute unit -- all resident at once, no tail --, in whole batches of DNP_KB rows.
   P.pool_split = 1; P.pool_rows = D;
   if (P.pooled) {
-    const int panels = (D + DNP_COLS - 1) / DNP_COLS;
+    const int panels = (D + DNP_COLS_OF(P.f32) - 1) / DNP_COLS_OF(P.f32);
     int s = std::max(1, std::min(DNP_SPLIT_MAX, (2 * 256) / panels));   // at most two workgroups per compute unit, all resident at once (measured: profiles/r06_dense_pooled.txt)
     if (const char *e = getenv("POTUS_POOL_SPLIT")) s = std::max(1, std::min(DNP_SPLIT_MAX, atoi(e)));   // development: sweeps
     P.pool_rows = (((D + s - 1) / s + DNP_KB - 1) / DNP_KB) * DNP_KB;
     P.pool_split = (D + P.pool_rows - 1) / P.pool_rows;
   }
   const int mchains = P.pooled ? 1 : chains;
-  const size_t mat = (size_t)mchains * D * P.LD * 8 * (P.pooled ? 2 : 1) + (P.pooled ? (size_t)P.pool_split * DNP_RMAX * P.LD * 8 : 0), vec = (size_t)chains * DV_COUNT * P.LD * 8, win = (size_t)chains * P.win_cap * P.LD * 8;
+  const size_t mat = (size_t)mchains * D * P.LD * 8 * (P.pooled ? 2 : 1) + (P.pooled ? (size_t)P.pool_split * DNP_RMAX * P.LD * 8 : 0) + (P.pooled && P.f32 ? (size_t)D * P.LD * 4 : 0), vec = (size_t)chains * DV_COUNT * P.LD * 8, win = (size_t)chains * P.win_cap * P.LD * 8;
   const size_t tp = (size_t)chains * (P.nblk + P.ntile) * 3 * P.LD * 8;   // column sums per row block + row sums per column tile
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -1727,7 +1727,7 @@ int dense_alloc(Sampler *sp) {
   int rc;
   if ((rc = get((void **)&P.state, vec)) || (rc = get((void **)&P.A, (size_t)mchains * D * P.LD * 8)) || (rc = get((void **)&P.dg, (size_t)mchains * P.LD * 8)) || (rc = get((void **)&P.win, win)) ||
       (P.pooled && ((rc = get((void **)&P.Lf, (size_t)D * P.LD * 8)) || (rc = get((void **)&P.ypool, (size_t)P.pool_split * DNP_RMAX * P.LD * 8)) ||
-                    (rc = get((void **)&P.pmean, (size_t)P.LD * 8)))) ||
+                    (rc = get((void **)&P.pmean, (size_t)P.LD * 8)) || (P.f32 && (rc = get((void **)&P.A32, (size_t)D * P.LD * 4))))) ||
       (rc = get((void **)&P.tpart, (size_t)chains * P.nblk * 3 * P.LD * 8)) || (rc = get((void **)&P.srow, (size_t)chains * 3 * P.ntile * P.LD * 8)) ||
       (rc = get((void **)&P.partial, (size_t)chains * P.npart * 8)) || (rc = get((void **)&P.lpbuf, (size_t)chains * 8)) ||
       (rc = get((void **)&P.ts, (size_t)chains * sizeof(TS))) || (rc = get((void **)&P.rd, (size_t)chains * sizeof(DnRound))) ||
@@ -1743,14 +1743,15 @@ int dense_alloc(Sampler *sp) {
   if (sp->K == 1) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dn_grad1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->lds_bytes));
   else for (const void *f : {reinterpret_cast<const void *>(k_dn_gradK<4>), reinterpret_cast<const void *>(k_dn_gradK<8>), reinterpret_cast<const void *>(k_dn_gradK<12>), reinterpret_cast<const void *>(k_dn_gradK<16>), reinterpret_cast<const void *>(k_dn_gradK<17>)})
     HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->cl_lds_bytes));
-  for (const void *f : {reinterpret_cast<const void *>(k_dn_pool_mm<1>), reinterpret_cast<const void *>(k_dn_pool_mm<2>), reinterpret_cast<const void *>(k_dn_pool_mm<3>)})
+  for (const void *f : {reinterpret_cast<const void *>(k_dn_pool_mm<1>), reinterpret_cast<const void *>(k_dn_pool_mm<2>), reinterpret_cast<const void *>(k_dn_pool_mm<3>),
+                        reinterpret_cast<const void *>(k_dn_pool_mm<1, true>), reinterpret_cast<const void *>(k_dn_pool_mm<2, true>), reinterpret_cast<const void *>(k_dn_pool_mm<3, true>)})
     HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DNP_LDS(3)));
   hipLaunchKernelGGL(k_dn_identity, dim3((D + 255) / 256, mchains), dim3(256), 0, sp->stream, P);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(sp->stream));
   sp->dn_win_counter = 0; sp->dn_win_size = sp->R.window; sp->dn_win_next = sp->R.init_buffer + sp->R.window - 1; sp->dn_wf_n = 0;
   sp->dn_pass_bytes[0] = dense_pass_bytes(D, P.LD, DN_RB) / (P.f32 ? 2 : 1); sp->dn_pass_bytes[1] = dense_pass_bytes(D, P.LD, P.rb) / (P.f32 ? 2 : 1);   // ([1]: at the handle's own block size)
-  if (P.pooled) sp->dn_pass_bytes[0] = sp->dn_pass_bytes[1] = (long long)D * P.LD * 8;   // the whole symmetric matrix, once per pass whatever the number of chains
+  if (P.pooled) sp->dn_pass_bytes[0] = sp->dn_pass_bytes[1] = (long long)D * P.LD * (P.f32 ? 4 : 8);   // the whole symmetric matrix, once per pass whatever the number of chains
   return 0;
 }
 
@@ -1766,9 +1767,13 @@ void dense_symv_launch(hipStream_t st, const DnParams &P, const DnActive &act, i
       const int nc = std::min(per, nact - c0);
       R.n = nc * nrhs; R.nrhs = nrhs; R.job0 = 0;
       for (int r = 0; r < DNP_RMAX; r++) R.chain[r] = (unsigned char)(r < R.n ? (act.n ? act.idx[c0 + r / nrhs] : c0 + r / nrhs) : 0);
-      const dim3 grid((unsigned)((P.D + DNP_COLS - 1) / DNP_COLS), (unsigned)P.pool_split);
+      const dim3 grid((unsigned)((P.D + DNP_COLS_OF(P.f32) - 1) / DNP_COLS_OF(P.f32)), (unsigned)P.pool_split);
       const int nt = (R.n + 15) / 16;
-      if (nt == 1) hipLaunchKernelGGL(k_dn_pool_mm<1>, grid, dim3(DNP_THREADS), DNP_LDS(1), st, P, R, P.pool_rows);
+      if (P.f32) {
+        if (nt == 1) hipLaunchKernelGGL((k_dn_pool_mm<1, true>), grid, dim3(DNP_THREADS), DNP_LDS(1), st, P, R, P.pool_rows);
+        else if (nt == 2) hipLaunchKernelGGL((k_dn_pool_mm<2, true>), grid, dim3(DNP_THREADS), DNP_LDS(2), st, P, R, P.pool_rows);
+        else hipLaunchKernelGGL((k_dn_pool_mm<3, true>), grid, dim3(DNP_THREADS), DNP_LDS(3), st, P, R, P.pool_rows);
+      } else if (nt == 1) hipLaunchKernelGGL(k_dn_pool_mm<1>, grid, dim3(DNP_THREADS), DNP_LDS(1), st, P, R, P.pool_rows);
       else if (nt == 2) hipLaunchKernelGGL(k_dn_pool_mm<2>, grid, dim3(DNP_THREADS), DNP_LDS(2), st, P, R, P.pool_rows);
       else hipLaunchKernelGGL(k_dn_pool_mm<3>, grid, dim3(DNP_THREADS), DNP_LDS(3), st, P, R, P.pool_rows);
       hipLaunchKernelGGL(k_dn_pool_finish, dim3((unsigned)P.npart, (unsigned)R.n), dim3(64), 0, st, P, R, P.pool_split);
@@ -2019,6 +2024,7 @@ int dense_import_init(Sampler *sp) {
     DnParams &P = sp->dn;
     HIP_TRY(hipMemsetAsync(P.A, 0, (size_t)(P.pooled ? 1 : P.chains) * P.D * P.LD * 8, sp->stream));
     if (P.pooled) HIP_TRY(hipMemsetAsync(P.Lf, 0, (size_t)P.D * P.LD * 8, sp->stream));
+    if (P.pooled && P.f32) HIP_TRY(hipMemsetAsync(P.A32, 0, (size_t)P.D * P.LD * 4, sp->stream));
     HIP_TRY(hipMemsetAsync(P.fail, 0, 4, sp->stream));
     hipLaunchKernelGGL(k_dn_identity, dim3((P.D + 255) / 256, P.pooled ? 1 : P.chains), dim3(256), 0, sp->stream, P);
     HIP_TRY(hipGetLastError());
@@ -2158,7 +2164,6 @@ int potus_create(const potus_data *d, const potus_opts *o, int *handle) {
   if (o->metric_storage != POTUS_STORAGE_F64 && o->metric_storage != POTUS_STORAGE_F32) return fail(POTUS_ERR_ARG, "metric_storage must be POTUS_STORAGE_F64 or POTUS_STORAGE_F32");
   if (o->pooled_metric < 0 || o->pooled_metric > 2) return fail(POTUS_ERR_ARG, "pooled_metric must be 0, 1 or 2");
   if (o->pooled_metric && o->metric != POTUS_METRIC_DENSE) return fail(POTUS_ERR_ARG, "pooled_metric applies to the dense metric (metric = POTUS_METRIC_DENSE)");
-  if (o->pooled_metric && o->metric_storage != POTUS_STORAGE_F64) return fail(POTUS_ERR_ARG, "pooled_metric keeps its one matrix in fp64 (metric_storage = f64)");
   if (o->metric_storage == POTUS_STORAGE_F32 && o->metric != POTUS_METRIC_DENSE) return fail(POTUS_ERR_ARG, "metric_storage = f32 applies to the dense metric only");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(POTUS_ERR_DEVICE, "no HIP device: libpotus_hmc needs an MI355X (gfx950)");
@@ -2591,7 +2596,7 @@ int potus_get_dense_metric(int handle, int chain, double *inv_metric) {
   HIP_TRY(hipSetDevice(sp->device));
   const size_t D = sp->L.D;
   // the strict upper triangle of the chain's matrix is M^-1's (the lower one holds its Cholesky factor), the diagonal a vector
-  if (sp->dn.f32) {   // the upper triangle lives as floats in the second half of each row (dn_f32_row)
+  if (sp->dn.f32 && !sp->dn.pooled) {   // the upper triangle lives as floats in the second half of each row (dn_f32_row); pooled: A holds the rounded values as doubles
     const size_t LD = sp->dn.LD, rows_at_once = 256;
     std::vector<double> buf(rows_at_once * LD);
     for (size_t r0 = 0; r0 < D; r0 += rows_at_once) {
@@ -3308,15 +3313,19 @@ struct DenseProbe {   // a DnParams with every chain active, owned buffers
     const size_t mat = (size_t)(pooled ? 1 : chains) * D * P.LD * 8;
     HIP_TRY(bufs.alloc(&P.state, (size_t)chains * DV_COUNT * P.LD * 8)); HIP_TRY(bufs.alloc(&P.A, mat)); HIP_TRY(bufs.alloc(&P.dg, (size_t)chains * P.LD * 8));
     P.pool_split = 1; P.pool_rows = D;
+    // development: POTUS_PROBE_F32 = 1 -- the pooled pieces with metric_storage = f32 (the per-chain pass reads the variable itself, below)
+    P.f32 = pooled && getenv("POTUS_PROBE_F32") && atoi(getenv("POTUS_PROBE_F32")) ? 1 : 0;
     if (pooled) {   // (as dense_alloc)
-      const int panels = (D + DNP_COLS - 1) / DNP_COLS;
+      const int panels = (D + DNP_COLS_OF(P.f32) - 1) / DNP_COLS_OF(P.f32);
       int s = std::max(1, std::min(DNP_SPLIT_MAX, (2 * 256) / panels));   // at most two workgroups per compute unit, all resident at once (measured: profiles/r06_dense_pooled.txt)
       if (const char *e = getenv("POTUS_POOL_SPLIT")) s = std::max(1, std::min(DNP_SPLIT_MAX, atoi(e)));
       P.pool_rows = (((D + s - 1) / s + DNP_KB - 1) / DNP_KB) * DNP_KB;
       P.pool_split = (D + P.pool_rows - 1) / P.pool_rows;
       HIP_TRY(bufs.alloc(&P.Lf, mat)); HIP_TRY(hipMemset(P.Lf, 0, mat));
       HIP_TRY(bufs.alloc(&P.ypool, (size_t)P.pool_split * DNP_RMAX * P.LD * 8)); HIP_TRY(bufs.alloc(&P.pmean, (size_t)P.LD * 8));
-      for (const void *f : {reinterpret_cast<const void *>(k_dn_pool_mm<1>), reinterpret_cast<const void *>(k_dn_pool_mm<2>), reinterpret_cast<const void *>(k_dn_pool_mm<3>)})
+      if (P.f32) { HIP_TRY(bufs.alloc(&P.A32, mat / 2)); HIP_TRY(hipMemset(P.A32, 0, mat / 2)); }
+      for (const void *f : {reinterpret_cast<const void *>(k_dn_pool_mm<1>), reinterpret_cast<const void *>(k_dn_pool_mm<2>), reinterpret_cast<const void *>(k_dn_pool_mm<3>),
+                            reinterpret_cast<const void *>(k_dn_pool_mm<1, true>), reinterpret_cast<const void *>(k_dn_pool_mm<2, true>), reinterpret_cast<const void *>(k_dn_pool_mm<3, true>)})
         HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DNP_LDS(3)));
     }
     dense_launch_shape(P, chains);
@@ -3347,8 +3356,10 @@ static int dense_matvec_probe_impl(bool pooled, int device, int chains, int D, i
   if (rc) return rc;
   DnParams &P = pr.P;
   if (pooled) {   // ONE full symmetric matrix for every chain (generated: chain 0's of k_dn_fill, mirrored)
-    if (Minv_host) HIP_TRY(hipMemcpy2D(P.A, (size_t)P.LD * 8, Minv_host, (size_t)D * 8, (size_t)D * 8, (size_t)D, hipMemcpyHostToDevice));
-    else hipLaunchKernelGGL(k_dn_pool_fill, dim3(4096), dim3(256), 0, 0, P);
+    if (Minv_host) {
+      HIP_TRY(hipMemcpy2D(P.A, (size_t)P.LD * 8, Minv_host, (size_t)D * 8, (size_t)D * 8, (size_t)D, hipMemcpyHostToDevice));
+      if (P.f32) hipLaunchKernelGGL(k_dn_pool_round32, dim3(4096), dim3(256), 0, 0, P);
+    } else hipLaunchKernelGGL(k_dn_pool_fill, dim3(4096), dim3(256), 0, 0, P);
   } else if (Minv_host) {
     HIP_TRY(hipMemcpy2D(P.A, (size_t)P.LD * 8, Minv_host, (size_t)D * 8, (size_t)D * 8, (size_t)chains * D, hipMemcpyHostToDevice));   // the lower half is ignored
     std::vector<double> dg((size_t)chains * P.LD, 0.0);
@@ -3397,7 +3408,7 @@ static int dense_matvec_probe_impl(bool pooled, int device, int chains, int D, i
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (!ok) return fail(POTUS_ERR_DEVICE, "k_dn_symv failed");
   if (ms) *ms = (double)t / reps;
-  if (pass_bytes) *pass_bytes = pooled ? (long long)D * P.LD * 8 * ((n_act * nrhs + DNP_RMAX - 1) / DNP_RMAX)
+  if (pass_bytes) *pass_bytes = pooled ? (long long)D * P.LD * (P.f32 ? 4 : 8) * ((n_act * nrhs + DNP_RMAX - 1) / DNP_RMAX)
                                        : dense_pass_bytes(D, P.LD, P.rb) * (nrhs == 3 ? 2 : 1) / (P.f32 ? 2 : 1);
   for (int c = 0; c < chains; c++) {
     for (int k = 0; k < nrhs; k++)
