@@ -28,17 +28,21 @@
 #define DNP_XS 34                         // LDS row stride of a staged right-hand side (doubles): conflict-free for the B-operand reads of a half wave
 #define DNP_RMAX 48                       // right-hand sides per launch (three operand tiles of sixteen)
 #define DNP_SPLIT_MAX 8
-// waves per SIMD the product is compiled for (hipcc: the second launch bound is waves per execution unit).  Up to 32 right-hand sides: four, i.e. 128 registers
-// per lane and two workgroups per compute unit (2.49 against 2.63 ms at 32 right-hand sides, D = 41 610); 48 right-hand sides need 158 registers and lose a
-// third of their rate when squeezed into 128 (70 spills: 5.4 against 3.35 ms) -- profiles/r06_dense_pooled.txt
-#define DNP_WAVES_PER_SIMD(NT) ((NT) <= 2 ? 4 : 2)
+// waves per SIMD the product is compiled for (hipcc: the second launch bound is waves per execution unit): four, i.e. 128 registers per lane and two workgroups
+// per compute unit, wherever the variant fits them (DNP_WAVES_PER_SIMD_OF below; fp32 storage with three operand tiles needs 165).  Squeezing a variant that does not
+// fit costs more than it gives: three tiles of fp64 at 32-row batches needed 158 registers and lost a third of their rate in 128 (70 spills) -- profiles/r06_dense_pooled.txt
 #define DNP_LDS(NT) ((size_t)2 * (NT) * 16 * DNP_XS * 8)
 // potus_opts.metric_storage = f32 on top of pooled_metric: the ONE matrix is kept rounded to fp32 as well (DnParams::A32; the rounded matrix IS the metric, its
 // factor is the factor of the rounded values -- the argument of dn_f32_row), the pass streams 4 D^2 bytes.  A 16-byte load then brings FOUR columns: a wave
 // takes 64 columns as four interleaved operand tiles, a workgroup 512; the arithmetic stays fp64 (v_cvt_f64_f32 on the way into the matrix instruction).
 #define DNP_CT(F32) ((F32) ? 4 : 2)                     // operand tiles (= columns per 16-byte load) per wave
 #define DNP_COLS_OF(F32) (128 * DNP_CT(F32))            // columns per workgroup
-#define DNP_WAVES_PER_SIMD_OF(NT, F32) ((F32) ? ((NT) <= 1 ? 4 : 2) : DNP_WAVES_PER_SIMD(NT))
+// Rows per batch of a variant.  One operand tile of right-hand sides: 32 (eight 16-byte loads per lane and batch).  Two or three tiles: 16 -- half the registers of the two
+// batches in flight, which lets TWO workgroups share a compute unit (fp64 storage, three tiles: 113 registers instead of 158; fp32 storage, two tiles: 127 instead of 174),
+// and the matrix pipe no longer idles while the one resident workgroup sits at its barrier: 2.03 -> 1.81 ms at 32 right-hand sides with fp32 storage (61.4 TFLOP/s = 0.78
+// of the matrix peak), 3.38 -> 3.18 at 48 with fp64 (profiles/r06_dense_pooled.txt, section 6).  The order of the sums does not depend on it (steps of four rows, in row order).
+#define DNP_KB_OF(NT, F32) ((NT) >= 2 ? 16 : DNP_KB)
+#define DNP_WAVES_PER_SIMD_OF(NT, F32) ((F32) ? ((NT) <= 2 ? 4 : 2) : 4)
 
 // the right-hand sides of a pooled launch: column r = (chain, job)
 struct DnPoolRhs {
@@ -52,10 +56,11 @@ struct DnPoolRhs {
 // Software pipeline over batches of DNP_KB rows, two register sets and two LDS buffers: while batch b is multiplied, the matrix block and the right-hand sides of
 // batch b + 1 are on their way (128 registers at NT = 2: two workgroups per compute unit, i.e. four waves per SIMD to hide what is left).  First version of the
 // round (one batch of 64 rows in flight, nothing requested ahead): 4.6 TB/s with 32 right-hand sides at D = 41 610, the matrix pipe 47 % busy.
-template <int NT, bool F32 = false>
+template <int NT, bool F32 = false, int KB = DNP_KB_OF(NT, F32)>
 __global__ __launch_bounds__(DNP_THREADS, DNP_WAVES_PER_SIMD_OF(NT, F32)) void k_dn_pool_mm(const DnParams P, const DnPoolRhs R, int rows_per_split) {
+  constexpr int XS = KB + 2, NS = (16 * NT * KB + DNP_THREADS - 1) / DNP_THREADS;   // LDS row stride of a staged right-hand side; staging slots per thread
   constexpr int CT = DNP_CT(F32), EB = F32 ? 4 : 8;                  // operand tiles per wave; bytes per stored element
-  extern __shared__ __attribute__((aligned(16))) double dnp_lds[];   // [2][NT * 16][DNP_XS]
+  extern __shared__ __attribute__((aligned(16))) double dnp_lds[];   // [2][NT * 16][XS]
   typedef double d4_t __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = P.D, LD = P.LD;
@@ -74,11 +79,11 @@ __global__ __launch_bounds__(DNP_THREADS, DNP_WAVES_PER_SIMD_OF(NT, F32)) void k
 #pragma unroll
     for (int n = 0; n < NT; n++) acc[t][n] = d4_t{0.0, 0.0, 0.0, 0.0};
   // staging of the right-hand sides: thread -> (row tid & 31 of the batch, right-hand sides (tid >> 5) + 16 i); their vectors are looked up once
-  const int srow = tid & 31, sr = tid >> 5;
-  const double *xp[NT];
+  const int srow = tid & (KB - 1), sr = tid / KB;
+  const double *xp[NS];
 #pragma unroll
-  for (int i = 0; i < NT; i++) {
-    const int r = sr + 16 * i;
+  for (int i = 0; i < NS; i++) {
+    const int r = sr + (DNP_THREADS / KB) * i;
     xp[i] = nullptr;
     if (r < R.n) {
       const int chain = R.chain[r], job = R.job0 + r % R.nrhs;
@@ -86,25 +91,25 @@ __global__ __launch_bounds__(DNP_THREADS, DNP_WAVES_PER_SIMD_OF(NT, F32)) void k
       if (rd.active && rd.job[job].x >= 0) xp[i] = dn_vec(P, chain, rd.job[job].x);   // (the host's list of active chains may be a few rounds old)
     }
   }
-  auto request = [&](u32x4 (&a)[DNP_KB / 4], int r0) {    // the batch's rows are one resource (none left: size 0, zeros come back); the step of four rows is the scalar offset
-    const int nrows = max(0, min(DNP_KB, rend - r0));
+  auto request = [&](u32x4 (&a)[KB / 4], int r0) {    // the batch's rows are one resource (none left: size 0, zeros come back); the step of four rows is the scalar offset
+    const int nrows = max(0, min(KB, rend - r0));
     const rsrc_t rsA = F32 ? make_rsrc(uni_ptr(P.A32 + (size_t)min(r0, D - 1) * LD), uni32((unsigned)nrows * rowbytes))
                            : make_rsrc(uni_ptr(P.A + (size_t)min(r0, D - 1) * LD), uni32((unsigned)nrows * rowbytes));
 #pragma unroll
-    for (int k = 0; k < DNP_KB / 4; k++)
+    for (int k = 0; k < KB / 4; k++)
       a[k] = __builtin_amdgcn_raw_buffer_load_b128(rsA, 4 * k + krow < nrows ? voffA : PT_OOB, (unsigned)(4 * k) * rowbytes, 2 /* nt: read once per round */);
   };
-  auto xload = [&](double (&xv)[NT], int r0) {
+  auto xload = [&](double (&xv)[NS], int r0) {
 #pragma unroll
-    for (int i = 0; i < NT; i++) xv[i] = (xp[i] && r0 + srow < rend) ? xp[i][r0 + srow] : 0.0;
+    for (int i = 0; i < NS; i++) xv[i] = (xp[i] && r0 + srow < rend) ? xp[i][r0 + srow] : 0.0;
   };
-  auto xstore = [&](double *xs, const double (&xv)[NT]) {
+  auto xstore = [&](double *xs, const double (&xv)[NS]) {
 #pragma unroll
-    for (int i = 0; i < NT; i++) xs[(sr + 16 * i) * DNP_XS + srow] = xv[i];
+    for (int i = 0; i < NS; i++) { const int r = sr + (DNP_THREADS / KB) * i; if (r < 16 * NT) xs[r * XS + srow] = xv[i]; }
   };
-  auto multiply = [&](const u32x4 (&a)[DNP_KB / 4], const double *xs) {
+  auto multiply = [&](const u32x4 (&a)[KB / 4], const double *xs) {
 #pragma unroll
-    for (int k = 0; k < DNP_KB / 4; k++) {
+    for (int k = 0; k < KB / 4; k++) {
       double av[CT];
       if constexpr (F32) {
 #pragma unroll
@@ -114,28 +119,28 @@ __global__ __launch_bounds__(DNP_THREADS, DNP_WAVES_PER_SIMD_OF(NT, F32)) void k
       }
       double bv[NT];
 #pragma unroll
-      for (int n = 0; n < NT; n++) bv[n] = xs[(16 * n + mcol) * DNP_XS + 4 * k + krow];
+      for (int n = 0; n < NT; n++) bv[n] = xs[(16 * n + mcol) * XS + 4 * k + krow];
 #pragma unroll
       for (int n = 0; n < NT; n++)
 #pragma unroll
         for (int t = 0; t < CT; t++) acc[t][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[n], acc[t][n], 0, 0, 0);
     }
   };
-  double *xs0 = dnp_lds, *xs1 = dnp_lds + (size_t)NT * 16 * DNP_XS;
-  u32x4 a0[DNP_KB / 4], a1[DNP_KB / 4];
-  double xv[NT];
+  double *xs0 = dnp_lds, *xs1 = dnp_lds + (size_t)NT * 16 * XS;
+  u32x4 a0[KB / 4], a1[KB / 4];
+  double xv[NS];
   request(a0, rbeg);
   xload(xv, rbeg);
   xstore(xs0, xv);
   __syncthreads();
-  for (int r0 = rbeg; r0 < rend; r0 += 2 * DNP_KB) {
-    request(a1, r0 + DNP_KB);
-    xload(xv, r0 + DNP_KB);
+  for (int r0 = rbeg; r0 < rend; r0 += 2 * KB) {
+    request(a1, r0 + KB);
+    xload(xv, r0 + KB);
     multiply(a0, xs0);
     xstore(xs1, xv);
     __syncthreads();
-    request(a0, r0 + 2 * DNP_KB);
-    xload(xv, r0 + 2 * DNP_KB);
+    request(a0, r0 + 2 * KB);
+    xload(xv, r0 + 2 * KB);
     multiply(a1, xs1);                                                  // (past the split's end: zeros times zeros)
     xstore(xs0, xv);
     __syncthreads();
