@@ -5,11 +5,15 @@ Default workload = BASELINE.json configs[1]: scripts/model/final_2016.R's poster
 D = 15 098), 8 chains per MI355X, 1000 warm-up + 1000 sampling iterations, seed 1843, NUTS diag_e, delta 0.8,
 max depth 10.
 
-A STEP is one launch chunk of `--chunk` (100) NUTS transitions of every chain on the GPU -- the granularity at which
-the reference's own driver reports progress (`refresh`, final_2016.R:11,540).  `--steps K` runs the first K // 2
-chunks as warm-up and the rest as sampling from a fresh initialisation, so the default K = 20 IS the configuration
-above (8 chains x (1000 + 1000)); `--warmup W` first runs W untimed chunks on a throw-away sampler (clocks, code
-objects, allocator).
+A STEP is `--chunk` (100) NUTS transitions of every chain on the GPU -- the granularity at which the reference's own
+driver reports progress (`refresh`, final_2016.R:11,540).  `--steps K` runs the first K // 2 steps as warm-up and the
+rest as sampling from a fresh initialisation, so the default K = 20 IS the configuration above (8 chains x (1000 +
+1000)); `--warmup W` first runs W untimed steps on a throw-away sampler (clocks, code objects, allocator).
+How the K steps reach the GPU is `--launch-steps L`: L steps per potus_run call = per kernel launch.  The default (0) is
+what a caller without a progress display does -- potus_run(handle, num_warmup) and potus_run(handle, num_samples): ONE
+launch per phase -- because a launch lasts as long as its slowest chain, and the chains of a short launch wait for each
+other twenty times instead of twice (same draws either way; 650 k against 625 k leapfrogs/s, profiles/r06_launch_size.txt).
+`--launch-steps 1` is rounds 1-6's one launch per step.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|3|4]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -125,6 +129,18 @@ def launch_ranks(n):
 
 # ------------------------------------------------------------------------------------------------ the other configurations, beside the
 # default line
+def launch_groups(steps, warm_steps, launch_steps):
+    """The K steps as potus_run calls: how many steps each launch covers.  A launch never straddles the end of the warm-up (the line
+    reports the sampling phase's time on its own); launch_steps = 0: one launch per phase."""
+    out = []
+    for n in (warm_steps, steps - warm_steps):
+        per = launch_steps if launch_steps > 0 else n
+        while n > 0:
+            out.append(min(per, n))
+            n -= out[-1]
+    return out
+
+
 def seed_summary(entry):
     """What `side.seeds` keeps of one configs[1] run: rate, time, ESS / s and how deep each chain's trees go in the sampling phase."""
     post = next(iter(entry["config"]["posteriors"].values()))
@@ -222,7 +238,8 @@ def side_measurements(seed, budget_s=200.0, headline=None):
                    "concurrently on this one GPU (4 chains each), configs[4]_preset = the dense-metric stress shape in its "
                            "driver-runnable preset, "
                    "configs[4]_pooled = the same preset with potus_opts.pooled_metric (one inverse metric per GPU: a declared "
-                           "deviation from Stan), configs[4]_pooled_f32 = that one matrix kept rounded to fp32 as well (metric_storage = f32: "
+                           "deviation from Stan), configs[4]_pooled_f32 = that one matrix kept rounded to fp32 as well "
+                                   "(metric_storage = f32: "
                            "half the bytes per pass, fp64 arithmetic)")
     out["seconds"] = time.perf_counter() - t_all
     return out
@@ -237,7 +254,8 @@ def single_process_side(args, n):
     try:
         cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", str(n), "--single-process", "--seed", str(args.seed), "--steps",
                str(args.steps), "--warmup", "1", "--chunk", str(args.chunk), "--chains-per-gpu", str(args.chains_per_gpu),
-               "--cus-per-chain", str(args.cus_per_chain), "--twin", str(args.twin), "--warm-steps", str(args.warm_steps)]
+               "--cus-per-chain", str(args.cus_per_chain), "--twin", str(args.twin), "--warm-steps", str(args.warm_steps), "--launch-steps",
+               str(args.launch_steps)]
         cmd += ["--max-depth", str(args.max_depth)] if args.max_depth is not None else []
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=420,
                            env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR",
@@ -277,6 +295,7 @@ def single_process_line(args):
     steps = 20 if args.steps is None else args.steps
     warmup = 2 if args.warmup is None else args.warmup
     chunk = args.chunk or 100
+    args.launch_steps = max(args.launch_steps, 0)
     warm_steps = steps // 2 if args.warm_steps < 0 else min(args.warm_steps, steps)
     nw, ns = warm_steps * chunk, (steps - warm_steps) * chunk
     md = 10 if args.max_depth is None else args.max_depth
@@ -297,11 +316,12 @@ def single_process_line(args):
     t0 = time.perf_counter()
     for h in hs:
         h.init()
-    kernel_ms, t_warm_end = 0.0, None
-    for step in range(steps):
-        run_many(hs, chunk)
+    kernel_ms, t_warm_end, done = 0.0, None, 0
+    for g in launch_groups(steps, warm_steps, args.launch_steps):
+        run_many(hs, chunk * g)
         kernel_ms += max(h.last_run_timing()[0] for h in hs)
-        if step + 1 == warm_steps:
+        done += g
+        if done == warm_steps:
             t_warm_end = time.perf_counter()
     ess, rhat, diag_s = None, None, 0.0
     if ns >= 8:
@@ -328,7 +348,8 @@ def single_process_line(args):
             "config": {"workload": f"configs[{1 if n == 1 else 2}]: 2016 backtest, adaptive NUTS diag_e, {C} chains per MI355X x {n}, "
                                    f"{nw} warmup + {ns} sampling, seed {args.seed}; "
                                    f"ONE process, {n} handles under potus_run_many (the R-facing path: potus_sample(gpus = "
-                                           f"...)); a step = one launch chunk of {chunk} transitions",
+                                           f"...)); a step = {chunk} transitions, one potus_run_many call per phase unless "
+                                                   f"--launch-steps says otherwise",
                        "baseline_config_index": 1 if n == 1 else 2, "chains_per_gpu": C, "total_chains": C * n, "devices": devs,
                                "iter_warmup": nw, "iter_sampling": ns,
                        "parallelism": f"one host process, {n} handles of {C} chains, one per device; pooled R-hat / ESS through "
@@ -559,6 +580,9 @@ def main():
             help="--config 3: the posteriors (comma-separated years) that get two clusters per chain")
     ap.add_argument("--chunk", type=int, default=0, help="transitions per step (0 = the configuration's: 100; 1 for --config 4)")
     ap.add_argument("--warm-steps", type=int, default=-1, help="how many of the --steps are warm-up (-1 = half of them)")
+    ap.add_argument("--launch-steps", type=int, default=-1,
+                    help="steps per potus_run call = per kernel launch: 0 = one launch per phase (default; --config 4: 1, the run is "
+                            "reported step by step)")
     ap.add_argument("--metric-storage", default="f64", choices=["f64", "f32"], help="--config 4: storage of the dense inverse metric")
     ap.add_argument("--pooled-metric", action="store_true",
             help="--config 4: ONE dense inverse metric per GPU, adapted from the window draws of all its chains "
@@ -632,6 +656,8 @@ def main():
         args.max_depth = 7 if cfg == 4 else 10
     if preset4:
         args.chunk, args.warm_steps = 5, 4
+    if args.launch_steps < 0:
+        args.launch_steps = 1 if cfg == 4 else 0
     if cfg == 0:
         if world != 1:
             raise SystemExit("--config 0 (the reference's own sampler calls, GPU and CPU port side by side) runs on one GPU")
@@ -697,21 +723,23 @@ def main():
         h.init()
     kernel_ms, t_warm_end, lf_warm = 0.0, None, 0
     per_step = []                                                   # --config 4: the run chunk by chunk (where the window ends fall)
-    for step in range(args.steps):
+    groups, done = launch_groups(args.steps, warm_steps, args.launch_steps), 0
+    for g in groups:
         ts0, lf0 = time.perf_counter(), sum(h.total_leapfrogs() for h in hs)
         dt0 = hs[0].dense_timing() if cfg == 4 else None
         if pooled_mode == 2:
             from us_potus_model_amd import sampler as _sampler
-            _sampler.run_pooled(hs, chunk, coll_dev)
+            _sampler.run_pooled(hs, chunk * g, coll_dev)
         else:
-            run_many(hs, chunk)
-        kernel_ms += max(h.last_run_timing()[0] for h in hs)        # the handles of a step run concurrently
+            run_many(hs, chunk * g)
+        kernel_ms += max(h.last_run_timing()[0] for h in hs)        # the handles of a launch run concurrently
         if cfg == 4:
             dt1, at = hs[0].dense_timing(), hs[0].dense_adapt_timing()
-            per_step.append({"iterations": [step * chunk, (step + 1) * chunk], "seconds": time.perf_counter() - ts0,
+            per_step.append({"iterations": [done * chunk, (done + g) * chunk], "seconds": time.perf_counter() - ts0,
                              "leapfrogs": sum(h.total_leapfrogs() for h in hs) - lf0, "matrix_pass_ms": dt1[0] - dt0[0],
                              "matrix_bytes": dt1[2] - dt0[2], "window_ends_so_far": at["window_ends"]})
-        if step + 1 == warm_steps:
+        done += g
+        if done == warm_steps:
             torch.cuda.synchronize()
             t_warm_end = time.perf_counter()
             lf_warm = sum(h.total_leapfrogs() for h in hs)
@@ -881,8 +909,9 @@ def main():
                      "poll data of the reference (fixtures built from its CSVs, tests/golden/data_*.npz)") + "; random inits",
             "config": {"workload": f"{names[2 if (cfg == 1 and world > 1) else cfg]}, adaptive NUTS {'dense_e' if dense else 'diag_e'}, "
                                    f"{C_tot} chains per MI355X, "
-                                   f"{nw} warmup + {ns} sampling, seed {args.seed}; a step = one launch chunk of {chunk} transitions",
-                       "step": f"{chunk} NUTS transitions of every chain", "iter_warmup": nw, "iter_sampling": ns,
+                                   f"{nw} warmup + {ns} sampling, seed {args.seed}; a step = {chunk} transitions of every chain, "
+                                   f"the {args.steps} steps issued as {len(groups)} potus_run call(s) = kernel launch(es) per handle",
+                       "step": f"{chunk} NUTS transitions of every chain", "launch_steps": groups, "iter_warmup": nw, "iter_sampling": ns,
                                "max_depth": args.max_depth,
                        **({"adapt_windows_init_window_term": args.adapt_windows} if args.adapt_windows else {}),
                        "baseline_config_index": 2 if (cfg == 1 and world > 1) else cfg,
@@ -904,7 +933,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": traffic_note,
                          "kernel": kernel, "algorithmic_bytes_per_leapfrog": bpl if len(bpl) > 1 else bpl[0],
-                         "leapfrogs_in_launches": int(sum(lf_local)), "launch_ms_total": kernel_ms,
+                         "leapfrogs_in_launches": int(sum(lf_local)), "launch_ms_total": kernel_ms, "launches": len(groups),
+                         "avg_launch_ms": kernel_ms / max(len(groups), 1),
                          **({"matrix_passes": dense_t[1], "matrix_pass_ms_total": dense_t[0], "matrix_bytes_streamed": dense_t[2],
                              "avg_pass_ms": dense_t[0] / max(dense_t[1], 1), "leaf_rounds": dense_t[3],
                              "metric_storage": args.metric_storage} if dense else {}),
