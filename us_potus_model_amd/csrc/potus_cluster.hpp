@@ -1014,24 +1014,27 @@ __device__ __forceinline__ double cl_pass_partial(CMp M_in, CCp CL_in, cip part_
         ldp L0 = Lw + s * SP, C0 = C + tl, CW = X + (int)((meta >> 48) & 0xffu) * SE;   // CW: the carry of the wave that owns day tl
         double a0 = 0.0, a1 = 0.0;
           int k0 = 0;
-          for (; k0 + 16 <= S; k0 += 16) {               // 51-term dot, sixteen terms in flight
-            double l[16], c[16];
+          // 51-term dot in batches of TEN terms, the three operands of a batch -- factor row, suffix sum, the wave's carry -- in flight together: one LDS round per batch.
+          // (Sixteen terms with the carry in a round of its own: +1.1 % per leapfrog; twelve or sixteen with all three in flight spill in this loop: +13 ... 20 %;
+          //  the single term that 51 = 5 x 10 + 1 leaves over, requested with the first batch: 23 spills, +8 % -- profiles/r06_cl_carry_table.txt.)
+          constexpr int DW_ = 10;
+          for (; k0 + DW_ <= S; k0 += DW_) {
+            double l[DW_], c[DW_], cw[DW_];
 #pragma unroll
-            for (int j = 0; j < 16; j++) c[j] = C0[(k0 + j) * NDP] + CW[k0 + j];   // (the three arrays in flight at once spill in this loop: +20 %)
+            for (int j = 0; j < DW_; j++) { l[j] = L0[k0 + j]; c[j] = C0[(k0 + j) * NDP]; cw[j] = CW[k0 + j]; }
             ISSUE_FENCE();
 #pragma unroll
-            for (int j = 0; j < 16; j++) l[j] = L0[k0 + j];
-            ISSUE_FENCE();
+            for (int j = 0; j < DW_; j++) c[j] = c[j] + cw[j];
 #pragma unroll
-            for (int j = 0; j < 16; j += 2) { a0 += l[j] * c[j]; a1 += l[j + 1] * c[j + 1]; }
+            for (int j = 0; j < DW_; j += 2) { a0 += l[j] * c[j]; a1 += l[j + 1] * c[j + 1]; }
           }
-          if (k0 < S) {                                  // remainder: clamped reads, masked products
-            double l[16], c[16];
+          for (; k0 < S; k0 += 4) {                      // remainder in fours: clamped reads, masked products
+            double l[4], c[4];
 #pragma unroll
-            for (int j = 0; j < 16; j++) { const int kk = min(k0 + j, S - 1); l[j] = L0[kk]; c[j] = C0[kk * NDP] + CW[kk]; }
+            for (int j = 0; j < 4; j++) { const int kk = min(k0 + j, S - 1); l[j] = L0[kk]; c[j] = C0[kk * NDP] + CW[kk]; }
             ISSUE_FENCE();
 #pragma unroll
-            for (int j = 0; j < 16; j += 2) {
+            for (int j = 0; j < 4; j += 2) {
               a0 += (k0 + j < S ? l[j] : 0.0) * c[j];
               a1 += (k0 + j + 1 < S ? l[j + 1] : 0.0) * c[j + 1];
             }
