@@ -43,6 +43,10 @@ DEF_KERNEL(k_plain_sc1, "", "sc1")
 DEF_KERNEL(k_sc1_sc0, "sc1", "sc0")
 DEF_KERNEL(k_plain_plain, "", "")
 DEF_KERNEL(k_nt_nt, "nt", "nt")
+DEF_KERNEL(k_sc1_nt, "sc1", "nt")
+DEF_KERNEL(k_plain_nt, "", "nt")
+DEF_KERNEL(k_sc1_sc0nt, "sc1", "sc0 nt")
+DEF_KERNEL(k_sc1_sc1nt, "sc1 nt", "sc1 nt")
 
 template <class F> void run(F kern, const char *name, int other) {
   unsigned *buf, *xcc; long long *cyc;
@@ -67,6 +71,10 @@ int main() {
     run(k_plain_sc1, "store plain, load sc1", other);
     run(k_sc1_sc0, "store sc1, load sc0", other);
     run(k_nt_nt, "store nt, load nt", other);
+    run(k_sc1_nt, "store sc1, load nt", other);
+    run(k_plain_nt, "store plain, load nt", other);
+    run(k_sc1_sc0nt, "store sc1, load sc0 nt", other);
+    run(k_sc1_sc1nt, "store sc1 nt, load sc1 nt", other);
     run(k_plain_plain, "store plain, load plain", other);
   }
   return 0;

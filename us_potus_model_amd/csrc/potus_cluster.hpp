@@ -16,10 +16,11 @@
 //       sums of everything indexed by pollster/mode/population and of the two transposed
 //       51x51 mat-vecs                                       -> owners finish their gradients
 //   X3  log density and kinetic energy partials             -> every member takes the same decision
-// An exchange word travels as 16 bytes {value, tag = (launch id, exchange number)} written with one write-through
-// (sc1) 16-byte store; a reader re-loads (sc1) until the tag is the one it expects -- no counter, no flag, no barrier
-// on the consumer side (struct Xch below); one-way latency 0.23 us inside an XCD, 0.38 us across
-// (scripts/micro/pingpong.hip).  All members sum the
+// An exchange word travels as 16 bytes {value, tag = (launch id, exchange number)} written with one 16-byte store -- write-through
+// (sc1) in general, plain when the launch has found every member of the cluster on one XCD (cl_find_local: a plain store reaches
+// that XCD's L2, where the sc1 loads of its compute units see it, in 0.23 us instead of 0.55; it is invisible to another XCD) --;
+// a reader re-loads (sc1) until the tag is the one it expects -- no counter, no flag, no barrier on the consumer side (struct Xch
+// below; scripts/micro/pingpong.hip).  All members sum the
 // partials in the same fixed order, so they hold bit-identical scalars and run the NUTS control
 // flow redundantly without ever diverging; results are reproducible run to run for a given K.
 //
@@ -193,6 +194,7 @@ template <class P> __device__ __forceinline__ P launder_s(P p) { // keep address
 // drains in about a second, the chain scalars get status POTUS_ERR_WATCHDOG and potus_run returns that error --
 // instead of a trap, which would leave the whole process with a sticky HIP error.
 __shared__ int cl_dead;
+__shared__ int cl_local;   // the members of this cluster sit on one XCD (set by k_cl_run once per launch, Xch::local)
 // A buffer store of more than 64 bits reads its data registers AFTER it has issued, and hipcc 7.2 pads the pair "store, VALU write
 // of a data register" only when the store has no register soffset (LLVM's createsVALUHazard) -- every store of an exchange word
 // has one.  Found in round 4: once the 51 x 51 mat-vecs had left the pass, the word of a slot partial was followed directly by
@@ -207,6 +209,7 @@ struct Xch {
   unsigned launch;         // launch id (host counter): stale words of earlier launches never match
   unsigned x1e;            // number of an X1 published ahead for the next pass (0 = none), see cl_pass_partial
   int K, m, XW;
+  int local;               // 1: every member of the cluster runs on the same XCD -- exchange words are published with plain stores (see xst)
 };
 // byte offset of member mm's payload: w = the exchange being assembled (number epoch+1), r = the one
 // just published (call after epoch++)
@@ -229,7 +232,12 @@ __device__ __forceinline__ void xst(const Xch &x, unsigned voff, double v) {
   const u32x4 w = {(unsigned)u, (unsigned)(u >> 32), x.epoch + 1u, x.launch};
   // (soffset through readfirstlane: the exchange counter ends up in a vector register wherever it was updated under a
   // branch whose condition came out of LDS, and a "divergent" scalar offset costs a waterfall loop around every access)
-  __builtin_amdgcn_raw_buffer_store_b128(w, x.xb, voff, __builtin_amdgcn_readfirstlane(xch_wslot(x, x.m)), CL_AUX_SC1);
+  // A write-through (sc1) store is acknowledged by the memory side; a plain one is visible to the sc1 loads of the same XCD as soon as it is in that XCD's L2
+  // (scripts/micro/pingpong.hip: 552 against 1 304 cycles one way on an idle GPU) and to nobody else.  When the launch has found all members of the cluster on
+  // one XCD (Xch::local, cl_find_local) the word goes out plain; both stores are always issued, one of them out of range -- no branch around a memory operation.
+  const unsigned so = __builtin_amdgcn_readfirstlane(xch_wslot(x, x.m));
+  __builtin_amdgcn_raw_buffer_store_b128(w, x.xb, x.local ? voff : PT_OOB, so, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(w, x.xb, x.local ? PT_OOB : voff, so, CL_AUX_SC1);
   STORE128_PAD(w);
 }
 // fetch NB words of the exchange just published (per-lane byte offsets vo, PT_OOB = idle lane -> 0;
@@ -478,6 +486,20 @@ __device__ __forceinline__ void cl_sync(Xch &x, ldp red) {
   double v[1] = {0.0};
   cl_allreduce(v, red, x, (int)threadIdx.x);
 }
+// Once per launch: do all members of the cluster run on the same XCD?  (Blocks are dealt to the XCDs round-robin, so with a multiple of eight chains they do --
+// but nothing promises it, and a plain store is invisible to another XCD.)  One all-reduce of the XCC ids (write-through, as everything is until the answer is in).
+__device__ __forceinline__ void cl_find_local(Xch &x, ldp red) {
+  unsigned id;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+  const double xi = threadIdx.x == 0 ? (double)(id & 15u) : 0.0;
+  double v[2] = {xi, xi * xi};
+  x.local = 0;
+  cl_allreduce(v, red, x, (int)threadIdx.x);
+  const int local = (double)x.K * v[1] == v[0] * v[0] ? 1 : 0;      // n sum x^2 == (sum x)^2  <=>  all ids equal (small integers: exact)
+  if (threadIdx.x == 0) cl_local = local;
+  __syncthreads();
+  x.local = local;
+}
 
 // ---------------------------------------------------------------- policies (internal element order)
 struct ClPlainPolicy {
@@ -645,7 +667,7 @@ __device__ __forceinline__ ClStatic cl_load_static(CCp CL, cip part) {
 }
 // Stage the walk factor and the (pseudo-)states of the member's polls in LDS, once per kernel.
 __device__ __forceinline__ ClStatic cl_setup_lds(CMp M, CCp CL, cip part, ldp lds) {
-  if (threadIdx.x == 0) cl_dead = 0;
+  if (threadIdx.x == 0) { cl_dead = 0; cl_local = 0; }
 #ifdef CL_POISON_LDS
   // development: whatever a kernel reads from LDS before writing it shows up as NaN instead of depending on the previous kernel
   for (int i = threadIdx.x; i < CL->lds_doubles; i += PT_THREADS) lds[i] = __builtin_nan("");

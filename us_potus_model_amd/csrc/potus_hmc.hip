@@ -396,7 +396,7 @@ __device__ __forceinline__ ClChain make_clchain(CMp M, CCp CL, CRp R, int chain,
   c.key = RngKey{R->seed_lo, R->seed_hi, (uint32_t)(R->chain_id_offset + chain + 1)};
   c.perm = as_g(CL->perm);
   c.x.xb = make_rsrc(R->xbuf + (size_t)blk * (8 * K * CL->XW + 16), 4u * (unsigned)K * (unsigned)CL->XW * 16u + 16u);   // + the watchdog word
-  c.x.epoch = 0; c.x.launch = launch; c.x.x1e = 0; c.x.K = K; c.x.m = m; c.x.XW = CL->XW;
+  c.x.epoch = 0; c.x.launch = launch; c.x.x1e = 0; c.x.K = K; c.x.m = m; c.x.XW = CL->XW; c.x.local = 0;
   c.D = M->D; c.Dpad = Dpad; c.tid = (int)threadIdx.x;
   c.e0 = c.part[CP_E0]; c.e1 = c.e0 + c.part[CP_NE];
   c.max_depth = R->max_depth; c.num_warmup = R->num_warmup; c.init_buffer = R->init_buffer; c.term_buffer = R->term_buffer;
@@ -523,7 +523,7 @@ __device__ __noinline__ unsigned cl_cold_transition_begin(const DevModel *Mg, co
   CCp CL = (CCp)uni_ptr(CLg);
   CRp R = (CRp)uni_ptr(Rg);
   ClChain c = make_clchain(M, CL, R, (int)uni32((unsigned)chain_), (int)uni32((unsigned)m_), uni32(launch_), (int)uni32((unsigned)side_));
-  c.x.epoch = uni32(epoch_);
+  c.x.epoch = uni32(epoch_); c.x.local = uni_i(cl_local);   // (what k_cl_run found out about this launch's placement)
   c.cst = cl_load_static(CL, c.part);
   CPROF_START(c);
   cl_transition_begin<CL_DW>(c, uni32(iter_));
@@ -538,7 +538,7 @@ __device__ __noinline__ unsigned cl_cold_transition_end(const DevModel *Mg, cons
   CRp R = (CRp)uni_ptr(Rg);
   const int chain = (int)uni32((unsigned)chain_);
   ClChain c = make_clchain(M, CL, R, chain, (int)uni32((unsigned)m_), uni32(launch_));
-  c.x.epoch = uni32(epoch_);
+  c.x.epoch = uni32(epoch_); c.x.local = uni_i(cl_local);   // (what k_cl_run found out about this launch's placement)
   c.cst = cl_load_static(CL, c.part);
   CPROF_START(c);
   cl_transition_end<CL_DW>(c, R, chain, (int)uni32(iter_));
@@ -559,7 +559,7 @@ __device__ __noinline__ unsigned cl_cold_twin_combine(const DevModel *Mg, const 
   const int valid = (int)uni32((unsigned)valid_), leaf = (int)uni32((unsigned)leaf_);
   const uint32_t iter = uni32(iter_);
   ClChain c = make_clchain(M, CL, R, chain, (int)uni32((unsigned)m_), uni32(launch_), side);
-  c.x.epoch = uni32(epoch_);
+  c.x.epoch = uni32(epoch_); c.x.local = uni_i(cl_local);   // (what k_cl_run found out about this launch's placement)
   const Twin t = make_twin(R, chain, side, c.x.launch, iter);
   ltp ts = c.ts;
   const int tid = c.tid;
@@ -661,7 +661,7 @@ __device__ __noinline__ unsigned cl_cold_twin_end(const DevModel *Mg, const ClMo
   CRp R = (CRp)uni_ptr(Rg);
   const int chain = (int)uni32((unsigned)chain_), side = (int)uni32((unsigned)side_), it = (int)uni32(iter_);
   ClChain c = make_clchain(M, CL, R, chain, (int)uni32((unsigned)m_), uni32(launch_), side);
-  c.x.epoch = uni32(epoch_);
+  c.x.epoch = uni32(epoch_); c.x.local = uni_i(cl_local);   // (what k_cl_run found out about this launch's placement)
   c.cst = cl_load_static(CL, c.part);
   const Twin t = make_twin(R, chain, side, c.x.launch, (uint32_t)it);
   ltp ts = c.ts;
@@ -734,6 +734,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_run(const DevModel *Mg, const
   if (c.sc->status != 0) return;
   if (R->debug_drop_member == m + 1) return;       // test hook: a member that never shows up
   c.cst = cl_setup_lds(M, CL, c.part, c.lds);
+  cl_find_local(c.x, c.red());                      // (one all-reduce per launch: exchange words go out as plain stores when the cluster sits on one XCD)
   const ClTwinArgs ta{Mg, CLg, Rg, chain, m, side, launch};
   const int total = R->num_warmup + R->num_samples;
   for (int k = 0; k < n_iter; k++) {

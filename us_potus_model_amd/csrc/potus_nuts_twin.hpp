@@ -19,7 +19,7 @@
 __device__ __forceinline__ Xch tw1_watch(CRp R, int blk, unsigned launch) {
   Xch x;
   x.xb = make_rsrc(uni_ptr(R->xbuf + (size_t)blk * 16), 128u);
-  x.epoch = 0; x.launch = uni32(launch); x.x1e = 0; x.K = 1; x.m = 0; x.XW = 0;
+  x.epoch = 0; x.launch = uni32(launch); x.x1e = 0; x.K = 1; x.m = 0; x.XW = 0; x.local = 0;
   return x;
 }
 
