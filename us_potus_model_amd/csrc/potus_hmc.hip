@@ -728,8 +728,23 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_run(const DevModel *Mg, const
   CMp M = (CMp)Mg;
   CCp CL = (CCp)CLg;
   CRp R = (CRp)Rg;
-  const int chain = blockIdx.x % R->chains, r = blockIdx.x / R->chains;
-  const int m = TWIN ? r % CL->K : r, side = TWIN ? r / CL->K : 0;
+  // Which cluster a block works for.  Blocks are dealt to the eight XCDs round-robin: whenever the launch has a multiple of eight clusters, the blocks of one residue
+  // b % 8 -- one XCD -- form whole clusters (cluster x + 8 q, member (b / 8) % K), so that the members of a cluster share an L2 and publish their exchange words with plain
+  // stores (cl_find_local checks, per launch).  With a multiple of eight chains this is the mapping of rounds 1-6 (chain = b % chains, both clusters of a chain on one XCD);
+  // with four chains x two clusters the clusters of a chain sit on XCDs c and c + 4.  Otherwise: chain = b % chains, members wherever they fall, write-through stores.
+  int chain, m, side;
+  {
+    const int C = R->chains, K = CL->K, b = (int)blockIdx.x, sides = TWIN ? 2 : 1, ncl = C * sides;
+    if (ncl % 8 == 0) {
+      const int x = b & 7, i = b >> 3, q = i / K, j = x + 8 * q;                      // cluster j of ncl
+      m = i % K;
+      if (C % 8 == 0) { chain = x + 8 * (q / sides); side = q % sides; }
+      else { chain = j % C; side = j / C; }
+    } else {
+      const int r = b / C;
+      chain = b % C; m = TWIN ? r % K : r; side = TWIN ? r / K : 0;
+    }
+  }
   ClChain c = make_clchain(M, CL, R, chain, m, launch, side);
   if (c.sc->status != 0) return;
   if (R->debug_drop_member == m + 1) return;       // test hook: a member that never shows up
