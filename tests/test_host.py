@@ -217,9 +217,9 @@ def test_bench_bookkeeping_on_the_committed_profiles():
     assert one and two and one[0] != two[0] and "two clusters" in two[1]["command"] and "two clusters" not in one[1]["command"]
     # (two clusters per chain: 1.04 x / 1.007 x the algorithmic bytes in rounds 3 / 4, 0.785 x since round 5 keeps a member's share of three vectors in LDS, 0.769 x with round 6's carry table)
     assert 0.5 < one[1]["hbm_bytes_per_leapfrog"] / 844784 < 0.8 and 0.6 < two[1]["hbm_bytes_per_leapfrog"] / 844784 < 1.3
-    assert two[0] == "r06g_cl_twin_pmc_traffic.json"                    # the latest committed pass is the one the bench line quotes
+    assert two[0] == "r06h_cl_twin_pmc_traffic.json"                    # the latest committed pass is the one the bench line quotes
     for committed in ("r03_bench_line.json", "r04b_bench_line.json", "r05_bench_line.json", "r05b_bench_line.json", "r06_bench_line.json",
-                      "r06b_bench_line.json", "r06c_bench_line.json", "r06d_bench_line.json", "r06e_bench_line.json", "r06f_bench_line.json", "r06g_bench_line.json"):
+                      "r06b_bench_line.json", "r06c_bench_line.json", "r06d_bench_line.json", "r06e_bench_line.json", "r06f_bench_line.json", "r06g_bench_line.json", "r06h_bench_line.json"):
         _check_committed_bench_line(json.loads([ln for ln in (ROOT / "profiles" / committed).read_text().splitlines() if ln.startswith("{")][0]),
                                     device_diagnostics=int(committed[1:3]) if int(committed[1:3]) >= 4 else 0)
 
