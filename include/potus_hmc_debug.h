@@ -25,6 +25,10 @@ int potus_debug_profile(int handle, double *out);
  * wave with the adjoint product on the fp64 matrix cores, 16 / 17 = the fixed-layout builds of poll_model_2020.stan / its
  * no_mode_adjustment variant; 0 = one workgroup per chain; -1 = bad handle (tests: which posterior gets which kernel). */
 int potus_debug_build_tag(int handle);
+/* Cluster mode: what the last launch found about its placement (potus_cluster.hpp, cl_find_local), one int per chain and side ([side][chain]): 1 = every
+ * member of that cluster ran on one XCD and published its exchange words with plain stores, 0 = write-through.  Returns the number of ints written, -1 for a
+ * bad handle or a one-workgroup sampler.  (POTUS_DEBUG_DROP_MEMBER=-1 at potus_create forces the write-through path: the two must give the same bytes.) */
+int potus_debug_xcd_local(int handle, int *out);
 /* Dense metric, without a sampler: y = M^-1 x for `chains` matrices (D x D, row-major, upper triangle read) and nrhs <= 3 vectors
  * each by the sampler's matrix pass (k_dn_symv + k_dn_symv_finish), repeated `reps` times; dot_host: x_0 . y_0 per chain; ms: time
  * of the passes; pass_bytes: bytes of matrix one pass loads (tests/test_gpu_dense.py, scripts/micro/dense_probe.py). */

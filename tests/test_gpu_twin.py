@@ -224,3 +224,38 @@ def test_twin_watchdog(cases):
     g.init(); g.run(3)
     assert g.total_leapfrogs() > 0
     g.close()
+
+
+def _xcd_local(h):
+    import ctypes as C
+    L = h.L
+    L.potus_debug_xcd_local.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    L.potus_debug_xcd_local.restype = C.c_int
+    out = (C.c_int * 64)()
+    n = L.potus_debug_xcd_local(h.h, out)
+    return [int(out[i]) for i in range(max(n, 0))]
+
+
+@pytest.mark.parametrize("chains,twin", [(8, 1), (8, 0), (4, 1), (6, 1)])
+def test_exchange_stores_plain_inside_an_xcd_and_write_through_across_give_the_same_bytes(cases, chains, twin, monkeypatch):
+    """Round 6: a launch finds out whether every member of a cluster runs on one XCD (cl_find_local: the hardware XCC ids, all-reduced once per launch) and
+    then publishes its exchange words with PLAIN stores, which only that XCD's L2 sees -- 552 instead of 1 304 cycles one way (scripts/micro/pingpong.hip).
+    With a multiple of eight clusters in the launch k_cl_run deals the blocks of one XCD residue to whole clusters, so 8 chains (one or two clusters each) and
+    4 chains x 2 clusters are XCD-local; 6 chains x 2 clusters are not and keep the write-through stores.  Either way the draws are the bytes of the run with the
+    write-through path forced (POTUS_DEBUG_DROP_MEMBER=-1)."""
+    data, variant = cases["2016"]
+    kw = dict(chains=chains, num_warmup=12, num_samples=4, seed=1843, cus_per_chain=16, twin=twin)
+    h = Handle(data, variant, **kw)
+    h.init(); h.run(16)
+    a, loc = h.draws(), _xcd_local(h)
+    h.close()
+    assert len(loc) == chains * (2 if twin else 1)
+    assert all(v == (0 if chains == 6 else 1) for v in loc), loc
+    monkeypatch.setenv("POTUS_DEBUG_DROP_MEMBER", "-1")
+    g = Handle(data, variant, **kw)
+    monkeypatch.delenv("POTUS_DEBUG_DROP_MEMBER")
+    g.init(); g.run(16)
+    b, locb = g.draws(), _xcd_local(g)
+    g.close()
+    assert all(v == 0 for v in locb), locb
+    assert np.array_equal(a, b) and np.isfinite(a).all()

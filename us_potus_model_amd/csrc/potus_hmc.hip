@@ -750,6 +750,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_cl_run(const DevModel *Mg, const
   if (R->debug_drop_member == m + 1) return;       // test hook: a member that never shows up
   c.cst = cl_setup_lds(M, CL, c.part, c.lds);
   cl_find_local(c.x, c.red());                      // (one all-reduce per launch: exchange words go out as plain stores when the cluster sits on one XCD)
+  if (R->debug_drop_member == -1) {                 // test hook: the write-through path whatever the placement
+    if (c.tid == 0) cl_local = 0;
+    __syncthreads();
+    c.x.local = 0;
+  }
+  if (c.tid == 0) c.sc->xcd_local = c.x.local;
   const ClTwinArgs ta{Mg, CLg, Rg, chain, m, side, launch};
   const int total = R->num_warmup + R->num_samples;
   for (int k = 0; k < n_iter; k++) {
@@ -3308,6 +3314,18 @@ int potus_debug_profile(int handle, double *out) {
   (void)hipSetDevice(sp->device);
   if (hipMemcpy(out, sp->R.prof, sizeof(double) * PT_NPROF * sp->R.chains * sp->K * sp->sides(), hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return PT_NPROF;
+}
+
+// What the last cluster launch found about its placement, per chain and side: 1 = the cluster's members on one XCD (exchange words published with plain stores).
+int potus_debug_xcd_local(int handle, int *out) {
+  Sampler *sp = get(handle);
+  if (!sp || !out || sp->K <= 1) return -1;
+  (void)hipSetDevice(sp->device);
+  const int blocks = sp->R.chains * sp->sides();
+  std::vector<ChainScalars> all((size_t)blocks * sp->K);
+  if (hipMemcpy(all.data(), sp->R.scal, sizeof(ChainScalars) * all.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  for (int b = 0; b < blocks; b++) out[b] = all[(size_t)b * sp->K].xcd_local;
+  return blocks;
 }
 
 // Which build of the cluster pass a handle runs (template tag of potus_cluster.hpp: 4, 8, 12, 16, 17), 0 for one workgroup per chain.

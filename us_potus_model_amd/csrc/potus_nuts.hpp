@@ -61,8 +61,9 @@ struct ChainScalars { // persistent per chain, global memory
   long long total_leapfrogs;
   int iter, win_counter, win_next, win_size, status, n_divergent, saved;
   int leaves_run;          // twin mode: leaves this side has integrated, those of dropped (speculative) subtrees included
-  int spec_limit, pad;     // twin mode: doublings (combines taken) of the last four transitions, a byte each: a doubling beyond their
+  int spec_limit;          // twin mode: doublings (combines taken) of the last four transitions, a byte each: a doubling beyond their
                            // maximum is not started ahead of its turn
+  int xcd_local;           // cluster mode: what the last launch found (cl_find_local): 1 = every member of the cluster on one XCD, exchange words published with plain stores
 };
 typedef ChainScalars AS_G *gsc;
 
@@ -82,7 +83,8 @@ struct RunParams {
                            // blocks: side s of chain c uses block c + s * chains); twbuf = their mailbox
   double *twbuf;           // [chains][TWB_WORDS] words of 16 bytes {value, tag}
   int debug_drop_member;   // test hook (POTUS_DEBUG_DROP_MEMBER = m + 1): member m of every cluster leaves k_cl_run at once, the
-                           // rest must find out through the watchdog (tests/test_gpu_parity.py)
+                           // rest must find out through the watchdog (tests/test_gpu_parity.py); -1: nobody leaves, but the exchange words are
+                           // published write-through whatever the placement (the two store paths must give the same bytes)
 };
 
 typedef const RunParams AS_C *CRp;
