@@ -219,7 +219,7 @@ def test_bench_bookkeeping_on_the_committed_profiles():
     assert 0.5 < one[1]["hbm_bytes_per_leapfrog"] / 844784 < 0.8 and 0.6 < two[1]["hbm_bytes_per_leapfrog"] / 844784 < 1.3
     assert two[0] == "r06h_cl_twin_pmc_traffic.json"                    # the latest committed pass is the one the bench line quotes
     for committed in ("r03_bench_line.json", "r04b_bench_line.json", "r05_bench_line.json", "r05b_bench_line.json", "r06_bench_line.json",
-                      "r06b_bench_line.json", "r06c_bench_line.json", "r06d_bench_line.json", "r06e_bench_line.json", "r06f_bench_line.json", "r06g_bench_line.json", "r06h_bench_line.json"):
+                      "r06b_bench_line.json", "r06c_bench_line.json", "r06d_bench_line.json", "r06e_bench_line.json", "r06f_bench_line.json", "r06g_bench_line.json", "r06h_bench_line.json", "r06i_bench_line.json"):
         _check_committed_bench_line(json.loads([ln for ln in (ROOT / "profiles" / committed).read_text().splitlines() if ln.startswith("{")][0]),
                                     device_diagnostics=int(committed[1:3]) if int(committed[1:3]) >= 4 else 0)
 
